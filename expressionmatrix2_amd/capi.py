@@ -1,0 +1,194 @@
+"""ctypes binding of the C ABI declared in include/em2_lsh.h (libem2lsh.so, built for gfx950).
+
+This module is plumbing only: it loads the shared library that holds the HIP kernels and exposes numpy /
+device-pointer level wrappers.  There is no Python or CPU implementation of the path behind it: if the
+library is missing or no GPU is visible the calls raise RuntimeError.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(_HERE, "libem2lsh.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+# std::pair<CellId,float> (src/SimilarPairs.hpp:53-56) and std::pair<GeneId,float> (src/ExpressionMatrixSubset.hpp:36)
+PAIR_DTYPE = np.dtype([("cell", "<u4"), ("similarity", "<f4")])
+COUNT_DTYPE = np.dtype([("gene", "<u4"), ("count", "<f4")])
+
+EM2_OK = 0
+EM2_ERROR_NO_DEVICE = 2
+EM2_ERROR_UNSUPPORTED = 6
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/em2_lsh.h declares.
+_c = ctypes
+SYMBOLS = {
+    "em2_abi_version": (_c.c_int, []),
+    "em2_last_error": (_c.c_char_p, []),
+    "em2_lsh_generate_vectors": (_c.c_int, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_void_p]),
+    "em2_lsh_similarity_table": (_c.c_int, [_c.c_uint32, _c.c_void_p]),
+    "em2_murmur_hash_64a": (_c.c_uint64, [_c.c_void_p, _c.c_int, _c.c_uint64]),
+    "em2_device_count": (_c.c_int, [_c.POINTER(_c.c_int)]),
+    "em2_set_device": (_c.c_int, [_c.c_int]),
+    "em2_compute_signatures": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p,
+                                          _c.c_uint32, _c.c_void_p]),
+    "em2_find_similar_pairs4": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_double,
+                                           _c.c_void_p, _c.c_void_p]),
+    "em2_find_similar_pairs5": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_double,
+                                           _c.c_uint32, _c.c_uint64, _c.c_void_p, _c.c_void_p]),
+    "em2_dev_compute_signatures_workspace": (_c.c_size_t, [_c.c_uint32, _c.c_uint32]),
+    "em2_dev_compute_signatures": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p,
+                                              _c.c_void_p, _c.c_uint32, _c.c_void_p, _c.c_void_p, _c.c_size_t,
+                                              _c.c_void_p]),
+    "em2_dev_vector_sums": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p, _c.c_void_p]),
+    "em2_dev_find_similar_pairs4_workspace": (_c.c_size_t, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32]),
+    "em2_dev_find_similar_pairs4": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
+                                               _c.c_uint32, _c.c_double, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                               _c.c_size_t, _c.c_void_p]),
+}
+
+
+def build_library(verbose=False):
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    result = subprocess.run(["make", "-C", CSRC_DIR, "-j4"], capture_output=True, text=True)
+    if verbose or result.returncode != 0:
+        print(result.stdout)
+        print(result.stderr)
+    if result.returncode != 0:
+        raise RuntimeError("building libem2lsh.so failed:\n" + result.stderr[-4000:])
+    return LIBRARY_PATH
+
+
+def load():
+    """Load libem2lsh.so.  Raises RuntimeError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBRARY_PATH):
+        raise RuntimeError(
+            "%s is missing: run `make -C %s` (or __graft_entry__.build()). "
+            "There is no fallback implementation." % (LIBRARY_PATH, CSRC_DIR))
+    lib = ctypes.CDLL(LIBRARY_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)       # AttributeError here == the library does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error():
+    message = load().em2_last_error()
+    return message.decode("utf-8", "replace") if message else ""
+
+
+def check(rc):
+    if rc != EM2_OK:
+        raise RuntimeError(last_error() or ("em2 error %d" % rc))
+
+
+def word_count(lsh_count):
+    return (int(lsh_count) - 1) // 64 + 1
+
+
+def _ptr(array):
+    return array.ctypes.data_as(ctypes.c_void_p)
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(load().em2_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def lsh_generate_vectors(gene_count, lsh_count, seed):
+    """Lsh::generateLshVectors (src/Lsh.cpp:68-113) -> float64 [gene_count, lsh_count]."""
+    out = np.empty((gene_count, lsh_count), dtype=np.float64)
+    check(load().em2_lsh_generate_vectors(gene_count, lsh_count, seed, _ptr(out)))
+    return out
+
+
+def similarity_table(lsh_count):
+    out = np.empty(lsh_count + 1, dtype=np.float64)
+    check(load().em2_lsh_similarity_table(lsh_count, _ptr(out)))
+    return out
+
+
+def murmur_hash_64a(data, seed=231):
+    buf = np.ascontiguousarray(data).view(np.uint8)
+    return int(load().em2_murmur_hash_64a(_ptr(buf), buf.size, seed))
+
+
+def make_counts(genes, counts):
+    data = np.empty(len(genes), dtype=COUNT_DTYPE)
+    data["gene"] = genes
+    data["count"] = counts
+    return data
+
+
+def compute_signatures(toc, data, gene_count, vectors, lsh_count):
+    """Host-buffer Lsh::computeCellLshSignatures (src/Lsh.cpp:118-224) on the GPU -> uint64 [cells, words]."""
+    toc = np.ascontiguousarray(toc, dtype=np.uint64)
+    data = np.ascontiguousarray(data, dtype=COUNT_DTYPE)
+    vectors = np.ascontiguousarray(vectors, dtype=np.float64)
+    cell_count = len(toc) - 1
+    assert vectors.shape == (gene_count, lsh_count)
+    out = np.zeros((cell_count, word_count(lsh_count)), dtype=np.uint64)
+    check(load().em2_compute_signatures(_ptr(toc), _ptr(data), cell_count, gene_count, _ptr(vectors), lsh_count,
+                                        _ptr(out)))
+    return out
+
+
+def find_similar_pairs4(signatures, lsh_count, k=100, similarity_threshold=0.2):
+    """Host-buffer findSimilarPairs4 pair loop (src/ExpressionMatrixLsh.cpp:200-285) on the GPU.
+    Returns (pairs[cells, k] of PAIR_DTYPE, used_count[cells])."""
+    signatures = np.ascontiguousarray(signatures, dtype=np.uint64)
+    cell_count = signatures.shape[0]
+    assert signatures.shape[1] == word_count(lsh_count)
+    pairs = np.zeros((cell_count, k), dtype=PAIR_DTYPE)
+    used = np.zeros(cell_count, dtype=np.uint32)
+    check(load().em2_find_similar_pairs4(_ptr(signatures), cell_count, lsh_count, k, similarity_threshold,
+                                         _ptr(pairs), _ptr(used)))
+    return pairs, used
+
+
+def find_similar_pairs5(signatures, lsh_count, k, similarity_threshold, lsh_slice_length, bucket_overflow=1000):
+    signatures = np.ascontiguousarray(signatures, dtype=np.uint64)
+    cell_count = signatures.shape[0]
+    pairs = np.zeros((cell_count, k), dtype=PAIR_DTYPE)
+    used = np.zeros(cell_count, dtype=np.uint32)
+    check(load().em2_find_similar_pairs5(_ptr(signatures), cell_count, lsh_count, k, similarity_threshold,
+                                         lsh_slice_length, bucket_overflow, _ptr(pairs), _ptr(used)))
+    return pairs, used
+
+
+# ---- device-pointer level (torch tensors supply the memory and the stream; this module never imports torch) ----
+
+def dev_find_similar_pairs4_workspace(cell_count, row_count, lsh_count, k):
+    return int(load().em2_dev_find_similar_pairs4_workspace(cell_count, row_count, lsh_count, k))
+
+
+def dev_find_similar_pairs4(sig_ptr, cell_count, row_begin, row_end, lsh_count, k, similarity_threshold,
+                            pairs_ptr, used_ptr, workspace_ptr, workspace_bytes, stream):
+    check(load().em2_dev_find_similar_pairs4(sig_ptr, cell_count, row_begin, row_end, lsh_count, k,
+                                             similarity_threshold, pairs_ptr, used_ptr, workspace_ptr,
+                                             workspace_bytes, stream))
+
+
+def dev_compute_signatures_workspace(cell_count, lsh_count):
+    return int(load().em2_dev_compute_signatures_workspace(cell_count, lsh_count))
+
+
+def dev_compute_signatures(toc_ptr, data_ptr, cell_count, gene_count, vectors_ptr, vector_sums_ptr, lsh_count,
+                           sig_ptr, workspace_ptr, workspace_bytes, stream):
+    check(load().em2_dev_compute_signatures(toc_ptr, data_ptr, cell_count, gene_count, vectors_ptr,
+                                            vector_sums_ptr, lsh_count, sig_ptr, workspace_ptr, workspace_bytes,
+                                            stream))
+
+
+def dev_vector_sums(vectors_ptr, gene_count, lsh_count, sums_ptr, stream):
+    check(load().em2_dev_vector_sums(vectors_ptr, gene_count, lsh_count, sums_ptr, stream))

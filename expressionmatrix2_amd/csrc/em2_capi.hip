@@ -1,0 +1,371 @@
+// em2_capi.hip -- the C ABI of include/em2_lsh.h: argument checking, device memory, kernel launches.
+// No algorithmic work happens on the host here except the O(geneCount*lshCount) hyperplane generator and the
+// O(lshCount) lookup tables; there is no CPU fallback for the device paths.
+
+#include "../../include/em2_lsh.h"
+
+#include "em2_device.h"
+#include "em2_tables.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <random>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string lastError;
+
+int fail(int code, const std::string& message)
+{
+    lastError = message;
+    return code;
+}
+
+int failHip(hipError_t e, const char* what)
+{
+    return fail(EM2_ERROR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define EM2_HIP(call)                                   \
+    do {                                                \
+        hipError_t em2HipError_ = (call);               \
+        if (em2HipError_ != hipSuccess) return failHip(em2HipError_, #call); \
+    } while (0)
+
+size_t alignUp(size_t x) { return (x + 255u) & ~size_t(255u); }
+
+uint32_t wordCountOf(uint32_t lshCount) { return (lshCount - 1u) / 64u + 1u; }
+
+bool haveDevice()
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+// Per-device cache of the lookup tables of em2_tables.h.
+struct CachedTables {
+    int device;
+    uint32_t lshCount;
+    uint64_t thresholdBits;
+    em2::DeviceTables tables;
+};
+std::mutex cacheMutex;
+std::vector<CachedTables> tableCache;
+
+int getDeviceTables(uint32_t lshCount, double similarityThreshold, em2::DeviceTables& out)
+{
+    int device = 0;
+    EM2_HIP(hipGetDevice(&device));
+    uint64_t bits;
+    std::memcpy(&bits, &similarityThreshold, sizeof(bits));
+    std::lock_guard<std::mutex> lock(cacheMutex);
+    for (const CachedTables& c : tableCache) {
+        if (c.device == device && c.lshCount == lshCount && c.thresholdBits == bits) {
+            out = c.tables;
+            return EM2_OK;
+        }
+    }
+    em2::SimilarityTables host;
+    const char* error = nullptr;
+    if (!em2::buildSimilarityTables(lshCount, similarityThreshold, host, &error)) {
+        return fail(EM2_ERROR_RUNTIME, error ? error : "similarity table construction failed");
+    }
+    void* block = nullptr;
+    const size_t keyCount = host.keySimilarity.size();
+    const size_t bytes0 = alignUp(host.keyOfMismatch.size() * sizeof(uint32_t));
+    const size_t bytes1 = alignUp(keyCount * sizeof(int32_t));
+    const size_t bytes2 = alignUp(keyCount * sizeof(float));
+    EM2_HIP(hipMalloc(&block, bytes0 + bytes1 + bytes2));
+    char* base = static_cast<char*>(block);
+    EM2_HIP(hipMemcpy(base, host.keyOfMismatch.data(), host.keyOfMismatch.size() * sizeof(uint32_t),
+                      hipMemcpyHostToDevice));
+    EM2_HIP(hipMemcpy(base + bytes0, host.acceptMaxByKey.data(), keyCount * sizeof(int32_t),
+                      hipMemcpyHostToDevice));
+    EM2_HIP(hipMemcpy(base + bytes0 + bytes1, host.keySimilarity.data(), keyCount * sizeof(float),
+                      hipMemcpyHostToDevice));
+    CachedTables c;
+    c.device = device;
+    c.lshCount = lshCount;
+    c.thresholdBits = bits;
+    c.tables.keyOfMismatch = reinterpret_cast<const uint32_t*>(base);
+    c.tables.acceptMaxByKey = reinterpret_cast<const int32_t*>(base + bytes0);
+    c.tables.keySimilarity = reinterpret_cast<const float*>(base + bytes0 + bytes1);
+    c.tables.mGlobal = host.mGlobal;
+    c.tables.mMaxInitial = host.mMaxInitial;
+    tableCache.push_back(c);
+    out = c.tables;
+    return EM2_OK;
+}
+
+// RAII device allocation for the host-buffer entry points.
+struct DeviceBuffer {
+    void* p = nullptr;
+    ~DeviceBuffer() { if (p) (void)hipFree(p); }
+    hipError_t allocate(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+
+extern "C" {
+
+int em2_abi_version(void) { return 1; }
+
+const char* em2_last_error(void) { return lastError.c_str(); }
+
+
+int em2_lsh_generate_vectors(uint32_t geneCount, uint32_t lshCount, uint32_t seed, double* vectors)
+{
+    if (!vectors || lshCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_lsh_generate_vectors: bad argument");
+    // boost::mt19937 has the parameters of std::mt19937.  uniform_01<double> over a 32-bit engine is
+    // eng() / 2^32; normal_distribution (Boost <= 1.55) draws two uniforms per PAIR of variates and returns
+    // rho*cos(2 pi r1) first, rho*sin(2 pi r1) second, rho = sqrt(-2 log(1 - r2)).
+    std::mt19937 engine(seed);
+    const double scale = 1.0 / 4294967296.0;
+    const double twoPi = 2.0 * 3.14159265358979323846;
+    std::vector<double> sumOfSquares(lshCount, 0.);
+    bool haveSecond = false;
+    double r1 = 0., rho = 0.;
+    const size_t total = size_t(geneCount) * lshCount;
+    for (size_t t = 0; t < total; t++) {            // gene-major, bit-minor draw order (Lsh.cpp:90-101)
+        double x;
+        if (!haveSecond) {
+            r1 = double(engine()) * scale;
+            const double r2 = double(engine()) * scale;
+            rho = std::sqrt(-2.0 * std::log(1.0 - r2));
+            x = rho * std::cos(twoPi * r1);
+            haveSecond = true;
+        } else {
+            x = rho * std::sin(twoPi * r1);
+            haveSecond = false;
+        }
+        vectors[t] = x;
+        sumOfSquares[t % lshCount] += x * x;
+    }
+    for (double& f : sumOfSquares) f = 1. / std::sqrt(f);                    // Lsh.cpp:104-106
+    for (size_t t = 0; t < total; t++) vectors[t] *= sumOfSquares[t % lshCount];   // Lsh.cpp:107-111
+    return EM2_OK;
+}
+
+
+int em2_lsh_similarity_table(uint32_t lshCount, double* table)
+{
+    if (!table || lshCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_lsh_similarity_table: bad argument");
+    em2::computeSimilarityTable(lshCount, table);
+    return EM2_OK;
+}
+
+
+uint64_t em2_murmur_hash_64a(const void* key, int len, uint64_t seed)
+{
+    // MurmurHash64A, Austin Appleby, public domain; 64-bit little-endian form.
+    const uint64_t mul = 0xc6a4a7935bd1e995ULL;
+    const int shift = 47;
+    const unsigned char* bytes = static_cast<const unsigned char*>(key);
+    uint64_t hash = seed ^ (uint64_t(len) * mul);
+    const int blocks = len / 8;
+    for (int b = 0; b < blocks; b++) {
+        uint64_t v;
+        std::memcpy(&v, bytes + size_t(b) * 8, 8);
+        v *= mul;
+        v ^= v >> shift;
+        v *= mul;
+        hash ^= v;
+        hash *= mul;
+    }
+    const unsigned char* tail = bytes + size_t(blocks) * 8;
+    const int rest = len & 7;
+    for (int i = rest - 1; i >= 0; i--) hash ^= uint64_t(tail[i]) << (8 * i);
+    if (rest) hash *= mul;
+    hash ^= hash >> shift;
+    hash *= mul;
+    hash ^= hash >> shift;
+    return hash;
+}
+
+
+int em2_device_count(int* count)
+{
+    if (!count) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_device_count: null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return EM2_OK;
+}
+
+
+int em2_set_device(int device)
+{
+    if (!haveDevice()) return fail(EM2_ERROR_NO_DEVICE, "no HIP device is visible");
+    EM2_HIP(hipSetDevice(device));
+    return EM2_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Device-resident entry points.
+// ---------------------------------------------------------------------------------------------------------
+
+size_t em2_dev_compute_signatures_workspace(uint32_t cellCount, uint32_t lshCount)
+{
+    return alignUp(size_t(cellCount) * sizeof(double)) + alignUp(size_t(lshCount) * sizeof(double));
+}
+
+
+int em2_dev_vector_sums(const double* d_vectors, uint32_t geneCount, uint32_t lshCount, double* d_sums, void* stream)
+{
+    if (!d_vectors || !d_sums || lshCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_vector_sums: bad argument");
+    EM2_HIP(em2::launchVectorSums(d_vectors, geneCount, lshCount, d_sums, static_cast<hipStream_t>(stream)));
+    return EM2_OK;
+}
+
+
+int em2_dev_compute_signatures(const uint64_t* d_toc, const em2_count* d_data, uint32_t cellCount,
+                               uint32_t geneCount, const double* d_vectors, const double* d_vectorSums,
+                               uint32_t lshCount, uint64_t* d_signatures, void* d_workspace,
+                               size_t workspaceBytes, void* stream)
+{
+    if (lshCount == 0 || geneCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_compute_signatures: lshCount and geneCount must be positive");
+    if (cellCount == 0) return EM2_OK;
+    if (!d_toc || !d_vectors || !d_signatures || !d_workspace) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_compute_signatures: null pointer");
+    if (workspaceBytes < em2_dev_compute_signatures_workspace(cellCount, lshCount)) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_compute_signatures: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* means = static_cast<double*>(d_workspace);
+    double* sums = reinterpret_cast<double*>(static_cast<char*>(d_workspace) + alignUp(size_t(cellCount) * sizeof(double)));
+    const em2::CountIn* data = reinterpret_cast<const em2::CountIn*>(d_data);
+    if (!d_vectorSums) {
+        EM2_HIP(em2::launchVectorSums(d_vectors, geneCount, lshCount, sums, s));
+        d_vectorSums = sums;
+    }
+    EM2_HIP(em2::launchCellMeans(d_toc, data, cellCount, geneCount, means, s));
+    EM2_HIP(em2::launchProjection(d_toc, data, cellCount, d_vectors, d_vectorSums, means, lshCount, d_signatures, s));
+    return EM2_OK;
+}
+
+
+size_t em2_dev_find_similar_pairs4_workspace(uint32_t cellCount, uint32_t rowCount, uint32_t lshCount, uint32_t k)
+{
+    if (lshCount == 0) return 0;
+    const uint32_t padded = em2::paddedDwords(lshCount);
+    size_t bytes = alignUp(size_t(rowCount) * 2u * k * sizeof(em2::Entry));
+    if (padded != 2u * wordCountOf(lshCount)) bytes += alignUp(size_t(cellCount) * padded * sizeof(uint32_t));
+    return bytes + 256;
+}
+
+
+int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount, uint32_t rowBegin,
+                                uint32_t rowEnd, uint32_t lshCount, uint32_t k, double similarityThreshold,
+                                em2_pair* d_pairs, uint32_t* d_usedCount, void* d_workspace,
+                                size_t workspaceBytes, void* stream)
+{
+    if (lshCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs4: lshCount must be positive");
+    if (rowBegin > rowEnd || rowEnd > cellCount) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs4: bad row range");
+    if (rowBegin == rowEnd) return EM2_OK;
+    if (!d_signatures || !d_usedCount || (!d_pairs && k) || !d_workspace) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs4: null pointer");
+    const uint32_t rows = rowEnd - rowBegin;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (k == 0) {       // keepBest(v, 0) empties every list (src/heap.hpp:116-126)
+        EM2_HIP(hipMemsetAsync(d_usedCount, 0, size_t(rows) * sizeof(uint32_t), s));
+        return EM2_OK;
+    }
+    const uint32_t padded = em2::paddedDwords(lshCount);
+    if (padded == 0) return fail(EM2_ERROR_UNSUPPORTED, "em2_dev_find_similar_pairs4: lshCount above 4096 is not supported");
+    if (k > em2::fsp4MaxK()) return fail(EM2_ERROR_UNSUPPORTED, "em2_dev_find_similar_pairs4: k above " + std::to_string(em2::fsp4MaxK()) + " is not supported");
+    if (workspaceBytes < em2_dev_find_similar_pairs4_workspace(cellCount, rows, lshCount, k)) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs4: workspace too small");
+
+    em2::DeviceTables tables;
+    const int rc = getDeviceTables(lshCount, similarityThreshold, tables);
+    if (rc != EM2_OK) return rc;
+
+    char* ws = reinterpret_cast<char*>(alignUp(reinterpret_cast<size_t>(d_workspace)));
+    em2::Entry* buffers = reinterpret_cast<em2::Entry*>(ws);
+    ws += alignUp(size_t(rows) * 2u * k * sizeof(em2::Entry));
+    const uint32_t words = wordCountOf(lshCount);
+    const uint32_t* sig32 = reinterpret_cast<const uint32_t*>(d_signatures);
+    if (padded != 2u * words) {
+        uint32_t* repacked = reinterpret_cast<uint32_t*>(ws);
+        EM2_HIP(em2::launchRepackSignatures(d_signatures, cellCount, words, repacked, padded, s));
+        sig32 = repacked;
+    }
+    EM2_HIP(em2::launchFsp4Scan(sig32, padded, cellCount, rowBegin, rowEnd, k, tables, buffers,
+                                reinterpret_cast<em2::PairOut*>(d_pairs), d_usedCount, s));
+    return EM2_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Host-buffer entry points.
+// ---------------------------------------------------------------------------------------------------------
+
+int em2_compute_signatures(const uint64_t* toc, const em2_count* data, uint32_t cellCount, uint32_t geneCount,
+                           const double* vectors, uint32_t lshCount, uint64_t* signatures)
+{
+    if (lshCount == 0 || geneCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_compute_signatures: lshCount and geneCount must be positive");
+    if (cellCount == 0) return EM2_OK;
+    if (!toc || !vectors || !signatures) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_compute_signatures: null pointer");
+    if (!haveDevice()) return fail(EM2_ERROR_NO_DEVICE, "em2_compute_signatures: no HIP device is visible (this library has no CPU path)");
+    const uint64_t nnz = toc[cellCount];
+    if (nnz && !data) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_compute_signatures: null data");
+    const uint32_t words = wordCountOf(lshCount);
+    DeviceBuffer dToc, dData, dVectors, dSig, dWs;
+    const size_t wsBytes = em2_dev_compute_signatures_workspace(cellCount, lshCount);
+    EM2_HIP(dToc.allocate((size_t(cellCount) + 1) * sizeof(uint64_t)));
+    EM2_HIP(dData.allocate(nnz * sizeof(em2_count)));
+    EM2_HIP(dVectors.allocate(size_t(geneCount) * lshCount * sizeof(double)));
+    EM2_HIP(dSig.allocate(size_t(cellCount) * words * sizeof(uint64_t)));
+    EM2_HIP(dWs.allocate(wsBytes));
+    EM2_HIP(hipMemcpy(dToc.p, toc, (size_t(cellCount) + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (nnz) EM2_HIP(hipMemcpy(dData.p, data, nnz * sizeof(em2_count), hipMemcpyHostToDevice));
+    EM2_HIP(hipMemcpy(dVectors.p, vectors, size_t(geneCount) * lshCount * sizeof(double), hipMemcpyHostToDevice));
+    const int rc = em2_dev_compute_signatures(dToc.as<uint64_t>(), dData.as<em2_count>(), cellCount, geneCount,
+                                              dVectors.as<double>(), nullptr, lshCount, dSig.as<uint64_t>(),
+                                              dWs.p, wsBytes, nullptr);
+    if (rc != EM2_OK) return rc;
+    EM2_HIP(hipStreamSynchronize(nullptr));
+    EM2_HIP(hipMemcpy(signatures, dSig.p, size_t(cellCount) * words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return EM2_OK;
+}
+
+
+int em2_find_similar_pairs4(const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount, uint32_t k,
+                            double similarityThreshold, em2_pair* pairs, uint32_t* usedCount)
+{
+    if (lshCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_find_similar_pairs4: lshCount must be positive");
+    if (cellCount == 0) return EM2_OK;
+    if (!signatures || !usedCount || (!pairs && k)) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_find_similar_pairs4: null pointer");
+    if (!haveDevice()) return fail(EM2_ERROR_NO_DEVICE, "em2_find_similar_pairs4: no HIP device is visible (this library has no CPU path)");
+    const uint32_t words = wordCountOf(lshCount);
+    const size_t wsBytes = em2_dev_find_similar_pairs4_workspace(cellCount, cellCount, lshCount, k);
+    DeviceBuffer dSig, dPairs, dUsed, dWs;
+    EM2_HIP(dSig.allocate(size_t(cellCount) * words * sizeof(uint64_t)));
+    EM2_HIP(dPairs.allocate(size_t(cellCount) * k * sizeof(em2_pair)));
+    EM2_HIP(dUsed.allocate(size_t(cellCount) * sizeof(uint32_t)));
+    EM2_HIP(dWs.allocate(wsBytes));
+    EM2_HIP(hipMemcpy(dSig.p, signatures, size_t(cellCount) * words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    const int rc = em2_dev_find_similar_pairs4(dSig.as<uint64_t>(), cellCount, 0, cellCount, lshCount, k,
+                                               similarityThreshold, dPairs.as<em2_pair>(), dUsed.as<uint32_t>(),
+                                               dWs.p, wsBytes, nullptr);
+    if (rc != EM2_OK) return rc;
+    EM2_HIP(hipStreamSynchronize(nullptr));
+    if (k) EM2_HIP(hipMemcpy(pairs, dPairs.p, size_t(cellCount) * k * sizeof(em2_pair), hipMemcpyDeviceToHost));
+    EM2_HIP(hipMemcpy(usedCount, dUsed.p, size_t(cellCount) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return EM2_OK;
+}
+
+
+
+int em2_find_similar_pairs5(const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount, uint32_t k,
+                            double similarityThreshold, uint32_t lshSliceLength, uint64_t bucketOverflow,
+                            em2_pair* pairs, uint32_t* usedCount)
+{
+    (void)signatures; (void)cellCount; (void)lshCount; (void)k; (void)similarityThreshold;
+    (void)lshSliceLength; (void)bucketOverflow; (void)pairs; (void)usedCount;
+    return fail(EM2_ERROR_UNSUPPORTED, "em2_find_similar_pairs5: not implemented yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// em2_device.h -- internal declarations shared by the HIP translation units and the C ABI glue.
+#ifndef EM2_DEVICE_H
+#define EM2_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "em2_select.h"
+
+namespace em2 {
+
+// Layout-compatible with std::pair<CellId, float> (src/SimilarPairs.hpp:53-56) and em2_pair (include/em2_lsh.h).
+struct PairOut {
+    uint32_t cell;
+    float similarity;
+};
+
+// Layout-compatible with std::pair<GeneId, float> (src/ExpressionMatrixSubset.hpp:36) and em2_count.
+struct CountIn {
+    uint32_t gene;
+    float count;
+};
+
+// Device-resident copies of the tables of em2_tables.h.
+struct DeviceTables {
+    const uint32_t* keyOfMismatch;   // [lshCount+1]
+    const int32_t* acceptMaxByKey;   // [keyCount]
+    const float* keySimilarity;      // [keyCount]
+    int32_t mGlobal;
+    int32_t mMaxInitial;
+};
+
+// Signature words per cell padded to a supported kernel width (in 32-bit words); 0 if lshCount is too large.
+uint32_t paddedDwords(uint32_t lshCount);
+
+// Copies [cellCount][wordCount] uint64 signatures into the zero-padded [cellCount][paddedDwords/2] layout.
+hipError_t launchRepackSignatures(const uint64_t* src, uint32_t cellCount, uint32_t wordCount,
+                                  uint32_t* dst, uint32_t paddedDw, hipStream_t stream);
+
+// Largest k the scan kernel supports (limited by the per-wave LDS staging area).
+uint32_t fsp4MaxK();
+
+// findSimilarPairs4 for rows [rowBegin,rowEnd) against all cellCount columns.
+//   sig32    [cellCount][paddedDw] device
+//   buffers  [(rowEnd-rowBegin)][2k] Entry, device scratch
+//   outPairs [(rowEnd-rowBegin)][k], outUsed [(rowEnd-rowBegin)]
+hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cellCount,
+                          uint32_t rowBegin, uint32_t rowEnd, uint32_t k, const DeviceTables& tables,
+                          Entry* buffers, PairOut* outPairs, uint32_t* outUsed, hipStream_t stream);
+
+// ExpressionMatrixSubset::computeSums (sum1 only) -> mean = sum1 / geneCount, per cell.
+hipError_t launchCellMeans(const uint64_t* toc, const CountIn* data, uint32_t cellCount, uint32_t geneCount,
+                           double* means, hipStream_t stream);
+
+// lshVectorsSums[i] = sum over genes (ascending) of vectors[g][i]   (Lsh.cpp:137-144)
+hipError_t launchVectorSums(const double* vectors, uint32_t geneCount, uint32_t lshCount, double* sums,
+                            hipStream_t stream);
+
+// Lsh::computeCellLshSignatures for the cellCount cells of the CSR (toc[0..cellCount], data); writes
+// signatures[cellCount][wordCount].  means[cellCount] from launchCellMeans.
+hipError_t launchProjection(const uint64_t* toc, const CountIn* data, uint32_t cellCount, const double* vectors,
+                            const double* vectorSums, const double* means, uint32_t lshCount,
+                            uint64_t* signatures, hipStream_t stream);
+
+}  // namespace em2
+
+#endif

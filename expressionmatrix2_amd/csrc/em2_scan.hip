@@ -1,0 +1,341 @@
+// em2_scan.hip -- findSimilarPairs4 on gfx950: all-pairs Hamming scan with the reference's per-cell
+// candidate selection, bit-identical to src/ExpressionMatrixLsh.cpp:200-285 + src/SimilarPairs.cpp:369-405.
+//
+// Per-cell contract (equivalent to the reference's 64x64 blocked loop, which offers every
+// unordered pair to both of its cells, because each cell sees the other cells in ascending id order either
+// way): for a cell c, candidates o = 0..N-1, o != c, arrive in ascending order; a candidate with mismatch
+// count m is accepted iff m <= mMax(c) (integer form of the two floating-point tests, em2_tables.h), appended
+// to the cell's list; when the list holds 2k entries it is cut to k with std::nth_element semantics
+// (em2_select.h) and mMax(c) is re-derived from the entry that ends at position k-1.
+//
+// Mapping to CDNA4:
+//   * one LANE owns one row (cell c).  Its signature (W32 32-bit words) lives in VGPRs for the whole kernel.
+//   * columns are wave-uniform: the column signature is streamed through the SCALAR unit (s_load_dwordx16 from
+//     the cell-major signature array, which is one linear stream) and enters the vector ALU as the SGPR
+//     operand of v_xor_b32; v_bcnt_u32_b32 accumulates the popcount.  2 VALU instructions per 32 bits per
+//     (row, column) pair is the instruction floor for XOR+popcount on this ISA; there is no LDS traffic, no
+//     vector memory traffic and no barrier in the steady-state loop.
+//   * scalar loads are software-pipelined one chunk (<= 32 dwords) ahead behind an explicit lgkmcnt(0)
+//     (SMEM returns out of order, so the wait precedes the next issue).
+//   * a lane whose candidate passes appends {column, key} to its row's list in HBM; lists that reach 2k are
+//     staged into LDS by the whole wave and cut by one lane running the exact introselect emulation.
+//   * every wave walks the columns in the same order, so the 128 MB (1M cells x 1024 bit) stream is shared
+//     through the scalar caches / L2 / Infinity Cache.
+
+#include "em2_device.h"
+
+namespace em2 {
+namespace {
+
+typedef const __attribute__((address_space(4))) uint32_t* ScalarPtr;
+
+constexpr uint32_t kLdsBytesPerBlock = 64u * 1024u;
+
+__device__ __forceinline__ void waveLdsFence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Entries of a row list are written by one lane and read back by other lanes of the same wave: read them
+// at agent scope (L2-served, bypassing the CU's L1) after the writer's vmcnt(0).
+__device__ __forceinline__ Entry loadEntryCoherent(const Entry* p)
+{
+    const uint64_t v = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+    Entry e;
+    e.cell = uint32_t(v);
+    e.key = uint32_t(v >> 32);
+    return e;
+}
+
+__device__ __forceinline__ void storeEntry(Entry* p, uint32_t cell, uint32_t key)
+{
+    *reinterpret_cast<uint64_t*>(p) = uint64_t(cell) | (uint64_t(key) << 32);
+}
+
+// Kernel arguments, passed by value as ONE struct so that the kernarg segment is exactly this struct.
+// The steady-state loop reads only sig32 / cellCount / mMaxInitial.  Everything else is needed by the rare
+// path and the epilogue only; they re-read it from the kernarg segment through a laundered pointer so that
+// the loop keeps its SGPRs for the two column chunks (a build that kept these values live across the loop
+// spilled SGPRs into VGPR lanes inside it).
+struct Fsp4Args {
+    const uint32_t* sig32;
+    uint32_t cellCount;
+    int32_t mMaxInitial;
+    const uint32_t* keyOfMismatch;
+    const int32_t* acceptMaxByKey;
+    const float* keySimilarity;
+    Entry* buffers;
+    PairOut* outPairs;
+    uint32_t* outUsed;
+    uint32_t k;
+    uint32_t rowBegin;
+    uint32_t rowEnd;
+    uint32_t pad;
+};
+
+typedef const __attribute__((address_space(4))) Fsp4Args* ArgsPtr;
+
+__device__ __forceinline__ ArgsPtr kernelArgs()
+{
+    ArgsPtr p = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// Cuts the list at g (n entries) to its best k exactly as keepBest does, staging it through this wave's LDS
+// area.  Out of line on purpose: inlining the selection's nested loops into the scan kernel raised SGPR
+// pressure enough to spill the column chunk registers inside the steady-state loop.
+// Returns the key of the entry that ends at position k-1 (tmp.back(), ExpressionMatrixLsh.cpp:249,256).
+__device__ __attribute__((noinline)) uint32_t cutListToBest(Entry* lds, Entry* g, uint32_t n, uint32_t k,
+                                                            uint32_t lane, bool writeBack)
+{
+    for (uint32_t i = lane; i < n; i += 64u) lds[i] = loadEntryCoherent(g + i);
+    waveLdsFence();
+    if (lane == 0u) nthElement(lds, int(k), int(n));
+    waveLdsFence();
+    if (writeBack) {
+        for (uint32_t i = lane; i < k; i += 64u) g[i] = lds[i];
+    }
+    const uint32_t backKey = lds[k - 1u].key;
+    return backKey;
+}
+
+template <int W32>
+__global__ void __launch_bounds__(256)
+fsp4ScanKernel(Fsp4Args args)
+{
+    const uint32_t* __restrict__ sig32 = args.sig32;
+    const uint32_t cellCount = args.cellCount;
+    const int32_t mMaxInitial = args.mMaxInitial;
+    constexpr int CH = W32 < 32 ? W32 : 32;      // dwords per scalar-load chunk
+    constexpr int H = W32 / CH;                  // chunks per column
+    constexpr int U = H < 2 ? 2 : H;             // chunk steps per loop iteration (even, multiple of H)
+    constexpr int COLS = U / H;                  // columns per loop iteration
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waveIndex = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+
+    uint32_t row;           // this lane's cell id
+    uint32_t r[W32];        // this lane's signature
+    int32_t mMax;
+    {
+        ArgsPtr aux = kernelArgs();
+        const uint32_t waveRowBase = aux->rowBegin + waveIndex * 64u;
+        if (waveRowBase >= aux->rowEnd) return;
+        row = waveRowBase + lane;
+        const bool rowValid = row < aux->rowEnd;
+        const uint32_t* rp = sig32 + size_t(rowValid ? row : waveRowBase) * W32;
+#pragma unroll
+        for (int w = 0; w < W32; ++w) r[w] = rp[w];
+        mMax = rowValid ? mMaxInitial : -1;
+    }
+    uint32_t count = 0;
+
+    ScalarPtr p = (ScalarPtr)(uintptr_t)sig32;
+    uint32_t chunk[2][CH];
+#pragma unroll
+    for (int w = 0; w < CH; ++w) chunk[0][w] = p[w];
+    __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0): the row signature has landed before the loop starts
+
+    uint32_t m = 0;
+    for (uint32_t colBase = 0; colBase < cellCount; colBase += COLS) {
+#pragma unroll
+        for (int s = 0; s < U; ++s) {
+            const int part = s % H;
+            const uint32_t col = colBase + uint32_t(s / H);
+            if (col < cellCount) {
+                // The chunk for this step was requested one step ago; wait for it, then request the next
+                // one so that its latency is covered by this step's 2*CH vector instructions.
+                __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
+                __builtin_amdgcn_sched_barrier(0);
+                const bool lastChunk = (col == cellCount - 1u) && (part == H - 1);
+                ScalarPtr pn = lastChunk ? p : p + CH;
+#pragma unroll
+                for (int w = 0; w < CH; ++w) chunk[(s + 1) & 1][w] = pn[w];
+                p = pn;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int w = 0; w < CH; ++w) {
+                    m += uint32_t(__builtin_popcount(r[part * CH + w] ^ chunk[s & 1][w]));
+                }
+                if (part == H - 1) {
+                    const bool pass = int32_t(m) <= mMax;
+                    if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                        // ---- rare path: some row of this wave accepts this column ----
+                        ArgsPtr aux = kernelArgs();
+                        const uint32_t k = aux->k;
+                        const uint32_t twoK = 2u * k;
+                        Entry* const waveBuffers = aux->buffers + size_t(waveIndex) * 64u * twoK;
+                        if (pass && col != row) {
+                            storeEntry(waveBuffers + size_t(lane) * twoK + count, col, aux->keyOfMismatch[m]);
+                            ++count;
+                        }
+                        uint64_t full = __builtin_amdgcn_ballot_w64(count == twoK);
+                        if (full != 0ull) {
+                            Entry* lds = reinterpret_cast<Entry*>(ldsRaw) + size_t(threadIdx.x >> 6) * twoK;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            do {
+                                const uint32_t src = uint32_t(__builtin_ctzll(full));
+                                full &= full - 1ull;
+                                Entry* g = waveBuffers + size_t(src) * twoK;
+                                const uint32_t backKey = cutListToBest(lds, g, twoK, k, lane, true);
+                                const int32_t newMax = aux->acceptMaxByKey[backKey];
+                                if (lane == src) {
+                                    count = k;
+                                    mMax = newMax;
+                                }
+                                waveLdsFence();
+                            } while (full != 0ull);
+                        }
+                    }
+                    m = 0;
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: final keepBest (ExpressionMatrixLsh.cpp:265-269), SimilarPairs::copy + sort ----
+    {
+        ArgsPtr aux = kernelArgs();
+        const uint32_t k = aux->k;
+        const uint32_t twoK = 2u * k;
+        const uint32_t rowBegin = aux->rowBegin;
+        const uint32_t rowEnd = aux->rowEnd;
+        const uint32_t waveRowBase = rowBegin + waveIndex * 64u;
+        Entry* const waveBuffers = aux->buffers + size_t(waveIndex) * 64u * twoK;
+        Entry* lds = reinterpret_cast<Entry*>(ldsRaw) + size_t(threadIdx.x >> 6) * twoK;
+        const float* keySimilarity = aux->keySimilarity;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        for (uint32_t src = 0; src < 64u; ++src) {
+            const uint32_t srow = waveRowBase + src;
+            if (srow >= rowEnd) break;
+            uint32_t n = uint32_t(__builtin_amdgcn_readlane(int(count), int(src)));
+            Entry* g = waveBuffers + size_t(src) * twoK;
+            if (n > k) {
+                cutListToBest(lds, g, n, k, lane, false);
+                n = k;
+            } else {
+                for (uint32_t i = lane; i < n; i += 64u) lds[i] = loadEntryCoherent(g + i);
+                waveLdsFence();
+            }
+            PairOut* out = aux->outPairs + size_t(srow - rowBegin) * k;
+            for (uint32_t i = lane; i < n; i += 64u) {
+                const Entry e = lds[i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < n; ++j) {
+                    const Entry o = lds[j];
+                    rank += uint32_t((o.key < e.key) || (o.key == e.key && o.cell < e.cell));
+                }
+                PairOut po;
+                po.cell = e.cell;
+                po.similarity = keySimilarity[e.key];
+                out[rank] = po;
+            }
+            for (uint32_t i = n + lane; i < k; i += 64u) {
+                PairOut zero;
+                zero.cell = 0u;
+                zero.similarity = 0.0f;
+                out[i] = zero;
+            }
+            if (lane == 0u) aux->outUsed[srow - rowBegin] = n;
+            waveLdsFence();
+        }
+    }
+}
+
+__global__ void repackSignaturesKernel(const uint64_t* __restrict__ src, uint32_t cellCount, uint32_t wordCount,
+                                       uint32_t* __restrict__ dst, uint32_t paddedDw)
+{
+    const uint64_t total = uint64_t(cellCount) * paddedDw;
+    for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += uint64_t(gridDim.x) * blockDim.x) {
+        const uint64_t cell = i / paddedDw;
+        const uint32_t dw = uint32_t(i % paddedDw);
+        uint32_t v = 0;
+        if (dw < 2u * wordCount) {
+            const uint64_t word = src[cell * wordCount + (dw >> 1)];
+            v = (dw & 1u) ? uint32_t(word >> 32) : uint32_t(word);
+        }
+        dst[i] = v;
+    }
+}
+
+}  // namespace
+
+
+uint32_t paddedDwords(uint32_t lshCount)
+{
+    if (lshCount == 0) return 0;
+    const uint32_t dw = 2u * ((lshCount - 1u) / 64u + 1u);
+    uint32_t p = 2;
+    while (p < dw) p <<= 1;
+    return p <= 128u ? p : 0u;
+}
+
+uint32_t fsp4MaxK()
+{
+    return kLdsBytesPerBlock / (2u * uint32_t(sizeof(Entry)));
+}
+
+hipError_t launchRepackSignatures(const uint64_t* src, uint32_t cellCount, uint32_t wordCount, uint32_t* dst,
+                                  uint32_t paddedDw, hipStream_t stream)
+{
+    const uint64_t total = uint64_t(cellCount) * paddedDw;
+    if (total == 0) return hipSuccess;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    repackSignaturesKernel<<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(src, cellCount, wordCount, dst,
+                                                                              paddedDw);
+    return hipGetLastError();
+}
+
+hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cellCount, uint32_t rowBegin,
+                          uint32_t rowEnd, uint32_t k, const DeviceTables& t, Entry* buffers, PairOut* outPairs,
+                          uint32_t* outUsed, hipStream_t stream)
+{
+    if (rowEnd <= rowBegin) return hipSuccess;
+    if (k == 0 || k > fsp4MaxK()) return hipErrorInvalidValue;
+    const uint32_t bytesPerWave = 2u * k * uint32_t(sizeof(Entry));
+    uint32_t wavesPerBlock = kLdsBytesPerBlock / bytesPerWave;
+    if (wavesPerBlock > 4) wavesPerBlock = 4;
+    const uint32_t rows = rowEnd - rowBegin;
+    const uint32_t waves = (rows + 63u) / 64u;
+    if (wavesPerBlock > waves) wavesPerBlock = waves;
+    const dim3 grid((waves + wavesPerBlock - 1u) / wavesPerBlock);
+    const dim3 block(64u * wavesPerBlock);
+    const size_t lds = size_t(wavesPerBlock) * bytesPerWave;
+
+    Fsp4Args args;
+    args.sig32 = sig32;
+    args.cellCount = cellCount;
+    args.mMaxInitial = t.mMaxInitial;
+    args.keyOfMismatch = t.keyOfMismatch;
+    args.acceptMaxByKey = t.acceptMaxByKey;
+    args.keySimilarity = t.keySimilarity;
+    args.buffers = buffers;
+    args.outPairs = outPairs;
+    args.outUsed = outUsed;
+    args.k = k;
+    args.rowBegin = rowBegin;
+    args.rowEnd = rowEnd;
+    args.pad = 0;
+
+#define EM2_LAUNCH_SCAN(W32) fsp4ScanKernel<W32><<<grid, block, lds, stream>>>(args)
+    switch (paddedDw) {
+    case 2: EM2_LAUNCH_SCAN(2); break;
+    case 4: EM2_LAUNCH_SCAN(4); break;
+    case 8: EM2_LAUNCH_SCAN(8); break;
+    case 16: EM2_LAUNCH_SCAN(16); break;
+    case 32: EM2_LAUNCH_SCAN(32); break;
+    case 64: EM2_LAUNCH_SCAN(64); break;
+    case 128: EM2_LAUNCH_SCAN(128); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef EM2_LAUNCH_SCAN
+    return hipGetLastError();
+}
+
+}  // namespace em2

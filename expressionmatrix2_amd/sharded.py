@@ -1,0 +1,125 @@
+"""Row-sharded execution of the LSH similar-pairs path: one process per GPU, torch.distributed for the one
+exchange step (all-gather of signature shards; backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests).
+
+SURVEY.md 8(e): cells are split into contiguous id ranges; every rank projects its own cells, the signature
+shards are all-gathered (cell-major layout makes the gathered buffer the full signature array), and every
+rank scans its own ROWS against all columns, which is exactly the per-cell contract of findSimilarPairs4 --
+no collective on the result, no cross-rank merge of top-k state.
+
+torch is used here for device memory, streams and the collective only; the compute goes through the C ABI
+(capi.dev_*).  The compute callables can be replaced (the CPU tests inject the oracle, there being no GPU)."""
+import numpy as np
+
+from . import capi
+
+
+def shard_size(cell_count, world_size):
+    return (cell_count + world_size - 1) // world_size
+
+
+def shard_range(cell_count, world_size, rank):
+    """Contiguous cell-id range [begin, end) owned by `rank`."""
+    size = shard_size(cell_count, world_size)
+    begin = min(cell_count, rank * size)
+    end = min(cell_count, begin + size)
+    return begin, end
+
+
+def gather_signatures(local_signatures, cell_count, world_size, rank, dist=None):
+    """All-gather of per-rank signature shards [rows_r, words] (int64 torch tensors) into the full
+    [cell_count, words] array.  Shards are padded to the common shard size for the collective."""
+    import torch
+    words = local_signatures.shape[1]
+    size = shard_size(cell_count, world_size)
+    if world_size == 1:
+        return local_signatures
+    padded = local_signatures
+    if local_signatures.shape[0] != size:
+        padded = torch.zeros((size, words), dtype=local_signatures.dtype, device=local_signatures.device)
+        padded[:local_signatures.shape[0]] = local_signatures
+    full = torch.empty((size * world_size, words), dtype=local_signatures.dtype, device=local_signatures.device)
+    dist.all_gather_into_tensor(full, padded.contiguous())
+    return full[:cell_count]
+
+
+class DevicePipeline:
+    """Device-resident pipeline of one rank: CSR shard -> signatures -> all-gather -> row-shard scan.
+    All buffers are allocated once in __init__; step() only enqueues kernels and the collective."""
+
+    def __init__(self, cell_count, gene_count, lsh_count, k, similarity_threshold, world_size=1, rank=0,
+                 dist=None, device="cuda"):
+        import torch
+        self.torch = torch
+        self.cell_count = cell_count
+        self.gene_count = gene_count
+        self.lsh_count = lsh_count
+        self.k = k
+        self.thr = float(similarity_threshold)
+        self.world_size = world_size
+        self.rank = rank
+        self.dist = dist
+        self.device = device
+        self.words = capi.word_count(lsh_count)
+        self.row_begin, self.row_end = shard_range(cell_count, world_size, rank)
+        self.rows = self.row_end - self.row_begin
+        size = shard_size(cell_count, world_size)
+        self.shard = size
+        self.local_sig = torch.zeros((size, self.words), dtype=torch.int64, device=device)
+        self.full_sig = (self.local_sig if world_size == 1 else
+                         torch.empty((size * world_size, self.words), dtype=torch.int64, device=device))
+        self.pairs = torch.zeros((max(1, self.rows), max(1, k), 2), dtype=torch.int32, device=device)
+        self.used = torch.zeros(max(1, self.rows), dtype=torch.int32, device=device)
+        self.scan_ws_bytes = capi.dev_find_similar_pairs4_workspace(cell_count, self.rows, lsh_count, k)
+        self.scan_ws = torch.empty(max(1, self.scan_ws_bytes), dtype=torch.uint8, device=device)
+        self.proj_ws_bytes = capi.dev_compute_signatures_workspace(max(1, self.rows), lsh_count)
+        self.proj_ws = torch.empty(self.proj_ws_bytes, dtype=torch.uint8, device=device)
+        self.vector_sums = torch.empty(lsh_count, dtype=torch.float64, device=device)
+        self.scan_events = []
+
+    def set_inputs(self, toc, data, vectors):
+        """toc int64 [rows+1] (relative to this shard), data int64-viewed em2_count [nnz], vectors float64
+        [gene_count, lsh_count]; all on the device."""
+        self.toc, self.data, self.vectors = toc, data, vectors
+        stream = self.torch.cuda.current_stream().cuda_stream
+        capi.dev_vector_sums(vectors.data_ptr(), self.gene_count, self.lsh_count, self.vector_sums.data_ptr(),
+                             stream)
+
+    def project(self):
+        stream = self.torch.cuda.current_stream().cuda_stream
+        if self.rows:
+            capi.dev_compute_signatures(self.toc.data_ptr(), self.data.data_ptr(), self.rows, self.gene_count,
+                                        self.vectors.data_ptr(), self.vector_sums.data_ptr(), self.lsh_count,
+                                        self.local_sig.data_ptr(), self.proj_ws.data_ptr(), self.proj_ws_bytes,
+                                        stream)
+
+    def exchange(self):
+        if self.world_size > 1:
+            self.dist.all_gather_into_tensor(self.full_sig, self.local_sig)
+
+    def scan(self, record_events=False):
+        torch = self.torch
+        stream = torch.cuda.current_stream().cuda_stream
+        if record_events:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if self.rows:
+            capi.dev_find_similar_pairs4(self.full_sig.data_ptr(), self.cell_count, self.row_begin, self.row_end,
+                                         self.lsh_count, self.k, self.thr, self.pairs.data_ptr(),
+                                         self.used.data_ptr(), self.scan_ws.data_ptr(), self.scan_ws_bytes, stream)
+        if record_events:
+            e1.record()
+            self.scan_events.append((e0, e1))
+
+    def step(self, record_events=False):
+        self.project()
+        self.exchange()
+        self.scan(record_events)
+
+    def results(self):
+        """(pairs[rows,k] of capi.PAIR_DTYPE, used[rows]) for this rank's rows, on the host."""
+        p = self.pairs[:self.rows].cpu().numpy().view(np.uint32)
+        pairs = np.zeros((self.rows, self.k), dtype=capi.PAIR_DTYPE)
+        pairs["cell"] = p[:, :, 0]
+        pairs["similarity"] = p[:, :, 1].view(np.float32)
+        return pairs, self.used[:self.rows].cpu().numpy().view(np.uint32)

@@ -1,0 +1,135 @@
+/* em2_lsh.h -- C ABI of the MI355X implementation of ExpressionMatrix2's LSH similar-pairs path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  Each entry point names the
+ * reference interface it replaces (file:line under the ExpressionMatrix2 source tree).  The reference is a C++
+ * library with a pybind11 module; a maintainer binds these functions from ExpressionMatrixLsh.cpp /
+ * PythonModule.cpp as shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns EM2_OK (0) or an EM2_ERROR_* code; em2_last_error() returns the message of the
+ *     last failure on the calling thread.  Where the reference throws std::runtime_error with a fixed text
+ *     ("Gene set X does not exist." ...) the message is that text and the code is EM2_ERROR_RUNTIME.
+ *   - "dev" functions take DEVICE pointers valid on the current HIP device and a hipStream_t passed as void*;
+ *     they enqueue work and return without synchronising.  They never allocate.
+ *   - the other compute functions take HOST pointers, run on the current HIP device and return when the
+ *     result is in the output buffers.  They fail with EM2_ERROR_NO_DEVICE when no GPU is present: there is
+ *     no CPU fallback in this library.
+ *   - cell ids are local to the cell set, gene ids local to the gene set (src/SimilarPairs.hpp:28-33).
+ */
+#ifndef EM2_LSH_H
+#define EM2_LSH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EM2_OK 0
+#define EM2_ERROR_INVALID_ARGUMENT 1
+#define EM2_ERROR_NO_DEVICE 2
+#define EM2_ERROR_HIP 3
+#define EM2_ERROR_IO 4
+#define EM2_ERROR_RUNTIME 5
+#define EM2_ERROR_UNSUPPORTED 6
+
+/* Layout of std::pair<CellId, float> (src/SimilarPairs.hpp:53-56): one stored neighbour of a cell. */
+typedef struct em2_pair {
+    uint32_t cell;
+    float similarity;
+} em2_pair;
+
+/* Layout of std::pair<GeneId, float> (src/ExpressionMatrixSubset.hpp:36): one stored expression count. */
+typedef struct em2_count {
+    uint32_t gene;
+    float count;
+} em2_count;
+
+int em2_abi_version(void);
+const char* em2_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Host-side pieces of the path (no GPU needed).
+ * ------------------------------------------------------------------------------------------------------ */
+
+/* Lsh::generateLshVectors (src/Lsh.cpp:68-113).  vectors is gene-major [geneCount][lshCount] like
+ * Lsh::lshVectors (src/Lsh.hpp:104-113).  Generator: mt19937(seed) + the Box-Muller normal_distribution of
+ * Boost <= 1.55, normalised per hyperplane.  Boost is not vendored by the reference and its
+ * normal_distribution changed algorithm in 1.56, so a bit-for-bit match with a particular reference build is
+ * not claimed: pass that build's own hyperplanes to em2_compute_signatures instead ("Oracle"). */
+int em2_lsh_generate_vectors(uint32_t geneCount, uint32_t lshCount, uint32_t seed, double* vectors);
+
+/* Lsh::computeSimilarityTable (src/Lsh.cpp:229-249): table[m] = cos(m*pi/lshCount), m = 0..lshCount. */
+int em2_lsh_similarity_table(uint32_t lshCount, double* table);
+
+/* MurmurHash64A as used by MemoryMapped::Vector::hash (src/MemoryMappedVector.hpp:715-723, seed 231). */
+uint64_t em2_murmur_hash_64a(const void* key, int len, uint64_t seed);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Device management.
+ * ------------------------------------------------------------------------------------------------------ */
+int em2_device_count(int* count);
+int em2_set_device(int device);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Host-buffer entry points: what a reference-side binding calls.
+ * ------------------------------------------------------------------------------------------------------ */
+
+/* ExpressionMatrixSubset::computeSums (src/ExpressionMatrixSubset.cpp:47-58) + Lsh::computeCellLshSignatures
+ * (src/Lsh.cpp:118-224).  CSR: toc[cellCount+1] offsets into data, gene ids ascending within a cell and
+ * < geneCount.  vectors as above.  signatures: cellCount * ((lshCount-1)/64+1) words, cell-major, bit i of a
+ * cell in word i>>6 at bit position 63-(i&63) (src/BitSet.hpp:48-62). */
+int em2_compute_signatures(const uint64_t* toc, const em2_count* data, uint32_t cellCount, uint32_t geneCount,
+                           const double* vectors, uint32_t lshCount, uint64_t* signatures);
+
+/* The pair loop, selection and storage order of ExpressionMatrix::findSimilarPairs4
+ * (src/ExpressionMatrixLsh.cpp:200-285) + SimilarPairs::copy/sort (src/SimilarPairs.cpp:369-405).
+ * pairs: cellCount*k slots, cell c at [c*k, c*k+usedCount[c]), sorted by similarity descending then cell id
+ * ascending; unused slots are zero (as in a freshly created SimilarPairs-*-Pairs file). */
+int em2_find_similar_pairs4(const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount, uint32_t k,
+                            double similarityThreshold, em2_pair* pairs, uint32_t* usedCount);
+
+/* ExpressionMatrix::findSimilarPairs5 (src/ExpressionMatrixLsh.cpp:355-496).  lshSliceLength must be in
+ * [1,30] (the reference divides by zero for 0). */
+int em2_find_similar_pairs5(const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount, uint32_t k,
+                            double similarityThreshold, uint32_t lshSliceLength, uint64_t bucketOverflow,
+                            em2_pair* pairs, uint32_t* usedCount);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Device-resident entry points (multi-GPU sharding, benchmarking, callers that keep data in HBM).
+ * ------------------------------------------------------------------------------------------------------ */
+
+/* Bytes of device scratch em2_dev_compute_signatures needs. */
+size_t em2_dev_compute_signatures_workspace(uint32_t cellCount, uint32_t lshCount);
+
+/* As em2_compute_signatures, for the cellCount cells of a (shard of a) CSR in device memory.
+ * d_vectorSums: lshCount doubles from em2_dev_vector_sums, or NULL to compute them into the workspace. */
+int em2_dev_compute_signatures(const uint64_t* d_toc, const em2_count* d_data, uint32_t cellCount,
+                               uint32_t geneCount, const double* d_vectors, const double* d_vectorSums,
+                               uint32_t lshCount, uint64_t* d_signatures, void* d_workspace,
+                               size_t workspaceBytes, void* stream);
+
+/* lshVectorsSums of src/Lsh.cpp:137-144 into d_sums[lshCount]. */
+int em2_dev_vector_sums(const double* d_vectors, uint32_t geneCount, uint32_t lshCount, double* d_sums,
+                        void* stream);
+
+/* Bytes of device scratch em2_dev_find_similar_pairs4 needs for rowCount rows. */
+size_t em2_dev_find_similar_pairs4_workspace(uint32_t cellCount, uint32_t rowCount, uint32_t lshCount,
+                                             uint32_t k);
+
+/* findSimilarPairs4 for the rows [rowBegin,rowEnd) of the cell set against all cellCount cells: the shard
+ * one rank owns.  d_signatures holds ALL cellCount signatures (after the all-gather).  d_pairs has
+ * (rowEnd-rowBegin)*k slots and d_usedCount (rowEnd-rowBegin) entries, indexed by row-rowBegin.
+ * The first call for a given (lshCount, similarityThreshold) on a device builds and caches small lookup
+ * tables (one synchronous allocation + copy); later calls only enqueue kernels. */
+int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount, uint32_t rowBegin,
+                                uint32_t rowEnd, uint32_t lshCount, uint32_t k, double similarityThreshold,
+                                em2_pair* d_pairs, uint32_t* d_usedCount, void* d_workspace,
+                                size_t workspaceBytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

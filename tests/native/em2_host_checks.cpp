@@ -1,0 +1,115 @@
+// em2_host_checks.cpp -- TEST-ONLY host build of the product's host/device-shared headers.
+//
+// Compiles expressionmatrix2_amd/csrc/em2_select.h and em2_tables.cpp for the host so that the exact
+// selection emulation and the integer acceptance tables can be checked on a machine without a GPU:
+//   * em2t_nth_element        the product's introselect restatement on (cell,key) entries
+//   * em2t_std_introselect    libstdc++'s own std::__introselect on the same data with a caller-chosen
+//                             depth limit (forces the heap-select fallback that random data never reaches)
+//   * em2t_fsp4_rows          the per-row state machine of em2_scan.hip replayed on the host with the same
+//                             tables and the same selection code, to be compared with the oracle
+// Nothing here is shipped or used by the product path.
+
+#include "../../expressionmatrix2_amd/csrc/em2_select.h"
+#include "../../expressionmatrix2_amd/csrc/em2_tables.h"
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+extern "C" {
+
+void em2t_nth_element(uint32_t* cell, uint32_t* key, uint32_t n, uint32_t nth, int depthLimit)
+{
+    std::vector<em2::Entry> a(n);
+    for (uint32_t i = 0; i < n; i++) { a[i].cell = cell[i]; a[i].key = key[i]; }
+    em2::nthElement(a.data(), int(nth), int(n), depthLimit);
+    for (uint32_t i = 0; i < n; i++) { cell[i] = a[i].cell; key[i] = a[i].key; }
+}
+
+struct KeyLess {
+    bool operator()(const std::pair<uint32_t, uint32_t>& x, const std::pair<uint32_t, uint32_t>& y) const
+    {
+        return x.second < y.second;
+    }
+};
+
+void em2t_std_introselect(uint32_t* cell, uint32_t* key, uint32_t n, uint32_t nth, int depthLimit)
+{
+    std::vector< std::pair<uint32_t, uint32_t> > a(n);
+    for (uint32_t i = 0; i < n; i++) a[i] = std::make_pair(cell[i], key[i]);
+    if (n != 0 && nth != n) {
+        if (depthLimit < 0) {
+            std::nth_element(a.begin(), a.begin() + nth, a.end(), KeyLess());
+        } else {
+            std::__introselect(a.begin(), a.begin() + nth, a.end(), long(depthLimit),
+                               __gnu_cxx::__ops::__iter_comp_iter(KeyLess()));
+        }
+    }
+    for (uint32_t i = 0; i < n; i++) { cell[i] = a[i].first; key[i] = a[i].second; }
+}
+
+// Tables: returns keyCount; arrays sized lshCount+1 by the caller.
+uint32_t em2t_tables(uint32_t lshCount, double threshold, double* similarity, uint32_t* keyOfMismatch,
+                     float* keySimilarity, int32_t* acceptMaxByKey, int32_t* mGlobal, int32_t* mMaxInitial)
+{
+    em2::SimilarityTables t;
+    const char* error = nullptr;
+    if (!em2::buildSimilarityTables(lshCount, threshold, t, &error)) return 0;
+    std::memcpy(similarity, t.similarity.data(), t.similarity.size() * sizeof(double));
+    std::memcpy(keyOfMismatch, t.keyOfMismatch.data(), t.keyOfMismatch.size() * sizeof(uint32_t));
+    std::memcpy(keySimilarity, t.keySimilarity.data(), t.keySimilarity.size() * sizeof(float));
+    std::memcpy(acceptMaxByKey, t.acceptMaxByKey.data(), t.acceptMaxByKey.size() * sizeof(int32_t));
+    *mGlobal = t.mGlobal;
+    *mMaxInitial = t.mMaxInitial;
+    return uint32_t(t.keySimilarity.size());
+}
+
+// Host replay of fsp4ScanKernel's per-row logic (em2_scan.hip) for rows [rowBegin,rowEnd).
+int em2t_fsp4_rows(const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount, uint32_t k,
+                   double threshold, uint32_t rowBegin, uint32_t rowEnd,
+                   uint32_t* outCell, float* outSim, uint32_t* outUsed)
+{
+    em2::SimilarityTables t;
+    const char* error = nullptr;
+    if (!em2::buildSimilarityTables(lshCount, threshold, t, &error)) return 1;
+    const size_t W = (size_t(lshCount) - 1) / 64 + 1;
+    std::vector<em2::Entry> list(2 * size_t(k));
+    for (uint32_t row = rowBegin; row < rowEnd; row++) {
+        int32_t mMax = t.mMaxInitial;
+        uint32_t count = 0;
+        const uint64_t* r = signatures + size_t(row) * W;
+        for (uint32_t col = 0; col < cellCount && k > 0; col++) {
+            const uint64_t* c = signatures + size_t(col) * W;
+            int32_t m = 0;
+            for (size_t w = 0; w < W; w++) m += __builtin_popcountll(r[w] ^ c[w]);
+            if (m <= mMax && col != row) {
+                list[count].cell = col;
+                list[count].key = t.keyOfMismatch[size_t(m)];
+                ++count;
+                if (count == 2 * k) {
+                    em2::nthElement(list.data(), int(k), int(count));
+                    count = k;
+                    mMax = t.acceptMaxByKey[list[k - 1].key];
+                }
+            }
+        }
+        if (count > k) {
+            em2::nthElement(list.data(), int(k), int(count));
+            count = k;
+        }
+        std::sort(list.begin(), list.begin() + count, [](const em2::Entry& x, const em2::Entry& y) {
+            return x.key < y.key || (x.key == y.key && x.cell < y.cell);
+        });
+        const size_t base = size_t(row - rowBegin) * k;
+        for (uint32_t j = 0; j < k; j++) {
+            outCell[base + j] = j < count ? list[j].cell : 0u;
+            outSim[base + j] = j < count ? t.keySimilarity[list[j].key] : 0.0f;
+        }
+        outUsed[row - rowBegin] = count;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+"""ctypes bindings of the CHECKERS used by the tests: the CPU oracle (oracle/libem2oracle.so), the reference's
+own Boost-free components (oracle/_ref/libem2ref.so, only where /root/reference exists) and a host build of
+the product's shared headers (tests/native).  Test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+NATIVE_DIR = os.path.join(ROOT, "tests", "native")
+
+c = ctypes
+P = c.c_void_p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(c.c_void_p)
+
+
+def _make(target=None):
+    cmd = ["make", "-C", ORACLE_DIR]
+    if target:
+        cmd.append(target)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed: " + r.stderr)
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.em2o_generate_lsh_vectors.argtypes = [c.c_uint32, c.c_uint32, c.c_uint32, P]
+        lib.em2o_similarity_table.argtypes = [c.c_uint32, P]
+        lib.em2o_compute_signatures.argtypes = [P, P, P, c.c_uint32, c.c_uint32, P, c.c_uint32, P]
+        lib.em2o_mismatch_matrix.argtypes = [P, c.c_uint32, c.c_uint32, P]
+        lib.em2o_find_similar_pairs4.argtypes = [P, c.c_uint32, c.c_uint32, c.c_uint32, c.c_double, P, P, P]
+        lib.em2o_find_similar_pairs4_rows.argtypes = [P, c.c_uint32, c.c_uint32, c.c_uint32, c.c_double,
+                                                      c.c_uint32, c.c_uint32, P, P, P]
+        lib.em2o_find_similar_pairs5.argtypes = [P, c.c_uint32, c.c_uint32, c.c_uint32, c.c_double, c.c_uint32,
+                                                 c.c_uint64, P, P, P]
+        lib.em2o_find_similar_pairs5.restype = c.c_int
+        lib.em2o_keep_best.argtypes = [P, P, c.c_uint32, c.c_uint32]
+        lib.em2o_keep_best.restype = c.c_uint32
+        lib.em2o_multiple_set_union.argtypes = [P, P, c.c_uint32, P]
+        lib.em2o_multiple_set_union.restype = c.c_uint32
+        lib.em2o_murmur_hash_64a.argtypes = [P, c.c_int, c.c_uint64]
+        lib.em2o_murmur_hash_64a.restype = c.c_uint64
+
+    def generate_lsh_vectors(self, gene_count, lsh_count, seed):
+        out = np.empty((gene_count, lsh_count), dtype=np.float64)
+        self.lib.em2o_generate_lsh_vectors(gene_count, lsh_count, seed, _ptr(out))
+        return out
+
+    def similarity_table(self, lsh_count):
+        out = np.empty(lsh_count + 1, dtype=np.float64)
+        self.lib.em2o_similarity_table(lsh_count, _ptr(out))
+        return out
+
+    def compute_signatures(self, toc, genes, counts, gene_count, vectors, lsh_count):
+        toc = np.ascontiguousarray(toc, dtype=np.uint64)
+        genes = np.ascontiguousarray(genes, dtype=np.uint32)
+        counts = np.ascontiguousarray(counts, dtype=np.float32)
+        vectors = np.ascontiguousarray(vectors, dtype=np.float64)
+        n = len(toc) - 1
+        out = np.zeros((n, (lsh_count - 1) // 64 + 1), dtype=np.uint64)
+        self.lib.em2o_compute_signatures(_ptr(toc), _ptr(genes), _ptr(counts), n, gene_count, _ptr(vectors),
+                                         lsh_count, _ptr(out))
+        return out
+
+    def mismatch_matrix(self, sig, lsh_count):
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        n = sig.shape[0]
+        out = np.zeros((n, n), dtype=np.uint16)
+        self.lib.em2o_mismatch_matrix(_ptr(sig), n, lsh_count, _ptr(out))
+        return out
+
+    def find_similar_pairs4(self, sig, lsh_count, k, thr):
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        n = sig.shape[0]
+        cell = np.zeros((n, k), dtype=np.uint32)
+        sim = np.zeros((n, k), dtype=np.float32)
+        used = np.zeros(n, dtype=np.uint32)
+        self.lib.em2o_find_similar_pairs4(_ptr(sig), n, lsh_count, k, thr, _ptr(cell), _ptr(sim), _ptr(used))
+        return cell, sim, used
+
+    def find_similar_pairs4_rows(self, sig, lsh_count, k, thr, row_begin, row_end):
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        n = sig.shape[0]
+        rows = row_end - row_begin
+        cell = np.zeros((rows, k), dtype=np.uint32)
+        sim = np.zeros((rows, k), dtype=np.float32)
+        used = np.zeros(rows, dtype=np.uint32)
+        self.lib.em2o_find_similar_pairs4_rows(_ptr(sig), n, lsh_count, k, thr, row_begin, row_end, _ptr(cell),
+                                               _ptr(sim), _ptr(used))
+        return cell, sim, used
+
+    def find_similar_pairs5(self, sig, lsh_count, k, thr, slice_length, bucket_overflow):
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        n = sig.shape[0]
+        cell = np.zeros((n, k), dtype=np.uint32)
+        sim = np.zeros((n, k), dtype=np.float32)
+        used = np.zeros(n, dtype=np.uint32)
+        rc = self.lib.em2o_find_similar_pairs5(_ptr(sig), n, lsh_count, k, thr, slice_length, bucket_overflow,
+                                               _ptr(cell), _ptr(sim), _ptr(used))
+        if rc != 0:
+            raise ValueError("oracle fsp5 rejected the arguments")
+        return cell, sim, used
+
+    def keep_best(self, cell, sim, k):
+        cell = np.array(cell, dtype=np.uint32)
+        sim = np.array(sim, dtype=np.float32)
+        n = self.lib.em2o_keep_best(_ptr(cell), _ptr(sim), len(cell), k)
+        return cell[:n], sim[:n]
+
+    def multiple_set_union(self, sets):
+        values = np.concatenate([np.asarray(s, dtype=np.uint32) for s in sets]) if sets else np.zeros(0, np.uint32)
+        offsets = np.zeros(len(sets) + 1, dtype=np.uint32)
+        offsets[1:] = np.cumsum([len(s) for s in sets])
+        out = np.zeros(max(1, len(values)), dtype=np.uint32)
+        n = self.lib.em2o_multiple_set_union(_ptr(values), _ptr(offsets), len(sets), _ptr(out))
+        return out[:n]
+
+    def murmur(self, data, seed=231):
+        buf = np.ascontiguousarray(data).view(np.uint8)
+        return int(self.lib.em2o_murmur_hash_64a(_ptr(buf), buf.size, seed))
+
+
+class Ref:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.em2ref_keep_best.argtypes = [P, P, c.c_uint32, c.c_uint32]
+        lib.em2ref_keep_best.restype = c.c_uint32
+        lib.em2ref_keep_best_int_greater.argtypes = [P, c.c_uint32, c.c_uint32]
+        lib.em2ref_keep_best_int_greater.restype = c.c_uint32
+        lib.em2ref_sort_pairs.argtypes = [P, P, c.c_uint32]
+        lib.em2ref_murmur_hash_64a.argtypes = [P, c.c_int, c.c_uint64]
+        lib.em2ref_murmur_hash_64a.restype = c.c_uint64
+
+    def keep_best(self, cell, sim, k):
+        cell = np.array(cell, dtype=np.uint32)
+        sim = np.array(sim, dtype=np.float32)
+        n = self.lib.em2ref_keep_best(_ptr(cell), _ptr(sim), len(cell), k)
+        return cell[:n], sim[:n]
+
+    def keep_best_int_greater(self, values, k):
+        v = np.array(values, dtype=np.int32)
+        n = self.lib.em2ref_keep_best_int_greater(_ptr(v), len(v), k)
+        return v[:n]
+
+    def sort_pairs(self, cell, sim):
+        cell = np.array(cell, dtype=np.uint32)
+        sim = np.array(sim, dtype=np.float32)
+        self.lib.em2ref_sort_pairs(_ptr(cell), _ptr(sim), len(cell))
+        return cell, sim
+
+    def murmur(self, data, seed=231):
+        buf = np.ascontiguousarray(data).view(np.uint8)
+        return int(self.lib.em2ref_murmur_hash_64a(_ptr(buf), buf.size, seed))
+
+
+class HostChecks:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.em2t_nth_element.argtypes = [P, P, c.c_uint32, c.c_uint32, c.c_int]
+        lib.em2t_std_introselect.argtypes = [P, P, c.c_uint32, c.c_uint32, c.c_int]
+        lib.em2t_tables.argtypes = [c.c_uint32, c.c_double, P, P, P, P, c.POINTER(c.c_int32), c.POINTER(c.c_int32)]
+        lib.em2t_tables.restype = c.c_uint32
+        lib.em2t_fsp4_rows.argtypes = [P, c.c_uint32, c.c_uint32, c.c_uint32, c.c_double, c.c_uint32, c.c_uint32,
+                                       P, P, P]
+        lib.em2t_fsp4_rows.restype = c.c_int
+
+    def nth_element(self, cell, key, nth, depth_limit=-1):
+        cell = np.array(cell, dtype=np.uint32)
+        key = np.array(key, dtype=np.uint32)
+        self.lib.em2t_nth_element(_ptr(cell), _ptr(key), len(cell), nth, depth_limit)
+        return cell, key
+
+    def std_introselect(self, cell, key, nth, depth_limit=-1):
+        cell = np.array(cell, dtype=np.uint32)
+        key = np.array(key, dtype=np.uint32)
+        self.lib.em2t_std_introselect(_ptr(cell), _ptr(key), len(cell), nth, depth_limit)
+        return cell, key
+
+    def tables(self, lsh_count, thr):
+        sim = np.zeros(lsh_count + 1, dtype=np.float64)
+        key_of_m = np.zeros(lsh_count + 1, dtype=np.uint32)
+        key_sim = np.zeros(lsh_count + 1, dtype=np.float32)
+        accept = np.zeros(lsh_count + 1, dtype=np.int32)
+        mg = c.c_int32(0)
+        m0 = c.c_int32(0)
+        kc = self.lib.em2t_tables(lsh_count, thr, _ptr(sim), _ptr(key_of_m), _ptr(key_sim), _ptr(accept),
+                                  c.byref(mg), c.byref(m0))
+        assert kc > 0
+        return dict(similarity=sim, key_of_mismatch=key_of_m, key_similarity=key_sim[:kc],
+                    accept_max_by_key=accept[:kc], m_global=mg.value, m_max_initial=m0.value)
+
+    def fsp4_rows(self, sig, lsh_count, k, thr, row_begin, row_end):
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        rows = row_end - row_begin
+        cell = np.zeros((rows, k), dtype=np.uint32)
+        sim = np.zeros((rows, k), dtype=np.float32)
+        used = np.zeros(rows, dtype=np.uint32)
+        rc = self.lib.em2t_fsp4_rows(_ptr(sig), sig.shape[0], lsh_count, k, thr, row_begin, row_end, _ptr(cell),
+                                     _ptr(sim), _ptr(used))
+        assert rc == 0
+        return cell, sim, used
+
+
+def load_oracle():
+    path = os.path.join(ORACLE_DIR, "libem2oracle.so")
+    src = os.path.join(ORACLE_DIR, "em2_oracle.cpp")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        _make()
+    return Oracle(ctypes.CDLL(path))
+
+
+def load_ref():
+    path = os.path.join(ORACLE_DIR, "_ref", "libem2ref.so")
+    if not os.path.exists(path):
+        if os.path.isdir("/root/reference/src"):
+            _make("ref")
+        else:
+            return None
+    return Ref(ctypes.CDLL(path))
+
+
+def load_host_checks():
+    build = os.path.join(NATIVE_DIR, "build")
+    os.makedirs(build, exist_ok=True)
+    path = os.path.join(build, "libem2hostchecks.so")
+    sources = [os.path.join(NATIVE_DIR, "em2_host_checks.cpp"),
+               os.path.join(ROOT, "expressionmatrix2_amd", "csrc", "em2_tables.cpp")]
+    deps = sources + [os.path.join(ROOT, "expressionmatrix2_amd", "csrc", "em2_select.h"),
+                      os.path.join(ROOT, "expressionmatrix2_amd", "csrc", "em2_tables.h")]
+    if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(d) for d in deps):
+        cmd = ["g++", "-std=c++17", "-O2", "-msse4.2", "-ffp-contract=off", "-fPIC", "-shared", "-o", path] + sources
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("host checks build failed: " + r.stderr)
+    return HostChecks(ctypes.CDLL(path))

@@ -1,0 +1,72 @@
+"""The C-ABI library on a machine without a GPU: it loads, exports every symbol include/em2_lsh.h declares,
+its host-side pieces agree with the oracle, and its device entry points fail loudly (no CPU fallback)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from expressionmatrix2_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(capi.LIBRARY_PATH):
+        capi.build_library()
+    return capi.load()
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "em2_lsh.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(em2_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    declared = declared_functions()
+    assert len(declared) >= 15
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIBRARY_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (em2_[a-z0-9_]+)", out))
+    assert set(declared) <= exported, sorted(set(declared) - exported)
+    assert set(declared) == set(capi.SYMBOLS), sorted(set(declared) ^ set(capi.SYMBOLS))
+    assert lib.em2_abi_version() == 1
+
+
+def test_library_holds_gfx950_code(lib):
+    blob = open(capi.LIBRARY_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"fsp4ScanKernel" in blob and b"projectionKernel" in blob
+
+
+def test_generate_vectors_matches_oracle(lib, oracle):
+    for genes, L, seed in [(7, 64, 231), (50, 128, 231), (33, 100, 5), (1, 1, 9)]:
+        a = capi.lsh_generate_vectors(genes, L, seed)
+        b = oracle.generate_lsh_vectors(genes, L, seed)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+        if genes > 1:
+            assert np.allclose((a * a).sum(axis=0), 1.0, atol=1e-12)
+
+
+def test_similarity_table_matches_oracle(lib, oracle):
+    for L in (1, 64, 128, 1000, 1024, 2048, 4096):
+        assert np.array_equal(capi.similarity_table(L).view(np.uint64), oracle.similarity_table(L).view(np.uint64))
+
+
+def test_murmur_matches_oracle(lib, oracle):
+    for n in (0, 1, 7, 8, 9, 4000):
+        data = (np.arange(n, dtype=np.uint64) * 2654435761 % 251).astype(np.uint8)
+        assert capi.murmur_hash_64a(data) == oracle.murmur(data)
+
+
+def test_device_paths_fail_loudly_without_gpu(lib):
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    sig = np.zeros((4, 2), dtype=np.uint64)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        capi.find_similar_pairs4(sig, 128, 3, 0.2)
+    toc = np.zeros(5, dtype=np.uint64)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        capi.compute_signatures(toc, np.zeros(0, dtype=capi.COUNT_DTYPE), 3, np.zeros((3, 64)), 64)

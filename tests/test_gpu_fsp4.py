@@ -1,0 +1,101 @@
+"""GPU parity of findSimilarPairs4: the HIP scan kernel, through the C ABI, against the CPU oracle.
+Bit-exact on cell ids, float similarity bit patterns and usedCount."""
+import numpy as np
+import pytest
+
+import synth
+from expressionmatrix2_amd import capi
+from test_fsp4_cpu import CASES, make
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same(gpu_pairs, gpu_used, cell, sim, used):
+    assert np.array_equal(gpu_used, used)
+    assert np.array_equal(gpu_pairs["cell"], cell)
+    assert np.array_equal(gpu_pairs["similarity"].view(np.uint32), sim.view(np.uint32))
+
+
+@pytest.mark.parametrize("n,L,k,thr,kind", CASES)
+def test_fsp4_matches_oracle(oracle, n, L, k, thr, kind):
+    sig = make(n, L, kind)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
+    pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+@pytest.mark.parametrize("L", [1, 63, 64, 65, 128, 192, 320, 512, 1000, 1024, 2048, 3000, 4096])
+def test_fsp4_signature_widths(oracle, L):
+    sig = synth.clustered_signatures(333, L, cluster_count=3, flip=0.2, seed=L)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, 6, 0.1)
+    pairs, gused = capi.find_similar_pairs4(sig, L, 6, 0.1)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+@pytest.mark.parametrize("k", [1, 2, 31, 32, 33, 64, 100, 257])
+def test_fsp4_k_values(oracle, k):
+    sig = synth.clustered_signatures(900, 256, cluster_count=2, flip=0.1, seed=k)
+    cell, sim, used = oracle.find_similar_pairs4(sig, 256, k, 0.2)
+    pairs, gused = capi.find_similar_pairs4(sig, 256, k, 0.2)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+def test_fsp4_k_zero_and_nothing_passes(oracle):
+    sig = synth.random_signatures(100, 128)
+    pairs, used = capi.find_similar_pairs4(sig, 128, 0, 0.2)
+    assert used.sum() == 0
+    pairs, used = capi.find_similar_pairs4(sig, 128, 5, 1.0)       # nothing is > 1.0
+    cell, sim, oused = oracle.find_similar_pairs4(sig, 128, 5, 1.0)
+    assert_same(pairs, used, cell, sim, oused)
+    assert used.sum() == 0 and not pairs["cell"].any()
+
+
+def test_fsp4_all_identical_cells(oracle):
+    sig = np.tile(synth.random_signatures(1, 256, seed=3), (700, 1))
+    cell, sim, used = oracle.find_similar_pairs4(sig, 256, 8, 0.2)
+    pairs, gused = capi.find_similar_pairs4(sig, 256, 8, 0.2)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+def test_fsp4_sampled_rows_of_larger_problem(oracle):
+    """20k cells: the full O(N^2) oracle is too slow for a unit test, so compare sampled row ranges
+    (rows are independent under the per-cell contract)."""
+    n, L, k, thr = 20000, 1024, 100, 0.2
+    sig = synth.clustered_signatures(n, L, cluster_count=16, flip=0.15, seed=99)
+    pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    for begin in (0, 6400, 19900):
+        end = min(n, begin + 100)
+        cell, sim, used = oracle.find_similar_pairs4_rows(sig, L, k, thr, begin, end)
+        assert_same(pairs[begin:end], gused[begin:end], cell, sim, used)
+    # size-independent properties on the whole result
+    assert (gused <= k).all()
+    s = pairs["similarity"]
+    for row in range(0, n, 997):
+        u = int(gused[row])
+        assert (np.diff(s[row, :u]) <= 0).all()
+        assert row not in pairs["cell"][row, :u]
+        assert len(set(pairs["cell"][row, :u].tolist())) == u
+        assert not pairs["cell"][row, u:].any() and not s[row, u:].any()
+
+
+def test_fsp4_row_shard_through_device_api(oracle):
+    """The sharded entry point (rows [begin,end) vs all columns) used by the multi-GPU path."""
+    import torch
+    n, L, k, thr = 3000, 1024, 20, 0.2
+    sig = synth.clustered_signatures(n, L, cluster_count=8, flip=0.15, seed=5)
+    d_sig = torch.from_numpy(sig.view(np.int64)).cuda()
+    for begin, end in [(0, 1000), (1000, 1001), (1001, 3000), (2999, 3000)]:
+        rows = end - begin
+        ws_bytes = capi.dev_find_similar_pairs4_workspace(n, rows, L, k)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+        d_pairs = torch.empty((rows, k, 2), dtype=torch.int32, device="cuda")
+        d_used = torch.empty(rows, dtype=torch.int32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        capi.dev_find_similar_pairs4(d_sig.data_ptr(), n, begin, end, L, k, thr, d_pairs.data_ptr(),
+                                     d_used.data_ptr(), ws.data_ptr(), ws_bytes, stream)
+        torch.cuda.synchronize()
+        pairs = d_pairs.cpu().numpy().view(np.uint32)
+        cell, sim, used = oracle.find_similar_pairs4_rows(sig, L, k, thr, begin, end)
+        assert np.array_equal(d_used.cpu().numpy().view(np.uint32), used)
+        assert np.array_equal(pairs[:, :, 0], cell)
+        assert np.array_equal(pairs[:, :, 1], sim.view(np.uint32))

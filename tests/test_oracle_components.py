@@ -1,0 +1,96 @@
+"""The oracle's building blocks against the reference's own code and known-answer vectors.
+
+Pinned here:
+  * keepBest (src/heap.hpp:116-126) with OrderPairsBySecondGreater: the oracle's std::nth_element call against
+    the reference header compiled in place (oracle/_ref), on tie-heavy inputs;
+  * the reference's print-only self-test inputs (src/heap.cpp:32-38, src/multipleSetUnion.cpp:9-23);
+  * MurmurHash64A against src/MurmurHash2.cpp;
+  * SimilarPairs::sort's comparator (src/orderPairs.hpp:44-52).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def tie_heavy_pairs(n, distinct, seed):
+    idx = np.arange(n, dtype=np.uint64)
+    cell = (synth.hash_u64(seed, 1, idx) % np.uint64(1 << 20)).astype(np.uint32)
+    level = (synth.hash_u64(seed, 2, idx) % np.uint64(distinct)).astype(np.int64)
+    sim = np.cos(level * np.pi / 1024.0).astype(np.float32)
+    return cell, sim
+
+
+@pytest.mark.parametrize("n,k,distinct", [(200, 100, 7), (200, 100, 40), (200, 100, 400), (13, 6, 13),
+                                           (10, 5, 1), (5, 5, 3), (4, 9, 3), (1000, 100, 25), (2, 1, 2),
+                                           (3, 1, 2), (64, 32, 3)])
+def test_oracle_keep_best_matches_reference_header(oracle, reflib, n, k, distinct):
+    for seed in range(20):
+        cell, sim = tie_heavy_pairs(n, distinct, seed)
+        oc, osim = oracle.keep_best(cell, sim, k)
+        rc, rsim = reflib.keep_best(cell, sim, k)
+        assert np.array_equal(oc, rc) and np.array_equal(osim.view(np.uint32), rsim.view(np.uint32))
+
+
+def test_reference_test_keep_best_vector(oracle, reflib):
+    # src/heap.cpp:32-38: keepBest({35,9,14,39,17,10,18,28,19,36,7,43,16}, 6, std::greater<int>)
+    values = [35, 9, 14, 39, 17, 10, 18, 28, 19, 36, 7, 43, 16]
+    kept = reflib.keep_best_int_greater(values, 6)
+    assert sorted(kept.tolist(), reverse=True) == [43, 39, 36, 35, 28, 19]
+    # the same through the oracle's pair form: value as similarity, index as cell id
+    cell = np.arange(len(values), dtype=np.uint32)
+    oc, osim = oracle.keep_best(cell, np.array(values, dtype=np.float32), 6)
+    assert osim.astype(np.int64).tolist() == kept.tolist()
+    with open(os.path.join(GOLDEN, "reference_known_answers.json")) as f:
+        golden = json.load(f)
+    assert kept.tolist() == golden["testKeepBest"]["kept_in_order"]
+
+
+def test_reference_multiple_set_union_vector(oracle):
+    # src/multipleSetUnion.cpp:9-23 prints 2 3 7 8 10 25 40
+    out = oracle.multiple_set_union([[3, 7, 10], [2, 7, 25], [7, 10], [3, 8, 25, 40]])
+    assert out.tolist() == [2, 3, 7, 8, 10, 25, 40]
+    assert oracle.multiple_set_union([[], [5], []]).tolist() == [5]
+
+
+def test_murmur_matches_reference(oracle, reflib):
+    for n in [0, 1, 3, 7, 8, 9, 15, 16, 17, 64, 1000, 4001]:
+        data = (synth.hash_u64(99, np.arange(n, dtype=np.uint64)) & np.uint64(0xFF)).astype(np.uint8)
+        assert oracle.murmur(data) == reflib.murmur(data)
+
+
+def test_murmur_golden(oracle):
+    with open(os.path.join(GOLDEN, "reference_known_answers.json")) as f:
+        golden = json.load(f)
+    for item in golden["murmur64a_seed231"]:
+        data = np.array(item["bytes"], dtype=np.uint8)
+        assert oracle.murmur(data) == int(item["hash"])
+
+
+def test_sort_comparator_matches_reference(oracle, reflib):
+    for seed in range(10):
+        cell, sim = tie_heavy_pairs(100, 9, seed)
+        cell = np.unique(cell)
+        sim = sim[:len(cell)]
+        rc, rs = reflib.sort_pairs(cell, sim)
+        order = np.lexsort((cell, -sim.astype(np.float64)))
+        assert np.array_equal(rc, cell[order]) and np.array_equal(rs, sim[order])
+
+
+def test_keep_best_golden_from_reference_header(oracle):
+    """Outputs of the reference's keepBest recorded by tests/golden/make_golden.py; checked everywhere
+    (the GPU box has no /root/reference)."""
+    data = np.load(os.path.join(GOLDEN, "keepbest_reference_header.npz"))
+    cases = int(data["case_count"])
+    for i in range(cases):
+        cell = data["in_cell_%d" % i]
+        sim = data["in_sim_%d" % i]
+        k = int(data["k_%d" % i])
+        oc, osim = oracle.keep_best(cell, sim, k)
+        assert np.array_equal(oc, data["out_cell_%d" % i])
+        assert np.array_equal(osim.view(np.uint32), data["out_sim_%d" % i].view(np.uint32))
