@@ -63,11 +63,28 @@ def build_library(verbose=False):
     return LIBRARY_PATH
 
 
+def _share_hip_runtime_with_torch():
+    """torch wheels bundle their own libamdhip64.so.  Two HIP runtimes in one process cannot both see the GPU,
+    and the only load order that works is torch first (libem2lsh.so then binds to the runtime torch mapped,
+    same SONAME).  So when torch is installed, import it before mapping libem2lsh.so.  torch stays plumbing:
+    nothing of it is called here."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def load():
     """Load libem2lsh.so.  Raises RuntimeError (never falls back) when it has not been built."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIBRARY_PATH):
         raise RuntimeError(
             "%s is missing: run `make -C %s` (or __graft_entry__.build()). "

@@ -1,0 +1,98 @@
+// ubench_valu.hip -- what is the real instruction roofline of XOR+popcount on this chip?
+// Measures v_xor_b32(sgpr,vgpr)+v_bcnt_u32_b32 throughput at 1,2,4,8 waves per SIMD, with the column operand
+// (a) held in SGPRs (no memory), (b) streamed with s_load_dwordx16 like the scan kernel.
+// Build & run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip -o /tmp/ubench && /tmp/ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+typedef const __attribute__((address_space(4))) uint32_t* ScalarPtr;
+
+__global__ void __launch_bounds__(256) kRegs(const uint32_t* __restrict__ sig, uint32_t iters, uint32_t* out)
+{
+    uint32_t r[32];
+    const uint32_t* rp = sig + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) % 4096 * 32;
+#pragma unroll
+    for (int w = 0; w < 32; ++w) r[w] = rp[w];
+    ScalarPtr p = (ScalarPtr)(uintptr_t)sig;
+    uint32_t c[32];
+#pragma unroll
+    for (int w = 0; w < 32; ++w) c[w] = p[w];
+    uint32_t best = 0;
+    for (uint32_t i = 0; i < iters; ++i) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int w = 0; w < 32; ++w) m += __builtin_popcount(r[w] ^ c[w]);
+        best += (m <= 3u) ? 1u : 0u;
+        // make the SGPR operands loop-variant without memory traffic
+#pragma unroll
+        for (int w = 0; w < 32; w += 8) c[w] += i;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = best;
+}
+
+__global__ void __launch_bounds__(256) kStream(const uint32_t* __restrict__ sig, uint32_t cols, uint32_t* out)
+{
+    uint32_t r[32];
+    const uint32_t* rp = sig + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) % 4096 * 32;
+#pragma unroll
+    for (int w = 0; w < 32; ++w) r[w] = rp[w];
+    ScalarPtr p = (ScalarPtr)(uintptr_t)sig;
+    uint32_t chunk[2][32];
+#pragma unroll
+    for (int w = 0; w < 32; ++w) chunk[0][w] = p[w];
+    uint32_t best = 0;
+    for (uint32_t col = 0; col < cols; col += 2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_sched_barrier(0);
+            ScalarPtr pn = (col + s + 1 < cols) ? p + 32 : p;
+#pragma unroll
+            for (int w = 0; w < 32; ++w) chunk[(s + 1) & 1][w] = pn[w];
+            p = pn;
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t m = 0;
+#pragma unroll
+            for (int w = 0; w < 32; ++w) m += __builtin_popcount(r[w] ^ chunk[s & 1][w]);
+            best += (m <= 3u) ? 1u : 0u;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = best;
+}
+
+int main()
+{
+    const uint32_t cells = 1u << 20;
+    std::vector<uint32_t> h((size_t)cells * 32);
+    uint64_t s = 88172645463325252ull;
+    for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (uint32_t)s; }
+    uint32_t *d, *o;
+    hipMalloc(&d, h.size() * 4);
+    hipMalloc(&o, 256 * 4 * 8 * 64 * 4 * 4);
+    hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int wavesPerSimd[] = {1, 2, 4, 5, 8};
+    for (int mode = 0; mode < 2; ++mode) {
+        for (int wps : wavesPerSimd) {
+            const int blocks = 256 * wps;      // 256 CUs x wps blocks of 4 waves
+            const uint32_t n = mode == 0 ? 200000u : 200000u;
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEventRecord(e0);
+                if (mode == 0) kRegs<<<blocks, 256>>>(d, n, o); else kStream<<<blocks, 256>>>(d, n, o);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+            }
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            const double waveInstr = (double)n * 64.0;                 // xor+bcnt per wave
+            const double perSimd = waveInstr * wps;                    // instructions issued per SIMD
+            const double cyc = ms * 1e-3 * 2.4e9 / perSimd;
+            printf("%s waves/SIMD=%d  %.3f ms  -> %.2f cycles(@2.4GHz) per wave-instruction per SIMD; "
+                   "%.3e comparisons/s\n", mode == 0 ? "regs  " : "stream", wps, ms, cyc,
+                   (double)n * 64.0 * 4 * wps * 256 / (ms * 1e-3));
+        }
+    }
+    return 0;
+}
