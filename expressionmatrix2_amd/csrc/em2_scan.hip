@@ -24,6 +24,8 @@
 
 #include "em2_device.h"
 
+#include <cstdlib>
+
 namespace em2 {
 namespace {
 
@@ -102,13 +104,110 @@ __device__ __attribute__((noinline)) uint32_t cutListToBest(Entry* lds, Entry* g
     return backKey;
 }
 
-template <int W32>
+// ---- rare path: some row of this wave accepts column `col` (mismatch count m in each lane) ----
+// Appends {col, key(m)} to the lists of the passing lanes, then cuts every list that reached 2k.
+__device__ __forceinline__ void acceptColumn(bool pass, uint32_t col, uint32_t row, uint32_t m, uint32_t lane,
+                                             uint32_t waveIndex, uint32_t& count, int32_t& mMax,
+                                             unsigned char* ldsRaw)
+{
+    ArgsPtr aux = kernelArgs();
+    const uint32_t k = aux->k;
+    const uint32_t twoK = 2u * k;
+    Entry* const waveBuffers = aux->buffers + size_t(waveIndex) * 64u * twoK;
+    if (pass && col != row) {
+        storeEntry(waveBuffers + size_t(lane) * twoK + count, col, aux->keyOfMismatch[m]);
+        ++count;
+    }
+    uint64_t full = __builtin_amdgcn_ballot_w64(count == twoK);
+    if (full != 0ull) {
+        Entry* lds = reinterpret_cast<Entry*>(ldsRaw) + size_t(threadIdx.x >> 6) * twoK;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        do {
+            const uint32_t src = uint32_t(__builtin_ctzll(full));
+            full &= full - 1ull;
+            Entry* g = waveBuffers + size_t(src) * twoK;
+            const uint32_t backKey = cutListToBest(lds, g, twoK, k, lane, true);
+            const int32_t newMax = aux->acceptMaxByKey[backKey];
+            if (lane == src) {
+                count = k;
+                mMax = newMax;
+            }
+            waveLdsFence();
+        } while (full != 0ull);
+    }
+}
+
+// ---- epilogue: final keepBest (ExpressionMatrixLsh.cpp:265-269), SimilarPairs::copy + sort ----
+__device__ __forceinline__ void finishRows(uint32_t lane, uint32_t waveIndex, uint32_t count, unsigned char* ldsRaw)
+{
+    ArgsPtr aux = kernelArgs();
+    const uint32_t k = aux->k;
+    const uint32_t twoK = 2u * k;
+    const uint32_t rowBegin = aux->rowBegin;
+    const uint32_t rowEnd = aux->rowEnd;
+    const uint32_t waveRowBase = rowBegin + waveIndex * 64u;
+    Entry* const waveBuffers = aux->buffers + size_t(waveIndex) * 64u * twoK;
+    Entry* lds = reinterpret_cast<Entry*>(ldsRaw) + size_t(threadIdx.x >> 6) * twoK;
+    const float* keySimilarity = aux->keySimilarity;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    for (uint32_t src = 0; src < 64u; ++src) {
+        const uint32_t srow = waveRowBase + src;
+        if (srow >= rowEnd) break;
+        uint32_t n = uint32_t(__builtin_amdgcn_readlane(int(count), int(src)));
+        Entry* g = waveBuffers + size_t(src) * twoK;
+        if (n > k) {
+            cutListToBest(lds, g, n, k, lane, false);
+            n = k;
+        } else {
+            for (uint32_t i = lane; i < n; i += 64u) lds[i] = loadEntryCoherent(g + i);
+            waveLdsFence();
+        }
+        PairOut* out = aux->outPairs + size_t(srow - rowBegin) * k;
+        for (uint32_t i = lane; i < n; i += 64u) {
+            const Entry e = lds[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; ++j) {
+                const Entry o = lds[j];
+                rank += uint32_t((o.key < e.key) || (o.key == e.key && o.cell < e.cell));
+            }
+            PairOut po;
+            po.cell = e.cell;
+            po.similarity = keySimilarity[e.key];
+            out[rank] = po;
+        }
+        for (uint32_t i = n + lane; i < k; i += 64u) {
+            PairOut zero;
+            zero.cell = 0u;
+            zero.similarity = 0.0f;
+            out[i] = zero;
+        }
+        if (lane == 0u) aux->outUsed[srow - rowBegin] = n;
+        waveLdsFence();
+    }
+}
+
+
+// =========================================================================================================
+// The scan kernel.  W32 = dwords per signature, R = rows owned by each lane (the wave owns 64*R rows).
+//
+// Measured on MI355X (profiles/r01_pmc_1Mcells_scan_projection.json, profiles/r01_ubench_valu_xor_bcnt.txt):
+//   * v_xor_b32 / v_bcnt_u32_b32 issue at one wave64 instruction per 4 clocks per SIMD (16 lanes/clk):
+//     SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles, clock 2.38 GHz (GRBM_GUI_ACTIVE), so the
+//     instruction roofline of this formulation is 256 CU x 4 SIMD x 16 lanes x 2.4 GHz / (4*W lane-ops per
+//     comparison) = 6.1e11 ordered comparisons/s at 1024 bits; this kernel keeps the VALUs 89% busy at 1M cells.
+//   * the scalar path is NOT the limiter: R = 1, 2, 4 (2x / 4x fewer scalar loads per comparison) run within
+//     3% of each other, R = 1 fastest (most waves).  R stays a template parameter for experiments
+//     (EM2_ROWS_PER_LANE); the product path uses R = 1.
+//   * the other operand path that keeps the per-pair instruction count at the floor -- column in VGPRs,
+//     broadcast with DPP row_newbcast -- was built and measured as well: v_xor_b32_dpp is slower than the
+//     SGPR-operand form on gfx950 and the kernel came out 5% slower; removed.
+// =========================================================================================================
+template <int W32, int R>
 __global__ void __launch_bounds__(256)
 fsp4ScanKernel(Fsp4Args args)
 {
     const uint32_t* __restrict__ sig32 = args.sig32;
     const uint32_t cellCount = args.cellCount;
-    const int32_t mMaxInitial = args.mMaxInitial;
     constexpr int CH = W32 < 32 ? W32 : 32;      // dwords per scalar-load chunk
     constexpr int H = W32 / CH;                  // chunks per column
     constexpr int U = H < 2 ? 2 : H;             // chunk steps per loop iteration (even, multiple of H)
@@ -118,29 +217,35 @@ fsp4ScanKernel(Fsp4Args args)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waveIndex = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 
-    uint32_t row;           // this lane's cell id
-    uint32_t r[W32];        // this lane's signature
-    int32_t mMax;
+    uint32_t row[R];            // this lane's cell ids: waveRowBase + 64*j + lane
+    uint32_t r[R][W32];         // their signatures
+    int32_t mMax[R];
+    uint32_t count[R];
     {
         ArgsPtr aux = kernelArgs();
-        const uint32_t waveRowBase = aux->rowBegin + waveIndex * 64u;
+        const uint32_t waveRowBase = aux->rowBegin + waveIndex * (64u * R);
         if (waveRowBase >= aux->rowEnd) return;
-        row = waveRowBase + lane;
-        const bool rowValid = row < aux->rowEnd;
-        const uint32_t* rp = sig32 + size_t(rowValid ? row : waveRowBase) * W32;
 #pragma unroll
-        for (int w = 0; w < W32; ++w) r[w] = rp[w];
-        mMax = rowValid ? mMaxInitial : -1;
+        for (int j = 0; j < R; ++j) {
+            row[j] = waveRowBase + 64u * j + lane;
+            const bool rowValid = row[j] < aux->rowEnd;
+            const uint32_t* rp = sig32 + size_t(rowValid ? row[j] : waveRowBase) * W32;
+#pragma unroll
+            for (int w = 0; w < W32; ++w) r[j][w] = rp[w];
+            mMax[j] = rowValid ? args.mMaxInitial : -1;
+            count[j] = 0;
+        }
     }
-    uint32_t count = 0;
 
     ScalarPtr p = (ScalarPtr)(uintptr_t)sig32;
     uint32_t chunk[2][CH];
 #pragma unroll
     for (int w = 0; w < CH; ++w) chunk[0][w] = p[w];
-    __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0): the row signature has landed before the loop starts
+    __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0): the row signatures have landed before the loop starts
 
-    uint32_t m = 0;
+    uint32_t m[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) m[j] = 0;
     for (uint32_t colBase = 0; colBase < cellCount; colBase += COLS) {
 #pragma unroll
         for (int s = 0; s < U; ++s) {
@@ -148,7 +253,7 @@ fsp4ScanKernel(Fsp4Args args)
             const uint32_t col = colBase + uint32_t(s / H);
             if (col < cellCount) {
                 // The chunk for this step was requested one step ago; wait for it, then request the next
-                // one so that its latency is covered by this step's 2*CH vector instructions.
+                // one so that its latency is covered by this step's 2*CH*R vector instructions.
                 __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
                 __builtin_amdgcn_sched_barrier(0);
                 const bool lastChunk = (col == cellCount - 1u) && (part == H - 1);
@@ -158,92 +263,34 @@ fsp4ScanKernel(Fsp4Args args)
                 p = pn;
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int w = 0; w < CH; ++w) {
-                    m += uint32_t(__builtin_popcount(r[part * CH + w] ^ chunk[s & 1][w]));
+                for (int j = 0; j < R; ++j) {
+#pragma unroll
+                    for (int w = 0; w < CH; ++w) {
+                        m[j] += uint32_t(__builtin_popcount(r[j][part * CH + w] ^ chunk[s & 1][w]));
+                    }
                 }
                 if (part == H - 1) {
-                    const bool pass = int32_t(m) <= mMax;
-                    if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
-                        // ---- rare path: some row of this wave accepts this column ----
-                        ArgsPtr aux = kernelArgs();
-                        const uint32_t k = aux->k;
-                        const uint32_t twoK = 2u * k;
-                        Entry* const waveBuffers = aux->buffers + size_t(waveIndex) * 64u * twoK;
-                        if (pass && col != row) {
-                            storeEntry(waveBuffers + size_t(lane) * twoK + count, col, aux->keyOfMismatch[m]);
-                            ++count;
-                        }
-                        uint64_t full = __builtin_amdgcn_ballot_w64(count == twoK);
-                        if (full != 0ull) {
-                            Entry* lds = reinterpret_cast<Entry*>(ldsRaw) + size_t(threadIdx.x >> 6) * twoK;
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                            do {
-                                const uint32_t src = uint32_t(__builtin_ctzll(full));
-                                full &= full - 1ull;
-                                Entry* g = waveBuffers + size_t(src) * twoK;
-                                const uint32_t backKey = cutListToBest(lds, g, twoK, k, lane, true);
-                                const int32_t newMax = aux->acceptMaxByKey[backKey];
-                                if (lane == src) {
-                                    count = k;
-                                    mMax = newMax;
-                                }
-                                waveLdsFence();
-                            } while (full != 0ull);
+                    bool any = false;
+#pragma unroll
+                    for (int j = 0; j < R; ++j) any |= int32_t(m[j]) <= mMax[j];
+                    if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+#pragma unroll
+                        for (int j = 0; j < R; ++j) {
+                            const bool pass = int32_t(m[j]) <= mMax[j];
+                            if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                                acceptColumn(pass, col, row[j], m[j], lane, waveIndex * R + j, count[j], mMax[j],
+                                             ldsRaw);
+                            }
                         }
                     }
-                    m = 0;
+#pragma unroll
+                    for (int j = 0; j < R; ++j) m[j] = 0;
                 }
             }
         }
     }
-
-    // ---- epilogue: final keepBest (ExpressionMatrixLsh.cpp:265-269), SimilarPairs::copy + sort ----
-    {
-        ArgsPtr aux = kernelArgs();
-        const uint32_t k = aux->k;
-        const uint32_t twoK = 2u * k;
-        const uint32_t rowBegin = aux->rowBegin;
-        const uint32_t rowEnd = aux->rowEnd;
-        const uint32_t waveRowBase = rowBegin + waveIndex * 64u;
-        Entry* const waveBuffers = aux->buffers + size_t(waveIndex) * 64u * twoK;
-        Entry* lds = reinterpret_cast<Entry*>(ldsRaw) + size_t(threadIdx.x >> 6) * twoK;
-        const float* keySimilarity = aux->keySimilarity;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        for (uint32_t src = 0; src < 64u; ++src) {
-            const uint32_t srow = waveRowBase + src;
-            if (srow >= rowEnd) break;
-            uint32_t n = uint32_t(__builtin_amdgcn_readlane(int(count), int(src)));
-            Entry* g = waveBuffers + size_t(src) * twoK;
-            if (n > k) {
-                cutListToBest(lds, g, n, k, lane, false);
-                n = k;
-            } else {
-                for (uint32_t i = lane; i < n; i += 64u) lds[i] = loadEntryCoherent(g + i);
-                waveLdsFence();
-            }
-            PairOut* out = aux->outPairs + size_t(srow - rowBegin) * k;
-            for (uint32_t i = lane; i < n; i += 64u) {
-                const Entry e = lds[i];
-                uint32_t rank = 0;
-                for (uint32_t j = 0; j < n; ++j) {
-                    const Entry o = lds[j];
-                    rank += uint32_t((o.key < e.key) || (o.key == e.key && o.cell < e.cell));
-                }
-                PairOut po;
-                po.cell = e.cell;
-                po.similarity = keySimilarity[e.key];
-                out[rank] = po;
-            }
-            for (uint32_t i = n + lane; i < k; i += 64u) {
-                PairOut zero;
-                zero.cell = 0u;
-                zero.similarity = 0.0f;
-                out[i] = zero;
-            }
-            if (lane == 0u) aux->outUsed[srow - rowBegin] = n;
-            waveLdsFence();
-        }
-    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) finishRows(lane, waveIndex * R + j, count[j], ldsRaw);
 }
 
 __global__ void repackSignaturesKernel(const uint64_t* __restrict__ src, uint32_t cellCount, uint32_t wordCount,
@@ -275,6 +322,13 @@ uint32_t paddedDwords(uint32_t lshCount)
     return p <= 128u ? p : 0u;
 }
 
+// EM2_ROWS_PER_LANE=2 selects two rows per lane for 1024/2048-bit signatures (A/B measurements only).
+static uint32_t forcedRowsPerLane()
+{
+    const char* v = getenv("EM2_ROWS_PER_LANE");
+    return (v && atoi(v) == 2) ? 2u : 0u;
+}
+
 uint32_t fsp4MaxK()
 {
     return kLdsBytesPerBlock / (2u * uint32_t(sizeof(Entry)));
@@ -302,7 +356,9 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     uint32_t wavesPerBlock = kLdsBytesPerBlock / bytesPerWave;
     if (wavesPerBlock > 4) wavesPerBlock = 4;
     const uint32_t rows = rowEnd - rowBegin;
-    const uint32_t waves = (rows + 63u) / 64u;
+    uint32_t rowsPerLane = forcedRowsPerLane();
+    if (rowsPerLane == 0 || paddedDw >= 128) rowsPerLane = 1;
+    const uint32_t waves = (rows + 64u * rowsPerLane - 1u) / (64u * rowsPerLane);
     if (wavesPerBlock > waves) wavesPerBlock = waves;
     const dim3 grid((waves + wavesPerBlock - 1u) / wavesPerBlock);
     const dim3 block(64u * wavesPerBlock);
@@ -323,18 +379,24 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     args.rowEnd = rowEnd;
     args.pad = 0;
 
-#define EM2_LAUNCH_SCAN(W32) fsp4ScanKernel<W32><<<grid, block, lds, stream>>>(args)
+#define EM2_LAUNCH_SCAN(W32, RR) fsp4ScanKernel<W32, RR><<<grid, block, lds, stream>>>(args)
+#define EM2_LAUNCH_SCAN_R(W32)                                  \
+    do {                                                        \
+        if (rowsPerLane == 2) EM2_LAUNCH_SCAN(W32, 2);          \
+        else EM2_LAUNCH_SCAN(W32, 1);                           \
+    } while (0)
     switch (paddedDw) {
-    case 2: EM2_LAUNCH_SCAN(2); break;
-    case 4: EM2_LAUNCH_SCAN(4); break;
-    case 8: EM2_LAUNCH_SCAN(8); break;
-    case 16: EM2_LAUNCH_SCAN(16); break;
-    case 32: EM2_LAUNCH_SCAN(32); break;
-    case 64: EM2_LAUNCH_SCAN(64); break;
-    case 128: EM2_LAUNCH_SCAN(128); break;
+    case 2: EM2_LAUNCH_SCAN(2, 1); break;
+    case 4: EM2_LAUNCH_SCAN(4, 1); break;
+    case 8: EM2_LAUNCH_SCAN(8, 1); break;
+    case 16: EM2_LAUNCH_SCAN(16, 1); break;
+    case 32: EM2_LAUNCH_SCAN_R(32); break;
+    case 64: EM2_LAUNCH_SCAN_R(64); break;
+    case 128: EM2_LAUNCH_SCAN(128, 1); break;
     default: return hipErrorInvalidValue;
     }
 #undef EM2_LAUNCH_SCAN
+#undef EM2_LAUNCH_SCAN_R
     return hipGetLastError();
 }
 

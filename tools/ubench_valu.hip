@@ -62,6 +62,70 @@ __global__ void __launch_bounds__(256) kStream(const uint32_t* __restrict__ sig,
     out[blockIdx.x * blockDim.x + threadIdx.x] = best;
 }
 
+template <int N> __device__ __forceinline__ uint32_t bcast16(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xf, 0xf, false);
+}
+__device__ __forceinline__ void bcntAcc(uint32_t& m, uint32_t x)
+{
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(m) : "v"(x));
+}
+template <int W> struct AccDpp {
+    static __device__ __forceinline__ void run(const uint32_t (&r)[32], uint32_t c0, uint32_t c1, uint32_t& m)
+    {
+        bcntAcc(m, r[W] ^ bcast16<(W >> 1)>((W & 1) ? c1 : c0));
+        AccDpp<W + 1>::run(r, c0, c1, m);
+    }
+};
+template <> struct AccDpp<32> {
+    static __device__ __forceinline__ void run(const uint32_t (&)[32], uint32_t, uint32_t, uint32_t&) {}
+};
+
+// column operand in 2 VGPRs (lane l holds dwords 2(l&15), 2(l&15)+1), broadcast with DPP row_newbcast
+__global__ void __launch_bounds__(256) kDppRegs(const uint32_t* __restrict__ sig, uint32_t iters, uint32_t* out)
+{
+    uint32_t r[32];
+    const uint32_t* rp = sig + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) % 4096 * 32;
+#pragma unroll
+    for (int w = 0; w < 32; ++w) r[w] = rp[w];
+    uint32_t c0 = rp[3], c1 = rp[5];
+    uint32_t best = 0;
+    for (uint32_t i = 0; i < iters; ++i) {
+        uint32_t m = 0;
+        AccDpp<0>::run(r, c0, c1, m);
+        best += (m <= 3u) ? 1u : 0u;
+        c0 += i; c1 ^= i;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = best;
+}
+
+template <int DEPTH>
+__global__ void __launch_bounds__(256) kDppStream(const uint32_t* __restrict__ sig, uint32_t cols, uint32_t* out)
+{
+    uint32_t r[32];
+    const uint32_t* rp = sig + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) % 4096 * 32;
+#pragma unroll
+    for (int w = 0; w < 32; ++w) r[w] = rp[w];
+    const uint32_t* base = sig + (threadIdx.x & 15u) * 2u;
+    uint2 q[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) q[d] = *reinterpret_cast<const uint2*>(base + (size_t)d * 32);
+    uint32_t best = 0;
+    for (uint32_t col = 0; col < cols; col += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const uint2 cur = q[d];
+            uint32_t nc = col + d + DEPTH;
+            nc = nc < cols ? nc : cols - 1;
+            q[d] = *reinterpret_cast<const uint2*>(base + (size_t)nc * 32);
+            uint32_t m = 0;
+            AccDpp<0>::run(r, cur.x, cur.y, m);
+            best += (m <= 3u) ? 1u : 0u;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = best;
+}
+
 int main()
 {
     const uint32_t cells = 1u << 20;
@@ -75,13 +139,17 @@ int main()
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int wavesPerSimd[] = {1, 2, 4, 5, 8};
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
         for (int wps : wavesPerSimd) {
             const int blocks = 256 * wps;      // 256 CUs x wps blocks of 4 waves
-            const uint32_t n = mode == 0 ? 200000u : 200000u;
+            const uint32_t n = 200000u;
             for (int rep = 0; rep < 2; ++rep) {
                 hipEventRecord(e0);
-                if (mode == 0) kRegs<<<blocks, 256>>>(d, n, o); else kStream<<<blocks, 256>>>(d, n, o);
+                if (mode == 0) kRegs<<<blocks, 256>>>(d, n, o);
+                else if (mode == 1) kStream<<<blocks, 256>>>(d, n, o);
+                else if (mode == 2) kDppRegs<<<blocks, 256>>>(d, n, o);
+                else if (mode == 3) kDppStream<4><<<blocks, 256>>>(d, n, o);
+                else kDppStream<8><<<blocks, 256>>>(d, n, o);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
             }
@@ -90,7 +158,7 @@ int main()
             const double perSimd = waveInstr * wps;                    // instructions issued per SIMD
             const double cyc = ms * 1e-3 * 2.4e9 / perSimd;
             printf("%s waves/SIMD=%d  %.3f ms  -> %.2f cycles(@2.4GHz) per wave-instruction per SIMD; "
-                   "%.3e comparisons/s\n", mode == 0 ? "regs  " : "stream", wps, ms, cyc,
+                   "%.3e comparisons/s\n", mode == 0 ? "sgpr-regs  " : mode == 1 ? "sgpr-stream" : mode == 2 ? "dpp-regs   " : mode == 3 ? "dpp-stream4" : "dpp-stream8", wps, ms, cyc,
                    (double)n * 64.0 * 4 * wps * 256 / (ms * 1e-3));
         }
     }
