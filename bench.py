@@ -40,7 +40,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9     # 256 CUs x 4 SIMD x 32 lanes/clk x 2.4 GHz
+# v_xor_b32 / v_bcnt_u32_b32 issue one wave64 instruction per 4 clocks per SIMD on gfx950 (measured:
+# profiles/r01_pmc_1Mcells_scan_projection.json, SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles): 16 lanes/clk.
+VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9     # 256 CUs x 4 SIMD x 16 lanes/clk x 2.4 GHz
 
 
 def parse_args():
@@ -195,7 +197,7 @@ def main():
             "traffic": None,
             "valu_frac": valu_frac,
             "note": "algorithmic bytes = 16*W per unordered pair; operands are cache/SGPR resident so frac is not "
-                    "bounded by 1; valu_frac = (v_xor+v_bcnt lane-ops)/(256 CU x 4 SIMD x 32 lanes x 2.4 GHz)",
+                    "bounded by 1; valu_frac = (v_xor+v_bcnt lane-ops)/(256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz), the measured issue rate of these ops",
         },
         "parity_check": check,
     }
