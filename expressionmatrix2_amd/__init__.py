@@ -5,6 +5,7 @@ findSimilarPairs5 Hamming scans and the SimilarPairs / Lsh file formats around t
 ExpressionMatrix method names.  The compute is in hand-written HIP (csrc/), reached through the C ABI of
 include/em2_lsh.h.
 """
-from . import capi  # noqa: F401
+from . import capi, files  # noqa: F401
+from .expression_matrix import ExpressionMatrix  # noqa: F401
 
-__all__ = ["capi"]
+__all__ = ["capi", "files", "ExpressionMatrix"]

@@ -49,6 +49,27 @@ SYMBOLS = {
     "em2_dev_find_similar_pairs4": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                                _c.c_uint32, _c.c_double, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                _c.c_size_t, _c.c_void_p]),
+    "em2_matrix_open": (_c.c_int, [_c.c_char_p, _c.POINTER(_c.c_void_p)]),
+    "em2_matrix_close": (None, [_c.c_void_p]),
+    "em2_matrix_find_similar_pairs4": (_c.c_int, [_c.c_void_p, _c.c_char_p, _c.c_char_p, _c.c_char_p, _c.c_size_t,
+                                                  _c.c_double, _c.c_size_t, _c.c_uint]),
+    "em2_matrix_compute_lsh_signatures": (_c.c_int, [_c.c_void_p, _c.c_char_p, _c.c_char_p, _c.c_char_p,
+                                                     _c.c_size_t, _c.c_uint]),
+    "em2_matrix_find_similar_pairs5": (_c.c_int, [_c.c_void_p, _c.c_char_p, _c.c_char_p, _c.c_char_p, _c.c_char_p,
+                                                  _c.c_size_t, _c.c_double, _c.c_size_t, _c.c_size_t]),
+    "em2_matrix_remove_similar_pairs": (_c.c_int, [_c.c_void_p, _c.c_char_p]),
+    "em2_matrix_subset": (_c.c_int, [_c.c_void_p, _c.c_char_p, _c.c_char_p, _c.POINTER(_c.c_uint32),
+                                     _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_uint64), _c.c_void_p, _c.c_void_p]),
+    "em2_similar_pairs_write": (_c.c_int, [_c.c_char_p, _c.c_char_p, _c.c_char_p, _c.c_char_p, _c.c_size_t,
+                                           _c.c_uint32, _c.c_void_p, _c.c_void_p]),
+    "em2_similar_pairs_read": (_c.c_int, [_c.c_char_p, _c.c_char_p, _c.POINTER(_c.c_uint64),
+                                          _c.POINTER(_c.c_uint64), _c.c_void_p, _c.c_void_p]),
+    "em2_lsh_write": (_c.c_int, [_c.c_char_p, _c.c_char_p, _c.c_uint64, _c.c_uint64, _c.c_void_p]),
+    "em2_lsh_read": (_c.c_int, [_c.c_char_p, _c.c_char_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64),
+                                _c.c_void_p]),
+    "em2_tool_create_directory": (_c.c_int, [_c.c_char_p, _c.c_uint32, _c.c_uint32, _c.c_void_p, _c.c_void_p]),
+    "em2_tool_add_gene_set": (_c.c_int, [_c.c_char_p, _c.c_char_p, _c.c_void_p, _c.c_uint32]),
+    "em2_tool_add_cell_set": (_c.c_int, [_c.c_char_p, _c.c_char_p, _c.c_void_p, _c.c_uint32]),
 }
 
 

@@ -114,6 +114,9 @@ struct DeviceBuffer {
 
 extern "C" {
 
+// Used by em2_matrix_capi.cpp (same shared object) to report through the same thread-local slot.
+void em2_internal_set_last_error(const char* message) { lastError = message ? message : ""; }
+
 int em2_abi_version(void) { return 1; }
 
 const char* em2_last_error(void) { return lastError.c_str(); }

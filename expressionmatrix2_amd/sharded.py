@@ -123,3 +123,89 @@ class DevicePipeline:
         pairs["cell"] = p[:, :, 0]
         pairs["similarity"] = p[:, :, 1].view(np.float32)
         return pairs, self.used[:self.rows].cpu().numpy().view(np.uint32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Collective form of ExpressionMatrix.findSimilarPairs4: every rank calls it with the same arguments.
+# ---------------------------------------------------------------------------------------------------------------
+
+class HipBackend:
+    """The compute of one rank, through the C ABI on the current HIP device."""
+    comm_device = "cuda"
+
+    def project(self, toc, data, gene_count, vectors, lsh_count):
+        return capi.compute_signatures(toc, data, gene_count, vectors, lsh_count)
+
+    def scan_rows(self, signatures, row_begin, row_end, lsh_count, k, thr):
+        import torch
+        cell_count = signatures.shape[0]
+        rows = row_end - row_begin
+        d_sig = torch.from_numpy(np.ascontiguousarray(signatures).view(np.int64)).cuda()
+        ws_bytes = capi.dev_find_similar_pairs4_workspace(cell_count, rows, lsh_count, k)
+        ws = torch.empty(max(1, ws_bytes), dtype=torch.uint8, device="cuda")
+        d_pairs = torch.zeros((max(1, rows), max(1, k), 2), dtype=torch.int32, device="cuda")
+        d_used = torch.zeros(max(1, rows), dtype=torch.int32, device="cuda")
+        if rows:
+            capi.dev_find_similar_pairs4(d_sig.data_ptr(), cell_count, row_begin, row_end, lsh_count, k, thr,
+                                         d_pairs.data_ptr(), d_used.data_ptr(), ws.data_ptr(), ws_bytes,
+                                         torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        p = d_pairs[:rows].cpu().numpy().view(np.uint32)
+        pairs = np.zeros((rows, k), dtype=capi.PAIR_DTYPE)
+        if k:
+            pairs["cell"] = p[:, :k, 0]
+            pairs["similarity"] = p[:, :k, 1].view(np.float32)
+        return pairs, d_used[:rows].cpu().numpy().view(np.uint32).copy()
+
+
+def find_similar_pairs4_collective(matrix, gene_set_name, cell_set_name, similar_pairs_name, k,
+                                   similarity_threshold, lsh_count, seed, dist, backend=None):
+    """ExpressionMatrix::findSimilarPairs4 (src/ExpressionMatrixLsh.cpp:155-290) across the ranks of `dist`:
+    subset -> hyperplanes (same seed on every rank) -> each rank projects its cells -> all-gather -> each rank
+    scans its rows -> rank 0 collects the rows and writes SimilarPairs-<name>-*.  Returns None like the reference."""
+    import torch
+    from . import files
+    backend = backend or HipBackend()
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    gene_count, toc, data = matrix._subset(gene_set_name, cell_set_name)      # raises the reference's errors
+    cell_count = len(toc) - 1
+    begin, end = shard_range(cell_count, world, rank)
+    local_toc = (toc[begin:end + 1] - toc[begin]).astype(np.uint64)
+    local_data = data[int(toc[begin]):int(toc[end])]
+    vectors = capi.lsh_generate_vectors(gene_count, lsh_count, seed)
+    words = capi.word_count(lsh_count)
+    if end > begin:
+        local_sig = backend.project(local_toc, local_data, gene_count, vectors, lsh_count)
+    else:
+        local_sig = np.zeros((0, words), dtype=np.uint64)
+    del vectors
+    t_local = torch.from_numpy(np.ascontiguousarray(local_sig).view(np.int64)).to(backend.comm_device)
+    t_full = gather_signatures(t_local, cell_count, world, rank, dist)
+    signatures = t_full.cpu().numpy().view(np.uint64)
+    pairs, used = backend.scan_rows(signatures, begin, end, lsh_count, k, similarity_threshold)
+
+    # collect the row shards on rank 0 (padded to the common shard size)
+    size = shard_size(cell_count, world)
+    send_pairs = np.zeros((size, max(1, k), 2), dtype=np.int32)
+    send_used = np.zeros(size, dtype=np.int32)
+    if end > begin and k:
+        send_pairs[:end - begin, :k, 0] = pairs["cell"].view(np.int32)
+        send_pairs[:end - begin, :k, 1] = pairs["similarity"].view(np.int32)
+    send_used[:end - begin] = used.view(np.int32)
+    tp = torch.from_numpy(send_pairs).to(backend.comm_device)
+    tu = torch.from_numpy(send_used).to(backend.comm_device)
+    all_pairs = torch.empty((world * size,) + tuple(tp.shape[1:]), dtype=tp.dtype, device=tp.device)
+    all_used = torch.empty(world * size, dtype=tu.dtype, device=tu.device)
+    dist.all_gather_into_tensor(all_pairs, tp)
+    dist.all_gather_into_tensor(all_used, tu)
+    if rank == 0:
+        ap = all_pairs[:cell_count].cpu().numpy().view(np.uint32)
+        out = np.zeros((cell_count, k), dtype=capi.PAIR_DTYPE)
+        if k:
+            out["cell"] = ap[:, :k, 0]
+            out["similarity"] = ap[:, :k, 1].view(np.float32)
+        files.write_similar_pairs(matrix.directoryName, similar_pairs_name, gene_set_name, cell_set_name, k, out,
+                                  all_used[:cell_count].cpu().numpy().view(np.uint32))
+    dist.barrier()
+    return None

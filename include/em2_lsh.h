@@ -128,6 +128,68 @@ int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount
                                 em2_pair* d_pairs, uint32_t* d_usedCount, void* d_workspace,
                                 size_t workspaceBytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * ExpressionMatrix-level entry points: the methods the reference binds to Python (src/PythonModule.cpp),
+ * operating by NAME on a data directory in the reference's memory-mapped formats.  Results are files in
+ * that directory (SimilarPairs-<name>-{Info,Pairs,CellInfo}, Lsh-<name>-{Info,Signatures}), byte-compatible
+ * with what the reference writes.  Errors the reference reports with std::runtime_error come back as
+ * EM2_ERROR_RUNTIME with the reference's message text.
+ * ------------------------------------------------------------------------------------------------------ */
+typedef struct em2_matrix em2_matrix;
+
+/* ExpressionMatrix(directoryName, allowReadOnly) for an existing directory (src/ExpressionMatrix.cpp:109-160);
+ * opens only what the LSH path reads: CellExpressionCounts.{toc,data}, CellSet-*, GeneSet-*-{GlobalIds,LocalIds}. */
+int em2_matrix_open(const char* directoryName, em2_matrix** matrix);
+void em2_matrix_close(em2_matrix* matrix);
+
+/* ExpressionMatrix::findSimilarPairs4 (src/ExpressionMatrixLsh.cpp:155-303; bound at src/PythonModule.cpp:802-824,
+ * defaults AllGenes, AllCells, k=100, similarityThreshold=0.2, lshCount=1024, seed=231). */
+int em2_matrix_find_similar_pairs4(em2_matrix* matrix, const char* geneSetName, const char* cellSetName,
+                                   const char* similarPairsName, size_t k, double similarityThreshold,
+                                   size_t lshCount, unsigned int seed);
+
+/* ExpressionMatrix::computeLshSignatures (src/ExpressionMatrixLsh.cpp:1150-1192; src/PythonModule.cpp:945-953). */
+int em2_matrix_compute_lsh_signatures(em2_matrix* matrix, const char* geneSetName, const char* cellSetName,
+                                      const char* lshName, size_t lshCount, unsigned int seed);
+
+/* ExpressionMatrix::findSimilarPairs5 (src/ExpressionMatrixLsh.cpp:312-501; src/PythonModule.cpp:852-865,
+ * default bucketOverflow=1000). */
+int em2_matrix_find_similar_pairs5(em2_matrix* matrix, const char* geneSetName, const char* cellSetName,
+                                   const char* lshName, const char* similarPairsName, size_t k,
+                                   double similarityThreshold, size_t lshSliceLength, size_t bucketOverflow);
+
+/* ExpressionMatrix::removeSimilarPairs (src/ExpressionMatrixFindSimilarPairs.cpp:126-135). */
+int em2_matrix_remove_similar_pairs(em2_matrix* matrix, const char* similarPairsName);
+
+/* ExpressionMatrixSubset (src/ExpressionMatrixSubset.cpp:9-42) as plain arrays, for drivers that shard the work
+ * themselves: first call with toc == NULL to get the sizes, then with toc[cellCount+1] and data[nnz]. */
+int em2_matrix_subset(em2_matrix* matrix, const char* geneSetName, const char* cellSetName, uint32_t* geneCount,
+                      uint32_t* cellCount, uint64_t* nnz, uint64_t* toc, em2_count* data);
+
+/* SimilarPairs files: constructor + copy (src/SimilarPairs.cpp:11-42,369-379) from already selected and
+ * sorted pairs; and the existing-object constructor (:47-83) with its hash / length checks.  For the read,
+ * pass pairs/usedCount == NULL to get only k and cellCount. */
+int em2_similar_pairs_write(const char* directoryName, const char* similarPairsName, const char* geneSetName,
+                            const char* cellSetName, size_t k, uint32_t cellCount, const em2_pair* pairs,
+                            const uint32_t* usedCount);
+int em2_similar_pairs_read(const char* directoryName, const char* similarPairsName, uint64_t* k,
+                           uint64_t* cellCount, em2_pair* pairs, uint32_t* usedCount);
+
+/* Lsh files Lsh-<name>-{Info,Signatures} (src/Lsh.hpp:136-141, src/Lsh.cpp:26-28,48-64,148). */
+int em2_lsh_write(const char* directoryName, const char* lshName, uint64_t cellCount, uint64_t lshCount,
+                  const uint64_t* signatures);
+int em2_lsh_read(const char* directoryName, const char* lshName, uint64_t* cellCount, uint64_t* lshCount,
+                 uint64_t* signatures);
+
+/* Tooling for tests and benchmarks -- NOT a reference API.  Creates a directory that holds exactly the files
+ * the LSH path reads (the reference's own constructor needs more files than that). */
+int em2_tool_create_directory(const char* directoryName, uint32_t geneCount, uint32_t cellCount,
+                              const uint64_t* toc, const em2_count* data);
+int em2_tool_add_gene_set(const char* directoryName, const char* name, const uint32_t* sortedGlobalIds,
+                          uint32_t count);
+int em2_tool_add_cell_set(const char* directoryName, const char* name, const uint32_t* sortedCellIds,
+                          uint32_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,151 @@
+"""Host side of the boundary without a GPU: the reference's file formats (byte layout), name lookup, subset
+construction and the reference's error messages."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import synth
+from expressionmatrix2_amd import ExpressionMatrix, capi, files
+
+
+@pytest.fixture()
+def data_dir(tmp_path):
+    d = str(tmp_path / "data")
+    toc, g, c = synth.expression_matrix(60, 50, density=0.2, cluster_count=3, seed=5)
+    files.create_directory(d, 50, toc, capi.make_counts(g, c))
+    return d, toc, g, c
+
+
+def header(path):
+    raw = open(path, "rb").read()
+    fields = struct.unpack("<7Q", raw[:56])
+    return dict(zip(["headerSize", "objectSize", "objectCount", "pageCount", "fileSize", "capacity", "magic"],
+                    fields)), raw
+
+
+def test_vector_file_layout_matches_reference_format(data_dir):
+    """src/MemoryMappedVector.hpp:141-197: 256-byte header, magic, page-rounded size, capacity."""
+    d, toc, g, c = data_dir
+    h, raw = header(os.path.join(d, "CellExpressionCounts.toc"))
+    assert h["headerSize"] == 256 and h["objectSize"] == 8 and h["objectCount"] == 61
+    assert h["magic"] == 0xa3756fd4b5d8bcc1
+    assert h["fileSize"] == len(raw) == h["pageCount"] * 4096
+    assert h["pageCount"] == (256 + 8 * 61 - 1) // 4096 + 1
+    assert h["capacity"] == (h["fileSize"] - 256) // 8
+    assert raw[56:256] == bytes(200)
+    assert np.array_equal(np.frombuffer(raw[256:256 + 8 * 61], dtype=np.uint64), toc)
+    h, raw = header(os.path.join(d, "CellExpressionCounts.data"))
+    assert h["objectSize"] == 8 and h["objectCount"] == len(g)
+    rec = np.frombuffer(raw[256:256 + 8 * len(g)], dtype=capi.COUNT_DTYPE)
+    assert np.array_equal(rec["gene"], g) and np.array_equal(rec["count"], c)
+
+
+def test_similar_pairs_files_layout(data_dir):
+    """SimilarPairs(new) + copy: src/SimilarPairs.cpp:11-42,369-379; Info layout src/SimilarPairs.hpp:188-198."""
+    d, toc, g, c = data_dir
+    k = 3
+    pairs = np.zeros((60, k), dtype=capi.PAIR_DTYPE)
+    used = np.zeros(60, dtype=np.uint32)
+    pairs[7, 0] = (9, 0.5)
+    pairs[7, 1] = (3, 0.25)
+    used[7] = 2
+    files.write_similar_pairs(d, "P", "AllGenes", "AllCells", k, pairs, used)
+    base = os.path.join(d, "SimilarPairs-P")
+    h, raw = header(base + "-Info")
+    assert h["magic"] == 0xb7756f4515d8bc94 and h["objectSize"] == 536 and h["objectCount"] == 1
+    assert h["capacity"] == 1 and h["fileSize"] == 4096
+    body = raw[256:256 + 536]
+    assert struct.unpack("<Q", body[:8])[0] == k
+    assert body[8] == len("AllGenes") and body[9:9 + 8] == b"AllGenes" and body[17:264] == bytes(247)
+    gene_ids = np.arange(50, dtype=np.uint32)
+    assert struct.unpack("<Q", body[264:272])[0] == capi.murmur_hash_64a(gene_ids)
+    assert body[272] == len("AllCells") and body[273:281] == b"AllCells"
+    assert struct.unpack("<Q", body[528:536])[0] == capi.murmur_hash_64a(np.arange(60, dtype=np.uint32))
+    h, raw = header(base + "-Pairs")
+    assert h["objectSize"] == 8 and h["objectCount"] == 60 * k
+    assert np.array_equal(np.frombuffer(raw[256:256 + 8 * 60 * k], dtype=capi.PAIR_DTYPE).reshape(60, k), pairs)
+    h, raw = header(base + "-CellInfo")
+    assert h["objectSize"] == 12 and h["objectCount"] == 60
+    ci = np.frombuffer(raw[256:256 + 12 * 60], dtype=[("used", "<u4"), ("idx", "<u4"), ("low", "<f4")])
+    assert np.array_equal(ci["used"], used)
+    assert (ci["idx"] == 0xFFFFFFFF).all() and (ci["low"] == np.finfo(np.float32).max).all()
+    # round trip + the consistency checks of the existing-object constructor
+    k2, p2, u2 = files.read_similar_pairs(d, "P")
+    assert k2 == k and np.array_equal(p2, pairs) and np.array_equal(u2, used)
+
+
+def test_similar_pairs_hash_check_detects_changed_cell_set(data_dir):
+    d, toc, g, c = data_dir
+    files.write_similar_pairs(d, "P", "AllGenes", "AllCells", 1, np.zeros((60, 1), dtype=capi.PAIR_DTYPE),
+                              np.zeros(60, dtype=np.uint32))
+    files.add_cell_set(d, "AllCells", np.arange(1, 61, dtype=np.uint32))        # same length, different content
+    with pytest.raises(RuntimeError, match="Hash for cell set AllCells is not consistent"):
+        files.read_similar_pairs(d, "P")
+
+
+def test_lsh_files_layout_and_round_trip(data_dir):
+    d, toc, g, c = data_dir
+    sig = synth.random_signatures(60, 192)
+    files.write_lsh(d, "L", 192, sig)
+    h, raw = header(os.path.join(d, "Lsh-L-Info"))
+    assert h["magic"] == 0xb7756f4515d8bc94 and h["objectSize"] == 16
+    assert struct.unpack("<2Q", raw[256:272]) == (60, 192)                       # {cellCount, lshCount}
+    h, raw = header(os.path.join(d, "Lsh-L-Signatures"))
+    assert h["magic"] == 0xa3756fd4b5d8bcc1 and h["objectSize"] == 8 and h["objectCount"] == 60 * 3
+    L, s2 = files.read_lsh(d, "L")
+    assert L == 192 and np.array_equal(s2, sig)
+
+
+def test_subset_restricts_and_renumbers_like_reference(data_dir):
+    """ExpressionMatrixSubset (src/ExpressionMatrixSubset.cpp:9-42): local gene ids, local cell order."""
+    d, toc, g, c = data_dir
+    gene_ids = np.array([2, 3, 5, 8, 13, 21, 34, 49], dtype=np.uint32)
+    cell_ids = np.array([0, 4, 5, 17, 59], dtype=np.uint32)
+    files.add_gene_set(d, "Fib", gene_ids)
+    files.add_cell_set(d, "Some", cell_ids)
+    e = ExpressionMatrix(d)
+    n_genes, stoc, sdata = e._subset("Fib", "Some")
+    assert n_genes == len(gene_ids) and len(stoc) == len(cell_ids) + 1
+    local = {int(x): i for i, x in enumerate(gene_ids)}
+    for i, cell in enumerate(cell_ids):
+        rows = slice(int(toc[cell]), int(toc[cell + 1]))
+        keep = [j for j in range(rows.start, rows.stop) if int(g[j]) in local]
+        got = sdata[int(stoc[i]):int(stoc[i + 1])]
+        assert [local[int(g[j])] for j in keep] == got["gene"].tolist()
+        assert np.array_equal(c[keep], got["count"])
+
+
+def test_reference_error_messages(data_dir):
+    """src/ExpressionMatrixLsh.cpp:168-187, 349-351; src/ExpressionMatrixFindSimilarPairs.cpp:126-135."""
+    d, toc, g, c = data_dir
+    files.add_gene_set(d, "Empty", np.zeros(0, dtype=np.uint32))
+    files.add_cell_set(d, "None", np.zeros(0, dtype=np.uint32))
+    e = ExpressionMatrix(d)
+    with pytest.raises(RuntimeError, match=r"^Gene set Nope does not exist\.$"):
+        e.findSimilarPairs4(geneSetName="Nope", similarPairsName="x")
+    with pytest.raises(RuntimeError, match=r"^Gene set Empty is empty\.$"):
+        e.findSimilarPairs4(geneSetName="Empty", similarPairsName="x")
+    with pytest.raises(RuntimeError, match=r"^Cell set Nope does not exist\.$"):
+        e.computeLshSignatures(cellSetName="Nope", lshName="x")
+    with pytest.raises(RuntimeError, match=r"^Cell set None is empty\.$"):
+        e.findSimilarPairs4(cellSetName="None", similarPairsName="x")
+    with pytest.raises(RuntimeError, match=r"^Error removing similar pairs object Missing$"):
+        e.removeSimilarPairs("Missing")
+    with pytest.raises(TypeError):
+        e.findSimilarPairs4()
+    files.write_lsh(d, "Short", 64, synth.random_signatures(10, 64))
+    with pytest.raises(RuntimeError, match="LSH object Short has a number of cells inconsistent with cell set AllCells"):
+        e.findSimilarPairs5(lshName="Short", similarPairsName="x", lshSliceLength=8)
+    with pytest.raises(RuntimeError):
+        ExpressionMatrix(os.path.join(d, "does-not-exist"))
+
+
+def test_remove_similar_pairs(data_dir):
+    d, toc, g, c = data_dir
+    files.write_similar_pairs(d, "P", "AllGenes", "AllCells", 2, np.zeros((60, 2), dtype=capi.PAIR_DTYPE),
+                              np.zeros(60, dtype=np.uint32))
+    e = ExpressionMatrix(d)
+    e.removeSimilarPairs("P")
+    assert not [f for f in os.listdir(d) if f.startswith("SimilarPairs-")]
