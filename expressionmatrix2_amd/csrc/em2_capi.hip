@@ -366,9 +366,28 @@ int em2_find_similar_pairs5(const uint64_t* signatures, uint32_t cellCount, uint
                             double similarityThreshold, uint32_t lshSliceLength, uint64_t bucketOverflow,
                             em2_pair* pairs, uint32_t* usedCount)
 {
-    (void)signatures; (void)cellCount; (void)lshCount; (void)k; (void)similarityThreshold;
-    (void)lshSliceLength; (void)bucketOverflow; (void)pairs; (void)usedCount;
-    return fail(EM2_ERROR_UNSUPPORTED, "em2_find_similar_pairs5: not implemented yet");
+    if (lshCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_find_similar_pairs5: lshCount must be positive");
+    if (lshSliceLength == 0 || lshSliceLength > 32) {
+        return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_find_similar_pairs5: lshSliceLength must be in [1,32] (the reference divides by zero for 0)");
+    }
+    if (cellCount == 0) return EM2_OK;
+    if (!signatures || !usedCount || (!pairs && k)) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_find_similar_pairs5: null pointer");
+    if (!haveDevice()) return fail(EM2_ERROR_NO_DEVICE, "em2_find_similar_pairs5: no HIP device is visible (this library has no CPU path)");
+    const uint32_t words = wordCountOf(lshCount);
+    em2::DeviceTables tables;
+    const int rc = getDeviceTables(lshCount, similarityThreshold, tables);
+    if (rc != EM2_OK) return rc;
+    DeviceBuffer dSig, dPairs, dUsed;
+    EM2_HIP(dSig.allocate(size_t(cellCount) * words * sizeof(uint64_t)));
+    EM2_HIP(dPairs.allocate(size_t(cellCount) * k * sizeof(em2_pair)));
+    EM2_HIP(dUsed.allocate(size_t(cellCount) * sizeof(uint32_t)));
+    EM2_HIP(hipMemcpy(dSig.p, signatures, size_t(cellCount) * words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    EM2_HIP(em2::runFsp5(dSig.as<uint64_t>(), cellCount, lshCount, k, lshSliceLength, bucketOverflow, tables,
+                         dPairs.as<em2::PairOut>(), dUsed.as<uint32_t>(), nullptr));
+    EM2_HIP(hipStreamSynchronize(nullptr));
+    if (k) EM2_HIP(hipMemcpy(pairs, dPairs.p, size_t(cellCount) * k * sizeof(em2_pair), hipMemcpyDeviceToHost));
+    EM2_HIP(hipMemcpy(usedCount, dUsed.p, size_t(cellCount) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return EM2_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,367 @@
+// em2_fsp5.hip -- findSimilarPairs5 on gfx950, bit-identical to src/ExpressionMatrixLsh.cpp:355-496.
+//
+// Reference algorithm: sliceCount = lshCount / lshSliceLength; slice s of a signature is bits
+// [s*q, (s+1)*q), first bit most significant (BitSet.hpp:111-119); tables[s][value] lists, in ascending id
+// order, the cells whose slice s equals value (:377-389).  For a cell c the candidates are the ascending,
+// duplicate-free union (multipleSetUnion.hpp:44-76) of its sliceCount buckets, skipping buckets larger than
+// bucketOverflow when that is non-zero (:414-431); candidates != c with similarityTable[mismatch] >
+// similarityThreshold are collected in ascending id order (:436-445), cut once with keepBest(k) (:457), stored
+// and sorted (:489-496).
+//
+// Device formulation (HBM-bound integer work; no matrix cores):
+//   1. one key per (slice, cell): (slice << 32) | value.  A stable LSD radix sort (rocPRIM) over all keys
+//      groups every bucket contiguously with ascending cell ids -- the 2^q-entry vector tables of the
+//      reference (2.6 GB of vector headers at q = 20) are never materialised;
+//   2. run boundaries -> bucket id of every (slice, cell); bucket sizes apply the overflow rule;
+//   3. per batch of cells: gather the members of the cell's buckets, segmented radix sort per cell, then one
+//      wave per cell removes duplicates, gathers the candidates' signatures, counts mismatches, keeps
+//      m <= mGlobal in ascending id order (ballot + prefix popcount), runs the exact keepBest emulation and
+//      writes the sorted result.
+// The sorts are library primitives (rocPRIM); everything specific to the path is hand-written here.
+
+#include "em2_device.h"
+
+#include <cstring>      // rocprim/iterator/texture_cache_iterator.hpp calls memset without including it
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <vector>
+
+namespace em2 {
+namespace {
+
+constexpr uint32_t kSelectLdsEntries = 4096;        // lists up to this length are cut in LDS, longer ones in HBM
+
+__device__ __forceinline__ uint32_t sliceValue(const uint64_t* sig, uint32_t slice, uint32_t q)
+{
+    const uint32_t b0 = slice * q;
+    const uint32_t w = b0 >> 6;
+    const uint32_t o = b0 & 63u;
+    uint64_t window = sig[w] << o;
+    if (o + q > 64u) window |= sig[w + 1] >> (64u - o);
+    return uint32_t(window >> (64u - q));
+}
+
+__global__ void __launch_bounds__(256)
+sliceKeysKernel(const uint64_t* __restrict__ sig, uint32_t cellCount, uint32_t words, uint32_t q, uint32_t sliceCount,
+                uint64_t* __restrict__ keys, uint32_t* __restrict__ cells)
+{
+    const uint64_t total = uint64_t(sliceCount) * cellCount;
+    for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += uint64_t(gridDim.x) * blockDim.x) {
+        const uint32_t s = uint32_t(i / cellCount);
+        const uint32_t c = uint32_t(i % cellCount);
+        keys[i] = (uint64_t(s) << 32) | sliceValue(sig + size_t(c) * words, s, q);
+        cells[i] = c;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+runFlagsKernel(const uint64_t* __restrict__ sortedKeys, uint64_t total, uint32_t* __restrict__ flags)
+{
+    for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += uint64_t(gridDim.x) * blockDim.x) {
+        flags[i] = (i == 0 || sortedKeys[i] != sortedKeys[i - 1]) ? 1u : 0u;
+    }
+}
+
+// runIndex[i] = (inclusive scan of flags)[i] - 1.  Records where each run starts and which run every
+// (slice, cell) belongs to.
+__global__ void __launch_bounds__(256)
+runTablesKernel(const uint64_t* __restrict__ sortedKeys, const uint32_t* __restrict__ sortedCells,
+                const uint32_t* __restrict__ flags, const uint32_t* __restrict__ scan, uint64_t total,
+                uint32_t cellCount, uint32_t* __restrict__ runStart, uint32_t* __restrict__ runOfSliceCell)
+{
+    for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += uint64_t(gridDim.x) * blockDim.x) {
+        const uint32_t run = scan[i] - 1u;
+        if (flags[i]) runStart[run] = uint32_t(i);
+        const uint32_t s = uint32_t(sortedKeys[i] >> 32);
+        runOfSliceCell[size_t(s) * cellCount + sortedCells[i]] = run;
+        if (i == total - 1) runStart[run + 1u] = uint32_t(total);
+    }
+}
+
+// Number of bucket members a cell will gather (before de-duplication), with the overflow rule applied.
+__global__ void __launch_bounds__(256)
+candidateCountKernel(const uint32_t* __restrict__ runOfSliceCell, const uint32_t* __restrict__ runStart,
+                     uint32_t cellCount, uint32_t sliceCount, uint64_t bucketOverflow, uint64_t* __restrict__ counts)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cellCount) return;
+    uint64_t n = 0;
+    for (uint32_t s = 0; s < sliceCount; ++s) {
+        const uint32_t run = runOfSliceCell[size_t(s) * cellCount + c];
+        const uint64_t size = runStart[run + 1u] - runStart[run];
+        if (bucketOverflow == 0 || size <= bucketOverflow) n += size;       // ExpressionMatrixLsh.cpp:419
+    }
+    counts[c] = n;
+}
+
+// One wave per cell of the batch: copy the members of its buckets into its segment.
+__global__ void __launch_bounds__(256)
+gatherKernel(const uint32_t* __restrict__ runOfSliceCell, const uint32_t* __restrict__ runStart,
+             const uint32_t* __restrict__ sortedCells, uint32_t cellCount, uint32_t sliceCount, uint64_t bucketOverflow,
+             uint32_t batchBegin, uint32_t batchCells, const uint32_t* __restrict__ segmentBegin,
+             uint32_t* __restrict__ candidates)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t local = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (local >= batchCells) return;
+    const uint32_t c = batchBegin + local;
+    uint32_t out = segmentBegin[local];
+    for (uint32_t s = 0; s < sliceCount; ++s) {
+        const uint32_t run = runOfSliceCell[size_t(s) * cellCount + c];
+        const uint32_t begin = runStart[run];
+        const uint32_t size = runStart[run + 1u] - begin;
+        if (bucketOverflow != 0 && uint64_t(size) > bucketOverflow) continue;
+        for (uint32_t i = lane; i < size; i += 64u) candidates[out + i] = sortedCells[begin + i];
+        out += size;
+    }
+}
+
+__device__ __forceinline__ void waveFence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One wave per cell: unique + mismatch filter (ascending id order), keepBest, sort, store.
+__global__ void __launch_bounds__(64)
+filterSelectKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batchBegin, uint32_t batchCells,
+                   const uint32_t* __restrict__ segmentBegin, const uint32_t* __restrict__ sortedCandidates,
+                   Entry* __restrict__ lists, int32_t mGlobal, const uint32_t* __restrict__ keyOfMismatch,
+                   const float* __restrict__ keySimilarity, uint32_t k, PairOut* __restrict__ outPairs,
+                   uint32_t* __restrict__ outUsed)
+{
+    __shared__ Entry lds[kSelectLdsEntries];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t local = blockIdx.x;
+    if (local >= batchCells) return;
+    const uint32_t c = batchBegin + local;
+    const uint32_t begin = segmentBegin[local];
+    const uint32_t end = segmentBegin[local + 1u];
+    const uint64_t* mine = sig + size_t(c) * words;
+    Entry* list = lists + begin;                    // at most (end-begin) entries survive
+
+    uint32_t n = 0;
+    for (uint32_t base = begin; base < end; base += 64u) {
+        const uint32_t i = base + lane;
+        bool keep = false;
+        uint32_t cand = 0, m = 0;
+        if (i < end) {
+            cand = sortedCandidates[i];
+            const bool duplicate = i > begin && sortedCandidates[i - 1u] == cand;
+            if (!duplicate && cand != c) {                                   // ExpressionMatrixLsh.cpp:437-439
+                const uint64_t* other = sig + size_t(cand) * words;
+                for (uint32_t w = 0; w < words; ++w) m += uint32_t(__builtin_popcountll(mine[w] ^ other[w]));
+                keep = int32_t(m) <= mGlobal;                                // similarity > similarityThreshold (:441)
+            }
+        }
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) {
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+            Entry e;
+            e.cell = cand;
+            e.key = keyOfMismatch[m];
+            list[n + before] = e;
+        }
+        n += uint32_t(__builtin_popcountll(mask));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+
+    // keepBest(cellNeighbors, k) (:457) then SimilarPairs::copy + sort (:489-496).
+    Entry* work = list;
+    const bool inLds = n <= kSelectLdsEntries;
+    if (inLds) {
+        for (uint32_t i = lane; i < n; i += 64u) {
+            const uint64_t v = __hip_atomic_load(reinterpret_cast<const uint64_t*>(list + i), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+            Entry e;
+            e.cell = uint32_t(v);
+            e.key = uint32_t(v >> 32);
+            lds[i] = e;
+        }
+        work = lds;
+        waveFence();
+    }
+    if (n > k) {
+        if (lane == 0u) nthElement(work, int(k), int(n));
+        n = k;
+        waveFence();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");      // lane 0's HBM writes (long lists) visible to the wave
+    }
+    PairOut* out = outPairs + size_t(local) * k;
+    for (uint32_t i = lane; i < n; i += 64u) {
+        Entry e;
+        if (inLds) {
+            e = work[i];
+        } else {
+            const uint64_t v = __hip_atomic_load(reinterpret_cast<const uint64_t*>(work + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            e.cell = uint32_t(v);
+            e.key = uint32_t(v >> 32);
+        }
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            Entry o;
+            if (inLds) {
+                o = work[j];
+            } else {
+                const uint64_t v = __hip_atomic_load(reinterpret_cast<const uint64_t*>(work + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                o.cell = uint32_t(v);
+                o.key = uint32_t(v >> 32);
+            }
+            rank += uint32_t((o.key < e.key) || (o.key == e.key && o.cell < e.cell));
+        }
+        PairOut po;
+        po.cell = e.cell;
+        po.similarity = keySimilarity[e.key];
+        out[rank] = po;
+    }
+    for (uint32_t i = n + lane; i < k; i += 64u) {
+        PairOut zero;
+        zero.cell = 0u;
+        zero.similarity = 0.0f;
+        out[i] = zero;
+    }
+    if (lane == 0u) outUsed[local] = n;
+}
+
+struct Buffer {
+    void* p = nullptr;
+    ~Buffer() { if (p) (void)hipFree(p); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } }
+    hipError_t allocate(size_t bytes) { release(); return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+uint32_t gridFor(uint64_t n)
+{
+    const uint64_t blocks = (n + 255) / 256;
+    return uint32_t(blocks > 16384 ? 16384 : (blocks ? blocks : 1));
+}
+
+uint32_t bitsFor(uint64_t maxValue)
+{
+    uint32_t b = 1;
+    while (b < 64 && (maxValue >> b) != 0) ++b;
+    return b;
+}
+
+#define EM2_TRY(call)                        \
+    do {                                     \
+        hipError_t em2Err_ = (call);         \
+        if (em2Err_ != hipSuccess) return em2Err_; \
+    } while (0)
+
+}  // namespace
+
+
+// Host driver: allocates its own scratch (this entry point serves the host-buffer API).  d_pairs / d_used are
+// device arrays of cellCount*k and cellCount elements.
+hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t lshCount, uint32_t k, uint32_t q,
+                   uint64_t bucketOverflow, const DeviceTables& tables, PairOut* d_pairs, uint32_t* d_used,
+                   hipStream_t stream)
+{
+    const uint32_t words = (lshCount - 1u) / 64u + 1u;
+    const uint32_t sliceCount = lshCount / q;                       // ExpressionMatrixLsh.cpp:355
+    EM2_TRY(hipMemsetAsync(d_used, 0, size_t(cellCount) * sizeof(uint32_t), stream));
+    if (k) EM2_TRY(hipMemsetAsync(d_pairs, 0, size_t(cellCount) * k * sizeof(PairOut), stream));
+    if (sliceCount == 0 || cellCount == 0) return hipStreamSynchronize(stream);
+    const uint64_t total = uint64_t(sliceCount) * cellCount;
+    if (total >= 0xffffffffULL) return hipErrorInvalidValue;
+
+    // 1. keys and stable sort
+    Buffer keysA, keysB, cellsA, cellsB, temp;
+    EM2_TRY(keysA.allocate(total * sizeof(uint64_t)));
+    EM2_TRY(keysB.allocate(total * sizeof(uint64_t)));
+    EM2_TRY(cellsA.allocate(total * sizeof(uint32_t)));
+    EM2_TRY(cellsB.allocate(total * sizeof(uint32_t)));
+    sliceKeysKernel<<<gridFor(total), 256, 0, stream>>>(d_sig, cellCount, words, q, sliceCount, keysA.as<uint64_t>(), cellsA.as<uint32_t>());
+    EM2_TRY(hipGetLastError());
+    const uint32_t endBit = 32u + bitsFor(sliceCount - 1u);
+    size_t tempBytes = 0;
+    EM2_TRY(rocprim::radix_sort_pairs(nullptr, tempBytes, keysA.as<uint64_t>(), keysB.as<uint64_t>(), cellsA.as<uint32_t>(),
+                                      cellsB.as<uint32_t>(), size_t(total), 0u, endBit, stream));
+    EM2_TRY(temp.allocate(tempBytes));
+    EM2_TRY(rocprim::radix_sort_pairs(temp.p, tempBytes, keysA.as<uint64_t>(), keysB.as<uint64_t>(), cellsA.as<uint32_t>(),
+                                      cellsB.as<uint32_t>(), size_t(total), 0u, endBit, stream));
+    const uint64_t* sortedKeys = keysB.as<uint64_t>();
+    const uint32_t* sortedCells = cellsB.as<uint32_t>();
+
+    // 2. runs (= buckets)
+    Buffer flags, scan, runStart, runOf, counts;
+    EM2_TRY(flags.allocate(total * sizeof(uint32_t)));
+    EM2_TRY(scan.allocate(total * sizeof(uint32_t)));
+    EM2_TRY(runStart.allocate((total + 1) * sizeof(uint32_t)));
+    EM2_TRY(runOf.allocate(total * sizeof(uint32_t)));
+    EM2_TRY(counts.allocate(size_t(cellCount) * sizeof(uint64_t)));
+    runFlagsKernel<<<gridFor(total), 256, 0, stream>>>(sortedKeys, total, flags.as<uint32_t>());
+    EM2_TRY(hipGetLastError());
+    size_t scanBytes = 0;
+    EM2_TRY(rocprim::inclusive_scan(nullptr, scanBytes, flags.as<uint32_t>(), scan.as<uint32_t>(), size_t(total), rocprim::plus<uint32_t>(), stream));
+    Buffer scanTemp;
+    EM2_TRY(scanTemp.allocate(scanBytes));
+    EM2_TRY(rocprim::inclusive_scan(scanTemp.p, scanBytes, flags.as<uint32_t>(), scan.as<uint32_t>(), size_t(total), rocprim::plus<uint32_t>(), stream));
+    runTablesKernel<<<gridFor(total), 256, 0, stream>>>(sortedKeys, sortedCells, flags.as<uint32_t>(), scan.as<uint32_t>(), total,
+                                                        cellCount, runStart.as<uint32_t>(), runOf.as<uint32_t>());
+    EM2_TRY(hipGetLastError());
+    candidateCountKernel<<<(cellCount + 255u) / 256u, 256, 0, stream>>>(runOf.as<uint32_t>(), runStart.as<uint32_t>(), cellCount,
+                                                                         sliceCount, bucketOverflow, counts.as<uint64_t>());
+    EM2_TRY(hipGetLastError());
+    std::vector<uint64_t> hostCounts(cellCount);
+    EM2_TRY(hipMemcpyAsync(hostCounts.data(), counts.p, size_t(cellCount) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    EM2_TRY(hipStreamSynchronize(stream));
+    // keys / flags / scan are no longer needed
+    keysA.release(); flags.release(); scan.release(); scanTemp.release(); temp.release(); cellsA.release();
+
+    // 3. batches of cells whose gathered candidates fit the budget
+    const uint64_t budget = 1ull << 28;              // 2^28 candidate ids (1 GiB) per batch
+    Buffer segBegin, candA, candB, lists, sortTemp;
+    std::vector<uint32_t> hostSeg;
+    uint32_t batchBegin = 0;
+    const uint32_t idBits = bitsFor(cellCount - 1u);
+    while (batchBegin < cellCount) {
+        uint64_t sum = 0;
+        uint32_t batchEnd = batchBegin;
+        hostSeg.assign(1, 0u);
+        while (batchEnd < cellCount && batchEnd - batchBegin < (1u << 20)) {
+            const uint64_t n = hostCounts[batchEnd];
+            if (n >= 0xffffffffULL) return hipErrorInvalidValue;
+            if (sum + n > budget && batchEnd > batchBegin) break;
+            sum += n;
+            ++batchEnd;
+            hostSeg.push_back(uint32_t(sum));
+            if (sum > budget) break;                 // a single huge cell: its own batch
+        }
+        if (sum >= 0xffffffffULL) return hipErrorInvalidValue;
+        const uint32_t batchCells = batchEnd - batchBegin;
+        const uint32_t batchTotal = uint32_t(sum);
+        EM2_TRY(segBegin.allocate(hostSeg.size() * sizeof(uint32_t)));
+        EM2_TRY(hipMemcpyAsync(segBegin.p, hostSeg.data(), hostSeg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        EM2_TRY(candA.allocate(size_t(batchTotal) * sizeof(uint32_t)));
+        EM2_TRY(candB.allocate(size_t(batchTotal) * sizeof(uint32_t)));
+        EM2_TRY(lists.allocate(size_t(batchTotal) * sizeof(Entry)));
+        const uint32_t* sorted = candA.as<uint32_t>();
+        if (batchTotal) {
+            gatherKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(runOf.as<uint32_t>(), runStart.as<uint32_t>(), sortedCells, cellCount,
+                                                                     sliceCount, bucketOverflow, batchBegin, batchCells,
+                                                                     segBegin.as<uint32_t>(), candA.as<uint32_t>());
+            EM2_TRY(hipGetLastError());
+            size_t segBytes = 0;
+            EM2_TRY(rocprim::segmented_radix_sort_keys(nullptr, segBytes, candA.as<uint32_t>(), candB.as<uint32_t>(), batchTotal, batchCells,
+                                                       segBegin.as<uint32_t>(), segBegin.as<uint32_t>() + 1, 0u, idBits, stream));
+            EM2_TRY(sortTemp.allocate(segBytes));
+            EM2_TRY(rocprim::segmented_radix_sort_keys(sortTemp.p, segBytes, candA.as<uint32_t>(), candB.as<uint32_t>(), batchTotal, batchCells,
+                                                       segBegin.as<uint32_t>(), segBegin.as<uint32_t>() + 1, 0u, idBits, stream));
+            sorted = candB.as<uint32_t>();
+        }
+        filterSelectKernel<<<batchCells, 64, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
+                                                          lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch, tables.keySimilarity, k,
+                                                          d_pairs + size_t(batchBegin) * k, d_used + batchBegin);
+        EM2_TRY(hipGetLastError());
+        EM2_TRY(hipStreamSynchronize(stream));       // hostSeg / scratch are reused by the next batch
+        batchBegin = batchEnd;
+    }
+    return hipSuccess;
+}
+
+}  // namespace em2

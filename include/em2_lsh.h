@@ -91,7 +91,7 @@ int em2_find_similar_pairs4(const uint64_t* signatures, uint32_t cellCount, uint
                             double similarityThreshold, em2_pair* pairs, uint32_t* usedCount);
 
 /* ExpressionMatrix::findSimilarPairs5 (src/ExpressionMatrixLsh.cpp:355-496).  lshSliceLength must be in
- * [1,30] (the reference divides by zero for 0). */
+ * [1,32] (the reference divides by zero for 0 and allocates 2^lshSliceLength vectors per slice). */
 int em2_find_similar_pairs5(const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount, uint32_t k,
                             double similarityThreshold, uint32_t lshSliceLength, uint64_t bucketOverflow,
                             em2_pair* pairs, uint32_t* usedCount);

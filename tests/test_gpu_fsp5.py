@@ -1,0 +1,84 @@
+"""GPU parity of findSimilarPairs5 (slice buckets -> candidate union -> mismatch filter -> keepBest) against the
+CPU oracle's restatement of src/ExpressionMatrixLsh.cpp:355-496.  Bit-exact."""
+import numpy as np
+import pytest
+
+import synth
+from expressionmatrix2_amd import ExpressionMatrix, capi, files
+
+pytestmark = pytest.mark.gpu
+
+
+def check(oracle, sig, L, k, thr, q, ovf):
+    cell, sim, used = oracle.find_similar_pairs5(sig, L, k, thr, q, ovf)
+    pairs, gused = capi.find_similar_pairs5(sig, L, k, thr, q, ovf)
+    assert np.array_equal(gused, used)
+    assert np.array_equal(pairs["cell"], cell)
+    assert np.array_equal(pairs["similarity"].view(np.uint32), sim.view(np.uint32))
+    return used
+
+
+@pytest.mark.parametrize("n,L,k,thr,q,ovf", [
+    (300, 128, 5, 0.2, 8, 1000),
+    (300, 1024, 100, 0.2, 14, 1000),      # slices straddle 64-bit words
+    (1000, 1024, 10, 0.2, 10, 50),        # overflow rule drops the big buckets
+    (1000, 1024, 10, 0.2, 10, 0),         # bucketOverflow = 0: no limit
+    (777, 2048, 20, 0.0, 20, 1000),       # BASELINE config D shape (q = 20)
+    (500, 192, 7, -0.5, 7, 1000),         # 192 / 7 leaves unused bits
+    (400, 100, 3, 0.1, 3, 1000),
+    (64, 64, 2, 0.2, 1, 0),               # 1-bit slices: two giant buckets per slice
+    (200, 256, 4, 0.2, 30, 1000),
+    (200, 256, 4, 0.2, 32, 1000),
+])
+def test_fsp5_matches_oracle(oracle, n, L, k, thr, q, ovf):
+    if q > 30:
+        # the oracle restates the reference's 2^q-entry tables and stops at 30; compare against a run with the
+        # same slices expressed through identical signatures is not possible -> only sanity-check shape here
+        sig = synth.clustered_signatures(n, L, cluster_count=4, flip=0.02, seed=n + q)
+        pairs, used = capi.find_similar_pairs5(sig, L, k, thr, q, ovf)
+        assert (used <= k).all()
+        return
+    sig = synth.clustered_signatures(n, L, cluster_count=4, flip=0.05, seed=n + q)
+    used = check(oracle, sig, L, k, thr, q, ovf)
+    if ovf == 0 or ovf >= 1000:
+        assert used.sum() > 0
+
+
+def test_fsp5_slice_longer_than_signature(oracle):
+    sig = synth.random_signatures(50, 64)
+    pairs, used = capi.find_similar_pairs5(sig, 64, 5, 0.2, 32, 1000)       # sliceCount = 2
+    cell, sim, oused = oracle.find_similar_pairs5(sig, 64, 5, 0.2, 30, 1000)
+    pairs, used = capi.find_similar_pairs5(sig, 8, 5, 0.2, 16, 1000)        # lshCount 8 < 16: sliceCount 0
+    assert used.sum() == 0 and not pairs["cell"].any()
+
+
+def test_fsp5_identical_cells_long_lists(oracle):
+    """Every cell identical: one bucket of 6000 per slice, every candidate passes, lists longer than the LDS
+    staging area -> the HBM selection path; ties everywhere."""
+    sig = np.tile(synth.random_signatures(1, 128, seed=5), (6000, 1))
+    check(oracle, sig, 128, 9, 0.2, 16, 0)
+    # with the overflow rule every bucket is dropped
+    pairs, used = capi.find_similar_pairs5(sig, 128, 9, 0.2, 16, 1000)
+    assert used.sum() == 0
+
+
+def test_fsp5_rejects_zero_slice_length():
+    sig = synth.random_signatures(10, 64)
+    with pytest.raises(RuntimeError, match="lshSliceLength"):
+        capi.find_similar_pairs5(sig, 64, 5, 0.2, 0, 1000)
+
+
+def test_fsp5_through_expression_matrix_api(oracle, tmp_path):
+    d = str(tmp_path / "data")
+    cells, genes = 600, 500
+    toc, g, c = synth.expression_matrix(cells, genes, density=0.05, cluster_count=4, seed=31)
+    files.create_directory(d, genes, toc, capi.make_counts(g, c))
+    e = ExpressionMatrix(d)
+    e.computeLshSignatures(lshName="L", lshCount=1024, seed=231)
+    e.findSimilarPairs5(lshName="L", similarPairsName="P5", k=12, similarityThreshold=0.2, lshSliceLength=12)
+    L, sig = files.read_lsh(d, "L")
+    cell, sim, used = oracle.find_similar_pairs5(sig, L, 12, 0.2, 12, 1000)
+    k2, pairs, u2 = files.read_similar_pairs(d, "P5")
+    assert k2 == 12 and np.array_equal(u2, used) and np.array_equal(pairs["cell"], cell)
+    assert np.array_equal(pairs["similarity"].view(np.uint32), sim.view(np.uint32))
+    assert used.sum() > 0
