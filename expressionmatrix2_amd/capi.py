@@ -49,6 +49,9 @@ SYMBOLS = {
     "em2_dev_find_similar_pairs4": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                                _c.c_uint32, _c.c_double, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                _c.c_size_t, _c.c_void_p]),
+    "em2_dev_find_similar_pairs5": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
+                                               _c.c_uint32, _c.c_double, _c.c_uint32, _c.c_uint64, _c.c_void_p,
+                                               _c.c_void_p, _c.c_void_p]),
     "em2_matrix_open": (_c.c_int, [_c.c_char_p, _c.POINTER(_c.c_void_p)]),
     "em2_matrix_close": (None, [_c.c_void_p]),
     "em2_matrix_find_similar_pairs4": (_c.c_int, [_c.c_void_p, _c.c_char_p, _c.c_char_p, _c.c_char_p, _c.c_size_t,
@@ -215,6 +218,13 @@ def dev_find_similar_pairs4(sig_ptr, cell_count, row_begin, row_end, lsh_count, 
     check(load().em2_dev_find_similar_pairs4(sig_ptr, cell_count, row_begin, row_end, lsh_count, k,
                                              similarity_threshold, pairs_ptr, used_ptr, workspace_ptr,
                                              workspace_bytes, stream))
+
+
+def dev_find_similar_pairs5(sig_ptr, cell_count, row_begin, row_end, lsh_count, k, similarity_threshold,
+                            lsh_slice_length, bucket_overflow, pairs_ptr, used_ptr, stream):
+    check(load().em2_dev_find_similar_pairs5(sig_ptr, cell_count, row_begin, row_end, lsh_count, k,
+                                             similarity_threshold, lsh_slice_length, bucket_overflow, pairs_ptr,
+                                             used_ptr, stream))
 
 
 def dev_compute_signatures_workspace(cell_count, lsh_count):

@@ -301,6 +301,25 @@ int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount
 }
 
 
+int em2_dev_find_similar_pairs5(const uint64_t* d_signatures, uint32_t cellCount, uint32_t rowBegin,
+                                uint32_t rowEnd, uint32_t lshCount, uint32_t k, double similarityThreshold,
+                                uint32_t lshSliceLength, uint64_t bucketOverflow, em2_pair* d_pairs,
+                                uint32_t* d_usedCount, void* stream)
+{
+    if (lshCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs5: lshCount must be positive");
+    if (lshSliceLength == 0 || lshSliceLength > 32) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs5: lshSliceLength must be in [1,32]");
+    if (rowBegin > rowEnd || rowEnd > cellCount) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs5: bad row range");
+    if (rowBegin == rowEnd) return EM2_OK;
+    if (!d_signatures || !d_usedCount || (!d_pairs && k)) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs5: null pointer");
+    em2::DeviceTables tables;
+    const int rc = getDeviceTables(lshCount, similarityThreshold, tables);
+    if (rc != EM2_OK) return rc;
+    EM2_HIP(em2::runFsp5(d_signatures, cellCount, rowBegin, rowEnd, lshCount, k, lshSliceLength, bucketOverflow, tables,
+                         reinterpret_cast<em2::PairOut*>(d_pairs), d_usedCount, static_cast<hipStream_t>(stream)));
+    return EM2_OK;
+}
+
+
 // ---------------------------------------------------------------------------------------------------------
 // Host-buffer entry points.
 // ---------------------------------------------------------------------------------------------------------
@@ -382,8 +401,8 @@ int em2_find_similar_pairs5(const uint64_t* signatures, uint32_t cellCount, uint
     EM2_HIP(dPairs.allocate(size_t(cellCount) * k * sizeof(em2_pair)));
     EM2_HIP(dUsed.allocate(size_t(cellCount) * sizeof(uint32_t)));
     EM2_HIP(hipMemcpy(dSig.p, signatures, size_t(cellCount) * words * sizeof(uint64_t), hipMemcpyHostToDevice));
-    EM2_HIP(em2::runFsp5(dSig.as<uint64_t>(), cellCount, lshCount, k, lshSliceLength, bucketOverflow, tables,
-                         dPairs.as<em2::PairOut>(), dUsed.as<uint32_t>(), nullptr));
+    EM2_HIP(em2::runFsp5(dSig.as<uint64_t>(), cellCount, 0, cellCount, lshCount, k, lshSliceLength, bucketOverflow,
+                         tables, dPairs.as<em2::PairOut>(), dUsed.as<uint32_t>(), nullptr));
     EM2_HIP(hipStreamSynchronize(nullptr));
     if (k) EM2_HIP(hipMemcpy(pairs, dPairs.p, size_t(cellCount) * k * sizeof(em2_pair), hipMemcpyDeviceToHost));
     EM2_HIP(hipMemcpy(usedCount, dUsed.p, size_t(cellCount) * sizeof(uint32_t), hipMemcpyDeviceToHost));

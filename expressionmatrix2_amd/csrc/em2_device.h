@@ -62,11 +62,11 @@ hipError_t launchProjection(const uint64_t* toc, const CountIn* data, uint32_t c
                             const double* vectorSums, const double* means, uint32_t lshCount,
                             uint64_t* signatures, hipStream_t stream);
 
-// findSimilarPairs5 (src/ExpressionMatrixLsh.cpp:355-496) for all cells; allocates its own scratch and
-// synchronises the stream (host-buffer entry point).  q = lshSliceLength in [1,32].
-hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t lshCount, uint32_t k, uint32_t q,
-                   uint64_t bucketOverflow, const DeviceTables& tables, PairOut* d_pairs, uint32_t* d_used,
-                   hipStream_t stream);
+// findSimilarPairs5 (src/ExpressionMatrixLsh.cpp:355-496): bucket tables over all cells, results for the cells
+// [rowBegin,rowEnd).  Allocates its own scratch and synchronises the stream.  q = lshSliceLength in [1,32].
+hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin, uint32_t rowEnd, uint32_t lshCount,
+                   uint32_t k, uint32_t q, uint64_t bucketOverflow, const DeviceTables& tables, PairOut* d_pairs,
+                   uint32_t* d_used, hipStream_t stream);
 
 }  // namespace em2
 

@@ -255,16 +255,19 @@ uint32_t bitsFor(uint64_t maxValue)
 }  // namespace
 
 
-// Host driver: allocates its own scratch (this entry point serves the host-buffer API).  d_pairs / d_used are
-// device arrays of cellCount*k and cellCount elements.
-hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t lshCount, uint32_t k, uint32_t q,
-                   uint64_t bucketOverflow, const DeviceTables& tables, PairOut* d_pairs, uint32_t* d_used,
-                   hipStream_t stream)
+// Host driver: allocates its own scratch and synchronises the stream.  The bucket tables are built over ALL
+// cellCount cells; candidates are generated and selected for the cells [rowBegin,rowEnd) only (the shard one
+// rank owns).  d_pairs / d_used are device arrays of (rowEnd-rowBegin)*k and (rowEnd-rowBegin) elements.
+hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin, uint32_t rowEnd, uint32_t lshCount,
+                   uint32_t k, uint32_t q, uint64_t bucketOverflow, const DeviceTables& tables, PairOut* d_pairs,
+                   uint32_t* d_used, hipStream_t stream)
 {
+    const uint32_t rowCount = rowEnd - rowBegin;
     const uint32_t words = (lshCount - 1u) / 64u + 1u;
     const uint32_t sliceCount = lshCount / q;                       // ExpressionMatrixLsh.cpp:355
-    EM2_TRY(hipMemsetAsync(d_used, 0, size_t(cellCount) * sizeof(uint32_t), stream));
-    if (k) EM2_TRY(hipMemsetAsync(d_pairs, 0, size_t(cellCount) * k * sizeof(PairOut), stream));
+    if (rowCount == 0) return hipSuccess;
+    EM2_TRY(hipMemsetAsync(d_used, 0, size_t(rowCount) * sizeof(uint32_t), stream));
+    if (k) EM2_TRY(hipMemsetAsync(d_pairs, 0, size_t(rowCount) * k * sizeof(PairOut), stream));
     if (sliceCount == 0 || cellCount == 0) return hipStreamSynchronize(stream);
     const uint64_t total = uint64_t(sliceCount) * cellCount;
     if (total >= 0xffffffffULL) return hipErrorInvalidValue;
@@ -317,13 +320,13 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t lshCount,
     const uint64_t budget = 1ull << 28;              // 2^28 candidate ids (1 GiB) per batch
     Buffer segBegin, candA, candB, lists, sortTemp;
     std::vector<uint32_t> hostSeg;
-    uint32_t batchBegin = 0;
+    uint32_t batchBegin = rowBegin;
     const uint32_t idBits = bitsFor(cellCount - 1u);
-    while (batchBegin < cellCount) {
+    while (batchBegin < rowEnd) {
         uint64_t sum = 0;
         uint32_t batchEnd = batchBegin;
         hostSeg.assign(1, 0u);
-        while (batchEnd < cellCount && batchEnd - batchBegin < (1u << 20)) {
+        while (batchEnd < rowEnd && batchEnd - batchBegin < (1u << 20)) {
             const uint64_t n = hostCounts[batchEnd];
             if (n >= 0xffffffffULL) return hipErrorInvalidValue;
             if (sum + n > budget && batchEnd > batchBegin) break;
@@ -356,7 +359,7 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t lshCount,
         }
         filterSelectKernel<<<batchCells, 64, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
                                                           lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch, tables.keySimilarity, k,
-                                                          d_pairs + size_t(batchBegin) * k, d_used + batchBegin);
+                                                          d_pairs + size_t(batchBegin - rowBegin) * k, d_used + (batchBegin - rowBegin));
         EM2_TRY(hipGetLastError());
         EM2_TRY(hipStreamSynchronize(stream));       // hostSeg / scratch are reused by the next batch
         batchBegin = batchEnd;

@@ -128,6 +128,15 @@ int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount
                                 em2_pair* d_pairs, uint32_t* d_usedCount, void* d_workspace,
                                 size_t workspaceBytes, void* stream);
 
+/* findSimilarPairs5 for the cells [rowBegin,rowEnd) of the cell set (the bucket tables are built over all
+ * cellCount signatures, which every rank holds after the all-gather).  Unlike the other dev entry points this one
+ * sizes its scratch from the data (bucket sizes are only known after the sort), so it allocates and frees device
+ * memory itself and returns after synchronising the stream. */
+int em2_dev_find_similar_pairs5(const uint64_t* d_signatures, uint32_t cellCount, uint32_t rowBegin,
+                                uint32_t rowEnd, uint32_t lshCount, uint32_t k, double similarityThreshold,
+                                uint32_t lshSliceLength, uint64_t bucketOverflow, em2_pair* d_pairs,
+                                uint32_t* d_usedCount, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * ExpressionMatrix-level entry points: the methods the reference binds to Python (src/PythonModule.cpp),
  * operating by NAME on a data directory in the reference's memory-mapped formats.  Results are files in

@@ -374,6 +374,53 @@ int em2o_find_similar_pairs5(
 }
 
 
+// findSimilarPairs5 for the cells [rowBegin,rowEnd) only (tables over all cells): the checker for shards and for
+// sampled cells of problems too large to run in full.  Same code path as above per cell.
+int em2o_find_similar_pairs5_rows(
+    const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount,
+    uint32_t k, double similarityThreshold, uint32_t lshSliceLength, uint64_t bucketOverflow,
+    uint32_t rowBegin, uint32_t rowEnd, uint32_t* outCell, float* outSim, uint32_t* outUsed)
+{
+    if (lshSliceLength == 0 || lshSliceLength > 30) return 1;
+    const size_t W = (size_t(lshCount) - 1) / 64 + 1;
+    std::vector<double> table;
+    similarityTable(lshCount, table);
+    const size_t sliceCount = size_t(lshCount) / lshSliceLength;
+    std::vector< std::vector< std::vector<CellId> > > tables(sliceCount);
+    for (size_t s = 0; s < sliceCount; s++) {
+        tables[s].resize(1ULL << lshSliceLength);
+        for (CellId c = 0; c < cellCount; c++) {
+            tables[s][getBitsRange(signatures + size_t(c) * W, s * lshSliceLength, lshSliceLength)].push_back(c);
+        }
+    }
+    std::vector< std::vector<Pair> > tmp(rowEnd - rowBegin);
+    std::vector<CellId> candidates;
+    std::vector<Pair> cellNeighbors;
+    for (CellId c0 = rowBegin; c0 < rowEnd; c0++) {
+        candidates.clear();
+        for (size_t s = 0; s < sliceCount; s++) {
+            const std::vector<CellId>& bucket =
+                tables[s][getBitsRange(signatures + size_t(c0) * W, s * lshSliceLength, lshSliceLength)];
+            if (bucketOverflow == 0 || bucket.size() <= bucketOverflow) {
+                candidates.insert(candidates.end(), bucket.begin(), bucket.end());
+            }
+        }
+        std::sort(candidates.begin(), candidates.end());
+        candidates.erase(std::unique(candidates.begin(), candidates.end()), candidates.end());
+        cellNeighbors.clear();
+        for (const CellId c1 : candidates) {
+            if (c1 == c0) continue;
+            const double similarity = table[countMismatches(signatures + size_t(c0) * W, signatures + size_t(c1) * W, W)];
+            if (similarity > similarityThreshold) cellNeighbors.push_back(std::make_pair(c1, float(similarity)));
+        }
+        keepBest(cellNeighbors, k);
+        tmp[c0 - rowBegin] = cellNeighbors;
+    }
+    storeAndSort(tmp, k, outCell, outSim, outUsed);
+    return 0;
+}
+
+
 // keepBest on caller data (heap.hpp:116-126 with OrderPairsBySecondGreater); n pairs in, returns new size.
 uint32_t em2o_keep_best(uint32_t* cell, float* sim, uint32_t n, uint32_t k)
 {

@@ -41,6 +41,9 @@ class Oracle:
         lib.em2o_find_similar_pairs5.argtypes = [P, c.c_uint32, c.c_uint32, c.c_uint32, c.c_double, c.c_uint32,
                                                  c.c_uint64, P, P, P]
         lib.em2o_find_similar_pairs5.restype = c.c_int
+        lib.em2o_find_similar_pairs5_rows.argtypes = [P, c.c_uint32, c.c_uint32, c.c_uint32, c.c_double, c.c_uint32,
+                                                      c.c_uint64, c.c_uint32, c.c_uint32, P, P, P]
+        lib.em2o_find_similar_pairs5_rows.restype = c.c_int
         lib.em2o_keep_best.argtypes = [P, P, c.c_uint32, c.c_uint32]
         lib.em2o_keep_best.restype = c.c_uint32
         lib.em2o_multiple_set_union.argtypes = [P, P, c.c_uint32, P]
@@ -104,6 +107,19 @@ class Oracle:
         used = np.zeros(n, dtype=np.uint32)
         rc = self.lib.em2o_find_similar_pairs5(_ptr(sig), n, lsh_count, k, thr, slice_length, bucket_overflow,
                                                _ptr(cell), _ptr(sim), _ptr(used))
+        if rc != 0:
+            raise ValueError("oracle fsp5 rejected the arguments")
+        return cell, sim, used
+
+    def find_similar_pairs5_rows(self, sig, lsh_count, k, thr, slice_length, bucket_overflow, row_begin, row_end):
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        rows = row_end - row_begin
+        cell = np.zeros((rows, k), dtype=np.uint32)
+        sim = np.zeros((rows, k), dtype=np.float32)
+        used = np.zeros(rows, dtype=np.uint32)
+        rc = self.lib.em2o_find_similar_pairs5_rows(_ptr(sig), sig.shape[0], lsh_count, k, thr, slice_length,
+                                                    bucket_overflow, row_begin, row_end, _ptr(cell), _ptr(sim),
+                                                    _ptr(used))
         if rc != 0:
             raise ValueError("oracle fsp5 rejected the arguments")
         return cell, sim, used

@@ -87,3 +87,21 @@ def test_fsp5_through_expression_matrix_api(oracle, tmp_path):
     assert k2 == 12 and np.array_equal(u2, used) and np.array_equal(pairs["cell"], cell)
     assert np.array_equal(pairs["similarity"].view(np.uint32), sim.view(np.uint32))
     assert used.sum() > 0
+
+
+def test_fsp5_row_shard_through_device_api(oracle):
+    import torch
+    n, L, k, thr, q, ovf = 2500, 1024, 15, 0.2, 12, 1000
+    sig = synth.clustered_signatures(n, L, cluster_count=6, flip=0.08, seed=77)
+    d_sig = torch.from_numpy(sig.view(np.int64)).cuda()
+    for begin, end in [(0, 900), (900, 901), (901, 2500)]:
+        rows = end - begin
+        d_pairs = torch.zeros((rows, k, 2), dtype=torch.int32, device="cuda")
+        d_used = torch.zeros(rows, dtype=torch.int32, device="cuda")
+        capi.dev_find_similar_pairs5(d_sig.data_ptr(), n, begin, end, L, k, thr, q, ovf, d_pairs.data_ptr(),
+                                     d_used.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        cell, sim, used = oracle.find_similar_pairs5_rows(sig, L, k, thr, q, ovf, begin, end)
+        p = d_pairs.cpu().numpy().view(np.uint32)
+        assert np.array_equal(d_used.cpu().numpy().view(np.uint32), used)
+        assert np.array_equal(p[:, :, 0], cell) and np.array_equal(p[:, :, 1], sim.view(np.uint32))

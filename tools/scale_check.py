@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Scale checks on a real MI355X (not part of pytest: minutes of GPU time, GBs of memory).
+
+    python3 tools/scale_check.py fsp5   # BASELINE configs[3] shape: 1M cells, 2048 bit, lshSliceLength 20
+    python3 tools/scale_check.py fsp4w  # findSimilarPairs4 at 2048 bit, 200k cells
+
+Signatures are synthetic (64 cluster centres, each bit flipped with probability 0.15), generated in HBM with
+torch.  Sampled cells are compared bit-for-bit with the CPU oracle; timings are printed as JSON."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_binding  # noqa: E402
+from expressionmatrix2_amd import capi  # noqa: E402
+
+
+def clustered_signatures_gpu(cells, lsh_count, clusters=64, flip=0.15, seed=1):
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    words = (lsh_count - 1) // 64 + 1
+    centre = torch.randint(0, 2, (clusters, words * 64), generator=gen, device="cuda", dtype=torch.uint8)
+    cluster = torch.randint(0, clusters, (cells,), generator=gen, device="cuda")
+    out = torch.empty((cells, words), dtype=torch.int64, device="cuda")
+    weights = (1 << torch.arange(63, -1, -1, device="cuda", dtype=torch.int64))       # first bit most significant
+    for begin in range(0, cells, 65536):
+        end = min(cells, begin + 65536)
+        bits = centre[cluster[begin:end]] ^ (torch.rand((end - begin, words * 64), generator=gen, device="cuda") < flip).to(torch.uint8)
+        bits[:, lsh_count:] = 0
+        out[begin:end] = (bits.view(end - begin, words, 64).to(torch.int64) * weights).sum(dim=2)
+    return out
+
+
+def compare(pairs_dev, used_dev, cell, sim, used, rows):
+    p = pairs_dev[rows].cpu().numpy().view(np.uint32)
+    u = used_dev[rows].cpu().numpy().view(np.uint32)
+    return bool(np.array_equal(u, used) and np.array_equal(p[:, :, 0], cell) and np.array_equal(p[:, :, 1], sim.view(np.uint32)))
+
+
+def main():
+    what = sys.argv[1]
+    oracle = oracle_binding.load_oracle()
+    capi.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    if what == "fsp5":
+        cells, L, k, thr, q, ovf = int(os.environ.get("CELLS", 1000000)), 2048, 100, 0.2, 20, 1000
+        sig = clustered_signatures_gpu(cells, L)
+        d_pairs = torch.zeros((cells, k, 2), dtype=torch.int32, device="cuda")
+        d_used = torch.zeros(cells, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        capi.dev_find_similar_pairs5(sig.data_ptr(), cells, 0, cells, L, k, thr, q, ovf, d_pairs.data_ptr(),
+                                     d_used.data_ptr(), stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        host = sig.cpu().numpy().view(np.uint64)
+        begin = cells // 3
+        t1 = time.perf_counter()
+        cell, sim, used = oracle.find_similar_pairs5_rows(host, L, k, thr, q, ovf, begin, begin + 32)
+        t_oracle = time.perf_counter() - t1
+        ok = compare(d_pairs, d_used, cell, sim, used, slice(begin, begin + 32))
+        u = d_used.cpu().numpy()
+        print(json.dumps({"check": "fsp5", "cells": cells, "lsh_count": L, "lsh_slice_length": q, "k": k,
+                          "gpu_seconds": dt, "cells_with_k_neighbours": int((u == k).sum()),
+                          "mean_used": float(u.mean()), "sampled_rows_bit_exact": ok,
+                          "oracle_seconds_for_32_rows_incl_tables": t_oracle}))
+        if not ok:
+            raise SystemExit("PARITY FAILURE")
+    elif what == "fsp4w":
+        cells, L, k, thr = int(os.environ.get("CELLS", 200000)), 2048, 100, 0.2
+        sig = clustered_signatures_gpu(cells, L)
+        ws_bytes = capi.dev_find_similar_pairs4_workspace(cells, cells, L, k)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+        d_pairs = torch.zeros((cells, k, 2), dtype=torch.int32, device="cuda")
+        d_used = torch.zeros(cells, dtype=torch.int32, device="cuda")
+        times = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            capi.dev_find_similar_pairs4(sig.data_ptr(), cells, 0, cells, L, k, thr, d_pairs.data_ptr(),
+                                         d_used.data_ptr(), ws.data_ptr(), ws_bytes, stream)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        host = sig.cpu().numpy().view(np.uint64)
+        begin = cells // 2
+        cell, sim, used = oracle.find_similar_pairs4_rows(host, L, k, thr, begin, begin + 32)
+        ok = compare(d_pairs, d_used, cell, sim, used, slice(begin, begin + 32))
+        print(json.dumps({"check": "fsp4 2048-bit", "cells": cells, "seconds": min(times),
+                          "ordered_comparisons_per_s": cells * cells / min(times), "sampled_rows_bit_exact": ok}))
+        if not ok:
+            raise SystemExit("PARITY FAILURE")
+
+
+if __name__ == "__main__":
+    main()
