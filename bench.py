@@ -166,6 +166,18 @@ def main():
     lane_ops = pipe.rows * float(C) * 4.0 * W          # (v_xor + v_bcnt) per 32 bits per ordered comparison
     valu_frac = lane_ops / (scan_ms * 1e-3) / VALU_LANE_OPS_PER_S if scan_ms else 0.0
 
+    # HBM-side traffic of one scan launch from the PMC counters, when a profile of THIS configuration has been
+    # collected (rocprofv3 --pmc runs are separate from timing runs; see the file for the command and caveats).
+    traffic = None
+    traffic_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_1Mcells.json")
+    if os.path.exists(traffic_file):
+        with open(traffic_file) as f:
+            prof = json.load(f)
+        cfg = prof.get("config", {})
+        if (cfg.get("cells"), cfg.get("genes"), cfg.get("lsh_count"), cfg.get("k"), cfg.get("n_gpus")) == (C, G, L, k, world):
+            t = prof["per_launch_bytes"]["fsp4ScanKernel"]
+            traffic = t["fetch"] + t["write"]
+
     result = {
         "metric": "cell-pair Hamming comparisons/sec (whole node), findSimilarPairs4 incl. signature projection",
         "value": value,
@@ -194,7 +206,10 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": "profiles/r01_pmc_hbm_traffic_1Mcells.json (FETCH_SIZE+WRITE_SIZE, bytes per launch)"
+                              if traffic is not None else None,
+            "algorithmic_bytes": algorithmic_bytes,
             "valu_frac": valu_frac,
             "note": "algorithmic bytes = 16*W per unordered pair; operands are cache/SGPR resident so frac is not "
                     "bounded by 1; valu_frac = (v_xor+v_bcnt lane-ops)/(256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz), the measured issue rate of these ops",
