@@ -149,6 +149,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    pipe.check()                 # the scan's inter-wave hand-offs all completed (raises otherwise)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -49,6 +49,7 @@ SYMBOLS = {
     "em2_dev_find_similar_pairs4": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                                _c.c_uint32, _c.c_double, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                _c.c_size_t, _c.c_void_p]),
+    "em2_dev_find_similar_pairs4_status": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p]),
     "em2_dev_find_similar_pairs5": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                                _c.c_uint32, _c.c_double, _c.c_uint32, _c.c_uint64, _c.c_void_p,
                                                _c.c_void_p, _c.c_void_p]),
@@ -218,6 +219,11 @@ def dev_find_similar_pairs4(sig_ptr, cell_count, row_begin, row_end, lsh_count, 
     check(load().em2_dev_find_similar_pairs4(sig_ptr, cell_count, row_begin, row_end, lsh_count, k,
                                              similarity_threshold, pairs_ptr, used_ptr, workspace_ptr,
                                              workspace_bytes, stream))
+
+
+def dev_find_similar_pairs4_status(workspace_ptr, row_count, k, stream):
+    """Synchronises the stream; raises if the scan reported an incomplete hand-off."""
+    check(load().em2_dev_find_similar_pairs4_status(workspace_ptr, row_count, k, stream))
 
 
 def dev_find_similar_pairs5(sig_ptr, cell_count, row_begin, row_end, lsh_count, k, similarity_threshold,

@@ -96,6 +96,7 @@ int getDeviceTables(uint32_t lshCount, double similarityThreshold, em2::DeviceTa
     c.tables.keySimilarity = reinterpret_cast<const float*>(base + bytes0 + bytes1);
     c.tables.mGlobal = host.mGlobal;
     c.tables.mMaxInitial = host.mMaxInitial;
+    c.tables.identityKeys = host.keySimilarity.size() == host.keyOfMismatch.size();
     tableCache.push_back(c);
     out = c.tables;
     return EM2_OK;
@@ -257,6 +258,7 @@ size_t em2_dev_find_similar_pairs4_workspace(uint32_t cellCount, uint32_t rowCou
     const uint32_t padded = em2::paddedDwords(lshCount);
     size_t bytes = alignUp(size_t(rowCount) * 2u * k * sizeof(em2::Entry));
     if (padded != 2u * wordCountOf(lshCount)) bytes += alignUp(size_t(cellCount) * padded * sizeof(uint32_t));
+    bytes += alignUp(em2::fsp4ControlBytes(rowCount));
     return bytes + 256;
 }
 
@@ -288,6 +290,8 @@ int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount
     char* ws = reinterpret_cast<char*>(alignUp(reinterpret_cast<size_t>(d_workspace)));
     em2::Entry* buffers = reinterpret_cast<em2::Entry*>(ws);
     ws += alignUp(size_t(rows) * 2u * k * sizeof(em2::Entry));
+    void* control = ws;
+    ws += alignUp(em2::fsp4ControlBytes(rows));
     const uint32_t words = wordCountOf(lshCount);
     const uint32_t* sig32 = reinterpret_cast<const uint32_t*>(d_signatures);
     if (padded != 2u * words) {
@@ -296,7 +300,20 @@ int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount
         sig32 = repacked;
     }
     EM2_HIP(em2::launchFsp4Scan(sig32, padded, cellCount, rowBegin, rowEnd, k, tables, buffers,
-                                reinterpret_cast<em2::PairOut*>(d_pairs), d_usedCount, s));
+                                reinterpret_cast<em2::PairOut*>(d_pairs), d_usedCount, control, s));
+    return EM2_OK;
+}
+
+
+int em2_dev_find_similar_pairs4_status(const void* d_workspace, uint32_t rowCount, uint32_t k, void* stream)
+{
+    if (!d_workspace) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs4_status: null workspace");
+    if (rowCount == 0 || k == 0) return EM2_OK;
+    const char* ws = reinterpret_cast<const char*>(alignUp(reinterpret_cast<size_t>(d_workspace)));
+    ws += alignUp(size_t(rowCount) * 2u * k * sizeof(em2::Entry));
+    uint32_t error = 0;
+    EM2_HIP(em2::readFsp4Error(ws, rowCount, static_cast<hipStream_t>(stream), &error));
+    if (error) return fail(EM2_ERROR_RUNTIME, "findSimilarPairs4: a segment hand-off between waves timed out; the result is incomplete");
     return EM2_OK;
 }
 

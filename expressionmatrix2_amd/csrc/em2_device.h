@@ -28,6 +28,7 @@ struct DeviceTables {
     const float* keySimilarity;      // [keyCount]
     int32_t mGlobal;
     int32_t mMaxInitial;
+    bool identityKeys;               // keyOfMismatch[m] == m for every m
 };
 
 // Signature words per cell padded to a supported kernel width (in 32-bit words); 0 if lshCount is too large.
@@ -44,9 +45,14 @@ uint32_t fsp4MaxK();
 //   sig32    [cellCount][paddedDw] device
 //   buffers  [(rowEnd-rowBegin)][2k] Entry, device scratch
 //   outPairs [(rowEnd-rowBegin)][k], outUsed [(rowEnd-rowBegin)]
+//   control  fsp4ControlBytes(rows) bytes of device scratch for the persistent kernel's hand-off state (NULL
+//            selects the simple one-wave-per-row-block kernel)
 hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cellCount,
                           uint32_t rowBegin, uint32_t rowEnd, uint32_t k, const DeviceTables& tables,
-                          Entry* buffers, PairOut* outPairs, uint32_t* outUsed, hipStream_t stream);
+                          Entry* buffers, PairOut* outPairs, uint32_t* outUsed, void* control,
+                          hipStream_t stream);
+size_t fsp4ControlBytes(uint32_t rowCount);
+hipError_t readFsp4Error(const void* control, uint32_t rowCount, hipStream_t stream, uint32_t* error);
 
 // ExpressionMatrixSubset::computeSums (sum1 only) -> mean = sum1 / geneCount, per cell.
 hipError_t launchCellMeans(const uint64_t* toc, const CountIn* data, uint32_t cellCount, uint32_t geneCount,

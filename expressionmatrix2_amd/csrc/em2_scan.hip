@@ -75,6 +75,14 @@ struct Fsp4Args {
     uint32_t rowBegin;
     uint32_t rowEnd;
     uint32_t pad;
+    // persistent (segment-chained) variant only
+    uint32_t* rowState;         // [rowBlocks*64][2] = {count, mMax} handed from one column segment to the next
+    uint32_t* segmentsDone;     // [rowBlocks] number of finished column segments of the row block
+    uint32_t* control;          // [0] ticket counter, [1] error flag
+    uint32_t rowBlocks;
+    uint32_t segments;
+    uint32_t columnsPerSegment;
+    uint32_t pad2;
 };
 
 typedef const __attribute__((address_space(4))) Fsp4Args* ArgsPtr;
@@ -106,20 +114,26 @@ __device__ __attribute__((noinline)) uint32_t cutListToBest(Entry* lds, Entry* g
 
 // ---- rare path: some row of this wave accepts column `col` (mismatch count m in each lane) ----
 // Appends {col, key(m)} to the lists of the passing lanes, then cuts every list that reached 2k.
+// The append itself touches no kernel argument and waits for nothing (one address computation + one store);
+// only a list reaching 2k goes to the kernarg segment.  IDENTITY: float similarities of different mismatch
+// counts are all different (true for every lshCount <= 4096 with glibc's cos; checked on the host), so the rank
+// key of a mismatch count is the mismatch count itself and no table lookup is needed.
+template <bool IDENTITY>
 __device__ __forceinline__ void acceptColumn(bool pass, uint32_t col, uint32_t row, uint32_t m, uint32_t lane,
-                                             uint32_t waveIndex, uint32_t& count, int32_t& mMax,
-                                             unsigned char* ldsRaw)
+                                             uint32_t listBlock, Entry* myList, uint32_t twoK, uint32_t& count,
+                                             int32_t& mMax, unsigned char* ldsRaw)
 {
-    ArgsPtr aux = kernelArgs();
-    const uint32_t k = aux->k;
-    const uint32_t twoK = 2u * k;
-    Entry* const waveBuffers = aux->buffers + size_t(waveIndex) * 64u * twoK;
     if (pass && col != row) {
-        storeEntry(waveBuffers + size_t(lane) * twoK + count, col, aux->keyOfMismatch[m]);
+        uint32_t key = m;
+        if (!IDENTITY) key = kernelArgs()->keyOfMismatch[m];
+        storeEntry(myList + count, col, key);
         ++count;
     }
     uint64_t full = __builtin_amdgcn_ballot_w64(count == twoK);
     if (full != 0ull) {
+        ArgsPtr aux = kernelArgs();
+        const uint32_t k = aux->k;
+        Entry* const waveBuffers = aux->buffers + size_t(listBlock) * 64u * twoK;
         Entry* lds = reinterpret_cast<Entry*>(ldsRaw) + size_t(threadIdx.x >> 6) * twoK;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         do {
@@ -127,7 +141,8 @@ __device__ __forceinline__ void acceptColumn(bool pass, uint32_t col, uint32_t r
             full &= full - 1ull;
             Entry* g = waveBuffers + size_t(src) * twoK;
             const uint32_t backKey = cutListToBest(lds, g, twoK, k, lane, true);
-            const int32_t newMax = aux->acceptMaxByKey[backKey];
+            // readfirstlane: the table load completes HERE, so the scan loop never has to wait on vector memory
+            const int32_t newMax = __builtin_amdgcn_readfirstlane(aux->acceptMaxByKey[backKey]);
             if (lane == src) {
                 count = k;
                 mMax = newMax;
@@ -202,7 +217,7 @@ __device__ __forceinline__ void finishRows(uint32_t lane, uint32_t waveIndex, ui
 //     broadcast with DPP row_newbcast -- was built and measured as well: v_xor_b32_dpp is slower than the
 //     SGPR-operand form on gfx950 and the kernel came out 5% slower; removed.
 // =========================================================================================================
-template <int W32, int R>
+template <int W32, int R, bool IDENTITY>
 __global__ void __launch_bounds__(256)
 fsp4ScanKernel(Fsp4Args args)
 {
@@ -221,13 +236,18 @@ fsp4ScanKernel(Fsp4Args args)
     uint32_t r[R][W32];         // their signatures
     int32_t mMax[R];
     uint32_t count[R];
+    Entry* myList[R];           // their candidate lists
+    uint32_t twoK;
     {
         ArgsPtr aux = kernelArgs();
         const uint32_t waveRowBase = aux->rowBegin + waveIndex * (64u * R);
         if (waveRowBase >= aux->rowEnd) return;
+        twoK = 2u * aux->k;
+        asm volatile("" : "+v"(twoK));      // keep it in a VGPR: the scan loop is short of SGPRs, not VGPRs
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             row[j] = waveRowBase + 64u * j + lane;
+            myList[j] = aux->buffers + (size_t(waveIndex * R + j) * 64u + lane) * twoK;
             const bool rowValid = row[j] < aux->rowEnd;
             const uint32_t* rp = sig32 + size_t(rowValid ? row[j] : waveRowBase) * W32;
 #pragma unroll
@@ -256,7 +276,7 @@ fsp4ScanKernel(Fsp4Args args)
                 // one so that its latency is covered by this step's 2*CH*R vector instructions.
                 __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
                 __builtin_amdgcn_sched_barrier(0);
-                const bool lastChunk = (col == cellCount - 1u) && (part == H - 1);
+                const bool lastChunk = (col + 1u == cellCount) && (part == H - 1);
                 ScalarPtr pn = lastChunk ? p : p + CH;
 #pragma unroll
                 for (int w = 0; w < CH; ++w) chunk[(s + 1) & 1][w] = pn[w];
@@ -278,8 +298,8 @@ fsp4ScanKernel(Fsp4Args args)
                         for (int j = 0; j < R; ++j) {
                             const bool pass = int32_t(m[j]) <= mMax[j];
                             if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
-                                acceptColumn(pass, col, row[j], m[j], lane, waveIndex * R + j, count[j], mMax[j],
-                                             ldsRaw);
+                                acceptColumn<IDENTITY>(pass, col, row[j], m[j], lane, waveIndex * R + j, myList[j],
+                                                       twoK, count[j], mMax[j], ldsRaw);
                             }
                         }
                     }
@@ -291,6 +311,154 @@ fsp4ScanKernel(Fsp4Args args)
     }
 #pragma unroll
     for (int j = 0; j < R; ++j) finishRows(lane, waveIndex * R + j, count[j], ldsRaw);
+}
+
+// =========================================================================================================
+// Persistent, segment-chained form of the same scan.
+//
+// Problem it solves (measured): a wave of fsp4ScanKernel owns 64 rows for ALL columns, so the grid is
+// rows/64 equal, indivisible work items.  At 1M rows that is 15625 waves on 5120 resident slots: three full
+// rounds and a fourth with 265 waves that run alone for a full wave lifetime (+9.5% wall); at 100k rows 1563
+// waves on 1024 SIMDs leave half the SIMDs with one wave and half with two (+80% over balanced).
+//
+// Here the columns are cut into S segments and a work item is (segment s, row block b).  Resident waves take
+// items from one ticket counter in segment-major order (t -> s = t / B, b = t % B), so all row blocks advance
+// together and the tail is one segment, not one whole scan.  The per-cell contract needs block b's segments in
+// order: item (s,b) starts after item (s-1,b) has published its state -- per-row {count,mMax} plus the row
+// lists it appended in HBM -- with an agent-scope release; the consumer polls segmentsDone[b] and acquires
+// (cdna_hip_programming.md, Guideline 16: stores, vmcnt(0), release fence, flag; poll, acquire fence, loads).
+// No deadlock: item (s-1,b) holds a lower ticket, tickets are only taken by running waves, and the chain ends
+// at s = 0 which waits for nothing.  Spins are bounded (~4 s) and raise an error flag instead of hanging.
+// =========================================================================================================
+template <int W32, bool IDENTITY>
+__global__ void __launch_bounds__(256)
+fsp4ScanPersistentKernel(Fsp4Args args)
+{
+    constexpr int CH = W32 < 32 ? W32 : 32;
+    constexpr int H = W32 / CH;
+    constexpr int U = H < 2 ? 2 : H;
+    constexpr int COLS = U / H;
+    const uint32_t* __restrict__ sig32 = args.sig32;
+    const uint32_t cellCount = args.cellCount;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    const uint32_t lane = threadIdx.x & 63u;
+
+    for (;;) {
+        // ---- take the next work item ----
+        uint32_t ticket = 0;
+        if (lane == 0u) {
+            ticket = __hip_atomic_fetch_add(kernelArgs()->control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ticket = uint32_t(__builtin_amdgcn_readfirstlane(int(ticket)));
+        uint32_t colBegin, colEnd, row;
+        uint32_t r[W32];
+        int32_t mMax;
+        uint32_t count;
+        Entry* myList;
+        uint32_t twoK;
+        {
+            ArgsPtr aux = kernelArgs();
+            const uint32_t rowBlocks = aux->rowBlocks;
+            if (ticket >= rowBlocks * aux->segments) return;
+            const uint32_t seg = ticket / rowBlocks;
+            const uint32_t block = ticket - seg * rowBlocks;
+            twoK = 2u * aux->k;
+            myList = aux->buffers + (size_t(block) * 64u + lane) * twoK;
+            asm volatile("" : "+v"(twoK));  // keep it in a VGPR: the scan loop is short of SGPRs, not VGPRs
+            colBegin = seg * aux->columnsPerSegment;
+            colEnd = colBegin + aux->columnsPerSegment;
+            if (colEnd > cellCount || seg + 1u == aux->segments) colEnd = cellCount;
+            row = aux->rowBegin + block * 64u + lane;
+            const bool rowValid = row < aux->rowEnd;
+            const uint32_t* rp = sig32 + size_t(rowValid ? row : aux->rowBegin + block * 64u) * W32;
+#pragma unroll
+            for (int w = 0; w < W32; ++w) r[w] = rp[w];
+            mMax = rowValid ? args.mMaxInitial : -1;
+            count = 0;
+            if (seg != 0u) {
+                // ---- wait for the previous segment of this row block, then take over its state ----
+                const uint32_t* flag = aux->segmentsDone + block;
+                uint32_t error = 0;
+                const uint64_t start = __builtin_amdgcn_s_memrealtime();         // 100 MHz
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (__builtin_amdgcn_s_memrealtime() - start > 400000000ull) {
+                        error = 1;
+                        break;
+                    }
+                }
+                if (error) {
+                    if (lane == 0u) __hip_atomic_store(aux->control + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const uint64_t st = __hip_atomic_load(reinterpret_cast<const uint64_t*>(aux->rowState) + size_t(block) * 64u + lane,
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                count = uint32_t(st);
+                mMax = rowValid ? int32_t(uint32_t(st >> 32)) : -1;
+            }
+        }
+
+        // ---- scan columns [colBegin, colEnd) exactly like fsp4ScanKernel ----
+        ScalarPtr p = (ScalarPtr)(uintptr_t)sig32 + size_t(colBegin) * W32;
+        uint32_t chunk[2][CH];
+#pragma unroll
+        for (int w = 0; w < CH; ++w) chunk[0][w] = p[w];
+        __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
+        uint32_t m = 0;
+        for (uint32_t colBase = colBegin; colBase < colEnd; colBase += COLS) {
+#pragma unroll
+            for (int s = 0; s < U; ++s) {
+                const int part = s % H;
+                const uint32_t col = colBase + uint32_t(s / H);
+                if (col < colEnd) {
+                    __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bool lastChunk = (col + 1u == colEnd) && (part == H - 1);
+                    ScalarPtr pn = lastChunk ? p : p + CH;
+#pragma unroll
+                    for (int w = 0; w < CH; ++w) chunk[(s + 1) & 1][w] = pn[w];
+                    p = pn;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int w = 0; w < CH; ++w) {
+                        m += uint32_t(__builtin_popcount(r[part * CH + w] ^ chunk[s & 1][w]));
+                    }
+                    if (part == H - 1) {
+                        const bool pass = int32_t(m) <= mMax;
+                        if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                            // the row block is recomputed from the ticket here: keeping it live across the
+                            // loop cost SGPR spills inside the loop
+                            acceptColumn<IDENTITY>(pass, col, row, m, lane, ticket % kernelArgs()->rowBlocks, myList, twoK,
+                                                   count, mMax, ldsRaw);
+                        }
+                        m = 0;
+                    }
+                }
+            }
+        }
+
+        // ---- last segment: finish the rows; otherwise publish the state for the next segment ----
+        {
+            ArgsPtr aux = kernelArgs();
+            const uint32_t seg = ticket / aux->rowBlocks;
+            const uint32_t block = ticket - seg * aux->rowBlocks;
+            if (seg + 1u == aux->segments) {
+                finishRows(lane, block, count, ldsRaw);
+            } else {
+                const uint64_t st = uint64_t(count) | (uint64_t(uint32_t(mMax)) << 32);
+                __hip_atomic_store(reinterpret_cast<uint64_t*>(aux->rowState) + size_t(block) * 64u + lane, st,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0u) {
+                    __hip_atomic_store(aux->segmentsDone + block, seg + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
 }
 
 __global__ void repackSignaturesKernel(const uint64_t* __restrict__ src, uint32_t cellCount, uint32_t wordCount,
@@ -346,9 +514,24 @@ hipError_t launchRepackSignatures(const uint64_t* src, uint32_t cellCount, uint3
     return hipGetLastError();
 }
 
+size_t fsp4ControlBytes(uint32_t rowCount)
+{
+    const size_t rowBlocks = (size_t(rowCount) + 63u) / 64u;
+    // rowState (8 B per row of every block) + segmentsDone (4 B per block) + control words, each 256-aligned
+    return ((rowBlocks * 64u * 8u + 255u) & ~size_t(255u)) + ((rowBlocks * 4u + 255u) & ~size_t(255u)) + 256u;
+}
+
+// EM2_SCAN_MODE=simple selects the one-wave-per-row-block kernel (A/B measurements); default is the persistent
+// segment-chained kernel.
+static bool scanModeIsSimple()
+{
+    const char* v = getenv("EM2_SCAN_MODE");
+    return v && v[0] == 's';
+}
+
 hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cellCount, uint32_t rowBegin,
                           uint32_t rowEnd, uint32_t k, const DeviceTables& t, Entry* buffers, PairOut* outPairs,
-                          uint32_t* outUsed, hipStream_t stream)
+                          uint32_t* outUsed, void* control, hipStream_t stream)
 {
     if (rowEnd <= rowBegin) return hipSuccess;
     if (k == 0 || k > fsp4MaxK()) return hipErrorInvalidValue;
@@ -356,14 +539,9 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     uint32_t wavesPerBlock = kLdsBytesPerBlock / bytesPerWave;
     if (wavesPerBlock > 4) wavesPerBlock = 4;
     const uint32_t rows = rowEnd - rowBegin;
-    uint32_t rowsPerLane = forcedRowsPerLane();
-    if (rowsPerLane == 0 || paddedDw >= 128) rowsPerLane = 1;
-    const uint32_t waves = (rows + 64u * rowsPerLane - 1u) / (64u * rowsPerLane);
-    if (wavesPerBlock > waves) wavesPerBlock = waves;
-    const dim3 grid((waves + wavesPerBlock - 1u) / wavesPerBlock);
-    const dim3 block(64u * wavesPerBlock);
-    const size_t lds = size_t(wavesPerBlock) * bytesPerWave;
+    const uint32_t rowBlocks = (rows + 63u) / 64u;
 
+    const bool identity = t.identityKeys;
     Fsp4Args args;
     args.sig32 = sig32;
     args.cellCount = cellCount;
@@ -378,26 +556,118 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     args.rowBegin = rowBegin;
     args.rowEnd = rowEnd;
     args.pad = 0;
+    args.rowState = nullptr;
+    args.segmentsDone = nullptr;
+    args.control = nullptr;
+    args.rowBlocks = rowBlocks;
+    args.segments = 1;
+    args.columnsPerSegment = cellCount;
+    args.pad2 = 0;
 
-#define EM2_LAUNCH_SCAN(W32, RR) fsp4ScanKernel<W32, RR><<<grid, block, lds, stream>>>(args)
+    if (scanModeIsSimple() || !control) {
+        uint32_t rowsPerLane = forcedRowsPerLane();
+        if (rowsPerLane == 0 || paddedDw >= 128) rowsPerLane = 1;
+        const uint32_t waves = (rows + 64u * rowsPerLane - 1u) / (64u * rowsPerLane);
+        if (wavesPerBlock > waves) wavesPerBlock = waves;
+        const dim3 grid((waves + wavesPerBlock - 1u) / wavesPerBlock);
+        const dim3 block(64u * wavesPerBlock);
+        const size_t lds = size_t(wavesPerBlock) * bytesPerWave;
+#define EM2_LAUNCH_SCAN(W32, RR)                                                          \
+    do {                                                                                  \
+        if (identity) fsp4ScanKernel<W32, RR, true><<<grid, block, lds, stream>>>(args);  \
+        else fsp4ScanKernel<W32, RR, false><<<grid, block, lds, stream>>>(args);          \
+    } while (0)
 #define EM2_LAUNCH_SCAN_R(W32)                                  \
     do {                                                        \
         if (rowsPerLane == 2) EM2_LAUNCH_SCAN(W32, 2);          \
         else EM2_LAUNCH_SCAN(W32, 1);                           \
     } while (0)
-    switch (paddedDw) {
-    case 2: EM2_LAUNCH_SCAN(2, 1); break;
-    case 4: EM2_LAUNCH_SCAN(4, 1); break;
-    case 8: EM2_LAUNCH_SCAN(8, 1); break;
-    case 16: EM2_LAUNCH_SCAN(16, 1); break;
-    case 32: EM2_LAUNCH_SCAN_R(32); break;
-    case 64: EM2_LAUNCH_SCAN_R(64); break;
-    case 128: EM2_LAUNCH_SCAN(128, 1); break;
-    default: return hipErrorInvalidValue;
-    }
+        switch (paddedDw) {
+        case 2: EM2_LAUNCH_SCAN(2, 1); break;
+        case 4: EM2_LAUNCH_SCAN(4, 1); break;
+        case 8: EM2_LAUNCH_SCAN(8, 1); break;
+        case 16: EM2_LAUNCH_SCAN(16, 1); break;
+        case 32: EM2_LAUNCH_SCAN_R(32); break;
+        case 64: EM2_LAUNCH_SCAN_R(64); break;
+        case 128: EM2_LAUNCH_SCAN(128, 1); break;
+        default: return hipErrorInvalidValue;
+        }
 #undef EM2_LAUNCH_SCAN
 #undef EM2_LAUNCH_SCAN_R
+        return hipGetLastError();
+    }
+
+    // ---- persistent, segment-chained launch ----
+    const dim3 block(64u * wavesPerBlock);
+    const size_t lds = size_t(wavesPerBlock) * bytesPerWave;
+    const void* kernel = nullptr;
+#define EM2_PERSISTENT(W32) \
+    (identity ? reinterpret_cast<const void*>(&fsp4ScanPersistentKernel<W32, true>) \
+              : reinterpret_cast<const void*>(&fsp4ScanPersistentKernel<W32, false>))
+    switch (paddedDw) {
+    case 2: kernel = EM2_PERSISTENT(2); break;
+    case 4: kernel = EM2_PERSISTENT(4); break;
+    case 8: kernel = EM2_PERSISTENT(8); break;
+    case 16: kernel = EM2_PERSISTENT(16); break;
+    case 32: kernel = EM2_PERSISTENT(32); break;
+    case 64: kernel = EM2_PERSISTENT(64); break;
+    case 128: kernel = EM2_PERSISTENT(128); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef EM2_PERSISTENT
+    int device = 0, cuCount = 0, blocksPerCu = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cuCount, hipDeviceAttributeMultiprocessorCount, device);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCu, kernel, int(block.x), lds);
+    if (e != hipSuccess) return e;
+    if (blocksPerCu < 1) blocksPerCu = 1;
+    const uint32_t slots = uint32_t(cuCount) * uint32_t(blocksPerCu) * wavesPerBlock;     // resident waves
+    // Segments: enough work items (~32 per resident wave) for an even finish, at least 4096 columns each.
+    uint64_t segments = (32ull * slots + rowBlocks - 1u) / rowBlocks;
+    const uint64_t maxByColumns = cellCount / 4096u;
+    if (segments > maxByColumns) segments = maxByColumns;
+    if (segments > 64) segments = 64;
+    if (segments < 1) segments = 1;
+    const uint32_t columnsPerSegment = uint32_t((uint64_t(cellCount) + segments - 1u) / segments);
+    segments = (uint64_t(cellCount) + columnsPerSegment - 1u) / columnsPerSegment;
+    if (uint64_t(rowBlocks) * segments >= 0xffffffffull) return hipErrorInvalidValue;
+
+    char* c = static_cast<char*>(control);
+    const size_t stateBytes = (size_t(rowBlocks) * 64u * 8u + 255u) & ~size_t(255u);
+    const size_t doneBytes = (size_t(rowBlocks) * 4u + 255u) & ~size_t(255u);
+    args.rowState = reinterpret_cast<uint32_t*>(c);
+    args.segmentsDone = reinterpret_cast<uint32_t*>(c + stateBytes);
+    args.control = reinterpret_cast<uint32_t*>(c + stateBytes + doneBytes);
+    args.segments = uint32_t(segments);
+    args.columnsPerSegment = columnsPerSegment;
+    e = hipMemsetAsync(c + stateBytes, 0, doneBytes + 256u, stream);
+    if (e != hipSuccess) return e;
+
+    uint64_t wavesWanted = uint64_t(rowBlocks) * segments;
+    if (wavesWanted > slots) wavesWanted = slots;
+    const dim3 grid(uint32_t((wavesWanted + wavesPerBlock - 1u) / wavesPerBlock));
+    void* kernelArgsArray[] = {&args};
+    e = hipLaunchKernel(kernel, grid, block, kernelArgsArray, lds, stream);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
+}
+
+// Reads the error word a persistent launch raises when a hand-off wait timed out (never observed; a bounded
+// spin is the alternative to a hung GPU).  Synchronises the stream.
+hipError_t readFsp4Error(const void* control, uint32_t rowCount, hipStream_t stream, uint32_t* error)
+{
+    const size_t rowBlocks = (size_t(rowCount) + 63u) / 64u;
+    const size_t stateBytes = (rowBlocks * 64u * 8u + 255u) & ~size_t(255u);
+    const size_t doneBytes = (rowBlocks * 4u + 255u) & ~size_t(255u);
+    uint32_t words[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(words, static_cast<const char*>(control) + stateBytes + doneBytes, sizeof(words),
+                                  hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    *error = words[1];
+    return e;
 }
 
 }  // namespace em2

@@ -116,6 +116,12 @@ class DevicePipeline:
         self.exchange()
         self.scan(record_events)
 
+    def check(self):
+        """Synchronise and raise if the last scan did not complete (capi.dev_find_similar_pairs4_status)."""
+        if self.rows and self.k:
+            capi.dev_find_similar_pairs4_status(self.scan_ws.data_ptr(), self.rows, self.k,
+                                                self.torch.cuda.current_stream().cuda_stream)
+
     def results(self):
         """(pairs[rows,k] of capi.PAIR_DTYPE, used[rows]) for this rank's rows, on the host."""
         p = self.pairs[:self.rows].cpu().numpy().view(np.uint32)
@@ -149,6 +155,8 @@ class HipBackend:
             capi.dev_find_similar_pairs4(d_sig.data_ptr(), cell_count, row_begin, row_end, lsh_count, k, thr,
                                          d_pairs.data_ptr(), d_used.data_ptr(), ws.data_ptr(), ws_bytes,
                                          torch.cuda.current_stream().cuda_stream)
+        if rows and k:
+            capi.dev_find_similar_pairs4_status(ws.data_ptr(), rows, k, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         p = d_pairs[:rows].cpu().numpy().view(np.uint32)
         pairs = np.zeros((rows, k), dtype=capi.PAIR_DTYPE)

@@ -128,6 +128,11 @@ int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount
                                 em2_pair* d_pairs, uint32_t* d_usedCount, void* d_workspace,
                                 size_t workspaceBytes, void* stream);
 
+/* Synchronises `stream` and reports whether the last em2_dev_find_similar_pairs4 on this workspace completed: the
+ * scan hands per-row state from one column segment to the next between waves, and a hand-off wait that exceeds
+ * ~4 s raises an error word instead of hanging the GPU (never observed).  rowCount and k as in that call. */
+int em2_dev_find_similar_pairs4_status(const void* d_workspace, uint32_t rowCount, uint32_t k, void* stream);
+
 /* findSimilarPairs5 for the cells [rowBegin,rowEnd) of the cell set (the bucket tables are built over all
  * cellCount signatures, which every rank holds after the all-gather).  Unlike the other dev entry points this one
  * sizes its scratch from the data (bucket sizes are only known after the sort), so it allocates and frees device
