@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBRARY_PATH = os.path.join(_HERE, "libem2lsh.so")
+LIBRARY_PATH = os.environ.get("EM2_LIBRARY") or os.path.join(_HERE, "libem2lsh.so")   # override: A/B builds only
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 # std::pair<CellId,float> (src/SimilarPairs.hpp:53-56) and std::pair<GeneId,float> (src/ExpressionMatrixSubset.hpp:36)

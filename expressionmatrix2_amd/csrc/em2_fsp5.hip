@@ -20,6 +20,7 @@
 // The sorts are library primitives (rocPRIM); everything specific to the path is hand-written here.
 
 #include "em2_device.h"
+#include "em2_select_wave.h"
 
 #include <cstring>      // rocprim/iterator/texture_cache_iterator.hpp calls memset without including it
 
@@ -133,6 +134,8 @@ filterSelectKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t ba
                    uint32_t* __restrict__ outUsed)
 {
     __shared__ Entry lds[kSelectLdsEntries];
+    __shared__ uint16_t ldsL[kSelectLdsEntries];
+    __shared__ uint16_t ldsR[kSelectLdsEntries];
     const uint32_t lane = threadIdx.x;
     const uint32_t local = blockIdx.x;
     if (local >= batchCells) return;
@@ -184,7 +187,8 @@ filterSelectKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t ba
         waveFence();
     }
     if (n > k) {
-        if (lane == 0u) nthElement(work, int(k), int(n));
+        if (inLds) nthElementWave(work, ldsL, ldsR, int(k), int(n), lane);
+        else if (lane == 0u) nthElement(work, int(k), int(n));
         n = k;
         waveFence();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");      // lane 0's HBM writes (long lists) visible to the wave

@@ -23,6 +23,7 @@
 //     through the scalar caches / L2 / Infinity Cache.
 
 #include "em2_device.h"
+#include "em2_select_wave.h"
 
 #include <cstdlib>
 
@@ -32,6 +33,7 @@ namespace {
 typedef const __attribute__((address_space(4))) uint32_t* ScalarPtr;
 
 constexpr uint32_t kLdsBytesPerBlock = 64u * 1024u;
+constexpr uint32_t kLdsBytesPerEntrySlot = uint32_t(sizeof(Entry)) + 2u * uint32_t(sizeof(uint16_t));   // entry + Lpos + Rpos
 
 __device__ __forceinline__ void waveLdsFence()
 {
@@ -103,8 +105,9 @@ __device__ __attribute__((noinline)) uint32_t cutListToBest(Entry* lds, Entry* g
 {
     for (uint32_t i = lane; i < n; i += 64u) lds[i] = loadEntryCoherent(g + i);
     waveLdsFence();
-    if (lane == 0u) nthElement(lds, int(k), int(n));
-    waveLdsFence();
+    // This wave's LDS area is [2k entries][2k uint16][2k uint16] (kLdsBytesPerEntrySlot each); n <= 2k.
+    uint16_t* Lpos = reinterpret_cast<uint16_t*>(lds + 2u * k);
+    nthElementWave(lds, Lpos, Lpos + 2u * k, int(k), int(n), lane);
     if (writeBack) {
         for (uint32_t i = lane; i < k; i += 64u) g[i] = lds[i];
     }
@@ -134,7 +137,7 @@ __device__ __forceinline__ void acceptColumn(bool pass, uint32_t col, uint32_t r
         ArgsPtr aux = kernelArgs();
         const uint32_t k = aux->k;
         Entry* const waveBuffers = aux->buffers + size_t(listBlock) * 64u * twoK;
-        Entry* lds = reinterpret_cast<Entry*>(ldsRaw) + size_t(threadIdx.x >> 6) * twoK;
+        Entry* lds = reinterpret_cast<Entry*>(ldsRaw + size_t(threadIdx.x >> 6) * twoK * kLdsBytesPerEntrySlot);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         do {
             const uint32_t src = uint32_t(__builtin_ctzll(full));
@@ -162,7 +165,7 @@ __device__ __forceinline__ void finishRows(uint32_t lane, uint32_t waveIndex, ui
     const uint32_t rowEnd = aux->rowEnd;
     const uint32_t waveRowBase = rowBegin + waveIndex * 64u;
     Entry* const waveBuffers = aux->buffers + size_t(waveIndex) * 64u * twoK;
-    Entry* lds = reinterpret_cast<Entry*>(ldsRaw) + size_t(threadIdx.x >> 6) * twoK;
+    Entry* lds = reinterpret_cast<Entry*>(ldsRaw + size_t(threadIdx.x >> 6) * twoK * kLdsBytesPerEntrySlot);
     const float* keySimilarity = aux->keySimilarity;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     for (uint32_t src = 0; src < 64u; ++src) {
@@ -345,7 +348,9 @@ fsp4ScanPersistentKernel(Fsp4Args args)
     const uint32_t lane = threadIdx.x & 63u;
 
     for (;;) {
-        // ---- take the next work item ----
+        // ---- take the next work item (one ticket per WAVE: a variant with one ticket per 16-wave workgroup, whose
+        // waves then stream the same columns in step, measured 43% slower: waves in step stall on their scalar
+        // loads together) ----
         uint32_t ticket = 0;
         if (lane == 0u) {
             ticket = __hip_atomic_fetch_add(kernelArgs()->control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -499,7 +504,7 @@ static uint32_t forcedRowsPerLane()
 
 uint32_t fsp4MaxK()
 {
-    return kLdsBytesPerBlock / (2u * uint32_t(sizeof(Entry)));
+    return kLdsBytesPerBlock / (2u * kLdsBytesPerEntrySlot);
 }
 
 hipError_t launchRepackSignatures(const uint64_t* src, uint32_t cellCount, uint32_t wordCount, uint32_t* dst,
@@ -535,7 +540,7 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
 {
     if (rowEnd <= rowBegin) return hipSuccess;
     if (k == 0 || k > fsp4MaxK()) return hipErrorInvalidValue;
-    const uint32_t bytesPerWave = 2u * k * uint32_t(sizeof(Entry));
+    const uint32_t bytesPerWave = 2u * k * kLdsBytesPerEntrySlot;
     uint32_t wavesPerBlock = kLdsBytesPerBlock / bytesPerWave;
     if (wavesPerBlock > 4) wavesPerBlock = 4;
     const uint32_t rows = rowEnd - rowBegin;
@@ -623,6 +628,16 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCu, kernel, int(block.x), lds);
     if (e != hipSuccess) return e;
     if (blocksPerCu < 1) blocksPerCu = 1;
+    {
+        // Resident workgroups per CU.  Measured at 1M cells x 1024 bit (scan ms): 2 -> 2025, 3 -> 1755, 4 -> 1729,
+        // 5 -> 1936: a fifth wave per SIMD costs more in the scalar-load path than it hides, so the default is
+        // min(occupancy limit, 4 waves per SIMD).  EM2_BLOCKS_PER_CU overrides (measurements only).
+        int wanted = int(16u / wavesPerBlock);
+        if (wanted < 1) wanted = 1;
+        const char* v = getenv("EM2_BLOCKS_PER_CU");
+        if (v && atoi(v) >= 1) wanted = atoi(v);
+        if (wanted < blocksPerCu) blocksPerCu = wanted;
+    }
     const uint32_t slots = uint32_t(cuCount) * uint32_t(blocksPerCu) * wavesPerBlock;     // resident waves
     // Segments: enough work items (~32 per resident wave) for an even finish, at least 4096 columns each.
     uint64_t segments = (32ull * slots + rowBlocks - 1u) / rowBlocks;

@@ -113,3 +113,84 @@ int em2t_fsp4_rows(const uint64_t* signatures, uint32_t cellCount, uint32_t lshC
 }
 
 }  // extern "C"
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Host MODEL of the wave-parallel selection used on the device (csrc/em2_select_wave.h): the same algorithm with
+// the 64 lanes emulated by loops.  It validates the formulation (which elements a Hoare partition swaps and where
+// it cuts can be computed from the ORIGINAL positions of the "stopper" elements) against std::nth_element.
+// ---------------------------------------------------------------------------------------------------------
+namespace wave_model {
+
+using em2::Entry;
+
+// Exact result of __unguarded_partition(a+lo, a+hi, pivot = a[lo-1]) computed "in parallel".
+int partition(std::vector<Entry>& a, int lo, int hi, std::vector<uint16_t>& Lpos, std::vector<uint16_t>& Rpos)
+{
+    const uint32_t pk = a[lo - 1].key;
+    int nL = 0, nR = 0;
+    for (int base = lo; base < hi; base += 64) {                 // pass 1: stoppers in ascending position order
+        for (int lane = 0; lane < 64; lane++) {
+            const int x = base + lane;
+            if (x >= hi) break;
+            if (a[x].key >= pk) Lpos[nL++] = uint16_t(x);        // left scan stops here:  !(a[x] < pivot)
+            if (a[x].key <= pk) Rpos[nR++] = uint16_t(x);        // right scan stops here: !(pivot < a[x])
+        }
+    }
+    int T = 0;
+    for (int base = 0; base < nL; base += 64) {                  // pass 2: swap pair t = (L[t], R[nR-1-t]) while L < R
+        bool allTrue = true;
+        Entry ex[64], ey[64];
+        int xs[64], ys[64];
+        bool cond[64];
+        for (int lane = 0; lane < 64; lane++) {
+            const int t = base + lane;
+            cond[lane] = false;
+            if (t >= nL) continue;
+            xs[lane] = Lpos[t];
+            ys[lane] = t < nR ? int(Rpos[nR - 1 - t]) : lo - 1;
+            cond[lane] = xs[lane] < ys[lane];
+            if (cond[lane]) { ex[lane] = a[xs[lane]]; ey[lane] = a[ys[lane]]; }
+            else allTrue = false;
+        }
+        for (int lane = 0; lane < 64; lane++) {
+            if (cond[lane]) { a[xs[lane]] = ey[lane]; a[ys[lane]] = ex[lane]; ++T; }
+        }
+        if (!allTrue) break;
+    }
+    if (T < nL && (T == 0 || int(Lpos[T]) < int(Rpos[nR - T]))) return Lpos[T];
+    return Rpos[nR - T];                                          // = Rdesc[T-1]
+}
+
+void nthElement(std::vector<Entry>& a, int nth, int depthLimit)
+{
+    const int n = int(a.size());
+    if (n == 0 || nth == n) return;
+    std::vector<uint16_t> Lpos(n), Rpos(n);
+    int first = 0, last = n;
+    if (depthLimit < 0) depthLimit = 2 * em2::floorLog2(uint32_t(n));
+    while (last - first > 3) {
+        if (depthLimit == 0) {
+            em2::heapSelect(a.data(), first, nth + 1, last);
+            em2::entrySwap(a.data(), first, nth);
+            return;
+        }
+        --depthLimit;
+        const int mid = first + (last - first) / 2;
+        em2::medianToFirst(a.data(), first, first + 1, mid, last - 1);
+        const int cut = partition(a, first + 1, last, Lpos, Rpos);
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    em2::insertionSort(a.data(), first, last);
+}
+
+}  // namespace wave_model
+
+extern "C" void em2t_wave_model_nth_element(uint32_t* cell, uint32_t* key, uint32_t n, uint32_t nth, int depthLimit)
+{
+    std::vector<em2::Entry> a(n);
+    for (uint32_t i = 0; i < n; i++) { a[i].cell = cell[i]; a[i].key = key[i]; }
+    wave_model::nthElement(a, int(nth), depthLimit);
+    for (uint32_t i = 0; i < n; i++) { cell[i] = a[i].cell; key[i] = a[i].key; }
+}

@@ -181,6 +181,7 @@ class HostChecks:
         self.lib = lib
         lib.em2t_nth_element.argtypes = [P, P, c.c_uint32, c.c_uint32, c.c_int]
         lib.em2t_std_introselect.argtypes = [P, P, c.c_uint32, c.c_uint32, c.c_int]
+        lib.em2t_wave_model_nth_element.argtypes = [P, P, c.c_uint32, c.c_uint32, c.c_int]
         lib.em2t_tables.argtypes = [c.c_uint32, c.c_double, P, P, P, P, c.POINTER(c.c_int32), c.POINTER(c.c_int32)]
         lib.em2t_tables.restype = c.c_uint32
         lib.em2t_fsp4_rows.argtypes = [P, c.c_uint32, c.c_uint32, c.c_uint32, c.c_double, c.c_uint32, c.c_uint32,
@@ -191,6 +192,12 @@ class HostChecks:
         cell = np.array(cell, dtype=np.uint32)
         key = np.array(key, dtype=np.uint32)
         self.lib.em2t_nth_element(_ptr(cell), _ptr(key), len(cell), nth, depth_limit)
+        return cell, key
+
+    def wave_model_nth_element(self, cell, key, nth, depth_limit=-1):
+        cell = np.array(cell, dtype=np.uint32)
+        key = np.array(key, dtype=np.uint32)
+        self.lib.em2t_wave_model_nth_element(_ptr(cell), _ptr(key), len(cell), nth, depth_limit)
         return cell, key
 
     def std_introselect(self, cell, key, nth, depth_limit=-1):
