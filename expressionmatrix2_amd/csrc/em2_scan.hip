@@ -58,6 +58,14 @@ __device__ __forceinline__ void storeEntry(Entry* p, uint32_t cell, uint32_t key
     *reinterpret_cast<uint64_t*>(p) = uint64_t(cell) | (uint64_t(key) << 32);
 }
 
+// m += popcount(x) as ONE instruction.  The compiler usually forms v_bcnt_u32_b32 with its free accumulate from
+// __builtin_popcount(x) + m, but in some instantiations it reassociates the 32 additions into a v_add3_u32 tree
+// (+16 VALU instructions per column, measured in the .s); the asm pins the chain.
+__device__ __forceinline__ void popcountAccumulate(uint32_t& m, uint32_t x)
+{
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(m) : "v"(x));
+}
+
 // Kernel arguments, passed by value as ONE struct so that the kernarg segment is exactly this struct.
 // The steady-state loop reads only sig32 / cellCount / mMaxInitial.  Everything else is needed by the rare
 // path and the epilogue only; they re-read it from the kernarg segment through a laundered pointer so that
@@ -84,7 +92,8 @@ struct Fsp4Args {
     uint32_t rowBlocks;
     uint32_t segments;
     uint32_t columnsPerSegment;
-    uint32_t pad2;
+    uint32_t logCapacity;       // entries per row of a wave's speculative log
+    Entry* logs;                // [resident waves][64][logCapacity]
 };
 
 typedef const __attribute__((address_space(4))) Fsp4Args* ArgsPtr;
@@ -288,9 +297,7 @@ fsp4ScanKernel(Fsp4Args args)
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
 #pragma unroll
-                    for (int w = 0; w < CH; ++w) {
-                        m[j] += uint32_t(__builtin_popcount(r[j][part * CH + w] ^ chunk[s & 1][w]));
-                    }
+                    for (int w = 0; w < CH; ++w) popcountAccumulate(m[j], r[j][part * CH + w] ^ chunk[s & 1][w]);
                 }
                 if (part == H - 1) {
                     bool any = false;
@@ -317,30 +324,96 @@ fsp4ScanKernel(Fsp4Args args)
 }
 
 // =========================================================================================================
-// Persistent, segment-chained form of the same scan.
+// Persistent, segment-chained form of the same scan, with speculative look-ahead.
 //
 // Problem it solves (measured): a wave of fsp4ScanKernel owns 64 rows for ALL columns, so the grid is
-// rows/64 equal, indivisible work items.  At 1M rows that is 15625 waves on 5120 resident slots: three full
-// rounds and a fourth with 265 waves that run alone for a full wave lifetime (+9.5% wall); at 100k rows 1563
-// waves on 1024 SIMDs leave half the SIMDs with one wave and half with two (+80% over balanced).
+// rows/64 equal, indivisible work items: 100k rows = 1563 waves for 1024 SIMDs (half of them get one wave, half
+// two: 30 ms against a balanced 16 ms); 125k rows per GPU (1M cells on 8 GPUs) = 1954 waves.
 //
-// Here the columns are cut into S segments and a work item is (segment s, row block b).  Resident waves take
-// items from one ticket counter in segment-major order (t -> s = t / B, b = t % B), so all row blocks advance
-// together and the tail is one segment, not one whole scan.  The per-cell contract needs block b's segments in
-// order: item (s,b) starts after item (s-1,b) has published its state -- per-row {count,mMax} plus the row
-// lists it appended in HBM -- with an agent-scope release; the consumer polls segmentsDone[b] and acquires
-// (cdna_hip_programming.md, Guideline 16: stores, vmcnt(0), release fence, flag; poll, acquire fence, loads).
+// Here the columns are cut into S segments and a work item is (segment s, row block b).  Resident waves (4 per
+// SIMD, the measured optimum) take items from one ticket counter in segment-major order (t -> s = t / B,
+// b = t % B), so all row blocks advance together.  The per-cell contract needs block b's segments IN ORDER:
+//   * exact path: if item (s-1,b) has already published its state -- per-row {count,mMax} plus the row lists in
+//     HBM, with an agent-scope release -- item (s,b) acquires it and scans its columns exactly like
+//     fsp4ScanKernel (cdna_hip_programming.md Guideline 16: stores, vmcnt(0), release fence, flag; poll,
+//     acquire fence, loads);
+//   * speculative path: if it has not (fewer row blocks than resident waves), item (s,b) does not idle: it scans
+//     its columns against a SNAPSHOT of the rows' cut-offs (the last published mMax, or the initial one) and
+//     LOGS every (column, mismatch) that passes.  Cut-offs only ever tighten, so the log is a superset, in
+//     ascending column order, of what the exact state machine can accept in this segment.  Once (s-1,b) has
+//     published, the log is replayed through the exact state machine (same append / keepBest code); columns that
+//     are not in the log would have been rejected anyway.  A log that fills up (capacity per row = logCapacity)
+//     stops the speculation at that column; the rest of the segment is scanned exactly after the hand-off.
 // No deadlock: item (s-1,b) holds a lower ticket, tickets are only taken by running waves, and the chain ends
 // at s = 0 which waits for nothing.  Spins are bounded (~4 s) and raise an error flag instead of hanging.
 // =========================================================================================================
-template <int W32, bool IDENTITY>
-__global__ void __launch_bounds__(256)
-fsp4ScanPersistentKernel(Fsp4Args args)
+
+// Scans columns [colBegin, colEnd) for this wave's 64 rows.
+//   SPECULATIVE == false: accepted candidates go through acceptColumn (row lists, keepBest); returns colEnd.
+//   SPECULATIVE == true : candidates with m <= mMax (a snapshot) are logged per lane; returns the first column
+//                         NOT scanned (colEnd, or earlier if some lane's log filled up).
+template <int W32, bool IDENTITY, bool SPECULATIVE>
+__device__ __forceinline__ uint32_t scanColumns(const uint32_t* __restrict__ sig32, uint32_t colBegin, uint32_t colEnd,
+                                                const uint32_t (&r)[W32], uint32_t row, uint32_t lane, uint32_t ticket,
+                                                Entry* myList, uint32_t twoK, uint32_t& count, int32_t& mMax,
+                                                Entry* myLog, uint32_t logCapacity, uint32_t& logCount,
+                                                unsigned char* ldsRaw)
 {
     constexpr int CH = W32 < 32 ? W32 : 32;
     constexpr int H = W32 / CH;
     constexpr int U = H < 2 ? 2 : H;
     constexpr int COLS = U / H;
+    if (colBegin >= colEnd) return colEnd;
+    ScalarPtr p = (ScalarPtr)(uintptr_t)sig32 + size_t(colBegin) * W32;
+    uint32_t chunk[2][CH];
+#pragma unroll
+    for (int w = 0; w < CH; ++w) chunk[0][w] = p[w];
+    __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
+    uint32_t m = 0;
+    for (uint32_t colBase = colBegin; colBase < colEnd; colBase += COLS) {
+#pragma unroll
+        for (int s = 0; s < U; ++s) {
+            const int part = s % H;
+            const uint32_t col = colBase + uint32_t(s / H);
+            if (col < colEnd) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
+                __builtin_amdgcn_sched_barrier(0);
+                const bool lastChunk = (col + 1u == colEnd) && (part == H - 1);
+                ScalarPtr pn = lastChunk ? p : p + CH;
+#pragma unroll
+                for (int w = 0; w < CH; ++w) chunk[(s + 1) & 1][w] = pn[w];
+                p = pn;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int w = 0; w < CH; ++w) popcountAccumulate(m, r[part * CH + w] ^ chunk[s & 1][w]);
+                if (part == H - 1) {
+                    const bool pass = int32_t(m) <= mMax;
+                    if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                        if (SPECULATIVE) {
+                            if (pass && col != row) {
+                                storeEntry(myLog + logCount, col, m);
+                                ++logCount;
+                            }
+                            if (__builtin_amdgcn_ballot_w64(logCount == logCapacity) != 0ull) return col + 1u;
+                        } else {
+                            // the row block is recomputed from the ticket here: keeping it live across the
+                            // loop cost SGPR spills inside the loop
+                            acceptColumn<IDENTITY>(pass, col, row, m, lane, ticket % kernelArgs()->rowBlocks, myList,
+                                                   twoK, count, mMax, ldsRaw);
+                        }
+                    }
+                    m = 0;
+                }
+            }
+        }
+    }
+    return colEnd;
+}
+
+template <int W32, bool IDENTITY>
+__global__ void __launch_bounds__(256)
+fsp4ScanPersistentKernel(Fsp4Args args)
+{
     const uint32_t* __restrict__ sig32 = args.sig32;
     const uint32_t cellCount = args.cellCount;
 
@@ -356,12 +429,17 @@ fsp4ScanPersistentKernel(Fsp4Args args)
             ticket = __hip_atomic_fetch_add(kernelArgs()->control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         ticket = uint32_t(__builtin_amdgcn_readfirstlane(int(ticket)));
+
         uint32_t colBegin, colEnd, row;
         uint32_t r[W32];
         int32_t mMax;
-        uint32_t count;
+        uint32_t count = 0;
         Entry* myList;
-        uint32_t twoK;
+        Entry* myLog;
+        uint32_t twoK, logCapacity;
+        uint32_t logCount = 0;
+        bool rowValid;
+        bool speculate = false;
         {
             ArgsPtr aux = kernelArgs();
             const uint32_t rowBlocks = aux->rowBlocks;
@@ -369,80 +447,87 @@ fsp4ScanPersistentKernel(Fsp4Args args)
             const uint32_t seg = ticket / rowBlocks;
             const uint32_t block = ticket - seg * rowBlocks;
             twoK = 2u * aux->k;
+            logCapacity = aux->logCapacity;
             myList = aux->buffers + (size_t(block) * 64u + lane) * twoK;
-            asm volatile("" : "+v"(twoK));  // keep it in a VGPR: the scan loop is short of SGPRs, not VGPRs
+            myLog = aux->logs + (size_t(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane) * logCapacity;
+            asm volatile("" : "+v"(twoK));          // VGPRs: the scan loop is short of SGPRs, not VGPRs
+            asm volatile("" : "+v"(logCapacity));
             colBegin = seg * aux->columnsPerSegment;
             colEnd = colBegin + aux->columnsPerSegment;
             if (colEnd > cellCount || seg + 1u == aux->segments) colEnd = cellCount;
             row = aux->rowBegin + block * 64u + lane;
-            const bool rowValid = row < aux->rowEnd;
+            rowValid = row < aux->rowEnd;
             const uint32_t* rp = sig32 + size_t(rowValid ? row : aux->rowBegin + block * 64u) * W32;
 #pragma unroll
             for (int w = 0; w < W32; ++w) r[w] = rp[w];
             mMax = rowValid ? args.mMaxInitial : -1;
-            count = 0;
             if (seg != 0u) {
-                // ---- wait for the previous segment of this row block, then take over its state ----
-                const uint32_t* flag = aux->segmentsDone + block;
-                uint32_t error = 0;
-                const uint64_t start = __builtin_amdgcn_s_memrealtime();         // 100 MHz
-                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg) {
-                    __builtin_amdgcn_s_sleep(16);
-                    if (__builtin_amdgcn_s_memrealtime() - start > 400000000ull) {
-                        error = 1;
-                        break;
-                    }
+                const uint32_t done = uint32_t(__builtin_amdgcn_readfirstlane(
+                    int(__hip_atomic_load(aux->segmentsDone + block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+                speculate = done < seg;
+                if (speculate && done != 0u) {
+                    // snapshot of the cut-offs some earlier segment published: a valid (looser or equal) bound
+                    const uint64_t st = __hip_atomic_load(reinterpret_cast<const uint64_t*>(aux->rowState) + size_t(block) * 64u + lane,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mMax = rowValid ? int32_t(uint32_t(st >> 32)) : -1;
                 }
-                if (error) {
-                    if (lane == 0u) __hip_atomic_store(aux->control + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const uint64_t st = __hip_atomic_load(reinterpret_cast<const uint64_t*>(aux->rowState) + size_t(block) * 64u + lane,
-                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                count = uint32_t(st);
-                mMax = rowValid ? int32_t(uint32_t(st >> 32)) : -1;
             }
         }
 
-        // ---- scan columns [colBegin, colEnd) exactly like fsp4ScanKernel ----
-        ScalarPtr p = (ScalarPtr)(uintptr_t)sig32 + size_t(colBegin) * W32;
-        uint32_t chunk[2][CH];
-#pragma unroll
-        for (int w = 0; w < CH; ++w) chunk[0][w] = p[w];
-        __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
-        uint32_t m = 0;
-        for (uint32_t colBase = colBegin; colBase < colEnd; colBase += COLS) {
-#pragma unroll
-            for (int s = 0; s < U; ++s) {
-                const int part = s % H;
-                const uint32_t col = colBase + uint32_t(s / H);
-                if (col < colEnd) {
-                    __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
-                    __builtin_amdgcn_sched_barrier(0);
-                    const bool lastChunk = (col + 1u == colEnd) && (part == H - 1);
-                    ScalarPtr pn = lastChunk ? p : p + CH;
-#pragma unroll
-                    for (int w = 0; w < CH; ++w) chunk[(s + 1) & 1][w] = pn[w];
-                    p = pn;
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int w = 0; w < CH; ++w) {
-                        m += uint32_t(__builtin_popcount(r[part * CH + w] ^ chunk[s & 1][w]));
+        uint32_t resume = colBegin;
+        if (speculate) {
+            resume = scanColumns<W32, IDENTITY, true>(sig32, colBegin, colEnd, r, row, lane, ticket, myList, twoK, count, mMax,
+                                                      myLog, logCapacity, logCount, ldsRaw);
+        }
+
+        if (ticket >= kernelArgs()->rowBlocks) {
+            // ---- wait for the previous segment of this row block, then take over its exact state ----
+            ArgsPtr aux = kernelArgs();
+            const uint32_t seg = ticket / aux->rowBlocks;
+            const uint32_t block = ticket - seg * aux->rowBlocks;
+            const uint32_t* flag = aux->segmentsDone + block;
+            uint32_t error = 0;
+            const uint64_t start = __builtin_amdgcn_s_memrealtime();         // 100 MHz
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg) {
+                __builtin_amdgcn_s_sleep(16);
+                if (__builtin_amdgcn_s_memrealtime() - start > 400000000ull) {
+                    error = 1;
+                    break;
+                }
+            }
+            if (error) {
+                if (lane == 0u) __hip_atomic_store(aux->control + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const uint64_t st = __hip_atomic_load(reinterpret_cast<const uint64_t*>(aux->rowState) + size_t(block) * 64u + lane,
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            count = uint32_t(st);
+            mMax = rowValid ? int32_t(uint32_t(st >> 32)) : -1;
+
+            // ---- replay the speculative log through the exact state machine (ascending column order per row) ----
+            if (speculate) {
+                const uint32_t block2 = block;
+                for (uint32_t i = 0;; ++i) {
+                    const bool active = i < logCount;
+                    if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+                    uint32_t c = 0, m = 0;
+                    if (active) {
+                        const Entry e = myLog[i];
+                        c = e.cell;
+                        m = e.key;
                     }
-                    if (part == H - 1) {
-                        const bool pass = int32_t(m) <= mMax;
-                        if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
-                            // the row block is recomputed from the ticket here: keeping it live across the
-                            // loop cost SGPR spills inside the loop
-                            acceptColumn<IDENTITY>(pass, col, row, m, lane, ticket % kernelArgs()->rowBlocks, myList, twoK,
-                                                   count, mMax, ldsRaw);
-                        }
-                        m = 0;
+                    const bool pass = active && int32_t(m) <= mMax;
+                    if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                        acceptColumn<IDENTITY>(pass, c, row, m, lane, block2, myList, twoK, count, mMax, ldsRaw);
                     }
                 }
             }
         }
+
+        // ---- exact scan of whatever the speculation did not cover (all of the segment on the exact path) ----
+        scanColumns<W32, IDENTITY, false>(sig32, resume, colEnd, r, row, lane, ticket, myList, twoK, count, mMax, myLog,
+                                          logCapacity, logCount, ldsRaw);
 
         // ---- last segment: finish the rows; otherwise publish the state for the next segment ----
         {
@@ -519,11 +604,27 @@ hipError_t launchRepackSignatures(const uint64_t* src, uint32_t cellCount, uint3
     return hipGetLastError();
 }
 
+constexpr uint32_t kLogCapacity = 256;       // speculative log entries per row (2 KB per row, 128 KB per wave)
+
+// Upper bound of the waves a persistent launch keeps resident on the current device (4 per SIMD).
+static uint32_t maxResidentWaves()
+{
+    int device = 0, cuCount = 0;
+    if (hipGetDevice(&device) != hipSuccess ||
+        hipDeviceGetAttribute(&cuCount, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cuCount <= 0) {
+        cuCount = 304;
+    }
+    return uint32_t(cuCount) * 16u;
+}
+
+static size_t align256(size_t x) { return (x + 255u) & ~size_t(255u); }
+
 size_t fsp4ControlBytes(uint32_t rowCount)
 {
     const size_t rowBlocks = (size_t(rowCount) + 63u) / 64u;
-    // rowState (8 B per row of every block) + segmentsDone (4 B per block) + control words, each 256-aligned
-    return ((rowBlocks * 64u * 8u + 255u) & ~size_t(255u)) + ((rowBlocks * 4u + 255u) & ~size_t(255u)) + 256u;
+    // rowState (8 B per row of every block) + segmentsDone (4 B per block) + control words + speculative logs
+    return align256(rowBlocks * 64u * 8u) + align256(rowBlocks * 4u) + 256u +
+           align256(size_t(maxResidentWaves()) * 64u * kLogCapacity * sizeof(Entry));
 }
 
 // EM2_SCAN_MODE=simple selects the one-wave-per-row-block kernel (A/B measurements); default is the persistent
@@ -567,7 +668,8 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     args.rowBlocks = rowBlocks;
     args.segments = 1;
     args.columnsPerSegment = cellCount;
-    args.pad2 = 0;
+    args.logCapacity = 0;
+    args.logs = nullptr;
 
     if (scanModeIsSimple() || !control) {
         uint32_t rowsPerLane = forcedRowsPerLane();
@@ -641,7 +743,13 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     const uint32_t slots = uint32_t(cuCount) * uint32_t(blocksPerCu) * wavesPerBlock;     // resident waves
     // Segments: enough work items (~32 per resident wave) for an even finish, at least 4096 columns each.
     uint64_t segments = (32ull * slots + rowBlocks - 1u) / rowBlocks;
-    const uint64_t maxByColumns = cellCount / 4096u;
+    // Test knobs (tests/test_gpu_fsp4.py drives the hand-off, speculation and log-overflow paths at small sizes
+    // with them): EM2_MIN_SEGMENT_COLUMNS (default 4096), EM2_LOG_CAPACITY (default, and maximum, kLogCapacity).
+    uint64_t minSegmentColumns = 4096;
+    if (const char* v = getenv("EM2_MIN_SEGMENT_COLUMNS")) {
+        if (atoi(v) >= 1) minSegmentColumns = uint64_t(atoi(v));
+    }
+    const uint64_t maxByColumns = cellCount / minSegmentColumns;
     if (segments > maxByColumns) segments = maxByColumns;
     if (segments > 64) segments = 64;
     if (segments < 1) segments = 1;
@@ -650,11 +758,16 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     if (uint64_t(rowBlocks) * segments >= 0xffffffffull) return hipErrorInvalidValue;
 
     char* c = static_cast<char*>(control);
-    const size_t stateBytes = (size_t(rowBlocks) * 64u * 8u + 255u) & ~size_t(255u);
-    const size_t doneBytes = (size_t(rowBlocks) * 4u + 255u) & ~size_t(255u);
+    const size_t stateBytes = align256(size_t(rowBlocks) * 64u * 8u);
+    const size_t doneBytes = align256(size_t(rowBlocks) * 4u);
     args.rowState = reinterpret_cast<uint32_t*>(c);
     args.segmentsDone = reinterpret_cast<uint32_t*>(c + stateBytes);
     args.control = reinterpret_cast<uint32_t*>(c + stateBytes + doneBytes);
+    args.logs = reinterpret_cast<Entry*>(c + stateBytes + doneBytes + 256u);
+    args.logCapacity = kLogCapacity;
+    if (const char* v = getenv("EM2_LOG_CAPACITY")) {
+        if (atoi(v) >= 1 && uint32_t(atoi(v)) < kLogCapacity) args.logCapacity = uint32_t(atoi(v));
+    }
     args.segments = uint32_t(segments);
     args.columnsPerSegment = columnsPerSegment;
     e = hipMemsetAsync(c + stateBytes, 0, doneBytes + 256u, stream);
@@ -662,6 +775,7 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
 
     uint64_t wavesWanted = uint64_t(rowBlocks) * segments;
     if (wavesWanted > slots) wavesWanted = slots;
+    if (wavesWanted > maxResidentWaves()) wavesWanted = maxResidentWaves();       // the log area is sized for this
     const dim3 grid(uint32_t((wavesWanted + wavesPerBlock - 1u) / wavesPerBlock));
     void* kernelArgsArray[] = {&args};
     e = hipLaunchKernel(kernel, grid, block, kernelArgsArray, lds, stream);
@@ -674,8 +788,8 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
 hipError_t readFsp4Error(const void* control, uint32_t rowCount, hipStream_t stream, uint32_t* error)
 {
     const size_t rowBlocks = (size_t(rowCount) + 63u) / 64u;
-    const size_t stateBytes = (rowBlocks * 64u * 8u + 255u) & ~size_t(255u);
-    const size_t doneBytes = (rowBlocks * 4u + 255u) & ~size_t(255u);
+    const size_t stateBytes = align256(rowBlocks * 64u * 8u);
+    const size_t doneBytes = align256(rowBlocks * 4u);
     uint32_t words[2] = {0, 0};
     hipError_t e = hipMemcpyAsync(words, static_cast<const char*>(control) + stateBytes + doneBytes, sizeof(words),
                                   hipMemcpyDeviceToHost, stream);

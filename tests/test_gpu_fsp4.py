@@ -99,3 +99,56 @@ def test_fsp4_row_shard_through_device_api(oracle):
         assert np.array_equal(d_used.cpu().numpy().view(np.uint32), used)
         assert np.array_equal(pairs[:, :, 0], cell)
         assert np.array_equal(pairs[:, :, 1], sim.view(np.uint32))
+
+
+@pytest.fixture()
+def scan_knobs():
+    """Set / restore the scan kernel's test knobs (read with getenv at every launch)."""
+    import os
+    saved = {k: os.environ.get(k) for k in ("EM2_MIN_SEGMENT_COLUMNS", "EM2_LOG_CAPACITY", "EM2_SCAN_MODE",
+                                             "EM2_BLOCKS_PER_CU")}
+
+    def set_knobs(**kw):
+        for key, value in kw.items():
+            if value is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = str(value)
+    yield set_knobs
+    for key, value in saved.items():
+        if value is None:
+            os.environ.pop(key, None)
+        else:
+            os.environ[key] = value
+
+
+@pytest.mark.parametrize("min_cols,log_cap", [(64, None), (64, 3), (100, 1), (257, 16), (1000, 2)])
+@pytest.mark.parametrize("n,L,k,thr,kind", [(1200, 1024, 25, 0.2, "clustered"), (2000, 256, 7, -0.5, "clustered"),
+                                             (900, 128, 3, 0.0, "random")])
+def test_fsp4_segment_handoff_speculation_and_log_overflow(oracle, scan_knobs, min_cols, log_cap, n, L, k, thr, kind):
+    """Many short column segments (hand-off between waves, speculative look-ahead) and tiny speculative logs
+    (overflow -> resume exactly): the result must not depend on any of it."""
+    sig = make(n, L, kind)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
+    scan_knobs(EM2_MIN_SEGMENT_COLUMNS=min_cols, EM2_LOG_CAPACITY=log_cap)
+    pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+def test_fsp4_simple_kernel_still_matches(oracle, scan_knobs):
+    sig = make(1200, 1024, "clustered")
+    cell, sim, used = oracle.find_similar_pairs4(sig, 1024, 25, 0.2)
+    scan_knobs(EM2_SCAN_MODE="simple")
+    pairs, gused = capi.find_similar_pairs4(sig, 1024, 25, 0.2)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+def test_fsp4_repeated_runs_are_identical(scan_knobs):
+    """The speculative path depends on timing (which segments find their predecessor finished); the result must not."""
+    sig = synth.clustered_signatures(6000, 512, cluster_count=5, flip=0.15, seed=8)
+    scan_knobs(EM2_MIN_SEGMENT_COLUMNS=128, EM2_LOG_CAPACITY=8)
+    first = capi.find_similar_pairs4(sig, 512, 50, 0.2)
+    for blocks in (1, 2, 4):
+        scan_knobs(EM2_BLOCKS_PER_CU=blocks)
+        again = capi.find_similar_pairs4(sig, 512, 50, 0.2)
+        assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])
