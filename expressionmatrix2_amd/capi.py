@@ -44,7 +44,8 @@ SYMBOLS = {
     "em2_dev_compute_signatures": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p,
                                               _c.c_void_p, _c.c_uint32, _c.c_void_p, _c.c_void_p, _c.c_size_t,
                                               _c.c_void_p]),
-    "em2_dev_vector_sums": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p, _c.c_void_p]),
+    "em2_dev_vector_aux_bytes": (_c.c_size_t, [_c.c_uint32, _c.c_uint32]),
+    "em2_dev_prepare_vectors": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p, _c.c_void_p]),
     "em2_dev_find_similar_pairs4_workspace": (_c.c_size_t, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32]),
     "em2_dev_find_similar_pairs4": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                                _c.c_uint32, _c.c_double, _c.c_void_p, _c.c_void_p, _c.c_void_p,
@@ -237,12 +238,16 @@ def dev_compute_signatures_workspace(cell_count, lsh_count):
     return int(load().em2_dev_compute_signatures_workspace(cell_count, lsh_count))
 
 
-def dev_compute_signatures(toc_ptr, data_ptr, cell_count, gene_count, vectors_ptr, vector_sums_ptr, lsh_count,
+def dev_compute_signatures(toc_ptr, data_ptr, cell_count, gene_count, vectors_ptr, vector_aux_ptr, lsh_count,
                            sig_ptr, workspace_ptr, workspace_bytes, stream):
     check(load().em2_dev_compute_signatures(toc_ptr, data_ptr, cell_count, gene_count, vectors_ptr,
-                                            vector_sums_ptr, lsh_count, sig_ptr, workspace_ptr, workspace_bytes,
+                                            vector_aux_ptr, lsh_count, sig_ptr, workspace_ptr, workspace_bytes,
                                             stream))
 
 
-def dev_vector_sums(vectors_ptr, gene_count, lsh_count, sums_ptr, stream):
-    check(load().em2_dev_vector_sums(vectors_ptr, gene_count, lsh_count, sums_ptr, stream))
+def dev_vector_aux_bytes(gene_count, lsh_count):
+    return int(load().em2_dev_vector_aux_bytes(gene_count, lsh_count))
+
+
+def dev_prepare_vectors(vectors_ptr, gene_count, lsh_count, aux_ptr, stream):
+    check(load().em2_dev_prepare_vectors(vectors_ptr, gene_count, lsh_count, aux_ptr, stream))

@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <random>
@@ -217,20 +218,28 @@ int em2_set_device(int device)
 
 size_t em2_dev_compute_signatures_workspace(uint32_t cellCount, uint32_t lshCount)
 {
-    return alignUp(size_t(cellCount) * sizeof(double)) + alignUp(size_t(lshCount) * sizeof(double));
+    const size_t exact = alignUp(size_t(cellCount) * sizeof(double)) + alignUp(size_t(lshCount) * sizeof(double));
+    const size_t screened = lshCount ? em2::projectionScreenedWorkspaceBytes(cellCount, lshCount) : 0;
+    return (exact > screened ? exact : screened) + 256;
 }
 
 
-int em2_dev_vector_sums(const double* d_vectors, uint32_t geneCount, uint32_t lshCount, double* d_sums, void* stream)
+size_t em2_dev_vector_aux_bytes(uint32_t geneCount, uint32_t lshCount)
 {
-    if (!d_vectors || !d_sums || lshCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_vector_sums: bad argument");
-    EM2_HIP(em2::launchVectorSums(d_vectors, geneCount, lshCount, d_sums, static_cast<hipStream_t>(stream)));
+    return alignUp(em2::vectorAuxBytes(geneCount, lshCount));
+}
+
+
+int em2_dev_prepare_vectors(const double* d_vectors, uint32_t geneCount, uint32_t lshCount, void* d_vectorAux, void* stream)
+{
+    if (!d_vectors || !d_vectorAux || lshCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_prepare_vectors: bad argument");
+    EM2_HIP(em2::launchPrepareVectors(d_vectors, geneCount, lshCount, d_vectorAux, static_cast<hipStream_t>(stream)));
     return EM2_OK;
 }
 
 
 int em2_dev_compute_signatures(const uint64_t* d_toc, const em2_count* d_data, uint32_t cellCount,
-                               uint32_t geneCount, const double* d_vectors, const double* d_vectorSums,
+                               uint32_t geneCount, const double* d_vectors, const void* d_vectorAux,
                                uint32_t lshCount, uint64_t* d_signatures, void* d_workspace,
                                size_t workspaceBytes, void* stream)
 {
@@ -239,15 +248,23 @@ int em2_dev_compute_signatures(const uint64_t* d_toc, const em2_count* d_data, u
     if (!d_toc || !d_vectors || !d_signatures || !d_workspace) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_compute_signatures: null pointer");
     if (workspaceBytes < em2_dev_compute_signatures_workspace(cellCount, lshCount)) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_compute_signatures: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    double* means = static_cast<double*>(d_workspace);
-    double* sums = reinterpret_cast<double*>(static_cast<char*>(d_workspace) + alignUp(size_t(cellCount) * sizeof(double)));
+    void* ws = reinterpret_cast<void*>(alignUp(reinterpret_cast<size_t>(d_workspace)));
     const em2::CountIn* data = reinterpret_cast<const em2::CountIn*>(d_data);
-    if (!d_vectorSums) {
+    if (d_vectorAux && lshCount % 4u == 0u) {
+        // screening pass on a float copy of the hyperplanes + exact recomputation of the undecided words
+        EM2_HIP(em2::launchProjectionScreened(d_toc, data, cellCount, geneCount, d_vectors, d_vectorAux, lshCount,
+                                              d_signatures, ws, s));
+        return EM2_OK;
+    }
+    double* means = static_cast<double*>(ws);
+    double* sums = reinterpret_cast<double*>(static_cast<char*>(ws) + alignUp(size_t(cellCount) * sizeof(double)));
+    const double* vectorSums = static_cast<const double*>(d_vectorAux);      // the aux block starts with the sums
+    if (!vectorSums) {
         EM2_HIP(em2::launchVectorSums(d_vectors, geneCount, lshCount, sums, s));
-        d_vectorSums = sums;
+        vectorSums = sums;
     }
     EM2_HIP(em2::launchCellMeans(d_toc, data, cellCount, geneCount, means, s));
-    EM2_HIP(em2::launchProjection(d_toc, data, cellCount, d_vectors, d_vectorSums, means, lshCount, d_signatures, s));
+    EM2_HIP(em2::launchProjection(d_toc, data, cellCount, d_vectors, vectorSums, means, lshCount, d_signatures, s));
     return EM2_OK;
 }
 
@@ -351,7 +368,7 @@ int em2_compute_signatures(const uint64_t* toc, const em2_count* data, uint32_t 
     const uint64_t nnz = toc[cellCount];
     if (nnz && !data) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_compute_signatures: null data");
     const uint32_t words = wordCountOf(lshCount);
-    DeviceBuffer dToc, dData, dVectors, dSig, dWs;
+    DeviceBuffer dToc, dData, dVectors, dSig, dWs, dAux;
     const size_t wsBytes = em2_dev_compute_signatures_workspace(cellCount, lshCount);
     EM2_HIP(dToc.allocate((size_t(cellCount) + 1) * sizeof(uint64_t)));
     EM2_HIP(dData.allocate(nnz * sizeof(em2_count)));
@@ -361,8 +378,16 @@ int em2_compute_signatures(const uint64_t* toc, const em2_count* data, uint32_t 
     EM2_HIP(hipMemcpy(dToc.p, toc, (size_t(cellCount) + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     if (nnz) EM2_HIP(hipMemcpy(dData.p, data, nnz * sizeof(em2_count), hipMemcpyHostToDevice));
     EM2_HIP(hipMemcpy(dVectors.p, vectors, size_t(geneCount) * lshCount * sizeof(double), hipMemcpyHostToDevice));
+    const char* exactOnly = getenv("EM2_PROJECTION");             // EM2_PROJECTION=exact: no screening pass (A/B, tests)
+    void* aux = nullptr;
+    if (!(exactOnly && exactOnly[0] == 'e') && lshCount % 4u == 0u) {
+        EM2_HIP(dAux.allocate(em2_dev_vector_aux_bytes(geneCount, lshCount)));
+        const int prc = em2_dev_prepare_vectors(dVectors.as<double>(), geneCount, lshCount, dAux.p, nullptr);
+        if (prc != EM2_OK) return prc;
+        aux = dAux.p;
+    }
     const int rc = em2_dev_compute_signatures(dToc.as<uint64_t>(), dData.as<em2_count>(), cellCount, geneCount,
-                                              dVectors.as<double>(), nullptr, lshCount, dSig.as<uint64_t>(),
+                                              dVectors.as<double>(), aux, lshCount, dSig.as<uint64_t>(),
                                               dWs.p, wsBytes, nullptr);
     if (rc != EM2_OK) return rc;
     EM2_HIP(hipStreamSynchronize(nullptr));

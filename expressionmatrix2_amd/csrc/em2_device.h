@@ -68,6 +68,16 @@ hipError_t launchProjection(const uint64_t* toc, const CountIn* data, uint32_t c
                             const double* vectorSums, const double* means, uint32_t lshCount,
                             uint64_t* signatures, hipStream_t stream);
 
+// Screened projection (em2_project.hip): aux = per-bit sums and max |U|, and a float copy of the hyperplanes,
+// built once per hyperplane matrix; requires lshCount % 4 == 0.  Result identical to launchProjection.
+size_t vectorAuxBytes(uint32_t geneCount, uint32_t lshCount);
+hipError_t launchPrepareVectors(const double* vectors, uint32_t geneCount, uint32_t lshCount, void* aux,
+                                hipStream_t stream);
+size_t projectionScreenedWorkspaceBytes(uint32_t cellCount, uint32_t lshCount);
+hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, uint32_t cellCount, uint32_t geneCount,
+                                    const double* vectors, const void* aux, uint32_t lshCount, uint64_t* signatures,
+                                    void* workspace, hipStream_t stream);
+
 // findSimilarPairs5 (src/ExpressionMatrixLsh.cpp:355-496): bucket tables over all cells, results for the cells
 // [rowBegin,rowEnd).  Allocates its own scratch and synchronises the stream.  q = lshSliceLength in [1,32].
 hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin, uint32_t rowEnd, uint32_t lshCount,

@@ -14,6 +14,16 @@
 // The cell's (gene, count) stream is wave-uniform and comes through the scalar unit.  grid.y walks 256-bit
 // column chunks of the hyperplane matrix so the chunk in use (geneCount x 256 x 8 B) stays cache resident.
 
+// Screening (launchProjectionScreened).  The kernel above is bound by the hyperplane gathers (8 bytes per count and
+// bit).  Only the SIGN of each scalar product is needed, so a cheaper first pass decides almost every bit:
+//   a_i = (-mean)*S_i + sum_j x_j * float(U[g_j][i])      float copy of U = half the bytes; FP64 fma accumulation
+// differs from the reference's sequentially rounded value sp_i by at most
+//   E_i = (1.01*2^-24 + (n+2)*2^-52) * (|mean|*|S_i| + (sum_j |x_j|) * max_g |U[g][i]|)
+// (2^-24: rounding of U to float; (n+2)*2^-52: the two FP64 chains round differently; the bracket bounds the sum of
+// the magnitudes of all terms).  If |a_i| > E_i the reference's sign is the sign of a_i.  Otherwise the 64-bit
+// word holding bit i goes on a work list and is recomputed by the exact kernel's arithmetic (a few 1e-4 of the
+// words on the benchmark data).  The result is therefore still bit-identical to the sequential FP64 reference.
+
 #include "em2_device.h"
 
 namespace em2 {
@@ -94,6 +104,176 @@ projectionKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ d
     }
 }
 
+
+// Per-cell inputs of the screening pass: mean (as cellMeansKernel) and sum of |count|.
+__global__ void __launch_bounds__(256)
+cellStatsKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t cellCount,
+                uint32_t geneCount, double* __restrict__ means, double* __restrict__ sumAbs)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cellCount) return;
+    double sum1 = 0., abs1 = 0.;
+    const uint64_t end = toc[c + 1];
+    for (uint64_t j = toc[c]; j < end; ++j) {
+        const double x = double(data[j].count);
+        sum1 = __dadd_rn(sum1, x);
+        abs1 += fabs(x);
+    }
+    means[c] = sum1 / double(geneCount);
+    sumAbs[c] = abs1 * (1. + 1e-12);             // upper bound of the exact sum of magnitudes
+}
+
+// aux layout: [lshCount doubles: S_i][lshCount doubles: max_g |U[g][i]|][geneCount*lshCount floats: float(U)]
+__global__ void __launch_bounds__(256)
+vectorStatsKernel(const double* __restrict__ vectors, uint32_t geneCount, uint32_t lshCount, double* __restrict__ sums,
+                  double* __restrict__ maxAbs)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= lshCount) return;
+    double s = 0., m = 0.;
+    for (uint32_t g = 0; g < geneCount; ++g) {
+        const double u = vectors[size_t(g) * lshCount + i];
+        s = __dadd_rn(s, u);                                      // Lsh.cpp:137-144
+        m = fmax(m, fabs(u));
+    }
+    sums[i] = s;
+    maxAbs[i] = m;
+}
+
+__global__ void __launch_bounds__(256)
+vectorsToFloatKernel(const double* __restrict__ vectors, uint64_t count, float* __restrict__ out)
+{
+    for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += uint64_t(gridDim.x) * blockDim.x) {
+        out[i] = float(vectors[i]);
+    }
+}
+
+// Screening pass: one wave = 256 consecutive bits of one cell (4 per lane, one 16-byte load per count).
+__global__ void __launch_bounds__(256)
+projectionScreenKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t cellCount,
+                       const float* __restrict__ vectors32, const double* __restrict__ vectorSums,
+                       const double* __restrict__ vectorMaxAbs, const double* __restrict__ means,
+                       const double* __restrict__ sumAbs, uint32_t lshCount, uint32_t wordCount,
+                       uint64_t* __restrict__ signatures, uint64_t* __restrict__ workList,
+                       uint32_t* __restrict__ workCount)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t chunk = blockIdx.y * 4u + (threadIdx.x >> 6);          // 256-bit chunk of the signature
+    const uint32_t bit0 = chunk * 256u + lane * 4u;
+    if (chunk * 256u >= lshCount) return;
+    const bool valid = bit0 < lshCount;                                     // lshCount % 4 == 0 on this path
+    const float* column = vectors32 + (valid ? bit0 : 0u);
+    double s[4], mx[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        s[t] = valid ? vectorSums[bit0 + t] : 0.;
+        mx[t] = valid ? vectorMaxAbs[bit0 + t] : 0.;
+    }
+    ScalarPtr64 entries = (ScalarPtr64)(uintptr_t)data;
+    const uint32_t word = chunk * 4u + (lane >> 4);                         // the 64-bit word this lane's bits are in
+
+    const uint32_t cellBegin = blockIdx.x * kCellsPerBlock;
+    const uint32_t cellEnd = min(cellBegin + kCellsPerBlock, cellCount);
+    for (uint32_t c = cellBegin; c < cellEnd; ++c) {
+        const uint64_t jBegin = toc[c];
+        const uint64_t jEnd = toc[c + 1];
+        const double mean = means[c];
+        double a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = __dmul_rn(-mean, s[t]);
+        uint64_t j = jBegin;
+        for (; j + 4 <= jEnd; j += 4) {
+            float4 u[4];
+            double x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t e = entries[j + q];
+                u[q] = *reinterpret_cast<const float4*>(column + size_t(uint32_t(e)) * lshCount);
+                x[q] = double(__uint_as_float(uint32_t(e >> 32)));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[0] = __fma_rn(x[q], double(u[q].x), a[0]);
+                a[1] = __fma_rn(x[q], double(u[q].y), a[1]);
+                a[2] = __fma_rn(x[q], double(u[q].z), a[2]);
+                a[3] = __fma_rn(x[q], double(u[q].w), a[3]);
+            }
+        }
+        for (; j < jEnd; ++j) {
+            const uint64_t e = entries[j];
+            const float4 u = *reinterpret_cast<const float4*>(column + size_t(uint32_t(e)) * lshCount);
+            const double x = double(__uint_as_float(uint32_t(e >> 32)));
+            a[0] = __fma_rn(x, double(u.x), a[0]);
+            a[1] = __fma_rn(x, double(u.y), a[1]);
+            a[2] = __fma_rn(x, double(u.z), a[2]);
+            a[3] = __fma_rn(x, double(u.w), a[3]);
+        }
+        // error bound and decision
+        const double n = double(jEnd - jBegin);
+        const double factor = (1.01 * 5.9604644775390625e-08 + (n + 2.) * 2.220446049250313e-16) * 1.000001;
+        const double absMean = fabs(mean);
+        const double absX = sumAbs[c];
+        uint32_t nibble = 0;
+        bool ambiguous = false;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double bound = factor * (absMean * fabs(s[t]) + absX * mx[t]) + absX * 1.5e-45 + 1e-300;   // + float subnormal slack
+            ambiguous |= valid && !(fabs(a[t]) > bound);
+            nibble |= (valid && a[t] > 0.) ? (8u >> t) : 0u;                 // first bit most significant
+        }
+        // 16 lanes x 4 bits -> one MSB-first 64-bit word
+        uint64_t w = uint64_t(nibble) << (60u - 4u * (lane & 15u));
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const uint32_t lo = uint32_t(__shfl_xor(int(uint32_t(w)), d, 16));
+            const uint32_t hi = uint32_t(__shfl_xor(int(uint32_t(w >> 32)), d, 16));
+            w |= uint64_t(lo) | (uint64_t(hi) << 32);
+        }
+        const uint64_t ambMask = __builtin_amdgcn_ballot_w64(ambiguous);
+        if ((lane & 15u) == 0u && word < wordCount) {
+            signatures[size_t(c) * wordCount + word] = w;
+            if (((ambMask >> (lane & 48u)) & 0xffffull) != 0ull) {
+                const uint32_t slot = atomicAdd(workCount, 1u);
+                workList[slot] = (uint64_t(c) << 32) | word;
+            }
+        }
+    }
+}
+
+// Exact recomputation of the listed (cell, word) items: the arithmetic of projectionKernel, one wave per item.
+__global__ void __launch_bounds__(256)
+projectionExactItemsKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data,
+                           const double* __restrict__ vectors, const double* __restrict__ vectorSums,
+                           const double* __restrict__ means, uint32_t lshCount, uint32_t wordCount,
+                           uint64_t* __restrict__ signatures, const uint64_t* __restrict__ workList,
+                           const uint32_t* __restrict__ workCount)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t count = *workCount;
+    ScalarPtr64 entries = (ScalarPtr64)(uintptr_t)data;
+    for (uint32_t item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); item < count; item += waves) {
+        const uint64_t it = workList[item];
+        const uint32_t c = uint32_t(it >> 32);
+        const uint32_t word = uint32_t(it);
+        const uint32_t bit = word * 64u + lane;
+        const bool bitValid = bit < lshCount;
+        const double* column = vectors + (bitValid ? bit : 0u);
+        const double s = bitValid ? vectorSums[bit] : 0.;
+        const uint64_t jBegin = toc[c];
+        const uint64_t jEnd = toc[c + 1];
+        double sp = __dmul_rn(-means[c], s);
+        for (uint64_t j = jBegin; j < jEnd; ++j) {
+            const uint64_t e = entries[j];
+            const double u = column[size_t(uint32_t(e)) * lshCount];
+            const double x = double(__uint_as_float(uint32_t(e >> 32)));
+            sp = __dadd_rn(sp, __dmul_rn(x, u));
+        }
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(bitValid && sp > 0.);
+        if (lane == 0u) signatures[size_t(c) * wordCount + word] = __brevll(mask);
+    }
+}
+
 }  // namespace
 
 
@@ -123,6 +303,66 @@ hipError_t launchProjection(const uint64_t* toc, const CountIn* data, uint32_t c
     const dim3 grid((cellCount + kCellsPerBlock - 1u) / kCellsPerBlock, (wordCount + 3u) / 4u);
     projectionKernel<<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, vectors, vectorSums, means, lshCount,
                                                      wordCount, signatures);
+    return hipGetLastError();
+}
+
+size_t vectorAuxBytes(uint32_t geneCount, uint32_t lshCount)
+{
+    return 2u * size_t(lshCount) * sizeof(double) + size_t(geneCount) * lshCount * sizeof(float);
+}
+
+hipError_t launchPrepareVectors(const double* vectors, uint32_t geneCount, uint32_t lshCount, void* aux, hipStream_t stream)
+{
+    if (lshCount == 0) return hipSuccess;
+    double* sums = static_cast<double*>(aux);
+    double* maxAbs = sums + lshCount;
+    float* vectors32 = reinterpret_cast<float*>(maxAbs + lshCount);
+    vectorStatsKernel<<<dim3((lshCount + 63u) / 64u), dim3(64), 0, stream>>>(vectors, geneCount, lshCount, sums, maxAbs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const uint64_t count = uint64_t(geneCount) * lshCount;
+    if (count) {
+        uint64_t blocks = (count + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        vectorsToFloatKernel<<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(vectors, count, vectors32);
+    }
+    return hipGetLastError();
+}
+
+size_t projectionScreenedWorkspaceBytes(uint32_t cellCount, uint32_t lshCount)
+{
+    const size_t wordCount = (size_t(lshCount) - 1u) / 64u + 1u;
+    const size_t a = (size_t(cellCount) * sizeof(double) + 255u) & ~size_t(255u);
+    return 2u * a + 256u + ((size_t(cellCount) * wordCount * sizeof(uint64_t) + 255u) & ~size_t(255u));
+}
+
+hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, uint32_t cellCount, uint32_t geneCount,
+                                    const double* vectors, const void* aux, uint32_t lshCount, uint64_t* signatures,
+                                    void* workspace, hipStream_t stream)
+{
+    if (cellCount == 0 || lshCount == 0) return hipSuccess;
+    const uint32_t wordCount = (lshCount - 1u) / 64u + 1u;
+    const double* sums = static_cast<const double*>(aux);
+    const double* maxAbs = sums + lshCount;
+    const float* vectors32 = reinterpret_cast<const float*>(maxAbs + lshCount);
+    const size_t a = (size_t(cellCount) * sizeof(double) + 255u) & ~size_t(255u);
+    char* ws = static_cast<char*>(workspace);
+    double* means = reinterpret_cast<double*>(ws);
+    double* sumAbs = reinterpret_cast<double*>(ws + a);
+    uint32_t* workCount = reinterpret_cast<uint32_t*>(ws + 2u * a);
+    uint64_t* workList = reinterpret_cast<uint64_t*>(ws + 2u * a + 256u);
+    hipError_t e = hipMemsetAsync(workCount, 0, 256, stream);
+    if (e != hipSuccess) return e;
+    cellStatsKernel<<<dim3((cellCount + 255u) / 256u), dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, means, sumAbs);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const dim3 grid((cellCount + kCellsPerBlock - 1u) / kCellsPerBlock, (lshCount + 1023u) / 1024u);
+    projectionScreenKernel<<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, vectors32, sums, maxAbs, means, sumAbs,
+                                                           lshCount, wordCount, signatures, workList, workCount);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    projectionExactItemsKernel<<<dim3(1024), dim3(256), 0, stream>>>(toc, data, vectors, sums, means, lshCount, wordCount,
+                                                                     signatures, workList, workCount);
     return hipGetLastError();
 }
 

@@ -73,7 +73,8 @@ class DevicePipeline:
         self.scan_ws = torch.empty(max(1, self.scan_ws_bytes), dtype=torch.uint8, device=device)
         self.proj_ws_bytes = capi.dev_compute_signatures_workspace(max(1, self.rows), lsh_count)
         self.proj_ws = torch.empty(self.proj_ws_bytes, dtype=torch.uint8, device=device)
-        self.vector_sums = torch.empty(lsh_count, dtype=torch.float64, device=device)
+        self.vector_aux = torch.empty(capi.dev_vector_aux_bytes(gene_count, lsh_count), dtype=torch.uint8,
+                                      device=device)
         self.scan_events = []
 
     def set_inputs(self, toc, data, vectors):
@@ -81,14 +82,14 @@ class DevicePipeline:
         [gene_count, lsh_count]; all on the device."""
         self.toc, self.data, self.vectors = toc, data, vectors
         stream = self.torch.cuda.current_stream().cuda_stream
-        capi.dev_vector_sums(vectors.data_ptr(), self.gene_count, self.lsh_count, self.vector_sums.data_ptr(),
-                             stream)
+        capi.dev_prepare_vectors(vectors.data_ptr(), self.gene_count, self.lsh_count, self.vector_aux.data_ptr(),
+                                 stream)
 
     def project(self):
         stream = self.torch.cuda.current_stream().cuda_stream
         if self.rows:
             capi.dev_compute_signatures(self.toc.data_ptr(), self.data.data_ptr(), self.rows, self.gene_count,
-                                        self.vectors.data_ptr(), self.vector_sums.data_ptr(), self.lsh_count,
+                                        self.vectors.data_ptr(), self.vector_aux.data_ptr(), self.lsh_count,
                                         self.local_sig.data_ptr(), self.proj_ws.data_ptr(), self.proj_ws_bytes,
                                         stream)
 

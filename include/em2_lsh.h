@@ -103,16 +103,22 @@ int em2_find_similar_pairs5(const uint64_t* signatures, uint32_t cellCount, uint
 /* Bytes of device scratch em2_dev_compute_signatures needs. */
 size_t em2_dev_compute_signatures_workspace(uint32_t cellCount, uint32_t lshCount);
 
+/* Per-hyperplane-matrix auxiliary block (built once, reused for every shard / call): lshVectorsSums of
+ * src/Lsh.cpp:137-144, the per-hyperplane maximum magnitude and a float copy of the matrix used by the screening
+ * pass of em2_dev_compute_signatures. */
+size_t em2_dev_vector_aux_bytes(uint32_t geneCount, uint32_t lshCount);
+int em2_dev_prepare_vectors(const double* d_vectors, uint32_t geneCount, uint32_t lshCount, void* d_vectorAux,
+                            void* stream);
+
 /* As em2_compute_signatures, for the cellCount cells of a (shard of a) CSR in device memory.
- * d_vectorSums: lshCount doubles from em2_dev_vector_sums, or NULL to compute them into the workspace. */
+ * d_vectorAux: the block em2_dev_prepare_vectors filled, or NULL.  With it (and lshCount a multiple of 4) most bits
+ * are decided by a pass over the float copy of the hyperplanes under a rigorous error bound and only the undecided
+ * 64-bit words are recomputed in the reference's sequential FP64 arithmetic; without it every bit is.  Both give
+ * the same, reference-identical signatures. */
 int em2_dev_compute_signatures(const uint64_t* d_toc, const em2_count* d_data, uint32_t cellCount,
-                               uint32_t geneCount, const double* d_vectors, const double* d_vectorSums,
+                               uint32_t geneCount, const double* d_vectors, const void* d_vectorAux,
                                uint32_t lshCount, uint64_t* d_signatures, void* d_workspace,
                                size_t workspaceBytes, void* stream);
-
-/* lshVectorsSums of src/Lsh.cpp:137-144 into d_sums[lshCount]. */
-int em2_dev_vector_sums(const double* d_vectors, uint32_t geneCount, uint32_t lshCount, double* d_sums,
-                        void* stream);
 
 /* Bytes of device scratch em2_dev_find_similar_pairs4 needs for rowCount rows. */
 size_t em2_dev_find_similar_pairs4_workspace(uint32_t cellCount, uint32_t rowCount, uint32_t lshCount,

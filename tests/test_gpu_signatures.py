@@ -61,3 +61,44 @@ def test_empty_cells_and_unsorted_free_rows(oracle):
     got = capi.compute_signatures(toc, capi.make_counts(genes, counts), 5, vectors, 192)
     assert np.array_equal(got, expect)
     assert not got[0].any() and not got[2].any()
+
+
+def test_screening_pass_defers_to_exact_arithmetic_when_it_cannot_decide(oracle):
+    """Hyperplanes 1 + 1e-9*noise: their float copy is exactly 1.0, so the screening pass cannot see what decides
+    the signs; every word must go through the exact recomputation to match the oracle."""
+    cells, genes, L = 300, 400, 256
+    toc, g, c = synth.expression_matrix(cells, genes, density=0.05, cluster_count=3, seed=5)
+    idx = np.arange(genes * L, dtype=np.uint64).reshape(genes, L)
+    noise = (synth.uniform01(77, idx) - 0.5)
+    vectors = 1.0 + 1e-9 * noise
+    assert (vectors.astype(np.float32) == 1.0).all()
+    expect = oracle.compute_signatures(toc, g, c, genes, vectors, L)
+    got = capi.compute_signatures(toc, capi.make_counts(g, c), genes, vectors, L)
+    assert np.array_equal(got, expect)
+    ones = np.unpackbits(got.view(np.uint8)).sum()
+    assert 0.3 * cells * L < ones < 0.7 * cells * L            # the signs are genuinely mixed
+
+
+@pytest.mark.parametrize("mode", ["exact", "screened"])
+def test_exact_only_and_screened_paths_agree_with_oracle(oracle, mode, monkeypatch):
+    cells, genes, L = 800, 3000, 1024
+    toc, g, c = synth.expression_matrix(cells, genes, density=0.02, cluster_count=6, seed=9)
+    vectors = oracle.generate_lsh_vectors(genes, L, 231)
+    expect = oracle.compute_signatures(toc, g, c, genes, vectors, L)
+    if mode == "exact":
+        monkeypatch.setenv("EM2_PROJECTION", "exact")
+    got = capi.compute_signatures(toc, capi.make_counts(g, c), genes, vectors, L)
+    assert np.array_equal(got, expect)
+
+
+def test_screening_with_huge_and_tiny_magnitudes(oracle):
+    """Counts and hyperplane entries spanning many orders of magnitude (float subnormals included)."""
+    cells, genes, L = 200, 300, 128
+    toc, g, c = synth.expression_matrix(cells, genes, density=0.1, cluster_count=2, seed=3)
+    c = (c * np.float32(1e20)).astype(np.float32)
+    c[::7] = np.float32(1e-30)
+    idx = np.arange(genes * L, dtype=np.uint64).reshape(genes, L)
+    vectors = (synth.uniform01(5, idx) - 0.5) * np.power(10.0, -40.0 * synth.uniform01(6, idx))
+    expect = oracle.compute_signatures(toc, g, c, genes, vectors, L)
+    got = capi.compute_signatures(toc, capi.make_counts(g, c), genes, vectors, L)
+    assert np.array_equal(got, expect)
