@@ -85,6 +85,12 @@ class ExpressionMatrix:
                             ("lshSliceLength", lshSliceLength)):
             if value is _REQUIRED:
                 raise TypeError("findSimilarPairs5(): missing required argument '%s'" % name)
+        dist, world = _distributed()
+        if dist is not None:
+            from . import sharded
+            return sharded.find_similar_pairs5_collective(self, geneSetName, cellSetName, lshName, similarPairsName,
+                                                          k, similarityThreshold, lshSliceLength, bucketOverflow,
+                                                          dist)
         capi.check(capi.load().em2_matrix_find_similar_pairs5(self._handle, _b(geneSetName), _b(cellSetName),
                                                               _b(lshName), _b(similarPairsName), k,
                                                               similarityThreshold, lshSliceLength, bucketOverflow))
@@ -92,6 +98,15 @@ class ExpressionMatrix:
     # ---- src/PythonModule.cpp:926-934 ----
     def removeSimilarPairs(self, similarPairsName):
         capi.check(capi.load().em2_matrix_remove_similar_pairs(self._handle, _b(similarPairsName)))
+
+    def _subset_sizes(self, geneSetName, cellSetName):
+        """(geneCount, cellCount, nnz) of the subset; raises the reference's lookup / emptiness errors."""
+        genes = ctypes.c_uint32(0)
+        cells = ctypes.c_uint32(0)
+        nnz = ctypes.c_uint64(0)
+        capi.check(capi.load().em2_matrix_subset(self._handle, _b(geneSetName), _b(cellSetName), ctypes.byref(genes),
+                                                 ctypes.byref(cells), ctypes.byref(nnz), None, None))
+        return int(genes.value), int(cells.value), int(nnz.value)
 
     # ---- helper used by the sharded driver and by tests (ExpressionMatrixSubset as arrays) ----
     def _subset(self, geneSetName, cellSetName):

@@ -167,6 +167,80 @@ class HipBackend:
         return pairs, d_used[:rows].cpu().numpy().view(np.uint32).copy()
 
 
+    def bucket_rows(self, signatures, row_begin, row_end, lsh_count, k, thr, slice_length, bucket_overflow):
+        import torch
+        cell_count = signatures.shape[0]
+        rows = row_end - row_begin
+        d_sig = torch.from_numpy(np.ascontiguousarray(signatures).view(np.int64)).cuda()
+        d_pairs = torch.zeros((max(1, rows), max(1, k), 2), dtype=torch.int32, device="cuda")
+        d_used = torch.zeros(max(1, rows), dtype=torch.int32, device="cuda")
+        if rows:
+            capi.dev_find_similar_pairs5(d_sig.data_ptr(), cell_count, row_begin, row_end, lsh_count, k, thr,
+                                         slice_length, bucket_overflow, d_pairs.data_ptr(), d_used.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        p = d_pairs[:rows].cpu().numpy().view(np.uint32)
+        pairs = np.zeros((rows, k), dtype=capi.PAIR_DTYPE)
+        if k:
+            pairs["cell"] = p[:, :k, 0]
+            pairs["similarity"] = p[:, :k, 1].view(np.float32)
+        return pairs, d_used[:rows].cpu().numpy().view(np.uint32).copy()
+
+
+def _collect_and_write(matrix, similar_pairs_name, gene_set_name, cell_set_name, k, cell_count, begin, end, pairs,
+                       used, dist, comm_device):
+    """All-gather the row shards (padded to the common shard size); rank 0 writes SimilarPairs-<name>-*."""
+    import torch
+    from . import files
+    world = dist.get_world_size()
+    size = shard_size(cell_count, world)
+    send_pairs = np.zeros((size, max(1, k), 2), dtype=np.int32)
+    send_used = np.zeros(size, dtype=np.int32)
+    if end > begin and k:
+        send_pairs[:end - begin, :k, 0] = pairs["cell"].view(np.int32)
+        send_pairs[:end - begin, :k, 1] = pairs["similarity"].view(np.int32)
+    send_used[:end - begin] = used.view(np.int32)
+    tp = torch.from_numpy(send_pairs).to(comm_device)
+    tu = torch.from_numpy(send_used).to(comm_device)
+    all_pairs = torch.empty((world * size,) + tuple(tp.shape[1:]), dtype=tp.dtype, device=tp.device)
+    all_used = torch.empty(world * size, dtype=tu.dtype, device=tu.device)
+    dist.all_gather_into_tensor(all_pairs, tp)
+    dist.all_gather_into_tensor(all_used, tu)
+    if dist.get_rank() == 0:
+        ap = all_pairs[:cell_count].cpu().numpy().view(np.uint32)
+        out = np.zeros((cell_count, k), dtype=capi.PAIR_DTYPE)
+        if k:
+            out["cell"] = ap[:, :k, 0]
+            out["similarity"] = ap[:, :k, 1].view(np.float32)
+        files.write_similar_pairs(matrix.directoryName, similar_pairs_name, gene_set_name, cell_set_name, k, out,
+                                  all_used[:cell_count].cpu().numpy().view(np.uint32))
+    dist.barrier()
+
+
+def find_similar_pairs5_collective(matrix, gene_set_name, cell_set_name, lsh_name, similar_pairs_name, k,
+                                   similarity_threshold, lsh_slice_length, bucket_overflow, dist, backend=None):
+    """ExpressionMatrix::findSimilarPairs5 (src/ExpressionMatrixLsh.cpp:312-501) across the ranks of `dist`: every
+    rank reads the stored signatures and builds the (replicated) bucket tables, queries only its own cell-id range
+    (SURVEY.md 8(e)); rank 0 collects and writes.  No collective on the data path besides the result gather."""
+    from . import files
+    backend = backend or HipBackend()
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    matrix._subset_sizes(gene_set_name, cell_set_name)          # the reference's lookup / emptiness errors (:326-345)
+    lsh_count, signatures = files.read_lsh(matrix.directoryName, lsh_name)
+    cell_count = matrix._subset_sizes(gene_set_name, cell_set_name)[1]
+    if signatures.shape[0] != cell_count:
+        raise RuntimeError("LSH object %s has a number of cells inconsistent with cell set %s" % (lsh_name, cell_set_name))
+    if lsh_slice_length == 0:
+        raise RuntimeError("findSimilarPairs5: lshSliceLength must be positive.")
+    begin, end = shard_range(cell_count, world, rank)
+    pairs, used = backend.bucket_rows(signatures, begin, end, lsh_count, k, similarity_threshold, lsh_slice_length,
+                                      bucket_overflow)
+    _collect_and_write(matrix, similar_pairs_name, gene_set_name, cell_set_name, k, cell_count, begin, end, pairs,
+                       used, dist, backend.comm_device)
+    return None
+
+
 def find_similar_pairs4_collective(matrix, gene_set_name, cell_set_name, similar_pairs_name, k,
                                    similarity_threshold, lsh_count, seed, dist, backend=None):
     """ExpressionMatrix::findSimilarPairs4 (src/ExpressionMatrixLsh.cpp:155-290) across the ranks of `dist`:
@@ -194,27 +268,6 @@ def find_similar_pairs4_collective(matrix, gene_set_name, cell_set_name, similar
     signatures = t_full.cpu().numpy().view(np.uint64)
     pairs, used = backend.scan_rows(signatures, begin, end, lsh_count, k, similarity_threshold)
 
-    # collect the row shards on rank 0 (padded to the common shard size)
-    size = shard_size(cell_count, world)
-    send_pairs = np.zeros((size, max(1, k), 2), dtype=np.int32)
-    send_used = np.zeros(size, dtype=np.int32)
-    if end > begin and k:
-        send_pairs[:end - begin, :k, 0] = pairs["cell"].view(np.int32)
-        send_pairs[:end - begin, :k, 1] = pairs["similarity"].view(np.int32)
-    send_used[:end - begin] = used.view(np.int32)
-    tp = torch.from_numpy(send_pairs).to(backend.comm_device)
-    tu = torch.from_numpy(send_used).to(backend.comm_device)
-    all_pairs = torch.empty((world * size,) + tuple(tp.shape[1:]), dtype=tp.dtype, device=tp.device)
-    all_used = torch.empty(world * size, dtype=tu.dtype, device=tu.device)
-    dist.all_gather_into_tensor(all_pairs, tp)
-    dist.all_gather_into_tensor(all_used, tu)
-    if rank == 0:
-        ap = all_pairs[:cell_count].cpu().numpy().view(np.uint32)
-        out = np.zeros((cell_count, k), dtype=capi.PAIR_DTYPE)
-        if k:
-            out["cell"] = ap[:, :k, 0]
-            out["similarity"] = ap[:, :k, 1].view(np.float32)
-        files.write_similar_pairs(matrix.directoryName, similar_pairs_name, gene_set_name, cell_set_name, k, out,
-                                  all_used[:cell_count].cpu().numpy().view(np.uint32))
-    dist.barrier()
+    _collect_and_write(matrix, similar_pairs_name, gene_set_name, cell_set_name, k, cell_count, begin, end, pairs,
+                       used, dist, backend.comm_device)
     return None

@@ -42,11 +42,17 @@ class OracleBackend:
         pairs = np.zeros((e - b, k), dtype=capi.PAIR_DTYPE)
         pairs["cell"] = cell; pairs["similarity"] = sim
         return pairs, used
+    def bucket_rows(self, sig, b, e, L, k, thr, q, ovf):
+        cell, sim, used = self.o.find_similar_pairs5_rows(sig, L, k, thr, q, ovf, b, e)
+        pairs = np.zeros((e - b, k), dtype=capi.PAIR_DTYPE)
+        pairs["cell"] = cell; pairs["similarity"] = sim
+        return pairs, used
 
 dist.init_process_group(backend="gloo")
 e = ExpressionMatrix(sys.argv[2])
 sharded.find_similar_pairs4_collective(e, "AllGenes", "AllCells", "Sharded", 7, 0.1, 256, 231, dist, OracleBackend())
 sharded.find_similar_pairs4_collective(e, "Sub", "Odd", "ShardedSub", 4, 0.0, 128, 9, dist, OracleBackend())
+sharded.find_similar_pairs5_collective(e, "AllGenes", "AllCells", "Stored", "Sharded5", 6, 0.1, 8, 1000, dist, OracleBackend())
 dist.destroy_process_group()
 '''
 
@@ -61,6 +67,11 @@ def test_collective_fsp4_equals_single_process(tmp_path, oracle, world):
     files.create_directory(d, genes, toc, capi.make_counts(g, c))
     files.add_gene_set(d, "Sub", np.arange(0, genes, 3, dtype=np.uint32))
     files.add_cell_set(d, "Odd", np.arange(1, cells, 2, dtype=np.uint32))
+
+    # a stored Lsh object for the findSimilarPairs5 leg (what computeLshSignatures leaves behind)
+    full_vectors = oracle.generate_lsh_vectors(genes, 256, 231)
+    stored = oracle.compute_signatures(toc, g, c, genes, full_vectors, 256)
+    files.write_lsh(d, "Stored", 256, stored)
 
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
@@ -86,3 +97,8 @@ def test_collective_fsp4_equals_single_process(tmp_path, oracle, world):
         assert np.array_equal(pairs["cell"], cell)
         assert np.array_equal(pairs["similarity"].view(np.uint32), sim.view(np.uint32))
         assert used.sum() > 0
+    cell, sim, used = oracle.find_similar_pairs5(stored, 256, 6, 0.1, 8, 1000)
+    k2, pairs, u2 = files.read_similar_pairs(d, "Sharded5")
+    assert k2 == 6 and np.array_equal(u2, used) and np.array_equal(pairs["cell"], cell)
+    assert np.array_equal(pairs["similarity"].view(np.uint32), sim.view(np.uint32))
+    assert used.sum() > 0
