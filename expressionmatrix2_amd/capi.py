@@ -69,6 +69,12 @@ SYMBOLS = {
                                            _c.c_uint32, _c.c_void_p, _c.c_void_p]),
     "em2_similar_pairs_read": (_c.c_int, [_c.c_char_p, _c.c_char_p, _c.POINTER(_c.c_uint64),
                                           _c.POINTER(_c.c_uint64), _c.c_void_p, _c.c_void_p]),
+    "em2_similar_pairs_info": (_c.c_int, [_c.c_char_p, _c.c_char_p, _c.POINTER(_c.c_uint64),
+                                          _c.POINTER(_c.c_uint64), _c.c_char_p, _c.c_char_p]),
+    "em2_matrix_cell_set": (_c.c_int, [_c.c_void_p, _c.c_char_p, _c.POINTER(_c.c_uint32), _c.c_void_p]),
+    "em2_cell_graph_edges": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p,
+                                        _c.c_void_p, _c.c_uint32, _c.c_double, _c.c_uint32, _c.c_void_p,
+                                        _c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_uint64)]),
     "em2_lsh_write": (_c.c_int, [_c.c_char_p, _c.c_char_p, _c.c_uint64, _c.c_uint64, _c.c_void_p]),
     "em2_lsh_read": (_c.c_int, [_c.c_char_p, _c.c_char_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64),
                                 _c.c_void_p]),
@@ -207,6 +213,31 @@ def find_similar_pairs5(signatures, lsh_count, k, similarity_threshold, lsh_slic
     check(load().em2_find_similar_pairs5(_ptr(signatures), cell_count, lsh_count, k, similarity_threshold,
                                          lsh_slice_length, bucket_overflow, _ptr(pairs), _ptr(used)))
     return pairs, used
+
+
+def cell_graph_edges(pairs, used_count, similar_pairs_cell_set, graph_cell_set, similarity_threshold,
+                     max_connectivity):
+    """CellGraph::CellGraph (src/CellGraph.cpp:33-117) -> (vertex0, vertex1, similarity) per edge, in the order
+    the reference adds them; vertex v is graph_cell_set[v]."""
+    pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+    used_count = np.ascontiguousarray(used_count, dtype=np.uint32)
+    sp_cells = np.ascontiguousarray(similar_pairs_cell_set, dtype=np.uint32)
+    graph_cells = np.ascontiguousarray(graph_cell_set, dtype=np.uint32)
+    cell_count = len(used_count)
+    k = pairs.shape[1] if pairs.ndim == 2 else 0
+    if len(sp_cells) != cell_count or (pairs.ndim == 2 and pairs.shape[0] != cell_count):
+        raise ValueError("pairs, used_count and the SimilarPairs cell set must describe the same cells")
+    per_vertex = k if (max_connectivity == 0 or max_connectivity > k) else int(max_connectivity)
+    capacity = max(1, len(graph_cells) * per_vertex)
+    v0 = np.zeros(capacity, dtype=np.uint32)
+    v1 = np.zeros(capacity, dtype=np.uint32)
+    sim = np.zeros(capacity, dtype=np.float32)
+    count = ctypes.c_uint64(0)
+    check(load().em2_cell_graph_edges(_ptr(pairs), _ptr(used_count), cell_count, k, _ptr(sp_cells), _ptr(graph_cells),
+                                      len(graph_cells), similarity_threshold, min(int(max_connectivity), 0xffffffff),
+                                      _ptr(v0), _ptr(v1), _ptr(sim), ctypes.byref(count)))
+    n = int(count.value)
+    return v0[:n].copy(), v1[:n].copy(), sim[:n].copy()
 
 
 # ---- device-pointer level (torch tensors supply the memory and the stream; this module never imports torch) ----

@@ -7,6 +7,7 @@
 #include "em2_device.h"
 #include "em2_tables.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -448,6 +449,68 @@ int em2_find_similar_pairs5(const uint64_t* signatures, uint32_t cellCount, uint
     EM2_HIP(hipStreamSynchronize(nullptr));
     if (k) EM2_HIP(hipMemcpy(pairs, dPairs.p, size_t(cellCount) * k * sizeof(em2_pair), hipMemcpyDeviceToHost));
     EM2_HIP(hipMemcpy(usedCount, dUsed.p, size_t(cellCount) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return EM2_OK;
+}
+
+
+
+int em2_cell_graph_edges(const em2_pair* pairs, const uint32_t* usedCount, uint32_t similarPairsCellCount, uint32_t k,
+                         const uint32_t* similarPairsCellSet, const uint32_t* graphCellSet, uint32_t graphCellCount,
+                         double similarityThreshold, uint32_t maxConnectivity, uint32_t* edgeVertex0,
+                         uint32_t* edgeVertex1, float* edgeSimilarity, uint64_t* edgeCount)
+{
+    if (!edgeCount) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_cell_graph_edges: null edgeCount");
+    *edgeCount = 0;
+    // CellGraph.cpp:101 tests pairs.size() == maxConnectivity after a push_back, so 0 never matches and means
+    // "no limit"; a vertex never selects more than the k stored pairs either way.
+    if (maxConnectivity == 0 || maxConnectivity > k) maxConnectivity = k;
+    if (graphCellCount == 0 || maxConnectivity == 0) return EM2_OK;
+    if (!usedCount || !similarPairsCellSet || !graphCellSet || (!pairs && k && similarPairsCellCount) || !edgeVertex0 || !edgeVertex1 || !edgeSimilarity) {
+        return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_cell_graph_edges: null pointer");
+    }
+    if (!haveDevice()) return fail(EM2_ERROR_NO_DEVICE, "em2_cell_graph_edges: no HIP device is visible (this library has no CPU path)");
+    for (uint32_t i = 1; i < similarPairsCellCount; i++) {
+        if (similarPairsCellSet[i - 1] > similarPairsCellSet[i]) return fail(EM2_ERROR_RUNTIME, "em2_cell_graph_edges: the SimilarPairs cell set is not sorted.");
+    }
+    // vertexTable of the reference (cell id -> vertex): the graph cell set sorted by id + the vertex of each entry.
+    std::vector<uint32_t> order(graphCellCount);
+    for (uint32_t i = 0; i < graphCellCount; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return graphCellSet[a] < graphCellSet[b]; });
+    std::vector<uint32_t> sortedIds(graphCellCount);
+    for (uint32_t i = 0; i < graphCellCount; i++) sortedIds[i] = graphCellSet[order[i]];
+    for (uint32_t i = 1; i < graphCellCount; i++) {
+        if (sortedIds[i] == sortedIds[i - 1]) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_cell_graph_edges: duplicate cell id in the graph cell set");
+    }
+    const size_t slots = size_t(graphCellCount) * maxConnectivity;
+    DeviceBuffer dPairs, dUsed, dSp, dGraph, dSorted, dOrder, dE0, dE1, dEs;
+    EM2_HIP(dPairs.allocate(size_t(similarPairsCellCount) * k * sizeof(em2_pair)));
+    EM2_HIP(dUsed.allocate(size_t(similarPairsCellCount) * sizeof(uint32_t)));
+    EM2_HIP(dSp.allocate(size_t(similarPairsCellCount) * sizeof(uint32_t)));
+    EM2_HIP(dGraph.allocate(size_t(graphCellCount) * sizeof(uint32_t)));
+    EM2_HIP(dSorted.allocate(size_t(graphCellCount) * sizeof(uint32_t)));
+    EM2_HIP(dOrder.allocate(size_t(graphCellCount) * sizeof(uint32_t)));
+    EM2_HIP(dE0.allocate(slots * sizeof(uint32_t)));
+    EM2_HIP(dE1.allocate(slots * sizeof(uint32_t)));
+    EM2_HIP(dEs.allocate(slots * sizeof(float)));
+    if (similarPairsCellCount) {
+        if (k) EM2_HIP(hipMemcpy(dPairs.p, pairs, size_t(similarPairsCellCount) * k * sizeof(em2_pair), hipMemcpyHostToDevice));
+        EM2_HIP(hipMemcpy(dUsed.p, usedCount, size_t(similarPairsCellCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
+        EM2_HIP(hipMemcpy(dSp.p, similarPairsCellSet, size_t(similarPairsCellCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    EM2_HIP(hipMemcpy(dGraph.p, graphCellSet, size_t(graphCellCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    EM2_HIP(hipMemcpy(dSorted.p, sortedIds.data(), size_t(graphCellCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    EM2_HIP(hipMemcpy(dOrder.p, order.data(), size_t(graphCellCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    uint64_t count = 0;
+    EM2_HIP(em2::runCellGraphEdges(dPairs.as<em2::PairOut>(), dUsed.as<uint32_t>(), similarPairsCellCount, k, dSp.as<uint32_t>(),
+                                   dGraph.as<uint32_t>(), dSorted.as<uint32_t>(), dOrder.as<uint32_t>(), graphCellCount,
+                                   similarityThreshold, maxConnectivity, dE0.as<uint32_t>(), dE1.as<uint32_t>(), dEs.as<float>(),
+                                   &count, nullptr));
+    if (count) {
+        EM2_HIP(hipMemcpy(edgeVertex0, dE0.p, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        EM2_HIP(hipMemcpy(edgeVertex1, dE1.p, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        EM2_HIP(hipMemcpy(edgeSimilarity, dEs.p, count * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    *edgeCount = count;
     return EM2_OK;
 }
 

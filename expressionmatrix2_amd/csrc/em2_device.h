@@ -84,6 +84,13 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
                    uint32_t k, uint32_t q, uint64_t bucketOverflow, const DeviceTables& tables, PairOut* d_pairs,
                    uint32_t* d_used, hipStream_t stream);
 
+// CellGraph::CellGraph (src/CellGraph.cpp:33-117): edges of the k-NN graph in the reference's insertion order.
+hipError_t runCellGraphEdges(const PairOut* pairs, const uint32_t* usedCount, uint32_t spCellCount, uint32_t k,
+                             const uint32_t* spCellSet, const uint32_t* graphCellSet, const uint32_t* graphSortedIds,
+                             const uint32_t* graphVertexOfSorted, uint32_t graphCellCount, double similarityThreshold,
+                             uint32_t maxConnectivity, uint32_t* edge0, uint32_t* edge1, float* edgeSimilarity,
+                             uint64_t* edgeCountHost, hipStream_t stream);
+
 }  // namespace em2
 
 #endif

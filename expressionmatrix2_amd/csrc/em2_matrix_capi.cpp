@@ -138,6 +138,32 @@ int em2_similar_pairs_read(const char* directoryName, const char* similarPairsNa
     });
 }
 
+int em2_similar_pairs_info(const char* directoryName, const char* similarPairsName, uint64_t* k, uint64_t* cellCount,
+                           char* geneSetName, char* cellSetName)
+{
+    if (!directoryName || !similarPairsName || !k || !cellCount || !geneSetName || !cellSetName) return nullArgument("em2_similar_pairs_info");
+    return guarded([&] {
+        em2::host::SimilarPairsInfo info;
+        em2::host::readSimilarPairs(directoryName, similarPairsName, info, nullptr, nullptr);
+        *k = info.k;
+        *cellCount = info.cellCount;
+        std::memset(geneSetName, 0, 256);
+        std::memset(cellSetName, 0, 256);
+        std::memcpy(geneSetName, info.geneSetName.data(), info.geneSetName.size());
+        std::memcpy(cellSetName, info.cellSetName.data(), info.cellSetName.size());
+    });
+}
+
+int em2_matrix_cell_set(em2_matrix* matrix, const char* cellSetName, uint32_t* count, uint32_t* ids)
+{
+    if (!matrix || !cellSetName || !count) return nullArgument("em2_matrix_cell_set");
+    return guarded([&] {
+        const em2::host::MappedFile& f = matrix->impl->cellSet(cellSetName);
+        *count = uint32_t(f.objectCount());
+        if (ids && *count) std::memcpy(ids, f.data(), size_t(*count) * sizeof(uint32_t));
+    });
+}
+
 int em2_lsh_write(const char* directoryName, const char* lshName, uint64_t cellCount, uint64_t lshCount,
                   const uint64_t* signatures)
 {

@@ -42,6 +42,7 @@ class ExpressionMatrix:
         # is an error.  allowReadOnly is accepted for signature compatibility: the path never writes its inputs.
         self.directoryName = directoryName
         self._handle = ctypes.c_void_p(None)
+        self._cellGraphs = {}          # ExpressionMatrix::cellGraphs (src/ExpressionMatrix.hpp): in memory only
         capi.check(capi.load().em2_matrix_open(_b(directoryName), ctypes.byref(self._handle)))
 
     def close(self):
@@ -98,6 +99,68 @@ class ExpressionMatrix:
     # ---- src/PythonModule.cpp:926-934 ----
     def removeSimilarPairs(self, similarPairsName):
         capi.check(capi.load().em2_matrix_remove_similar_pairs(self._handle, _b(similarPairsName)))
+
+    def _cell_set(self, cellSetName):
+        lib = capi.load()
+        count = ctypes.c_uint32(0)
+        capi.check(lib.em2_matrix_cell_set(self._handle, _b(cellSetName), ctypes.byref(count), None))
+        ids = np.zeros(count.value, dtype=np.uint32)
+        capi.check(lib.em2_matrix_cell_set(self._handle, _b(cellSetName), ctypes.byref(count), capi._ptr(ids)))
+        return ids
+
+    # ---- src/PythonModule.cpp:1007-1034: the consumer of SimilarPairs ----
+    def getCellGraphNames(self):
+        return sorted(self._cellGraphs)          # std::map order (src/ExpressionMatrix.cpp:1782-1789)
+
+    def createCellGraph(self, graphName=_REQUIRED, cellSetName="AllCells", similarPairsName=_REQUIRED,
+                        similarityThreshold=0.5, k=20, keepIsolatedVertices=False):
+        """ExpressionMatrix::createCellGraph (src/ExpressionMatrix.cpp:1795-1845).  The graph lives in memory, like
+        the reference's; its edges are built on the GPU (em2_cell_graph_edges) in the reference's insertion order."""
+        if graphName is _REQUIRED or similarPairsName is _REQUIRED:
+            raise TypeError("createCellGraph(): graphName and similarPairsName are required")
+        _b(graphName)
+        if graphName in self._cellGraphs:
+            raise RuntimeError("Graph " + graphName + " already exists.")
+        try:
+            graphCells = self._cell_set(cellSetName)
+        except RuntimeError:
+            raise RuntimeError("Cell set " + cellSetName + " does not exists.") from None   # sic, :1813
+        _, _, _, similarPairsCellSetName = files.similar_pairs_info(self.directoryName, similarPairsName)
+        storedK, pairs, used = files.read_similar_pairs(self.directoryName, similarPairsName)
+        similarPairsCells = self._cell_set(similarPairsCellSetName)
+        v0, v1, similarity = capi.cell_graph_edges(pairs, used, similarPairsCells, graphCells, similarityThreshold, k)
+        vertices = graphCells
+        isolatedRemoved = 0
+        if not keepIsolatedVertices:                # CellGraph::removeIsolatedVertices (src/CellGraph.cpp:189-205)
+            connected = np.zeros(len(graphCells), dtype=bool)
+            connected[v0] = True
+            connected[v1] = True
+            isolatedRemoved = int(len(graphCells) - connected.sum())
+            vertices = graphCells[connected]
+        self._cellGraphs[graphName] = {
+            "cellSetName": cellSetName, "similarPairsName": similarPairsName,
+            "similarityThreshold": similarityThreshold, "maxConnectivity": k,
+            "vertexCount": int(len(vertices)), "edgeCount": int(len(v0)),
+            "isolatedRemovedVertexCount": isolatedRemoved,
+            "vertexCellIds": vertices, "edgeCellIds": (graphCells[v0], graphCells[v1]), "edgeSimilarity": similarity,
+        }
+
+    def _cell_graph(self, graphName):
+        if graphName not in self._cellGraphs:
+            raise RuntimeError("Graph " + graphName + " does not exist.")
+        return self._cellGraphs[graphName]
+
+    def getCellGraphEdges(self, graphName):
+        """[(cellId0, cellId1)] per edge, in edge-list order (src/ExpressionMatrix.cpp:1892-1913)."""
+        c0, c1 = self._cell_graph(graphName)["edgeCellIds"]
+        return list(zip(c0.tolist(), c1.tolist()))
+
+    def _cell_graph_information(self, graphName):
+        """The CellGraphInformation fields stored beside the graph (src/ExpressionMatrix.cpp:1824-1839); the
+        reference shows them in its HTTP UI only, hence no public name here."""
+        g = self._cell_graph(graphName)
+        return {key: g[key] for key in ("cellSetName", "similarPairsName", "similarityThreshold", "maxConnectivity",
+                                        "vertexCount", "edgeCount", "isolatedRemovedVertexCount")}
 
     def _subset_sizes(self, geneSetName, cellSetName):
         """(geneCount, cellCount, nnz) of the subset; raises the reference's lookup / emptiness errors."""

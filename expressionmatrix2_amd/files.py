@@ -32,6 +32,17 @@ def read_similar_pairs(directory, name):
     return int(k.value), pairs, used
 
 
+def similar_pairs_info(directory, name):
+    """SimilarPairs::Info (src/SimilarPairs.hpp:188-198) -> (k, cellCount, geneSetName, cellSetName)."""
+    k = ctypes.c_uint64(0)
+    cells = ctypes.c_uint64(0)
+    gene_set = ctypes.create_string_buffer(256)
+    cell_set = ctypes.create_string_buffer(256)
+    capi.check(capi.load().em2_similar_pairs_info(_b(directory), _b(name), ctypes.byref(k), ctypes.byref(cells),
+                                                  gene_set, cell_set))
+    return int(k.value), int(cells.value), gene_set.value.decode("utf-8"), cell_set.value.decode("utf-8")
+
+
 def write_lsh(directory, lsh_name, lsh_count, signatures):
     signatures = np.ascontiguousarray(signatures, dtype=np.uint64)
     capi.check(capi.load().em2_lsh_write(_b(directory), _b(lsh_name), signatures.shape[0], lsh_count,

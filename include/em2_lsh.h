@@ -149,6 +149,22 @@ int em2_dev_find_similar_pairs5(const uint64_t* d_signatures, uint32_t cellCount
                                 uint32_t* d_usedCount, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * SURVEY.md 8(f), first "next" row: the consumer of SimilarPairs.
+ * ------------------------------------------------------------------------------------------------------ */
+
+/* CellGraph::CellGraph (src/CellGraph.cpp:33-117; reached from ExpressionMatrix::createCellGraph,
+ * src/ExpressionMatrix.cpp:1795-1845): the edges of the k-NN cell similarity graph in the order the reference adds
+ * them.  Vertex v is the v-th cell of graphCellSet (the order of add_vertex).  pairs / usedCount / k are the content
+ * of a SimilarPairs object whose cell set (sorted global ids) is similarPairsCellSet.  maxConnectivity 0 means no
+ * limit, as in the reference (the size test at :101 follows a push_back).  The three output arrays need room for
+ * graphCellCount*min(maxConnectivity ? maxConnectivity : k, k) edges; *edgeCount receives the number written.
+ * Host buffers. */
+int em2_cell_graph_edges(const em2_pair* pairs, const uint32_t* usedCount, uint32_t similarPairsCellCount, uint32_t k,
+                         const uint32_t* similarPairsCellSet, const uint32_t* graphCellSet, uint32_t graphCellCount,
+                         double similarityThreshold, uint32_t maxConnectivity, uint32_t* edgeVertex0,
+                         uint32_t* edgeVertex1, float* edgeSimilarity, uint64_t* edgeCount);
+
+/* ------------------------------------------------------------------------------------------------------
  * ExpressionMatrix-level entry points: the methods the reference binds to Python (src/PythonModule.cpp),
  * operating by NAME on a data directory in the reference's memory-mapped formats.  Results are files in
  * that directory (SimilarPairs-<name>-{Info,Pairs,CellInfo}, Lsh-<name>-{Info,Signatures}), byte-compatible
@@ -194,6 +210,14 @@ int em2_similar_pairs_write(const char* directoryName, const char* similarPairsN
                             const uint32_t* usedCount);
 int em2_similar_pairs_read(const char* directoryName, const char* similarPairsName, uint64_t* k,
                            uint64_t* cellCount, em2_pair* pairs, uint32_t* usedCount);
+
+/* SimilarPairs::Info (src/SimilarPairs.hpp:188-198): k, cell count and the names of the gene / cell set the object was
+ * built on; name buffers must hold 256 bytes.  Same consistency checks as em2_similar_pairs_read. */
+int em2_similar_pairs_info(const char* directoryName, const char* similarPairsName, uint64_t* k, uint64_t* cellCount,
+                           char* geneSetName, char* cellSetName);
+
+/* A cell set of the data directory (CellSet-<name>, src/CellSets.hpp:15): pass ids == NULL to get the count. */
+int em2_matrix_cell_set(em2_matrix* matrix, const char* cellSetName, uint32_t* count, uint32_t* ids);
 
 /* Lsh files Lsh-<name>-{Info,Signatures} (src/Lsh.hpp:136-141, src/Lsh.cpp:26-28,48-64,148). */
 int em2_lsh_write(const char* directoryName, const char* lshName, uint64_t cellCount, uint64_t lshCount,

@@ -33,6 +33,8 @@
 #include <cstring>
 #include <random>
 #include <utility>
+#include <map>
+#include <set>
 #include <vector>
 
 namespace {
@@ -473,5 +475,57 @@ uint64_t em2o_murmur_hash_64a(const void* key, int len, uint64_t seed)
     h ^= h >> r; h *= m; h ^= h >> r;
     return h;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// CellGraph::CellGraph (src/CellGraph.cpp:33-117), SURVEY.md 8(f) row 1.  Literal restatement: a vertex per cell of
+// the graph cell set in order (:55-58, std::map vertexTable whose insert keeps the first entry), then per cell the
+// scan of its stored pairs (:80-103) and add_edge unless boost::edge finds one (:108-117).  The edge list is the
+// m_edges std::list of adjacency_list<listS,listS,undirectedS>, i.e. insertion order, which is what
+// ExpressionMatrix::getCellGraphEdges (src/ExpressionMatrix.cpp:1892-1913) walks.
+// pairs are (localCellId, similarity) as stored in SimilarPairs; returns the edge count.
+uint64_t em2o_cell_graph_edges(const void* pairsRaw, const uint32_t* usedCount, uint32_t similarPairsCellCount, uint32_t k,
+                               const uint32_t* similarPairsCellSet, const uint32_t* graphCellSet, uint32_t graphCellCount,
+                               double similarityThreshold, uint64_t maxConnectivity, uint32_t* edgeVertex0,
+                               uint32_t* edgeVertex1, float* edgeSimilarity)
+{
+    struct StoredPair { uint32_t cell; float similarity; };
+    const StoredPair* pairs = static_cast<const StoredPair*>(pairsRaw);
+    std::map<uint32_t, uint32_t> vertexTable;
+    for (uint32_t v = 0; v < graphCellCount; v++) vertexTable.insert(std::make_pair(graphCellSet[v], v));
+    std::set<std::pair<uint32_t, uint32_t>> existing;   // boost::edge(v0, v1) on an undirected graph
+    uint64_t edgeCount = 0;
+    std::vector<std::pair<uint32_t, float>> selected;
+    for (uint32_t i = 0; i < graphCellCount; i++) {
+        const uint32_t cellId0 = graphCellSet[i];
+        // SimilarPairs::getLocalCellId: lower_bound in the sorted cell set, invalid when absent.
+        const uint32_t* it = std::lower_bound(similarPairsCellSet, similarPairsCellSet + similarPairsCellCount, cellId0);
+        if (it == similarPairsCellSet + similarPairsCellCount || *it != cellId0) continue;
+        const uint32_t local0 = uint32_t(it - similarPairsCellSet);
+        const uint32_t v0 = vertexTable[cellId0];
+        selected.clear();
+        const StoredPair* begin = pairs + size_t(local0) * k;
+        const StoredPair* end = begin + usedCount[local0];
+        for (const StoredPair* p = begin; p != end; ++p) {
+            const float similarity = p->similarity;
+            if (similarity < similarityThreshold) break;
+            const uint32_t cellId1 = similarPairsCellSet[p->cell];
+            const auto it1 = vertexTable.find(cellId1);
+            if (it1 == vertexTable.end()) continue;
+            selected.push_back(std::make_pair(it1->second, similarity));
+            if (selected.size() == maxConnectivity) break;
+        }
+        for (const auto& s : selected) {
+            const uint32_t v1 = s.first;
+            if (existing.count(std::make_pair(std::min(v0, v1), std::max(v0, v1)))) continue;
+            existing.insert(std::make_pair(std::min(v0, v1), std::max(v0, v1)));
+            edgeVertex0[edgeCount] = v0;
+            edgeVertex1[edgeCount] = v1;
+            edgeSimilarity[edgeCount] = s.second;
+            ++edgeCount;
+        }
+    }
+    return edgeCount;
+}
+
 
 }  // extern "C"

@@ -48,6 +48,9 @@ class Oracle:
         lib.em2o_keep_best.restype = c.c_uint32
         lib.em2o_multiple_set_union.argtypes = [P, P, c.c_uint32, P]
         lib.em2o_multiple_set_union.restype = c.c_uint32
+        lib.em2o_cell_graph_edges.argtypes = [P, P, c.c_uint32, c.c_uint32, P, P, c.c_uint32, c.c_double, c.c_uint64,
+                                              P, P, P]
+        lib.em2o_cell_graph_edges.restype = c.c_uint64
         lib.em2o_murmur_hash_64a.argtypes = [P, c.c_int, c.c_uint64]
         lib.em2o_murmur_hash_64a.restype = c.c_uint64
 
@@ -123,6 +126,22 @@ class Oracle:
         if rc != 0:
             raise ValueError("oracle fsp5 rejected the arguments")
         return cell, sim, used
+
+    def cell_graph_edges(self, cell, sim, used, sp_cells, graph_cells, thr, max_connectivity):
+        n, k = cell.shape
+        pairs = np.zeros((n, k), dtype=np.dtype([("cell", np.uint32), ("similarity", np.float32)]))
+        pairs["cell"] = cell
+        pairs["similarity"] = sim
+        used = np.ascontiguousarray(used, dtype=np.uint32)
+        sp_cells = np.ascontiguousarray(sp_cells, dtype=np.uint32)
+        graph_cells = np.ascontiguousarray(graph_cells, dtype=np.uint32)
+        cap = max(1, len(graph_cells) * k)
+        v0 = np.zeros(cap, dtype=np.uint32)
+        v1 = np.zeros(cap, dtype=np.uint32)
+        es = np.zeros(cap, dtype=np.float32)
+        m = self.lib.em2o_cell_graph_edges(_ptr(pairs), _ptr(used), n, k, _ptr(sp_cells), _ptr(graph_cells),
+                                           len(graph_cells), thr, max_connectivity, _ptr(v0), _ptr(v1), _ptr(es))
+        return v0[:m], v1[:m], es[:m]
 
     def keep_best(self, cell, sim, k):
         cell = np.array(cell, dtype=np.uint32)

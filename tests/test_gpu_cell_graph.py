@@ -1,0 +1,128 @@
+"""SURVEY.md 8(f) row 1 on the GPU: em2_cell_graph_edges and ExpressionMatrix.createCellGraph must reproduce the edge
+list of CellGraph::CellGraph (src/CellGraph.cpp:33-117) -- same edges, same order, same direction -- as restated by
+the oracle.  Index / float-compare work: bit-exact."""
+import numpy as np
+import pytest
+
+import synth
+from expressionmatrix2_amd import ExpressionMatrix, capi, files
+
+pytestmark = pytest.mark.gpu
+
+
+def to_pairs(cell, sim):
+    pairs = np.zeros(cell.shape, dtype=capi.PAIR_DTYPE)
+    pairs["cell"] = cell
+    pairs["similarity"] = sim
+    return pairs
+
+
+def assert_same(got, exp):
+    for g, x in zip(got, exp):
+        assert g.dtype == x.dtype and np.array_equal(g.view(np.uint32), x.view(np.uint32))
+
+
+@pytest.mark.parametrize("cells,L,k,thr,max_conn", [
+    (300, 128, 10, 0.5, 20),
+    (1000, 256, 20, 0.5, 5),
+    (1000, 256, 20, 0.3, 1),
+    (777, 64, 7, 0.0, 0),           # 0 = no cap
+    (2048, 1024, 100, 0.2, 20),
+    (500, 128, 10, 2.0, 20),        # nothing passes
+])
+def test_edges_match_oracle_same_cell_set(oracle, cells, L, k, thr, max_conn):
+    sig = synth.clustered_signatures(cells, L, cluster_count=9, flip=0.12, seed=cells + k)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, k, 0.2 if thr >= 0.2 else -1.0)
+    ids = np.arange(cells, dtype=np.uint32)
+    exp = oracle.cell_graph_edges(cell, sim, used, ids, ids, thr, max_conn)
+    got = capi.cell_graph_edges(to_pairs(cell, sim), used, ids, ids, thr, max_conn)
+    assert_same(got, exp)
+    if thr < 1.0:
+        assert len(exp[0]) > 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_edges_match_oracle_two_cell_sets_unsorted_graph_set(oracle, seed):
+    rng = np.random.default_rng(seed)
+    total, L, k = 1500, 128, 15
+    sp_cells = np.sort(rng.choice(total, 900, replace=False)).astype(np.uint32)
+    graph_cells = rng.permutation(total)[:700].astype(np.uint32)        # overlaps partially, vertex order arbitrary
+    sig = synth.clustered_signatures(len(sp_cells), L, cluster_count=5, flip=0.1, seed=seed)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, k, 0.2)
+    exp = oracle.cell_graph_edges(cell, sim, used, sp_cells, graph_cells, 0.4, 6)
+    got = capi.cell_graph_edges(to_pairs(cell, sim), used, sp_cells, graph_cells, 0.4, 6)
+    assert_same(got, exp)
+    assert len(exp[0]) > 0
+
+
+def test_duplicates_within_a_list_and_self_pairs(oracle):
+    # not producible by fsp4/fsp5, but SimilarPairs files are an input: boost::edge de-duplicates them
+    cell = np.array([[1, 1, 0], [0, 2, 2], [2, 1, 0]], dtype=np.uint32)
+    sim = np.array([[0.9, 0.8, 0.7], [0.9, 0.6, 0.6], [0.9, 0.6, 0.5]], dtype=np.float32)
+    used = np.array([3, 3, 3], dtype=np.uint32)
+    ids = np.arange(3, dtype=np.uint32)
+    exp = oracle.cell_graph_edges(cell, sim, used, ids, ids, 0.0, 0)
+    got = capi.cell_graph_edges(to_pairs(cell, sim), used, ids, ids, 0.0, 0)
+    assert_same(got, exp)
+    assert list(zip(exp[0].tolist(), exp[1].tolist())) == [(0, 1), (0, 0), (1, 2), (2, 2), (2, 0)]
+
+
+def test_empty_inputs_and_argument_errors(oracle):
+    ids = np.arange(4, dtype=np.uint32)
+    pairs = np.zeros((4, 3), dtype=capi.PAIR_DTYPE)
+    used = np.zeros(4, dtype=np.uint32)
+    v0, v1, s = capi.cell_graph_edges(pairs, used, ids, ids, 0.5, 20)
+    assert len(v0) == len(v1) == len(s) == 0
+    v0, _, _ = capi.cell_graph_edges(pairs, used, ids, np.zeros(0, np.uint32), 0.5, 20)
+    assert len(v0) == 0
+    with pytest.raises(RuntimeError, match="duplicate"):
+        capi.cell_graph_edges(pairs, used, ids, np.array([1, 1], np.uint32), 0.5, 20)
+    with pytest.raises(RuntimeError, match="not sorted"):
+        capi.cell_graph_edges(pairs, used, ids[::-1].copy(), ids, 0.5, 20)
+
+
+@pytest.fixture()
+def data_dir(tmp_path):
+    d = str(tmp_path / "data")
+    cells, genes = 800, 600
+    toc, g, c = synth.expression_matrix(cells, genes, density=0.04, cluster_count=4, seed=5)
+    files.create_directory(d, genes, toc, capi.make_counts(g, c))
+    files.add_cell_set(d, "Odd", np.arange(1, cells, 2, dtype=np.uint32))
+    files.add_cell_set(d, "FirstHalf", np.arange(0, cells // 2, dtype=np.uint32))
+    return d
+
+
+def test_create_cell_graph_facade(oracle, data_dir):
+    e = ExpressionMatrix(data_dir)
+    e.findSimilarPairs4(similarPairsName="Lsh", k=30, similarityThreshold=0.2, lshCount=256)
+    e.findSimilarPairs4(cellSetName="Odd", similarPairsName="LshOdd", k=30, similarityThreshold=0.2, lshCount=256)
+    assert e.getCellGraphNames() == []
+    # defaults of src/PythonModule.cpp:1027-1033: AllCells, 0.5, k=20, isolated vertices removed
+    e.createCellGraph(graphName="G", similarPairsName="Lsh")
+    # a graph on FirstHalf from pairs computed on Odd: two different cell sets
+    e.createCellGraph("H", "FirstHalf", "LshOdd", 0.3, 4, True)
+    assert e.getCellGraphNames() == ["G", "H"]
+
+    for name, graph_set, sp_name, thr, kk in (("G", "AllCells", "Lsh", 0.5, 20), ("H", "FirstHalf", "LshOdd", 0.3, 4)):
+        k, pairs, used = files.read_similar_pairs(data_dir, sp_name)
+        sp_cells = e._cell_set(files.similar_pairs_info(data_dir, sp_name)[3])
+        graph_cells = e._cell_set(graph_set)
+        v0, v1, _ = oracle.cell_graph_edges(pairs["cell"], pairs["similarity"], used, sp_cells, graph_cells, thr, kk)
+        assert e.getCellGraphEdges(name) == list(zip(graph_cells[v0].tolist(), graph_cells[v1].tolist()))
+        info = e._cell_graph_information(name)
+        touched = len(set(v0.tolist()) | set(v1.tolist()))
+        assert info["edgeCount"] == len(v0) > 0
+        if name == "G":
+            assert info["vertexCount"] == touched and info["isolatedRemovedVertexCount"] == len(graph_cells) - touched
+        else:
+            assert info["vertexCount"] == len(graph_cells) and info["isolatedRemovedVertexCount"] == 0
+
+    with pytest.raises(RuntimeError, match="Graph G already exists."):
+        e.createCellGraph(graphName="G", similarPairsName="Lsh")
+    with pytest.raises(RuntimeError, match="Cell set Nope does not exists."):
+        e.createCellGraph(graphName="X", cellSetName="Nope", similarPairsName="Lsh")
+    with pytest.raises(RuntimeError):
+        e.createCellGraph(graphName="X", similarPairsName="Missing")
+    with pytest.raises(RuntimeError, match="Graph Z does not exist."):
+        e.getCellGraphEdges("Z")
+    assert e.getCellGraphNames() == ["G", "H"]
