@@ -77,11 +77,19 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path to benchmark)")
+    # Dry-run aid for boxes with fewer GPUs than ranks (EM2_BENCH_SHARE_DEVICE=1 EM2_BENCH_BACKEND=gloo): all ranks
+    # use cuda:0 and the exchange goes through gloo.  Never set by the driver; such a run is not a measurement.
+    if os.environ.get("EM2_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     capi.load()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("EM2_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     C, G, L, k, thr = args.cells, args.genes, args.lsh_count, args.k, args.threshold
     W = capi.word_count(L)
@@ -201,7 +209,8 @@ def main():
         },
         "phases_ms_rank0": {"projection": proj_ms, "scan": scan_ms},
         "roofline": {
-            "kernel": "fsp4ScanKernel<%d>" % (2 * W),
+            "kernel": ("fsp4ScanKernel<%d,...>" if os.environ.get("EM2_SCAN_MODE") == "simple"
+                       else "fsp4ScanPersistentKernel<%d,true>") % (2 * W),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
