@@ -277,6 +277,7 @@ size_t em2_dev_find_similar_pairs4_workspace(uint32_t cellCount, uint32_t rowCou
     size_t bytes = alignUp(size_t(rowCount) * 2u * k * sizeof(em2::Entry));
     if (padded != 2u * wordCountOf(lshCount)) bytes += alignUp(size_t(cellCount) * padded * sizeof(uint32_t));
     bytes += alignUp(em2::fsp4ControlBytes(rowCount));
+    bytes += alignUp(em2::fsp4SymmetricBytes(cellCount, rowCount));
     return bytes + 256;
 }
 
@@ -316,9 +317,11 @@ int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount
         uint32_t* repacked = reinterpret_cast<uint32_t*>(ws);
         EM2_HIP(em2::launchRepackSignatures(d_signatures, cellCount, words, repacked, padded, s));
         sig32 = repacked;
+        ws += alignUp(size_t(cellCount) * padded * sizeof(uint32_t));
     }
+    void* symmetricWs = em2::fsp4SymmetricBytes(cellCount, rows) ? ws : nullptr;
     EM2_HIP(em2::launchFsp4Scan(sig32, padded, cellCount, rowBegin, rowEnd, k, tables, buffers,
-                                reinterpret_cast<em2::PairOut*>(d_pairs), d_usedCount, control, s));
+                                reinterpret_cast<em2::PairOut*>(d_pairs), d_usedCount, control, s, symmetricWs));
     return EM2_OK;
 }
 

@@ -50,8 +50,11 @@ uint32_t fsp4MaxK();
 hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cellCount,
                           uint32_t rowBegin, uint32_t rowEnd, uint32_t k, const DeviceTables& tables,
                           Entry* buffers, PairOut* outPairs, uint32_t* outUsed, void* control,
-                          hipStream_t stream);
+                          hipStream_t stream, void* symmetricWorkspace = nullptr);
 size_t fsp4ControlBytes(uint32_t rowCount);
+// Extra scratch for the symmetric (each unordered pair once) form of the scan, which launchFsp4Scan uses when all
+// rows of the problem are in one launch and this workspace is given; 0 when that form would not be used.
+size_t fsp4SymmetricBytes(uint32_t cellCount, uint32_t rowCount);
 hipError_t readFsp4Error(const void* control, uint32_t rowCount, hipStream_t stream, uint32_t* error);
 
 // ExpressionMatrixSubset::computeSums (sum1 only) -> mean = sum1 / geneCount, per cell.

@@ -26,6 +26,9 @@
 #include "em2_select_wave.h"
 
 #include <cstdlib>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
 
 namespace em2 {
 namespace {
@@ -94,6 +97,16 @@ struct Fsp4Args {
     uint32_t columnsPerSegment;
     uint32_t logCapacity;       // entries per row of a wave's speculative log
     Entry* logs;                // [resident waves][64][logCapacity]
+    // symmetric (each unordered pair once) variant only
+    int32_t* snap;              // [cellCount] last published cut-off of every cell; -1 = never emit to this column
+    uint64_t* inbox;            // pool of emitted (column, row, mismatch) keys, handed out in chunks
+    uint32_t* inboxControl;     // [0..1] 64-bit chunk cursor (entries), [2] overflow flag
+    const uint32_t* segTable;   // [0..segments] first ticket of each segment, [segments+1 .. 2*segments] its first triangle block
+    uint64_t inboxCapacity;     // entries
+    uint32_t inboxChunk;        // entries per chunk (>= 64)
+    uint32_t fullRowBlocks;     // row blocks [0, fullRowBlocks) scan every column themselves
+    uint32_t rowBits;           // bits of a cell id in an inbox key
+    uint32_t totalTickets;
 };
 
 typedef const __attribute__((address_space(4))) Fsp4Args* ArgsPtr;
@@ -551,6 +564,516 @@ fsp4ScanPersistentKernel(Fsp4Args args)
     }
 }
 
+// =========================================================================================================
+// Symmetric form: every unordered pair is counted ONCE (the reference's own accounting, N(N-1)/2), which halves
+// the v_xor/v_bcnt work the scan is bound by.
+//
+// The reference gets away with one evaluation per pair because its 64x64 block order happens to offer the
+// candidates of every cell in ascending id order.  The same contract is kept here as follows.  Row block b (64
+// cells, one per lane) scans only the columns BELOW its rows; for the pair (row r, column c < r) with mismatch m
+//   * the row side is the usual in-lane state machine: candidates c arrive in ascending order;
+//   * the column side -- cell c must be offered candidate r, but only after all its candidates below r -- is
+//     deferred: if m <= snap[c], the entry (c, r, m) is EMITTED to an inbox in HBM.  snap[c] is a cut-off cell c
+//     held at some earlier point of its own sequence (published at its segment hand-offs); cut-offs only tighten,
+//     so everything not emitted would have been rejected whenever it was offered.
+// After the scan the inbox is sorted by (c, r) (rocPRIM radix sort) and a second kernel replays, per cell, its
+// entries in ascending r through the exact state machine, then finishes the rows.  Cells below fullRowBlocks*64
+// have too few lower candidates for a useful snapshot; their blocks scan all columns themselves ("full rows",
+// snap = -1, nothing is emitted to them), which costs 2*c0/N extra work.
+// Work items are (segment, row block) as in the persistent kernel, but a triangle block only has the segments up
+// to its diagonal; tickets enumerate segment-major through segTable.  The last 64 columns of a triangle block are
+// its own cells (diagonal): a plain loop with the extra test column < row.
+// If the inbox pool overflows (adversarial similarity order), the launcher reruns the ordered scan.
+// =========================================================================================================
+
+typedef const __attribute__((address_space(4))) int32_t* ScalarIntPtr;
+
+// Returns the new chunk as pos | end << 32; pos > end (1, 0) = emission disabled after an overflow.
+__device__ __attribute__((noinline)) uint64_t refillInboxChunk(uint64_t* inbox, uint32_t* control, uint64_t capacity,
+                                                               uint32_t chunk, uint32_t lane, uint32_t pos, uint32_t end)
+{
+    for (uint32_t i = pos + lane; i < end; i += 64u) inbox[i] = ~0ull;      // sentinels sort to the end
+    unsigned long long base = 0;
+    if (lane == 0u) {
+        base = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(control), (unsigned long long)chunk,
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(base))));
+    const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(base >> 32))));
+    const uint64_t b = uint64_t(lo) | (uint64_t(hi) << 32);
+    if (b + chunk > capacity) {
+        if (lane == 0u) __hip_atomic_store(control + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 1ull;
+    }
+    return b | ((b + chunk) << 32);
+}
+
+__device__ __forceinline__ void emitColumn(bool emit, uint32_t col, uint32_t row, uint32_t m, uint32_t lane,
+                                           uint32_t& emitPos, uint32_t& emitEnd)
+{
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(emit);
+    if (mask == 0ull) return;
+    uint32_t p = uint32_t(__builtin_amdgcn_readfirstlane(int(emitPos)));
+    uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(emitEnd)));
+    if (p > e) return;
+    const uint32_t n = uint32_t(__builtin_popcountll(mask));
+    ArgsPtr aux = kernelArgs();
+    if (p + n > e) {
+        const uint64_t fresh = refillInboxChunk(aux->inbox, aux->inboxControl, aux->inboxCapacity, aux->inboxChunk, lane, p, e);
+        p = uint32_t(fresh);
+        e = uint32_t(fresh >> 32);
+        if (p > e) {
+            emitPos = p;
+            emitEnd = e;
+            return;
+        }
+    }
+    if (emit) {
+        const uint32_t nb = aux->rowBits;
+        aux->inbox[p + lanesBelow(mask)] = (uint64_t(col) << (13u + nb)) | (uint64_t(row) << 13u) | uint64_t(m);
+    }
+    emitPos = p + n;
+    emitEnd = e;
+}
+
+// Room left in this wave's inbox chunk; "unlimited" once emission is disabled (pos > end after an overflow).
+__device__ __forceinline__ uint32_t inboxRoom(uint32_t emitPos, uint32_t emitEnd)
+{
+    const uint32_t p = uint32_t(__builtin_amdgcn_readfirstlane(int(emitPos)));
+    const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(emitEnd)));
+    return p > e ? 0xffffffffu : e - p;
+}
+
+// Makes sure the chunk has room for one more column's worth of entries (64).
+__device__ __forceinline__ void ensureInboxRoom(uint32_t lane, uint32_t& emitPos, uint32_t& emitEnd)
+{
+    if (inboxRoom(emitPos, emitEnd) >= 64u) return;
+    ArgsPtr aux = kernelArgs();
+    const uint32_t p = uint32_t(__builtin_amdgcn_readfirstlane(int(emitPos)));
+    const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(emitEnd)));
+    const uint64_t fresh = refillInboxChunk(aux->inbox, aux->inboxControl, aux->inboxCapacity, aux->inboxChunk, lane, p, e);
+    emitPos = uint32_t(fresh);
+    emitEnd = uint32_t(fresh >> 32);
+}
+
+// scanColumns for the strictly-lower part of a triangle block: every column is below every row of the wave.
+// Two columns per loop iteration so that the snapshot registers alternate at compile time.
+//
+// The loop body contains NO calls: keeping a prefetched 32-dword chunk alive across a call needs more
+// call-preserved SGPRs than exist, and the compiler then parks a chunk in VGPR lanes on every step (measured:
+// +25% run time).  So the rare path only stores -- the inbox entries (the caller guarantees room for one
+// column, ensureInboxRoom), the row candidates (SPECULATIVE: to the log; otherwise straight to the row lists) --
+// and the scan RETURNS to its caller whenever something needs service: inbox room below 64, a full log, or a
+// row list that reached 2k entries (the caller cuts it and re-enters).  Returns the first column not scanned.
+template <int W32, bool IDENTITY, bool SPECULATIVE>
+__device__ __forceinline__ uint32_t scanColumnsEmit(const uint32_t* __restrict__ sig32, const int32_t* snap,
+                                                    uint32_t colBegin, uint32_t colEnd, const uint32_t (&r)[W32],
+                                                    uint32_t row, bool rowValid, uint32_t lane,
+                                                    Entry* myList, uint32_t twoK, uint32_t& count, int32_t mMax,
+                                                    Entry* myLog, uint32_t logCapacity, uint32_t& logCount,
+                                                    uint32_t& emitPos, uint32_t emitEnd)
+{
+    constexpr int CH = W32 < 32 ? W32 : 32;
+    constexpr int H = W32 / CH;
+    constexpr int U = 2 * H;
+    if (colBegin >= colEnd) return colEnd;
+    ScalarPtr p = (ScalarPtr)(uintptr_t)sig32 + size_t(colBegin) * W32;
+    ScalarIntPtr sp = (ScalarIntPtr)(uintptr_t)snap + colBegin;
+    uint32_t chunk[2][CH];
+    int32_t snapCol[2];
+#pragma unroll
+    for (int w = 0; w < CH; ++w) chunk[0][w] = p[w];
+    snapCol[0] = sp[0];
+    snapCol[1] = 0;
+    __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
+    uint32_t m = 0;
+    for (uint32_t colBase = colBegin; colBase < colEnd; colBase += 2u) {
+#pragma unroll
+        for (int s = 0; s < U; ++s) {
+            const int part = s % H;
+            const int ci = s / H;
+            const uint32_t col = colBase + uint32_t(ci);
+            if (col < colEnd) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
+                __builtin_amdgcn_sched_barrier(0);
+                const bool lastChunk = (col + 1u == colEnd) && (part == H - 1);
+                ScalarPtr pn = lastChunk ? p : p + CH;
+#pragma unroll
+                for (int w = 0; w < CH; ++w) chunk[(s + 1) & 1][w] = pn[w];
+                p = pn;
+                if (part == H - 1) {
+                    ScalarIntPtr spn = lastChunk ? sp : sp + 1;
+                    snapCol[ci ^ 1] = spn[0];
+                    sp = spn;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int w = 0; w < CH; ++w) popcountAccumulate(m, r[part * CH + w] ^ chunk[s & 1][w]);
+                if (part == H - 1) {
+                    // one compare in the steady state: m against the looser of the row's and the column's cut-off
+                    int32_t limit = mMax > snapCol[ci] ? mMax : snapCol[ci];
+                    asm volatile("" : "+v"(limit));
+                    if (__builtin_amdgcn_ballot_w64(int32_t(m) <= limit) != 0ull) {
+                        const bool pass = int32_t(m) <= mMax;
+                        const bool emit = rowValid && int32_t(m) <= snapCol[ci];
+                        bool stop = false;
+                        const uint64_t emitMask = __builtin_amdgcn_ballot_w64(emit);
+                        if (emitMask != 0ull) {
+                            const uint32_t at = uint32_t(__builtin_amdgcn_readfirstlane(int(emitPos)));
+                            if (at <= uint32_t(__builtin_amdgcn_readfirstlane(int(emitEnd)))) {
+                                if (emit) {
+                                    ArgsPtr aux = kernelArgs();
+                                    aux->inbox[at + lanesBelow(emitMask)] =
+                                        (uint64_t(col) << (13u + aux->rowBits)) | (uint64_t(row) << 13u) | uint64_t(m);
+                                }
+                                emitPos = at + uint32_t(__builtin_popcountll(emitMask));
+                                stop = inboxRoom(emitPos, emitEnd) < 64u;
+                            }
+                        }
+                        if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                            if (SPECULATIVE) {
+                                if (pass) {
+                                    storeEntry(myLog + logCount, col, m);
+                                    ++logCount;
+                                }
+                                stop |= __builtin_amdgcn_ballot_w64(logCount == logCapacity) != 0ull;
+                            } else {
+                                if (pass) {
+                                    uint32_t key = m;
+                                    if (!IDENTITY) key = kernelArgs()->keyOfMismatch[m];
+                                    storeEntry(myList + count, col, key);
+                                    ++count;
+                                }
+                                stop |= __builtin_amdgcn_ballot_w64(count == twoK) != 0ull;
+                            }
+                        }
+                        if (stop) return col + 1u;
+                    }
+                    m = 0;
+                }
+            }
+        }
+    }
+    return colEnd;
+}
+
+// The diagonal columns of a triangle block (its own 64 cells): pair (row, col) belongs to the lane with row > col.
+template <int W32, bool IDENTITY, bool SPECULATIVE>
+__device__ __forceinline__ uint32_t scanDiagonal(const uint32_t* __restrict__ sig32, const int32_t* snap,
+                                                 uint32_t colBegin, uint32_t colEnd, const uint32_t (&r)[W32],
+                                                 uint32_t row, bool rowValid, uint32_t lane, uint32_t blockV,
+                                                 Entry* myList, uint32_t twoK, uint32_t& count, int32_t& mMax,
+                                                 Entry* myLog, uint32_t logCapacity, uint32_t& logCount,
+                                                 uint32_t& emitPos, uint32_t& emitEnd, unsigned char* ldsRaw)
+{
+    for (uint32_t col = colBegin; col < colEnd; ++col) {
+        ScalarPtr cp = (ScalarPtr)(uintptr_t)sig32 + size_t(col) * W32;      // wave-uniform: scalar loads
+        uint32_t m = 0;
+#pragma unroll
+        for (int w = 0; w < W32; ++w) popcountAccumulate(m, r[w] ^ cp[w]);
+        const int32_t snapCol = __hip_atomic_load(snap + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool lower = col < row;
+        const bool pass = lower && int32_t(m) <= mMax;
+        const bool emit = lower && rowValid && int32_t(m) <= snapCol;
+        emitColumn(emit, col, row, m, lane, emitPos, emitEnd);
+        if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+            if (SPECULATIVE) {
+                if (pass) {
+                    storeEntry(myLog + logCount, col, m);
+                    ++logCount;
+                }
+                if (__builtin_amdgcn_ballot_w64(logCount == logCapacity) != 0ull) return col + 1u;
+            } else {
+                acceptColumn<IDENTITY>(pass, col, row, m, lane, uint32_t(__builtin_amdgcn_readfirstlane(int(blockV))),
+                                       myList, twoK, count, mMax, ldsRaw);
+            }
+        }
+    }
+    return colEnd;
+}
+
+// Uniform values that are only needed between the scan loops are parked in VGPRs (the loops need their ~100 SGPRs
+// for two 32-dword column chunks; a build that kept these values in SGPRs spilled a chunk to VGPR lanes INSIDE the
+// loop and ran 25% slower) and read back with v_readfirstlane_b32 where they are used.
+__device__ __forceinline__ uint32_t parkInVgpr(uint32_t x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ uint32_t unpark(uint32_t v)
+{
+    return uint32_t(__builtin_amdgcn_readfirstlane(int(v)));
+}
+
+constexpr uint32_t kItemTriangle = 1u, kItemLast = 2u, kItemSpeculate = 4u;
+
+template <int W32, bool IDENTITY>
+__global__ void __launch_bounds__(256)
+fsp4ScanSymmetricKernel(Fsp4Args args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t emitPos = 0, emitEnd = 0;      // no chunk yet: the first emission takes one
+
+    for (;;) {
+        uint32_t ticket = 0;
+        if (lane == 0u) {
+            ticket = __hip_atomic_fetch_add(kernelArgs()->control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ticket = uint32_t(__builtin_amdgcn_readfirstlane(int(ticket)));
+
+        // parked (VGPR) copies of the item's uniform values
+        uint32_t colBeginV, colEndV, segV, blockV, flagsV;
+        uint32_t row;
+        uint32_t r[W32];
+        int32_t mMax;
+        uint32_t count = 0;
+        Entry* myList;
+        Entry* myLog;
+        uint32_t twoK, logCapacity;
+        uint32_t logCount = 0;
+        bool rowValid;
+        {
+            ArgsPtr aux = kernelArgs();
+            if (ticket >= aux->totalTickets) break;
+            const uint32_t cellCount = aux->cellCount;
+            const uint32_t segments = aux->segments;
+            const uint32_t* table = aux->segTable;
+            uint32_t seg = 0;
+            while (ticket >= table[seg + 1u]) ++seg;
+            const uint32_t local = ticket - table[seg];
+            const uint32_t fullBlocks = aux->fullRowBlocks;
+            const uint32_t block = local < fullBlocks ? local : table[segments + 1u + seg] + (local - fullBlocks);
+            uint32_t flags = block >= fullBlocks ? kItemTriangle : 0u;
+            const uint32_t rowBase = block * 64u;
+            twoK = parkInVgpr(2u * aux->k);
+            logCapacity = parkInVgpr(aux->logCapacity);
+            myList = aux->buffers + (size_t(block) * 64u + lane) * twoK;
+            myLog = aux->logs + (size_t(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane) * logCapacity;
+            const uint32_t cps = aux->columnsPerSegment;
+            const uint32_t colBegin = seg * cps;
+            uint32_t colEnd = colBegin + cps;
+            if (colEnd > cellCount || seg + 1u == segments) colEnd = cellCount;
+            if (seg + 1u == segments) flags |= kItemLast;
+            if (flags & kItemTriangle) {
+                uint32_t diagEnd = rowBase + 64u;
+                if (diagEnd > cellCount) diagEnd = cellCount;
+                if (diagEnd <= colEnd) {
+                    colEnd = diagEnd;
+                    flags |= kItemLast;
+                }
+            }
+            row = rowBase + lane;
+            rowValid = row < cellCount;
+            const uint32_t* rp = aux->sig32 + size_t(rowValid ? row : rowBase) * W32;
+#pragma unroll
+            for (int w = 0; w < W32; ++w) r[w] = rp[w];
+            mMax = rowValid ? aux->mMaxInitial : -1;
+            if (seg != 0u) {
+                const uint32_t done = uint32_t(__builtin_amdgcn_readfirstlane(
+                    int(__hip_atomic_load(aux->segmentsDone + block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+                if (done < seg) {
+                    flags |= kItemSpeculate;
+                    if (done != 0u) {
+                        const uint64_t st = __hip_atomic_load(reinterpret_cast<const uint64_t*>(aux->rowState) + size_t(block) * 64u + lane,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        mMax = rowValid ? int32_t(uint32_t(st >> 32)) : -1;
+                    }
+                }
+            }
+            colBeginV = parkInVgpr(colBegin);
+            colEndV = parkInVgpr(colEnd);
+            segV = parkInVgpr(seg);
+            blockV = parkInVgpr(block);
+            flagsV = parkInVgpr(flags);
+        }
+
+        // Scans [from, colEnd) of the item: full-row blocks with scanColumns; triangle blocks with the emitting scan
+        // over the columns strictly below the block, then the diagonal columns.  Returns the first column not scanned
+        // (speculative scans stop when a log fills up).
+#define EM2_SCAN_ITEM(SPEC, from, result)                                                                                   \
+        do {                                                                                                                \
+            const uint32_t colEnd_ = unpark(colEndV);                                                                       \
+            uint32_t at_ = (from);                                                                                          \
+            if (!(unpark(flagsV) & kItemTriangle)) {                                                                        \
+                at_ = scanColumns<W32, IDENTITY, SPEC>(kernelArgs()->sig32, at_, colEnd_, r, row, lane, blockV, myList, twoK, \
+                                                       count, mMax, myLog, logCapacity, logCount, ldsRaw);                  \
+            } else {                                                                                                        \
+                for (;;) {                                                                                                  \
+                    const uint32_t colEndT_ = unpark(colEndV);                                                              \
+                    const uint32_t rowBaseT_ = unpark(blockV) * 64u;                                                        \
+                    const uint32_t triEnd_ = colEndT_ < rowBaseT_ ? colEndT_ : rowBaseT_;                                   \
+                    if (at_ >= triEnd_) break;                                                                              \
+                    ensureInboxRoom(lane, emitPos, emitEnd);                                                                \
+                    at_ = scanColumnsEmit<W32, IDENTITY, SPEC>(kernelArgs()->sig32, kernelArgs()->snap, at_, triEnd_, r, row, \
+                                                               rowValid, lane, myList, twoK, count, mMax, myLog,            \
+                                                               logCapacity, logCount, emitPos, emitEnd);                    \
+                    uint32_t atV_ = parkInVgpr(at_);                                                                        \
+                    if (SPEC) {                                                                                             \
+                        if (__builtin_amdgcn_ballot_w64(logCount == logCapacity) != 0ull) break;                            \
+                    } else {                                                                                                \
+                        /* cut the row lists that reached 2k entries (no new candidate: pass = false) */                    \
+                        acceptColumn<IDENTITY>(false, 0u, row, 0u, lane, unpark(blockV), myList, twoK, count, mMax, ldsRaw); \
+                    }                                                                                                       \
+                    at_ = unpark(atV_);                                                                                     \
+                }                                                                                                           \
+                const uint32_t colEnd2_ = unpark(colEndV);                                                                  \
+                const uint32_t rowBase2_ = unpark(blockV) * 64u;                                                            \
+                const uint32_t triEnd2_ = colEnd2_ < rowBase2_ ? colEnd2_ : rowBase2_;                                      \
+                if (at_ >= triEnd2_) {                                                                                      \
+                    const uint32_t colBegin2_ = unpark(colBeginV);                                                          \
+                    const uint32_t diagBegin_ = colBegin2_ > rowBase2_ ? colBegin2_ : rowBase2_;                            \
+                    at_ = scanDiagonal<W32, IDENTITY, SPEC>(kernelArgs()->sig32, kernelArgs()->snap,                        \
+                                                            at_ > diagBegin_ ? at_ : diagBegin_, colEnd2_, r, row, rowValid, \
+                                                            lane, blockV, myList, twoK, count, mMax, myLog, logCapacity,    \
+                                                            logCount, emitPos, emitEnd, ldsRaw);                            \
+                }                                                                                                           \
+            }                                                                                                               \
+            (result) = at_;                                                                                                 \
+        } while (0)
+
+        uint32_t resumeV = colBeginV;
+        if (unpark(flagsV) & kItemSpeculate) {
+            uint32_t resume;
+            EM2_SCAN_ITEM(true, unpark(colBeginV), resume);
+            resumeV = parkInVgpr(resume);
+        }
+
+        if (unpark(segV) != 0u) {
+            ArgsPtr aux = kernelArgs();
+            const uint32_t seg = unpark(segV);
+            const uint32_t block = unpark(blockV);
+            const uint32_t* flag = aux->segmentsDone + block;
+            uint32_t error = 0;
+            const uint64_t start = __builtin_amdgcn_s_memrealtime();         // 100 MHz
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg) {
+                __builtin_amdgcn_s_sleep(16);
+                if (__builtin_amdgcn_s_memrealtime() - start > 400000000ull) {
+                    error = 1;
+                    break;
+                }
+            }
+            if (error) {
+                if (lane == 0u) __hip_atomic_store(aux->control + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const uint64_t st = __hip_atomic_load(reinterpret_cast<const uint64_t*>(aux->rowState) + size_t(block) * 64u + lane,
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            count = uint32_t(st);
+            mMax = rowValid ? int32_t(uint32_t(st >> 32)) : -1;
+            if (unpark(flagsV) & kItemSpeculate) {
+                for (uint32_t i = 0;; ++i) {
+                    const bool active = i < logCount;
+                    if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+                    uint32_t c = 0, m = 0;
+                    if (active) {
+                        const Entry e = myLog[i];
+                        c = e.cell;
+                        m = e.key;
+                    }
+                    const bool pass = active && int32_t(m) <= mMax;
+                    if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                        acceptColumn<IDENTITY>(pass, c, row, m, lane, unpark(blockV), myList, twoK, count, mMax, ldsRaw);
+                    }
+                }
+            }
+        }
+
+        // ---- exact scan of whatever the speculation did not cover ----
+        {
+            uint32_t unused;
+            EM2_SCAN_ITEM(false, unpark(resumeV), unused);
+            (void)unused;
+        }
+#undef EM2_SCAN_ITEM
+
+        // ---- full-row block at its last segment: finish; otherwise publish the state (for the next segment, for
+        // the columns' snapshots and, at a triangle block's last segment, for the inbox replay) ----
+        {
+            ArgsPtr aux = kernelArgs();
+            const uint32_t block = unpark(blockV);
+            const uint32_t flags = unpark(flagsV);
+            if (!(flags & kItemTriangle) && (flags & kItemLast)) {
+                finishRows(lane, block, count, ldsRaw);
+            } else {
+                const uint64_t st = uint64_t(count) | (uint64_t(uint32_t(mMax)) << 32);
+                __hip_atomic_store(reinterpret_cast<uint64_t*>(aux->rowState) + size_t(block) * 64u + lane, st,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((flags & kItemTriangle) && rowValid) {
+                    __hip_atomic_store(aux->snap + row, mMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0u && !(flags & kItemLast)) {
+                    __hip_atomic_store(aux->segmentsDone + block, unpark(segV) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+
+    // the unused tail of this wave's last inbox chunk becomes sentinels
+    {
+        const uint32_t p = uint32_t(__builtin_amdgcn_readfirstlane(int(emitPos)));
+        const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(emitEnd)));
+        if (p <= e) {
+            uint64_t* inbox = kernelArgs()->inbox;
+            for (uint32_t i = p + lane; i < e; i += 64u) inbox[i] = ~0ull;
+        }
+    }
+}
+
+// Second phase of the symmetric scan: one wave per triangle row block replays the sorted inbox entries of its 64
+// cells (ascending candidate id per cell) through the exact state machine and finishes the rows.
+template <bool IDENTITY>
+__global__ void __launch_bounds__(256)
+fsp4InboxReplayKernel(Fsp4Args args, const uint64_t* __restrict__ sorted, uint64_t sortedCount)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t block = args.fullRowBlocks + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (block >= args.rowBlocks) return;
+    const uint32_t row = block * 64u + lane;
+    const bool rowValid = row < args.rowEnd;
+    uint32_t twoK = 2u * args.k;
+    Entry* myList = args.buffers + (size_t(block) * 64u + lane) * twoK;
+    const uint64_t st = reinterpret_cast<const uint64_t*>(args.rowState)[size_t(block) * 64u + lane];
+    uint32_t count = uint32_t(st);
+    int32_t mMax = rowValid ? int32_t(uint32_t(st >> 32)) : -1;
+    const uint32_t nb = args.rowBits;
+    const uint64_t fieldMask = (1ull << (2u * nb)) - 1ull;
+    uint64_t bound[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint64_t target = uint64_t(row + uint32_t(j)) << nb;
+        uint64_t lo = 0, hi = sortedCount;
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo) / 2u;
+            if (((sorted[mid] >> 13u) & fieldMask) < target) lo = mid + 1u;
+            else hi = mid;
+        }
+        bound[j] = lo;
+    }
+    if (!rowValid) bound[1] = bound[0];
+    const uint32_t idMask = (1u << nb) - 1u;
+    for (uint64_t i = bound[0];; ++i) {
+        const bool active = i < bound[1];
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+        uint32_t c = 0, m = 0;
+        if (active) {
+            const uint64_t e = sorted[i];
+            c = uint32_t(e >> 13u) & idMask;
+            m = uint32_t(e) & 0x1fffu;
+        }
+        const bool pass = active && int32_t(m) <= mMax;
+        if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+            acceptColumn<IDENTITY>(pass, c, row, m, lane, block, myList, twoK, count, mMax, ldsRaw);
+        }
+    }
+    finishRows(lane, block, count, ldsRaw);
+}
+
 __global__ void repackSignaturesKernel(const uint64_t* __restrict__ src, uint32_t cellCount, uint32_t wordCount,
                                        uint32_t* __restrict__ dst, uint32_t paddedDw)
 {
@@ -635,9 +1158,255 @@ static bool scanModeIsSimple()
     return v && v[0] == 's';
 }
 
+// ---- symmetric (triangle) scan: eligibility and workspace ----
+// EM2_SCAN_MODE=triangle forces it wherever it is possible (all rows of the problem in one launch),
+// EM2_SCAN_MODE=persistent / simple disable it; by default it is used from kSymmetricMinCells cells on.
+constexpr uint32_t kSymmetricMinCells = 131072;
+constexpr uint32_t kMaxSegments = 64;
+constexpr uint32_t kInboxChunk = 512;
+
+static uint64_t envNumber(const char* name, uint64_t fallback)
+{
+    const char* v = getenv(name);
+    if (!v || !*v) return fallback;
+    char* end = nullptr;
+    const unsigned long long x = strtoull(v, &end, 10);
+    return end == v ? fallback : uint64_t(x);
+}
+
+static bool symmetricEligible(uint32_t cellCount, uint32_t rowCount)
+{
+    if (rowCount != cellCount || cellCount < 128u) return false;
+    const char* v = getenv("EM2_SCAN_MODE");
+    if (v && v[0] == 't') return true;
+    if (v && (v[0] == 's' || v[0] == 'p')) return false;
+    return cellCount >= envNumber("EM2_SYMMETRIC_MIN_CELLS", kSymmetricMinCells);
+}
+
+static uint64_t inboxCapacity(uint32_t cellCount)
+{
+    // EM2_INBOX_CAPACITY (entries) is a test knob: tiny pools force the overflow -> ordered-scan fallback.
+    const uint64_t forced = envNumber("EM2_INBOX_CAPACITY", 0);
+    if (forced >= kInboxChunk) return forced < 0xfff00000ull ? forced : 0xfff00000ull;
+    uint64_t cap = uint64_t(cellCount) * envNumber("EM2_INBOX_PER_CELL", 1024);
+    const uint64_t floor = uint64_t(maxResidentWaves()) * kInboxChunk * 2u;      // every wave can hold a chunk
+    if (cap < floor) cap = floor;
+    if (cap > 0xfff00000ull) cap = 0xfff00000ull;
+    return cap;
+}
+
+static size_t inboxSortTempBytes(uint64_t capacity)
+{
+    size_t bytes = 0;
+    uint64_t* none = nullptr;
+    if (rocprim::radix_sort_keys(nullptr, bytes, none, none, size_t(capacity), 0u, 64u, hipStream_t(nullptr)) != hipSuccess) return 0;
+    return bytes;
+}
+
+struct SymmetricLayout {
+    size_t snap, table, control, poolA, poolB, temp, total, tempBytes;
+    uint64_t capacity;
+};
+
+static SymmetricLayout symmetricLayout(uint32_t cellCount)
+{
+    SymmetricLayout l;
+    l.capacity = inboxCapacity(cellCount);
+    l.tempBytes = inboxSortTempBytes(l.capacity);
+    size_t at = 0;
+    l.snap = at;    at += align256(size_t(cellCount) * 4u);
+    l.table = at;   at += align256((2u * kMaxSegments + 2u) * 4u);
+    l.control = at; at += 256u;
+    l.poolA = at;   at += align256(size_t(l.capacity) * 8u);
+    l.poolB = at;   at += align256(size_t(l.capacity) * 8u);
+    l.temp = at;    at += align256(l.tempBytes);
+    l.total = at;
+    return l;
+}
+
+size_t fsp4SymmetricBytes(uint32_t cellCount, uint32_t rowCount)
+{
+    if (!symmetricEligible(cellCount, rowCount)) return 0;
+    return symmetricLayout(cellCount).total;
+}
+
+// Resident waves of a persistent-style launch of `kernel` (min(occupancy, 4 waves per SIMD) x CUs).
+static hipError_t residentWaveSlots(const void* kernel, uint32_t wavesPerBlock, size_t lds, uint32_t* slots)
+{
+    int device = 0, cuCount = 0, blocksPerCu = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cuCount, hipDeviceAttributeMultiprocessorCount, device);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCu, kernel, int(64u * wavesPerBlock), lds);
+    if (e != hipSuccess) return e;
+    if (blocksPerCu < 1) blocksPerCu = 1;
+    int wanted = int(16u / wavesPerBlock);
+    if (wanted < 1) wanted = 1;
+    const char* v = getenv("EM2_BLOCKS_PER_CU");
+    if (v && atoi(v) >= 1) wanted = atoi(v);
+    if (wanted < blocksPerCu) blocksPerCu = wanted;
+    *slots = uint32_t(cuCount) * uint32_t(blocksPerCu) * wavesPerBlock;
+    return hipSuccess;
+}
+
+// The symmetric scan (see fsp4ScanSymmetricKernel).  *done = false when the inbox pool overflowed: nothing usable
+// was produced and the caller runs the ordered scan instead.  Synchronises the stream (the sort size is read back).
+static hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identity, uint32_t wavesPerBlock,
+                                          size_t lds, void* control, void* symmetricWs, hipStream_t stream, bool* done)
+{
+    *done = false;
+    const uint32_t cellCount = args.cellCount;
+    const uint32_t rowBlocks = args.rowBlocks;
+    const void* kernel = nullptr;
+#define EM2_SYMMETRIC(W32) \
+    (identity ? reinterpret_cast<const void*>(&fsp4ScanSymmetricKernel<W32, true>) \
+              : reinterpret_cast<const void*>(&fsp4ScanSymmetricKernel<W32, false>))
+    switch (paddedDw) {
+    case 2: kernel = EM2_SYMMETRIC(2); break;
+    case 4: kernel = EM2_SYMMETRIC(4); break;
+    case 8: kernel = EM2_SYMMETRIC(8); break;
+    case 16: kernel = EM2_SYMMETRIC(16); break;
+    case 32: kernel = EM2_SYMMETRIC(32); break;
+    case 64: kernel = EM2_SYMMETRIC(64); break;
+    case 128: kernel = EM2_SYMMETRIC(128); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef EM2_SYMMETRIC
+    uint32_t slots = 0;
+    hipError_t e = residentWaveSlots(kernel, wavesPerBlock, lds, &slots);
+    if (e != hipSuccess) return e;
+
+    // Cells below c0 scan all columns themselves (EM2_FULL_ROW_CELLS, default 16384 but at most 1/8 of the cells).
+    uint64_t fullCells = envNumber("EM2_FULL_ROW_CELLS", 16384);
+    if (getenv("EM2_FULL_ROW_CELLS") == nullptr && fullCells > cellCount / 8u) fullCells = cellCount / 8u;
+    uint32_t fullRowBlocks = uint32_t((fullCells + 63u) / 64u);
+    if (fullRowBlocks > rowBlocks) fullRowBlocks = rowBlocks;
+
+    // Segments: as many as the column-count floor allows, up to kMaxSegments (EM2_SEGMENTS overrides): short
+    // segments keep the column snapshots fresh and even out the triangle.
+    uint64_t minSegmentColumns = envNumber("EM2_MIN_SEGMENT_COLUMNS", 4096);
+    if (minSegmentColumns < 1) minSegmentColumns = 1;
+    uint64_t segments = cellCount / minSegmentColumns;
+    if (segments > kMaxSegments) segments = kMaxSegments;
+    const uint64_t forcedSegments = envNumber("EM2_SEGMENTS", 0);
+    if (forcedSegments >= 1 && forcedSegments <= kMaxSegments) segments = forcedSegments;
+    if (segments < 1) segments = 1;
+    const uint32_t cps = uint32_t((uint64_t(cellCount) + segments - 1u) / segments);
+    segments = (uint64_t(cellCount) + cps - 1u) / cps;
+
+    uint32_t table[2u * kMaxSegments + 2u];
+    uint64_t tickets = 0;
+    for (uint32_t sIdx = 0; sIdx < segments; ++sIdx) {
+        uint32_t firstTriangle = uint32_t((uint64_t(sIdx) * cps) / 64u);
+        if (firstTriangle < fullRowBlocks) firstTriangle = fullRowBlocks;
+        table[sIdx] = uint32_t(tickets);
+        table[segments + 1u + sIdx] = firstTriangle;
+        tickets += fullRowBlocks + (rowBlocks - firstTriangle);
+        if (tickets >= 0xffffffffull) return hipErrorInvalidValue;
+    }
+    table[segments] = uint32_t(tickets);
+
+    const SymmetricLayout layout = symmetricLayout(cellCount);
+    char* ws = static_cast<char*>(symmetricWs);
+    char* c = static_cast<char*>(control);
+    const size_t stateBytes = align256(size_t(rowBlocks) * 64u * 8u);
+    const size_t doneBytes = align256(size_t(rowBlocks) * 4u);
+    args.rowState = reinterpret_cast<uint32_t*>(c);
+    args.segmentsDone = reinterpret_cast<uint32_t*>(c + stateBytes);
+    args.control = reinterpret_cast<uint32_t*>(c + stateBytes + doneBytes);
+    args.logs = reinterpret_cast<Entry*>(c + stateBytes + doneBytes + 256u);
+    args.logCapacity = kLogCapacity;
+    if (const char* v = getenv("EM2_LOG_CAPACITY")) {
+        if (atoi(v) >= 1 && uint32_t(atoi(v)) < kLogCapacity) args.logCapacity = uint32_t(atoi(v));
+    }
+    args.segments = uint32_t(segments);
+    args.columnsPerSegment = cps;
+    args.snap = reinterpret_cast<int32_t*>(ws + layout.snap);
+    args.inbox = reinterpret_cast<uint64_t*>(ws + layout.poolA);
+    args.inboxControl = reinterpret_cast<uint32_t*>(ws + layout.control);
+    args.segTable = reinterpret_cast<const uint32_t*>(ws + layout.table);
+    args.inboxCapacity = layout.capacity;
+    args.inboxChunk = kInboxChunk;
+    args.fullRowBlocks = fullRowBlocks;
+    uint32_t rowBits = 1;
+    while ((1ull << rowBits) < uint64_t(cellCount)) ++rowBits;
+    args.rowBits = rowBits;
+    args.totalTickets = uint32_t(tickets);
+
+    e = hipMemsetAsync(c + stateBytes, 0, doneBytes + 256u, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws + layout.control, 0, 256u, stream);
+    if (e != hipSuccess) return e;
+    const size_t fullCellsClamped = size_t(fullRowBlocks) * 64u < cellCount ? size_t(fullRowBlocks) * 64u : cellCount;
+    if (fullCellsClamped) {
+        e = hipMemsetAsync(args.snap, 0xff, fullCellsClamped * 4u, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (cellCount > fullCellsClamped) {
+        e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(args.snap + fullCellsClamped), args.mMaxInitial,
+                              cellCount - fullCellsClamped, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (getenv("EM2_DEBUG_NO_EMIT")) {      // timing experiment only: results are wrong
+        e = hipMemsetAsync(args.snap, 0xff, size_t(cellCount) * 4u, stream);
+        if (e != hipSuccess) return e;
+    }
+    e = hipMemcpyAsync(ws + layout.table, table, (2u * segments + 2u) * 4u, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+
+    uint64_t wavesWanted = tickets;
+    if (wavesWanted > slots) wavesWanted = slots;
+    if (wavesWanted > maxResidentWaves()) wavesWanted = maxResidentWaves();
+    const dim3 block(64u * wavesPerBlock);
+    const dim3 grid(uint32_t((wavesWanted + wavesPerBlock - 1u) / wavesPerBlock));
+    void* kernelArgsArray[] = {&args};
+    e = hipLaunchKernel(kernel, grid, block, kernelArgsArray, lds, stream);
+    if (e != hipSuccess) return e;
+
+    // the number of inbox entries (incl. chunk tails), the overflow flag and the hand-off error word
+    uint32_t inboxWords[4] = {0, 0, 0, 0};
+    uint32_t controlWords[2] = {0, 0};
+    e = hipMemcpyAsync(inboxWords, ws + layout.control, sizeof(inboxWords), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(controlWords, args.control, sizeof(controlWords), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    if (controlWords[1] != 0u) {
+        *done = true;       // a hand-off timed out: the error word stays set for readFsp4Error
+        return hipSuccess;
+    }
+    const uint64_t used = uint64_t(inboxWords[0]) | (uint64_t(inboxWords[1]) << 32);
+    if (inboxWords[2] != 0u || used > layout.capacity) return hipSuccess;      // overflow: *done stays false
+    if (const char* v = getenv("EM2_SCAN_VERBOSE")) {
+        if (v[0] == '1') fprintf(stderr, "[em2] symmetric scan: %u segments x %u columns, %u full-row blocks, %llu tickets, %llu inbox slots\n",
+                                 uint32_t(segments), cps, fullRowBlocks, (unsigned long long)tickets, (unsigned long long)used);
+    }
+
+    const uint64_t* sorted = args.inbox;
+    if (used) {
+        size_t tempBytes = layout.tempBytes;
+        uint64_t* out = reinterpret_cast<uint64_t*>(ws + layout.poolB);
+        e = rocprim::radix_sort_keys(ws + layout.temp, tempBytes, args.inbox, out, size_t(used), 13u, 13u + 2u * rowBits, stream);
+        if (e != hipSuccess) return e;
+        sorted = out;
+    }
+    if (rowBlocks > fullRowBlocks) {
+        const uint32_t waves = rowBlocks - fullRowBlocks;
+        const dim3 rgrid((waves + wavesPerBlock - 1u) / wavesPerBlock);
+        if (identity) fsp4InboxReplayKernel<true><<<rgrid, block, lds, stream>>>(args, sorted, used);
+        else fsp4InboxReplayKernel<false><<<rgrid, block, lds, stream>>>(args, sorted, used);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    *done = true;
+    return hipSuccess;
+}
+
 hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cellCount, uint32_t rowBegin,
                           uint32_t rowEnd, uint32_t k, const DeviceTables& t, Entry* buffers, PairOut* outPairs,
-                          uint32_t* outUsed, void* control, hipStream_t stream)
+                          uint32_t* outUsed, void* control, hipStream_t stream, void* symmetricWs)
 {
     if (rowEnd <= rowBegin) return hipSuccess;
     if (k == 0 || k > fsp4MaxK()) return hipErrorInvalidValue;
@@ -670,6 +1439,24 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     args.columnsPerSegment = cellCount;
     args.logCapacity = 0;
     args.logs = nullptr;
+    args.snap = nullptr;
+    args.inbox = nullptr;
+    args.inboxControl = nullptr;
+    args.segTable = nullptr;
+    args.inboxCapacity = 0;
+    args.inboxChunk = 0;
+    args.fullRowBlocks = 0;
+    args.rowBits = 0;
+    args.totalTickets = 0;
+
+    if (control && symmetricWs && rowBegin == 0 && symmetricEligible(cellCount, rows)) {
+        bool done = false;
+        const hipError_t es = launchFsp4ScanSymmetric(args, paddedDw, identity, wavesPerBlock,
+                                                      size_t(wavesPerBlock) * bytesPerWave, control, symmetricWs, stream, &done);
+        if (es != hipSuccess) return es;
+        if (done) return hipSuccess;
+        // inbox overflow: fall through to the ordered scan, which starts from scratch
+    }
 
     if (scanModeIsSimple() || !control) {
         uint32_t rowsPerLane = forcedRowsPerLane();

@@ -106,7 +106,8 @@ def scan_knobs():
     """Set / restore the scan kernel's test knobs (read with getenv at every launch)."""
     import os
     saved = {k: os.environ.get(k) for k in ("EM2_MIN_SEGMENT_COLUMNS", "EM2_LOG_CAPACITY", "EM2_SCAN_MODE",
-                                             "EM2_BLOCKS_PER_CU")}
+                                             "EM2_BLOCKS_PER_CU", "EM2_FULL_ROW_CELLS", "EM2_SEGMENTS",
+                                             "EM2_INBOX_CAPACITY", "EM2_SYMMETRIC_MIN_CELLS")}
 
     def set_knobs(**kw):
         for key, value in kw.items():
@@ -151,4 +152,87 @@ def test_fsp4_repeated_runs_are_identical(scan_knobs):
     for blocks in (1, 2, 4):
         scan_knobs(EM2_BLOCKS_PER_CU=blocks)
         again = capi.find_similar_pairs4(sig, 512, 50, 0.2)
+        assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])
+
+
+# ---- the symmetric (each unordered pair once) scan: EM2_SCAN_MODE=triangle forces it at test sizes ----
+
+@pytest.mark.parametrize("n,L,k,thr,kind", CASES)
+def test_fsp4_symmetric_matches_oracle(oracle, scan_knobs, n, L, k, thr, kind):
+    sig = make(n, L, kind)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_MIN_SEGMENT_COLUMNS=64, EM2_FULL_ROW_CELLS=64)
+    pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+@pytest.mark.parametrize("full_rows,min_cols,log_cap", [(0, 64, None), (0, 100, 2), (64, 64, 3), (200, 257, 1),
+                                                         (640, 1000, None), (100000, 64, None)])
+@pytest.mark.parametrize("n,L,k,thr,kind", [(1200, 1024, 25, 0.2, "clustered"), (2000, 256, 7, -0.5, "clustered"),
+                                             (900, 128, 3, 0.0, "random"), (1537, 2048, 10, 0.1, "clustered"),
+                                             (777, 64, 300, -1.0, "random")])
+def test_fsp4_symmetric_layouts(oracle, scan_knobs, full_rows, min_cols, log_cap, n, L, k, thr, kind):
+    """Full-row prefix sizes (none .. everything), segment lengths that do and do not divide the block size,
+    tiny speculative logs: the symmetric scan's result must not depend on any of it."""
+    sig = make(n, L, kind)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_MIN_SEGMENT_COLUMNS=min_cols, EM2_FULL_ROW_CELLS=full_rows,
+               EM2_LOG_CAPACITY=log_cap)
+    pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+@pytest.mark.parametrize("L", [1, 64, 65, 192, 512, 1000, 3000, 4096])
+def test_fsp4_symmetric_signature_widths(oracle, scan_knobs, L):
+    sig = synth.clustered_signatures(333, L, cluster_count=3, flip=0.2, seed=L)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, 6, 0.1)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_MIN_SEGMENT_COLUMNS=50, EM2_FULL_ROW_CELLS=0)
+    pairs, gused = capi.find_similar_pairs4(sig, L, 6, 0.1)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+def test_fsp4_symmetric_identical_cells_and_increasing_similarity(oracle, scan_knobs):
+    """All-equal cells (every candidate ties) and the adversarial order in which every later cell is a better
+    match than all earlier ones (every candidate is accepted: the inbox takes the whole upper triangle)."""
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_MIN_SEGMENT_COLUMNS=64, EM2_FULL_ROW_CELLS=0)
+    sig = np.tile(synth.random_signatures(1, 256, seed=3), (700, 1))
+    cell, sim, used = oracle.find_similar_pairs4(sig, 256, 8, 0.2)
+    pairs, gused = capi.find_similar_pairs4(sig, 256, 8, 0.2)
+    assert_same(pairs, gused, cell, sim, used)
+    # cell i = the last cell with (n-1-i) low bits flipped: similarity to later cells grows with the id
+    n, L = 600, 1024
+    base = synth.random_signatures(1, L, seed=9)[0]
+    sig = np.tile(base, (n, 1))
+    for i in range(n):
+        flips = n - 1 - i
+        for b in range(flips):
+            sig[i, b // 64] ^= np.uint64(1) << np.uint64(b % 64)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, 5, 0.0)
+    pairs, gused = capi.find_similar_pairs4(sig, L, 5, 0.0)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+def test_fsp4_symmetric_inbox_overflow_falls_back(oracle, scan_knobs):
+    sig = make(2000, 256, "clustered")
+    cell, sim, used = oracle.find_similar_pairs4(sig, 256, 7, -0.5)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_MIN_SEGMENT_COLUMNS=64, EM2_FULL_ROW_CELLS=0, EM2_INBOX_CAPACITY=1024)
+    pairs, gused = capi.find_similar_pairs4(sig, 256, 7, -0.5)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+def test_fsp4_symmetric_sampled_rows_and_repeatability(oracle, scan_knobs):
+    n, L, k, thr = 20000, 1024, 100, 0.2
+    sig = synth.clustered_signatures(n, L, cluster_count=16, flip=0.15, seed=99)
+    scan_knobs(EM2_SCAN_MODE="persistent")
+    ordered = capi.find_similar_pairs4(sig, L, k, thr)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_FULL_ROW_CELLS=1024)
+    first = capi.find_similar_pairs4(sig, L, k, thr)
+    assert np.array_equal(first[0], ordered[0]) and np.array_equal(first[1], ordered[1])
+    for begin in (0, 1000, 6400, 19900):
+        end = min(n, begin + 60)
+        cell, sim, used = oracle.find_similar_pairs4_rows(sig, L, k, thr, begin, end)
+        assert_same(first[0][begin:end], first[1][begin:end], cell, sim, used)
+    for blocks, segments in ((1, 7), (2, 64), (4, 33)):
+        scan_knobs(EM2_BLOCKS_PER_CU=blocks, EM2_SEGMENTS=segments, EM2_MIN_SEGMENT_COLUMNS=64)
+        again = capi.find_similar_pairs4(sig, L, k, thr)
         assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])

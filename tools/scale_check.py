@@ -3,6 +3,8 @@
 
     python3 tools/scale_check.py fsp5   # BASELINE configs[3] shape: 1M cells, 2048 bit, lshSliceLength 20
     python3 tools/scale_check.py fsp4w  # findSimilarPairs4 at 2048 bit, 200k cells
+    CELLS=1000000 LSH=1024 SWEEP="EM2_SCAN_MODE=persistent;EM2_SEGMENTS=32,EM2_FULL_ROW_CELLS=8192" \
+        python3 tools/scale_check.py sweep   # scan-only timings under different EM2_* knobs, each parity-checked
 
 Signatures are synthetic (64 cluster centres, each bit flipped with probability 0.15), generated in HBM with
 torch.  Sampled cells are compared bit-for-bit with the CPU oracle; timings are printed as JSON."""
@@ -95,6 +97,35 @@ def main():
                           "ordered_comparisons_per_s": cells * cells / min(times), "sampled_rows_bit_exact": ok}))
         if not ok:
             raise SystemExit("PARITY FAILURE")
+    elif what == "sweep":
+        cells, L, k, thr = int(os.environ.get("CELLS", 1000000)), int(os.environ.get("LSH", 1024)), 100, 0.2
+        sig = clustered_signatures_gpu(cells, L)
+        host = sig.cpu().numpy().view(np.uint64)
+        sample = [0, cells // 2, cells - 24]
+        expected = [oracle.find_similar_pairs4_rows(host, L, k, thr, b, b + 24) for b in sample]
+        d_pairs = torch.zeros((cells, k, 2), dtype=torch.int32, device="cuda")
+        d_used = torch.zeros(cells, dtype=torch.int32, device="cuda")
+        for config in os.environ.get("SWEEP", "").split(";"):
+            knobs = dict(item.split("=", 1) for item in config.split(",") if "=" in item)
+            os.environ.update(knobs)
+            ws_bytes = capi.dev_find_similar_pairs4_workspace(cells, cells, L, k)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+            times = []
+            for _ in range(int(os.environ.get("REPEATS", 2))):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                capi.dev_find_similar_pairs4(sig.data_ptr(), cells, 0, cells, L, k, thr, d_pairs.data_ptr(),
+                                             d_used.data_ptr(), ws.data_ptr(), ws_bytes, stream)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            ok = all(compare(d_pairs, d_used, c, s_, u, slice(b, b + 24)) for b, (c, s_, u) in zip(sample, expected))
+            print(json.dumps({"check": "sweep", "cells": cells, "lsh_count": L, "knobs": knobs, "ms": [round(t * 1e3, 2) for t in times],
+                              "unordered_pairs_per_s": cells * (cells - 1) / 2 / min(times), "sampled_rows_bit_exact": ok}), flush=True)
+            del ws
+            for key in knobs:
+                os.environ.pop(key, None)
+            if not ok and "EM2_DEBUG_NO_EMIT" not in knobs:
+                raise SystemExit("PARITY FAILURE")
 
 
 if __name__ == "__main__":
