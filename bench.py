@@ -168,12 +168,17 @@ def main():
 
     total_pairs = C * (C - 1) / 2.0
     value = total_pairs * args.steps / elapsed
-    # scan kernel of THIS rank: rows*(C-1) ordered comparisons = rows*(C-1)/2 unordered pairs' worth of work
+    # The scan of THIS rank handles rows*(C-1)/2 unordered pairs' worth of the job (its share of N(N-1)/2).  In the
+    # ordered form that is rows*C comparisons by the kernel; in the symmetric form (1 GPU, all rows in one launch)
+    # every unordered pair is evaluated once.  The library reports what it ran.
+    launch = capi.dev_find_similar_pairs4_last_launch()
+    symmetric = launch["form"] == 1
+    kernel_ms = launch["scan_kernel_ms"] if symmetric and launch["scan_kernel_ms"] > 0 else scan_ms
     launch_pairs = pipe.rows * (C - 1) / 2.0
     algorithmic_bytes = launch_pairs * 16.0 * W
-    achieved = algorithmic_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms else 0.0
-    lane_ops = pipe.rows * float(C) * 4.0 * W          # (v_xor + v_bcnt) per 32 bits per ordered comparison
-    valu_frac = lane_ops / (scan_ms * 1e-3) / VALU_LANE_OPS_PER_S if scan_ms else 0.0
+    achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
+    lane_ops = launch["wave_column_steps"] * 64.0 * 4.0 * W      # (v_xor + v_bcnt) per 32 bits per (lane, column)
+    valu_frac = lane_ops / (kernel_ms * 1e-3) / VALU_LANE_OPS_PER_S if kernel_ms else 0.0
 
     # HBM-side traffic of one scan launch from the PMC counters, when a profile of THIS configuration has been
     # collected (rocprofv3 --pmc runs are separate from timing runs; see the file for the command and caveats).
@@ -185,7 +190,8 @@ def main():
         cfg = prof.get("config", {})
         if (cfg.get("cells"), cfg.get("genes"), cfg.get("lsh_count"), cfg.get("k"), cfg.get("n_gpus")) == (C, G, L, k, world):
             t = prof["per_launch_bytes"]["fsp4ScanKernel"]
-            traffic = t["fetch"] + t["write"]
+            if prof.get("form", "ordered") == ("symmetric" if symmetric else "ordered"):
+                traffic = t["fetch"] + t["write"]
 
     result = {
         "metric": "cell-pair Hamming comparisons/sec (whole node), findSimilarPairs4 incl. signature projection",
@@ -210,7 +216,12 @@ def main():
         "phases_ms_rank0": {"projection": proj_ms, "scan": scan_ms},
         "roofline": {
             "kernel": ("fsp4ScanKernel<%d,...>" if os.environ.get("EM2_SCAN_MODE") == "simple"
+                       else "fsp4ScanSymmetricKernel<%d,true>" if symmetric
                        else "fsp4ScanPersistentKernel<%d,true>") % (2 * W),
+            "kernel_ms": kernel_ms,
+            "form": "symmetric: every unordered pair evaluated once; inbox sort + replay follow the kernel"
+                    if symmetric else "ordered: every row of the shard against every column",
+            "inbox_entries": launch["inbox_entries"] if symmetric else None,
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -222,7 +233,9 @@ def main():
             "algorithmic_bytes": algorithmic_bytes,
             "valu_frac": valu_frac,
             "note": "algorithmic bytes = 16*W per unordered pair; operands are cache/SGPR resident so frac is not "
-                    "bounded by 1; valu_frac = (v_xor+v_bcnt lane-ops)/(256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz), the measured issue rate of these ops",
+                    "bounded by 1; valu_frac = (v_xor+v_bcnt lane-ops actually executed)/(256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz), "
+                    "the measured issue rate of these ops; kernel_ms = HIP events on the launch stream around the scan kernel "
+                    "(recorded inside the library for the symmetric form, around the call otherwise)",
         },
         "parity_check": check,
     }

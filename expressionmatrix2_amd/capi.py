@@ -50,6 +50,8 @@ SYMBOLS = {
     "em2_dev_find_similar_pairs4": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                                _c.c_uint32, _c.c_double, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                _c.c_size_t, _c.c_void_p]),
+    "em2_dev_find_similar_pairs4_form": (_c.c_int, [_c.c_uint32, _c.c_uint32]),
+    "em2_dev_find_similar_pairs4_last_launch": (_c.c_int, [_c.c_void_p, _c.c_uint32]),
     "em2_dev_find_similar_pairs4_status": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p]),
     "em2_dev_find_similar_pairs5": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                                _c.c_uint32, _c.c_double, _c.c_uint32, _c.c_uint64, _c.c_void_p,
@@ -244,6 +246,19 @@ def cell_graph_edges(pairs, used_count, similar_pairs_cell_set, graph_cell_set, 
 
 def dev_find_similar_pairs4_workspace(cell_count, row_count, lsh_count, k):
     return int(load().em2_dev_find_similar_pairs4_workspace(cell_count, row_count, lsh_count, k))
+
+
+def dev_find_similar_pairs4_form(cell_count, row_count):
+    """1 if the scan of this shape runs in its symmetric (each unordered pair once) form, else 0."""
+    return int(load().em2_dev_find_similar_pairs4_form(cell_count, row_count))
+
+
+def dev_find_similar_pairs4_last_launch():
+    """dict(form, scan_kernel_ms, wave_column_steps, inbox_entries, segments, full_row_cells) of the last launch."""
+    v = np.zeros(6, dtype=np.float64)
+    check(load().em2_dev_find_similar_pairs4_last_launch(_ptr(v), 6))
+    return {"form": int(v[0]), "scan_kernel_ms": float(v[1]), "wave_column_steps": float(v[2]),
+            "inbox_entries": float(v[3]), "segments": int(v[4]), "full_row_cells": int(v[5])}
 
 
 def dev_find_similar_pairs4(sig_ptr, cell_count, row_begin, row_end, lsh_count, k, similarity_threshold,

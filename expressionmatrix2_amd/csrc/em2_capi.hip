@@ -282,6 +282,22 @@ size_t em2_dev_find_similar_pairs4_workspace(uint32_t cellCount, uint32_t rowCou
 }
 
 
+int em2_dev_find_similar_pairs4_form(uint32_t cellCount, uint32_t rowCount)
+{
+    return em2::fsp4UsesSymmetricScan(cellCount, rowCount) ? 1 : 0;
+}
+
+
+int em2_dev_find_similar_pairs4_last_launch(double* values, uint32_t valueCount)
+{
+    if (!values && valueCount) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs4_last_launch: null pointer");
+    const em2::Fsp4LaunchInfo info = em2::fsp4LastLaunchInfo();
+    const double all[6] = {double(info.form), info.scanKernelMs, info.waveColumnSteps, info.inboxEntries, info.segments, info.fullRowCells};
+    for (uint32_t i = 0; i < valueCount; i++) values[i] = i < 6 ? all[i] : 0.0;
+    return EM2_OK;
+}
+
+
 int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount, uint32_t rowBegin,
                                 uint32_t rowEnd, uint32_t lshCount, uint32_t k, double similarityThreshold,
                                 em2_pair* d_pairs, uint32_t* d_usedCount, void* d_workspace,

@@ -55,6 +55,16 @@ size_t fsp4ControlBytes(uint32_t rowCount);
 // Extra scratch for the symmetric (each unordered pair once) form of the scan, which launchFsp4Scan uses when all
 // rows of the problem are in one launch and this workspace is given; 0 when that form would not be used.
 size_t fsp4SymmetricBytes(uint32_t cellCount, uint32_t rowCount);
+bool fsp4UsesSymmetricScan(uint32_t cellCount, uint32_t rowCount);
+struct Fsp4LaunchInfo {
+    int form;                 // 0 ordered rows x columns, 1 symmetric
+    double scanKernelMs;      // duration of the scan kernel proper when the launcher measured it (symmetric form), else -1
+    double waveColumnSteps;   // (64-row wave, column) steps executed: x 64 lanes x 2*W32 = v_xor/v_bcnt lane-ops
+    double inboxEntries;      // symmetric form: entries (incl. chunk padding) sorted and replayed
+    double segments;
+    double fullRowCells;
+};
+Fsp4LaunchInfo fsp4LastLaunchInfo();      // of the calling thread's last launchFsp4Scan
 hipError_t readFsp4Error(const void* control, uint32_t rowCount, hipStream_t stream, uint32_t* error);
 
 // ExpressionMatrixSubset::computeSums (sum1 only) -> mean = sum1 / geneCount, per cell.

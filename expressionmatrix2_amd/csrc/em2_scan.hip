@@ -1224,6 +1224,11 @@ static SymmetricLayout symmetricLayout(uint32_t cellCount)
     return l;
 }
 
+bool fsp4UsesSymmetricScan(uint32_t cellCount, uint32_t rowCount)
+{
+    return symmetricEligible(cellCount, rowCount);
+}
+
 size_t fsp4SymmetricBytes(uint32_t cellCount, uint32_t rowCount)
 {
     if (!symmetricEligible(cellCount, rowCount)) return 0;
@@ -1249,6 +1254,11 @@ static hipError_t residentWaveSlots(const void* kernel, uint32_t wavesPerBlock, 
     *slots = uint32_t(cuCount) * uint32_t(blocksPerCu) * wavesPerBlock;
     return hipSuccess;
 }
+
+// What the last launch on this thread did (benchmarks and logs): see em2_dev_find_similar_pairs4_last_launch.
+static thread_local Fsp4LaunchInfo lastLaunchInfo = {0, -1.0, 0.0, 0.0, 0.0, 0.0};
+
+Fsp4LaunchInfo fsp4LastLaunchInfo() { return lastLaunchInfo; }
 
 // The symmetric scan (see fsp4ScanSymmetricKernel).  *done = false when the inbox pool overflowed: nothing usable
 // was produced and the caller runs the ordered scan instead.  Synchronises the stream (the sort size is read back).
@@ -1277,9 +1287,14 @@ static hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool
     hipError_t e = residentWaveSlots(kernel, wavesPerBlock, lds, &slots);
     if (e != hipSuccess) return e;
 
-    // Cells below c0 scan all columns themselves (EM2_FULL_ROW_CELLS, default 16384 but at most 1/8 of the cells).
-    uint64_t fullCells = envNumber("EM2_FULL_ROW_CELLS", 16384);
-    if (getenv("EM2_FULL_ROW_CELLS") == nullptr && fullCells > cellCount / 8u) fullCells = cellCount / 8u;
+    // Cells below c0 scan all columns themselves.  Default max(4096, 32k), at most 1/8 of the cells: the snapshots of
+    // cells with fewer than ~k similar lower neighbours filter nothing.  Measured at 1M cells (64 clusters, k=100):
+    // c0 = 0 / 4096 / 16384 / 65536 -> 1088* / 932 / 940 / 1170* ms (* before the call-free loop).  EM2_FULL_ROW_CELLS
+    // overrides (tests use 0 .. everything).
+    uint64_t fullCells = 32ull * args.k;
+    if (fullCells < 4096) fullCells = 4096;
+    if (fullCells > cellCount / 8u) fullCells = cellCount / 8u;
+    fullCells = envNumber("EM2_FULL_ROW_CELLS", fullCells);
     uint32_t fullRowBlocks = uint32_t((fullCells + 63u) / 64u);
     if (fullRowBlocks > rowBlocks) fullRowBlocks = rowBlocks;
 
@@ -1361,8 +1376,14 @@ static hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool
     const dim3 block(64u * wavesPerBlock);
     const dim3 grid(uint32_t((wavesWanted + wavesPerBlock - 1u) / wavesPerBlock));
     void* kernelArgsArray[] = {&args};
+    static thread_local hipEvent_t timing[2] = {nullptr, nullptr};
+    if (!timing[0]) {
+        if (hipEventCreate(&timing[0]) != hipSuccess || hipEventCreate(&timing[1]) != hipSuccess) timing[0] = timing[1] = nullptr;
+    }
+    if (timing[0]) (void)hipEventRecord(timing[0], stream);
     e = hipLaunchKernel(kernel, grid, block, kernelArgsArray, lds, stream);
     if (e != hipSuccess) return e;
+    if (timing[0]) (void)hipEventRecord(timing[1], stream);
 
     // the number of inbox entries (incl. chunk tails), the overflow flag and the hand-off error word
     uint32_t inboxWords[4] = {0, 0, 0, 0};
@@ -1379,6 +1400,21 @@ static hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool
     }
     const uint64_t used = uint64_t(inboxWords[0]) | (uint64_t(inboxWords[1]) << 32);
     if (inboxWords[2] != 0u || used > layout.capacity) return hipSuccess;      // overflow: *done stays false
+    {
+        float ms = -1.0f;
+        if (!timing[0] || hipEventElapsedTime(&ms, timing[0], timing[1]) != hipSuccess) ms = -1.0f;
+        double steps = double(fullRowBlocks) * double(cellCount);       // (wave, column) steps of the scan kernel
+        for (uint32_t b = fullRowBlocks; b < rowBlocks; ++b) {
+            const uint64_t end = uint64_t(b) * 64u + 64u;
+            steps += double(end < cellCount ? end : cellCount);
+        }
+        lastLaunchInfo.form = 1;
+        lastLaunchInfo.scanKernelMs = double(ms);
+        lastLaunchInfo.waveColumnSteps = steps;
+        lastLaunchInfo.inboxEntries = double(used);
+        lastLaunchInfo.segments = double(segments);
+        lastLaunchInfo.fullRowCells = double(fullCellsClamped);
+    }
     if (const char* v = getenv("EM2_SCAN_VERBOSE")) {
         if (v[0] == '1') fprintf(stderr, "[em2] symmetric scan: %u segments x %u columns, %u full-row blocks, %llu tickets, %llu inbox slots\n",
                                  uint32_t(segments), cps, fullRowBlocks, (unsigned long long)tickets, (unsigned long long)used);
@@ -1457,6 +1493,13 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
         if (done) return hipSuccess;
         // inbox overflow: fall through to the ordered scan, which starts from scratch
     }
+
+    lastLaunchInfo.form = 0;
+    lastLaunchInfo.scanKernelMs = -1.0;
+    lastLaunchInfo.waveColumnSteps = double(rowBlocks) * double(cellCount);
+    lastLaunchInfo.inboxEntries = 0.0;
+    lastLaunchInfo.segments = 1.0;
+    lastLaunchInfo.fullRowCells = double(rows);
 
     if (scanModeIsSimple() || !control) {
         uint32_t rowsPerLane = forcedRowsPerLane();
@@ -1557,6 +1600,7 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     }
     args.segments = uint32_t(segments);
     args.columnsPerSegment = columnsPerSegment;
+    lastLaunchInfo.segments = double(segments);
     e = hipMemsetAsync(c + stateBytes, 0, doneBytes + 256u, stream);
     if (e != hipSuccess) return e;
 

@@ -124,6 +124,18 @@ int em2_dev_compute_signatures(const uint64_t* d_toc, const em2_count* d_data, u
 size_t em2_dev_find_similar_pairs4_workspace(uint32_t cellCount, uint32_t rowCount, uint32_t lshCount,
                                              uint32_t k);
 
+/* Which form of the scan em2_dev_find_similar_pairs4 runs for this shape -- information for benchmarks and logs, the
+ * results are identical.  0: every row of the launch is compared with every column (cellCount*rowCount ordered
+ * comparisons).  1: symmetric form, used when one launch holds all rows of a large problem: every unordered pair is
+ * evaluated once, as in the reference's own loop (src/ExpressionMatrixLsh.cpp:218-263), and offered to both cells. */
+int em2_dev_find_similar_pairs4_form(uint32_t cellCount, uint32_t rowCount);
+
+/* Facts about the calling thread's last em2_dev_find_similar_pairs4 launch, for benchmarks: values[0] form (as above),
+ * [1] duration in ms of the scan kernel proper when the launcher measured it with HIP events on the launch stream
+ * (symmetric form, which synchronises anyway), else -1, [2] (64-row wave, column) steps executed, [3] symmetric
+ * form: inbox entries sorted and replayed, [4] column segments, [5] cells whose rows scanned all columns. */
+int em2_dev_find_similar_pairs4_last_launch(double* values, uint32_t valueCount);
+
 /* findSimilarPairs4 for the rows [rowBegin,rowEnd) of the cell set against all cellCount cells: the shard
  * one rank owns.  d_signatures holds ALL cellCount signatures (after the all-gather).  d_pairs has
  * (rowEnd-rowBegin)*k slots and d_usedCount (rowEnd-rowBegin) entries, indexed by row-rowBegin.
