@@ -121,18 +121,24 @@ def main():
         if not np.array_equal(expect, got):
             raise SystemExit("PARITY FAILURE: signatures differ from the oracle")
         check["signature_cells"] = sample
-        # scan: sampled rows of this rank against all columns
-        pairs, used = pipe.results()
-        span = max(1, min(args.check_rows // 3, pipe.rows))
-        for begin in sorted(set([0, max(0, pipe.rows // 2 - span // 2), max(0, pipe.rows - span)])):
-            end = min(pipe.rows, begin + span)
-            cell, sim, oused = oracle.find_similar_pairs4_rows(sig_host, L, k, thr, pipe.row_begin + begin,
-                                                               pipe.row_begin + end)
-            ok = (np.array_equal(used[begin:end], oused) and np.array_equal(pairs["cell"][begin:end], cell) and
-                  np.array_equal(pairs["similarity"][begin:end].view(np.uint32), sim.view(np.uint32)))
-            if not ok:
-                raise SystemExit("PARITY FAILURE: SimilarPairs rows %d..%d differ from the oracle" % (begin, end))
-            check["fsp4_rows"] += end - begin
+        # scan: sampled rows this rank owns against all columns
+        ranges = pipe.owned_ranges()
+        span = max(1, args.check_rows // 3)
+        picks = [ranges[i] for i in sorted(set([0, len(ranges) // 2, len(ranges) - 1]))] if ranges else []
+        for r_begin, r_end in picks:
+            for begin in sorted(set([r_begin, max(r_begin, (r_begin + r_end) // 2 - span // 2), max(r_begin, r_end - span)])):
+                end = min(r_end, begin + span)
+                if end <= begin:
+                    continue
+                pairs, used = pipe.results_for(begin, end)
+                cell, sim, oused = oracle.find_similar_pairs4_rows(sig_host, L, k, thr, begin, end)
+                ok = (np.array_equal(used, oused) and np.array_equal(pairs["cell"], cell) and
+                      np.array_equal(pairs["similarity"].view(np.uint32), sim.view(np.uint32)))
+                if not ok:
+                    raise SystemExit("PARITY FAILURE: SimilarPairs rows %d..%d differ from the oracle" % (begin, end))
+                check["fsp4_rows"] += end - begin
+                if len(picks) > 1:
+                    break           # block-sized ranges: one sample each
 
     # ---- warmup + timed steps ----
     for _ in range(args.warmup):
@@ -173,8 +179,9 @@ def main():
     # every unordered pair is evaluated once.  The library reports what it ran.
     launch = capi.dev_find_similar_pairs4_last_launch()
     symmetric = launch["form"] == 1
+    sharded_symmetric = launch["form"] == 2
     kernel_ms = launch["scan_kernel_ms"] if symmetric and launch["scan_kernel_ms"] > 0 else scan_ms
-    launch_pairs = pipe.rows * (C - 1) / 2.0
+    launch_pairs = total_pairs / world if sharded_symmetric else pipe.rows * (C - 1) / 2.0
     algorithmic_bytes = launch_pairs * 16.0 * W
     achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
     lane_ops = launch["wave_column_steps"] * 64.0 * 4.0 * W      # (v_xor + v_bcnt) per 32 bits per (lane, column)
@@ -212,16 +219,21 @@ def main():
                         % (C, G, args.density * G, L, k, thr, world),
             "cells": C, "genes": G, "lsh_count": L, "k": k, "similarity_threshold": thr,
             "rows_per_gpu": pipe.shard, "nnz_rank0": nnz_local,
+            "scan": "sharded-symmetric" if sharded_symmetric else "symmetric" if symmetric else "row-shards",
         },
         "phases_ms_rank0": {"projection": proj_ms, "scan": scan_ms},
         "roofline": {
             "kernel": ("fsp4ScanKernel<%d,...>" if os.environ.get("EM2_SCAN_MODE") == "simple"
                        else "fsp4ScanSymmetricKernel<%d,true>" if symmetric
+                       else "fsp4ScanSymmetricKernel<%d,true> + fsp4TileKernel" if sharded_symmetric
                        else "fsp4ScanPersistentKernel<%d,true>") % (2 * W),
             "kernel_ms": kernel_ms,
             "form": "symmetric: every unordered pair evaluated once; inbox sort + replay follow the kernel"
-                    if symmetric else "ordered: every row of the shard against every column",
-            "inbox_entries": launch["inbox_entries"] if symmetric else None,
+                    if symmetric else
+                    "sharded symmetric: every unordered pair evaluated once across the ranks (blocks dealt round-robin; "
+                    "2 all_reduce + 1 all_gather inside the scan time)" if sharded_symmetric
+                    else "ordered: every row of the shard against every column",
+            "inbox_entries": launch["inbox_entries"] if (symmetric or sharded_symmetric) else None,
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

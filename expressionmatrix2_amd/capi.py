@@ -52,6 +52,13 @@ SYMBOLS = {
                                                _c.c_size_t, _c.c_void_p]),
     "em2_dev_find_similar_pairs4_form": (_c.c_int, [_c.c_uint32, _c.c_uint32]),
     "em2_dev_find_similar_pairs4_last_launch": (_c.c_int, [_c.c_void_p, _c.c_uint32]),
+    "em2_dev_fsp4_sharded_plan": (_c.c_int, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
+                                             _c.c_void_p, _c.c_uint32]),
+    "em2_dev_fsp4_sharded_phase": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_double,
+                                              _c.c_uint32, _c.c_uint32, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                              _c.c_size_t, _c.c_uint64, _c.c_void_p]),
+    "em2_dev_fsp4_sharded_status": (_c.c_int, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_void_p,
+                                               _c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint32)]),
     "em2_dev_find_similar_pairs4_status": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p]),
     "em2_dev_find_similar_pairs5": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                                _c.c_uint32, _c.c_double, _c.c_uint32, _c.c_uint64, _c.c_void_p,
@@ -266,6 +273,30 @@ def dev_find_similar_pairs4(sig_ptr, cell_count, row_begin, row_end, lsh_count, 
     check(load().em2_dev_find_similar_pairs4(sig_ptr, cell_count, row_begin, row_end, lsh_count, k,
                                              similarity_threshold, pairs_ptr, used_ptr, workspace_ptr,
                                              workspace_bytes, stream))
+
+
+def dev_fsp4_sharded_plan(cell_count, lsh_count, k, rank, world):
+    """Layout of one rank's workspace for the sharded symmetric scan (see include/em2_lsh.h)."""
+    v = np.zeros(10, dtype=np.uint64)
+    check(load().em2_dev_fsp4_sharded_plan(cell_count, lsh_count, k, rank, world, _ptr(v), 10))
+    names = ("eligible", "workspace_bytes", "snap_offset", "pool_offset", "pool_capacity", "gathered_offset",
+             "gathered_capacity", "prefix_cells", "own_blocks", "blocks")
+    return {name: int(x) for name, x in zip(names, v)}
+
+
+def dev_fsp4_sharded_phase(phase, sig_ptr, cell_count, lsh_count, k, similarity_threshold, rank, world, pairs_ptr,
+                           used_ptr, workspace_ptr, workspace_bytes, gathered_count, stream):
+    check(load().em2_dev_fsp4_sharded_phase(phase, sig_ptr, cell_count, lsh_count, k, similarity_threshold, rank, world,
+                                            pairs_ptr, used_ptr, workspace_ptr, workspace_bytes, gathered_count, stream))
+
+
+def dev_fsp4_sharded_status(cell_count, k, rank, world, workspace_ptr, stream):
+    """(entries in this rank's pool, overflow flag); synchronises the stream."""
+    used = ctypes.c_uint64(0)
+    overflow = ctypes.c_uint32(0)
+    check(load().em2_dev_fsp4_sharded_status(cell_count, k, rank, world, workspace_ptr, stream, ctypes.byref(used),
+                                             ctypes.byref(overflow)))
+    return int(used.value), int(overflow.value)
 
 
 def dev_find_similar_pairs4_status(workspace_ptr, row_count, k, stream):

@@ -342,6 +342,83 @@ int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount
 }
 
 
+// ---- sharded symmetric scan: one call per phase, the collectives between them are the caller's ----
+
+static size_t shardedRepackBytes(uint32_t cellCount, uint32_t lshCount)
+{
+    const uint32_t padded = em2::paddedDwords(lshCount);
+    return padded != 2u * wordCountOf(lshCount) ? alignUp(size_t(cellCount) * padded * sizeof(uint32_t)) : 0;
+}
+
+int em2_dev_fsp4_sharded_plan(uint32_t cellCount, uint32_t lshCount, uint32_t k, uint32_t rank, uint32_t world,
+                              uint64_t* values, uint32_t valueCount)
+{
+    if (!values && valueCount) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_fsp4_sharded_plan: null pointer");
+    uint64_t all[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t padded = lshCount ? em2::paddedDwords(lshCount) : 0;
+    if (padded != 0 && k != 0 && k <= em2::fsp4MaxK() && world >= 1 && rank < world) {
+        const em2::Fsp4ShardPlan plan = em2::fsp4ShardPlan(cellCount, k, rank, world);
+        if (plan.eligible) {
+            all[0] = 1;
+            all[1] = alignUp(plan.totalBytes) + shardedRepackBytes(cellCount, lshCount) + 256;
+            all[2] = plan.offSnap;
+            all[3] = plan.offPool;
+            all[4] = plan.capLocal;
+            all[5] = plan.offGathered;
+            all[6] = plan.capGathered;
+            all[7] = plan.prefixCells;
+            all[8] = plan.ownBlocks;
+            all[9] = plan.blocks;
+        }
+    }
+    for (uint32_t i = 0; i < valueCount; i++) values[i] = i < 10 ? all[i] : 0;
+    return EM2_OK;
+}
+
+int em2_dev_fsp4_sharded_phase(int phase, const uint64_t* d_signatures, uint32_t cellCount, uint32_t lshCount, uint32_t k,
+                               double similarityThreshold, uint32_t rank, uint32_t world, em2_pair* d_pairs,
+                               uint32_t* d_usedCount, void* d_workspace, size_t workspaceBytes, uint64_t gatheredCount,
+                               void* stream)
+{
+    if (!d_signatures || !d_pairs || !d_usedCount || !d_workspace) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_fsp4_sharded_phase: null pointer");
+    if (phase < 0 || phase > 3) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_fsp4_sharded_phase: phase must be 0..3");
+    uint64_t values[2] = {0, 0};
+    em2_dev_fsp4_sharded_plan(cellCount, lshCount, k, rank, world, values, 2);
+    if (!values[0]) return fail(EM2_ERROR_UNSUPPORTED, "em2_dev_fsp4_sharded_phase: this shape is not eligible for the sharded symmetric scan");
+    if ((reinterpret_cast<size_t>(d_workspace) & 255u) != 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_fsp4_sharded_phase: the workspace must be 256-byte aligned");
+    if (workspaceBytes < values[1]) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_fsp4_sharded_phase: workspace too small");
+    em2::DeviceTables tables;
+    const int rc = getDeviceTables(lshCount, similarityThreshold, tables);
+    if (rc != EM2_OK) return rc;
+    const em2::Fsp4ShardPlan plan = em2::fsp4ShardPlan(cellCount, k, rank, world);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t padded = em2::paddedDwords(lshCount);
+    const uint32_t words = wordCountOf(lshCount);
+    const uint32_t* sig32 = reinterpret_cast<const uint32_t*>(d_signatures);
+    if (padded != 2u * words) {
+        uint32_t* repacked = reinterpret_cast<uint32_t*>(static_cast<char*>(d_workspace) + alignUp(plan.totalBytes));
+        if (phase == 0) EM2_HIP(em2::launchRepackSignatures(d_signatures, cellCount, words, repacked, padded, s));
+        sig32 = repacked;
+    }
+    EM2_HIP(em2::launchFsp4ShardPhase(plan, phase, sig32, padded, tables, d_workspace,
+                                      static_cast<char*>(d_workspace) + plan.rankBytes,        // gathered / sorted / temp areas
+                                      reinterpret_cast<em2::PairOut*>(d_pairs), d_usedCount, gatheredCount, s));
+    return EM2_OK;
+}
+
+int em2_dev_fsp4_sharded_status(uint32_t cellCount, uint32_t k, uint32_t rank, uint32_t world, const void* d_workspace,
+                                void* stream, uint64_t* usedEntries, uint32_t* overflow)
+{
+    if (!d_workspace || !usedEntries || !overflow) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_fsp4_sharded_status: null pointer");
+    const em2::Fsp4ShardPlan plan = em2::fsp4ShardPlan(cellCount, k, rank, world);
+    if (!plan.eligible) return fail(EM2_ERROR_UNSUPPORTED, "em2_dev_fsp4_sharded_status: this shape is not eligible for the sharded symmetric scan");
+    uint32_t error = 0;
+    EM2_HIP(em2::readFsp4ShardStatus(plan, d_workspace, static_cast<hipStream_t>(stream), usedEntries, overflow, &error));
+    if (error) return fail(EM2_ERROR_RUNTIME, "findSimilarPairs4: a segment hand-off between waves timed out; the result is incomplete");
+    return EM2_OK;
+}
+
+
 int em2_dev_find_similar_pairs4_status(const void* d_workspace, uint32_t rowCount, uint32_t k, void* stream)
 {
     if (!d_workspace) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs4_status: null workspace");

@@ -67,6 +67,23 @@ struct Fsp4LaunchInfo {
 Fsp4LaunchInfo fsp4LastLaunchInfo();      // of the calling thread's last launchFsp4Scan
 hipError_t readFsp4Error(const void* control, uint32_t rowCount, hipStream_t stream, uint32_t* error);
 
+// Sharded symmetric scan (em2_scan.hip): plan of one rank, one launch per phase; the collectives between the phases
+// belong to the caller.
+struct Fsp4ShardPlan {
+    bool eligible;
+    uint32_t cellCount, world, rank, k;
+    uint32_t blocks, prefixBlocks, prefixCells, ownBlocks, maxOwnBlocks, ownPrefixBlocks;
+    uint64_t capLocal, capGathered;
+    size_t sortTempBytes;
+    size_t offLists, offControl, offSnap, offTable, offInboxControl, offPool, rankBytes, offGathered, offSorted, offTemp, totalBytes;
+};
+Fsp4ShardPlan fsp4ShardPlan(uint32_t cellCount, uint32_t k, uint32_t rank, uint32_t world);
+hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint32_t* sig32, uint32_t paddedDw,
+                                const DeviceTables& tables, void* rankWs, void* exchangeWs, PairOut* outPairs,
+                                uint32_t* outUsed, uint64_t gatheredCount, hipStream_t stream);
+hipError_t readFsp4ShardStatus(const Fsp4ShardPlan& plan, const void* rankWs, hipStream_t stream, uint64_t* used,
+                               uint32_t* overflow, uint32_t* error);
+
 // ExpressionMatrixSubset::computeSums (sum1 only) -> mean = sum1 / geneCount, per cell.
 hipError_t launchCellMeans(const uint64_t* toc, const CountIn* data, uint32_t cellCount, uint32_t geneCount,
                            double* means, hipStream_t stream);

@@ -27,6 +27,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -107,7 +108,18 @@ struct Fsp4Args {
     uint32_t fullRowBlocks;     // row blocks [0, fullRowBlocks) scan every column themselves
     uint32_t rowBits;           // bits of a cell id in an inbox key
     uint32_t totalTickets;
+    // row-block mapping (sharded symmetric scan; 1 / 0 / 0 / cellCount / 0 everywhere else): list / state slot b of
+    // this launch holds the 64 cells starting at rowBegin + (b * rowBlockStride + rowBlockOffset) * 64
+    uint32_t rowBlockStride;
+    uint32_t rowBlockOffset;
+    uint32_t localBlockBase;    // first list / state slot of this launch (symmetric kernels)
+    uint32_t columnLimit;       // columns [0, columnLimit) only (symmetric kernels)
+    uint32_t shardFlags;        // kShardNoFinish | kShardPublishAll | kShardGlobalOutput
 };
+
+constexpr uint32_t kShardNoFinish = 1u;       // full-row blocks publish their state instead of finishing the rows
+constexpr uint32_t kShardPublishAll = 2u;     // full-row blocks publish snapshots as well
+constexpr uint32_t kShardGlobalOutput = 4u;   // outPairs / outUsed are indexed by global cell id
 
 typedef const __attribute__((address_space(4))) Fsp4Args* ArgsPtr;
 
@@ -183,9 +195,10 @@ __device__ __forceinline__ void finishRows(uint32_t lane, uint32_t waveIndex, ui
     ArgsPtr aux = kernelArgs();
     const uint32_t k = aux->k;
     const uint32_t twoK = 2u * k;
-    const uint32_t rowBegin = aux->rowBegin;
     const uint32_t rowEnd = aux->rowEnd;
-    const uint32_t waveRowBase = rowBegin + waveIndex * 64u;
+    const uint32_t waveRowBase = aux->rowBegin + (waveIndex * aux->rowBlockStride + aux->rowBlockOffset) * 64u;
+    // output slot of the wave's first row: its position in the launch, or its global id (sharded scan)
+    const uint32_t outBase = (aux->shardFlags & kShardGlobalOutput) ? waveRowBase : waveIndex * 64u;
     Entry* const waveBuffers = aux->buffers + size_t(waveIndex) * 64u * twoK;
     Entry* lds = reinterpret_cast<Entry*>(ldsRaw + size_t(threadIdx.x >> 6) * twoK * kLdsBytesPerEntrySlot);
     const float* keySimilarity = aux->keySimilarity;
@@ -202,7 +215,7 @@ __device__ __forceinline__ void finishRows(uint32_t lane, uint32_t waveIndex, ui
             for (uint32_t i = lane; i < n; i += 64u) lds[i] = loadEntryCoherent(g + i);
             waveLdsFence();
         }
-        PairOut* out = aux->outPairs + size_t(srow - rowBegin) * k;
+        PairOut* out = aux->outPairs + size_t(outBase + src) * k;
         for (uint32_t i = lane; i < n; i += 64u) {
             const Entry e = lds[i];
             uint32_t rank = 0;
@@ -221,7 +234,7 @@ __device__ __forceinline__ void finishRows(uint32_t lane, uint32_t waveIndex, ui
             zero.similarity = 0.0f;
             out[i] = zero;
         }
-        if (lane == 0u) aux->outUsed[srow - rowBegin] = n;
+        if (lane == 0u) aux->outUsed[outBase + src] = n;
         waveLdsFence();
     }
 }
@@ -843,21 +856,24 @@ fsp4ScanSymmetricKernel(Fsp4Args args)
             while (ticket >= table[seg + 1u]) ++seg;
             const uint32_t local = ticket - table[seg];
             const uint32_t fullBlocks = aux->fullRowBlocks;
-            const uint32_t block = local < fullBlocks ? local : table[segments + 1u + seg] + (local - fullBlocks);
-            uint32_t flags = block >= fullBlocks ? kItemTriangle : 0u;
-            const uint32_t rowBase = block * 64u;
+            // slot = list / state slot of the launch; its 64 cells start at rowBase (block-cyclic in the sharded scan)
+            const uint32_t relative = local < fullBlocks ? local : table[segments + 1u + seg] + (local - fullBlocks);
+            const uint32_t block = aux->localBlockBase + relative;
+            uint32_t flags = relative >= fullBlocks ? kItemTriangle : 0u;
+            const uint32_t rowBase = (block * aux->rowBlockStride + aux->rowBlockOffset) * 64u;
             twoK = parkInVgpr(2u * aux->k);
             logCapacity = parkInVgpr(aux->logCapacity);
             myList = aux->buffers + (size_t(block) * 64u + lane) * twoK;
             myLog = aux->logs + (size_t(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane) * logCapacity;
             const uint32_t cps = aux->columnsPerSegment;
+            const uint32_t columnLimit = aux->columnLimit;
             const uint32_t colBegin = seg * cps;
             uint32_t colEnd = colBegin + cps;
-            if (colEnd > cellCount || seg + 1u == segments) colEnd = cellCount;
+            if (colEnd > columnLimit || seg + 1u == segments) colEnd = columnLimit;
             if (seg + 1u == segments) flags |= kItemLast;
             if (flags & kItemTriangle) {
                 uint32_t diagEnd = rowBase + 64u;
-                if (diagEnd > cellCount) diagEnd = cellCount;
+                if (diagEnd > columnLimit) diagEnd = columnLimit;
                 if (diagEnd <= colEnd) {
                     colEnd = diagEnd;
                     flags |= kItemLast;
@@ -901,7 +917,7 @@ fsp4ScanSymmetricKernel(Fsp4Args args)
             } else {                                                                                                        \
                 for (;;) {                                                                                                  \
                     const uint32_t colEndT_ = unpark(colEndV);                                                              \
-                    const uint32_t rowBaseT_ = unpark(blockV) * 64u;                                                        \
+                    const uint32_t rowBaseT_ = (unpark(blockV) * kernelArgs()->rowBlockStride + kernelArgs()->rowBlockOffset) * 64u;                                                        \
                     const uint32_t triEnd_ = colEndT_ < rowBaseT_ ? colEndT_ : rowBaseT_;                                   \
                     if (at_ >= triEnd_) break;                                                                              \
                     ensureInboxRoom(lane, emitPos, emitEnd);                                                                \
@@ -918,7 +934,7 @@ fsp4ScanSymmetricKernel(Fsp4Args args)
                     at_ = unpark(atV_);                                                                                     \
                 }                                                                                                           \
                 const uint32_t colEnd2_ = unpark(colEndV);                                                                  \
-                const uint32_t rowBase2_ = unpark(blockV) * 64u;                                                            \
+                const uint32_t rowBase2_ = (unpark(blockV) * kernelArgs()->rowBlockStride + kernelArgs()->rowBlockOffset) * 64u;                                                            \
                 const uint32_t triEnd2_ = colEnd2_ < rowBase2_ ? colEnd2_ : rowBase2_;                                      \
                 if (at_ >= triEnd2_) {                                                                                      \
                     const uint32_t colBegin2_ = unpark(colBeginV);                                                          \
@@ -994,13 +1010,14 @@ fsp4ScanSymmetricKernel(Fsp4Args args)
             ArgsPtr aux = kernelArgs();
             const uint32_t block = unpark(blockV);
             const uint32_t flags = unpark(flagsV);
-            if (!(flags & kItemTriangle) && (flags & kItemLast)) {
+            const uint32_t shardFlags = aux->shardFlags;
+            if (!(flags & kItemTriangle) && (flags & kItemLast) && !(shardFlags & kShardNoFinish)) {
                 finishRows(lane, block, count, ldsRaw);
             } else {
                 const uint64_t st = uint64_t(count) | (uint64_t(uint32_t(mMax)) << 32);
                 __hip_atomic_store(reinterpret_cast<uint64_t*>(aux->rowState) + size_t(block) * 64u + lane, st,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((flags & kItemTriangle) && rowValid) {
+                if (((flags & kItemTriangle) || (shardFlags & kShardPublishAll)) && rowValid) {
                     __hip_atomic_store(aux->snap + row, mMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1032,9 +1049,11 @@ fsp4InboxReplayKernel(Fsp4Args args, const uint64_t* __restrict__ sorted, uint64
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t block = args.fullRowBlocks + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // slots [replayBegin, replayEnd) = [localBlockBase + fullRowBlocks, rowBlocks) (full-row blocks of the
+    // one-GPU form are finished by the scan kernel itself)
+    const uint32_t block = args.localBlockBase + args.fullRowBlocks + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (block >= args.rowBlocks) return;
-    const uint32_t row = block * 64u + lane;
+    const uint32_t row = (block * args.rowBlockStride + args.rowBlockOffset) * 64u + lane;
     const bool rowValid = row < args.rowEnd;
     uint32_t twoK = 2u * args.k;
     Entry* myList = args.buffers + (size_t(block) * 64u + lane) * twoK;
@@ -1072,6 +1091,202 @@ fsp4InboxReplayKernel(Fsp4Args args, const uint64_t* __restrict__ sorted, uint64
         }
     }
     finishRows(lane, block, count, ldsRaw);
+}
+
+// =========================================================================================================
+// Sharded symmetric scan, third phase: the square of the non-prefix cells, [M,N) x [M,N), lower triangle.
+//
+// By now every cell holds a true snapshot of its cut-off (its state after the M prefix candidates, exchanged
+// between the ranks), so BOTH sides of a pair can be deferred: a tile is 64 rows x one column segment, belongs to
+// no cell in particular, keeps no per-row state and depends on nothing -- tiles are dealt round-robin to the ranks
+// (tile L goes to rank L % world) and to the waves of a rank through a ticket counter.  A pair (r, c), c < r, with
+// mismatch m emits (target c, candidate r) if m <= snap[c] and (target r, candidate c) if m <= snap[r].
+// Kernel-argument reuse: columnLimit = M, rowBlocks = number of 64-cell blocks of the whole problem,
+// rowBlockStride / rowBlockOffset = world / rank, segTable = first tile and first block of every column segment,
+// segments / columnsPerSegment = the segmentation of [M,N), totalTickets = tiles of this rank.
+// =========================================================================================================
+template <int W32>
+__device__ __forceinline__ uint32_t scanTileEmit(const uint32_t* __restrict__ sig32, const int32_t* snap, uint32_t colBegin,
+                                                 uint32_t colEnd, const uint32_t (&r)[W32], uint32_t row, bool rowValid,
+                                                 int32_t snapRow, uint32_t lane, uint32_t& emitPos, uint32_t emitEnd)
+{
+    constexpr int CH = W32 < 32 ? W32 : 32;
+    constexpr int H = W32 / CH;
+    constexpr int U = 2 * H;
+    if (colBegin >= colEnd) return colEnd;
+    ScalarPtr p = (ScalarPtr)(uintptr_t)sig32 + size_t(colBegin) * W32;
+    ScalarIntPtr sp = (ScalarIntPtr)(uintptr_t)snap + colBegin;
+    uint32_t chunk[2][CH];
+    int32_t snapCol[2];
+#pragma unroll
+    for (int w = 0; w < CH; ++w) chunk[0][w] = p[w];
+    snapCol[0] = sp[0];
+    snapCol[1] = 0;
+    __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
+    uint32_t m = 0;
+    for (uint32_t colBase = colBegin; colBase < colEnd; colBase += 2u) {
+#pragma unroll
+        for (int s = 0; s < U; ++s) {
+            const int part = s % H;
+            const int ci = s / H;
+            const uint32_t col = colBase + uint32_t(ci);
+            if (col < colEnd) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
+                __builtin_amdgcn_sched_barrier(0);
+                const bool lastChunk = (col + 1u == colEnd) && (part == H - 1);
+                ScalarPtr pn = lastChunk ? p : p + CH;
+#pragma unroll
+                for (int w = 0; w < CH; ++w) chunk[(s + 1) & 1][w] = pn[w];
+                p = pn;
+                if (part == H - 1) {
+                    ScalarIntPtr spn = lastChunk ? sp : sp + 1;
+                    snapCol[ci ^ 1] = spn[0];
+                    sp = spn;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int w = 0; w < CH; ++w) popcountAccumulate(m, r[part * CH + w] ^ chunk[s & 1][w]);
+                if (part == H - 1) {
+                    int32_t limit = snapRow > snapCol[ci] ? snapRow : snapCol[ci];
+                    asm volatile("" : "+v"(limit));
+                    if (__builtin_amdgcn_ballot_w64(int32_t(m) <= limit) != 0ull) {
+                        const bool toCol = rowValid && int32_t(m) <= snapCol[ci];
+                        const bool toRow = rowValid && int32_t(m) <= snapRow;
+                        const uint64_t maskCol = __builtin_amdgcn_ballot_w64(toCol);
+                        const uint64_t maskRow = __builtin_amdgcn_ballot_w64(toRow);
+                        const uint32_t at = uint32_t(__builtin_amdgcn_readfirstlane(int(emitPos)));
+                        if ((maskCol | maskRow) != 0ull && at <= uint32_t(__builtin_amdgcn_readfirstlane(int(emitEnd)))) {
+                            ArgsPtr aux = kernelArgs();
+                            const uint32_t nb = aux->rowBits;
+                            const uint32_t nCol = uint32_t(__builtin_popcountll(maskCol));
+                            if (toCol) {
+                                aux->inbox[at + lanesBelow(maskCol)] =
+                                    (uint64_t(col) << (13u + nb)) | (uint64_t(row) << 13u) | uint64_t(m);
+                            }
+                            if (toRow) {
+                                aux->inbox[at + nCol + lanesBelow(maskRow)] =
+                                    (uint64_t(row) << (13u + nb)) | (uint64_t(col) << 13u) | uint64_t(m);
+                            }
+                            emitPos = at + nCol + uint32_t(__builtin_popcountll(maskRow));
+                            if (inboxRoom(emitPos, emitEnd) < 128u) return col + 1u;
+                        }
+                    }
+                    m = 0;
+                }
+            }
+        }
+    }
+    return colEnd;
+}
+
+// Makes sure the chunk has room for one more column's worth of tile entries (2 per lane).
+__device__ __forceinline__ void ensureInboxRoomForTile(uint32_t lane, uint32_t& emitPos, uint32_t& emitEnd)
+{
+    if (inboxRoom(emitPos, emitEnd) >= 128u) return;
+    ArgsPtr aux = kernelArgs();
+    const uint32_t p = uint32_t(__builtin_amdgcn_readfirstlane(int(emitPos)));
+    const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(emitEnd)));
+    const uint64_t fresh = refillInboxChunk(aux->inbox, aux->inboxControl, aux->inboxCapacity, aux->inboxChunk, lane, p, e);
+    emitPos = uint32_t(fresh);
+    emitEnd = uint32_t(fresh >> 32);
+}
+
+template <int W32>
+__global__ void __launch_bounds__(256)
+fsp4TileKernel(Fsp4Args args)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t emitPos = 0, emitEnd = 0;
+    for (;;) {
+        uint32_t ticket = 0;
+        if (lane == 0u) {
+            ticket = __hip_atomic_fetch_add(kernelArgs()->control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ticket = uint32_t(__builtin_amdgcn_readfirstlane(int(ticket)));
+        uint32_t colBeginV, colEndV, rowBaseV;
+        uint32_t row;
+        uint32_t r[W32];
+        int32_t snapRow;
+        bool rowValid;
+        {
+            ArgsPtr aux = kernelArgs();
+            if (ticket >= aux->totalTickets) break;
+            const uint32_t cellCount = aux->cellCount;
+            const uint32_t segments = aux->segments;
+            const uint32_t* table = aux->segTable;
+            const uint32_t tile = ticket * aux->rowBlockStride + aux->rowBlockOffset;     // round-robin over the ranks
+            uint32_t lo = 0, hi = segments;              // last segment whose first tile is <= tile
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) / 2u;
+                if (table[mid] <= tile) lo = mid;
+                else hi = mid;
+            }
+            const uint32_t seg = lo;
+            const uint32_t block = table[segments + 1u + seg] + (tile - table[seg]);
+            const uint32_t rowBase = block * 64u;
+            const uint32_t colBegin = aux->columnLimit + seg * aux->columnsPerSegment;
+            uint32_t colEnd = colBegin + aux->columnsPerSegment;
+            uint32_t diagEnd = rowBase + 64u;
+            if (diagEnd > cellCount) diagEnd = cellCount;
+            if (colEnd > diagEnd) colEnd = diagEnd;
+            row = rowBase + lane;
+            rowValid = row < cellCount;
+            const uint32_t* rp = aux->sig32 + size_t(rowValid ? row : rowBase) * W32;
+#pragma unroll
+            for (int w = 0; w < W32; ++w) r[w] = rp[w];
+            snapRow = rowValid ? aux->snap[row] : -1;
+            colBeginV = parkInVgpr(colBegin);
+            colEndV = parkInVgpr(colEnd);
+            rowBaseV = parkInVgpr(rowBase);
+        }
+        // columns strictly below the block
+        uint32_t at = unpark(colBeginV);
+        for (;;) {
+            const uint32_t colEnd = unpark(colEndV);
+            const uint32_t rowBase = unpark(rowBaseV);
+            const uint32_t triEnd = colEnd < rowBase ? colEnd : rowBase;
+            if (at >= triEnd) break;
+            ensureInboxRoomForTile(lane, emitPos, emitEnd);
+            at = scanTileEmit<W32>(kernelArgs()->sig32, kernelArgs()->snap, at, triEnd, r, row, rowValid, snapRow, lane,
+                                   emitPos, emitEnd);
+        }
+        // the block's own cells: pair (row, col) belongs to the lane with row > col
+        {
+            const uint32_t colEnd = unpark(colEndV);
+            const uint32_t rowBase = unpark(rowBaseV);
+            const uint32_t colBegin = unpark(colBeginV);
+            const uint32_t* sig32 = kernelArgs()->sig32;
+            const int32_t* snap = kernelArgs()->snap;
+            for (uint32_t col = colBegin > rowBase ? colBegin : rowBase; col < colEnd; ++col) {
+                ScalarPtr cp = (ScalarPtr)(uintptr_t)sig32 + size_t(col) * W32;
+                uint32_t m = 0;
+#pragma unroll
+                for (int w = 0; w < W32; ++w) popcountAccumulate(m, r[w] ^ cp[w]);
+                const int32_t snapCol = snap[col];
+                const bool lower = rowValid && col < row;
+                emitColumn(lower && int32_t(m) <= snapCol, col, row, m, lane, emitPos, emitEnd);      // target col
+                emitColumn(lower && int32_t(m) <= snapRow, row, col, m, lane, emitPos, emitEnd);      // target row
+            }
+        }
+    }
+    {
+        const uint32_t p = uint32_t(__builtin_amdgcn_readfirstlane(int(emitPos)));
+        const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(emitEnd)));
+        if (p <= e) {
+            uint64_t* inbox = kernelArgs()->inbox;
+            for (uint32_t i = p + lane; i < e; i += 64u) inbox[i] = ~0ull;
+        }
+    }
+}
+
+// max over `count` arrays of `n` int32 laid out back to back (the emulation's stand-in for all_reduce(MAX))
+__global__ void maxReduceKernel(int32_t* __restrict__ arrays, uint32_t n, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t best = arrays[i];
+    for (uint32_t a = 1; a < count; ++a) best = arrays[size_t(a) * n + i] > best ? arrays[size_t(a) * n + i] : best;
+    for (uint32_t a = 0; a < count; ++a) arrays[size_t(a) * n + i] = best;
 }
 
 __global__ void repackSignaturesKernel(const uint64_t* __restrict__ src, uint32_t cellCount, uint32_t wordCount,
@@ -1440,6 +1655,426 @@ static hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool
     return hipSuccess;
 }
 
+// =========================================================================================================
+// Sharded symmetric scan (one process per GPU; the collectives between the phases are the caller's, see
+// expressionmatrix2_amd/sharded.py; runFsp4ShardedEmulation below plays all ranks on one GPU for the tests).
+//
+// 64-cell blocks are dealt to the ranks round-robin (block g belongs to rank g % world, where it is list / state
+// slot g / world), so every rank holds rows of every part of the triangle.  The first M = prefixBlocks*64 cells are
+// the PREFIX.
+//   phase 0  own prefix blocks x columns [0,M): ordered in-lane scan (every pair of prefix cells is evaluated from
+//            both sides: M^2 instead of M^2/2, 2% of the job at M = N/5); snapshots snap[c], c < M.
+//            -> all_reduce(MAX) of snap
+//   phase 1  own other blocks x columns [0,M): in-lane scan of the rows (their first M candidates), entries
+//            (target c < M, candidate r) filtered by snap[c];  snapshots snap[r], r >= M.
+//            -> all_reduce(MAX) of snap
+//   phase 2  tiles of [M,N)^2 dealt round-robin (fsp4TileKernel): both sides deferred, filtered by the snapshots.
+//            -> all_gather of the ranks' entry pools
+//   phase 3  sort all entries by (target, candidate), replay own slots, finish own rows (global output index).
+// Every cell is offered its candidates in ascending order: in-lane part first (columns < M), then its inbox.
+// =========================================================================================================
+
+static uint64_t shardCapLocal(uint32_t cellCount, uint32_t world)
+{
+    const uint64_t forced = envNumber("EM2_INBOX_CAPACITY", 0);
+    if (forced >= kInboxChunk) return forced;
+    uint64_t cap = uint64_t(cellCount) * envNumber("EM2_INBOX_PER_CELL", 1024) / world;
+    cap += cap / 4u;
+    const uint64_t floor = uint64_t(maxResidentWaves()) * kInboxChunk * 2u;
+    if (cap < floor) cap = floor;
+    if (cap > 0xfff00000ull) cap = 0xfff00000ull;
+    return cap;
+}
+
+Fsp4ShardPlan fsp4ShardPlan(uint32_t cellCount, uint32_t k, uint32_t rank, uint32_t world)
+{
+    Fsp4ShardPlan p;
+    memset(&p, 0, sizeof(p));
+    p.cellCount = cellCount;
+    p.world = world;
+    p.rank = rank;
+    p.k = k;
+    p.blocks = (cellCount + 63u) / 64u;
+    if (world == 0 || rank >= world || k == 0 || p.blocks < 4u * world) return p;     // not eligible: too small
+    // prefix: EM2_PREFIX_PERMILLE of the cells (default 200), a positive multiple of `world` blocks
+    uint64_t prefixBlocks = (uint64_t(p.blocks) * envNumber("EM2_PREFIX_PERMILLE", 200) / 1000u + world / 2u) / world * world;
+    if (prefixBlocks < world) prefixBlocks = world;
+    if (prefixBlocks > uint64_t(p.blocks) - world) prefixBlocks = (uint64_t(p.blocks) - world) / world * world;
+    p.prefixBlocks = uint32_t(prefixBlocks);
+    p.prefixCells = p.prefixBlocks * 64u;
+    p.ownBlocks = (p.blocks - rank + world - 1u) / world;
+    p.maxOwnBlocks = (p.blocks + world - 1u) / world;
+    p.ownPrefixBlocks = p.prefixBlocks / world;
+    p.capLocal = shardCapLocal(cellCount, world);
+    p.capGathered = p.capLocal * world;
+    p.sortTempBytes = inboxSortTempBytes(p.capGathered);
+    size_t at = 0;
+    p.offLists = at;        at += align256(size_t(p.maxOwnBlocks) * 64u * 2u * k * sizeof(Entry));
+    p.offControl = at;      at += align256(fsp4ControlBytes(p.maxOwnBlocks * 64u));
+    p.offSnap = at;         at += align256(size_t(cellCount) * 4u);
+    p.offTable = at;        at += align256((2u * 256u + 2u) * 4u);
+    p.offInboxControl = at; at += 256u;
+    p.offPool = at;         at += align256(size_t(p.capLocal) * 8u);
+    p.rankBytes = at;
+    p.offGathered = at;     at += align256(size_t(p.capGathered) * 8u);
+    p.offSorted = at;       at += align256(size_t(p.capGathered) * 8u);
+    p.offTemp = at;         at += align256(p.sortTempBytes);
+    p.totalBytes = at;
+    p.eligible = true;
+    return p;
+}
+
+static const void* symmetricKernelFor(uint32_t paddedDw, bool identity)
+{
+#define EM2_SYMMETRIC(W32) \
+    (identity ? reinterpret_cast<const void*>(&fsp4ScanSymmetricKernel<W32, true>) \
+              : reinterpret_cast<const void*>(&fsp4ScanSymmetricKernel<W32, false>))
+    switch (paddedDw) {
+    case 2: return EM2_SYMMETRIC(2);
+    case 4: return EM2_SYMMETRIC(4);
+    case 8: return EM2_SYMMETRIC(8);
+    case 16: return EM2_SYMMETRIC(16);
+    case 32: return EM2_SYMMETRIC(32);
+    case 64: return EM2_SYMMETRIC(64);
+    case 128: return EM2_SYMMETRIC(128);
+    default: return nullptr;
+    }
+#undef EM2_SYMMETRIC
+}
+
+static const void* tileKernelFor(uint32_t paddedDw)
+{
+    switch (paddedDw) {
+    case 2: return reinterpret_cast<const void*>(&fsp4TileKernel<2>);
+    case 4: return reinterpret_cast<const void*>(&fsp4TileKernel<4>);
+    case 8: return reinterpret_cast<const void*>(&fsp4TileKernel<8>);
+    case 16: return reinterpret_cast<const void*>(&fsp4TileKernel<16>);
+    case 32: return reinterpret_cast<const void*>(&fsp4TileKernel<32>);
+    case 64: return reinterpret_cast<const void*>(&fsp4TileKernel<64>);
+    case 128: return reinterpret_cast<const void*>(&fsp4TileKernel<128>);
+    default: return nullptr;
+    }
+}
+
+// rankWs = the rank part of the workspace (plan.rankBytes), exchangeWs = gathered / sorted / temp areas (in the real
+// multi-GPU run both are one allocation: exchangeWs = rankWs; the emulation shares one exchange area).
+// gatheredCount: phase 3 only, entries in the gathered area.  outPairs / outUsed are indexed by GLOBAL cell id.
+hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint32_t* sig32, uint32_t paddedDw,
+                                const DeviceTables& t, void* rankWs, void* exchangeWs, PairOut* outPairs, uint32_t* outUsed,
+                                uint64_t gatheredCount, hipStream_t stream)
+{
+    if (!plan.eligible) return hipErrorInvalidValue;
+    const uint32_t k = plan.k;
+    if (k == 0 || k > fsp4MaxK()) return hipErrorInvalidValue;
+    const uint32_t bytesPerWave = 2u * k * kLdsBytesPerEntrySlot;
+    uint32_t wavesPerBlock = kLdsBytesPerBlock / bytesPerWave;
+    if (wavesPerBlock > 4) wavesPerBlock = 4;
+    const size_t lds = size_t(wavesPerBlock) * bytesPerWave;
+    const dim3 block(64u * wavesPerBlock);
+    char* ws = static_cast<char*>(rankWs);
+    char* xs = static_cast<char*>(exchangeWs);
+    const uint32_t cellCount = plan.cellCount;
+    const uint32_t M = plan.prefixCells;
+
+    Fsp4Args args;
+    memset(&args, 0, sizeof(args));
+    args.sig32 = sig32;
+    args.cellCount = cellCount;
+    args.mMaxInitial = t.mMaxInitial;
+    args.keyOfMismatch = t.keyOfMismatch;
+    args.acceptMaxByKey = t.acceptMaxByKey;
+    args.keySimilarity = t.keySimilarity;
+    args.buffers = reinterpret_cast<Entry*>(ws + plan.offLists);
+    args.outPairs = outPairs;
+    args.outUsed = outUsed;
+    args.k = k;
+    args.rowBegin = 0;
+    args.rowEnd = cellCount;
+    char* c = ws + plan.offControl;
+    const size_t stateBytes = align256(size_t((plan.maxOwnBlocks * 64u + 63u) / 64u) * 64u * 8u);
+    const size_t doneBytes = align256(size_t((plan.maxOwnBlocks * 64u + 63u) / 64u) * 4u);
+    args.rowState = reinterpret_cast<uint32_t*>(c);
+    args.segmentsDone = reinterpret_cast<uint32_t*>(c + stateBytes);
+    args.control = reinterpret_cast<uint32_t*>(c + stateBytes + doneBytes);
+    args.logs = reinterpret_cast<Entry*>(c + stateBytes + doneBytes + 256u);
+    args.logCapacity = kLogCapacity;
+    if (const char* v = getenv("EM2_LOG_CAPACITY")) {
+        if (atoi(v) >= 1 && uint32_t(atoi(v)) < kLogCapacity) args.logCapacity = uint32_t(atoi(v));
+    }
+    args.snap = reinterpret_cast<int32_t*>(ws + plan.offSnap);
+    args.inbox = reinterpret_cast<uint64_t*>(ws + plan.offPool);
+    args.inboxControl = reinterpret_cast<uint32_t*>(ws + plan.offInboxControl);
+    args.segTable = reinterpret_cast<const uint32_t*>(ws + plan.offTable);
+    args.inboxCapacity = plan.capLocal;
+    args.inboxChunk = kInboxChunk;
+    uint32_t rowBits = 1;
+    while ((1ull << rowBits) < uint64_t(cellCount)) ++rowBits;
+    args.rowBits = rowBits;
+    args.rowBlockStride = plan.world;
+    args.rowBlockOffset = plan.rank;
+    args.columnLimit = M;
+    args.shardFlags = kShardNoFinish | kShardPublishAll | kShardGlobalOutput;
+
+    hipError_t e = hipSuccess;
+    if (phase == 0) {
+        lastLaunchInfo.form = 2;
+        lastLaunchInfo.scanKernelMs = -1.0;
+        lastLaunchInfo.waveColumnSteps = 0.0;
+        lastLaunchInfo.inboxEntries = 0.0;
+        lastLaunchInfo.segments = 0.0;
+        lastLaunchInfo.fullRowCells = double(M);
+    }
+    if (phase == 0 || phase == 1) {
+        if (phase == 0) {
+            e = hipMemsetAsync(args.snap, 0x80, size_t(cellCount) * 4u, stream);        // below every real cut-off
+            if (e != hipSuccess) return e;
+            e = hipMemsetAsync(args.inboxControl, 0, 256u, stream);
+            if (e != hipSuccess) return e;
+        }
+        const uint32_t slotBase = phase == 0 ? 0u : plan.ownPrefixBlocks;
+        const uint32_t slotCount = phase == 0 ? plan.ownPrefixBlocks : plan.ownBlocks - plan.ownPrefixBlocks;
+        if (slotCount == 0) return hipSuccess;
+        const void* kernel = symmetricKernelFor(paddedDw, t.identityKeys);
+        if (!kernel) return hipErrorInvalidValue;
+        uint32_t slots = 0;
+        e = residentWaveSlots(kernel, wavesPerBlock, lds, &slots);
+        if (e != hipSuccess) return e;
+        uint64_t minSegmentColumns = envNumber("EM2_MIN_SEGMENT_COLUMNS", 4096);
+        if (minSegmentColumns < 1) minSegmentColumns = 1;
+        // enough (segment, slot) items for an even finish (~32 per resident wave), at most kMaxSegments
+        uint64_t segments = (32ull * slots + slotCount - 1u) / slotCount;
+        if (segments > M / minSegmentColumns) segments = M / minSegmentColumns;
+        if (segments > kMaxSegments) segments = kMaxSegments;
+        if (segments < 1) segments = 1;
+        const uint32_t cps = uint32_t((uint64_t(M) + segments - 1u) / segments);
+        segments = (uint64_t(M) + cps - 1u) / cps;
+        uint32_t table[2u * kMaxSegments + 2u];
+        for (uint32_t sIdx = 0; sIdx < segments; ++sIdx) {
+            table[sIdx] = sIdx * slotCount;
+            table[segments + 1u + sIdx] = 0u;
+        }
+        const uint64_t tickets = segments * slotCount;
+        if (tickets >= 0xffffffffull) return hipErrorInvalidValue;
+        table[segments] = uint32_t(tickets);
+        args.segments = uint32_t(segments);
+        args.columnsPerSegment = cps;
+        args.localBlockBase = slotBase;
+        args.rowBlocks = slotBase + slotCount;
+        args.fullRowBlocks = phase == 0 ? slotCount : 0u;
+        args.totalTickets = uint32_t(tickets);
+        // hand-off flags and the ticket counter start at zero; the error word survives from phase 0 to phase 1
+        e = hipMemsetAsync(c + stateBytes, 0, doneBytes + (phase == 0 ? 256u : 4u), stream);
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(ws + plan.offTable, table, (2u * segments + 2u) * 4u, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+        lastLaunchInfo.waveColumnSteps += double(slotCount) * double(M);
+        uint64_t wavesWanted = tickets;
+        if (wavesWanted > slots) wavesWanted = slots;
+        if (wavesWanted > maxResidentWaves()) wavesWanted = maxResidentWaves();
+        const dim3 grid(uint32_t((wavesWanted + wavesPerBlock - 1u) / wavesPerBlock));
+        void* kernelArgsArray[] = {&args};
+        return hipLaunchKernel(kernel, grid, block, kernelArgsArray, lds, stream);
+    }
+    if (phase == 2) {
+        const void* kernel = tileKernelFor(paddedDw);
+        if (!kernel) return hipErrorInvalidValue;
+        const uint32_t span = cellCount - M;
+        uint64_t segments = span / 1024u;
+        if (segments > 256) segments = 256;
+        const uint64_t forced = envNumber("EM2_TILE_SEGMENTS", 0);
+        if (forced >= 1 && forced <= 256) segments = forced;
+        if (segments < 1) segments = 1;
+        const uint32_t cps = uint32_t((uint64_t(span) + segments - 1u) / segments);
+        segments = (uint64_t(span) + cps - 1u) / cps;
+        uint32_t table[2u * 256u + 2u];
+        uint64_t tiles = 0;
+        for (uint32_t sIdx = 0; sIdx < segments; ++sIdx) {
+            const uint32_t firstBlock = (M + sIdx * cps) / 64u;
+            table[sIdx] = uint32_t(tiles);
+            table[segments + 1u + sIdx] = firstBlock;
+            tiles += plan.blocks - firstBlock;
+            if (tiles >= 0xffffffffull) return hipErrorInvalidValue;
+        }
+        table[segments] = uint32_t(tiles);
+        const uint64_t own = tiles > plan.rank ? (tiles - plan.rank + plan.world - 1u) / plan.world : 0u;
+        if (own == 0) return hipSuccess;
+        {
+            double steps = 0.0;         // this rank's share of the tiles' (wave, column) steps
+            for (uint32_t b = plan.prefixBlocks; b < plan.blocks; ++b) {
+                const uint64_t end = uint64_t(b) * 64u + 64u;
+                steps += double((end < cellCount ? end : cellCount) - M);
+            }
+            lastLaunchInfo.waveColumnSteps += steps / double(plan.world);
+        }
+        args.segments = uint32_t(segments);
+        args.columnsPerSegment = cps;
+        args.rowBlocks = plan.blocks;
+        args.totalTickets = uint32_t(own);
+        e = hipMemsetAsync(c + stateBytes + doneBytes, 0, 4u, stream);         // ticket counter (the error word stays)
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(ws + plan.offTable, table, (2u * segments + 2u) * 4u, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+        int device = 0, cuCount = 0;
+        e = hipGetDevice(&device);
+        if (e != hipSuccess) return e;
+        e = hipDeviceGetAttribute(&cuCount, hipDeviceAttributeMultiprocessorCount, device);
+        if (e != hipSuccess) return e;
+        uint64_t wavesWanted = own;
+        const uint64_t resident = uint64_t(cuCount) * 16u;
+        if (wavesWanted > resident) wavesWanted = resident;
+        const dim3 tileBlock(256);
+        const dim3 grid(uint32_t((wavesWanted + 3u) / 4u));
+        void* kernelArgsArray[] = {&args};
+        return hipLaunchKernel(kernel, grid, tileBlock, kernelArgsArray, 0, stream);
+    }
+    if (phase == 3) {
+        if (gatheredCount > plan.capGathered) return hipErrorInvalidValue;
+        lastLaunchInfo.inboxEntries = double(gatheredCount);
+        const uint64_t* sorted = reinterpret_cast<const uint64_t*>(xs + plan.offGathered - plan.rankBytes);
+        if (gatheredCount) {
+            size_t tempBytes = plan.sortTempBytes;
+            uint64_t* in = reinterpret_cast<uint64_t*>(xs + plan.offGathered - plan.rankBytes);
+            uint64_t* out = reinterpret_cast<uint64_t*>(xs + plan.offSorted - plan.rankBytes);
+            e = rocprim::radix_sort_keys(xs + plan.offTemp - plan.rankBytes, tempBytes, in, out, size_t(gatheredCount), 13u,
+                                         13u + 2u * rowBits, stream);
+            if (e != hipSuccess) return e;
+            sorted = out;
+        }
+        args.localBlockBase = 0;
+        args.fullRowBlocks = 0;
+        args.rowBlocks = plan.ownBlocks;
+        args.shardFlags = kShardGlobalOutput;
+        if (plan.ownBlocks == 0) return hipSuccess;
+        const dim3 rgrid((plan.ownBlocks + wavesPerBlock - 1u) / wavesPerBlock);
+        if (t.identityKeys) fsp4InboxReplayKernel<true><<<rgrid, block, lds, stream>>>(args, sorted, gatheredCount);
+        else fsp4InboxReplayKernel<false><<<rgrid, block, lds, stream>>>(args, sorted, gatheredCount);
+        return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+}
+
+// Reads a rank's entry count and flags after phase 2 (synchronises): used (entries incl. chunk padding),
+// overflow (pool too small: the caller must fall back to the ordered scan), error (a hand-off timed out).
+hipError_t readFsp4ShardStatus(const Fsp4ShardPlan& plan, const void* rankWs, hipStream_t stream, uint64_t* used,
+                               uint32_t* overflow, uint32_t* error)
+{
+    const char* ws = static_cast<const char*>(rankWs);
+    uint32_t inboxWords[4] = {0, 0, 0, 0};
+    uint32_t controlWords[2] = {0, 0};
+    const size_t stateBytes = align256(size_t(plan.maxOwnBlocks) * 64u * 8u);
+    const size_t doneBytes = align256(size_t(plan.maxOwnBlocks) * 4u);
+    hipError_t e = hipMemcpyAsync(inboxWords, ws + plan.offInboxControl, sizeof(inboxWords), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(controlWords, ws + plan.offControl + stateBytes + doneBytes, sizeof(controlWords), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    *used = uint64_t(inboxWords[0]) | (uint64_t(inboxWords[1]) << 32);
+    *overflow = (inboxWords[2] != 0u || *used > plan.capLocal) ? 1u : 0u;
+    *error = controlWords[1];
+    return hipSuccess;
+}
+
+// All ranks of the sharded scan played one after the other on this GPU (tests; EM2_SCAN_MODE=virtual with
+// EM2_VIRTUAL_WORLD=P).  *done = false: not eligible or an entry pool overflowed; the caller runs the ordered scan.
+static hipError_t runFsp4ShardedEmulation(const uint32_t* sig32, uint32_t paddedDw, uint32_t cellCount, uint32_t k,
+                                          const DeviceTables& t, PairOut* outPairs, uint32_t* outUsed, uint32_t world,
+                                          hipStream_t stream, bool* done)
+{
+    *done = false;
+    std::vector<Fsp4ShardPlan> plans;
+    for (uint32_t r = 0; r < world; ++r) plans.push_back(fsp4ShardPlan(cellCount, k, r, world));
+    if (!plans[0].eligible) return hipSuccess;
+    const Fsp4ShardPlan& p0 = plans[0];
+    const bool verbose = getenv("EM2_SCAN_VERBOSE") && getenv("EM2_SCAN_VERBOSE")[0] == '1';
+    // rank parts back to back, except that the snap arrays are laid out contiguously ([world][cellCount]) at the
+    // end so that one kernel can play all_reduce(MAX)
+    char* base = nullptr;
+    const size_t exchangeBytes = p0.totalBytes - p0.rankBytes;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), p0.rankBytes * world + exchangeBytes);
+    if (e != hipSuccess) return e;
+    struct Free { char* p; ~Free() { (void)hipFree(p); } } guard{base};
+    char* exchange = base + p0.rankBytes * world;
+    std::vector<hipEvent_t> events;
+    auto mark = [&]() { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, stream); events.push_back(ev); };
+    auto reduceSnap = [&]() -> hipError_t {
+        // gather the ranks' snap arrays, reduce, scatter back (the emulation's all_reduce)
+        int32_t* tmp = reinterpret_cast<int32_t*>(exchange);      // the exchange area is free at this point
+        for (uint32_t r = 0; r < world; ++r) {
+            hipError_t ee = hipMemcpyAsync(tmp + size_t(r) * cellCount, base + p0.rankBytes * r + p0.offSnap, size_t(cellCount) * 4u,
+                                           hipMemcpyDeviceToDevice, stream);
+            if (ee != hipSuccess) return ee;
+        }
+        maxReduceKernel<<<dim3((cellCount + 255u) / 256u), dim3(256), 0, stream>>>(tmp, cellCount, world);
+        for (uint32_t r = 0; r < world; ++r) {
+            hipError_t ee = hipMemcpyAsync(base + p0.rankBytes * r + p0.offSnap, tmp + size_t(r) * cellCount, size_t(cellCount) * 4u,
+                                           hipMemcpyDeviceToDevice, stream);
+            if (ee != hipSuccess) return ee;
+        }
+        return hipGetLastError();
+    };
+    if (size_t(cellCount) * 4u * world > exchangeBytes) return hipSuccess;      // cannot happen with sane capacities
+    for (int phase = 0; phase < 3; ++phase) {
+        for (uint32_t r = 0; r < world; ++r) {
+            mark();
+            e = launchFsp4ShardPhase(plans[r], phase, sig32, paddedDw, t, base + p0.rankBytes * r, exchange, outPairs, outUsed, 0, stream);
+            if (e != hipSuccess) return e;
+        }
+        mark();
+        if (phase < 2) {
+            e = reduceSnap();
+            if (e != hipSuccess) return e;
+        }
+    }
+    // all_gather of the pools: each rank's used entries, padded with sentinels to the common maximum
+    std::vector<uint64_t> used(world, 0);
+    uint64_t maxUsed = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+        uint32_t overflow = 0, error = 0;
+        e = readFsp4ShardStatus(plans[r], base + p0.rankBytes * r, stream, &used[r], &overflow, &error);
+        if (e != hipSuccess) return e;
+        if (overflow || error) return hipSuccess;      // *done stays false
+        if (used[r] > maxUsed) maxUsed = used[r];
+    }
+    uint64_t* gathered = reinterpret_cast<uint64_t*>(exchange + p0.offGathered - p0.rankBytes);
+    e = hipMemsetAsync(gathered, 0xff, size_t(maxUsed) * world * 8u, stream);
+    if (e != hipSuccess) return e;
+    for (uint32_t r = 0; r < world; ++r) {
+        if (!used[r]) continue;
+        e = hipMemcpyAsync(gathered + size_t(r) * maxUsed, base + p0.rankBytes * r + p0.offPool, size_t(used[r]) * 8u,
+                           hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+    }
+    for (uint32_t r = 0; r < world; ++r) {
+        mark();
+        e = launchFsp4ShardPhase(plans[r], 3, sig32, paddedDw, t, base + p0.rankBytes * r, exchange, outPairs, outUsed,
+                                 maxUsed * world, stream);
+        if (e != hipSuccess) return e;
+    }
+    mark();
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    if (verbose) {
+        fprintf(stderr, "[em2] sharded emulation: world %u, prefix %u cells, entries per rank (max) %llu;", world, p0.prefixCells,
+                (unsigned long long)maxUsed);
+        size_t at = 0;
+        for (int phase = 0; phase < 4; ++phase) {
+            fprintf(stderr, " phase %d ms:", phase);
+            for (uint32_t r = 0; r < world; ++r) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, events[at], events[at + 1]);
+                fprintf(stderr, " %.2f", ms);
+                ++at;
+            }
+            ++at;
+        }
+        fprintf(stderr, "\n");
+    }
+    for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
+    *done = true;
+    return hipSuccess;
+}
+
 hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cellCount, uint32_t rowBegin,
                           uint32_t rowEnd, uint32_t k, const DeviceTables& t, Entry* buffers, PairOut* outPairs,
                           uint32_t* outUsed, void* control, hipStream_t stream, void* symmetricWs)
@@ -1484,6 +2119,24 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     args.fullRowBlocks = 0;
     args.rowBits = 0;
     args.totalTickets = 0;
+    args.rowBlockStride = 1;
+    args.rowBlockOffset = 0;
+    args.localBlockBase = 0;
+    args.columnLimit = cellCount;
+    args.shardFlags = 0;
+
+    {
+        // EM2_SCAN_MODE=virtual + EM2_VIRTUAL_WORLD=P: the multi-GPU symmetric scan with all ranks played on this GPU
+        const char* mode = getenv("EM2_SCAN_MODE");
+        if (mode && mode[0] == 'v' && rowBegin == 0 && rows == cellCount) {
+            uint64_t world = envNumber("EM2_VIRTUAL_WORLD", 2);
+            if (world < 1) world = 1;
+            bool done = false;
+            const hipError_t ev = runFsp4ShardedEmulation(sig32, paddedDw, cellCount, k, t, outPairs, outUsed, uint32_t(world), stream, &done);
+            if (ev != hipSuccess) return ev;
+            if (done) return hipSuccess;
+        }
+    }
 
     if (control && symmetricWs && rowBegin == 0 && symmetricEligible(cellCount, rows)) {
         bool done = false;

@@ -6,8 +6,16 @@ shards are all-gathered (cell-major layout makes the gathered buffer the full si
 rank scans its own ROWS against all columns, which is exactly the per-cell contract of findSimilarPairs4 --
 no collective on the result, no cross-rank merge of top-k state.
 
+DevicePipeline (device-resident, used by bench.py) goes one step further when the problem is large enough: the
+SHARDED SYMMETRIC scan (csrc/em2_scan.hip, include/em2_lsh.h: em2_dev_fsp4_sharded_*) evaluates every unordered
+pair once across all ranks instead of once per rank and side.  64-cell blocks are dealt round-robin to the ranks;
+four kernel phases are separated by two all_reduce(MAX) of a 4-byte-per-cell snapshot array and one all_gather of
+the ranks' deferred-candidate pools.  EM2_SHARDED_SCAN=0 keeps the row-shard scan.
+
 torch is used here for device memory, streams and the collective only; the compute goes through the C ABI
 (capi.dev_*).  The compute callables can be replaced (the CPU tests inject the oracle, there being no GPU)."""
+import os
+
 import numpy as np
 
 from . import capi
@@ -67,15 +75,46 @@ class DevicePipeline:
         self.local_sig = torch.zeros((size, self.words), dtype=torch.int64, device=device)
         self.full_sig = (self.local_sig if world_size == 1 else
                          torch.empty((size * world_size, self.words), dtype=torch.int64, device=device))
-        self.pairs = torch.zeros((max(1, self.rows), max(1, k), 2), dtype=torch.int32, device=device)
-        self.used = torch.zeros(max(1, self.rows), dtype=torch.int32, device=device)
-        self.scan_ws_bytes = capi.dev_find_similar_pairs4_workspace(cell_count, self.rows, lsh_count, k)
-        self.scan_ws = torch.empty(max(1, self.scan_ws_bytes), dtype=torch.uint8, device=device)
+        self.sharded = None
+        # From EM2_SHARDED_MIN_CELLS cells on (default 100000): below that the fixed costs of the extra phases and
+        # collectives outweigh the halved pair work.
+        min_cells = int(os.environ.get("EM2_SHARDED_MIN_CELLS", "100000"))
+        if world_size > 1 and k > 0 and cell_count >= min_cells and os.environ.get("EM2_SHARDED_SCAN", "1") != "0":
+            plan = capi.dev_fsp4_sharded_plan(cell_count, lsh_count, k, rank, world_size)
+            if plan["eligible"]:
+                self.sharded = plan
+        self.pairs = self.used = self.scan_ws = None
+        self.scan_ws_bytes = 0
+        self.scan_error = None
+        if self.sharded:
+            plan = self.sharded
+            # results indexed by GLOBAL cell id; this rank fills the rows of its own blocks (rank, rank+world, ...)
+            self.global_pairs = torch.zeros((cell_count, k, 2), dtype=torch.int32, device=device)
+            self.global_used = torch.zeros(cell_count, dtype=torch.int32, device=device)
+            self.shard_ws = torch.empty(plan["workspace_bytes"] + 256, dtype=torch.uint8, device=device)
+            skip = (-self.shard_ws.data_ptr()) % 256
+            self.shard_ws = self.shard_ws[skip:skip + plan["workspace_bytes"]]
+            self.snap = self.shard_ws[plan["snap_offset"]:plan["snap_offset"] + 4 * cell_count].view(torch.int32)
+            self.pool = self.shard_ws[plan["pool_offset"]:plan["pool_offset"] + 8 * plan["pool_capacity"]].view(torch.int64)
+            self.gathered = self.shard_ws[plan["gathered_offset"]:
+                                          plan["gathered_offset"] + 8 * plan["gathered_capacity"]].view(torch.int64)
+            self.count_buf = torch.zeros(2, dtype=torch.int64, device=device)
+        else:
+            self._allocate_row_shard_scan()
         self.proj_ws_bytes = capi.dev_compute_signatures_workspace(max(1, self.rows), lsh_count)
         self.proj_ws = torch.empty(self.proj_ws_bytes, dtype=torch.uint8, device=device)
         self.vector_aux = torch.empty(capi.dev_vector_aux_bytes(gene_count, lsh_count), dtype=torch.uint8,
                                       device=device)
         self.scan_events = []
+
+    def _allocate_row_shard_scan(self):
+        torch = self.torch
+        if self.scan_ws is not None:
+            return
+        self.pairs = torch.zeros((max(1, self.rows), max(1, self.k), 2), dtype=torch.int32, device=self.device)
+        self.used = torch.zeros(max(1, self.rows), dtype=torch.int32, device=self.device)
+        self.scan_ws_bytes = capi.dev_find_similar_pairs4_workspace(self.cell_count, self.rows, self.lsh_count, self.k)
+        self.scan_ws = torch.empty(max(1, self.scan_ws_bytes), dtype=torch.uint8, device=self.device)
 
     def set_inputs(self, toc, data, vectors):
         """toc int64 [rows+1] (relative to this shard), data int64-viewed em2_count [nnz], vectors float64
@@ -99,18 +138,75 @@ class DevicePipeline:
 
     def scan(self, record_events=False):
         torch = self.torch
-        stream = torch.cuda.current_stream().cuda_stream
         if record_events:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        if self.rows:
+        if self.sharded and not self._scan_sharded():
+            self.sharded = None                 # a pool overflowed somewhere: row shards from now on
+            self._allocate_row_shard_scan()
+        if not self.sharded and self.rows:
+            stream = torch.cuda.current_stream().cuda_stream
             capi.dev_find_similar_pairs4(self.full_sig.data_ptr(), self.cell_count, self.row_begin, self.row_end,
                                          self.lsh_count, self.k, self.thr, self.pairs.data_ptr(),
                                          self.used.data_ptr(), self.scan_ws.data_ptr(), self.scan_ws_bytes, stream)
         if record_events:
             e1.record()
             self.scan_events.append((e0, e1))
+
+    def _scan_sharded(self):
+        """The four phases of the sharded symmetric scan with their collectives; False if a pool overflowed."""
+        torch, dist, plan = self.torch, self.dist, self.sharded
+        stream = torch.cuda.current_stream().cuda_stream
+        world = self.world_size
+
+        def phase(number, gathered_count=0):
+            capi.dev_fsp4_sharded_phase(number, self.full_sig.data_ptr(), self.cell_count, self.lsh_count, self.k, self.thr,
+                                        self.rank, world, self.global_pairs.data_ptr(), self.global_used.data_ptr(),
+                                        self.shard_ws.data_ptr(), plan["workspace_bytes"], gathered_count, stream)
+
+        phase(0)
+        dist.all_reduce(self.snap, op=dist.ReduceOp.MAX)
+        phase(1)
+        dist.all_reduce(self.snap, op=dist.ReduceOp.MAX)
+        phase(2)
+        try:
+            used, overflow = capi.dev_fsp4_sharded_status(self.cell_count, self.k, self.rank, world,
+                                                          self.shard_ws.data_ptr(), stream)
+        except RuntimeError as error:            # a hand-off timed out: keep the collectives in step, report in check()
+            self.scan_error = error
+            used, overflow = 0, 1
+        self.count_buf[0] = used
+        self.count_buf[1] = overflow
+        dist.all_reduce(self.count_buf, op=dist.ReduceOp.MAX)
+        max_used, any_overflow = (int(x) for x in self.count_buf.tolist())
+        if any_overflow:
+            return False
+        if max_used:
+            if used < max_used:
+                self.pool[used:max_used].fill_(-1)           # ~0: sentinels sort behind every real entry
+            dist.all_gather_into_tensor(self.gathered[:world * max_used], self.pool[:max_used])
+        phase(3, world * max_used)
+        return True
+
+    def owned_ranges(self):
+        """Global [begin, end) cell ranges whose results this rank holds after scan()."""
+        if self.sharded:
+            blocks = range(self.rank, self.sharded["blocks"], self.world_size)
+            return [(64 * b, min(self.cell_count, 64 * b + 64)) for b in blocks]
+        return [(self.row_begin, self.row_end)] if self.rows else []
+
+    def results_for(self, begin, end):
+        """(pairs[end-begin, k] of capi.PAIR_DTYPE, used[end-begin]) of owned global rows [begin, end), on the host."""
+        if self.sharded:
+            p, u = self.global_pairs[begin:end], self.global_used[begin:end]
+        else:
+            p, u = self.pairs[begin - self.row_begin:end - self.row_begin], self.used[begin - self.row_begin:end - self.row_begin]
+        p = p.cpu().numpy().view(np.uint32)
+        pairs = np.zeros((end - begin, self.k), dtype=capi.PAIR_DTYPE)
+        pairs["cell"] = p[:, :, 0]
+        pairs["similarity"] = p[:, :, 1].view(np.float32)
+        return pairs, u.cpu().numpy().view(np.uint32)
 
     def step(self, record_events=False):
         self.project()
@@ -119,17 +215,19 @@ class DevicePipeline:
 
     def check(self):
         """Synchronise and raise if the last scan did not complete (capi.dev_find_similar_pairs4_status)."""
-        if self.rows and self.k:
+        if self.scan_error is not None:
+            raise self.scan_error
+        if self.sharded:
+            self.torch.cuda.synchronize()
+        elif self.rows and self.k:
             capi.dev_find_similar_pairs4_status(self.scan_ws.data_ptr(), self.rows, self.k,
                                                 self.torch.cuda.current_stream().cuda_stream)
 
     def results(self):
-        """(pairs[rows,k] of capi.PAIR_DTYPE, used[rows]) for this rank's rows, on the host."""
-        p = self.pairs[:self.rows].cpu().numpy().view(np.uint32)
-        pairs = np.zeros((self.rows, self.k), dtype=capi.PAIR_DTYPE)
-        pairs["cell"] = p[:, :, 0]
-        pairs["similarity"] = p[:, :, 1].view(np.float32)
-        return pairs, self.used[:self.rows].cpu().numpy().view(np.uint32)
+        """(pairs[rows,k] of capi.PAIR_DTYPE, used[rows]) for the contiguous row shard (row-shard scan only)."""
+        if self.sharded:
+            raise RuntimeError("results(): the sharded symmetric scan owns blocks, use owned_ranges() / results_for()")
+        return self.results_for(self.row_begin, self.row_end)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -146,6 +146,31 @@ int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount
                                 em2_pair* d_pairs, uint32_t* d_usedCount, void* d_workspace,
                                 size_t workspaceBytes, void* stream);
 
+/* ---- findSimilarPairs4 across GPUs with every unordered pair evaluated once (one process per GPU) ----
+ * The 64-cell blocks of the problem are dealt round-robin to the ranks (block g: rank g % world).  Every rank holds
+ * ALL signatures (after the all-gather of the projection shards) and calls the four phases in order with the same
+ * arguments; between the phases the CALLER runs the collectives on views of the workspace:
+ *     phase 0;  all_reduce(MAX) of snap = int32[cellCount] at snapOffset
+ *     phase 1;  all_reduce(MAX) of snap
+ *     phase 2;  em2_dev_fsp4_sharded_status -> own entry count; all ranks agree on maxUsed = max of the counts, fill
+ *               pool[used, maxUsed) with ~0 (pool = uint64[poolCapacity] at poolOffset), all_gather pool[0, maxUsed)
+ *               into gathered = uint64[world*maxUsed] at gatheredOffset
+ *     phase 3 with gatheredCount = world*maxUsed
+ * d_pairs [cellCount][k] and d_usedCount [cellCount] are indexed by GLOBAL cell id; phase 3 fills the rows of the
+ * cells this rank owns.  If any rank reports overflow the result is unusable and the caller falls back to
+ * em2_dev_find_similar_pairs4 on row shards.  em2_dev_fsp4_sharded_plan: values[0] eligible (0: shape too small, use
+ * the row-shard call), [1] workspace bytes (256-byte aligned allocation), [2] snapOffset, [3] poolOffset,
+ * [4] poolCapacity, [5] gatheredOffset, [6] gatheredCapacity, [7] prefix cells, [8] blocks owned, [9] blocks.
+ * No reference counterpart (the reference is single-threaded); results are those of src/ExpressionMatrixLsh.cpp:155-290. */
+int em2_dev_fsp4_sharded_plan(uint32_t cellCount, uint32_t lshCount, uint32_t k, uint32_t rank, uint32_t world,
+                              uint64_t* values, uint32_t valueCount);
+int em2_dev_fsp4_sharded_phase(int phase, const uint64_t* d_signatures, uint32_t cellCount, uint32_t lshCount, uint32_t k,
+                               double similarityThreshold, uint32_t rank, uint32_t world, em2_pair* d_pairs,
+                               uint32_t* d_usedCount, void* d_workspace, size_t workspaceBytes, uint64_t gatheredCount,
+                               void* stream);
+int em2_dev_fsp4_sharded_status(uint32_t cellCount, uint32_t k, uint32_t rank, uint32_t world, const void* d_workspace,
+                                void* stream, uint64_t* usedEntries, uint32_t* overflow);
+
 /* Synchronises `stream` and reports whether the last em2_dev_find_similar_pairs4 on this workspace completed: the
  * scan hands per-row state from one column segment to the next between waves, and a hand-off wait that exceeds
  * ~4 s raises an error word instead of hanging the GPU (never observed).  rowCount and k as in that call. */

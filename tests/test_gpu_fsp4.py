@@ -107,7 +107,8 @@ def scan_knobs():
     import os
     saved = {k: os.environ.get(k) for k in ("EM2_MIN_SEGMENT_COLUMNS", "EM2_LOG_CAPACITY", "EM2_SCAN_MODE",
                                              "EM2_BLOCKS_PER_CU", "EM2_FULL_ROW_CELLS", "EM2_SEGMENTS",
-                                             "EM2_INBOX_CAPACITY", "EM2_SYMMETRIC_MIN_CELLS")}
+                                             "EM2_INBOX_CAPACITY", "EM2_SYMMETRIC_MIN_CELLS", "EM2_VIRTUAL_WORLD",
+                                             "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS")}
 
     def set_knobs(**kw):
         for key, value in kw.items():
@@ -236,3 +237,50 @@ def test_fsp4_symmetric_sampled_rows_and_repeatability(oracle, scan_knobs):
         scan_knobs(EM2_BLOCKS_PER_CU=blocks, EM2_SEGMENTS=segments, EM2_MIN_SEGMENT_COLUMNS=64)
         again = capi.find_similar_pairs4(sig, L, k, thr)
         assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])
+
+
+# ---- the multi-GPU symmetric scan with all ranks played on one GPU (EM2_SCAN_MODE=virtual): block-cyclic row
+# ownership, prefix phases, deferred tiles, entry exchange, replay ----
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("n,L,k,thr,kind", [(1200, 1024, 25, 0.2, "clustered"), (2000, 256, 7, -0.5, "clustered"),
+                                             (2111, 128, 3, 0.0, "random"), (3000, 2048, 10, 0.1, "clustered"),
+                                             (2500, 64, 300, -1.0, "random")])
+def test_fsp4_sharded_virtual_world(oracle, scan_knobs, world, n, L, k, thr, kind):
+    sig = make(n, L, kind)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
+    scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=world, EM2_MIN_SEGMENT_COLUMNS=64, EM2_TILE_SEGMENTS=5)
+    pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+@pytest.mark.parametrize("permille,tile_segments,log_cap", [(50, 1, None), (200, 3, 2), (500, 7, None), (900, 256, 1)])
+def test_fsp4_sharded_prefix_sizes_and_tilings(oracle, scan_knobs, permille, tile_segments, log_cap):
+    sig = make(4000, 512, "clustered")
+    cell, sim, used = oracle.find_similar_pairs4(sig, 512, 20, 0.2)
+    scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=4, EM2_MIN_SEGMENT_COLUMNS=100, EM2_PREFIX_PERMILLE=permille,
+               EM2_TILE_SEGMENTS=tile_segments, EM2_LOG_CAPACITY=log_cap)
+    pairs, gused = capi.find_similar_pairs4(sig, 512, 20, 0.2)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+def test_fsp4_sharded_identical_cells_and_overflow_fallback(oracle, scan_knobs):
+    sig = np.tile(synth.random_signatures(1, 256, seed=3), (1500, 1))
+    cell, sim, used = oracle.find_similar_pairs4(sig, 256, 8, 0.2)
+    scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=2, EM2_MIN_SEGMENT_COLUMNS=64)
+    pairs, gused = capi.find_similar_pairs4(sig, 256, 8, 0.2)
+    assert_same(pairs, gused, cell, sim, used)
+    scan_knobs(EM2_INBOX_CAPACITY=1024)          # pools overflow -> the ordered scan runs instead
+    pairs, gused = capi.find_similar_pairs4(sig, 256, 8, 0.2)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+def test_fsp4_sharded_sampled_rows_of_larger_problem(oracle, scan_knobs):
+    n, L, k, thr = 20000, 1024, 100, 0.2
+    sig = synth.clustered_signatures(n, L, cluster_count=16, flip=0.15, seed=99)
+    scan_knobs(EM2_SCAN_MODE="persistent")
+    ordered = capi.find_similar_pairs4(sig, L, k, thr)
+    for world in (2, 8):
+        scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=world)
+        got = capi.find_similar_pairs4(sig, L, k, thr)
+        assert np.array_equal(got[0], ordered[0]) and np.array_equal(got[1], ordered[1])

@@ -1,0 +1,50 @@
+"""The multi-GPU scan paths end to end through bench.py's pipeline with TWO ranks on the one GPU of the test box
+(gloo for the collectives, EM2_BENCH_SHARE_DEVICE=1): projection shards -> all-gather -> scan -> parity gate of
+every rank against the CPU oracle (bench.py exits non-zero on any difference).  Covers the sharded symmetric scan
+(block-cyclic ownership, snapshot all_reduce, entry all_gather, replay) and the row-shard scan."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_two_ranks(extra_env, cells, port):
+    env = dict(os.environ)
+    env.update({"EM2_BENCH_SHARE_DEVICE": "1", "EM2_BENCH_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1",
+                # two persistent kernels share one GPU here: keep them from oversubscribing it (hand-off waits of one
+                # process must not keep the other's waves off the machine)
+                "EM2_BLOCKS_PER_CU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    env.update(extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "0", "--cells", str(cells), "--genes", "3000", "--no-cpu-baseline", "--check-rows", "96"]
+    done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
+    lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_sharded_symmetric_scan_two_ranks():
+    result = run_two_ranks({"EM2_SHARDED_MIN_CELLS": "1000"}, cells=30000, port=29631)
+    assert result["config"]["scan"] == "sharded-symmetric"
+    assert result["n_gpus"] == 2 and result["parity_check"]["fsp4_rows"] > 0
+    assert result["roofline"]["inbox_entries"] > 0
+
+
+def test_row_shard_scan_two_ranks():
+    result = run_two_ranks({"EM2_SHARDED_SCAN": "0"}, cells=30000, port=29632)
+    assert result["config"]["scan"] == "row-shards"
+    assert result["parity_check"]["fsp4_rows"] > 0
+
+
+def test_sharded_scan_overflow_falls_back_to_row_shards():
+    result = run_two_ranks({"EM2_SHARDED_MIN_CELLS": "1000", "EM2_INBOX_CAPACITY": "2048"}, cells=30000, port=29633)
+    assert result["config"]["scan"] == "row-shards"
+    assert result["parity_check"]["fsp4_rows"] > 0
