@@ -50,6 +50,14 @@ SYMBOLS = {
     "em2_dev_find_similar_pairs4": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                                _c.c_uint32, _c.c_double, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                _c.c_size_t, _c.c_void_p]),
+    "em2_dev_subset_workspace": (_c.c_size_t, [_c.c_uint32]),
+    "em2_dev_subset_count": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_void_p, _c.c_uint32,
+                                        _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "em2_dev_subset_fill": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_void_p, _c.c_uint32,
+                                       _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "em2_subset_find_similar_pairs4": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_void_p, _c.c_uint32,
+                                                  _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p, _c.c_uint32,
+                                                  _c.c_void_p, _c.c_uint32, _c.c_double, _c.c_void_p, _c.c_void_p]),
     "em2_dev_find_similar_pairs4_form": (_c.c_int, [_c.c_uint32, _c.c_uint32]),
     "em2_dev_find_similar_pairs4_last_launch": (_c.c_int, [_c.c_void_p, _c.c_uint32]),
     "em2_dev_fsp4_sharded_plan": (_c.c_int, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,

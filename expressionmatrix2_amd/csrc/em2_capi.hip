@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -131,30 +133,57 @@ int em2_lsh_generate_vectors(uint32_t geneCount, uint32_t lshCount, uint32_t see
     // boost::mt19937 has the parameters of std::mt19937.  uniform_01<double> over a 32-bit engine is
     // eng() / 2^32; normal_distribution (Boost <= 1.55) draws two uniforms per PAIR of variates and returns
     // rho*cos(2 pi r1) first, rho*sin(2 pi r1) second, rho = sqrt(-2 log(1 - r2)).
-    std::mt19937 engine(seed);
+    // The engine is inherently sequential and cheap; the libm calls are neither, so the raw draws are produced
+    // first (gene-major, bit-minor draw order, Lsh.cpp:90-101) and turned into variates by all host threads.  Every
+    // value and every sum is formed by the same operations in the same order as in the one-thread loop.
+    const size_t total = size_t(geneCount) * lshCount;
+    const size_t pairCount = (total + 1) / 2;
+    std::vector<uint32_t> raw(2 * pairCount);
+    {
+        std::mt19937 engine(seed);
+        for (size_t i = 0; i < 2 * pairCount; i++) raw[i] = uint32_t(engine());
+    }
+    unsigned threads = std::thread::hardware_concurrency();
+    if (threads > 32) threads = 32;
+    if (threads < 1 || total < (1u << 16)) threads = 1;
+    auto parallel = [&](size_t n, const std::function<void(size_t, size_t)>& body) {
+        if (threads == 1) {
+            body(0, n);
+            return;
+        }
+        std::vector<std::thread> pool;
+        const size_t per = (n + threads - 1) / threads;
+        for (unsigned t = 0; t < threads; t++) {
+            const size_t begin = std::min(n, size_t(t) * per), end = std::min(n, begin + per);
+            if (begin < end) pool.emplace_back(body, begin, end);
+        }
+        for (std::thread& th : pool) th.join();
+    };
     const double scale = 1.0 / 4294967296.0;
     const double twoPi = 2.0 * 3.14159265358979323846;
-    std::vector<double> sumOfSquares(lshCount, 0.);
-    bool haveSecond = false;
-    double r1 = 0., rho = 0.;
-    const size_t total = size_t(geneCount) * lshCount;
-    for (size_t t = 0; t < total; t++) {            // gene-major, bit-minor draw order (Lsh.cpp:90-101)
-        double x;
-        if (!haveSecond) {
-            r1 = double(engine()) * scale;
-            const double r2 = double(engine()) * scale;
-            rho = std::sqrt(-2.0 * std::log(1.0 - r2));
-            x = rho * std::cos(twoPi * r1);
-            haveSecond = true;
-        } else {
-            x = rho * std::sin(twoPi * r1);
-            haveSecond = false;
+    parallel(pairCount, [&](size_t begin, size_t end) {
+        for (size_t p = begin; p < end; p++) {
+            const double r1 = double(raw[2 * p]) * scale;
+            const double r2 = double(raw[2 * p + 1]) * scale;
+            const double rho = std::sqrt(-2.0 * std::log(1.0 - r2));
+            vectors[2 * p] = rho * std::cos(twoPi * r1);
+            if (2 * p + 1 < total) vectors[2 * p + 1] = rho * std::sin(twoPi * r1);
         }
-        vectors[t] = x;
-        sumOfSquares[t % lshCount] += x * x;
-    }
+    });
+    std::vector<double> sumOfSquares(lshCount, 0.);
+    parallel(lshCount, [&](size_t begin, size_t end) {          // per bit: genes in ascending order
+        for (size_t g = 0; g < geneCount; g++) {
+            const double* row = vectors + g * lshCount;
+            for (size_t i = begin; i < end; i++) sumOfSquares[i] += row[i] * row[i];
+        }
+    });
     for (double& f : sumOfSquares) f = 1. / std::sqrt(f);                    // Lsh.cpp:104-106
-    for (size_t t = 0; t < total; t++) vectors[t] *= sumOfSquares[t % lshCount];   // Lsh.cpp:107-111
+    parallel(geneCount, [&](size_t begin, size_t end) {                      // Lsh.cpp:107-111
+        for (size_t g = begin; g < end; g++) {
+            double* row = vectors + g * lshCount;
+            for (size_t i = 0; i < lshCount; i++) row[i] *= sumOfSquares[i];
+        }
+    });
     return EM2_OK;
 }
 
@@ -454,6 +483,152 @@ int em2_dev_find_similar_pairs5(const uint64_t* d_signatures, uint32_t cellCount
 // ---------------------------------------------------------------------------------------------------------
 // Host-buffer entry points.
 // ---------------------------------------------------------------------------------------------------------
+
+size_t em2_dev_subset_workspace(uint32_t cellCount)
+{
+    return em2::subsetWorkspaceBytes(cellCount);
+}
+
+int em2_dev_subset_count(const uint64_t* d_globalToc, const em2_count* d_globalData, const uint32_t* d_cellIds,
+                         uint32_t cellCount, const uint32_t* d_geneLocalIds, uint32_t globalGeneCount, uint64_t* d_toc,
+                         void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    if (!d_globalToc || !d_geneLocalIds || !d_toc || !d_workspace) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_subset_count: null pointer");
+    if (workspaceBytes < em2::subsetWorkspaceBytes(cellCount)) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_subset_count: workspace too small");
+    EM2_HIP(em2::launchSubsetCount(d_globalToc, reinterpret_cast<const em2::CountIn*>(d_globalData), d_cellIds, cellCount,
+                                   d_geneLocalIds, globalGeneCount, d_toc, d_workspace, workspaceBytes,
+                                   static_cast<hipStream_t>(stream)));
+    return EM2_OK;
+}
+
+int em2_dev_subset_fill(const uint64_t* d_globalToc, const em2_count* d_globalData, const uint32_t* d_cellIds,
+                        uint32_t cellCount, const uint32_t* d_geneLocalIds, uint32_t globalGeneCount, const uint64_t* d_toc,
+                        em2_count* d_data, void* stream)
+{
+    if (!d_globalToc || !d_geneLocalIds || !d_toc) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_subset_fill: null pointer");
+    EM2_HIP(em2::launchSubsetFill(d_globalToc, reinterpret_cast<const em2::CountIn*>(d_globalData), d_cellIds, cellCount,
+                                  d_geneLocalIds, globalGeneCount, d_toc, reinterpret_cast<em2::CountIn*>(d_data),
+                                  static_cast<hipStream_t>(stream)));
+    return EM2_OK;
+}
+
+
+int em2_subset_find_similar_pairs4(const uint64_t* globalToc, const em2_count* globalData, uint32_t globalCellCount,
+                                   const uint32_t* cellIds, uint32_t cellCount, const uint32_t* geneLocalIds,
+                                   uint32_t globalGeneCount, uint32_t geneCount, const double* vectors, uint32_t lshCount,
+                                   uint64_t* signatures, uint32_t k, double similarityThreshold, em2_pair* pairs,
+                                   uint32_t* usedCount)
+{
+    if (lshCount == 0 || geneCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_subset_find_similar_pairs4: lshCount and geneCount must be positive");
+    if (cellCount == 0) return EM2_OK;
+    if (!globalToc || !geneLocalIds || !vectors) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_subset_find_similar_pairs4: null pointer");
+    const bool wantPairs = usedCount != nullptr;
+    if (wantPairs && !pairs && k) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_subset_find_similar_pairs4: null pairs");
+    if (!wantPairs && !signatures) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_subset_find_similar_pairs4: nothing to compute");
+    if (!haveDevice()) return fail(EM2_ERROR_NO_DEVICE, "em2_subset_find_similar_pairs4: no HIP device is visible (this library has no CPU path)");
+    const uint32_t padded = em2::paddedDwords(lshCount);
+    if (wantPairs && k) {
+        if (padded == 0) return fail(EM2_ERROR_UNSUPPORTED, "em2_subset_find_similar_pairs4: lshCount above 4096 is not supported");
+        if (k > em2::fsp4MaxK()) return fail(EM2_ERROR_UNSUPPORTED, "em2_subset_find_similar_pairs4: k above " + std::to_string(em2::fsp4MaxK()) + " is not supported");
+    }
+    // The rows of the global CSR the cell set needs.  All cells in order (the usual case): the arrays go to the device
+    // as they are.  Otherwise the rows are gathered on the host first (a copy of only those rows), still with global
+    // gene ids; the gene restriction and the remapping happen on the device either way.
+    bool allCells = cellCount == globalCellCount;
+    if (cellIds) {
+        for (uint32_t i = 0; i < cellCount; i++) {
+            if (cellIds[i] >= globalCellCount) return fail(EM2_ERROR_RUNTIME, "em2_subset_find_similar_pairs4: the cell set refers to a cell that does not exist.");
+            allCells = allCells && cellIds[i] == i;
+        }
+    } else if (!allCells) {
+        return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_subset_find_similar_pairs4: null cellIds");
+    }
+    std::vector<uint64_t> rowToc;
+    std::vector<em2_count> rowData;
+    const uint64_t* srcToc = globalToc;
+    const em2_count* srcData = globalData;
+    if (!allCells) {
+        rowToc.assign(size_t(cellCount) + 1, 0);
+        for (uint32_t i = 0; i < cellCount; i++) rowToc[i + 1] = rowToc[i] + (globalToc[cellIds[i] + 1] - globalToc[cellIds[i]]);
+        rowData.resize(rowToc[cellCount]);
+        for (uint32_t i = 0; i < cellCount; i++) {
+            const uint64_t n = rowToc[i + 1] - rowToc[i];
+            if (n) std::memcpy(rowData.data() + rowToc[i], globalData + globalToc[cellIds[i]], n * sizeof(em2_count));
+        }
+        srcToc = rowToc.data();
+        srcData = rowData.data();
+    }
+    const uint64_t srcNnz = srcToc[cellCount];
+    if (srcNnz && !srcData) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_subset_find_similar_pairs4: null data");
+
+    const uint32_t words = wordCountOf(lshCount);
+    DeviceBuffer dSrcToc, dSrcData, dLocal, dToc, dData, dSubsetWs, dVectors, dSig, dWs, dAux;
+    EM2_HIP(dSrcToc.allocate((size_t(cellCount) + 1) * sizeof(uint64_t)));
+    EM2_HIP(dSrcData.allocate(srcNnz * sizeof(em2_count)));
+    EM2_HIP(dLocal.allocate(size_t(globalGeneCount) * sizeof(uint32_t)));
+    EM2_HIP(dToc.allocate((size_t(cellCount) + 1) * sizeof(uint64_t)));
+    const size_t subsetWs = em2::subsetWorkspaceBytes(cellCount);
+    EM2_HIP(dSubsetWs.allocate(subsetWs));
+    EM2_HIP(hipMemcpy(dSrcToc.p, srcToc, (size_t(cellCount) + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (srcNnz) EM2_HIP(hipMemcpy(dSrcData.p, srcData, srcNnz * sizeof(em2_count), hipMemcpyHostToDevice));
+    if (globalGeneCount) EM2_HIP(hipMemcpy(dLocal.p, geneLocalIds, size_t(globalGeneCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    std::vector<uint64_t>().swap(rowToc);
+    std::vector<em2_count>().swap(rowData);
+    EM2_HIP(em2::launchSubsetCount(dSrcToc.as<uint64_t>(), dSrcData.as<em2::CountIn>(), nullptr, cellCount, dLocal.as<uint32_t>(),
+                                   globalGeneCount, dToc.as<uint64_t>(), dSubsetWs.p, subsetWs, nullptr));
+    uint64_t nnz = 0;
+    EM2_HIP(hipMemcpy(&nnz, dToc.as<uint64_t>() + cellCount, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    EM2_HIP(dData.allocate(nnz * sizeof(em2_count)));
+    EM2_HIP(em2::launchSubsetFill(dSrcToc.as<uint64_t>(), dSrcData.as<em2::CountIn>(), nullptr, cellCount, dLocal.as<uint32_t>(),
+                                  globalGeneCount, dToc.as<uint64_t>(), dData.as<em2::CountIn>(), nullptr));
+    EM2_HIP(hipStreamSynchronize(nullptr));
+    (void)hipFree(dSrcData.p);
+    dSrcData.p = nullptr;
+
+    // signatures (same steps as em2_compute_signatures, on the device-resident subset)
+    const size_t wsBytes = em2_dev_compute_signatures_workspace(cellCount, lshCount);
+    EM2_HIP(dVectors.allocate(size_t(geneCount) * lshCount * sizeof(double)));
+    EM2_HIP(dSig.allocate(size_t(cellCount) * words * sizeof(uint64_t)));
+    EM2_HIP(dWs.allocate(wsBytes));
+    EM2_HIP(hipMemcpy(dVectors.p, vectors, size_t(geneCount) * lshCount * sizeof(double), hipMemcpyHostToDevice));
+    const char* exactOnly = getenv("EM2_PROJECTION");
+    void* aux = nullptr;
+    if (!(exactOnly && exactOnly[0] == 'e') && lshCount % 4u == 0u) {
+        EM2_HIP(dAux.allocate(em2_dev_vector_aux_bytes(geneCount, lshCount)));
+        const int prc = em2_dev_prepare_vectors(dVectors.as<double>(), geneCount, lshCount, dAux.p, nullptr);
+        if (prc != EM2_OK) return prc;
+        aux = dAux.p;
+    }
+    int rc = em2_dev_compute_signatures(dToc.as<uint64_t>(), dData.as<em2_count>(), cellCount, geneCount, dVectors.as<double>(),
+                                        aux, lshCount, dSig.as<uint64_t>(), dWs.p, wsBytes, nullptr);
+    if (rc != EM2_OK) return rc;
+    EM2_HIP(hipStreamSynchronize(nullptr));
+    if (signatures) EM2_HIP(hipMemcpy(signatures, dSig.p, size_t(cellCount) * words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (!wantPairs) return EM2_OK;
+    // free what the scan does not need before its (large) workspace is allocated
+    for (DeviceBuffer* b : {&dVectors, &dAux, &dWs, &dData, &dToc, &dSrcToc, &dLocal, &dSubsetWs}) {
+        if (b->p) (void)hipFree(b->p);
+        b->p = nullptr;
+    }
+    if (k == 0) {
+        std::memset(usedCount, 0, size_t(cellCount) * sizeof(uint32_t));
+        return EM2_OK;
+    }
+    const size_t scanWsBytes = em2_dev_find_similar_pairs4_workspace(cellCount, cellCount, lshCount, k);
+    DeviceBuffer dPairs, dUsed, dScanWs;
+    EM2_HIP(dPairs.allocate(size_t(cellCount) * k * sizeof(em2_pair)));
+    EM2_HIP(dUsed.allocate(size_t(cellCount) * sizeof(uint32_t)));
+    EM2_HIP(dScanWs.allocate(scanWsBytes));
+    rc = em2_dev_find_similar_pairs4(dSig.as<uint64_t>(), cellCount, 0, cellCount, lshCount, k, similarityThreshold,
+                                     dPairs.as<em2_pair>(), dUsed.as<uint32_t>(), dScanWs.p, scanWsBytes, nullptr);
+    if (rc != EM2_OK) return rc;
+    rc = em2_dev_find_similar_pairs4_status(dScanWs.p, cellCount, k, nullptr);
+    if (rc != EM2_OK) return rc;
+    EM2_HIP(hipMemcpy(pairs, dPairs.p, size_t(cellCount) * k * sizeof(em2_pair), hipMemcpyDeviceToHost));
+    EM2_HIP(hipMemcpy(usedCount, dUsed.p, size_t(cellCount) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return EM2_OK;
+}
+
 
 int em2_compute_signatures(const uint64_t* toc, const em2_count* data, uint32_t cellCount, uint32_t geneCount,
                            const double* vectors, uint32_t lshCount, uint64_t* signatures)

@@ -114,6 +114,16 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
                    uint32_t k, uint32_t q, uint64_t bucketOverflow, const DeviceTables& tables, PairOut* d_pairs,
                    uint32_t* d_used, hipStream_t stream);
 
+// ExpressionMatrixSubset::ExpressionMatrixSubset (src/ExpressionMatrixSubset.cpp:9-42) on the device (em2_subset.hip).
+// cellIds == NULL means all cells in order; geneLocalIds[globalGeneId] = local id or 0xffffffff.
+size_t subsetWorkspaceBytes(uint32_t cellCount);
+hipError_t launchSubsetCount(const uint64_t* globalToc, const CountIn* globalData, const uint32_t* cellIds, uint32_t cellCount,
+                             const uint32_t* geneLocalIds, uint32_t globalGeneCount, uint64_t* toc, void* workspace,
+                             size_t workspaceBytes, hipStream_t stream);
+hipError_t launchSubsetFill(const uint64_t* globalToc, const CountIn* globalData, const uint32_t* cellIds, uint32_t cellCount,
+                            const uint32_t* geneLocalIds, uint32_t globalGeneCount, const uint64_t* toc, CountIn* outData,
+                            hipStream_t stream);
+
 // CellGraph::CellGraph (src/CellGraph.cpp:33-117): edges of the k-NN graph in the reference's insertion order.
 hipError_t runCellGraphEdges(const PairOut* pairs, const uint32_t* usedCount, uint32_t spCellCount, uint32_t k,
                              const uint32_t* spCellSet, const uint32_t* graphCellSet, const uint32_t* graphSortedIds,

@@ -1,5 +1,9 @@
 #include "em2_host.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cerrno>
 #include <cfloat>
@@ -13,6 +17,24 @@
 
 namespace em2 {
 namespace host {
+
+// EM2_TIMING=1: wall time of the stages of the matrix-level calls on stderr (measurements only).
+class StageTimer {
+public:
+    explicit StageTimer(const char* what) : what_(what), on_(getenv("EM2_TIMING") && getenv("EM2_TIMING")[0] == '1'),
+                                            last_(std::chrono::steady_clock::now()) {}
+    void stage(const char* name)
+    {
+        if (!on_) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[em2 timing] %s: %s %.1f ms\n", what_, name, std::chrono::duration<double, std::milli>(now - last_).count());
+        last_ = now;
+    }
+private:
+    const char* what_;
+    bool on_;
+    std::chrono::steady_clock::time_point last_;
+};
 
 namespace {
 
@@ -252,27 +274,38 @@ const MappedFile& Matrix::cellSet(const std::string& name) const
     return *it->second;
 }
 
+// Lookup + emptiness checks in the reference's order (ExpressionMatrixLsh.cpp:168-187).
+void Matrix::lookupSubset(const std::string& geneSetName, const std::string& cellSetName, const GeneSet*& genes,
+                          const uint32_t*& cellIds, uint32_t& cellCount) const
+{
+    const GeneSet& g = geneSet(geneSetName);
+    if (g.size() == 0) fail(EM2_ERROR_RUNTIME, "Gene set " + geneSetName + " is empty.");
+    const MappedFile& cells = cellSet(cellSetName);
+    if (cells.objectCount() == 0) fail(EM2_ERROR_RUNTIME, "Cell set " + cellSetName + " is empty.");
+    cellIds = static_cast<const uint32_t*>(cells.data());
+    if (!isSorted(cellIds, cells.objectCount())) fail(EM2_ERROR_RUNTIME, "Cell set " + cellSetName + " is not sorted.");
+    cellCount = uint32_t(cells.objectCount());
+    const uint64_t globalCells = toc_.objectCount() - 1;
+    for (uint32_t local = 0; local < cellCount; local++) {
+        if (cellIds[local] >= globalCells) fail(EM2_ERROR_RUNTIME, "Cell set " + cellSetName + " refers to a cell that does not exist.");
+    }
+    genes = &g;
+}
+
 void Matrix::subset(const std::string& geneSetName, const std::string& cellSetName, std::vector<uint64_t>& toc,
                     std::vector<em2_count>& data, uint32_t& geneCount, uint32_t& cellCount) const
 {
-    // Lookup + emptiness checks in the reference's order (ExpressionMatrixLsh.cpp:168-187).
-    const GeneSet& genes = geneSet(geneSetName);
-    if (genes.size() == 0) fail(EM2_ERROR_RUNTIME, "Gene set " + geneSetName + " is empty.");
-    const MappedFile& cells = cellSet(cellSetName);
-    if (cells.objectCount() == 0) fail(EM2_ERROR_RUNTIME, "Cell set " + cellSetName + " is empty.");
-    const uint32_t* cellIds = static_cast<const uint32_t*>(cells.data());
-    if (!isSorted(cellIds, cells.objectCount())) fail(EM2_ERROR_RUNTIME, "Cell set " + cellSetName + " is not sorted.");
-
+    const GeneSet* genesPointer = nullptr;
+    const uint32_t* cellIds = nullptr;
+    lookupSubset(geneSetName, cellSetName, genesPointer, cellIds, cellCount);
+    const GeneSet& genes = *genesPointer;
     geneCount = genes.size();
-    cellCount = uint32_t(cells.objectCount());
     const uint64_t* globalToc = static_cast<const uint64_t*>(toc_.data());
     const em2_count* globalData = static_cast<const em2_count*>(data_.data());
-    const uint64_t globalCells = toc_.objectCount() - 1;
     toc.assign(size_t(cellCount) + 1, 0);
     data.clear();
     for (uint32_t local = 0; local < cellCount; local++) {                    // ExpressionMatrixSubset.cpp:24-39
         const uint32_t global = cellIds[local];
-        if (global >= globalCells) fail(EM2_ERROR_RUNTIME, "Cell set " + cellSetName + " refers to a cell that does not exist.");
         for (uint64_t j = globalToc[global]; j < globalToc[global + 1]; j++) {
             const uint32_t localGene = genes.localId(globalData[j].gene);
             if (localGene == kInvalidId) continue;
@@ -285,51 +318,61 @@ void Matrix::subset(const std::string& geneSetName, const std::string& cellSetNa
     }
 }
 
+// Subset + hyperplanes + signatures (+ pairs) with the restricted CSR built on the device
+// (em2_subset_find_similar_pairs4): the work of ExpressionMatrixSubset + Lsh (+ the pair loop).
+void Matrix::runLshPath(const char* what, const std::string& geneSetName, const std::string& cellSetName, size_t lshCount,
+                        unsigned int seed, uint32_t& cellCount, std::vector<uint64_t>* signatures, size_t k,
+                        double similarityThreshold, std::vector<em2_pair>* pairs, std::vector<uint32_t>* used) const
+{
+    StageTimer timer(what);
+    const GeneSet* genes = nullptr;
+    const uint32_t* cellIds = nullptr;
+    lookupSubset(geneSetName, cellSetName, genes, cellIds, cellCount);
+    if (lshCount == 0 || lshCount > 0xffffffffULL || k > 0xffffffffULL) fail(EM2_ERROR_INVALID_ARGUMENT, std::string(what) + ": lshCount or k out of range");
+    const uint32_t geneCount = genes->size();
+    timer.stage("lookup");
+    std::vector<double> vectors(size_t(geneCount) * lshCount);
+    if (em2_lsh_generate_vectors(geneCount, uint32_t(lshCount), seed, vectors.data()) != EM2_OK) fail(EM2_ERROR_RUNTIME, em2_last_error());
+    timer.stage("hyperplanes");
+    const size_t words = (lshCount - 1) / 64 + 1;
+    if (signatures) signatures->assign(size_t(cellCount) * words, 0);
+    if (pairs) {
+        pairs->assign(size_t(cellCount) * k, em2_pair());
+        used->assign(cellCount, 0);
+    }
+    const int rc = em2_subset_find_similar_pairs4(
+        static_cast<const uint64_t*>(toc_.data()), static_cast<const em2_count*>(data_.data()), uint32_t(toc_.objectCount() - 1),
+        cellIds, cellCount, static_cast<const uint32_t*>(genes->localIds.data()), uint32_t(genes->localIds.objectCount()),
+        geneCount, vectors.data(), uint32_t(lshCount), signatures ? signatures->data() : nullptr, uint32_t(k),
+        similarityThreshold, pairs ? pairs->data() : nullptr, pairs ? used->data() : nullptr);
+    if (rc != EM2_OK) fail(rc, em2_last_error());
+    timer.stage("device: subset, signatures, pairs (incl. transfers)");
+}
+
 void Matrix::findSimilarPairs4(const std::string& geneSetName, const std::string& cellSetName,
                                const std::string& similarPairsName, size_t k, double similarityThreshold,
                                size_t lshCount, unsigned int seed) const
 {
-    std::vector<uint64_t> toc;
-    std::vector<em2_count> data;
-    uint32_t geneCount = 0, cellCount = 0;
-    subset(geneSetName, cellSetName, toc, data, geneCount, cellCount);
-    if (lshCount == 0 || lshCount > 0xffffffffULL || k > 0xffffffffULL) fail(EM2_ERROR_INVALID_ARGUMENT, "findSimilarPairs4: lshCount or k out of range");
-
-    // Lsh lsh(tmp-Lsh, subset, lshCount, seed)  (ExpressionMatrixLsh.cpp:197): hyperplanes, signatures.
-    std::vector<double> vectors(size_t(geneCount) * lshCount);
-    if (em2_lsh_generate_vectors(geneCount, uint32_t(lshCount), seed, vectors.data()) != EM2_OK) fail(EM2_ERROR_RUNTIME, em2_last_error());
-    const size_t words = (lshCount - 1) / 64 + 1;
-    std::vector<uint64_t> signatures(size_t(cellCount) * words);
-    int rc = em2_compute_signatures(toc.data(), data.data(), cellCount, geneCount, vectors.data(), uint32_t(lshCount), signatures.data());
-    if (rc != EM2_OK) fail(rc, em2_last_error());
-    std::vector<double>().swap(vectors);
-
-    // The pair loop and the selection (ExpressionMatrixLsh.cpp:200-269).
-    std::vector<em2_pair> pairs(size_t(cellCount) * k);
-    std::vector<uint32_t> used(cellCount);
-    rc = em2_find_similar_pairs4(signatures.data(), cellCount, uint32_t(lshCount), uint32_t(k), similarityThreshold, pairs.data(), used.data());
-    if (rc != EM2_OK) fail(rc, em2_last_error());
-
+    // Lsh lsh(tmp-Lsh, subset, lshCount, seed) (ExpressionMatrixLsh.cpp:197), the pair loop and the selection
+    // (:200-269).
+    uint32_t cellCount = 0;
+    std::vector<em2_pair> pairs;
+    std::vector<uint32_t> used;
+    runLshPath("findSimilarPairs4", geneSetName, cellSetName, lshCount, seed, cellCount, nullptr, k, similarityThreshold, &pairs, &used);
     // SimilarPairs(directory, name, geneSet, cellSet, k) + copy + sort (ExpressionMatrixLsh.cpp:278-285); the
     // device already produced the sorted order.  tmp-Lsh / tmp-ExpressionMatrixSubset files of the reference
     // are deleted before it returns (:288, ExpressionMatrixSubset.cpp:62-73) and are not created here.
+    StageTimer timer("findSimilarPairs4");
     writeSimilarPairs(directoryName_, similarPairsName, geneSetName, cellSetName, k, cellCount, pairs.data(), used.data());
+    timer.stage("write files");
 }
 
 void Matrix::computeLshSignatures(const std::string& geneSetName, const std::string& cellSetName,
                                   const std::string& lshName, size_t lshCount, unsigned int seed) const
 {
-    std::vector<uint64_t> toc;
-    std::vector<em2_count> data;
-    uint32_t geneCount = 0, cellCount = 0;
-    subset(geneSetName, cellSetName, toc, data, geneCount, cellCount);
-    if (lshCount == 0 || lshCount > 0xffffffffULL) fail(EM2_ERROR_INVALID_ARGUMENT, "computeLshSignatures: lshCount out of range");
-    std::vector<double> vectors(size_t(geneCount) * lshCount);
-    if (em2_lsh_generate_vectors(geneCount, uint32_t(lshCount), seed, vectors.data()) != EM2_OK) fail(EM2_ERROR_RUNTIME, em2_last_error());
-    const size_t words = (lshCount - 1) / 64 + 1;
-    std::vector<uint64_t> signatures(size_t(cellCount) * words);
-    const int rc = em2_compute_signatures(toc.data(), data.data(), cellCount, geneCount, vectors.data(), uint32_t(lshCount), signatures.data());
-    if (rc != EM2_OK) fail(rc, em2_last_error());
+    uint32_t cellCount = 0;
+    std::vector<uint64_t> signatures;
+    runLshPath("computeLshSignatures", geneSetName, cellSetName, lshCount, seed, cellCount, &signatures, 0, 0., nullptr, nullptr);
     writeLsh(directoryName_ + "/Lsh-" + lshName, cellCount, lshCount, signatures.data());       // ExpressionMatrixLsh.cpp:1189
 }
 

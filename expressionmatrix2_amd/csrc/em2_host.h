@@ -80,6 +80,13 @@ public:
     void subset(const std::string& geneSetName, const std::string& cellSetName, std::vector<uint64_t>& toc,
                 std::vector<em2_count>& data, uint32_t& geneCount, uint32_t& cellCount) const;
 
+    // The lookups and checks of subset() without building it; runLshPath builds it on the device.
+    void lookupSubset(const std::string& geneSetName, const std::string& cellSetName, const GeneSet*& genes,
+                      const uint32_t*& cellIds, uint32_t& cellCount) const;
+    void runLshPath(const char* what, const std::string& geneSetName, const std::string& cellSetName, size_t lshCount,
+                    unsigned int seed, uint32_t& cellCount, std::vector<uint64_t>* signatures, size_t k,
+                    double similarityThreshold, std::vector<em2_pair>* pairs, std::vector<uint32_t>* used) const;
+
     void findSimilarPairs4(const std::string& geneSetName, const std::string& cellSetName,
                            const std::string& similarPairsName, size_t k, double similarityThreshold,
                            size_t lshCount, unsigned int seed) const;

@@ -90,6 +90,19 @@ int em2_compute_signatures(const uint64_t* toc, const em2_count* data, uint32_t 
 int em2_find_similar_pairs4(const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount, uint32_t k,
                             double similarityThreshold, em2_pair* pairs, uint32_t* usedCount);
 
+/* ExpressionMatrixSubset + Lsh + findSimilarPairs4 in one call on host buffers (SURVEY.md 8(a) row a1 on the device:
+ * src/ExpressionMatrixSubset.cpp:9-42 followed by src/Lsh.cpp:118-224 and src/ExpressionMatrixLsh.cpp:200-285): the
+ * global CSR (CellExpressionCounts toc/data, global gene ids) restricted to the cells cellIds[0..cellCount) (NULL =
+ * all cells in order) and to the genes with geneLocalIds[globalGeneId] != 0xffffffff (GeneSet-<name>-LocalIds), gene
+ * ids remapped to those local ids; geneCount = size of the gene set = rows of `vectors`.  The restricted CSR never
+ * exists on the host.  signatures may be NULL (not wanted); usedCount == NULL stops after the signatures
+ * (computeLshSignatures), otherwise pairs / usedCount receive the SimilarPairs content as em2_find_similar_pairs4. */
+int em2_subset_find_similar_pairs4(const uint64_t* globalToc, const em2_count* globalData, uint32_t globalCellCount,
+                                   const uint32_t* cellIds, uint32_t cellCount, const uint32_t* geneLocalIds,
+                                   uint32_t globalGeneCount, uint32_t geneCount, const double* vectors, uint32_t lshCount,
+                                   uint64_t* signatures, uint32_t k, double similarityThreshold, em2_pair* pairs,
+                                   uint32_t* usedCount);
+
 /* ExpressionMatrix::findSimilarPairs5 (src/ExpressionMatrixLsh.cpp:355-496).  lshSliceLength must be in
  * [1,32] (the reference divides by zero for 0 and allocates 2^lshSliceLength vectors per slice). */
 int em2_find_similar_pairs5(const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount, uint32_t k,
@@ -123,6 +136,17 @@ int em2_dev_compute_signatures(const uint64_t* d_toc, const em2_count* d_data, u
 /* Bytes of device scratch em2_dev_find_similar_pairs4 needs for rowCount rows. */
 size_t em2_dev_find_similar_pairs4_workspace(uint32_t cellCount, uint32_t rowCount, uint32_t lshCount,
                                              uint32_t k);
+
+/* ExpressionMatrixSubset on device-resident arrays (src/ExpressionMatrixSubset.cpp:9-42), two steps because the size
+ * of the result is not known beforehand: _count writes d_toc[0..cellCount] (offsets of the restricted CSR, d_toc[cellCount]
+ * = its entry count, read it back to size d_data), _fill writes the entries.  d_cellIds NULL = all cells in order. */
+size_t em2_dev_subset_workspace(uint32_t cellCount);
+int em2_dev_subset_count(const uint64_t* d_globalToc, const em2_count* d_globalData, const uint32_t* d_cellIds,
+                         uint32_t cellCount, const uint32_t* d_geneLocalIds, uint32_t globalGeneCount, uint64_t* d_toc,
+                         void* d_workspace, size_t workspaceBytes, void* stream);
+int em2_dev_subset_fill(const uint64_t* d_globalToc, const em2_count* d_globalData, const uint32_t* d_cellIds,
+                        uint32_t cellCount, const uint32_t* d_geneLocalIds, uint32_t globalGeneCount, const uint64_t* d_toc,
+                        em2_count* d_data, void* stream);
 
 /* Which form of the scan em2_dev_find_similar_pairs4 runs for this shape -- information for benchmarks and logs, the
  * results are identical.  0: every row of the launch is compared with every column (cellCount*rowCount ordered

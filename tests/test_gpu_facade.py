@@ -56,3 +56,40 @@ def test_compute_lsh_signatures_persists_reference_format(oracle, data_dir):
     L, sig = files.read_lsh(data_dir, "L")
     exp_sig, _ = expected(oracle, e, "AllGenes", "AllCells", 512, 231, 1, 0.2)
     assert L == 512 and np.array_equal(sig, exp_sig)
+
+
+@pytest.mark.parametrize("gene_set,cell_set", [("AllGenes", "AllCells"), ("HighInformationGenes", "AllCells"),
+                                               ("AllGenes", "Subset"), ("HighInformationGenes", "Subset")])
+def test_device_subset_equals_host_subset(data_dir, gene_set, cell_set):
+    """ExpressionMatrixSubset on the device (em2_dev_subset_count / _fill) against the host restatement of
+    src/ExpressionMatrixSubset.cpp:9-42 (em2_matrix_subset): same offsets, same (local gene id, count) entries."""
+    import torch
+    e = ExpressionMatrix(data_dir)
+    n_genes, toc, data = e._subset(gene_set, cell_set)                       # host
+    _, g_toc, g_data = e._subset("AllGenes", "AllCells")                    # the global CSR
+    cells = e._cell_set(cell_set)
+    local_ids = np.full(900, 0xffffffff, dtype=np.uint32)
+    if gene_set == "AllGenes":
+        local_ids[:] = np.arange(900, dtype=np.uint32)
+    else:
+        genes = np.unique((np.arange(300) * 7) % 900).astype(np.uint32)
+        local_ids[genes] = np.arange(len(genes), dtype=np.uint32)
+    lib = capi.load()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8)).cuda()
+    d_toc, d_data, d_cells, d_local = d(g_toc), d(g_data), d(cells), d(local_ids)
+    ws_bytes = lib.em2_dev_subset_workspace(len(cells))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    out_toc = torch.empty(len(cells) + 1, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    capi.check(lib.em2_dev_subset_count(d_toc.data_ptr(), d_data.data_ptr(), d_cells.data_ptr(), len(cells), d_local.data_ptr(),
+                                        900, out_toc.data_ptr(), ws.data_ptr(), ws_bytes, stream))
+    torch.cuda.synchronize()
+    assert np.array_equal(out_toc.cpu().numpy().view(np.uint64), toc)
+    out_data = torch.empty(max(1, int(toc[-1])) * 8, dtype=torch.uint8, device="cuda")
+    capi.check(lib.em2_dev_subset_fill(d_toc.data_ptr(), d_data.data_ptr(), d_cells.data_ptr(), len(cells), d_local.data_ptr(),
+                                       900, out_toc.data_ptr(), out_data.data_ptr(), stream))
+    torch.cuda.synchronize()
+    got = out_data.cpu().numpy()[:int(toc[-1]) * 8].view(capi.COUNT_DTYPE)
+    assert np.array_equal(got["gene"], data["gene"])
+    assert np.array_equal(got["count"].view(np.uint32), data["count"].view(np.uint32))
+    assert n_genes == (900 if gene_set == "AllGenes" else len(np.unique((np.arange(300) * 7) % 900)))
