@@ -50,6 +50,14 @@ SYMBOLS = {
     "em2_dev_find_similar_pairs4": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                                _c.c_uint32, _c.c_double, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                _c.c_size_t, _c.c_void_p]),
+    "em2_find_similar_pairs7": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_double, _c.c_void_p,
+                                           _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_void_p, _c.c_void_p]),
+    "em2_dev_find_similar_pairs7": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
+                                               _c.c_double, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32,
+                                               _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "em2_matrix_find_similar_pairs7": (_c.c_int, [_c.c_void_p, _c.c_char_p, _c.c_char_p, _c.c_char_p, _c.c_char_p,
+                                                  _c.c_size_t, _c.c_double, _c.c_void_p, _c.c_uint32, _c.c_uint32,
+                                                  _c.c_size_t]),
     "em2_dev_subset_workspace": (_c.c_size_t, [_c.c_uint32]),
     "em2_dev_subset_count": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_void_p, _c.c_uint32,
                                         _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
@@ -255,6 +263,17 @@ def cell_graph_edges(pairs, used_count, similar_pairs_cell_set, graph_cell_set, 
                                       _ptr(v0), _ptr(v1), _ptr(sim), ctypes.byref(count)))
     n = int(count.value)
     return v0[:n].copy(), v1[:n].copy(), sim[:n].copy()
+
+
+def find_similar_pairs7(signatures, lsh_count, k, similarity_threshold, lsh_slice_lengths, max_check, log2_bucket_count):
+    signatures = np.ascontiguousarray(signatures, dtype=np.uint64)
+    lengths = np.ascontiguousarray(lsh_slice_lengths, dtype=np.int32)
+    cell_count = signatures.shape[0]
+    pairs = np.zeros((cell_count, k), dtype=PAIR_DTYPE)
+    used = np.zeros(cell_count, dtype=np.uint32)
+    check(load().em2_find_similar_pairs7(_ptr(signatures), cell_count, lsh_count, k, similarity_threshold, _ptr(lengths),
+                                         len(lengths), max_check, log2_bucket_count, _ptr(pairs), _ptr(used)))
+    return pairs, used
 
 
 # ---- device-pointer level (torch tensors supply the memory and the stream; this module never imports torch) ----

@@ -480,9 +480,93 @@ int em2_dev_find_similar_pairs5(const uint64_t* d_signatures, uint32_t cellCount
 }
 
 
+// The argument checks of findSimilarPairs7 in the reference's order (src/ExpressionMatrixLsh.cpp:548-561) and
+// Lsh::computeMismatchCountThresholdFromSimilarityThreshold (src/Lsh.hpp:86-95).
+static int prepareFsp7(const char* who, uint32_t lshCount, double similarityThreshold, const int32_t* sliceLengths,
+                       uint32_t sliceLengthCount, uint32_t k, uint32_t log2BucketCount, uint64_t& mismatchThreshold)
+{
+    if (lshCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, std::string(who) + ": lshCount must be positive");
+    if (sliceLengthCount && !sliceLengths) return fail(EM2_ERROR_INVALID_ARGUMENT, std::string(who) + ": null sliceLengths");
+    for (uint32_t i = 1; i < sliceLengthCount; i++) {
+        if (sliceLengths[i] >= sliceLengths[i - 1]) return fail(EM2_ERROR_RUNTIME, "The slice lengths are not in decreasing order.");
+    }
+    for (uint32_t i = 0; i < sliceLengthCount; i++) {
+        if (sliceLengths[i] > 64) return fail(EM2_ERROR_RUNTIME, "Each slice length can be at most 64 bits.");
+    }
+    for (uint32_t i = 0; i < sliceLengthCount; i++) {
+        // the reference divides lshBitCount by the slice length (:760): zero is a crash there, negatives nonsense
+        if (sliceLengths[i] < 1) return fail(EM2_ERROR_INVALID_ARGUMENT, std::string(who) + ": slice lengths must be positive");
+    }
+    if (log2BucketCount > 40) return fail(EM2_ERROR_UNSUPPORTED, std::string(who) + ": log2BucketCount above 40 is not supported");
+    for (uint32_t i = 0; i < sliceLengthCount; i++) {
+        if (uint32_t(sliceLengths[i]) < log2BucketCount && sliceLengths[i] > 40) {
+            return fail(EM2_ERROR_UNSUPPORTED, std::string(who) + ": directly indexed slices longer than 40 bits are not supported");
+        }
+    }
+    if (k > em2::fsp7MaxK()) return fail(EM2_ERROR_UNSUPPORTED, std::string(who) + ": k above " + std::to_string(em2::fsp7MaxK()) + " is not supported");
+    std::vector<double> table(size_t(lshCount) + 1);
+    em2::computeSimilarityTable(lshCount, table.data());
+    for (size_t m = 0; m < table.size(); m++) {
+        if (table[m] < similarityThreshold) {
+            mismatchThreshold = uint64_t(m) - 1u;            // size_t arithmetic as in Lsh.hpp:91 (m == 0 wraps)
+            return EM2_OK;
+        }
+    }
+    return fail(EM2_ERROR_RUNTIME, "Assertion failed: no mismatch count has a similarity below the similarity threshold (Lsh::computeMismatchCountThresholdFromSimilarityThreshold)");
+}
+
+int em2_dev_find_similar_pairs7(const uint64_t* d_signatures, uint32_t cellCount, uint32_t rowBegin, uint32_t rowEnd,
+                                uint32_t lshCount, uint32_t k, double similarityThreshold, const int32_t* sliceLengths,
+                                uint32_t sliceLengthCount, uint32_t maxCheck, uint32_t log2BucketCount, em2_pair* d_pairs,
+                                uint32_t* d_usedCount, void* stream)
+{
+    uint64_t mismatchThreshold = 0;
+    const int prc = prepareFsp7("em2_dev_find_similar_pairs7", lshCount, similarityThreshold, sliceLengths, sliceLengthCount, k,
+                                log2BucketCount, mismatchThreshold);
+    if (prc != EM2_OK) return prc;
+    if (rowBegin > rowEnd || rowEnd > cellCount) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs7: bad row range");
+    if (rowBegin == rowEnd) return EM2_OK;
+    if (!d_signatures || !d_usedCount || (!d_pairs && k)) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs7: null pointer");
+    em2::DeviceTables tables;
+    const int rc = getDeviceTables(lshCount, similarityThreshold, tables);
+    if (rc != EM2_OK) return rc;
+    EM2_HIP(em2::runFsp7(d_signatures, cellCount, rowBegin, rowEnd, lshCount, k, sliceLengths, sliceLengthCount, maxCheck,
+                         log2BucketCount, mismatchThreshold, tables, reinterpret_cast<em2::PairOut*>(d_pairs), d_usedCount,
+                         static_cast<hipStream_t>(stream)));
+    return EM2_OK;
+}
+
+
 // ---------------------------------------------------------------------------------------------------------
 // Host-buffer entry points.
 // ---------------------------------------------------------------------------------------------------------
+
+int em2_find_similar_pairs7(const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount, uint32_t k,
+                            double similarityThreshold, const int32_t* sliceLengths, uint32_t sliceLengthCount,
+                            uint32_t maxCheck, uint32_t log2BucketCount, em2_pair* pairs, uint32_t* usedCount)
+{
+    uint64_t mismatchThreshold = 0;
+    const int prc = prepareFsp7("em2_find_similar_pairs7", lshCount, similarityThreshold, sliceLengths, sliceLengthCount, k,
+                                log2BucketCount, mismatchThreshold);
+    if (prc != EM2_OK) return prc;
+    if (cellCount == 0) return EM2_OK;
+    if (!signatures || !usedCount || (!pairs && k)) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_find_similar_pairs7: null pointer");
+    if (!haveDevice()) return fail(EM2_ERROR_NO_DEVICE, "em2_find_similar_pairs7: no HIP device is visible (this library has no CPU path)");
+    const uint32_t words = wordCountOf(lshCount);
+    DeviceBuffer dSig, dPairs, dUsed;
+    EM2_HIP(dSig.allocate(size_t(cellCount) * words * sizeof(uint64_t)));
+    EM2_HIP(dPairs.allocate(size_t(cellCount) * k * sizeof(em2_pair)));
+    EM2_HIP(dUsed.allocate(size_t(cellCount) * sizeof(uint32_t)));
+    EM2_HIP(hipMemcpy(dSig.p, signatures, size_t(cellCount) * words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    const int rc = em2_dev_find_similar_pairs7(dSig.as<uint64_t>(), cellCount, 0, cellCount, lshCount, k, similarityThreshold,
+                                               sliceLengths, sliceLengthCount, maxCheck, log2BucketCount, dPairs.as<em2_pair>(),
+                                               dUsed.as<uint32_t>(), nullptr);
+    if (rc != EM2_OK) return rc;
+    if (k) EM2_HIP(hipMemcpy(pairs, dPairs.p, size_t(cellCount) * k * sizeof(em2_pair), hipMemcpyDeviceToHost));
+    EM2_HIP(hipMemcpy(usedCount, dUsed.p, size_t(cellCount) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return EM2_OK;
+}
+
 
 size_t em2_dev_subset_workspace(uint32_t cellCount)
 {

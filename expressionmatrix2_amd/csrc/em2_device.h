@@ -124,6 +124,13 @@ hipError_t launchSubsetFill(const uint64_t* globalToc, const CountIn* globalData
                             const uint32_t* geneLocalIds, uint32_t globalGeneCount, const uint64_t* toc, CountIn* outData,
                             hipStream_t stream);
 
+// findSimilarPairs7 (src/ExpressionMatrixLsh.cpp:507-827), results for the cells [rowBegin,rowEnd).  Allocates its own
+// scratch and synchronises the stream.
+uint32_t fsp7MaxK();
+hipError_t runFsp7(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin, uint32_t rowEnd, uint32_t lshCount, uint32_t k,
+                   const int32_t* sliceLengths, uint32_t sliceLengthCount, uint32_t maxCheck, uint32_t log2BucketCount,
+                   uint64_t mismatchThreshold, const DeviceTables& tables, PairOut* d_pairs, uint32_t* d_used, hipStream_t stream);
+
 // CellGraph::CellGraph (src/CellGraph.cpp:33-117): edges of the k-NN graph in the reference's insertion order.
 hipError_t runCellGraphEdges(const PairOut* pairs, const uint32_t* usedCount, uint32_t spCellCount, uint32_t k,
                              const uint32_t* spCellSet, const uint32_t* graphCellSet, const uint32_t* graphSortedIds,

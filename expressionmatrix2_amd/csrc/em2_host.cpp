@@ -405,6 +405,33 @@ void Matrix::findSimilarPairs5(const std::string& geneSetName, const std::string
     writeSimilarPairs(directoryName_, similarPairsName, geneSetName, cellSetName, k, uint32_t(cellCount), pairs.data(), used.data());
 }
 
+void Matrix::findSimilarPairs7(const std::string& geneSetName, const std::string& cellSetName,
+                               const std::string& lshName, const std::string& similarPairsName, size_t k,
+                               double similarityThreshold, const std::vector<int32_t>& lshSliceLengths, uint32_t maxCheck,
+                               size_t log2BucketCount) const
+{
+    // ExpressionMatrixLsh.cpp:522-561
+    const GeneSet& genes = geneSet(geneSetName);
+    if (genes.size() == 0) fail(EM2_ERROR_RUNTIME, "Gene set " + geneSetName + " is empty.");
+    const MappedFile& cells = cellSet(cellSetName);
+    const uint64_t cellCount = cells.objectCount();
+    if (cellCount == 0) fail(EM2_ERROR_RUNTIME, "Cell set " + cellSetName + " is empty.");
+    uint64_t lshCells = 0, lshCount = 0;
+    std::vector<uint64_t> signatures;
+    readLsh(directoryName_ + "/Lsh-" + lshName, lshCells, lshCount, signatures);
+    if (lshCells != cellCount) {
+        fail(EM2_ERROR_RUNTIME, "LSH object " + lshName + " has a number of cells inconsistent with cell set " + cellSetName);
+    }
+    if (k > 0xffffffffULL || log2BucketCount > 0xffffffffULL) fail(EM2_ERROR_INVALID_ARGUMENT, "findSimilarPairs7: argument out of range");
+    std::vector<em2_pair> pairs(size_t(cellCount) * k);
+    std::vector<uint32_t> used(cellCount);
+    const int rc = em2_find_similar_pairs7(signatures.data(), uint32_t(cellCount), uint32_t(lshCount), uint32_t(k), similarityThreshold,
+                                           lshSliceLengths.data(), uint32_t(lshSliceLengths.size()), maxCheck,
+                                           uint32_t(log2BucketCount), pairs.data(), used.data());
+    if (rc != EM2_OK) fail(rc, em2_last_error());
+    writeSimilarPairs(directoryName_, similarPairsName, geneSetName, cellSetName, k, uint32_t(cellCount), pairs.data(), used.data());
+}
+
 void Matrix::removeSimilarPairs(const std::string& similarPairsName) const
 {
     // ExpressionMatrixFindSimilarPairs.cpp:126-135: open (with all consistency checks), then remove.

@@ -95,6 +95,9 @@ public:
     void findSimilarPairs5(const std::string& geneSetName, const std::string& cellSetName,
                            const std::string& lshName, const std::string& similarPairsName, size_t k,
                            double similarityThreshold, size_t lshSliceLength, size_t bucketOverflow) const;
+    void findSimilarPairs7(const std::string& geneSetName, const std::string& cellSetName, const std::string& lshName,
+                           const std::string& similarPairsName, size_t k, double similarityThreshold,
+                           const std::vector<int32_t>& lshSliceLengths, uint32_t maxCheck, size_t log2BucketCount) const;
     void removeSimilarPairs(const std::string& similarPairsName) const;
 
     const GeneSet& geneSet(const std::string& name) const;                 // throws "Gene set X does not exist."

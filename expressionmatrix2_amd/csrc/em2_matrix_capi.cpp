@@ -88,6 +88,21 @@ int em2_matrix_find_similar_pairs5(em2_matrix* matrix, const char* geneSetName, 
     });
 }
 
+int em2_matrix_find_similar_pairs7(em2_matrix* matrix, const char* geneSetName, const char* cellSetName,
+                                   const char* lshName, const char* similarPairsName, size_t k,
+                                   double similarityThreshold, const int32_t* lshSliceLengths, uint32_t sliceLengthCount,
+                                   uint32_t maxCheck, size_t log2BucketCount)
+{
+    if (!matrix || !geneSetName || !cellSetName || !lshName || !similarPairsName || (!lshSliceLengths && sliceLengthCount)) {
+        return nullArgument("em2_matrix_find_similar_pairs7");
+    }
+    return guarded([&] {
+        matrix->impl->findSimilarPairs7(geneSetName, cellSetName, lshName, similarPairsName, k, similarityThreshold,
+                                        std::vector<int32_t>(lshSliceLengths, lshSliceLengths + sliceLengthCount), maxCheck,
+                                        log2BucketCount);
+    });
+}
+
 int em2_matrix_remove_similar_pairs(em2_matrix* matrix, const char* similarPairsName)
 {
     if (!matrix || !similarPairsName) return nullArgument("em2_matrix_remove_similar_pairs");

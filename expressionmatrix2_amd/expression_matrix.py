@@ -96,6 +96,18 @@ class ExpressionMatrix:
                                                               _b(lshName), _b(similarPairsName), k,
                                                               similarityThreshold, lshSliceLength, bucketOverflow))
 
+    # ---- src/PythonModule.cpp:882-897 ("Prototype code. Use findSimilarPairs4 instead.") ----
+    def findSimilarPairs7(self, geneSetName="AllGenes", cellSetName="AllCells", lshName=_REQUIRED,
+                          similarPairsName=_REQUIRED, k=100, similarityThreshold=0.2, lshSliceLengths=_REQUIRED,
+                          maxCheck=_REQUIRED, log2BucketCount=_REQUIRED):
+        if _REQUIRED in (lshName, similarPairsName, lshSliceLengths, maxCheck, log2BucketCount):
+            raise TypeError("findSimilarPairs7(): lshName, similarPairsName, lshSliceLengths, maxCheck and "
+                            "log2BucketCount are required")
+        lengths = np.ascontiguousarray([int(x) for x in lshSliceLengths], dtype=np.int32)
+        capi.check(capi.load().em2_matrix_find_similar_pairs7(self._handle, _b(geneSetName), _b(cellSetName), _b(lshName),
+                                                              _b(similarPairsName), k, similarityThreshold,
+                                                              capi._ptr(lengths), len(lengths), maxCheck, log2BucketCount))
+
     # ---- src/PythonModule.cpp:926-934 ----
     def removeSimilarPairs(self, similarPairsName):
         capi.check(capi.load().em2_matrix_remove_similar_pairs(self._handle, _b(similarPairsName)))

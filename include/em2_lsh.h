@@ -90,6 +90,19 @@ int em2_compute_signatures(const uint64_t* toc, const em2_count* data, uint32_t 
 int em2_find_similar_pairs4(const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount, uint32_t k,
                             double similarityThreshold, em2_pair* pairs, uint32_t* usedCount);
 
+/* ExpressionMatrix::findSimilarPairs7 after its lookups (src/ExpressionMatrixLsh.cpp:563-690 with
+ * findSimilarPairs7AssignCellsToBuckets :727-827): LSH buckets of several slice lengths (decreasing, each 1..64 bits;
+ * buckets of slices with at least log2BucketCount bits are MurmurHash64A(value, seed 231) & (2^log2BucketCount - 1)),
+ * per cell the first maxCheck distinct bucket-mates in (length, slice, id) order, of those the k with the fewest
+ * mismatches among the ones with mismatchCount < Lsh::computeMismatchCountThresholdFromSimilarityThreshold
+ * (src/Lsh.hpp:86-95), ascending (mismatch, id).  maxCheck 0 behaves as in the reference: no limit (:657 follows a push_back), except that
+ * the walk ends at the first bucket that leaves the candidate list empty (:663).
+ * Errors carry the reference's texts ("The slice lengths are not in decreasing order.", "Each slice length can be at
+ * most 64 bits.").  Limits: k <= 4096, log2BucketCount <= 40, directly indexed slices <= 40 bits. */
+int em2_find_similar_pairs7(const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount, uint32_t k,
+                            double similarityThreshold, const int32_t* sliceLengths, uint32_t sliceLengthCount,
+                            uint32_t maxCheck, uint32_t log2BucketCount, em2_pair* pairs, uint32_t* usedCount);
+
 /* ExpressionMatrixSubset + Lsh + findSimilarPairs4 in one call on host buffers (SURVEY.md 8(a) row a1 on the device:
  * src/ExpressionMatrixSubset.cpp:9-42 followed by src/Lsh.cpp:118-224 and src/ExpressionMatrixLsh.cpp:200-285): the
  * global CSR (CellExpressionCounts toc/data, global gene ids) restricted to the cells cellIds[0..cellCount) (NULL =
@@ -169,6 +182,14 @@ int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount
                                 uint32_t rowEnd, uint32_t lshCount, uint32_t k, double similarityThreshold,
                                 em2_pair* d_pairs, uint32_t* d_usedCount, void* d_workspace,
                                 size_t workspaceBytes, void* stream);
+
+/* findSimilarPairs7 on device-resident signatures for the cells [rowBegin,rowEnd) (buckets over all cells; rows
+ * shard over ranks like em2_dev_find_similar_pairs5).  sliceLengths is a host array.  Allocates its own scratch and
+ * synchronises the stream. */
+int em2_dev_find_similar_pairs7(const uint64_t* d_signatures, uint32_t cellCount, uint32_t rowBegin, uint32_t rowEnd,
+                                uint32_t lshCount, uint32_t k, double similarityThreshold, const int32_t* sliceLengths,
+                                uint32_t sliceLengthCount, uint32_t maxCheck, uint32_t log2BucketCount, em2_pair* d_pairs,
+                                uint32_t* d_usedCount, void* stream);
 
 /* ---- findSimilarPairs4 across GPUs with every unordered pair evaluated once (one process per GPU) ----
  * The 64-cell blocks of the problem are dealt round-robin to the ranks (block g: rank g % world).  Every rank holds
@@ -254,6 +275,12 @@ int em2_matrix_compute_lsh_signatures(em2_matrix* matrix, const char* geneSetNam
 int em2_matrix_find_similar_pairs5(em2_matrix* matrix, const char* geneSetName, const char* cellSetName,
                                    const char* lshName, const char* similarPairsName, size_t k,
                                    double similarityThreshold, size_t lshSliceLength, size_t bucketOverflow);
+
+/* ExpressionMatrix::findSimilarPairs7 (src/ExpressionMatrixLsh.cpp:507-703; bound at src/PythonModule.cpp:882-897). */
+int em2_matrix_find_similar_pairs7(em2_matrix* matrix, const char* geneSetName, const char* cellSetName,
+                                   const char* lshName, const char* similarPairsName, size_t k,
+                                   double similarityThreshold, const int32_t* lshSliceLengths, uint32_t sliceLengthCount,
+                                   uint32_t maxCheck, size_t log2BucketCount);
 
 /* ExpressionMatrix::removeSimilarPairs (src/ExpressionMatrixFindSimilarPairs.cpp:126-135). */
 int em2_matrix_remove_similar_pairs(em2_matrix* matrix, const char* similarPairsName);

@@ -35,6 +35,7 @@
 #include <utility>
 #include <map>
 #include <set>
+#include <functional>
 #include <vector>
 
 namespace {
@@ -474,6 +475,101 @@ uint64_t em2o_murmur_hash_64a(const void* key, int len, uint64_t seed)
     }
     h ^= h >> r; h *= m; h ^= h >> r;
     return h;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ExpressionMatrix::findSimilarPairs7 + findSimilarPairs7AssignCellsToBuckets
+// (src/ExpressionMatrixLsh.cpp:507-827), SURVEY.md 8(f) row 3.  Literal restatement: table4[lengthId][sliceId]
+// [bucketId] = cells in ascending id (:795-823); bucket id = the slice value when sliceLength < log2BucketCount,
+// else MurmurHash64A(&value, 8, 231) & (bucketCount-1) (:815-819); per cell the buckets are walked in (length,
+// slice) order, unseen cells != cell0 become candidates until maxCheck of them exist (:636-668), those with
+// mismatchCount < mismatchCountThreshold (Lsh.hpp:86-95) become neighbours, keepBest(k, less<pair>) + sort
+// (:675-676), stored with float(similarityTable[mismatch]) (:679-684, SimilarPairs::addUnsymmetricNoCheck).
+// Returns 0, 1 (slice lengths not decreasing), 2 (a slice length above 64 or below 1), 3 (no threshold).
+int em2o_find_similar_pairs7(const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount, uint32_t k,
+                             double similarityThreshold, const int32_t* sliceLengths, uint32_t sliceLengthCount,
+                             uint32_t maxCheck, uint32_t log2BucketCount, uint32_t* outCell, float* outSimilarity,
+                             uint32_t* outUsed)
+{
+    for (uint32_t i = 1; i < sliceLengthCount; i++) {
+        if (sliceLengths[i] >= sliceLengths[i - 1]) return 1;
+    }
+    for (uint32_t i = 0; i < sliceLengthCount; i++) {
+        if (sliceLengths[i] > 64 || sliceLengths[i] < 1) return 2;
+    }
+    const size_t words = (size_t(lshCount) - 1) / 64 + 1;
+    std::vector<double> table(size_t(lshCount) + 1);
+    em2o_similarity_table(lshCount, table.data());
+    size_t mismatchCountThreshold = 0;
+    bool found = false;
+    for (size_t m = 0; m < table.size(); m++) {
+        if (table[m] < similarityThreshold) {
+            mismatchCountThreshold = m - 1;         // size_t arithmetic, as in Lsh.hpp:91
+            found = true;
+            break;
+        }
+    }
+    if (!found) return 3;
+    auto getBit = [&](uint32_t cell, size_t bit) -> uint64_t {
+        return (signatures[size_t(cell) * words + (bit >> 6)] >> (63u - (bit & 63u))) & 1ull;
+    };
+    const uint64_t bucketCount = 1ull << log2BucketCount;
+    const uint64_t bucketMask = bucketCount - 1ull;
+    auto bucketOf = [&](uint32_t cell, size_t sliceLength, size_t sliceId) -> uint64_t {
+        uint64_t bits = 0;
+        size_t bitPosition = sliceId * sliceLength;
+        for (size_t b = 0; b < sliceLength; b++, ++bitPosition) {
+            bits <<= 1;
+            bits += getBit(cell, bitPosition);
+        }
+        return (sliceLength < log2BucketCount) ? bits : (em2o_murmur_hash_64a(&bits, 8, 231) & bucketMask);
+    };
+    // sparse form of table4: only the buckets that hold a cell
+    std::vector<std::vector<std::map<uint64_t, std::vector<uint32_t>>>> table4(sliceLengthCount);
+    for (uint32_t li = 0; li < sliceLengthCount; li++) table4[li].resize(lshCount / size_t(sliceLengths[li]));
+    for (uint32_t cell = 0; cell < cellCount; cell++) {
+        for (uint32_t li = 0; li < sliceLengthCount; li++) {
+            for (size_t si = 0; si < table4[li].size(); si++) table4[li][si][bucketOf(cell, size_t(sliceLengths[li]), si)].push_back(cell);
+        }
+    }
+    std::vector<bool> cellMap(cellCount, false);
+    std::vector<uint32_t> candidateNeighbors;
+    std::vector<std::pair<uint32_t, uint32_t>> neighbors;
+    for (uint32_t cell0 = 0; cell0 < cellCount; cell0++) {
+        for (uint32_t li = 0; li < sliceLengthCount; li++) {
+            for (size_t si = 0; si < table4[li].size(); si++) {
+                const std::vector<uint32_t>& bucket = table4[li][si][bucketOf(cell0, size_t(sliceLengths[li]), si)];
+                for (const uint32_t cell1 : bucket) {
+                    if (cell1 == cell0) continue;
+                    if (cellMap[cell1]) continue;
+                    cellMap[cell1] = true;
+                    candidateNeighbors.push_back(cell1);
+                    uint32_t mismatchCount = 0;
+                    for (size_t w = 0; w < words; w++) {
+                        mismatchCount += uint32_t(__builtin_popcountll(signatures[size_t(cell0) * words + w] ^ signatures[size_t(cell1) * words + w]));
+                    }
+                    if (size_t(mismatchCount) < mismatchCountThreshold) neighbors.push_back(std::make_pair(mismatchCount, cell1));
+                    if (candidateNeighbors.size() == maxCheck) break;
+                }
+                if (candidateNeighbors.size() == maxCheck) break;
+            }
+            if (candidateNeighbors.size() == maxCheck) break;
+        }
+        if (neighbors.size() > k) {                          // keepBest (heap.hpp:116-126)
+            std::nth_element(neighbors.begin(), neighbors.begin() + k, neighbors.end(), std::less<std::pair<uint32_t, uint32_t>>());
+            neighbors.resize(k);
+        }
+        std::sort(neighbors.begin(), neighbors.end());
+        for (size_t i = 0; i < neighbors.size(); i++) {
+            outCell[size_t(cell0) * k + i] = neighbors[i].second;
+            outSimilarity[size_t(cell0) * k + i] = float(table[neighbors[i].first]);
+        }
+        outUsed[cell0] = uint32_t(neighbors.size());
+        for (const uint32_t cell1 : candidateNeighbors) cellMap[cell1] = false;
+        candidateNeighbors.clear();
+        neighbors.clear();
+    }
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -48,6 +48,9 @@ class Oracle:
         lib.em2o_keep_best.restype = c.c_uint32
         lib.em2o_multiple_set_union.argtypes = [P, P, c.c_uint32, P]
         lib.em2o_multiple_set_union.restype = c.c_uint32
+        lib.em2o_find_similar_pairs7.argtypes = [P, c.c_uint32, c.c_uint32, c.c_uint32, c.c_double, P, c.c_uint32,
+                                                 c.c_uint32, c.c_uint32, P, P, P]
+        lib.em2o_find_similar_pairs7.restype = c.c_int
         lib.em2o_cell_graph_edges.argtypes = [P, P, c.c_uint32, c.c_uint32, P, P, c.c_uint32, c.c_double, c.c_uint64,
                                               P, P, P]
         lib.em2o_cell_graph_edges.restype = c.c_uint64
@@ -125,6 +128,19 @@ class Oracle:
                                                     _ptr(used))
         if rc != 0:
             raise ValueError("oracle fsp5 rejected the arguments")
+        return cell, sim, used
+
+    def find_similar_pairs7(self, sig, lsh_count, k, thr, slice_lengths, max_check, log2_bucket_count):
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        n = sig.shape[0]
+        lengths = np.ascontiguousarray(slice_lengths, dtype=np.int32)
+        cell = np.zeros((n, k), dtype=np.uint32)
+        sim = np.zeros((n, k), dtype=np.float32)
+        used = np.zeros(n, dtype=np.uint32)
+        rc = self.lib.em2o_find_similar_pairs7(_ptr(sig), n, lsh_count, k, thr, _ptr(lengths), len(lengths), max_check,
+                                               log2_bucket_count, _ptr(cell), _ptr(sim), _ptr(used))
+        if rc != 0:
+            raise ValueError("oracle fsp7 rejected the arguments (%d)" % rc)
         return cell, sim, used
 
     def cell_graph_edges(self, cell, sim, used, sp_cells, graph_cells, thr, max_connectivity):

@@ -1,0 +1,76 @@
+"""GPU parity of findSimilarPairs7 through the C ABI against the oracle's literal restatement
+of src/ExpressionMatrixLsh.cpp:507-827.  Bit-exact: cell ids, float similarity bit patterns, usedCount."""
+import numpy as np
+import pytest
+
+import synth
+from expressionmatrix2_amd import ExpressionMatrix, capi, files
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same(pairs, gused, cell, sim, used):
+    assert np.array_equal(gused, used)
+    assert np.array_equal(pairs["cell"], cell)
+    assert np.array_equal(pairs["similarity"].view(np.uint32), sim.view(np.uint32))
+
+
+@pytest.mark.parametrize("n,L,k,thr,lengths,max_check,log2b", [
+    (300, 128, 5, 0.2, [16, 8], 50, 12),
+    (1000, 256, 10, 0.2, [32, 16, 8], 100, 12),          # 32 >= 12: hashed buckets; 8 < 12: direct
+    (1000, 256, 10, 0.2, [32, 16, 8], 7, 20),
+    (777, 1024, 100, 0.2, [20, 14], 0, 16),              # no check limit
+    (500, 192, 3, 0.0, [64, 33, 1], 1000, 10),           # 64-bit slices, slices straddling words, 1-bit slices
+    (2000, 512, 20, 0.5, [24], 300, 24),                 # length == log2BucketCount: hashed
+    (900, 100, 4, 0.1, [7, 3], 40, 5),                   # lshCount not a multiple of 64, remainder bits unused
+    (65, 64, 70, -0.9, [2], 0, 8),                       # k above the number of cells
+    (400, 128, 5, 2.0, [16], 50, 10),                    # threshold above 1: mismatchCount-1 wraps, everything passes
+])
+def test_fsp7_matches_oracle(oracle, n, L, k, thr, lengths, max_check, log2b):
+    sig = synth.clustered_signatures(n, L, cluster_count=4, flip=0.12, seed=n + L)
+    cell, sim, used = oracle.find_similar_pairs7(sig, L, k, thr, lengths, max_check, log2b)
+    pairs, gused = capi.find_similar_pairs7(sig, L, k, thr, lengths, max_check, log2b)
+    assert_same(pairs, gused, cell, sim, used)
+    if thr < 1.0 and n > 100:
+        assert used.sum() > 0
+
+
+def test_fsp7_identical_cells_and_repeat(oracle):
+    sig = np.tile(synth.random_signatures(1, 256, seed=3), (500, 1))
+    cell, sim, used = oracle.find_similar_pairs7(sig, 256, 8, 0.2, [16, 8], 64, 12)
+    for _ in range(2):
+        pairs, gused = capi.find_similar_pairs7(sig, 256, 8, 0.2, [16, 8], 64, 12)
+        assert_same(pairs, gused, cell, sim, used)
+
+
+def test_fsp7_errors():
+    sig = synth.random_signatures(10, 64)
+    with pytest.raises(RuntimeError, match="The slice lengths are not in decreasing order."):
+        capi.find_similar_pairs7(sig, 64, 3, 0.2, [8, 8], 5, 10)
+    with pytest.raises(RuntimeError, match="Each slice length can be at most 64 bits."):
+        capi.find_similar_pairs7(sig, 64, 3, 0.2, [65], 5, 10)
+    with pytest.raises(RuntimeError, match="Assertion failed"):
+        capi.find_similar_pairs7(sig, 64, 3, -1.5, [8], 5, 10)
+    with pytest.raises(RuntimeError, match="positive"):
+        capi.find_similar_pairs7(sig, 64, 3, 0.2, [8, 0], 5, 10)
+
+
+def test_fsp7_facade_files(oracle, tmp_path):
+    d = str(tmp_path / "data")
+    cells, genes = 600, 500
+    toc, g, c = synth.expression_matrix(cells, genes, density=0.05, cluster_count=4, seed=9)
+    files.create_directory(d, genes, toc, capi.make_counts(g, c))
+    e = ExpressionMatrix(d)
+    e.computeLshSignatures(lshName="L", lshCount=256, seed=231)
+    e.findSimilarPairs7(lshName="L", similarPairsName="P7", k=15, similarityThreshold=0.2, lshSliceLengths=[16, 10],
+                        maxCheck=80, log2BucketCount=12)
+    L, sig = files.read_lsh(d, "L")
+    cell, sim, used = oracle.find_similar_pairs7(sig, L, 15, 0.2, [16, 10], 80, 12)
+    k, pairs, u = files.read_similar_pairs(d, "P7")
+    assert k == 15
+    assert_same(pairs, u, cell, sim, used)
+    with pytest.raises(RuntimeError, match="The slice lengths are not in decreasing order."):
+        e.findSimilarPairs7(lshName="L", similarPairsName="Q", lshSliceLengths=[8, 16], maxCheck=10, log2BucketCount=10)
+    with pytest.raises(RuntimeError, match="Gene set Nope does not exist."):
+        e.findSimilarPairs7(geneSetName="Nope", lshName="L", similarPairsName="Q", lshSliceLengths=[8], maxCheck=10,
+                            log2BucketCount=10)
