@@ -59,7 +59,7 @@ def parse_args():
     p.add_argument("--seed", type=int, default=231)
     p.add_argument("--cpu-baseline-cells", type=int, default=50000)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--check-rows", type=int, default=48)
+    p.add_argument("--check-rows", type=int, default=384)
     return p.parse_args()
 
 
@@ -108,10 +108,20 @@ def main():
     # ---- correctness gate: one untimed pass, sampled rows/cells against the CPU oracle ----
     import oracle_binding
     oracle = oracle_binding.load_oracle()
+    check = {"golden_cases": 0, "signature_cells": 0, "fsp4_rows": 0}
+    if rank == 0:
+        # the committed golden digests (tests/golden/, produced by the oracle) against this build's GPU path
+        from golden.make_golden import digest, make_signatures, regression_cases
+        with open(os.path.join(ROOT, "tests", "golden", "oracle_regression.json")) as f:
+            golden = json.load(f)
+        for case in regression_cases():
+            g_pairs, g_used = capi.find_similar_pairs4(make_signatures(case), case["L"], case["k"], case["thr"])
+            if digest(np.ascontiguousarray(g_pairs["cell"]), np.ascontiguousarray(g_pairs["similarity"]), g_used) != golden[case["name"]]["fsp4"]:
+                raise SystemExit("PARITY FAILURE: golden case %s" % case["name"])
+            check["golden_cases"] += 1
     pipe.step()
     torch.cuda.synchronize()
     sig_host = pipe.full_sig[:C].cpu().numpy().view(np.uint64)
-    check = {"signature_cells": 0, "fsp4_rows": 0}
     if pipe.rows:
         # projection: a few of this rank's cells
         sample = min(64, pipe.rows)

@@ -284,3 +284,21 @@ def test_fsp4_sharded_sampled_rows_of_larger_problem(oracle, scan_knobs):
         scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=world)
         got = capi.find_similar_pairs4(sig, L, k, thr)
         assert np.array_equal(got[0], ordered[0]) and np.array_equal(got[1], ordered[1])
+
+
+@pytest.mark.parametrize("mode", ["persistent", "triangle", "virtual"])
+def test_fsp4_golden_digests(scan_knobs, mode):
+    """The committed golden digests (tests/golden/oracle_regression.json, made by the oracle at commit time) straight
+    against the GPU result, all three scan forms, including the 3000-cell case stored as hashes only."""
+    import json
+    import os
+    from golden.make_golden import digest, make_signatures, regression_cases
+    with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_regression.json")) as f:
+        golden = json.load(f)
+    scan_knobs(EM2_SCAN_MODE=mode, EM2_MIN_SEGMENT_COLUMNS=64, EM2_FULL_ROW_CELLS=128, EM2_VIRTUAL_WORLD=2)
+    for case in regression_cases():
+        sig = make_signatures(case)
+        pairs, used = capi.find_similar_pairs4(sig, case["L"], case["k"], case["thr"])
+        cell = np.ascontiguousarray(pairs["cell"])
+        sim = np.ascontiguousarray(pairs["similarity"])
+        assert digest(cell, sim, used) == golden[case["name"]]["fsp4"], case["name"]
