@@ -26,6 +26,9 @@
 
 #include "em2_device.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace em2 {
 namespace {
 
@@ -240,6 +243,116 @@ projectionScreenKernel(const uint64_t* __restrict__ toc, const CountIn* __restri
     }
 }
 
+// Screening pass, XCD-sliced form.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one),
+// so blockIdx.x & 7 picks the 32-bit slice of the signature a block works on: every XCD's 4 MB L2 then serves ONE
+// slice of the float hyperplanes (geneCount x 128 B: 3.8 MB at 30k genes) instead of competing for the whole matrix
+// (123 MB, served from the Infinity Cache at about half the L2 rate).  A block is 16 cells x 32 bits; a wave takes
+// one cell at a time, 8 entries per step: lane = (entry group g = lane/8, 4 bits sub = lane%8), one 16-byte load per
+// lane, one 128-byte line per entry.  The partial sums of the 8 groups are added by a butterfly; the screening bound
+// covers the different order of the additions.  Requires lshCount % 32 == 0.
+// Measured at 1M cells x 30k genes x 1024 bits (projection ms per step): one block per 1024 bits 151; this form
+// 110; with non-temporal loads of the CSR entries 118; with 16-bit slices (EM2_PROJECTION=sliced16, half a cache
+// line per entry) 179.
+template <int BITS>       // bits per slice: 32 (one 128-byte line per entry) or 16
+__global__ void __launch_bounds__(256)
+projectionScreenSlicedKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t cellCount,
+                             const float* __restrict__ vectors32, const double* __restrict__ vectorSums,
+                             const double* __restrict__ vectorMaxAbs, const double* __restrict__ means,
+                             const double* __restrict__ sumAbs, uint32_t lshCount, uint32_t wordCount,
+                             uint64_t* __restrict__ signatures, uint64_t* __restrict__ workList,
+                             uint32_t* __restrict__ workCount)
+{
+    constexpr uint32_t SUB = BITS / 4;             // lanes per entry (4 bits each)
+    constexpr uint32_t GROUPS = 64u / SUB;         // entries per wave step
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t bit0 = blockIdx.y * (8u * BITS) + (blockIdx.x & 7u) * BITS;
+    if (bit0 >= lshCount) return;
+    const uint32_t sub = lane % SUB;
+    const uint32_t group = lane / SUB;
+    const uint32_t myBit = bit0 + sub * 4u;
+    const float* column = vectors32 + myBit;
+    double s[4], mx[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        s[t] = vectorSums[myBit + t];
+        mx[t] = vectorMaxAbs[myBit + t];
+    }
+    const uint64_t* entries = reinterpret_cast<const uint64_t*>(data);
+    const uint32_t word = bit0 >> 6;
+    const uint32_t cellBegin = (blockIdx.x >> 3) * kCellsPerBlock;
+    const uint32_t cellEnd = min(cellBegin + kCellsPerBlock, cellCount);
+    for (uint32_t c = cellBegin + wave; c < cellEnd; c += 4u) {
+        const uint64_t jBegin = toc[c];
+        const uint64_t jEnd = toc[c + 1];
+        double a[4] = {0., 0., 0., 0.};
+        uint64_t j = jBegin + group;
+        for (; j + 3u * GROUPS < jEnd; j += 4u * GROUPS) {      // 4 entries per lane in flight
+            float4 u[4];
+            double x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t e = entries[j + GROUPS * q];
+                u[q] = *reinterpret_cast<const float4*>(column + size_t(uint32_t(e)) * lshCount);
+                x[q] = double(__uint_as_float(uint32_t(e >> 32)));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[0] = __fma_rn(x[q], double(u[q].x), a[0]);
+                a[1] = __fma_rn(x[q], double(u[q].y), a[1]);
+                a[2] = __fma_rn(x[q], double(u[q].z), a[2]);
+                a[3] = __fma_rn(x[q], double(u[q].w), a[3]);
+            }
+        }
+        for (; j < jEnd; j += GROUPS) {
+            const uint64_t e = entries[j];
+            const float4 u = *reinterpret_cast<const float4*>(column + size_t(uint32_t(e)) * lshCount);
+            const double x = double(__uint_as_float(uint32_t(e >> 32)));
+            a[0] = __fma_rn(x, double(u.x), a[0]);
+            a[1] = __fma_rn(x, double(u.y), a[1]);
+            a[2] = __fma_rn(x, double(u.z), a[2]);
+            a[3] = __fma_rn(x, double(u.w), a[3]);
+        }
+#pragma unroll
+        for (int d = SUB; d < 64; d <<= 1) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] += __shfl_xor(a[t], d, 64);
+        }
+        const double mean = means[c];
+        const double n = double(jEnd - jBegin);
+        // n products and n + 5 additions per bit in some order: (n + 8) half-ulps cover them
+        const double factor = (1.01 * 5.9604644775390625e-08 + (n + 8.) * 2.220446049250313e-16) * 1.000001;
+        const double absMean = fabs(mean);
+        const double absX = sumAbs[c];
+        uint32_t nibble = 0;
+        bool ambiguous = false;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double total = a[t] + __dmul_rn(-mean, s[t]);
+            const double bound = factor * (absMean * fabs(s[t]) + absX * mx[t]) + absX * 1.5e-45 + 1e-300;
+            ambiguous |= !(fabs(total) > bound);
+            nibble |= (total > 0.) ? (8u >> t) : 0u;
+        }
+        uint32_t piece = nibble << (BITS - 4u - 4u * sub);      // first bit most significant
+#pragma unroll
+        for (int d = 1; d < int(SUB); d <<= 1) piece |= uint32_t(__shfl_xor(int(piece), d, SUB));
+        const uint64_t ambMask = __builtin_amdgcn_ballot_w64(ambiguous);
+        if (lane == 0u) {
+            // the slice's position inside its MSB-first 64-bit word, as a little-endian sub-word store
+            const size_t wordIndex = size_t(c) * wordCount + word;
+            if (BITS == 32) {
+                reinterpret_cast<uint32_t*>(signatures)[wordIndex * 2u + (1u - ((bit0 >> 5) & 1u))] = piece;
+            } else {
+                reinterpret_cast<uint16_t*>(signatures)[wordIndex * 4u + (3u - ((bit0 >> 4) & 3u))] = uint16_t(piece);
+            }
+            if ((ambMask & ((1ull << SUB) - 1ull)) != 0ull) {
+                const uint32_t slot = atomicAdd(workCount, 1u);
+                workList[slot] = (uint64_t(c) << 32) | word;
+            }
+        }
+    }
+}
+
 // Exact recomputation of the listed (cell, word) items: the arithmetic of projectionKernel, one wave per item.
 __global__ void __launch_bounds__(256)
 projectionExactItemsKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data,
@@ -333,7 +446,8 @@ size_t projectionScreenedWorkspaceBytes(uint32_t cellCount, uint32_t lshCount)
 {
     const size_t wordCount = (size_t(lshCount) - 1u) / 64u + 1u;
     const size_t a = (size_t(cellCount) * sizeof(double) + 255u) & ~size_t(255u);
-    return 2u * a + 256u + ((size_t(cellCount) * wordCount * sizeof(uint64_t) + 255u) & ~size_t(255u));
+    // work list: one slot per (cell, 16-bit slice), the sliced screen can list a word once per slice
+    return 2u * a + 256u + ((4u * size_t(cellCount) * wordCount * sizeof(uint64_t) + 255u) & ~size_t(255u));
 }
 
 hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, uint32_t cellCount, uint32_t geneCount,
@@ -356,9 +470,29 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
     cellStatsKernel<<<dim3((cellCount + 255u) / 256u), dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, means, sumAbs);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const dim3 grid((cellCount + kCellsPerBlock - 1u) / kCellsPerBlock, (lshCount + 1023u) / 1024u);
-    projectionScreenKernel<<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, vectors32, sums, maxAbs, means, sumAbs,
-                                                           lshCount, wordCount, signatures, workList, workCount);
+    // EM2_PROJECTION=screen keeps the one-block-per-1024-bits form (A/B measurements); default is the XCD-sliced form
+    // whenever the signature is a whole number of 32-bit slices.
+    const char* mode = getenv("EM2_PROJECTION");
+    const bool sliced = lshCount % 32u == 0u && !(mode && mode[0] == 's' && mode[1] == 'c');
+    if (sliced) {
+        e = hipMemsetAsync(signatures, 0, size_t(cellCount) * wordCount * sizeof(uint64_t), stream);    // halves nobody owns
+        if (e != hipSuccess) return e;
+        const bool narrow = mode && mode[0] == 's' && mode[1] == 'l' && strstr(mode, "16") != nullptr;      // EM2_PROJECTION=sliced16
+        const uint32_t cellBlocks = (cellCount + kCellsPerBlock - 1u) / kCellsPerBlock;
+        if (narrow) {
+            const dim3 grid(cellBlocks * 8u, (lshCount + 127u) / 128u);
+            projectionScreenSlicedKernel<16><<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, vectors32, sums, maxAbs, means, sumAbs,
+                                                                             lshCount, wordCount, signatures, workList, workCount);
+        } else {
+            const dim3 grid(cellBlocks * 8u, (lshCount + 255u) / 256u);
+            projectionScreenSlicedKernel<32><<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, vectors32, sums, maxAbs, means, sumAbs,
+                                                                             lshCount, wordCount, signatures, workList, workCount);
+        }
+    } else {
+        const dim3 grid((cellCount + kCellsPerBlock - 1u) / kCellsPerBlock, (lshCount + 1023u) / 1024u);
+        projectionScreenKernel<<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, vectors32, sums, maxAbs, means, sumAbs,
+                                                               lshCount, wordCount, signatures, workList, workCount);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     projectionExactItemsKernel<<<dim3(1024), dim3(256), 0, stream>>>(toc, data, vectors, sums, means, lshCount, wordCount,
