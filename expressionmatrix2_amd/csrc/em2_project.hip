@@ -144,17 +144,28 @@ vectorStatsKernel(const double* __restrict__ vectors, uint32_t geneCount, uint32
 }
 
 __global__ void __launch_bounds__(256)
-vectorsToFloatKernel(const double* __restrict__ vectors, uint64_t count, float* __restrict__ out)
+vectorsToFloatKernel(const double* __restrict__ vectors, uint32_t geneCount, uint32_t lshCount, bool sliceMajor,
+                     float* __restrict__ out)
 {
+    const uint64_t count = uint64_t(geneCount) * lshCount;
     for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += uint64_t(gridDim.x) * blockDim.x) {
-        out[i] = float(vectors[i]);
+        uint64_t to = i;
+        if (sliceMajor) {       // [slice of 32 bits][gene][32]: a slice is one contiguous geneCount x 128 B block
+            const uint32_t gene = uint32_t(i / lshCount);
+            const uint32_t bit = uint32_t(i % lshCount);
+            to = (uint64_t(bit >> 5) * geneCount + gene) * 32u + (bit & 31u);
+        }
+        out[to] = float(vectors[i]);
     }
 }
+
+// The float copy of the hyperplanes is slice-major whenever the signature is a whole number of 32-bit slices.
+__host__ __device__ inline bool floatCopyIsSliceMajor(uint32_t lshCount) { return lshCount % 32u == 0u; }
 
 // Screening pass: one wave = 256 consecutive bits of one cell (4 per lane, one 16-byte load per count).
 __global__ void __launch_bounds__(256)
 projectionScreenKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t cellCount,
-                       const float* __restrict__ vectors32, const double* __restrict__ vectorSums,
+                       uint32_t geneCount, const float* __restrict__ vectors32, const double* __restrict__ vectorSums,
                        const double* __restrict__ vectorMaxAbs, const double* __restrict__ means,
                        const double* __restrict__ sumAbs, uint32_t lshCount, uint32_t wordCount,
                        uint64_t* __restrict__ signatures, uint64_t* __restrict__ workList,
@@ -165,7 +176,10 @@ projectionScreenKernel(const uint64_t* __restrict__ toc, const CountIn* __restri
     const uint32_t bit0 = chunk * 256u + lane * 4u;
     if (chunk * 256u >= lshCount) return;
     const bool valid = bit0 < lshCount;                                     // lshCount % 4 == 0 on this path
-    const float* column = vectors32 + (valid ? bit0 : 0u);
+    const bool sliceMajor = floatCopyIsSliceMajor(lshCount);
+    const uint32_t safeBit = valid ? bit0 : 0u;
+    const float* column = vectors32 + (sliceMajor ? size_t(safeBit >> 5) * geneCount * 32u + (safeBit & 31u) : size_t(safeBit));
+    const size_t rowStride = sliceMajor ? 32u : lshCount;
     double s[4], mx[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -191,7 +205,7 @@ projectionScreenKernel(const uint64_t* __restrict__ toc, const CountIn* __restri
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint64_t e = entries[j + q];
-                u[q] = *reinterpret_cast<const float4*>(column + size_t(uint32_t(e)) * lshCount);
+                u[q] = *reinterpret_cast<const float4*>(column + size_t(uint32_t(e)) * rowStride);
                 x[q] = double(__uint_as_float(uint32_t(e >> 32)));
             }
 #pragma unroll
@@ -204,7 +218,7 @@ projectionScreenKernel(const uint64_t* __restrict__ toc, const CountIn* __restri
         }
         for (; j < jEnd; ++j) {
             const uint64_t e = entries[j];
-            const float4 u = *reinterpret_cast<const float4*>(column + size_t(uint32_t(e)) * lshCount);
+            const float4 u = *reinterpret_cast<const float4*>(column + size_t(uint32_t(e)) * rowStride);
             const double x = double(__uint_as_float(uint32_t(e >> 32)));
             a[0] = __fma_rn(x, double(u.x), a[0]);
             a[1] = __fma_rn(x, double(u.y), a[1]);
@@ -251,12 +265,12 @@ projectionScreenKernel(const uint64_t* __restrict__ toc, const CountIn* __restri
 // lane, one 128-byte line per entry.  The partial sums of the 8 groups are added by a butterfly; the screening bound
 // covers the different order of the additions.  Requires lshCount % 32 == 0.
 // Measured at 1M cells x 30k genes x 1024 bits (projection ms per step): one block per 1024 bits 151; this form
-// 110; with non-temporal loads of the CSR entries 118; with 16-bit slices (EM2_PROJECTION=sliced16, half a cache
-// line per entry) 179.
+// 110 with a gene-major float copy, 77 with the slice-major copy; non-temporal loads of the CSR entries +8; 16-bit
+// slices (EM2_PROJECTION=sliced16, half a cache line per entry) 111.
 template <int BITS>       // bits per slice: 32 (one 128-byte line per entry) or 16
 __global__ void __launch_bounds__(256)
 projectionScreenSlicedKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t cellCount,
-                             const float* __restrict__ vectors32, const double* __restrict__ vectorSums,
+                             uint32_t geneCount, const float* __restrict__ vectors32, const double* __restrict__ vectorSums,
                              const double* __restrict__ vectorMaxAbs, const double* __restrict__ means,
                              const double* __restrict__ sumAbs, uint32_t lshCount, uint32_t wordCount,
                              uint64_t* __restrict__ signatures, uint64_t* __restrict__ workList,
@@ -271,7 +285,9 @@ projectionScreenSlicedKernel(const uint64_t* __restrict__ toc, const CountIn* __
     const uint32_t sub = lane % SUB;
     const uint32_t group = lane / SUB;
     const uint32_t myBit = bit0 + sub * 4u;
-    const float* column = vectors32 + myBit;
+    // slice-major float copy: the slice is one contiguous geneCount x 128 B block (a gene-major copy puts the lines
+    // of a slice 4 KB apart, which leaves most of the L2's sets unused by it)
+    const float* column = vectors32 + size_t(myBit >> 5) * geneCount * 32u + (myBit & 31u);
     double s[4], mx[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -293,7 +309,7 @@ projectionScreenSlicedKernel(const uint64_t* __restrict__ toc, const CountIn* __
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint64_t e = entries[j + GROUPS * q];
-                u[q] = *reinterpret_cast<const float4*>(column + size_t(uint32_t(e)) * lshCount);
+                u[q] = *reinterpret_cast<const float4*>(column + size_t(uint32_t(e)) * 32u);
                 x[q] = double(__uint_as_float(uint32_t(e >> 32)));
             }
 #pragma unroll
@@ -306,7 +322,7 @@ projectionScreenSlicedKernel(const uint64_t* __restrict__ toc, const CountIn* __
         }
         for (; j < jEnd; j += GROUPS) {
             const uint64_t e = entries[j];
-            const float4 u = *reinterpret_cast<const float4*>(column + size_t(uint32_t(e)) * lshCount);
+            const float4 u = *reinterpret_cast<const float4*>(column + size_t(uint32_t(e)) * 32u);
             const double x = double(__uint_as_float(uint32_t(e >> 32)));
             a[0] = __fma_rn(x, double(u.x), a[0]);
             a[1] = __fma_rn(x, double(u.y), a[1]);
@@ -437,7 +453,8 @@ hipError_t launchPrepareVectors(const double* vectors, uint32_t geneCount, uint3
     if (count) {
         uint64_t blocks = (count + 255) / 256;
         if (blocks > 16384) blocks = 16384;
-        vectorsToFloatKernel<<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(vectors, count, vectors32);
+        vectorsToFloatKernel<<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(vectors, geneCount, lshCount,
+                                                                               floatCopyIsSliceMajor(lshCount), vectors32);
     }
     return hipGetLastError();
 }
@@ -481,16 +498,16 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
         const uint32_t cellBlocks = (cellCount + kCellsPerBlock - 1u) / kCellsPerBlock;
         if (narrow) {
             const dim3 grid(cellBlocks * 8u, (lshCount + 127u) / 128u);
-            projectionScreenSlicedKernel<16><<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, vectors32, sums, maxAbs, means, sumAbs,
+            projectionScreenSlicedKernel<16><<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, vectors32, sums, maxAbs, means, sumAbs,
                                                                              lshCount, wordCount, signatures, workList, workCount);
         } else {
             const dim3 grid(cellBlocks * 8u, (lshCount + 255u) / 256u);
-            projectionScreenSlicedKernel<32><<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, vectors32, sums, maxAbs, means, sumAbs,
+            projectionScreenSlicedKernel<32><<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, vectors32, sums, maxAbs, means, sumAbs,
                                                                              lshCount, wordCount, signatures, workList, workCount);
         }
     } else {
         const dim3 grid((cellCount + kCellsPerBlock - 1u) / kCellsPerBlock, (lshCount + 1023u) / 1024u);
-        projectionScreenKernel<<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, vectors32, sums, maxAbs, means, sumAbs,
+        projectionScreenKernel<<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, vectors32, sums, maxAbs, means, sumAbs,
                                                                lshCount, wordCount, signatures, workList, workCount);
     }
     e = hipGetLastError();
