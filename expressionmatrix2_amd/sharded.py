@@ -142,9 +142,20 @@ class DevicePipeline:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        if self.sharded and not self._scan_sharded():
-            self.sharded = None                 # a pool overflowed somewhere: row shards from now on
-            self._allocate_row_shard_scan()
+        if self.sharded:
+            # A pool overflow (reported by the scan itself, agreed between the ranks) or an exception raised on this
+            # rank before any rank could be left waiting in a collective (argument / view / dtype errors are raised
+            # on every rank alike) sends all ranks to row shards together, for this and all later steps.
+            try:
+                ok = self._scan_sharded()
+            except (RuntimeError, TypeError, ValueError) as error:
+                import sys
+                print("[em2] sharded symmetric scan failed on rank %d (%s); using row shards" % (self.rank, error),
+                      file=sys.stderr)
+                ok = False
+            if not ok:
+                self.sharded = None
+                self._allocate_row_shard_scan()
         if not self.sharded and self.rows:
             stream = torch.cuda.current_stream().cuda_stream
             capi.dev_find_similar_pairs4(self.full_sig.data_ptr(), self.cell_count, self.row_begin, self.row_end,
