@@ -304,10 +304,10 @@ def dev_find_similar_pairs4(sig_ptr, cell_count, row_begin, row_end, lsh_count, 
 
 def dev_fsp4_sharded_plan(cell_count, lsh_count, k, rank, world):
     """Layout of one rank's workspace for the sharded symmetric scan (see include/em2_lsh.h)."""
-    v = np.zeros(10, dtype=np.uint64)
-    check(load().em2_dev_fsp4_sharded_plan(cell_count, lsh_count, k, rank, world, _ptr(v), 10))
+    v = np.zeros(12, dtype=np.uint64)
+    check(load().em2_dev_fsp4_sharded_plan(cell_count, lsh_count, k, rank, world, _ptr(v), 12))
     names = ("eligible", "workspace_bytes", "snap_offset", "pool_offset", "pool_capacity", "gathered_offset",
-             "gathered_capacity", "prefix_cells", "own_blocks", "blocks")
+             "gathered_capacity", "prefix_cells", "own_blocks", "blocks", "sorted_offset", "owner_shift")
     return {name: int(x) for name, x in zip(names, v)}
 
 

@@ -383,7 +383,7 @@ int em2_dev_fsp4_sharded_plan(uint32_t cellCount, uint32_t lshCount, uint32_t k,
                               uint64_t* values, uint32_t valueCount)
 {
     if (!values && valueCount) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_fsp4_sharded_plan: null pointer");
-    uint64_t all[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t all[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint32_t padded = lshCount ? em2::paddedDwords(lshCount) : 0;
     if (padded != 0 && k != 0 && k <= em2::fsp4MaxK() && world >= 1 && rank < world) {
         const em2::Fsp4ShardPlan plan = em2::fsp4ShardPlan(cellCount, k, rank, world);
@@ -398,9 +398,13 @@ int em2_dev_fsp4_sharded_plan(uint32_t cellCount, uint32_t lshCount, uint32_t k,
             all[7] = plan.prefixCells;
             all[8] = plan.ownBlocks;
             all[9] = plan.blocks;
+            all[10] = plan.offSorted;
+            uint32_t rowBits = 1;
+            while ((1ull << rowBits) < uint64_t(cellCount)) ++rowBits;
+            all[11] = 13u + rowBits + 6u;
         }
     }
-    for (uint32_t i = 0; i < valueCount; i++) values[i] = i < 10 ? all[i] : 0;
+    for (uint32_t i = 0; i < valueCount; i++) values[i] = i < 12 ? all[i] : 0;
     return EM2_OK;
 }
 
@@ -410,7 +414,7 @@ int em2_dev_fsp4_sharded_phase(int phase, const uint64_t* d_signatures, uint32_t
                                void* stream)
 {
     if (!d_signatures || !d_pairs || !d_usedCount || !d_workspace) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_fsp4_sharded_phase: null pointer");
-    if (phase < 0 || phase > 3) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_fsp4_sharded_phase: phase must be 0..3");
+    if (phase < 0 || phase > 4) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_fsp4_sharded_phase: phase must be 0..4");
     uint64_t values[2] = {0, 0};
     em2_dev_fsp4_sharded_plan(cellCount, lshCount, k, rank, world, values, 2);
     if (!values[0]) return fail(EM2_ERROR_UNSUPPORTED, "em2_dev_fsp4_sharded_phase: this shape is not eligible for the sharded symmetric scan");

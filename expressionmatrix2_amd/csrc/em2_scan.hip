@@ -1927,6 +1927,25 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
         void* kernelArgsArray[] = {&args};
         return hipLaunchKernel(kernel, grid, tileBlock, kernelArgsArray, 0, stream);
     }
+    if (phase == 4) {
+        // Groups this rank's pool entries by the rank that owns their target cell (block-cyclic: owner = (target / 64)
+        // % world, a bit field of the key when world is a power of two), for an all_to_all instead of the all_gather:
+        // a stable one-digit radix sort of pool[0, gatheredCount) into the sorted area.
+        if (gatheredCount > plan.capLocal || (plan.world & (plan.world - 1u)) != 0u) return hipErrorInvalidValue;
+        if (gatheredCount == 0 || plan.world == 1) {
+            if (gatheredCount) {
+                e = hipMemcpyAsync(xs + plan.offSorted - plan.rankBytes, ws + plan.offPool, size_t(gatheredCount) * 8u, hipMemcpyDeviceToDevice, stream);
+            }
+            return e;
+        }
+        uint32_t ownerBits = 0;
+        while ((1u << ownerBits) < plan.world) ++ownerBits;
+        const uint32_t ownerShift = 13u + rowBits + 6u;
+        size_t tempBytes = plan.sortTempBytes;
+        return rocprim::radix_sort_keys(xs + plan.offTemp - plan.rankBytes, tempBytes, reinterpret_cast<uint64_t*>(ws + plan.offPool),
+                                        reinterpret_cast<uint64_t*>(xs + plan.offSorted - plan.rankBytes), size_t(gatheredCount),
+                                        ownerShift, ownerShift + ownerBits, stream);
+    }
     if (phase == 3) {
         if (gatheredCount > plan.capGathered) return hipErrorInvalidValue;
         lastLaunchInfo.inboxEntries = double(gatheredCount);

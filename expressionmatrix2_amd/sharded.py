@@ -98,7 +98,13 @@ class DevicePipeline:
             self.pool = self.shard_ws[plan["pool_offset"]:plan["pool_offset"] + 8 * plan["pool_capacity"]].view(torch.int64)
             self.gathered = self.shard_ws[plan["gathered_offset"]:
                                           plan["gathered_offset"] + 8 * plan["gathered_capacity"]].view(torch.int64)
+            self.sorted_area = self.shard_ws[plan["sorted_offset"]:
+                                             plan["sorted_offset"] + 8 * plan["gathered_capacity"]].view(torch.int64)
             self.count_buf = torch.zeros(2, dtype=torch.int64, device=device)
+            # entries travel by all_to_all (each rank receives only the candidates of its own cells) when the owner
+            # of a target cell is a bit field of the entry key; EM2_SHARDED_EXCHANGE=gather keeps the all_gather
+            self.exchange_all_to_all = ((world_size & (world_size - 1)) == 0 and
+                                        os.environ.get("EM2_SHARDED_EXCHANGE", "alltoall") != "gather")
         else:
             self._allocate_row_shard_scan()
         self.proj_ws_bytes = capi.dev_compute_signatures_workspace(max(1, self.rows), lsh_count)
@@ -193,12 +199,41 @@ class DevicePipeline:
         max_used, any_overflow = (int(x) for x in self.count_buf.tolist())
         if any_overflow:
             return False
+        if self.exchange_all_to_all:
+            received = self._exchange_all_to_all(used, phase)
+            phase(3, received)
+            return True
         if max_used:
             if used < max_used:
                 self.pool[used:max_used].fill_(-1)           # ~0: sentinels sort behind every real entry
             dist.all_gather_into_tensor(self.gathered[:world * max_used], self.pool[:max_used])
         phase(3, world * max_used)
         return True
+
+    def _exchange_all_to_all(self, used, phase):
+        """Pool entries grouped by owner rank (phase 4) -> all_to_all_single -> self.gathered; returns the count received."""
+        torch, dist, plan = self.torch, self.dist, self.sharded
+        world = self.world_size
+        phase(4, used)
+        send = self.sorted_area[:used]
+        owners = (send >> plan["owner_shift"]) & (world - 1)
+        send_counts = torch.bincount(owners, minlength=world) if used else torch.zeros(world, dtype=torch.int64, device=send.device)
+        staged = dist.get_backend() != "nccl"               # gloo has no all_to_all on device tensors: go through the host
+        counts_in = send_counts.cpu() if staged else send_counts
+        counts_out = torch.empty_like(counts_in)
+        dist.all_to_all_single(counts_out, counts_in)
+        send_list = [int(x) for x in send_counts.tolist()]
+        recv_list = [int(x) for x in counts_out.tolist()]
+        received = sum(recv_list)
+        if received > plan["gathered_capacity"]:
+            raise RuntimeError("sharded scan: received more entries than the exchange area holds")
+        if staged:
+            recv_host = torch.empty(received, dtype=torch.int64)
+            dist.all_to_all_single(recv_host, send.cpu(), recv_list, send_list)
+            self.gathered[:received].copy_(recv_host)
+        else:
+            dist.all_to_all_single(self.gathered[:received], send, recv_list, send_list)
+        return received
 
     def owned_ranges(self):
         """Global [begin, end) cell ranges whose results this rank holds after scan()."""

@@ -201,11 +201,16 @@ int em2_dev_find_similar_pairs7(const uint64_t* d_signatures, uint32_t cellCount
  *               pool[used, maxUsed) with ~0 (pool = uint64[poolCapacity] at poolOffset), all_gather pool[0, maxUsed)
  *               into gathered = uint64[world*maxUsed] at gatheredOffset
  *     phase 3 with gatheredCount = world*maxUsed
+ * or, when world is a power of two, exchanging only what each rank needs:
+ *     phase 2;  status -> used;  phase 4 with gatheredCount = used: the pool entries grouped by the rank that owns their
+ *               target cell ((key >> ownerShift) & (world-1)) in sorted = uint64[..] at sortedOffset; all_to_all of those
+ *               groups into gathered; phase 3 with gatheredCount = entries received
  * d_pairs [cellCount][k] and d_usedCount [cellCount] are indexed by GLOBAL cell id; phase 3 fills the rows of the
  * cells this rank owns.  If any rank reports overflow the result is unusable and the caller falls back to
  * em2_dev_find_similar_pairs4 on row shards.  em2_dev_fsp4_sharded_plan: values[0] eligible (0: shape too small, use
  * the row-shard call), [1] workspace bytes (256-byte aligned allocation), [2] snapOffset, [3] poolOffset,
- * [4] poolCapacity, [5] gatheredOffset, [6] gatheredCapacity, [7] prefix cells, [8] blocks owned, [9] blocks.
+ * [4] poolCapacity, [5] gatheredOffset, [6] gatheredCapacity, [7] prefix cells, [8] blocks owned, [9] blocks,
+ * [10] sortedOffset, [11] ownerShift.
  * No reference counterpart (the reference is single-threaded); results are those of src/ExpressionMatrixLsh.cpp:155-290. */
 int em2_dev_fsp4_sharded_plan(uint32_t cellCount, uint32_t lshCount, uint32_t k, uint32_t rank, uint32_t world,
                               uint64_t* values, uint32_t valueCount);

@@ -31,8 +31,10 @@ def run_two_ranks(extra_env, cells, port):
     return json.loads(lines[0])
 
 
-def test_sharded_symmetric_scan_two_ranks():
-    result = run_two_ranks({"EM2_SHARDED_MIN_CELLS": "1000"}, cells=30000, port=29631)
+@pytest.mark.parametrize("exchange", ["alltoall", "gather"])
+def test_sharded_symmetric_scan_two_ranks(exchange):
+    result = run_two_ranks({"EM2_SHARDED_MIN_CELLS": "1000", "EM2_SHARDED_EXCHANGE": exchange}, cells=30000,
+                           port=29631 if exchange == "alltoall" else 29634)
     assert result["config"]["scan"] == "sharded-symmetric"
     assert result["n_gpus"] == 2 and result["parity_check"]["fsp4_rows"] > 0
     assert result["roofline"]["inbox_entries"] > 0
