@@ -372,7 +372,9 @@ fsp4ScanSymmetricKernel(Fsp4Args args)
                 const uint32_t colEnd2_ = unpark(colEndV);                                                                  \
                 const uint32_t rowBase2_ = (unpark(blockV) * kernelArgs()->rowBlockStride + kernelArgs()->rowBlockOffset) * 64u;                                                            \
                 const uint32_t triEnd2_ = colEnd2_ < rowBase2_ ? colEnd2_ : rowBase2_;                                      \
-                if (at_ >= triEnd2_) {                                                                                      \
+                /* a log that filled up at the very last column below the block must not take more entries */               \
+                const bool logFull_ = SPEC && __builtin_amdgcn_ballot_w64(logCount == logCapacity) != 0ull;                 \
+                if (at_ >= triEnd2_ && !logFull_) {                                                                         \
                     const uint32_t colBegin2_ = unpark(colBeginV);                                                          \
                     const uint32_t diagBegin_ = colBegin2_ > rowBase2_ ? colBegin2_ : rowBase2_;                            \
                     at_ = scanDiagonal<W32, IDENTITY, SPEC>(kernelArgs()->sig32, kernelArgs()->snap,                        \

@@ -302,3 +302,15 @@ def test_fsp4_golden_digests(scan_knobs, mode):
         cell = np.ascontiguousarray(pairs["cell"])
         sim = np.ascontiguousarray(pairs["similarity"])
         assert digest(cell, sim, used) == golden[case["name"]]["fsp4"], case["name"]
+
+
+@pytest.mark.parametrize("L", [2048, 4096])
+def test_fsp4_symmetric_log_full_at_last_column_below_the_block(oracle, scan_knobs, L):
+    """Found by tools/fuzz_parity.py: a speculative log that fills up exactly at the last column below a row block
+    must not receive the block's diagonal columns as well (rows 1222 / 1230 / 1254 of this case came out wrong)."""
+    sig = synth.clustered_signatures(1500, L, cluster_count=5, flip=0.1, seed=1)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, 10, -0.5)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_MIN_SEGMENT_COLUMNS=257, EM2_LOG_CAPACITY=16, EM2_FULL_ROW_CELLS=200,
+               EM2_BLOCKS_PER_CU=2)
+    pairs, gused = capi.find_similar_pairs4(sig, L, 10, -0.5)
+    assert_same(pairs, gused, cell, sim, used)

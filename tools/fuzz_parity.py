@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on a GPU box (not part of pytest): random shapes, thresholds, k and scan-form knobs, every
+result compared bit for bit with the CPU oracle.  SECONDS=300 python3 tools/fuzz_parity.py [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_binding  # noqa: E402
+import synth  # noqa: E402
+from expressionmatrix2_amd import capi  # noqa: E402
+
+KNOBS = ("EM2_SCAN_MODE", "EM2_MIN_SEGMENT_COLUMNS", "EM2_LOG_CAPACITY", "EM2_FULL_ROW_CELLS", "EM2_VIRTUAL_WORLD",
+         "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_BLOCKS_PER_CU", "EM2_SEGMENTS")
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    rng = np.random.default_rng(seed)
+    oracle = oracle_binding.load_oracle()
+    deadline = time.time() + float(os.environ.get("SECONDS", "120"))
+    runs = {"fsp4": 0, "fsp5": 0, "fsp7": 0, "signatures": 0}
+    while time.time() < deadline:
+        for key in KNOBS:
+            os.environ.pop(key, None)
+        n = int(rng.choice([1, 2, 63, 64, 65, 200, 500, 1000, 1500, 2500, 4000]))
+        L = int(rng.choice([1, 32, 64, 100, 128, 192, 256, 512, 1000, 1024, 2048, 4096]))
+        k = int(rng.choice([1, 2, 5, 10, 33, 100, 300]))
+        thr = float(rng.choice([-1.0, -0.5, 0.0, 0.1, 0.2, 0.5, 0.9]))
+        clusters = int(rng.choice([1, 2, 5, 20]))
+        flip = float(rng.choice([0.0, 0.02, 0.1, 0.3, 0.5]))
+        sig = synth.clustered_signatures(n, L, cluster_count=clusters, flip=flip, seed=int(rng.integers(1 << 30)))
+        what = rng.choice(["fsp4", "fsp4", "fsp4", "fsp5", "fsp7", "signatures"])
+        label = dict(n=n, L=L, k=k, thr=thr, clusters=clusters, flip=flip)
+        if what == "fsp4":
+            knobs = {"EM2_SCAN_MODE": str(rng.choice(["persistent", "triangle", "virtual", "simple"])),
+                     "EM2_MIN_SEGMENT_COLUMNS": str(int(rng.choice([64, 100, 257, 1000, 4096]))),
+                     "EM2_LOG_CAPACITY": str(int(rng.choice([1, 3, 16, 256]))),
+                     "EM2_FULL_ROW_CELLS": str(int(rng.choice([0, 64, 200, 1000, 100000]))),
+                     "EM2_VIRTUAL_WORLD": str(int(rng.choice([1, 2, 3, 4, 8]))),
+                     "EM2_PREFIX_PERMILLE": str(int(rng.choice([50, 200, 500, 900]))),
+                     "EM2_TILE_SEGMENTS": str(int(rng.choice([1, 3, 17, 256]))),
+                     "EM2_BLOCKS_PER_CU": str(int(rng.choice([1, 2, 4])))}
+            os.environ.update(knobs)
+            label.update(knobs)
+            cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
+            pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+        elif what == "fsp5":
+            q = int(rng.choice([1, 3, 8, 13, 20]))
+            overflow = int(rng.choice([0, 5, 1000]))
+            label.update(q=q, overflow=overflow)
+            cell, sim, used = oracle.find_similar_pairs5(sig, L, k, thr, q, overflow)
+            pairs, gused = capi.find_similar_pairs5(sig, L, k, thr, q, overflow)
+        elif what == "fsp7":
+            lengths = sorted(set(int(x) for x in rng.choice([1, 2, 5, 8, 13, 16, 24, 33, 64], size=int(rng.integers(1, 4)))), reverse=True)
+            max_check = int(rng.choice([0, 1, 7, 100, 100000]))
+            log2b = int(rng.choice([4, 10, 16, 24]))
+            if thr <= -1.0:
+                thr = -0.9            # the reference asserts when no mismatch count is below the threshold
+            label.update(lengths=lengths, max_check=max_check, log2b=log2b, thr=thr)
+            cell, sim, used = oracle.find_similar_pairs7(sig, L, k, thr, lengths, max_check, log2b)
+            pairs, gused = capi.find_similar_pairs7(sig, L, k, thr, lengths, max_check, log2b)
+        else:
+            cells, genes = int(rng.choice([1, 50, 300, 1000])), int(rng.choice([1, 10, 200, 1500]))
+            toc, g, c = synth.expression_matrix(cells, genes, density=float(rng.choice([0.0, 0.01, 0.2])), cluster_count=3,
+                                                seed=int(rng.integers(1 << 30)))
+            os.environ["EM2_PROJECTION"] = str(rng.choice(["sliced", "screen", "exact", "sliced16"]))
+            vectors = oracle.generate_lsh_vectors(genes, L, int(rng.integers(1 << 20)))
+            expect = oracle.compute_signatures(toc, g, c, genes, vectors, L)
+            got = capi.compute_signatures(toc, capi.make_counts(g, c), genes, vectors, L)
+            os.environ.pop("EM2_PROJECTION", None)
+            if not np.array_equal(expect, got):
+                raise SystemExit("PARITY FAILURE signatures %r" % dict(cells=cells, genes=genes, L=L))
+            runs[what] += 1
+            continue
+        ok = (np.array_equal(gused, used) and np.array_equal(pairs["cell"], cell) and
+              np.array_equal(pairs["similarity"].view(np.uint32), sim.view(np.uint32)))
+        if not ok:
+            raise SystemExit("PARITY FAILURE %s %r" % (what, label))
+        runs[what] += 1
+    print("fuzz ok", runs)
+
+
+if __name__ == "__main__":
+    main()
