@@ -279,6 +279,9 @@ hipError_t runFsp7(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
     }
     const uint32_t tableCount = uint32_t(tableLength.size());
     if (tableCount == 0 || cellCount == 0 || k == 0) return hipStreamSynchronize(stream);
+    // maxCheck == 0: the size test after the slice loop of a length (:667) also holds for a length that has no slice
+    // at all (slice length above lshCount; such lengths come first) -- nothing has been found yet, the walk ends.
+    if (maxCheck == 0 && sliceLengthCount > 0 && lshCount / uint32_t(sliceLengths[0]) == 0) return hipStreamSynchronize(stream);
     const uint64_t total = uint64_t(tableCount) * cellCount;
     if (total >= 0xffffffffULL || tableCount >= (1u << 23)) return hipErrorInvalidValue;
 
