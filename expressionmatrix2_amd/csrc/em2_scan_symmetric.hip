@@ -157,9 +157,14 @@ __device__ __forceinline__ uint32_t scanColumnsEmit(const uint32_t* __restrict__
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int w = 0; w < CH; ++w) popcountAccumulate(m, r[part * CH + w] ^ chunk[s & 1][w]);
+                for (int w = 0; w < CH; ++w) {
+                    if (part == 0 && w == 0) popcountFirst(m, r[0] ^ chunk[s & 1][0]);
+                    else popcountAccumulate(m, r[part * CH + w] ^ chunk[s & 1][w]);
+                }
                 if (part == H - 1) {
                     // one compare in the steady state: m against the looser of the row's and the column's cut-off
+                    // (the empty asm pins the v_max behind the popcounts; without it hipcc hoists it in front of them and
+                    // the kernel measured 1.2% slower)
                     int32_t limit = mMax > snapCol[ci] ? mMax : snapCol[ci];
                     asm volatile("" : "+v"(limit));
                     if (__builtin_amdgcn_ballot_w64(int32_t(m) <= limit) != 0ull) {
@@ -583,7 +588,10 @@ __device__ __forceinline__ uint32_t scanTileEmit(const uint32_t* __restrict__ si
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int w = 0; w < CH; ++w) popcountAccumulate(m, r[part * CH + w] ^ chunk[s & 1][w]);
+                for (int w = 0; w < CH; ++w) {
+                    if (part == 0 && w == 0) popcountFirst(m, r[0] ^ chunk[s & 1][0]);
+                    else popcountAccumulate(m, r[part * CH + w] ^ chunk[s & 1][w]);
+                }
                 if (part == H - 1) {
                     int32_t limit = snapRow > snapCol[ci] ? snapRow : snapCol[ci];
                     asm volatile("" : "+v"(limit));
