@@ -14,9 +14,9 @@
 //      reference (2.6 GB of vector headers at q = 20) are never materialised;
 //   2. run boundaries -> bucket id of every (slice, cell); bucket sizes apply the overflow rule;
 //   3. per batch of cells: gather the members of the cell's buckets, segmented radix sort per cell, then one
-//      wave per cell removes duplicates, gathers the candidates' signatures, counts mismatches, keeps
-//      m <= mGlobal in ascending id order (ballot + prefix popcount), runs the exact keepBest emulation and
-//      writes the sorted result.
+//      wave per cell removes duplicates, gathers the candidates' signatures, counts mismatches and keeps
+//      m <= mGlobal in ascending id order (ballot + prefix popcount) -- filterKernel, no LDS, full occupancy --
+//      and a second kernel runs the exact keepBest emulation in LDS and writes the sorted result (selectKernel).
 // The sorts are library primitives (rocPRIM); everything specific to the path is hand-written here.
 
 #include "em2_device.h"
@@ -32,7 +32,8 @@
 namespace em2 {
 namespace {
 
-constexpr uint32_t kSelectLdsEntries = 4096;        // lists up to this length are cut in LDS, longer ones in HBM
+constexpr uint32_t kSelectLdsEntries = 4096;        // lists up to this length are cut in 48 KB of LDS ...
+constexpr uint32_t kSelectLdsEntriesBig = 12288;    // ... up to this length in 144 KB, longer ones in HBM
 
 __device__ __forceinline__ uint32_t sliceValue(const uint64_t* sig, uint32_t slice, uint32_t q)
 {
@@ -125,26 +126,24 @@ __device__ __forceinline__ void waveFence()
     __builtin_amdgcn_wave_barrier();
 }
 
-// One wave per cell: unique + mismatch filter (ascending id order), keepBest, sort, store.
-__global__ void __launch_bounds__(64)
-filterSelectKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batchBegin, uint32_t batchCells,
-                   const uint32_t* __restrict__ segmentBegin, const uint32_t* __restrict__ sortedCandidates,
-                   Entry* __restrict__ lists, int32_t mGlobal, const uint32_t* __restrict__ keyOfMismatch,
-                   const float* __restrict__ keySimilarity, uint32_t k, PairOut* __restrict__ outPairs,
-                   uint32_t* __restrict__ outUsed)
+// One wave per cell: unique + mismatch filter in ascending id order (ExpressionMatrixLsh.cpp:436-445).  Uses no LDS
+// and few registers on purpose: the kernel is a latency-bound gather of candidate signatures and wants every wave
+// slot of the CU (the selection below, which stages lists in 48 KB of LDS, runs 3 waves per CU; as one fused kernel
+// the gathers ran at that occupancy too and took 1.58 s of a 1.81 s run at 1M cells x 2048 bits).
+__global__ void __launch_bounds__(256)
+filterKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batchBegin, uint32_t batchCells,
+             const uint32_t* __restrict__ segmentBegin, const uint32_t* __restrict__ sortedCandidates,
+             Entry* __restrict__ lists, int32_t mGlobal, const uint32_t* __restrict__ keyOfMismatch,
+             uint32_t* __restrict__ listCounts)
 {
-    __shared__ Entry lds[kSelectLdsEntries];
-    __shared__ uint16_t ldsL[kSelectLdsEntries];
-    __shared__ uint16_t ldsR[kSelectLdsEntries];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t local = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t local = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (local >= batchCells) return;
     const uint32_t c = batchBegin + local;
     const uint32_t begin = segmentBegin[local];
     const uint32_t end = segmentBegin[local + 1u];
     const uint64_t* mine = sig + size_t(c) * words;
     Entry* list = lists + begin;                    // at most (end-begin) entries survive
-
     uint32_t n = 0;
     for (uint32_t base = begin; base < end; base += 64u) {
         const uint32_t i = base + lane;
@@ -169,20 +168,35 @@ filterSelectKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t ba
         }
         n += uint32_t(__builtin_popcountll(mask));
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0u) listCounts[local] = n;
+}
 
-    // keepBest(cellNeighbors, k) (:457) then SimilarPairs::copy + sort (:489-496).
+// One wave per cell: keepBest(cellNeighbors, k) (:457), then SimilarPairs::copy + sort (:489-496), store.
+// CAPACITY entries are staged in LDS (12 bytes each).  The kernel is launched twice per batch: CAPACITY 4096 (48 KB,
+// 3 waves per CU) takes the cells with up to 4096 candidates, CAPACITY 12288 (144 KB, one wave per CU) the longer
+// lists; only lists beyond that are cut by a single lane in HBM (at 1M cells x 2048 bits, q = 20, a few per cent of
+// the cells have more than 4096 candidates, and cutting those in HBM took half of the whole run).
+template <uint32_t CAPACITY, uint32_t ABOVE>
+__global__ void __launch_bounds__(64)
+selectKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegin, Entry* __restrict__ lists,
+             const uint32_t* __restrict__ listCounts, const float* __restrict__ keySimilarity, uint32_t k,
+             PairOut* __restrict__ outPairs, uint32_t* __restrict__ outUsed)
+{
+    __shared__ Entry lds[CAPACITY];
+    __shared__ uint16_t ldsL[CAPACITY];
+    __shared__ uint16_t ldsR[CAPACITY];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t local = blockIdx.x;
+    if (local >= batchCells) return;
+    Entry* list = lists + segmentBegin[local];
+    uint32_t n = listCounts[local];
+    if (n <= ABOVE && ABOVE != 0u) return;              // the other launch's cells
+    if (ABOVE == 0u && n > CAPACITY) return;
+
     Entry* work = list;
-    const bool inLds = n <= kSelectLdsEntries;
+    const bool inLds = n <= CAPACITY;
     if (inLds) {
-        for (uint32_t i = lane; i < n; i += 64u) {
-            const uint64_t v = __hip_atomic_load(reinterpret_cast<const uint64_t*>(list + i), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-            Entry e;
-            e.cell = uint32_t(v);
-            e.key = uint32_t(v >> 32);
-            lds[i] = e;
-        }
+        for (uint32_t i = lane; i < n; i += 64u) lds[i] = list[i];
         work = lds;
         waveFence();
     }
@@ -322,7 +336,7 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
 
     // 3. batches of cells whose gathered candidates fit the budget
     const uint64_t budget = 1ull << 28;              // 2^28 candidate ids (1 GiB) per batch
-    Buffer segBegin, candA, candB, lists, sortTemp;
+    Buffer segBegin, candA, candB, lists, sortTemp, listCounts;
     std::vector<uint32_t> hostSeg;
     uint32_t batchBegin = rowBegin;
     const uint32_t idBits = bitsFor(cellCount - 1u);
@@ -361,9 +375,21 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
                                                        segBegin.as<uint32_t>(), segBegin.as<uint32_t>() + 1, 0u, idBits, stream));
             sorted = candB.as<uint32_t>();
         }
-        filterSelectKernel<<<batchCells, 64, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
-                                                          lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch, tables.keySimilarity, k,
-                                                          d_pairs + size_t(batchBegin - rowBegin) * k, d_used + (batchBegin - rowBegin));
+        EM2_TRY(listCounts.allocate(size_t(batchCells) * sizeof(uint32_t)));
+        filterKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
+                                                                 lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,
+                                                                 listCounts.as<uint32_t>());
+        EM2_TRY(hipGetLastError());
+        selectKernel<kSelectLdsEntries, 0u><<<batchCells, 64, 0, stream>>>(batchCells, segBegin.as<uint32_t>(), lists.as<Entry>(),
+                                                                           listCounts.as<uint32_t>(), tables.keySimilarity, k,
+                                                                           d_pairs + size_t(batchBegin - rowBegin) * k,
+                                                                           d_used + (batchBegin - rowBegin));
+        EM2_TRY(hipGetLastError());
+        selectKernel<kSelectLdsEntriesBig, kSelectLdsEntries><<<batchCells, 64, 0, stream>>>(batchCells, segBegin.as<uint32_t>(),
+                                                                                             lists.as<Entry>(), listCounts.as<uint32_t>(),
+                                                                                             tables.keySimilarity, k,
+                                                                                             d_pairs + size_t(batchBegin - rowBegin) * k,
+                                                                                             d_used + (batchBegin - rowBegin));
         EM2_TRY(hipGetLastError());
         EM2_TRY(hipStreamSynchronize(stream));       // hostSeg / scratch are reused by the next batch
         batchBegin = batchEnd;

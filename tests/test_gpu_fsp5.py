@@ -58,10 +58,17 @@ def test_fsp5_wide_slices_equal_narrow_run_on_duplicated_cells():
 
 
 def test_fsp5_identical_cells_long_lists(oracle):
-    """Every cell identical: one bucket of 6000 per slice, every candidate passes, lists longer than the LDS
-    staging area -> the HBM selection path; ties everywhere."""
+    """Every cell identical: one bucket of 6000 per slice, every candidate passes, lists longer than the 4096-entry LDS
+    staging area -> the 12288-entry selection launch; ties everywhere."""
     sig = np.tile(synth.random_signatures(1, 128, seed=5), (6000, 1))
     check(oracle, sig, 128, 9, 0.2, 16, 0)
+    # 13000 identical cells: lists beyond every LDS staging area -> cut by one lane in HBM
+    many = np.tile(synth.random_signatures(1, 64, seed=6), (13000, 1))
+    cell, sim, oused = oracle.find_similar_pairs5_rows(many, 64, 4, 0.2, 16, 0, 0, 40)
+    pairs, gused = capi.find_similar_pairs5(many, 64, 4, 0.2, 16, 0)
+    assert np.array_equal(gused[:40], oused) and np.array_equal(pairs["cell"][:40], cell)
+    assert np.array_equal(pairs["similarity"][:40].view(np.uint32), sim.view(np.uint32))
+    assert (gused == 4).all()
     # with the overflow rule every bucket is dropped
     pairs, used = capi.find_similar_pairs5(sig, 128, 9, 0.2, 16, 1000)
     assert used.sum() == 0
