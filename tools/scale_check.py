@@ -97,6 +97,35 @@ def main():
                           "ordered_comparisons_per_s": cells * cells / min(times), "sampled_rows_bit_exact": ok}))
         if not ok:
             raise SystemExit("PARITY FAILURE")
+    elif what == "fsp7":
+        cells, L, k, thr = int(os.environ.get("CELLS", 1000000)), int(os.environ.get("LSH", 1024)), 100, 0.2
+        lengths, max_check, log2b = [20, 14], int(os.environ.get("MAXCHECK", 1000)), 18
+        sig = clustered_signatures_gpu(cells, L)
+        host = sig.cpu().numpy().view(np.uint64)
+        import ctypes
+        lengths_arr = np.asarray(lengths, dtype=np.int32)
+        d_pairs = torch.zeros((cells, k, 2), dtype=torch.int32, device="cuda")
+        d_used = torch.zeros(cells, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        capi.check(capi.load().em2_dev_find_similar_pairs7(sig.data_ptr(), cells, 0, cells, L, k, thr, capi._ptr(lengths_arr),
+                                                           len(lengths), max_check, log2b, d_pairs.data_ptr(), d_used.data_ptr(),
+                                                           stream))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        u = d_used.cpu().numpy()
+        print(json.dumps({"check": "fsp7", "cells": cells, "lsh_count": L, "lengths": lengths, "max_check": max_check,
+                          "gpu_seconds": dt, "mean_used": float(u.mean())}), flush=True)
+        # parity on a problem the literal oracle can hold: the first 20000 cells on their own
+        small = 20000
+        sub = np.ascontiguousarray(host[:small])
+        cell, sim, used = oracle.find_similar_pairs7(sub, L, k, thr, lengths, max_check, log2b)
+        pairs, gused = capi.find_similar_pairs7(sub, L, k, thr, lengths, max_check, log2b)
+        ok = bool(np.array_equal(gused, used) and np.array_equal(pairs["cell"], cell) and
+                  np.array_equal(pairs["similarity"].view(np.uint32), sim.view(np.uint32)))
+        print(json.dumps({"check": "fsp7 parity on the first 20000 cells", "bit_exact": ok}))
+        if not ok:
+            raise SystemExit("PARITY FAILURE")
     elif what == "sweep":
         cells, L, k, thr = int(os.environ.get("CELLS", 1000000)), int(os.environ.get("LSH", 1024)), 100, 0.2
         sig = clustered_signatures_gpu(cells, L)
