@@ -8,6 +8,7 @@
 #include "em2_tables.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <functional>
 #include <thread>
@@ -107,6 +108,20 @@ int getDeviceTables(uint32_t lshCount, double similarityThreshold, em2::DeviceTa
 }
 
 // RAII device allocation for the host-buffer entry points.
+// EM2_TIMING=1: wall time of the stages of the fused host-buffer call on stderr (measurements only).
+struct CallTimer {
+    bool on = getenv("EM2_TIMING") && getenv("EM2_TIMING")[0] == '1';
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void stage(const char* name)
+    {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[em2 timing]   device call: %s %.1f ms\n", name, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+
 struct DeviceBuffer {
     void* p = nullptr;
     ~DeviceBuffer() { if (p) (void)hipFree(p); }
@@ -650,6 +665,7 @@ int em2_subset_find_similar_pairs4(const uint64_t* globalToc, const em2_count* g
     if (srcNnz && !srcData) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_subset_find_similar_pairs4: null data");
 
     const uint32_t words = wordCountOf(lshCount);
+    CallTimer timer;
     DeviceBuffer dSrcToc, dSrcData, dLocal, dToc, dData, dSubsetWs, dVectors, dSig, dWs, dAux;
     EM2_HIP(dSrcToc.allocate((size_t(cellCount) + 1) * sizeof(uint64_t)));
     EM2_HIP(dSrcData.allocate(srcNnz * sizeof(em2_count)));
@@ -662,6 +678,7 @@ int em2_subset_find_similar_pairs4(const uint64_t* globalToc, const em2_count* g
     if (globalGeneCount) EM2_HIP(hipMemcpy(dLocal.p, geneLocalIds, size_t(globalGeneCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
     std::vector<uint64_t>().swap(rowToc);
     std::vector<em2_count>().swap(rowData);
+    timer.stage("allocate + CSR to device");
     EM2_HIP(em2::launchSubsetCount(dSrcToc.as<uint64_t>(), dSrcData.as<em2::CountIn>(), nullptr, cellCount, dLocal.as<uint32_t>(),
                                    globalGeneCount, dToc.as<uint64_t>(), dSubsetWs.p, subsetWs, nullptr));
     uint64_t nnz = 0;
@@ -672,6 +689,7 @@ int em2_subset_find_similar_pairs4(const uint64_t* globalToc, const em2_count* g
     EM2_HIP(hipStreamSynchronize(nullptr));
     (void)hipFree(dSrcData.p);
     dSrcData.p = nullptr;
+    timer.stage("subset");
 
     // signatures (same steps as em2_compute_signatures, on the device-resident subset)
     const size_t wsBytes = em2_dev_compute_signatures_workspace(cellCount, lshCount);
@@ -691,6 +709,7 @@ int em2_subset_find_similar_pairs4(const uint64_t* globalToc, const em2_count* g
                                         aux, lshCount, dSig.as<uint64_t>(), dWs.p, wsBytes, nullptr);
     if (rc != EM2_OK) return rc;
     EM2_HIP(hipStreamSynchronize(nullptr));
+    timer.stage("hyperplanes to device + projection");
     if (signatures) EM2_HIP(hipMemcpy(signatures, dSig.p, size_t(cellCount) * words * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (!wantPairs) return EM2_OK;
     // free what the scan does not need before its (large) workspace is allocated
@@ -712,8 +731,10 @@ int em2_subset_find_similar_pairs4(const uint64_t* globalToc, const em2_count* g
     if (rc != EM2_OK) return rc;
     rc = em2_dev_find_similar_pairs4_status(dScanWs.p, cellCount, k, nullptr);
     if (rc != EM2_OK) return rc;
+    timer.stage("allocate + scan");
     EM2_HIP(hipMemcpy(pairs, dPairs.p, size_t(cellCount) * k * sizeof(em2_pair), hipMemcpyDeviceToHost));
     EM2_HIP(hipMemcpy(usedCount, dUsed.p, size_t(cellCount) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    timer.stage("pairs to host");
     return EM2_OK;
 }
 
