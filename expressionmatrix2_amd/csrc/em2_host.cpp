@@ -1,6 +1,8 @@
 #include "em2_host.h"
 
 #include <chrono>
+#include <functional>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 
@@ -322,7 +324,8 @@ void Matrix::subset(const std::string& geneSetName, const std::string& cellSetNa
 // (em2_subset_find_similar_pairs4): the work of ExpressionMatrixSubset + Lsh (+ the pair loop).
 void Matrix::runLshPath(const char* what, const std::string& geneSetName, const std::string& cellSetName, size_t lshCount,
                         unsigned int seed, uint32_t& cellCount, std::vector<uint64_t>* signatures, size_t k,
-                        double similarityThreshold, std::vector<em2_pair>* pairs, std::vector<uint32_t>* used) const
+                        double similarityThreshold, const std::function<em2_pair*(uint32_t)>& pairsFor,
+                        std::vector<uint32_t>* used) const
 {
     StageTimer timer(what);
     const GeneSet* genes = nullptr;
@@ -336,15 +339,16 @@ void Matrix::runLshPath(const char* what, const std::string& geneSetName, const 
     timer.stage("hyperplanes");
     const size_t words = (lshCount - 1) / 64 + 1;
     if (signatures) signatures->assign(size_t(cellCount) * words, 0);
-    if (pairs) {
-        pairs->assign(size_t(cellCount) * k, em2_pair());
+    em2_pair* pairs = nullptr;
+    if (used) {
+        pairs = pairsFor(cellCount);           // where the pairs go (the mapped SimilarPairs file)
         used->assign(cellCount, 0);
     }
     const int rc = em2_subset_find_similar_pairs4(
         static_cast<const uint64_t*>(toc_.data()), static_cast<const em2_count*>(data_.data()), uint32_t(toc_.objectCount() - 1),
         cellIds, cellCount, static_cast<const uint32_t*>(genes->localIds.data()), uint32_t(genes->localIds.objectCount()),
         geneCount, vectors.data(), uint32_t(lshCount), signatures ? signatures->data() : nullptr, uint32_t(k),
-        similarityThreshold, pairs ? pairs->data() : nullptr, pairs ? used->data() : nullptr);
+        similarityThreshold, pairs, used ? used->data() : nullptr);
     if (rc != EM2_OK) fail(rc, em2_last_error());
     timer.stage("device: subset, signatures, pairs (incl. transfers)");
 }
@@ -355,15 +359,22 @@ void Matrix::findSimilarPairs4(const std::string& geneSetName, const std::string
 {
     // Lsh lsh(tmp-Lsh, subset, lshCount, seed) (ExpressionMatrixLsh.cpp:197), the pair loop and the selection
     // (:200-269).
+    // SimilarPairs(directory, name, geneSet, cellSet, k) + copy + sort (ExpressionMatrixLsh.cpp:278-285): the device
+    // produces the sorted order and its result is copied straight into the mapped -Pairs file.  tmp-Lsh /
+    // tmp-ExpressionMatrixSubset files of the reference are deleted before it returns (:288,
+    // ExpressionMatrixSubset.cpp:62-73) and are not created here.
     uint32_t cellCount = 0;
-    std::vector<em2_pair> pairs;
     std::vector<uint32_t> used;
-    runLshPath("findSimilarPairs4", geneSetName, cellSetName, lshCount, seed, cellCount, nullptr, k, similarityThreshold, &pairs, &used);
-    // SimilarPairs(directory, name, geneSet, cellSet, k) + copy + sort (ExpressionMatrixLsh.cpp:278-285); the
-    // device already produced the sorted order.  tmp-Lsh / tmp-ExpressionMatrixSubset files of the reference
-    // are deleted before it returns (:288, ExpressionMatrixSubset.cpp:62-73) and are not created here.
+    std::unique_ptr<SimilarPairsWriter> writer;
+    runLshPath("findSimilarPairs4", geneSetName, cellSetName, lshCount, seed, cellCount, nullptr, k, similarityThreshold,
+               [&](uint32_t cells) {
+                   writer.reset(new SimilarPairsWriter(directoryName_, similarPairsName, geneSetName, cellSetName, k, cells));
+                   return writer->pairs();
+               },
+               &used);
     StageTimer timer("findSimilarPairs4");
-    writeSimilarPairs(directoryName_, similarPairsName, geneSetName, cellSetName, k, cellCount, pairs.data(), used.data());
+    writer->finish(used.data());
+    writer.reset();
     timer.stage("write files");
 }
 
@@ -452,9 +463,10 @@ void Matrix::removeSimilarPairs(const std::string& similarPairsName) const
 // SimilarPairs / Lsh files
 // ---------------------------------------------------------------------------------------------------------
 
-void writeSimilarPairs(const std::string& directoryName, const std::string& similarPairsName,
-                       const std::string& geneSetName, const std::string& cellSetName, size_t k,
-                       uint32_t cellCount, const em2_pair* pairs, const uint32_t* usedCount)
+SimilarPairsWriter::SimilarPairsWriter(const std::string& directoryName, const std::string& similarPairsName,
+                                       const std::string& geneSetName, const std::string& cellSetName, size_t k,
+                                       uint32_t cellCount)
+    : cellCount_(cellCount)
 {
     // accessGeneSet / accessCellSet (SimilarPairs.cpp:97-113)
     GeneSet genes;
@@ -467,27 +479,36 @@ void writeSimilarPairs(const std::string& directoryName, const std::string& simi
     if (cells.objectCount() != cellCount) fail(EM2_ERROR_RUNTIME, "SimilarPairs: cell count is not the size of cell set " + cellSetName);
 
     const std::string base = directoryName + "/SimilarPairs-" + similarPairsName;
-    MappedFile infoFile;
-    infoFile.createNew(base + "-Info", true, sizeof(SimilarPairsInfoRecord), 1);
-    SimilarPairsInfoRecord* info = static_cast<SimilarPairsInfoRecord*>(infoFile.data());
+    infoFile_.createNew(base + "-Info", true, sizeof(SimilarPairsInfoRecord), 1);
+    SimilarPairsInfoRecord* info = static_cast<SimilarPairsInfoRecord*>(infoFile_.data());
     info->k = k;
     setStaticString(info->geneSetName, geneSetName);
     info->geneSetHash = hashOf(genes.globalIds, sizeof(uint32_t));
     setStaticString(info->cellSetName, cellSetName);
     info->cellSetHash = hashOf(cells, sizeof(uint32_t));
+    pairsFile_.createNew(base + "-Pairs", false, sizeof(em2_pair), k * size_t(cellCount));
+    cellInfoFile_.createNew(base + "-CellInfo", false, sizeof(CellInfoRecord), cellCount);
+}
 
-    MappedFile pairsFile;
-    pairsFile.createNew(base + "-Pairs", false, sizeof(em2_pair), k * size_t(cellCount));
-    if (k && cellCount) std::memcpy(pairsFile.data(), pairs, k * size_t(cellCount) * sizeof(em2_pair));
+em2_pair* SimilarPairsWriter::pairs() { return static_cast<em2_pair*>(pairsFile_.data()); }
 
-    MappedFile cellInfoFile;
-    cellInfoFile.createNew(base + "-CellInfo", false, sizeof(CellInfoRecord), cellCount);
-    CellInfoRecord* ci = static_cast<CellInfoRecord*>(cellInfoFile.data());
-    for (uint32_t c = 0; c < cellCount; c++) {
+void SimilarPairsWriter::finish(const uint32_t* usedCount)
+{
+    CellInfoRecord* ci = static_cast<CellInfoRecord*>(cellInfoFile_.data());
+    for (uint32_t c = 0; c < cellCount_; c++) {
         ci[c].usedCount = usedCount[c];                      // SimilarPairs::copy, :376
         ci[c].lowestSimilarityIndex = 0xffffffffu;           // constructor values, never updated by copy (:36-40)
         ci[c].lowestSimilarity = FLT_MAX;
     }
+}
+
+void writeSimilarPairs(const std::string& directoryName, const std::string& similarPairsName,
+                       const std::string& geneSetName, const std::string& cellSetName, size_t k,
+                       uint32_t cellCount, const em2_pair* pairs, const uint32_t* usedCount)
+{
+    SimilarPairsWriter writer(directoryName, similarPairsName, geneSetName, cellSetName, k, cellCount);
+    if (k && cellCount) std::memcpy(writer.pairs(), pairs, k * size_t(cellCount) * sizeof(em2_pair));
+    writer.finish(usedCount);
 }
 
 void readSimilarPairs(const std::string& directoryName, const std::string& similarPairsName,

@@ -14,6 +14,7 @@
 
 #include <stdint.h>
 #include <map>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -83,9 +84,11 @@ public:
     // The lookups and checks of subset() without building it; runLshPath builds it on the device.
     void lookupSubset(const std::string& geneSetName, const std::string& cellSetName, const GeneSet*& genes,
                       const uint32_t*& cellIds, uint32_t& cellCount) const;
+    // pairsFor(cellCount) returns where the pairs are to be written (used != nullptr asks for pairs at all).
     void runLshPath(const char* what, const std::string& geneSetName, const std::string& cellSetName, size_t lshCount,
                     unsigned int seed, uint32_t& cellCount, std::vector<uint64_t>* signatures, size_t k,
-                    double similarityThreshold, std::vector<em2_pair>* pairs, std::vector<uint32_t>* used) const;
+                    double similarityThreshold, const std::function<em2_pair*(uint32_t)>& pairsFor,
+                    std::vector<uint32_t>* used) const;
 
     void findSimilarPairs4(const std::string& geneSetName, const std::string& cellSetName,
                            const std::string& similarPairsName, size_t k, double similarityThreshold,
@@ -112,6 +115,19 @@ private:
 };
 
 // SimilarPairs files (src/SimilarPairs.cpp:11-42 create, :369-379 copy): -Info, -Pairs, -CellInfo.
+// SimilarPairs(directory, name, geneSetName, cellSetName, k) for writing (src/SimilarPairs.cpp:11-42): creates the three
+// files; the pairs are written in place (k per cell, the caller's order is final), finish() fills CellInfo.
+class SimilarPairsWriter {
+public:
+    SimilarPairsWriter(const std::string& directoryName, const std::string& similarPairsName, const std::string& geneSetName,
+                       const std::string& cellSetName, size_t k, uint32_t cellCount);
+    em2_pair* pairs();
+    void finish(const uint32_t* usedCount);
+private:
+    MappedFile infoFile_, pairsFile_, cellInfoFile_;
+    uint32_t cellCount_;
+};
+
 void writeSimilarPairs(const std::string& directoryName, const std::string& similarPairsName,
                        const std::string& geneSetName, const std::string& cellSetName, size_t k,
                        uint32_t cellCount, const em2_pair* pairs, const uint32_t* usedCount);
