@@ -929,10 +929,6 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
                               cellCount - fullCellsClamped, stream);
         if (e != hipSuccess) return e;
     }
-    if (getenv("EM2_DEBUG_NO_EMIT")) {      // timing experiment only: results are wrong
-        e = hipMemsetAsync(args.snap, 0xff, size_t(cellCount) * 4u, stream);
-        if (e != hipSuccess) return e;
-    }
     e = hipMemcpyAsync(ws + layout.table, table, (2u * segments + 2u) * 4u, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return e;
 
