@@ -14,15 +14,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_two_ranks(extra_env, cells, port):
+def run_two_ranks(extra_env, cells, port, ranks=2):
     env = dict(os.environ)
     env.update({"EM2_BENCH_SHARE_DEVICE": "1", "EM2_BENCH_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1",
                 # two persistent kernels share one GPU here: keep them from oversubscribing it (hand-off waits of one
                 # process must not keep the other's waves off the machine)
                 "EM2_BLOCKS_PER_CU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     env.update(extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1",
            "--warmup", "0", "--cells", str(cells), "--genes", "3000", "--no-cpu-baseline", "--check-rows", "96"]
     done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
@@ -38,6 +38,13 @@ def test_sharded_symmetric_scan_two_ranks(exchange):
     assert result["config"]["scan"] == "sharded-symmetric"
     assert result["n_gpus"] == 2 and result["parity_check"]["fsp4_rows"] > 0
     assert result["roofline"]["inbox_entries"] > 0
+
+
+def test_sharded_symmetric_scan_four_ranks_ragged_size():
+    """Four ranks (all_to_all exchange with more than one peer) on a cell count that is no multiple of anything."""
+    result = run_two_ranks({"EM2_SHARDED_MIN_CELLS": "1000"}, cells=40003, port=29635, ranks=4)
+    assert result["config"]["scan"] == "sharded-symmetric"
+    assert result["n_gpus"] == 4 and result["parity_check"]["fsp4_rows"] > 0
 
 
 def test_row_shard_scan_two_ranks():
