@@ -519,18 +519,23 @@ fsp4InboxReplayKernel(Fsp4Args args, const uint64_t* __restrict__ sorted, uint64
     }
     if (!rowValid) bound[1] = bound[0];
     const uint32_t idMask = (1u << nb) - 1u;
-    for (uint64_t i = bound[0];; ++i) {
-        const bool active = i < bound[1];
-        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
-        uint32_t c = 0, m = 0;
-        if (active) {
-            const uint64_t e = sorted[i];
-            c = uint32_t(e >> 13u) & idMask;
-            m = uint32_t(e) & 0x1fffu;
-        }
-        const bool pass = active && int32_t(m) <= mMax;
-        if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
-            acceptColumn<IDENTITY>(pass, c, row, m, lane, block, myList, twoK, count, mMax, ldsRaw);
+    // Entries are fetched four at a time (independent loads in flight: the loop is latency-bound otherwise) and then
+    // offered one by one, in order.
+    constexpr int kAhead = 4;
+    for (uint64_t i = bound[0];; i += kAhead) {
+        if (__builtin_amdgcn_ballot_w64(i < bound[1]) == 0ull) break;
+        uint64_t e[kAhead];
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) e[q] = (i + q < bound[1]) ? sorted[i + q] : 0ull;
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) {
+            const bool active = i + q < bound[1];
+            const uint32_t c = uint32_t(e[q] >> 13u) & idMask;
+            const uint32_t m = uint32_t(e[q]) & 0x1fffu;
+            const bool pass = active && int32_t(m) <= mMax;
+            if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                acceptColumn<IDENTITY>(pass, c, row, m, lane, block, myList, twoK, count, mMax, ldsRaw);
+            }
         }
     }
     finishRows(lane, block, count, ldsRaw);
