@@ -47,6 +47,31 @@ def regression_cases():
     ]
 
 
+def bucketed_cases():
+    """(name, signatures, arguments) of the fsp5 / fsp7 / cell-graph regression digests."""
+    sig = synth.clustered_signatures(900, 512, cluster_count=6, flip=0.12, seed=99)
+    return sig, {
+        "fsp5_900_L512_k10_q14_overflow1000": dict(k=10, thr=0.2, q=14, overflow=1000),
+        "fsp5_900_L512_k25_q9_overflow0": dict(k=25, thr=0.0, q=9, overflow=0),
+        "fsp7_900_L512_k10_lengths24_12_check60_log2b16": dict(k=10, thr=0.2, lengths=[24, 12], max_check=60, log2b=16),
+        "fsp7_900_L512_k30_lengths64_7_check0_log2b5": dict(k=30, thr=0.1, lengths=[64, 7], max_check=0, log2b=5),
+    }
+
+
+def bucketed_digests(oracle):
+    sig, cases = bucketed_cases()
+    out = {}
+    for name, a in cases.items():
+        if name.startswith("fsp5"):
+            out[name] = digest(*oracle.find_similar_pairs5(sig, 512, a["k"], a["thr"], a["q"], a["overflow"]))
+        else:
+            out[name] = digest(*oracle.find_similar_pairs7(sig, 512, a["k"], a["thr"], a["lengths"], a["max_check"], a["log2b"]))
+    cell, sim, used = oracle.find_similar_pairs4(sig, 512, 20, 0.2)
+    ids = np.arange(900, dtype=np.uint32)
+    out["cellgraph_900_thr0.5_k5"] = digest(*oracle.cell_graph_edges(cell, sim, used, ids, ids, 0.5, 5))
+    return out
+
+
 def make_signatures(case):
     if case["kind"] == "clustered":
         return synth.clustered_signatures(case["n"], case["L"], cluster_count=8, flip=0.15, seed=4242)
@@ -101,6 +126,7 @@ def main():
     for L in (128, 1024, 2048):
         t = oracle.similarity_table(L)
         regression["similarity_table_%d" % L] = {"double_bits": digest(t), "float_bits": digest(t.astype(np.float32))}
+    regression.update(bucketed_digests(oracle))
     with open(os.path.join(HERE, "oracle_regression.json"), "w") as f:
         json.dump(regression, f, indent=1)
     print("wrote fixtures:", i, "keepBest cases,", len(regression), "regression digests")

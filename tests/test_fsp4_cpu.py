@@ -80,6 +80,9 @@ def test_oracle_regression_digests(oracle):
         assert digest(sig) == golden[case["name"]]["signatures"]
         cell, sim, used = oracle.find_similar_pairs4(sig, case["L"], case["k"], case["thr"])
         assert digest(cell, sim, used) == golden[case["name"]]["fsp4"]
+    from golden.make_golden import bucketed_digests
+    for name, value in bucketed_digests(oracle).items():
+        assert golden[name] == value, name
     for L in (128, 1024, 2048):
         t = oracle.similarity_table(L)
         assert digest(t) == golden["similarity_table_%d" % L]["double_bits"]

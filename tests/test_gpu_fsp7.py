@@ -77,3 +77,23 @@ def test_fsp7_facade_files(oracle, tmp_path):
     with pytest.raises(RuntimeError, match="Gene set Nope does not exist."):
         e.findSimilarPairs7(geneSetName="Nope", lshName="L", similarPairsName="Q", lshSliceLengths=[8], maxCheck=10,
                             log2BucketCount=10)
+
+
+def test_bucketed_and_graph_golden_digests():
+    """The committed digests of the fsp5 / fsp7 / cell-graph regression cases (tests/golden/oracle_regression.json,
+    written by the oracle) straight against the GPU results."""
+    import json
+    import os
+    from golden.make_golden import bucketed_cases, digest
+    with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_regression.json")) as f:
+        golden = json.load(f)
+    sig, cases = bucketed_cases()
+    for name, a in cases.items():
+        if name.startswith("fsp5"):
+            pairs, used = capi.find_similar_pairs5(sig, 512, a["k"], a["thr"], a["q"], a["overflow"])
+        else:
+            pairs, used = capi.find_similar_pairs7(sig, 512, a["k"], a["thr"], a["lengths"], a["max_check"], a["log2b"])
+        assert digest(np.ascontiguousarray(pairs["cell"]), np.ascontiguousarray(pairs["similarity"]), used) == golden[name], name
+    pairs, used = capi.find_similar_pairs4(sig, 512, 20, 0.2)
+    ids = np.arange(900, dtype=np.uint32)
+    assert digest(*capi.cell_graph_edges(pairs, used, ids, ids, 0.5, 5)) == golden["cellgraph_900_thr0.5_k5"]
