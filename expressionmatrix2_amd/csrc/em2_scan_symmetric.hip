@@ -752,7 +752,8 @@ constexpr uint32_t kInboxChunk = 512;
 
 bool symmetricEligible(uint32_t cellCount, uint32_t rowCount)
 {
-    if (rowCount != cellCount || cellCount < 128u) return false;
+    // inbox keys hold two cell ids and a mismatch count in 64 bits: 13 + 2 * bits(cellCount) <= 64
+    if (rowCount != cellCount || cellCount < 128u || cellCount > (1u << 25)) return false;
     const char* v = getenv("EM2_SCAN_MODE");
     if (v && v[0] == 't') return true;
     if (v && (v[0] == 's' || v[0] == 'p')) return false;
@@ -1047,7 +1048,7 @@ Fsp4ShardPlan fsp4ShardPlan(uint32_t cellCount, uint32_t k, uint32_t rank, uint3
     p.rank = rank;
     p.k = k;
     p.blocks = (cellCount + 63u) / 64u;
-    if (world == 0 || rank >= world || k == 0 || p.blocks < 4u * world) return p;     // not eligible: too small
+    if (world == 0 || rank >= world || k == 0 || p.blocks < 4u * world || cellCount > (1u << 25)) return p;     // not eligible
     // prefix: EM2_PREFIX_PERMILLE of the cells (default 200), a positive multiple of `world` blocks
     uint64_t prefixBlocks = (uint64_t(p.blocks) * envNumber("EM2_PREFIX_PERMILLE", 200) / 1000u + world / 2u) / world * world;
     if (prefixBlocks < world) prefixBlocks = world;
