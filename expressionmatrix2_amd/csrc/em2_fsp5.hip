@@ -22,6 +22,7 @@
 #include "em2_device.h"
 #include "em2_select_wave.h"
 
+#include <cstdlib>
 #include <cstring>      // rocprim/iterator/texture_cache_iterator.hpp calls memset without including it
 
 #include <rocprim/rocprim.hpp>
@@ -158,6 +159,83 @@ filterKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batchBeg
                 keep = int32_t(m) <= mGlobal;                                // similarity > similarityThreshold (:441)
             }
         }
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) {
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+            Entry e;
+            e.cell = cand;
+            e.key = keyOfMismatch[m];
+            list[n + before] = e;
+        }
+        n += uint32_t(__builtin_popcountll(mask));
+    }
+    if (lane == 0u) listCounts[local] = n;
+}
+
+// Default form of the filter: groups of lpc lanes (16 from 1024 bits on) read consecutive words of one candidate's
+// signature -- one contiguous request per candidate instead of 64 scattered 8-byte reads per wave instruction -- and
+// add their partial popcounts with a butterfly; only the candidates that need a count (not a duplicate, not the cell
+// itself) are visited, looked up by rank through LDS.  rocprof at 1M cells x 2048 bits, q = 20: 210 ms against 730 ms
+// for the one-lane-per-candidate filterKernel above (kept for signatures beyond 8192 bits and A/B runs).
+__global__ void __launch_bounds__(256)
+filterCooperativeKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batchBegin, uint32_t batchCells,
+                        const uint32_t* __restrict__ segmentBegin, const uint32_t* __restrict__ sortedCandidates,
+                        Entry* __restrict__ lists, int32_t mGlobal, const uint32_t* __restrict__ keyOfMismatch,
+                        uint32_t* __restrict__ listCounts)
+{
+    __shared__ uint32_t candOfRankAll[4][64];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* candOfRank = candOfRankAll[threadIdx.x >> 6];
+    const uint32_t local = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (local >= batchCells) return;
+    const uint32_t c = batchBegin + local;
+    const uint32_t begin = segmentBegin[local];
+    const uint32_t end = segmentBegin[local + 1u];
+    Entry* list = lists + begin;
+    uint32_t lpc = 16u;
+    while (lpc > words) lpc >>= 1;
+    if (lpc == 0u) lpc = 1u;
+    const uint32_t perStep = 64u / lpc;
+    const uint32_t sub = lane % lpc;
+    const uint32_t slot = lane / lpc;
+    // this lane's share of the cell's own signature (words sub, sub+lpc, ...), at most 8 registers (words <= 64... 128)
+    uint64_t mine[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) mine[t] = (sub + t * lpc < words) ? sig[size_t(c) * words + sub + t * lpc] : 0ull;
+    uint32_t n = 0;
+    for (uint32_t base = begin; base < end; base += 64u) {
+        const uint32_t i = base + lane;
+        bool need = false;
+        uint32_t cand = 0;
+        if (i < end) {
+            cand = sortedCandidates[i];
+            const bool duplicate = i > begin && sortedCandidates[i - 1u] == cand;
+            need = !duplicate && cand != c;
+        }
+        const uint64_t needMask = __builtin_amdgcn_ballot_w64(need);
+        const uint32_t needCount = uint32_t(__builtin_popcountll(needMask));
+        const uint32_t myRank = __builtin_amdgcn_mbcnt_hi(uint32_t(needMask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(needMask), 0u));
+        if (need) candOfRank[myRank] = cand;
+        waveFence();
+        // step s computes the counts of the candidates of rank s*perStep .. s*perStep+perStep-1; the count of rank r is
+        // parked in lane r of mOfRank (a register indexed by lane) through a shuffle-free trick: lane r reads it from LDS
+        uint32_t m = 0;
+        for (uint32_t first = 0; first < needCount; first += perStep) {
+            const uint32_t rank = first + slot;
+            uint32_t part = 0;
+            if (rank < needCount) {
+                const uint64_t* theirs = sig + size_t(candOfRank[rank]) * words + sub;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (sub + t * lpc < words) part += uint32_t(__builtin_popcountll(mine[t] ^ theirs[t * lpc]));
+                }
+            }
+            for (uint32_t d = 1; d < lpc; d <<= 1) part += uint32_t(__shfl_xor(int(part), int(d), 64));
+            const uint32_t got = uint32_t(__shfl(int(part), int(((myRank - first) % perStep) * lpc), 64));
+            if (need && myRank >= first && myRank < first + perStep) m = got;
+        }
+        waveFence();
+        const bool keep = need && int32_t(m) <= mGlobal;
         const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
         if (keep) {
             const uint32_t before = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
@@ -334,33 +412,51 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
     // keys / flags / scan are no longer needed
     keysA.release(); flags.release(); scan.release(); scanTemp.release(); temp.release(); cellsA.release();
 
-    // 3. batches of cells whose gathered candidates fit the budget
+    // 3. batches of cells whose gathered candidates fit the budget.  The batches are planned first so that the scratch
+    // is allocated once, at the size of the largest batch (allocating per batch cost more than the kernels).
     const uint64_t budget = 1ull << 28;              // 2^28 candidate ids (1 GiB) per batch
-    Buffer segBegin, candA, candB, lists, sortTemp, listCounts;
-    std::vector<uint32_t> hostSeg;
-    uint32_t batchBegin = rowBegin;
-    const uint32_t idBits = bitsFor(cellCount - 1u);
-    while (batchBegin < rowEnd) {
+    struct Batch { uint32_t begin, end; std::vector<uint32_t> seg; };
+    std::vector<Batch> batches;
+    uint64_t maxTotal = 0;
+    uint32_t maxCells = 0;
+    for (uint32_t batchBegin = rowBegin; batchBegin < rowEnd;) {
+        Batch batch;
+        batch.begin = batchBegin;
         uint64_t sum = 0;
         uint32_t batchEnd = batchBegin;
-        hostSeg.assign(1, 0u);
+        batch.seg.assign(1, 0u);
         while (batchEnd < rowEnd && batchEnd - batchBegin < (1u << 20)) {
             const uint64_t n = hostCounts[batchEnd];
             if (n >= 0xffffffffULL) return hipErrorInvalidValue;
             if (sum + n > budget && batchEnd > batchBegin) break;
             sum += n;
             ++batchEnd;
-            hostSeg.push_back(uint32_t(sum));
+            batch.seg.push_back(uint32_t(sum));
             if (sum > budget) break;                 // a single huge cell: its own batch
         }
         if (sum >= 0xffffffffULL) return hipErrorInvalidValue;
-        const uint32_t batchCells = batchEnd - batchBegin;
-        const uint32_t batchTotal = uint32_t(sum);
-        EM2_TRY(segBegin.allocate(hostSeg.size() * sizeof(uint32_t)));
-        EM2_TRY(hipMemcpyAsync(segBegin.p, hostSeg.data(), hostSeg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        EM2_TRY(candA.allocate(size_t(batchTotal) * sizeof(uint32_t)));
-        EM2_TRY(candB.allocate(size_t(batchTotal) * sizeof(uint32_t)));
-        EM2_TRY(lists.allocate(size_t(batchTotal) * sizeof(Entry)));
+        batch.end = batchEnd;
+        if (sum > maxTotal) maxTotal = sum;
+        if (batchEnd - batchBegin > maxCells) maxCells = batchEnd - batchBegin;
+        batches.push_back(std::move(batch));
+        batchBegin = batchEnd;
+    }
+    Buffer segBegin, candA, candB, lists, sortTemp, listCounts;
+    EM2_TRY(segBegin.allocate((size_t(maxCells) + 1u) * sizeof(uint32_t)));
+    EM2_TRY(candA.allocate(size_t(maxTotal) * sizeof(uint32_t)));
+    EM2_TRY(candB.allocate(size_t(maxTotal) * sizeof(uint32_t)));
+    EM2_TRY(lists.allocate(size_t(maxTotal) * sizeof(Entry)));
+    EM2_TRY(listCounts.allocate(size_t(maxCells) * sizeof(uint32_t)));
+    size_t sortTempBytes = 0;
+    const uint32_t idBits = bitsFor(cellCount - 1u);
+    // EM2_FSP5_FILTER=lane selects the one-lane-per-candidate filter (A/B measurements)
+    const char* filterMode = getenv("EM2_FSP5_FILTER");
+    const bool cooperative = words <= 8u * 16u && !(filterMode && filterMode[0] == 'l');
+    for (const Batch& batch : batches) {
+        const uint32_t batchBegin = batch.begin;
+        const uint32_t batchCells = batch.end - batch.begin;
+        const uint32_t batchTotal = batch.seg.back();
+        EM2_TRY(hipMemcpyAsync(segBegin.p, batch.seg.data(), batch.seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         const uint32_t* sorted = candA.as<uint32_t>();
         if (batchTotal) {
             gatherKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(runOf.as<uint32_t>(), runStart.as<uint32_t>(), sortedCells, cellCount,
@@ -370,15 +466,24 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
             size_t segBytes = 0;
             EM2_TRY(rocprim::segmented_radix_sort_keys(nullptr, segBytes, candA.as<uint32_t>(), candB.as<uint32_t>(), batchTotal, batchCells,
                                                        segBegin.as<uint32_t>(), segBegin.as<uint32_t>() + 1, 0u, idBits, stream));
-            EM2_TRY(sortTemp.allocate(segBytes));
+            if (segBytes > sortTempBytes) {
+                EM2_TRY(hipStreamSynchronize(stream));
+                EM2_TRY(sortTemp.allocate(segBytes));
+                sortTempBytes = segBytes;
+            }
             EM2_TRY(rocprim::segmented_radix_sort_keys(sortTemp.p, segBytes, candA.as<uint32_t>(), candB.as<uint32_t>(), batchTotal, batchCells,
                                                        segBegin.as<uint32_t>(), segBegin.as<uint32_t>() + 1, 0u, idBits, stream));
             sorted = candB.as<uint32_t>();
         }
-        EM2_TRY(listCounts.allocate(size_t(batchCells) * sizeof(uint32_t)));
-        filterKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
-                                                                 lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,
-                                                                 listCounts.as<uint32_t>());
+        if (cooperative) {
+            filterCooperativeKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(),
+                                                                                sorted, lists.as<Entry>(), tables.mGlobal,
+                                                                                tables.keyOfMismatch, listCounts.as<uint32_t>());
+        } else {
+            filterKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
+                                                                     lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,
+                                                                     listCounts.as<uint32_t>());
+        }
         EM2_TRY(hipGetLastError());
         selectKernel<kSelectLdsEntries, 0u><<<batchCells, 64, 0, stream>>>(batchCells, segBegin.as<uint32_t>(), lists.as<Entry>(),
                                                                            listCounts.as<uint32_t>(), tables.keySimilarity, k,
@@ -391,8 +496,7 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
                                                                                              d_pairs + size_t(batchBegin - rowBegin) * k,
                                                                                              d_used + (batchBegin - rowBegin));
         EM2_TRY(hipGetLastError());
-        EM2_TRY(hipStreamSynchronize(stream));       // hostSeg / scratch are reused by the next batch
-        batchBegin = batchEnd;
+        EM2_TRY(hipStreamSynchronize(stream));       // the batch's offsets (pageable host memory) and scratch are reused
     }
     return hipSuccess;
 }
