@@ -171,9 +171,6 @@ template <int W32, bool IDENTITY>
 __global__ void __launch_bounds__(256)
 fsp4ScanPersistentKernel(Fsp4Args args)
 {
-    const uint32_t* __restrict__ sig32 = args.sig32;
-    const uint32_t cellCount = args.cellCount;
-
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     const uint32_t lane = threadIdx.x & 63u;
 
@@ -186,6 +183,10 @@ fsp4ScanPersistentKernel(Fsp4Args args)
             ticket = __hip_atomic_fetch_add(kernelArgs()->control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         ticket = uint32_t(__builtin_amdgcn_readfirstlane(int(ticket)));
+        // the ticket and the column range are only needed between the scan loops: parked in VGPRs, so that the loops
+        // keep their SGPRs for the column chunks
+        uint32_t ticketV = ticket;
+        asm volatile("" : "+v"(ticketV));
 
         uint32_t colBegin, colEnd, row;
         uint32_t r[W32];
@@ -211,10 +212,10 @@ fsp4ScanPersistentKernel(Fsp4Args args)
             asm volatile("" : "+v"(logCapacity));
             colBegin = seg * aux->columnsPerSegment;
             colEnd = colBegin + aux->columnsPerSegment;
-            if (colEnd > cellCount || seg + 1u == aux->segments) colEnd = cellCount;
+            if (colEnd > aux->cellCount || seg + 1u == aux->segments) colEnd = aux->cellCount;
             row = aux->rowBegin + block * 64u + lane;
             rowValid = row < aux->rowEnd;
-            const uint32_t* rp = sig32 + size_t(rowValid ? row : aux->rowBegin + block * 64u) * W32;
+            const uint32_t* rp = aux->sig32 + size_t(rowValid ? row : aux->rowBegin + block * 64u) * W32;
 #pragma unroll
             for (int w = 0; w < W32; ++w) r[w] = rp[w];
             mMax = rowValid ? args.mMaxInitial : -1;
@@ -231,11 +232,16 @@ fsp4ScanPersistentKernel(Fsp4Args args)
             }
         }
 
+        uint32_t colEndV = colEnd;
+        asm volatile("" : "+v"(colEndV));
         uint32_t resume = colBegin;
         if (speculate) {
-            resume = scanColumns<W32, IDENTITY, true>(sig32, colBegin, colEnd, r, row, lane, ticket, myList, twoK, count, mMax,
-                                                      myLog, logCapacity, logCount, ldsRaw);
+            resume = scanColumns<W32, IDENTITY, true>(kernelArgs()->sig32, colBegin, colEnd, r, row, lane, ticketV, myList, twoK,
+                                                      count, mMax, myLog, logCapacity, logCount, ldsRaw);
         }
+        uint32_t resumeV = resume;
+        asm volatile("" : "+v"(resumeV));
+        ticket = uint32_t(__builtin_amdgcn_readfirstlane(int(ticketV)));
 
         if (ticket >= kernelArgs()->rowBlocks) {
             // ---- wait for the previous segment of this row block, then take over its exact state ----
@@ -283,8 +289,10 @@ fsp4ScanPersistentKernel(Fsp4Args args)
         }
 
         // ---- exact scan of whatever the speculation did not cover (all of the segment on the exact path) ----
-        scanColumns<W32, IDENTITY, false>(sig32, resume, colEnd, r, row, lane, ticket, myList, twoK, count, mMax, myLog,
-                                          logCapacity, logCount, ldsRaw);
+        scanColumns<W32, IDENTITY, false>(kernelArgs()->sig32, uint32_t(__builtin_amdgcn_readfirstlane(int(resumeV))),
+                                          uint32_t(__builtin_amdgcn_readfirstlane(int(colEndV))), r, row, lane, ticketV, myList,
+                                          twoK, count, mMax, myLog, logCapacity, logCount, ldsRaw);
+        ticket = uint32_t(__builtin_amdgcn_readfirstlane(int(ticketV)));
 
         // ---- last segment: finish the rows; otherwise publish the state for the next segment ----
         {
