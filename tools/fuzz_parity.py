@@ -23,7 +23,7 @@ def main():
     rng = np.random.default_rng(seed)
     oracle = oracle_binding.load_oracle()
     deadline = time.time() + float(os.environ.get("SECONDS", "120"))
-    runs = {"fsp4": 0, "fsp5": 0, "fsp7": 0, "signatures": 0}
+    runs = {"fsp4": 0, "fsp5": 0, "fsp7": 0, "signatures": 0, "graph": 0}
     while time.time() < deadline:
         for key in KNOBS:
             os.environ.pop(key, None)
@@ -34,7 +34,7 @@ def main():
         clusters = int(rng.choice([1, 2, 5, 20]))
         flip = float(rng.choice([0.0, 0.02, 0.1, 0.3, 0.5]))
         sig = synth.clustered_signatures(n, L, cluster_count=clusters, flip=flip, seed=int(rng.integers(1 << 30)))
-        what = rng.choice(["fsp4", "fsp4", "fsp4", "fsp5", "fsp7", "signatures"])
+        what = rng.choice(["fsp4", "fsp4", "fsp4", "fsp5", "fsp7", "signatures", "graph"])
         label = dict(n=n, L=L, k=k, thr=thr, clusters=clusters, flip=flip)
         if what == "fsp4":
             knobs = {"EM2_SCAN_MODE": str(rng.choice(["persistent", "triangle", "virtual", "simple"])),
@@ -64,6 +64,22 @@ def main():
             label.update(lengths=lengths, max_check=max_check, log2b=log2b, thr=thr)
             cell, sim, used = oracle.find_similar_pairs7(sig, L, k, thr, lengths, max_check, log2b)
             pairs, gused = capi.find_similar_pairs7(sig, L, k, thr, lengths, max_check, log2b)
+        elif what == "graph":
+            cell, sim, used = oracle.find_similar_pairs4(sig, L, k, min(thr, 0.2))
+            total = n + int(rng.integers(0, n + 1))
+            sp_cells = np.sort(rng.choice(total, n, replace=False)).astype(np.uint32)
+            graph_cells = rng.permutation(total)[:int(rng.integers(1, total + 1))].astype(np.uint32)
+            g_thr = float(rng.choice([-1.0, 0.0, 0.3, 0.5, 0.9]))
+            max_conn = int(rng.choice([0, 1, 3, 20, 1000]))
+            expect = oracle.cell_graph_edges(cell, sim, used, sp_cells, graph_cells, g_thr, max_conn)
+            pairs = np.zeros(cell.shape, dtype=capi.PAIR_DTYPE)
+            pairs["cell"] = cell
+            pairs["similarity"] = sim
+            got = capi.cell_graph_edges(pairs, used, sp_cells, graph_cells, g_thr, max_conn)
+            if not all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(expect, got)):
+                raise SystemExit("PARITY FAILURE graph %r" % dict(label, g_thr=g_thr, max_conn=max_conn))
+            runs[what] += 1
+            continue
         else:
             cells, genes = int(rng.choice([1, 50, 300, 1000])), int(rng.choice([1, 10, 200, 1500]))
             toc, g, c = synth.expression_matrix(cells, genes, density=float(rng.choice([0.0, 0.01, 0.2])), cluster_count=3,
