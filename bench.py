@@ -253,8 +253,11 @@ def main():
             "traffic_source": "profiles/r01_pmc_hbm_traffic_1Mcells.json (FETCH_SIZE+WRITE_SIZE, bytes per launch)"
                               if traffic is not None else None,
             "algorithmic_bytes": algorithmic_bytes,
+            "comparisons_executed_per_s": launch["wave_column_steps"] * 64.0 / (kernel_ms * 1e-3) if kernel_ms else 0.0,
             "valu_frac": valu_frac,
-            "note": "algorithmic bytes = 16*W per unordered pair; operands are cache/SGPR resident so frac is not "
+            "note": "algorithmic bytes = 16*W per unordered pair; comparisons_executed_per_s = (row, column) mismatch counts the kernel "
+                    "actually evaluated per second (about one per unordered pair in the symmetric forms, two in the ordered one); "
+                    "operands are cache/SGPR resident so frac is not "
                     "bounded by 1; valu_frac = (v_xor+v_bcnt lane-ops actually executed)/(256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz), "
                     "the measured issue rate of these ops; kernel_ms = HIP events on the launch stream around the scan kernel "
                     "(recorded inside the library for the symmetric form, around the call otherwise)",
