@@ -107,7 +107,6 @@ int getDeviceTables(uint32_t lshCount, double similarityThreshold, em2::DeviceTa
     return EM2_OK;
 }
 
-// RAII device allocation for the host-buffer entry points.
 // EM2_TIMING=1: wall time of the stages of the fused host-buffer call on stderr (measurements only).
 struct CallTimer {
     bool on = getenv("EM2_TIMING") && getenv("EM2_TIMING")[0] == '1';
@@ -122,6 +121,7 @@ struct CallTimer {
     }
 };
 
+// RAII device allocation for the host-buffer entry points.
 struct DeviceBuffer {
     void* p = nullptr;
     ~DeviceBuffer() { if (p) (void)hipFree(p); }
