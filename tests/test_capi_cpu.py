@@ -70,3 +70,22 @@ def test_device_paths_fail_loudly_without_gpu(lib):
     toc = np.zeros(5, dtype=np.uint64)
     with pytest.raises(RuntimeError, match="no HIP device"):
         capi.compute_signatures(toc, np.zeros(0, dtype=capi.COUNT_DTYPE), 3, np.zeros((3, 64)), 64)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        capi.find_similar_pairs5(sig, 128, 3, 0.2, 8)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        capi.find_similar_pairs7(sig, 128, 3, 0.2, [10, 8], 100, 12)
+    pairs = np.zeros((4, 3), dtype=capi.PAIR_DTYPE)
+    used = np.zeros(4, dtype=np.uint32)
+    cells = np.arange(4, dtype=np.uint32)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        capi.cell_graph_edges(pairs, used, cells, cells, 0.2, 3)
+    # the fused subset call has no numpy wrapper (the facade drives it through the matrix handle): raw ABI
+    counts = np.zeros(0, dtype=capi.COUNT_DTYPE)
+    genes = np.arange(3, dtype=np.uint32)
+    vectors = np.zeros((64, 3))
+    status = capi.load().em2_subset_find_similar_pairs4(
+        toc.ctypes.data, counts.ctypes.data, 4, cells.ctypes.data, 4, genes.ctypes.data, 3, 3,
+        vectors.ctypes.data, 64, None, 3, 0.2, pairs.ctypes.data, used.ctypes.data)
+    assert status != 0
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        capi.check(status)
