@@ -66,6 +66,9 @@ SYMBOLS = {
     "em2_subset_find_similar_pairs4": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_void_p, _c.c_uint32,
                                                   _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p, _c.c_uint32,
                                                   _c.c_void_p, _c.c_uint32, _c.c_double, _c.c_void_p, _c.c_void_p]),
+    "em2_cell_graph_label_propagation": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                                    _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_void_p,
+                                                    _c.c_void_p]),
     "em2_dev_find_similar_pairs4_form": (_c.c_int, [_c.c_uint32, _c.c_uint32]),
     "em2_dev_find_similar_pairs4_last_launch": (_c.c_int, [_c.c_void_p, _c.c_uint32]),
     "em2_dev_fsp4_sharded_plan": (_c.c_int, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
@@ -263,6 +266,25 @@ def cell_graph_edges(pairs, used_count, similar_pairs_cell_set, graph_cell_set, 
                                       _ptr(v0), _ptr(v1), _ptr(sim), ctypes.byref(count)))
     n = int(count.value)
     return v0[:n].copy(), v1[:n].copy(), sim[:n].copy()
+
+
+def cell_graph_label_propagation(vertex_cell_ids, edge_vertex0, edge_vertex1, edge_similarity, seed=231,
+                                 stable_iteration_count_threshold=3, max_iteration_count=100):
+    """CellGraph::labelPropagationClustering (src/CellGraph.cpp:443-612) -> (clusterId per vertex, iterations run).
+    Host code by nature (a serial schedule defines the result); defaults are ClusterGraphCreationParameters'
+    (src/ClusterGraph.hpp:48-50)."""
+    cells = np.ascontiguousarray(vertex_cell_ids, dtype=np.uint32)
+    v0 = np.ascontiguousarray(edge_vertex0, dtype=np.uint32)
+    v1 = np.ascontiguousarray(edge_vertex1, dtype=np.uint32)
+    sim = np.ascontiguousarray(edge_similarity, dtype=np.float32)
+    if not (len(v0) == len(v1) == len(sim)):
+        raise ValueError("the three edge arrays must have one entry per edge")
+    clusters = np.zeros(len(cells), dtype=np.uint32)
+    iterations = ctypes.c_uint64(0)
+    check(load().em2_cell_graph_label_propagation(_ptr(cells), len(cells), _ptr(v0), _ptr(v1), _ptr(sim), len(v0),
+                                                  seed, stable_iteration_count_threshold, max_iteration_count,
+                                                  _ptr(clusters), ctypes.byref(iterations)))
+    return clusters, int(iterations.value)
 
 
 def find_similar_pairs7(signatures, lsh_count, k, similarity_threshold, lsh_slice_lengths, max_check, log2_bucket_count):

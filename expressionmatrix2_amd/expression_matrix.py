@@ -142,6 +142,7 @@ class ExpressionMatrix:
         similarPairsCells = self._cell_set(similarPairsCellSetName)
         v0, v1, similarity = capi.cell_graph_edges(pairs, used, similarPairsCells, graphCells, similarityThreshold, k)
         vertices = graphCells
+        edgeVertices = (v0, v1)
         isolatedRemoved = 0
         if not keepIsolatedVertices:                # CellGraph::removeIsolatedVertices (src/CellGraph.cpp:189-205)
             connected = np.zeros(len(graphCells), dtype=bool)
@@ -149,12 +150,15 @@ class ExpressionMatrix:
             connected[v1] = True
             isolatedRemoved = int(len(graphCells) - connected.sum())
             vertices = graphCells[connected]
+            position = np.cumsum(connected, dtype=np.int64) - 1     # vertex index once the isolated ones are gone
+            edgeVertices = (position[v0].astype(np.uint32), position[v1].astype(np.uint32))
         self._cellGraphs[graphName] = {
             "cellSetName": cellSetName, "similarPairsName": similarPairsName,
             "similarityThreshold": similarityThreshold, "maxConnectivity": k,
             "vertexCount": int(len(vertices)), "edgeCount": int(len(v0)),
             "isolatedRemovedVertexCount": isolatedRemoved,
             "vertexCellIds": vertices, "edgeCellIds": (graphCells[v0], graphCells[v1]), "edgeSimilarity": similarity,
+            "edgeVertices": edgeVertices,
         }
 
     def _cell_graph(self, graphName):
@@ -166,6 +170,20 @@ class ExpressionMatrix:
         """[(cellId0, cellId1)] per edge, in edge-list order (src/ExpressionMatrix.cpp:1892-1913)."""
         c0, c1 = self._cell_graph(graphName)["edgeCellIds"]
         return list(zip(c0.tolist(), c1.tolist()))
+
+    def labelPropagationClustering(self, graphName, seed=231, stableIterationCountThreshold=3, maxIterationCount=100):
+        """CellGraph::labelPropagationClustering (src/CellGraph.cpp:443-612), the first step of
+        ExpressionMatrix::createClusterGraph (src/ExpressionMatrix.cpp:2145-2149; defaults from
+        ClusterGraphCreationParameters, src/ClusterGraph.hpp:48-50).  The reference keeps the result in the
+        clusterId of every graph vertex; here it is returned: (cellIds, clusterIds), one entry per vertex, clusters
+        numbered from 0 by decreasing size.  The rest of createClusterGraph (ClusterGraph) is outside SURVEY.md 8."""
+        g = self._cell_graph(graphName)
+        v0, v1 = g["edgeVertices"]
+        clusters, iterations = capi.cell_graph_label_propagation(g["vertexCellIds"], v0, v1, g["edgeSimilarity"], seed,
+                                                                 stableIterationCountThreshold, maxIterationCount)
+        g["clusterIds"] = clusters
+        g["labelPropagationIterations"] = iterations
+        return g["vertexCellIds"].copy(), clusters
 
     def _cell_graph_information(self, graphName):
         """The CellGraphInformation fields stored beside the graph (src/ExpressionMatrix.cpp:1824-1839); the

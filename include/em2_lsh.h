@@ -251,6 +251,19 @@ int em2_cell_graph_edges(const em2_pair* pairs, const uint32_t* usedCount, uint3
                          double similarityThreshold, uint32_t maxConnectivity, uint32_t* edgeVertex0,
                          uint32_t* edgeVertex1, float* edgeSimilarity, uint64_t* edgeCount);
 
+/* CellGraph::labelPropagationClustering (src/CellGraph.cpp:443-612, ClusterTable src/CellGraph.hpp:50-121; reached
+ * from ExpressionMatrix::createClusterGraph, src/ExpressionMatrix.cpp:2145-2149) over the graph em2_cell_graph_edges
+ * built.  SURVEY.md 8(f) row 2.  vertexCellIds[v] is the cell id of vertex v, in add_vertex order with removed
+ * isolated vertices left out; edges index that array and are in add_edge order.  clusterIds[v] receives the cluster
+ * of vertex v after the reference's renumbering (0 = largest; equal sizes by decreasing original label).
+ * *iterationCount (may be NULL) receives the number of iterations that ran.  The reference's schedule is serial by
+ * definition (each update reads labels written earlier in the same std::shuffle(std::mt19937(seed)) order, and
+ * the float weights accumulate in that order), so this is host code over host buffers and needs no device. */
+int em2_cell_graph_label_propagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
+                                     const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount,
+                                     uint64_t seed, uint64_t stableIterationCountThreshold,
+                                     uint64_t maxIterationCount, uint32_t* clusterIds, uint64_t* iterationCount);
+
 /* ------------------------------------------------------------------------------------------------------
  * ExpressionMatrix-level entry points: the methods the reference binds to Python (src/PythonModule.cpp),
  * operating by NAME on a data directory in the reference's memory-mapped formats.  Results are files in

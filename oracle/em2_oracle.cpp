@@ -36,6 +36,7 @@
 #include <map>
 #include <set>
 #include <functional>
+#include <limits>
 #include <vector>
 
 namespace {
@@ -621,6 +622,118 @@ uint64_t em2o_cell_graph_edges(const void* pairsRaw, const uint32_t* usedCount, 
         }
     }
     return edgeCount;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// CellGraph::labelPropagationClustering (src/CellGraph.cpp:443-612) with ClusterTable (src/CellGraph.hpp:50-121),
+// SURVEY.md 8(f) row 2.  Literal restatement over the vertex / edge lists em2o_cell_graph_edges produces:
+//   * vertices are visited in add_vertex order by BGL_FORALL_VERTICES, and in ascending cell id (the std::map
+//     vertexTable, :484-489) when the shuffle input is built; a removed isolated vertex is simply absent;
+//   * out_edges(v) of adjacency_list<listS,listS,undirectedS> lists the edges incident to v in add_edge order;
+//   * std::mt19937(seed) + std::shuffle are libstdc++'s, which is what the reference links.
+// clusterIds[v] receives the renumbered cluster of vertex v; returns the number of iterations that ran.
+namespace {
+struct OracleClusterTable {
+    std::vector<std::pair<uint32_t, float>> data;
+    uint32_t bestClusterId = std::numeric_limits<uint32_t>::max();
+    float bestWeight = -1.;
+    void addWeightQuick(uint32_t clusterId, float weight) { data.push_back(std::make_pair(clusterId, weight)); }
+    void findBestCluster()
+    {
+        bestClusterId = std::numeric_limits<uint32_t>::max();
+        bestWeight = -1.;
+        for (const auto& p : data) {
+            if (p.second > bestWeight) {
+                bestWeight = p.second;
+                bestClusterId = p.first;
+            }
+        }
+    }
+    void addWeight(uint32_t clusterId, float weight)
+    {
+        for (auto& p : data) {
+            if (p.first == clusterId) {
+                p.second += weight;
+                if (clusterId == bestClusterId) {
+                    if (weight < 0.) findBestCluster();
+                    else bestWeight = p.second;
+                } else if (p.second > bestWeight) {
+                    bestClusterId = clusterId;
+                    bestWeight = p.second;
+                }
+                return;
+            }
+        }
+        data.push_back(std::make_pair(clusterId, weight));
+        if (weight > bestWeight) {
+            bestClusterId = clusterId;
+            bestWeight = weight;
+        }
+    }
+};
+}  // namespace
+
+uint64_t em2o_label_propagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
+                                const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount,
+                                uint64_t seed, uint64_t stableIterationCountThreshold, uint64_t maxIterationCount,
+                                uint32_t* clusterIds)
+{
+    std::vector<std::vector<std::pair<uint32_t, float>>> outEdges(vertexCount);
+    for (uint64_t e = 0; e < edgeCount; e++) {
+        outEdges[edgeVertex0[e]].push_back(std::make_pair(edgeVertex1[e], edgeSimilarity[e]));
+        outEdges[edgeVertex1[e]].push_back(std::make_pair(edgeVertex0[e], edgeSimilarity[e]));
+    }
+    std::map<uint32_t, uint32_t> vertexTable;
+    for (uint32_t v = 0; v < vertexCount; v++) vertexTable.insert(std::make_pair(vertexCellIds[v], v));
+
+    for (uint32_t v = 0; v < vertexCount; v++) clusterIds[v] = vertexCellIds[v];                       // :459-462
+    std::vector<OracleClusterTable> tables(vertexCount);
+    for (uint32_t v0 = 0; v0 < vertexCount; v0++) {                                                    // :465-476
+        for (const auto& e : outEdges[v0]) tables[v0].addWeightQuick(clusterIds[e.first], e.second);
+        tables[v0].findBestCluster();
+    }
+
+    std::mt19937 randomGenerator(seed);                                                                // :480
+    std::vector<uint32_t> allVertices;
+    for (const auto& p : vertexTable) allVertices.push_back(p.second);
+    std::vector<uint32_t> shuffledVertices;
+    uint64_t stableIterationCount = 0;
+    uint64_t iteration = 0;
+    for (; iteration < maxIterationCount; iteration++) {                                               // :501-549
+        uint64_t changeCount = 0;
+        shuffledVertices = allVertices;
+        std::shuffle(shuffledVertices.begin(), shuffledVertices.end(), randomGenerator);
+        for (const uint32_t v0 : shuffledVertices) {
+            if (tables[v0].data.empty()) continue;
+            const uint32_t bestClusterId = tables[v0].bestClusterId;
+            if (clusterIds[v0] == bestClusterId) continue;
+            const uint32_t oldClusterId = clusterIds[v0];
+            clusterIds[v0] = bestClusterId;
+            ++changeCount;
+            for (const auto& e : outEdges[v0]) {
+                tables[e.first].addWeight(bestClusterId, e.second);
+                tables[e.first].addWeight(oldClusterId, -e.second);
+            }
+        }
+        if (changeCount) stableIterationCount = 0;
+        else ++stableIterationCount;
+        if (stableIterationCount == stableIterationCountThreshold) {
+            ++iteration;
+            break;
+        }
+    }
+
+    std::map<uint32_t, size_t> clusterSize;                                                            // :561-570
+    for (uint32_t v = 0; v < vertexCount; v++) ++clusterSize[clusterIds[v]];
+    std::vector<std::pair<size_t, uint32_t>> clusterSizeVector;                                        // :575-579
+    for (const auto& p : clusterSize) clusterSizeVector.push_back(std::make_pair(p.second, p.first));
+    std::sort(clusterSizeVector.begin(), clusterSizeVector.end(), std::greater<std::pair<size_t, size_t>>());
+    std::map<uint32_t, uint32_t> clusterMap;
+    for (uint32_t newClusterId = 0; newClusterId < clusterSizeVector.size(); newClusterId++)
+        clusterMap.insert(std::make_pair(clusterSizeVector[newClusterId].second, newClusterId));
+    for (uint32_t v = 0; v < vertexCount; v++) clusterIds[v] = clusterMap[clusterIds[v]];              // :593-596
+    return iteration;
 }
 
 

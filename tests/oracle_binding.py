@@ -54,6 +54,8 @@ class Oracle:
         lib.em2o_cell_graph_edges.argtypes = [P, P, c.c_uint32, c.c_uint32, P, P, c.c_uint32, c.c_double, c.c_uint64,
                                               P, P, P]
         lib.em2o_cell_graph_edges.restype = c.c_uint64
+        lib.em2o_label_propagation.argtypes = [P, c.c_uint32, P, P, P, c.c_uint64, c.c_uint64, c.c_uint64, c.c_uint64, P]
+        lib.em2o_label_propagation.restype = c.c_uint64
         lib.em2o_murmur_hash_64a.argtypes = [P, c.c_int, c.c_uint64]
         lib.em2o_murmur_hash_64a.restype = c.c_uint64
 
@@ -158,6 +160,16 @@ class Oracle:
         m = self.lib.em2o_cell_graph_edges(_ptr(pairs), _ptr(used), n, k, _ptr(sp_cells), _ptr(graph_cells),
                                            len(graph_cells), thr, max_connectivity, _ptr(v0), _ptr(v1), _ptr(es))
         return v0[:m], v1[:m], es[:m]
+
+    def label_propagation(self, vertex_cells, v0, v1, sim, seed=231, stable=3, max_iterations=100):
+        vertex_cells = np.ascontiguousarray(vertex_cells, dtype=np.uint32)
+        v0 = np.ascontiguousarray(v0, dtype=np.uint32)
+        v1 = np.ascontiguousarray(v1, dtype=np.uint32)
+        sim = np.ascontiguousarray(sim, dtype=np.float32)
+        out = np.zeros(len(vertex_cells), dtype=np.uint32)
+        iterations = self.lib.em2o_label_propagation(_ptr(vertex_cells), len(vertex_cells), _ptr(v0), _ptr(v1), _ptr(sim),
+                                                     len(v0), seed, stable, max_iterations, _ptr(out))
+        return out, int(iterations)
 
     def keep_best(self, cell, sim, k):
         cell = np.array(cell, dtype=np.uint32)

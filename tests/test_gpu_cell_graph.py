@@ -126,3 +126,30 @@ def test_create_cell_graph_facade(oracle, data_dir):
     with pytest.raises(RuntimeError, match="Graph Z does not exist."):
         e.getCellGraphEdges("Z")
     assert e.getCellGraphNames() == ["G", "H"]
+
+
+def test_label_propagation_over_the_gpu_built_graph(oracle, data_dir):
+    """fsp4 -> createCellGraph -> labelPropagationClustering: the facade's clusters against the oracle chain
+    (cell_graph_edges + label_propagation) with the isolated-vertex removal redone here."""
+    e = ExpressionMatrix(data_dir)
+    e.findSimilarPairs4(similarPairsName="Lsh", k=30, similarityThreshold=0.2, lshCount=256)
+    for name, thr, kk, keep in (("G", 0.5, 20, False), ("K", 0.3, 5, True)):
+        e.createCellGraph(name, "AllCells", "Lsh", thr, kk, keep)
+        k, pairs, used = files.read_similar_pairs(data_dir, "Lsh")
+        cells = e._cell_set("AllCells")
+        v0, v1, sim = oracle.cell_graph_edges(pairs["cell"], pairs["similarity"], used, cells, cells, thr, kk)
+        if keep:
+            vertex_cells, w0, w1 = cells, v0, v1
+        else:
+            kept = np.array(sorted(set(v0.tolist()) | set(v1.tolist())), dtype=np.int64)
+            vertex_cells = cells[kept]
+            w0, w1 = np.searchsorted(kept, v0), np.searchsorted(kept, v1)
+        expected, _ = oracle.label_propagation(vertex_cells, w0, w1, sim, 231, 3, 100)
+        got_cells, got = e.labelPropagationClustering(name)
+        assert np.array_equal(got_cells, vertex_cells)
+        assert np.array_equal(got, expected)
+        assert len(set(got.tolist())) < len(got)            # the four synthetic clusters pull cells together
+        other, _ = oracle.label_propagation(vertex_cells, w0, w1, sim, 7, 1, 5)
+        assert np.array_equal(e.labelPropagationClustering(name, 7, 1, 5)[1], other)
+    with pytest.raises(RuntimeError, match="Graph Z does not exist."):
+        e.labelPropagationClustering("Z")
