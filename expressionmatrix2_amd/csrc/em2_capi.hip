@@ -894,4 +894,68 @@ int em2_cell_graph_edges(const em2_pair* pairs, const uint32_t* usedCount, uint3
     return EM2_OK;
 }
 
+int em2_cell_graph_label_propagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
+                                     const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount,
+                                     uint64_t seed, uint64_t stableIterationCountThreshold,
+                                     uint64_t maxIterationCount, uint32_t* clusterIds, uint64_t* iterationCount)
+{
+    if (iterationCount) *iterationCount = 0;
+    if (vertexCount == 0) return EM2_OK;
+    if (!vertexCellIds || !clusterIds || (edgeCount && (!edgeVertex0 || !edgeVertex1 || !edgeSimilarity))) {
+        return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_cell_graph_label_propagation: null pointer");
+    }
+    for (uint64_t e = 0; e < edgeCount; e++) {
+        if (edgeVertex0[e] >= vertexCount || edgeVertex1[e] >= vertexCount) {
+            return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_cell_graph_label_propagation: an edge names a vertex that does not exist");
+        }
+        if (edgeVertex0[e] == edgeVertex1[e]) {
+            return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_cell_graph_label_propagation: an edge joins a vertex to itself");
+        }
+    }
+    // The vector the reference shuffles: the vertices in the order of its std::map vertexTable (CellGraph.cpp:484-489).
+    std::vector<uint32_t> byCellId(vertexCount);
+    for (uint32_t v = 0; v < vertexCount; v++) byCellId[v] = v;
+    std::stable_sort(byCellId.begin(), byCellId.end(), [&](uint32_t a, uint32_t b) { return vertexCellIds[a] < vertexCellIds[b]; });
+    for (uint32_t i = 1; i < vertexCount; i++) {
+        if (vertexCellIds[byCellId[i]] == vertexCellIds[byCellId[i - 1]]) {
+            return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_cell_graph_label_propagation: duplicate cell id among the vertices");
+        }
+    }
+    if (!haveDevice()) return fail(EM2_ERROR_NO_DEVICE, "em2_cell_graph_label_propagation: no HIP device is visible (this library has no CPU path)");
+    uint64_t iterations = 0;
+    uint32_t error = 0;
+    EM2_HIP(em2::runLabelPropagation(vertexCellIds, vertexCount, edgeVertex0, edgeVertex1, edgeSimilarity, edgeCount,
+                                     byCellId.data(), seed, stableIterationCountThreshold, maxIterationCount, clusterIds,
+                                     &iterations, &error, nullptr));
+    if (error == 1) return fail(EM2_ERROR_RUNTIME, "em2_cell_graph_label_propagation: a wave waited too long for an earlier vertex (is the GPU shared?)");
+    if (error != 0) return fail(EM2_ERROR_RUNTIME, "em2_cell_graph_label_propagation: the cluster tables outgrew their arena");
+    if (iterationCount) *iterationCount = iterations;
+
+    // CellGraph.cpp:561-596: clusters renumbered from 0 by decreasing size; equal sizes by decreasing label
+    // (std::greater on (size, label)).
+    std::vector<uint32_t> sortedLabels(clusterIds, clusterIds + vertexCount);
+    std::sort(sortedLabels.begin(), sortedLabels.end());
+    struct Cluster {
+        uint64_t size;
+        uint32_t label;
+    };
+    std::vector<Cluster> clusters;
+    for (size_t i = 0; i < sortedLabels.size();) {
+        size_t j = i;
+        while (j < sortedLabels.size() && sortedLabels[j] == sortedLabels[i]) ++j;
+        clusters.push_back(Cluster{uint64_t(j - i), sortedLabels[i]});
+        i = j;
+    }
+    std::sort(clusters.begin(), clusters.end(), [](const Cluster& a, const Cluster& b) {
+        return a.size != b.size ? a.size > b.size : a.label > b.label;
+    });
+    std::vector<std::pair<uint32_t, uint32_t>> renumber(clusters.size());
+    for (uint32_t i = 0; i < clusters.size(); i++) renumber[i] = std::make_pair(clusters[i].label, i);
+    std::sort(renumber.begin(), renumber.end());
+    for (uint32_t v = 0; v < vertexCount; v++) {
+        clusterIds[v] = std::lower_bound(renumber.begin(), renumber.end(), std::make_pair(clusterIds[v], 0u))->second;
+    }
+    return EM2_OK;
+}
+
 }  // extern "C"

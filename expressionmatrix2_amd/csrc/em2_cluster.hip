@@ -1,0 +1,558 @@
+// em2_cluster.hip -- label propagation over the cell graph on the GPU, bit-identical to the serial reference.
+// CellGraph::labelPropagationClustering (src/CellGraph.cpp:443-612) with ClusterTable
+// (src/CellGraph.hpp:50-121), the first step of ExpressionMatrix::createClusterGraph (src/ExpressionMatrix.cpp:2145).
+//
+// Reference: per iteration the vertices are visited in one std::shuffle order; a vertex whose label differs from
+// the best cluster of its table takes that cluster and PUSHES (+similarity on the new label, -similarity on the old)
+// into the table of every neighbour.  A table is an insertion-ordered list of (cluster, float weight) with a
+// (bestCluster, bestWeight) pair maintained incrementally, so its state depends on the ORDER of the pushes it
+// receives -- but on nothing else: tables of different vertices never interact.
+//
+// Here the pushes become pulls.  A label change of u is an event at time (iteration, position of u in that
+// iteration's order).  When vertex v gets its turn it applies, in time order, the events of its neighbours since its
+// previous turn: those of the previous iteration that came after v (phase A: labels of two iterations ago and of
+// last iteration differ, and posPrev[u] > posPrev[v]) and those of this iteration that came before v (phase B:
+// posCur[u] < posCur[v]).  The sequence of addWeight calls every table sees is exactly the reference's, so are the
+// float sums, the tie decisions and the labels.  What is gained is parallelism: v only has to wait for the
+// neighbours that precede it in this iteration's order.
+//
+// Schedule: one launch per iteration; waves draw positions from one atomic ticket in shuffle order and handle one
+// vertex each.  A wave only ever waits (phase B) for vertices with smaller tickets, which running waves hold, so the
+// waits cannot deadlock whatever the grid size.  The only data shared inside a launch is state[v] = (iteration+1)<<32
+// | label, one 64-bit agent-scope atomic word, so no fences are needed; everything else a wave touches is private
+// to its vertex until the next launch.
+//
+// Layout: adjacency CSR in add_edge order (what out_edges() of adjacency_list<listS,listS,undirectedS> walks);
+// tables in one arena of (cluster, weight), 2*degree+8 entries per vertex to start with, relocated to the bump-
+// allocated tail when full (entries are never removed, as in the reference); labels of the last four iterations;
+// for vertices of degree > 64 the candidate events are staged in a scratch area addressed like the adjacency.
+
+#include "em2_device.h"
+#include "em2_select_wave.h"
+
+#include <algorithm>
+#include <numeric>
+#include <random>
+#include <vector>
+
+namespace em2 {
+namespace {
+
+constexpr uint32_t kNone = 0xffffffffu;
+
+struct TableEntry {
+    uint32_t cluster;
+    float weight;
+};
+
+struct TableMeta {
+    uint64_t begin;
+    uint32_t size;
+    uint32_t capacity;
+    uint32_t best;          // ClusterTable::bestClusterId, kNone = the reference's numeric_limits<uint32_t>::max()
+    float bestWeight;
+};
+
+// Phase A: a = old label, b = new label.  Phase B: a = the neighbour, b = its label before this iteration.
+struct Candidate {
+    uint32_t key;
+    uint32_t a;
+    uint32_t b;
+    float weight;
+};
+
+struct ClusterArgs {
+    uint32_t vertexCount;
+    uint32_t iteration;
+    const uint64_t* offsets;
+    const uint32_t* neighbour;
+    const float* weight;
+    const uint32_t* order;
+    const uint32_t* posCur;
+    const uint32_t* posPrev;
+    const uint32_t* labelPrev;
+    const uint32_t* labelPrev2;
+    uint32_t* labelCur;
+    uint64_t* state;
+    TableMeta* meta;
+    TableEntry* arena;
+    unsigned long long* arenaTop;
+    uint64_t arenaCapacity;
+    uint32_t* control;          // [0] ticket, [1] label changes, [2] error (1 wait timed out, 2 arena exhausted)
+    Candidate* scratchA;
+    Candidate* scratchB;
+};
+
+__device__ __forceinline__ uint32_t uniform(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
+__device__ __forceinline__ float uniform(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ __forceinline__ uint64_t uniform(uint64_t x) { return uint64_t(uniform(uint32_t(x))) | (uint64_t(uniform(uint32_t(x >> 32))) << 32); }
+
+__device__ __forceinline__ uint32_t waveMin(uint32_t x)
+{
+    for (int offset = 32; offset; offset >>= 1) x = min(x, uint32_t(__shfl_xor(int(x), offset)));
+    return x;
+}
+
+// ClusterTable::findBestCluster (CellGraph.hpp:104-114): the first entry holding the largest weight, if above -1.
+__device__ void findBest(TableMeta& t, const TableEntry* arena, uint32_t lane)
+{
+    float bestWeight = -1.f;
+    uint32_t bestIndex = kNone;
+    for (uint32_t base = 0; base < t.size; base += 64u) {
+        const uint32_t i = base + lane;
+        if (i < t.size) {
+            const float w = arena[t.begin + i].weight;
+            if (w > bestWeight) {
+                bestWeight = w;
+                bestIndex = i;
+            }
+        }
+    }
+    for (int offset = 32; offset; offset >>= 1) {
+        const float otherWeight = __shfl_xor(bestWeight, offset);
+        const uint32_t otherIndex = uint32_t(__shfl_xor(int(bestIndex), offset));
+        if (otherWeight > bestWeight || (otherWeight == bestWeight && otherIndex < bestIndex)) {
+            bestWeight = otherWeight;
+            bestIndex = otherIndex;
+        }
+    }
+    bestIndex = uniform(bestIndex);
+    if (bestIndex == kNone) {
+        t.best = kNone;
+        t.bestWeight = -1.f;
+    } else {
+        t.best = uniform(arena[t.begin + bestIndex].cluster);
+        t.bestWeight = uniform(bestWeight);
+    }
+}
+
+// ClusterTable::addWeight (CellGraph.hpp:70-99).  Returns false when the arena is exhausted.
+__device__ bool addWeight(TableMeta& t, const ClusterArgs& args, uint32_t cluster, float weight, uint32_t lane)
+{
+    TableEntry* arena = args.arena;
+    for (uint32_t base = 0; base < t.size; base += 64u) {
+        const uint32_t i = base + lane;
+        bool hit = false;
+        float w = 0.f;
+        if (i < t.size) {
+            const TableEntry e = arena[t.begin + i];
+            hit = e.cluster == cluster;
+            w = e.weight;
+        }
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(hit);
+        if (mask == 0ull) continue;
+        // The first entry of that cluster, like the reference's linear search (parallel edges can leave an initial
+        // table with the same cluster twice).
+        const int owner = __ffsll((unsigned long long)mask) - 1;
+        if (int(lane) == owner) {
+            w += weight;
+            arena[t.begin + i].weight = w;
+        }
+        const float updated = __shfl(w, owner);
+        if (cluster == t.best) {
+            if (weight < 0.f) findBest(t, arena, lane);
+            else t.bestWeight = updated;
+        } else if (updated > t.bestWeight) {
+            t.best = cluster;
+            t.bestWeight = updated;
+        }
+        return true;
+    }
+    if (t.size == t.capacity) {
+        const uint32_t capacity = t.capacity * 2u + 8u;
+        unsigned long long at = 0;
+        if (lane == 0u) at = atomicAdd(args.arenaTop, (unsigned long long)capacity);
+        at = uniform(uint64_t(at));
+        if (at + capacity > args.arenaCapacity) return false;
+        for (uint32_t i = lane; i < t.size; i += 64u) arena[at + i] = arena[t.begin + i];
+        t.begin = at;
+        t.capacity = capacity;
+    }
+    if (lane == 0u) arena[t.begin + t.size] = TableEntry{cluster, weight};
+    ++t.size;
+    if (weight > t.bestWeight) {
+        t.best = cluster;
+        t.bestWeight = weight;
+    }
+    return true;
+}
+
+// One label change of a neighbour as the table of the current vertex sees it (CellGraph.cpp:529-530).
+__device__ __forceinline__ bool applyEvent(TableMeta& t, const ClusterArgs& args, uint32_t oldLabel, uint32_t newLabel,
+                                           float weight, uint32_t lane)
+{
+    return addWeight(t, args, newLabel, weight, lane) && addWeight(t, args, oldLabel, -weight, lane);
+}
+
+// Waits until the vertex has had its turn in this iteration; returns its label, or sets failed.
+__device__ uint32_t labelAfterTurn(const ClusterArgs& args, uint32_t vertex, bool& failed)
+{
+    const uint64_t* word = args.state + vertex;
+    const uint32_t want = args.iteration + 1u;
+    uint64_t s = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (uint32_t(s >> 32) != want) {
+        const uint64_t start = __builtin_amdgcn_s_memrealtime();             // 100 MHz
+        for (;;) {
+            __builtin_amdgcn_s_sleep(2);
+            s = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (uint32_t(s >> 32) == want) break;
+            if (__hip_atomic_load(args.control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                __builtin_amdgcn_s_memrealtime() - start > 400000000ull) {
+                failed = true;
+                break;
+            }
+        }
+    }
+    return uniform(uint32_t(s));
+}
+
+__global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    for (;;) {
+        uint32_t p = kNone;
+        if (lane == 0u && __hip_atomic_load(args.control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            p = __hip_atomic_fetch_add(args.control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        p = uniform(p);
+        if (p >= args.vertexCount) return;
+        const uint32_t v = uniform(args.order[p]);
+        const uint64_t base = uniform(args.offsets[v]);
+        const uint32_t degree = uniform(uint32_t(args.offsets[v + 1] - base));
+        TableMeta t = args.meta[v];
+        t.begin = uniform(t.begin);
+        t.size = uniform(t.size);
+        t.capacity = uniform(t.capacity);
+        t.best = uniform(t.best);
+        t.bestWeight = uniform(t.bestWeight);
+        uint32_t label = uniform(args.labelPrev[v]);
+        const bool later = args.iteration > 0u;
+        const uint32_t posPrevV = later ? uniform(args.posPrev[v]) : 0u;
+        uint32_t error = 0;
+
+        if (degree <= 64u) {
+            // ---- one neighbour per lane; both candidate lists stay in registers ----
+            uint32_t u = 0, labelU = 0, beforeU = 0, keyA = kNone, keyB = kNone;
+            float w = 0.f;
+            if (lane < degree) {
+                u = args.neighbour[base + lane];
+                w = args.weight[base + lane];
+                labelU = args.labelPrev[u];
+                if (later) {
+                    beforeU = args.labelPrev2[u];
+                    const uint32_t pp = args.posPrev[u];
+                    if (labelU != beforeU && pp > posPrevV) keyA = pp;
+                }
+                const uint32_t pc = args.posCur[u];
+                if (pc < p) keyB = pc;
+            }
+            while (!error) {
+                const uint32_t m = waveMin(keyA);
+                if (m == kNone) break;
+                const int owner = __ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(keyA == m)) - 1;
+                const uint32_t oldLabel = uint32_t(__shfl(int(beforeU), owner));
+                const uint32_t newLabel = uint32_t(__shfl(int(labelU), owner));
+                const float weight = __shfl(w, owner);
+                if (int(lane) == owner) keyA = kNone;
+                if (!applyEvent(t, args, oldLabel, newLabel, weight, lane)) error = 2;
+            }
+            while (!error) {
+                const uint32_t m = waveMin(keyB);
+                if (m == kNone) break;
+                const int owner = __ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(keyB == m)) - 1;
+                const uint32_t other = uint32_t(__shfl(int(u), owner));
+                const uint32_t oldLabel = uint32_t(__shfl(int(labelU), owner));
+                const float weight = __shfl(w, owner);
+                if (int(lane) == owner) keyB = kNone;
+                bool failed = false;
+                const uint32_t newLabel = labelAfterTurn(args, other, failed);
+                if (failed) error = 1;
+                else if (newLabel != oldLabel && !applyEvent(t, args, oldLabel, newLabel, weight, lane)) error = 2;
+            }
+        } else {
+            // ---- the candidate lists go through scratch memory (slots base .. base+degree of each list) ----
+            Candidate* listA = args.scratchA + base;
+            Candidate* listB = args.scratchB + base;
+            uint32_t countA = 0, countB = 0;
+            for (uint32_t c = 0; c < degree; c += 64u) {
+                const uint32_t i = c + lane;
+                bool isA = false, isB = false;
+                uint32_t u = 0, labelU = 0, beforeU = 0, pp = 0, pc = 0;
+                float w = 0.f;
+                if (i < degree) {
+                    u = args.neighbour[base + i];
+                    w = args.weight[base + i];
+                    labelU = args.labelPrev[u];
+                    if (later) {
+                        beforeU = args.labelPrev2[u];
+                        pp = args.posPrev[u];
+                        isA = labelU != beforeU && pp > posPrevV;
+                    }
+                    pc = args.posCur[u];
+                    isB = pc < p;
+                }
+                const uint64_t maskA = __builtin_amdgcn_ballot_w64(isA);
+                const uint64_t maskB = __builtin_amdgcn_ballot_w64(isB);
+                if (isA) listA[countA + lanesBelow(maskA)] = Candidate{pp, beforeU, labelU, w};
+                if (isB) listB[countB + lanesBelow(maskB)] = Candidate{pc, u, labelU, w};
+                countA += uint32_t(__builtin_popcountll(maskA));
+                countB += uint32_t(__builtin_popcountll(maskB));
+            }
+            for (int phase = 0; phase < 2 && !error; ++phase) {
+                Candidate* list = phase ? listB : listA;
+                const uint32_t count = phase ? countB : countA;
+                while (!error) {
+                    uint32_t bestKey = kNone, bestIndex = kNone;
+                    for (uint32_t c = 0; c < count; c += 64u) {
+                        const uint32_t i = c + lane;
+                        if (i < count) {
+                            const uint32_t key = list[i].key;
+                            if (key < bestKey) {
+                                bestKey = key;
+                                bestIndex = i;
+                            }
+                        }
+                    }
+                    for (int offset = 32; offset; offset >>= 1) {
+                        const uint32_t otherKey = uint32_t(__shfl_xor(int(bestKey), offset));
+                        const uint32_t otherIndex = uint32_t(__shfl_xor(int(bestIndex), offset));
+                        if (otherKey < bestKey || (otherKey == bestKey && otherIndex < bestIndex)) {
+                            bestKey = otherKey;
+                            bestIndex = otherIndex;
+                        }
+                    }
+                    if (uniform(bestKey) == kNone) break;
+                    const uint32_t index = uniform(bestIndex);
+                    const Candidate candidate = list[index];
+                    const uint32_t a = uniform(candidate.a), b = uniform(candidate.b);
+                    const float weight = uniform(candidate.weight);
+                    if (lane == 0u) list[index].key = kNone;
+                    if (phase == 0) {
+                        if (!applyEvent(t, args, a, b, weight, lane)) error = 2;
+                    } else {
+                        bool failed = false;
+                        const uint32_t newLabel = labelAfterTurn(args, a, failed);
+                        if (failed) error = 1;
+                        else if (newLabel != b && !applyEvent(t, args, b, newLabel, weight, lane)) error = 2;
+                    }
+                }
+            }
+        }
+
+        if (error) {
+            if (lane == 0u) {
+                // Keep the first cause: a timeout that follows an exhausted arena is only its consequence.
+                uint32_t expected = 0;
+                __hip_atomic_compare_exchange_strong(args.control + 2, &expected, error, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+
+        // ---- the turn proper (CellGraph.cpp:507-524) ----
+        const bool change = t.size != 0u && label != t.best;
+        if (change) label = t.best;
+        if (lane == 0u) {
+            args.labelCur[v] = label;
+            args.meta[v] = t;
+            if (change) __hip_atomic_fetch_add(args.control + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(args.state + v, (uint64_t(args.iteration + 1u) << 32) | label, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// CellGraph.cpp:459-476: every vertex starts in the cluster named by its own cell id; its table lists the clusters of
+// its neighbours in out-edge order (addWeightQuick) and then finds its best cluster.
+__global__ void __launch_bounds__(256)
+initialTablesKernel(uint32_t vertexCount, const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ neighbour,
+                    const float* __restrict__ weight, const uint32_t* __restrict__ vertexCellIds, TableMeta* __restrict__ meta,
+                    TableEntry* __restrict__ arena, uint32_t* __restrict__ label0, uint64_t* __restrict__ state)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wavesPerGrid = gridDim.x * (blockDim.x / 64u);
+    for (uint32_t v = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; v < vertexCount; v += wavesPerGrid) {
+        const uint64_t base = offsets[v];
+        const uint32_t degree = uint32_t(offsets[v + 1] - base);
+        TableMeta t;
+        t.begin = 2ull * base + 8ull * v;
+        t.size = degree;
+        t.capacity = 2u * degree + 8u;
+        for (uint32_t i = lane; i < degree; i += 64u) {
+            arena[t.begin + i] = TableEntry{vertexCellIds[neighbour[base + i]], weight[base + i]};
+        }
+        findBest(t, arena, lane);
+        if (lane == 0u) {
+            meta[v] = t;
+            label0[v] = vertexCellIds[v];
+            state[v] = 0ull;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+positionsKernel(const uint32_t* __restrict__ order, uint32_t count, uint32_t* __restrict__ position)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < count) position[order[p]] = p;
+}
+
+struct Buffer {
+    void* p = nullptr;
+    ~Buffer() { if (p) (void)hipFree(p); }
+    hipError_t allocate(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+#define EM2_TRY(call)                        \
+    do {                                     \
+        hipError_t em2Err_ = (call);         \
+        if (em2Err_ != hipSuccess) return em2Err_; \
+    } while (0)
+
+}  // namespace
+
+// Host buffers in, raw labels (cell ids of the cluster seeds) out; the caller renumbers them.  shuffleInput is the
+// vector the reference shuffles every iteration: the vertices in ascending cell id (CellGraph.cpp:484-489).  Edges
+// must not be self loops (a vertex never pulls from itself).  *error: 0 ok, 1 a wait timed out, 2 table arena
+// exhausted.  Synchronises the stream.
+hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
+                               const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount,
+                               const uint32_t* shuffleInput, uint64_t seed, uint64_t stableIterationCountThreshold,
+                               uint64_t maxIterationCount, uint32_t* labels, uint64_t* iterationCount, uint32_t* error,
+                               hipStream_t stream)
+{
+    *iterationCount = 0;
+    *error = 0;
+    if (vertexCount == 0) return hipSuccess;
+
+    // out_edges() of every vertex, in add_edge order.
+    std::vector<uint64_t> offsets(size_t(vertexCount) + 1, 0);
+    for (uint64_t e = 0; e < edgeCount; e++) {
+        ++offsets[edgeVertex0[e] + 1];
+        ++offsets[edgeVertex1[e] + 1];
+    }
+    std::partial_sum(offsets.begin(), offsets.end(), offsets.begin());
+    const uint64_t slots = 2 * edgeCount;
+    std::vector<uint32_t> neighbour(slots);
+    std::vector<float> weight(slots);
+    uint64_t maxDegree = 0;
+    {
+        std::vector<uint64_t> cursor(offsets.begin(), offsets.end() - 1);
+        for (uint64_t e = 0; e < edgeCount; e++) {
+            const uint32_t a = edgeVertex0[e], b = edgeVertex1[e];
+            neighbour[cursor[a]] = b;
+            weight[cursor[a]++] = edgeSimilarity[e];
+            neighbour[cursor[b]] = a;
+            weight[cursor[b]++] = edgeSimilarity[e];
+        }
+        for (uint32_t v = 0; v < vertexCount; v++) maxDegree = std::max(maxDegree, offsets[v + 1] - offsets[v]);
+    }
+
+    const uint64_t initialEntries = 2 * slots + 8ull * vertexCount;
+    const uint64_t arenaCapacity = initialEntries + std::max<uint64_t>(initialEntries, 1ull << 20);
+    Buffer dOffsets, dNeighbour, dWeight, dCells, dLabels, dState, dPositions, dOrder, dMeta, dArena, dControl, dScratch;
+    EM2_TRY(dOffsets.allocate(offsets.size() * sizeof(uint64_t)));
+    EM2_TRY(dNeighbour.allocate(slots * sizeof(uint32_t)));
+    EM2_TRY(dWeight.allocate(slots * sizeof(float)));
+    EM2_TRY(dCells.allocate(size_t(vertexCount) * sizeof(uint32_t)));
+    EM2_TRY(dLabels.allocate(4 * size_t(vertexCount) * sizeof(uint32_t)));
+    EM2_TRY(dState.allocate(size_t(vertexCount) * sizeof(uint64_t)));
+    EM2_TRY(dPositions.allocate(2 * size_t(vertexCount) * sizeof(uint32_t)));
+    EM2_TRY(dOrder.allocate(size_t(vertexCount) * sizeof(uint32_t)));
+    EM2_TRY(dMeta.allocate(size_t(vertexCount) * sizeof(TableMeta)));
+    EM2_TRY(dArena.allocate(arenaCapacity * sizeof(TableEntry)));
+    EM2_TRY(dControl.allocate(4 * sizeof(uint32_t) + sizeof(unsigned long long)));
+    if (maxDegree > 64) EM2_TRY(dScratch.allocate(2 * slots * sizeof(Candidate)));
+    EM2_TRY(hipMemcpyAsync(dOffsets.p, offsets.data(), offsets.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    if (slots) {
+        EM2_TRY(hipMemcpyAsync(dNeighbour.p, neighbour.data(), slots * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        EM2_TRY(hipMemcpyAsync(dWeight.p, weight.data(), slots * sizeof(float), hipMemcpyHostToDevice, stream));
+    }
+    EM2_TRY(hipMemcpyAsync(dCells.p, vertexCellIds, size_t(vertexCount) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+
+    int device = 0, computeUnits = 0;
+    EM2_TRY(hipGetDevice(&device));
+    EM2_TRY(hipDeviceGetAttribute(&computeUnits, hipDeviceAttributeMultiprocessorCount, device));
+    const uint32_t waveBlocks = (vertexCount + 3u) / 4u;
+    const dim3 grid(std::min<uint32_t>(waveBlocks, uint32_t(computeUnits) * 8u)), block(256);
+    uint32_t* label[4];
+    for (int i = 0; i < 4; i++) label[i] = dLabels.as<uint32_t>() + size_t(i) * vertexCount;
+    uint32_t* position[2] = {dPositions.as<uint32_t>(), dPositions.as<uint32_t>() + vertexCount};
+    uint32_t* control = dControl.as<uint32_t>();
+    unsigned long long* arenaTop = reinterpret_cast<unsigned long long*>(control + 4);
+
+    initialTablesKernel<<<grid, block, 0, stream>>>(vertexCount, dOffsets.as<uint64_t>(), dNeighbour.as<uint32_t>(),
+                                                    dWeight.as<float>(), dCells.as<uint32_t>(), dMeta.as<TableMeta>(),
+                                                    dArena.as<TableEntry>(), label[0], dState.as<uint64_t>());
+    EM2_TRY(hipGetLastError());
+    {
+        const uint32_t zero[4] = {0, 0, 0, 0};
+        EM2_TRY(hipMemcpyAsync(control, zero, sizeof(zero), hipMemcpyHostToDevice, stream));
+        const unsigned long long top = initialEntries;
+        EM2_TRY(hipMemcpyAsync(arenaTop, &top, sizeof(top), hipMemcpyHostToDevice, stream));
+        EM2_TRY(hipStreamSynchronize(stream));
+    }
+
+    // :480-549.  std::mt19937 / std::shuffle are libstdc++'s, which is what the reference links; the order of one
+    // iteration is drawn while the GPU works on the previous one.
+    std::mt19937 randomGenerator(seed);
+    std::vector<uint32_t> allVertices(shuffleInput, shuffleInput + vertexCount);
+    std::vector<uint32_t> shuffled[2];
+    uint64_t stable = 0, iterations = 0;
+    if (maxIterationCount > 0) {
+        shuffled[0] = allVertices;
+        std::shuffle(shuffled[0].begin(), shuffled[0].end(), randomGenerator);
+    }
+    while (iterations < maxIterationCount) {
+        const uint32_t t = uint32_t(iterations);
+        const std::vector<uint32_t>& order = shuffled[t & 1u];
+        EM2_TRY(hipMemcpyAsync(dOrder.p, order.data(), size_t(vertexCount) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        positionsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, stream>>>(dOrder.as<uint32_t>(), vertexCount, position[t & 1u]);
+        EM2_TRY(hipGetLastError());
+        EM2_TRY(hipMemsetAsync(control, 0, 2 * sizeof(uint32_t), stream));
+        ClusterArgs args;
+        args.vertexCount = vertexCount;
+        args.iteration = t;
+        args.offsets = dOffsets.as<uint64_t>();
+        args.neighbour = dNeighbour.as<uint32_t>();
+        args.weight = dWeight.as<float>();
+        args.order = dOrder.as<uint32_t>();
+        args.posCur = position[t & 1u];
+        args.posPrev = position[(t + 1u) & 1u];
+        args.labelPrev = label[t & 3u];
+        args.labelPrev2 = label[(t + 3u) & 3u];
+        args.labelCur = label[(t + 1u) & 3u];
+        args.state = dState.as<uint64_t>();
+        args.meta = dMeta.as<TableMeta>();
+        args.arena = dArena.as<TableEntry>();
+        args.arenaTop = arenaTop;
+        args.arenaCapacity = arenaCapacity;
+        args.control = control;
+        args.scratchA = dScratch.as<Candidate>();
+        args.scratchB = dScratch.as<Candidate>() + slots;
+        labelPropagationKernel<<<grid, block, 0, stream>>>(args);
+        EM2_TRY(hipGetLastError());
+        ++iterations;
+        if (iterations < maxIterationCount) {
+            shuffled[iterations & 1u] = allVertices;
+            std::shuffle(shuffled[iterations & 1u].begin(), shuffled[iterations & 1u].end(), randomGenerator);
+        }
+        uint32_t result[3] = {0, 0, 0};
+        EM2_TRY(hipMemcpyAsync(result, control, sizeof(result), hipMemcpyDeviceToHost, stream));
+        EM2_TRY(hipStreamSynchronize(stream));
+        if (result[2] != 0) {
+            *error = result[2];
+            *iterationCount = iterations;
+            return hipSuccess;
+        }
+        stable = result[1] ? 0 : stable + 1;
+        if (stable == stableIterationCountThreshold) break;
+    }
+    EM2_TRY(hipMemcpyAsync(labels, label[iterations & 3u], size_t(vertexCount) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    EM2_TRY(hipStreamSynchronize(stream));
+    *iterationCount = iterations;
+    return hipSuccess;
+}
+
+}  // namespace em2

@@ -138,6 +138,14 @@ hipError_t runCellGraphEdges(const PairOut* pairs, const uint32_t* usedCount, ui
                              uint32_t maxConnectivity, uint32_t* edge0, uint32_t* edge1, float* edgeSimilarity,
                              uint64_t* edgeCountHost, hipStream_t stream);
 
+// CellGraph::labelPropagationClustering (src/CellGraph.cpp:443-612) on the device (em2_cluster.hip).  Host buffers;
+// labels[v] = the raw label (a cell id) of vertex v after the last iteration.
+hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
+                               const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount,
+                               const uint32_t* shuffleInput, uint64_t seed, uint64_t stableIterationCountThreshold,
+                               uint64_t maxIterationCount, uint32_t* labels, uint64_t* iterationCount, uint32_t* error,
+                               hipStream_t stream);
+
 }  // namespace em2
 
 #endif

@@ -157,11 +157,6 @@ void addGeneSet(const std::string& directoryName, const std::string& name, const
 void addCellSet(const std::string& directoryName, const std::string& name, const uint32_t* sortedCellIds,
                 uint32_t count);
 
-// CellGraph::labelPropagationClustering (src/CellGraph.cpp:443-612), em2_cluster.cpp.  Returns the iterations run.
-uint64_t labelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
-                          const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount, uint64_t seed,
-                          uint64_t stableIterationCountThreshold, uint64_t maxIterationCount, uint32_t* clusterIds);
-
 }  // namespace host
 }  // namespace em2
 

@@ -223,22 +223,4 @@ int em2_tool_add_cell_set(const char* directoryName, const char* name, const uin
     return guarded([&] { em2::host::addCellSet(directoryName, name, sortedCellIds, count); });
 }
 
-int em2_cell_graph_label_propagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
-                                     const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount,
-                                     uint64_t seed, uint64_t stableIterationCountThreshold,
-                                     uint64_t maxIterationCount, uint32_t* clusterIds, uint64_t* iterationCount)
-{
-    if (iterationCount) *iterationCount = 0;
-    if (vertexCount == 0) return EM2_OK;
-    if (!vertexCellIds || !clusterIds || (edgeCount && (!edgeVertex0 || !edgeVertex1 || !edgeSimilarity))) {
-        return nullArgument("em2_cell_graph_label_propagation");
-    }
-    return guarded([&] {
-        const uint64_t iterations = em2::host::labelPropagation(vertexCellIds, vertexCount, edgeVertex0, edgeVertex1,
-                                                                edgeSimilarity, edgeCount, seed,
-                                                                stableIterationCountThreshold, maxIterationCount, clusterIds);
-        if (iterationCount) *iterationCount = iterations;
-    });
-}
-
 }  // extern "C"

@@ -1,0 +1,104 @@
+"""Label propagation over a cell graph: the GPU schedule behind
+em2_cell_graph_label_propagation (em2_cluster.hip: pulls in event-time order, one wave per vertex, waits only on
+earlier positions of the shuffle) against the oracle's literal, serial restatement of
+CellGraph::labelPropagationClustering (src/CellGraph.cpp:443-612).  Labels must be identical, not merely an
+equivalent partition."""
+import os
+
+import numpy as np
+import pytest
+
+from expressionmatrix2_amd import capi
+from label_graphs import fast_graph, random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(capi.LIBRARY_PATH):
+        capi.build_library()
+    return capi.load()
+
+
+def test_two_vertices_by_hand(lib):
+    # Whichever vertex the shuffle puts first adopts the other's label, and the second then finds itself
+    # consistent: one cluster, numbered 0; one changing iteration and three stable ones.
+    clusters, iterations = capi.cell_graph_label_propagation([5, 9], [0], [1], [0.5])
+    assert clusters.tolist() == [0, 0]
+    assert iterations == 4
+
+
+def test_isolated_vertices_keep_their_own_cluster(lib, oracle):
+    # keepIsolatedVertices=True graphs: singleton clusters are numbered by decreasing original label
+    # (std::greater on (size, id), CellGraph.cpp:579).
+    cells = np.array([3, 8, 20, 21, 40], np.uint32)
+    clusters, iterations = capi.cell_graph_label_propagation(cells, [1], [2], [0.7])
+    assert clusters[1] == clusters[2] == 0
+    assert clusters[[4, 3, 0]].tolist() == [1, 2, 3]
+    expected, expected_iterations = oracle.label_propagation(cells, [1], [2], [0.7])
+    assert clusters.tolist() == expected.tolist() and iterations == expected_iterations
+
+
+def test_no_edges_and_no_vertices(lib):
+    clusters, iterations = capi.cell_graph_label_propagation(np.arange(4), [], [], [])
+    assert clusters.tolist() == [3, 2, 1, 0] and iterations == 3
+    clusters, iterations = capi.cell_graph_label_propagation([], [], [], [])
+    assert len(clusters) == 0 and iterations == 0
+
+
+def test_arguments_the_schedule_cannot_take_are_refused(lib):
+    with pytest.raises((RuntimeError, ValueError), match="vertex that does not exist"):
+        capi.cell_graph_label_propagation([1, 2], [0], [2], [0.5])
+    with pytest.raises((RuntimeError, ValueError), match="joins a vertex to itself"):
+        capi.cell_graph_label_propagation([1, 2], [1], [1], [0.5])
+    with pytest.raises((RuntimeError, ValueError), match="duplicate cell id"):
+        capi.cell_graph_label_propagation([4, 4], [0], [1], [0.5])
+
+
+@pytest.mark.parametrize("vertex_count,degree,clusters,tie_levels,sorted_ids,seed,stable,max_iterations", [
+    (50, 3, 3, 0, True, 231, 3, 100),
+    (400, 6, 5, 0, True, 231, 3, 100),
+    (400, 6, 5, 4, True, 7, 3, 100),          # heavy weight ties: first-entry and first-maximum rules decide
+    (1500, 10, 12, 16, True, 231, 3, 100),
+    (1500, 10, 12, 0, False, 99, 2, 100),     # vertex order differs from cell id order (shuffle input is by cell id)
+    (3000, 20, 40, 0, True, 231, 3, 2),       # stopped by maxIterationCount
+    (3000, 20, 40, 8, True, 2 ** 40 + 5, 1, 100),   # seed beyond 32 bits (std::mt19937 takes it modulo 2^32)
+    (800, 4, 2, 0, True, 231, 0, 100),        # threshold 0: leaves after the first iteration that changes something
+])
+def test_matches_oracle(lib, oracle, vertex_count, degree, clusters, tie_levels, sorted_ids, seed, stable, max_iterations):
+    rng = np.random.default_rng(vertex_count * 31 + degree)
+    cells, v0, v1, sim = random_graph(rng, vertex_count, degree, clusters, tie_levels, sorted_ids)
+    got, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim, seed, stable, max_iterations)
+    expected, expected_iterations = oracle.label_propagation(cells, v0, v1, sim, seed, stable, max_iterations)
+    assert iterations == expected_iterations
+    assert np.array_equal(got, expected)
+    # cluster numbers are contiguous from 0 and ordered by decreasing size
+    sizes = np.bincount(got)
+    assert sizes.min() > 0 and np.all(np.diff(sizes) <= 0)
+
+
+@pytest.mark.parametrize("vertex_count,degree,clusters,hubs,hub_degree,parallel_edges,tie_levels,seed", [
+    (20000, 10, 16, 0, 0, 0, 0, 231),         # many waves in flight: waits on earlier positions really happen
+    (20000, 10, 16, 0, 0, 0, 8, 5),
+    (6000, 6, 8, 5, 300, 0, 0, 231),          # hubs: degree > 64 stages its candidate events in scratch memory
+    (6000, 6, 8, 3, 2500, 0, 4, 231),         # ... and tables longer than one 64-entry chunk, relocated when they grow
+    (3000, 8, 6, 2, 200, 400, 0, 231),        # parallel edges: equal event times, duplicate clusters in a first table
+    (60000, 20, 64, 0, 0, 0, 0, 231),
+])
+def test_large_graphs_match_oracle(lib, oracle, vertex_count, degree, clusters, hubs, hub_degree, parallel_edges, tie_levels, seed):
+    rng = np.random.default_rng(vertex_count + degree + hubs)
+    cells, v0, v1, sim = fast_graph(rng, vertex_count, degree, clusters, hubs, hub_degree, parallel_edges, tie_levels)
+    got, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim, seed, 3, 100)
+    expected, expected_iterations = oracle.label_propagation(cells, v0, v1, sim, seed, 3, 100)
+    assert iterations == expected_iterations
+    assert np.array_equal(got, expected)
+
+
+def test_repeated_runs_are_identical(lib):
+    rng = np.random.default_rng(77)
+    cells, v0, v1, sim = fast_graph(rng, 30000, 12, 20, 2, 150)
+    first = capi.cell_graph_label_propagation(cells, v0, v1, sim)
+    for _ in range(3):
+        again = capi.cell_graph_label_propagation(cells, v0, v1, sim)
+        assert again[1] == first[1] and np.array_equal(again[0], first[0])
