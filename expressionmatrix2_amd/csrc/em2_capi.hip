@@ -924,12 +924,14 @@ int em2_cell_graph_label_propagation(const uint32_t* vertexCellIds, uint32_t ver
     if (!haveDevice()) return fail(EM2_ERROR_NO_DEVICE, "em2_cell_graph_label_propagation: no HIP device is visible (this library has no CPU path)");
     uint64_t iterations = 0;
     uint32_t error = 0;
+    CallTimer timer;
     EM2_HIP(em2::runLabelPropagation(vertexCellIds, vertexCount, edgeVertex0, edgeVertex1, edgeSimilarity, edgeCount,
                                      byCellId.data(), seed, stableIterationCountThreshold, maxIterationCount, clusterIds,
                                      &iterations, &error, nullptr));
     if (error == 1) return fail(EM2_ERROR_RUNTIME, "em2_cell_graph_label_propagation: a wave waited too long for an earlier vertex (is the GPU shared?)");
     if (error != 0) return fail(EM2_ERROR_RUNTIME, "em2_cell_graph_label_propagation: the cluster tables outgrew their arena");
     if (iterationCount) *iterationCount = iterations;
+    timer.stage("label propagation");
 
     // CellGraph.cpp:561-596: clusters renumbered from 0 by decreasing size; equal sizes by decreasing label
     // (std::greater on (size, label)).
@@ -955,6 +957,7 @@ int em2_cell_graph_label_propagation(const uint32_t* vertexCellIds, uint32_t ver
     for (uint32_t v = 0; v < vertexCount; v++) {
         clusterIds[v] = std::lower_bound(renumber.begin(), renumber.end(), std::make_pair(clusterIds[v], 0u))->second;
     }
+    timer.stage("cluster renumbering");
     return EM2_OK;
 }
 

@@ -31,9 +31,15 @@
 #include "em2_select_wave.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <random>
 #include <vector>
+
+#include <rocprim/rocprim.hpp>
 
 namespace em2 {
 namespace {
@@ -53,12 +59,15 @@ struct TableMeta {
     float bestWeight;
 };
 
-// Phase A: a = old label, b = new label.  Phase B: a = the neighbour, b = its label before this iteration.
+// Phase A: a = old label, b = new label.  Phase B: a = the neighbour, b = its label before this iteration, and when
+// the neighbour had already had its turn at the first look, known = 1 and c = its new label.
 struct Candidate {
     uint32_t key;
     uint32_t a;
     uint32_t b;
     float weight;
+    uint32_t c;
+    uint32_t known;
 };
 
 struct ClusterArgs {
@@ -79,6 +88,7 @@ struct ClusterArgs {
     unsigned long long* arenaTop;
     uint64_t arenaCapacity;
     uint32_t* control;          // [0] ticket, [1] label changes, [2] error (1 wait timed out, 2 arena exhausted)
+    uint32_t ticketBatch;       // 0: wave w of W takes positions w, w+W, ..; else positions drawn from the ticket, this many at a time
     Candidate* scratchA;
     Candidate* scratchB;
 };
@@ -209,13 +219,33 @@ __device__ uint32_t labelAfterTurn(const ClusterArgs& args, uint32_t vertex, boo
 __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
 {
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t want = args.iteration + 1u;
+    const uint32_t waves = gridDim.x * (blockDim.x / 64u);
+    uint32_t next = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u, end = 0, changes = 0;
     for (;;) {
-        uint32_t p = kNone;
-        if (lane == 0u && __hip_atomic_load(args.control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            p = __hip_atomic_fetch_add(args.control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Every wave takes its positions in ascending order, so the smallest unfinished position is always the one
+        // its wave is working on and the waits below cannot deadlock -- with the strided assignment provided the
+        // whole grid is resident (the launcher sizes it so), with the ticket whatever the grid.  The ticket costs one
+        // same-address agent-scope atomic per draw (about 45 ns each, the floor of an iteration at one position per
+        // draw), and drawing several positions at a time widens the band of positions in flight, hence the waits.
+        uint32_t p;
+        if (args.ticketBatch == 0u) {
+            if (next >= args.vertexCount) break;
+            p = next;
+            next += waves;
+        } else {
+            if (next >= end) {
+                uint32_t first = kNone;
+                if (lane == 0u && __hip_atomic_load(args.control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    first = __hip_atomic_fetch_add(args.control, args.ticketBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                first = uniform(first);
+                if (first >= args.vertexCount) break;
+                next = first;
+                end = min(first + args.ticketBatch, args.vertexCount);
+            }
+            p = next++;
         }
-        p = uniform(p);
-        if (p >= args.vertexCount) return;
         const uint32_t v = uniform(args.order[p]);
         const uint64_t base = uniform(args.offsets[v]);
         const uint32_t degree = uniform(uint32_t(args.offsets[v + 1] - base));
@@ -246,6 +276,16 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
                 const uint32_t pc = args.posCur[u];
                 if (pc < p) keyB = pc;
             }
+            // First look at the earlier neighbours, all at once: most have had their turn and kept their label.
+            uint32_t afterU = 0;
+            bool known = false;
+            if (keyB != kNone) {
+                const uint64_t s = __hip_atomic_load(args.state + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                known = uint32_t(s >> 32) == want;
+                afterU = uint32_t(s);
+                if (known && afterU == labelU) keyB = kNone;
+            }
+            const uint64_t knownMask = __builtin_amdgcn_ballot_w64(known);
             while (!error) {
                 const uint32_t m = waveMin(keyA);
                 if (m == kNone) break;
@@ -265,7 +305,8 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
                 const float weight = __shfl(w, owner);
                 if (int(lane) == owner) keyB = kNone;
                 bool failed = false;
-                const uint32_t newLabel = labelAfterTurn(args, other, failed);
+                const uint32_t newLabel = ((knownMask >> owner) & 1ull) ? uint32_t(__shfl(int(afterU), owner))
+                                                                        : labelAfterTurn(args, other, failed);
                 if (failed) error = 1;
                 else if (newLabel != oldLabel && !applyEvent(t, args, oldLabel, newLabel, weight, lane)) error = 2;
             }
@@ -291,10 +332,17 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
                     pc = args.posCur[u];
                     isB = pc < p;
                 }
+                uint32_t afterU = 0, known = 0;
+                if (isB) {
+                    const uint64_t s = __hip_atomic_load(args.state + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    known = uint32_t(s >> 32) == want ? 1u : 0u;
+                    afterU = uint32_t(s);
+                    if (known && afterU == labelU) isB = false;
+                }
                 const uint64_t maskA = __builtin_amdgcn_ballot_w64(isA);
                 const uint64_t maskB = __builtin_amdgcn_ballot_w64(isB);
-                if (isA) listA[countA + lanesBelow(maskA)] = Candidate{pp, beforeU, labelU, w};
-                if (isB) listB[countB + lanesBelow(maskB)] = Candidate{pc, u, labelU, w};
+                if (isA) listA[countA + lanesBelow(maskA)] = Candidate{pp, beforeU, labelU, w, 0u, 0u};
+                if (isB) listB[countB + lanesBelow(maskB)] = Candidate{pc, u, labelU, w, afterU, known};
                 countA += uint32_t(__builtin_popcountll(maskA));
                 countB += uint32_t(__builtin_popcountll(maskB));
             }
@@ -331,7 +379,7 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
                         if (!applyEvent(t, args, a, b, weight, lane)) error = 2;
                     } else {
                         bool failed = false;
-                        const uint32_t newLabel = labelAfterTurn(args, a, failed);
+                        const uint32_t newLabel = uniform(candidate.known) ? uniform(candidate.c) : labelAfterTurn(args, a, failed);
                         if (failed) error = 1;
                         else if (newLabel != b && !applyEvent(t, args, b, newLabel, weight, lane)) error = 2;
                     }
@@ -351,15 +399,17 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
 
         // ---- the turn proper (CellGraph.cpp:507-524) ----
         const bool change = t.size != 0u && label != t.best;
-        if (change) label = t.best;
+        if (change) {
+            label = t.best;
+            ++changes;
+        }
         if (lane == 0u) {
             args.labelCur[v] = label;
             args.meta[v] = t;
-            if (change) __hip_atomic_fetch_add(args.control + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(args.state + v, (uint64_t(args.iteration + 1u) << 32) | label, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(args.state + v, (uint64_t(want) << 32) | label, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (lane == 0u && changes) __hip_atomic_fetch_add(args.control + 1, changes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // CellGraph.cpp:459-476: every vertex starts in the cluster named by its own cell id; its table lists the clusters of
@@ -397,11 +447,53 @@ positionsKernel(const uint32_t* __restrict__ order, uint32_t count, uint32_t* __
     if (p < count) position[order[p]] = p;
 }
 
+// The two ends of edge e are records 2e and 2e+1: key = the vertex whose list the record joins.
+__global__ void __launch_bounds__(256)
+edgeEndsKernel(const uint32_t* __restrict__ edge0, const uint32_t* __restrict__ edge1, uint32_t slots,
+               uint32_t* __restrict__ keys, uint32_t* __restrict__ ends, uint32_t* __restrict__ degree)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= slots) return;
+    const uint32_t vertex = (r & 1u) ? edge1[r >> 1] : edge0[r >> 1];
+    keys[r] = vertex;
+    ends[r] = r;
+    atomicAdd(degree + vertex, 1u);
+}
+
+__global__ void __launch_bounds__(256)
+adjacencyKernel(const uint32_t* __restrict__ endsSorted, uint32_t slots, const uint32_t* __restrict__ edge0,
+                const uint32_t* __restrict__ edge1, const float* __restrict__ similarity, uint32_t* __restrict__ neighbour,
+                float* __restrict__ weight)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= slots) return;
+    const uint32_t r = endsSorted[j];
+    neighbour[j] = (r & 1u) ? edge0[r >> 1] : edge1[r >> 1];
+    weight[j] = similarity[r >> 1];
+}
+
 struct Buffer {
     void* p = nullptr;
     ~Buffer() { if (p) (void)hipFree(p); }
     hipError_t allocate(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
     template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// EM2_TIMING=1: wall time of the stages of one call, on stderr.
+struct StageClock {
+    bool on = getenv("EM2_TIMING") && getenv("EM2_TIMING")[0] == '1';
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    double lap()
+    {
+        const auto now = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(now - last).count();
+        last = now;
+        return ms;
+    }
+    void stage(const char* name)
+    {
+        if (on) fprintf(stderr, "[em2 timing]   label propagation: %s %.1f ms\n", name, lap());
+    }
 };
 
 #define EM2_TRY(call)                        \
@@ -425,37 +517,68 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
     *iterationCount = 0;
     *error = 0;
     if (vertexCount == 0) return hipSuccess;
+    StageClock clock;
+    const dim3 block(256);
 
-    // out_edges() of every vertex, in add_edge order.
-    std::vector<uint64_t> offsets(size_t(vertexCount) + 1, 0);
-    for (uint64_t e = 0; e < edgeCount; e++) {
-        ++offsets[edgeVertex0[e] + 1];
-        ++offsets[edgeVertex1[e] + 1];
-    }
-    std::partial_sum(offsets.begin(), offsets.end(), offsets.begin());
+    // ---- out_edges() of every vertex in add_edge order: a stable sort of the 2E edge ends by vertex ----
     const uint64_t slots = 2 * edgeCount;
-    std::vector<uint32_t> neighbour(slots);
-    std::vector<float> weight(slots);
-    uint64_t maxDegree = 0;
-    {
-        std::vector<uint64_t> cursor(offsets.begin(), offsets.end() - 1);
-        for (uint64_t e = 0; e < edgeCount; e++) {
-            const uint32_t a = edgeVertex0[e], b = edgeVertex1[e];
-            neighbour[cursor[a]] = b;
-            weight[cursor[a]++] = edgeSimilarity[e];
-            neighbour[cursor[b]] = a;
-            weight[cursor[b]++] = edgeSimilarity[e];
-        }
-        for (uint32_t v = 0; v < vertexCount; v++) maxDegree = std::max(maxDegree, offsets[v + 1] - offsets[v]);
-    }
-
-    const uint64_t initialEntries = 2 * slots + 8ull * vertexCount;
-    const uint64_t arenaCapacity = initialEntries + std::max<uint64_t>(initialEntries, 1ull << 20);
-    Buffer dOffsets, dNeighbour, dWeight, dCells, dLabels, dState, dPositions, dOrder, dMeta, dArena, dControl, dScratch;
-    EM2_TRY(dOffsets.allocate(offsets.size() * sizeof(uint64_t)));
+    if (slots >= (1ull << 32)) return hipErrorInvalidValue;
+    Buffer dOffsets, dNeighbour, dWeight, dCells, dDegree;
+    EM2_TRY(dOffsets.allocate((size_t(vertexCount) + 1) * sizeof(uint64_t)));
     EM2_TRY(dNeighbour.allocate(slots * sizeof(uint32_t)));
     EM2_TRY(dWeight.allocate(slots * sizeof(float)));
     EM2_TRY(dCells.allocate(size_t(vertexCount) * sizeof(uint32_t)));
+    EM2_TRY(dDegree.allocate((size_t(vertexCount) + 1) * sizeof(uint32_t)));
+    EM2_TRY(hipMemcpyAsync(dCells.p, vertexCellIds, size_t(vertexCount) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    EM2_TRY(hipMemsetAsync(dDegree.p, 0, (size_t(vertexCount) + 1) * sizeof(uint32_t), stream));
+    uint32_t maxDegree = 0;
+    if (slots) {
+        Buffer dEdge0, dEdge1, dSimilarity, dKeys, dKeysSorted, dEnds, dEndsSorted, dTemp, dMax;
+        EM2_TRY(dEdge0.allocate(edgeCount * sizeof(uint32_t)));
+        EM2_TRY(dEdge1.allocate(edgeCount * sizeof(uint32_t)));
+        EM2_TRY(dSimilarity.allocate(edgeCount * sizeof(float)));
+        EM2_TRY(dKeys.allocate(slots * sizeof(uint32_t)));
+        EM2_TRY(dKeysSorted.allocate(slots * sizeof(uint32_t)));
+        EM2_TRY(dEnds.allocate(slots * sizeof(uint32_t)));
+        EM2_TRY(dEndsSorted.allocate(slots * sizeof(uint32_t)));
+        EM2_TRY(dMax.allocate(sizeof(uint32_t)));
+        EM2_TRY(hipMemcpyAsync(dEdge0.p, edgeVertex0, edgeCount * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        EM2_TRY(hipMemcpyAsync(dEdge1.p, edgeVertex1, edgeCount * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        EM2_TRY(hipMemcpyAsync(dSimilarity.p, edgeSimilarity, edgeCount * sizeof(float), hipMemcpyHostToDevice, stream));
+        const dim3 endGrid(uint32_t((slots + 255u) / 256u));
+        edgeEndsKernel<<<endGrid, block, 0, stream>>>(dEdge0.as<uint32_t>(), dEdge1.as<uint32_t>(), uint32_t(slots),
+                                                      dKeys.as<uint32_t>(), dEnds.as<uint32_t>(), dDegree.as<uint32_t>());
+        EM2_TRY(hipGetLastError());
+        uint32_t keyBits = 1;
+        while (keyBits < 32u && (1ull << keyBits) < vertexCount) ++keyBits;
+        size_t sortBytes = 0, scanBytes = 0, maxBytes = 0;
+        EM2_TRY(rocprim::radix_sort_pairs(nullptr, sortBytes, dKeys.as<uint32_t>(), dKeysSorted.as<uint32_t>(), dEnds.as<uint32_t>(),
+                                          dEndsSorted.as<uint32_t>(), size_t(slots), 0u, keyBits, stream));
+        EM2_TRY(rocprim::exclusive_scan(nullptr, scanBytes, dDegree.as<uint32_t>(), dOffsets.as<uint64_t>(), uint64_t(0),
+                                        size_t(vertexCount) + 1, rocprim::plus<uint64_t>(), stream));
+        EM2_TRY(rocprim::reduce(nullptr, maxBytes, dDegree.as<uint32_t>(), dMax.as<uint32_t>(), 0u, size_t(vertexCount),
+                                rocprim::maximum<uint32_t>(), stream));
+        EM2_TRY(dTemp.allocate(std::max(sortBytes, std::max(scanBytes, maxBytes))));
+        EM2_TRY(rocprim::radix_sort_pairs(dTemp.p, sortBytes, dKeys.as<uint32_t>(), dKeysSorted.as<uint32_t>(), dEnds.as<uint32_t>(),
+                                          dEndsSorted.as<uint32_t>(), size_t(slots), 0u, keyBits, stream));
+        EM2_TRY(rocprim::exclusive_scan(dTemp.p, scanBytes, dDegree.as<uint32_t>(), dOffsets.as<uint64_t>(), uint64_t(0),
+                                        size_t(vertexCount) + 1, rocprim::plus<uint64_t>(), stream));
+        EM2_TRY(rocprim::reduce(dTemp.p, maxBytes, dDegree.as<uint32_t>(), dMax.as<uint32_t>(), 0u, size_t(vertexCount),
+                                rocprim::maximum<uint32_t>(), stream));
+        adjacencyKernel<<<endGrid, block, 0, stream>>>(dEndsSorted.as<uint32_t>(), uint32_t(slots), dEdge0.as<uint32_t>(),
+                                                       dEdge1.as<uint32_t>(), dSimilarity.as<float>(), dNeighbour.as<uint32_t>(),
+                                                       dWeight.as<float>());
+        EM2_TRY(hipGetLastError());
+        EM2_TRY(hipMemcpyAsync(&maxDegree, dMax.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        EM2_TRY(hipStreamSynchronize(stream));
+    } else {
+        EM2_TRY(hipMemsetAsync(dOffsets.p, 0, (size_t(vertexCount) + 1) * sizeof(uint64_t), stream));
+    }
+    clock.stage("adjacency");
+
+    const uint64_t initialEntries = 2 * slots + 8ull * vertexCount;
+    const uint64_t arenaCapacity = initialEntries + std::max<uint64_t>(initialEntries, 1ull << 20);
+    Buffer dLabels, dState, dPositions, dOrder, dMeta, dArena, dControl, dScratch;
     EM2_TRY(dLabels.allocate(4 * size_t(vertexCount) * sizeof(uint32_t)));
     EM2_TRY(dState.allocate(size_t(vertexCount) * sizeof(uint64_t)));
     EM2_TRY(dPositions.allocate(2 * size_t(vertexCount) * sizeof(uint32_t)));
@@ -463,96 +586,111 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
     EM2_TRY(dMeta.allocate(size_t(vertexCount) * sizeof(TableMeta)));
     EM2_TRY(dArena.allocate(arenaCapacity * sizeof(TableEntry)));
     EM2_TRY(dControl.allocate(4 * sizeof(uint32_t) + sizeof(unsigned long long)));
-    if (maxDegree > 64) EM2_TRY(dScratch.allocate(2 * slots * sizeof(Candidate)));
-    EM2_TRY(hipMemcpyAsync(dOffsets.p, offsets.data(), offsets.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-    if (slots) {
-        EM2_TRY(hipMemcpyAsync(dNeighbour.p, neighbour.data(), slots * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        EM2_TRY(hipMemcpyAsync(dWeight.p, weight.data(), slots * sizeof(float), hipMemcpyHostToDevice, stream));
-    }
-    EM2_TRY(hipMemcpyAsync(dCells.p, vertexCellIds, size_t(vertexCount) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    if (maxDegree > 64u) EM2_TRY(dScratch.allocate(2 * slots * sizeof(Candidate)));
 
     int device = 0, computeUnits = 0;
     EM2_TRY(hipGetDevice(&device));
     EM2_TRY(hipDeviceGetAttribute(&computeUnits, hipDeviceAttributeMultiprocessorCount, device));
+    // The strided schedule needs every wave of the grid resident: at most 4 blocks (16 waves) per CU, where the kernel's
+    // registers allow 7.  EM2_LABEL_TICKET_BATCH=n (n > 0) selects the ticket schedule instead, which does not care
+    // (a GPU shared with another process); a strided run that times out is repeated that way, from the start.
+    const char* batchText = getenv("EM2_LABEL_TICKET_BATCH");
+    uint32_t ticketBatch = batchText && atoi(batchText) > 0 ? uint32_t(atoi(batchText)) : 0u;
+    int blocksPerUnit = 0;
+    EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerUnit, labelPropagationKernel, 256, 0));
+    blocksPerUnit = std::max(1, std::min(blocksPerUnit, 4));
     const uint32_t waveBlocks = (vertexCount + 3u) / 4u;
-    const dim3 grid(std::min<uint32_t>(waveBlocks, uint32_t(computeUnits) * 8u)), block(256);
+    const dim3 grid(std::min<uint32_t>(waveBlocks, uint32_t(computeUnits) * uint32_t(blocksPerUnit)));
     uint32_t* label[4];
     for (int i = 0; i < 4; i++) label[i] = dLabels.as<uint32_t>() + size_t(i) * vertexCount;
     uint32_t* position[2] = {dPositions.as<uint32_t>(), dPositions.as<uint32_t>() + vertexCount};
     uint32_t* control = dControl.as<uint32_t>();
     unsigned long long* arenaTop = reinterpret_cast<unsigned long long*>(control + 4);
+    const std::vector<uint32_t> allVertices(shuffleInput, shuffleInput + vertexCount);
+    std::vector<uint32_t> shuffled[2];
+    clock.stage("allocate");
 
-    initialTablesKernel<<<grid, block, 0, stream>>>(vertexCount, dOffsets.as<uint64_t>(), dNeighbour.as<uint32_t>(),
-                                                    dWeight.as<float>(), dCells.as<uint32_t>(), dMeta.as<TableMeta>(),
-                                                    dArena.as<TableEntry>(), label[0], dState.as<uint64_t>());
-    EM2_TRY(hipGetLastError());
-    {
+    for (int attempt = 0;; ++attempt) {
+        initialTablesKernel<<<grid, block, 0, stream>>>(vertexCount, dOffsets.as<uint64_t>(), dNeighbour.as<uint32_t>(),
+                                                        dWeight.as<float>(), dCells.as<uint32_t>(), dMeta.as<TableMeta>(),
+                                                        dArena.as<TableEntry>(), label[0], dState.as<uint64_t>());
+        EM2_TRY(hipGetLastError());
         const uint32_t zero[4] = {0, 0, 0, 0};
         EM2_TRY(hipMemcpyAsync(control, zero, sizeof(zero), hipMemcpyHostToDevice, stream));
         const unsigned long long top = initialEntries;
         EM2_TRY(hipMemcpyAsync(arenaTop, &top, sizeof(top), hipMemcpyHostToDevice, stream));
-        EM2_TRY(hipStreamSynchronize(stream));
-    }
 
-    // :480-549.  std::mt19937 / std::shuffle are libstdc++'s, which is what the reference links; the order of one
-    // iteration is drawn while the GPU works on the previous one.
-    std::mt19937 randomGenerator(seed);
-    std::vector<uint32_t> allVertices(shuffleInput, shuffleInput + vertexCount);
-    std::vector<uint32_t> shuffled[2];
-    uint64_t stable = 0, iterations = 0;
-    if (maxIterationCount > 0) {
-        shuffled[0] = allVertices;
-        std::shuffle(shuffled[0].begin(), shuffled[0].end(), randomGenerator);
-    }
-    while (iterations < maxIterationCount) {
-        const uint32_t t = uint32_t(iterations);
-        const std::vector<uint32_t>& order = shuffled[t & 1u];
-        EM2_TRY(hipMemcpyAsync(dOrder.p, order.data(), size_t(vertexCount) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        positionsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, stream>>>(dOrder.as<uint32_t>(), vertexCount, position[t & 1u]);
-        EM2_TRY(hipGetLastError());
-        EM2_TRY(hipMemsetAsync(control, 0, 2 * sizeof(uint32_t), stream));
-        ClusterArgs args;
-        args.vertexCount = vertexCount;
-        args.iteration = t;
-        args.offsets = dOffsets.as<uint64_t>();
-        args.neighbour = dNeighbour.as<uint32_t>();
-        args.weight = dWeight.as<float>();
-        args.order = dOrder.as<uint32_t>();
-        args.posCur = position[t & 1u];
-        args.posPrev = position[(t + 1u) & 1u];
-        args.labelPrev = label[t & 3u];
-        args.labelPrev2 = label[(t + 3u) & 3u];
-        args.labelCur = label[(t + 1u) & 3u];
-        args.state = dState.as<uint64_t>();
-        args.meta = dMeta.as<TableMeta>();
-        args.arena = dArena.as<TableEntry>();
-        args.arenaTop = arenaTop;
-        args.arenaCapacity = arenaCapacity;
-        args.control = control;
-        args.scratchA = dScratch.as<Candidate>();
-        args.scratchB = dScratch.as<Candidate>() + slots;
-        labelPropagationKernel<<<grid, block, 0, stream>>>(args);
-        EM2_TRY(hipGetLastError());
-        ++iterations;
-        if (iterations < maxIterationCount) {
-            shuffled[iterations & 1u] = allVertices;
-            std::shuffle(shuffled[iterations & 1u].begin(), shuffled[iterations & 1u].end(), randomGenerator);
+        // :480-549.  std::mt19937 / std::shuffle are libstdc++'s, which is what the reference links; the order of
+        // one iteration is drawn while the GPU works on the previous one.
+        std::mt19937 randomGenerator(seed);
+        uint64_t stable = 0, iterations = 0;
+        uint32_t failure = 0;
+        if (maxIterationCount > 0) {
+            shuffled[0] = allVertices;
+            std::shuffle(shuffled[0].begin(), shuffled[0].end(), randomGenerator);
         }
-        uint32_t result[3] = {0, 0, 0};
-        EM2_TRY(hipMemcpyAsync(result, control, sizeof(result), hipMemcpyDeviceToHost, stream));
-        EM2_TRY(hipStreamSynchronize(stream));
-        if (result[2] != 0) {
-            *error = result[2];
-            *iterationCount = iterations;
+        clock.stage("first tables, first shuffle");
+        while (iterations < maxIterationCount) {
+            const uint32_t t = uint32_t(iterations);
+            const std::vector<uint32_t>& order = shuffled[t & 1u];
+            EM2_TRY(hipMemcpyAsync(dOrder.p, order.data(), size_t(vertexCount) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            positionsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, stream>>>(dOrder.as<uint32_t>(), vertexCount, position[t & 1u]);
+            EM2_TRY(hipGetLastError());
+            EM2_TRY(hipMemsetAsync(control, 0, 2 * sizeof(uint32_t), stream));
+            ClusterArgs args;
+            args.vertexCount = vertexCount;
+            args.iteration = t;
+            args.offsets = dOffsets.as<uint64_t>();
+            args.neighbour = dNeighbour.as<uint32_t>();
+            args.weight = dWeight.as<float>();
+            args.order = dOrder.as<uint32_t>();
+            args.posCur = position[t & 1u];
+            args.posPrev = position[(t + 1u) & 1u];
+            args.labelPrev = label[t & 3u];
+            args.labelPrev2 = label[(t + 3u) & 3u];
+            args.labelCur = label[(t + 1u) & 3u];
+            args.state = dState.as<uint64_t>();
+            args.meta = dMeta.as<TableMeta>();
+            args.arena = dArena.as<TableEntry>();
+            args.arenaTop = arenaTop;
+            args.arenaCapacity = arenaCapacity;
+            args.control = control;
+            args.ticketBatch = ticketBatch;
+            args.scratchA = dScratch.as<Candidate>();
+            args.scratchB = dScratch.as<Candidate>() + slots;
+            labelPropagationKernel<<<grid, block, 0, stream>>>(args);
+            EM2_TRY(hipGetLastError());
+            ++iterations;
+            if (iterations < maxIterationCount) {
+                shuffled[iterations & 1u] = allVertices;
+                std::shuffle(shuffled[iterations & 1u].begin(), shuffled[iterations & 1u].end(), randomGenerator);
+            }
+            uint32_t result[3] = {0, 0, 0};
+            EM2_TRY(hipMemcpyAsync(result, control, sizeof(result), hipMemcpyDeviceToHost, stream));
+            EM2_TRY(hipStreamSynchronize(stream));
+            if (clock.on) fprintf(stderr, "[em2 timing]   label propagation: iteration %u, %u changes, %.1f ms\n", t, result[1], clock.lap());
+            if (result[2] != 0) {
+                failure = result[2];
+                break;
+            }
+            stable = result[1] ? 0 : stable + 1;
+            if (stable == stableIterationCountThreshold) break;
+        }
+        if (failure == 1 && ticketBatch == 0 && attempt == 0) {
+            if (clock.on) fprintf(stderr, "[em2 timing]   label propagation: the strided schedule timed out, repeating with the ticket\n");
+            ticketBatch = 4;
+            continue;
+        }
+        *iterationCount = iterations;
+        if (failure) {
+            *error = failure;
             return hipSuccess;
         }
-        stable = result[1] ? 0 : stable + 1;
-        if (stable == stableIterationCountThreshold) break;
+        EM2_TRY(hipMemcpyAsync(labels, label[iterations & 3u], size_t(vertexCount) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        EM2_TRY(hipStreamSynchronize(stream));
+        clock.stage("labels to the host");
+        return hipSuccess;
     }
-    EM2_TRY(hipMemcpyAsync(labels, label[iterations & 3u], size_t(vertexCount) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    EM2_TRY(hipStreamSynchronize(stream));
-    *iterationCount = iterations;
-    return hipSuccess;
 }
 
 }  // namespace em2

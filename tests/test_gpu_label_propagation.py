@@ -102,3 +102,14 @@ def test_repeated_runs_are_identical(lib):
     for _ in range(3):
         again = capi.cell_graph_label_propagation(cells, v0, v1, sim)
         assert again[1] == first[1] and np.array_equal(again[0], first[0])
+
+
+@pytest.mark.parametrize("batch", ["1", "4"])
+def test_ticket_schedule_matches_too(lib, oracle, monkeypatch, batch):
+    # EM2_LABEL_TICKET_BATCH selects the schedule that draws positions from an atomic ticket (for a shared GPU).
+    monkeypatch.setenv("EM2_LABEL_TICKET_BATCH", batch)
+    rng = np.random.default_rng(11)
+    cells, v0, v1, sim = fast_graph(rng, 20000, 10, 16, 2, 200)
+    got, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim)
+    expected, expected_iterations = oracle.label_propagation(cells, v0, v1, sim)
+    assert iterations == expected_iterations and np.array_equal(got, expected)
