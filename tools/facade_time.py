@@ -16,4 +16,12 @@ for gs in ("AllGenes", "Half"):
     for rep in range(2):
         t0 = time.perf_counter(); e.findSimilarPairs4(geneSetName=gs, similarPairsName="P"); dt = time.perf_counter() - t0
         print("findSimilarPairs4(%s) run %d: %.2f s" % (gs, rep, dt), flush=True)
+# BASELINE config E: the consumers of SimilarPairs
+for rep in range(2):
+    name = "G%d" % rep
+    t0 = time.perf_counter(); e.createCellGraph(name, "AllCells", "P", float(os.environ.get("GRAPH_THRESHOLD", 0.2)), 20); dt = time.perf_counter() - t0
+    info = e._cell_graph_information(name)
+    print("createCellGraph run %d: %.2f s (%d vertices, %d edges)" % (rep, dt, info["vertexCount"], info["edgeCount"]), flush=True)
+    t0 = time.perf_counter(); cells, clusters = e.labelPropagationClustering(name); dt = time.perf_counter() - t0
+    print("labelPropagationClustering run %d: %.2f s (%d clusters)" % (rep, dt, int(clusters.max()) + 1 if len(clusters) else 0), flush=True)
 shutil.rmtree(d)

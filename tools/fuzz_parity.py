@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_binding  # noqa: E402
 import synth  # noqa: E402
+from label_graphs import fast_graph  # noqa: E402
 from expressionmatrix2_amd import capi  # noqa: E402
 
 KNOBS = ("EM2_SCAN_MODE", "EM2_MIN_SEGMENT_COLUMNS", "EM2_LOG_CAPACITY", "EM2_FULL_ROW_CELLS", "EM2_VIRTUAL_WORLD",
@@ -23,10 +24,31 @@ def main():
     rng = np.random.default_rng(seed)
     oracle = oracle_binding.load_oracle()
     deadline = time.time() + float(os.environ.get("SECONDS", "120"))
-    runs = {"fsp4": 0, "fsp5": 0, "fsp7": 0, "signatures": 0, "graph": 0}
+    runs = {"fsp4": 0, "fsp5": 0, "fsp7": 0, "signatures": 0, "graph": 0, "labels": 0}
     while time.time() < deadline:
         for key in KNOBS:
             os.environ.pop(key, None)
+        if rng.random() < 0.15:
+            # label propagation over a random k-NN-like graph: every schedule against the serial oracle
+            vertices = int(rng.choice([2, 3, 50, 64, 65, 1000, 5000, 30000]))
+            degree = int(rng.choice([1, 2, 5, 12, 30]))
+            hubs = int(rng.choice([0, 0, 1, 4]))
+            case = dict(vertices=vertices, degree=degree, clusters=int(rng.choice([1, 3, 10, 40])), hubs=min(hubs, vertices),
+                        hub_degree=int(rng.choice([70, 300, 3000])), parallel=int(rng.choice([0, 0, 5, 200])),
+                        ties=int(rng.choice([0, 0, 2, 16])), graph_seed=int(rng.integers(1 << 30)),
+                        seed=int(rng.choice([231, 1, 2 ** 33 + 7])), stable=int(rng.choice([0, 1, 3])),
+                        max_iterations=int(rng.choice([0, 1, 3, 100])), ticket=str(rng.choice(["", "1", "3", "8"])))
+            cells, v0, v1, s = fast_graph(np.random.default_rng(case["graph_seed"]), vertices, degree, case["clusters"],
+                                          case["hubs"], case["hub_degree"], case["parallel"] if vertices > 3 else 0, case["ties"])
+            if case["ticket"]:
+                os.environ["EM2_LABEL_TICKET_BATCH"] = case["ticket"]
+            got = capi.cell_graph_label_propagation(cells, v0, v1, s, case["seed"], case["stable"], case["max_iterations"])
+            os.environ.pop("EM2_LABEL_TICKET_BATCH", None)
+            expect = oracle.label_propagation(cells, v0, v1, s, case["seed"], case["stable"], case["max_iterations"])
+            if got[1] != expect[1] or not np.array_equal(got[0], expect[0]):
+                raise SystemExit("PARITY FAILURE labels %r" % case)
+            runs["labels"] += 1
+            continue
         n = int(rng.choice([1, 2, 63, 64, 65, 200, 500, 1000, 1500, 2500, 4000]))
         L = int(rng.choice([1, 32, 64, 100, 128, 192, 256, 512, 1000, 1024, 2048, 4096]))
         k = int(rng.choice([1, 2, 5, 10, 33, 100, 300]))
