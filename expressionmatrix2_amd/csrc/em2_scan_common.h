@@ -58,6 +58,10 @@ struct Fsp4Args {
     uint32_t localBlockBase;    // first list / state slot of this launch (symmetric kernels)
     uint32_t columnLimit;       // columns [0, columnLimit) only (symmetric kernels)
     uint32_t shardFlags;        // kShardNoFinish | kShardPublishAll | kShardGlobalOutput
+    // matrix-core form of the symmetric scan only (em2_scan_symmetric.hip)
+    const void* fragments;      // the signatures as FP4 +-1 in MFMA fragment order, 512 B per cell
+    uint32_t matrixLdsOffset;   // where the column tiles start in the block's dynamic LDS
+    uint32_t pad2;
 };
 
 constexpr uint32_t kShardNoFinish = 1u;       // full-row blocks publish their state instead of finishing the rows

@@ -484,6 +484,322 @@ fsp4ScanSymmetricKernel(Fsp4Args args)
     }
 }
 
+// =========================================================================================================
+// Matrix-core form of the triangle part (1024-bit signatures).  A signature bit becomes the FP4 (E2M1) value +1 or -1;
+// the dot product of two cells over the 1024 (padded) bits is 1024 - 2m, exact in the f32 accumulator, and
+// v_mfma_scale_f32_32x32x64_f8f6f4 (scales 2^0) contracts 64 bits of 32 x 32 cells per instruction: 8 times the
+// pairs per SIMD clock of the v_xor/v_bcnt loop at its instruction floor (tools/ubench_mfma_pairs.hip).
+//
+// The contract of the scan does not change, only who counts.  A block of 4 waves owns 4 consecutive triangle row
+// blocks (a "quad", 256 cells); its waves walk the columns below the quad in lock step, 32 at a time: the tile's
+// fragments (16 KB, stored in fragment order so the copy is linear) go through a double-buffered LDS image shared by
+// the 4 waves; each wave contracts the tile with its own 64 rows, which it holds as the B operand (128 VGPRs), so a
+// row of the result sits on lane & 31; 16 v_permlane32_swap turn the two 32x32 results into "lane = row, register =
+// column", the layout of the v_xor/v_bcnt loop, and every column is tested against the looser of the row's and the
+// column's bound with one v_min, one v_cmp and one branch, exactly as there.  What passes is rare and takes the old
+// paths: the column side goes to the inbox, the row side to the wave's log (the lock step cannot stop for a list
+// that fills up), which the wave replays through the exact state machine when the walk is over -- the speculative
+// mode of the other kernels, always on.  The last columns of a quad (its own 256 cells: the band below each wave's
+// rows and the diagonal) are done by the v_xor/v_bcnt code, each wave on its own.
+// Items are (segment, quad); segment and full-row boundaries are multiples of 256 cells, so the 4 waves of a block
+// always have the same columns.  Full-row blocks stay with fsp4ScanSymmetricKernel (a launch of their own).
+// =========================================================================================================
+
+typedef int FragmentWord4 __attribute__((ext_vector_type(4)));
+typedef int FragmentWord8 __attribute__((ext_vector_type(8)));
+typedef float Accumulator16 __attribute__((ext_vector_type(16)));
+
+constexpr uint32_t kMatrixSteps = 16;                        // 1024 bits / 64 per MFMA
+constexpr uint32_t kMatrixTileWords = kMatrixSteps * 64u;    // FragmentWord4 per 32-cell tile (16 KB)
+constexpr float kMatrixBits = 1024.f;
+
+// sig32 [cell][32] -> fragments [cell / 32][k-step][lane]: lane l of k-step s holds cell (l & 31) of the block, bits
+// s*64 + (l >> 5)*32 .. +31, one nibble per bit (0x2 = +1, 0xA = -1).  Cells past the end repeat the last one.
+__global__ void __launch_bounds__(256)
+expandFragmentsKernel(const uint32_t* __restrict__ sig32, uint32_t cellCount, uint32_t fragmentCount,
+                      FragmentWord4* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= fragmentCount) return;
+    const uint32_t lane = i & 63u, step = (i >> 6) % kMatrixSteps, block = (i >> 6) / kMatrixSteps;
+    uint32_t cell = block * 32u + (lane & 31u);
+    if (cell >= cellCount) cell = cellCount - 1u;
+    const uint32_t word = sig32[size_t(cell) * 32u + step * 2u + (lane >> 5)];
+    FragmentWord4 v;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int n = 0; n < 8; n++) packed |= (((word >> (d * 8 + n)) & 1u) ? 0xAu : 0x2u) << (4 * n);
+        v[d] = int(packed);
+    }
+    out[i] = v;
+}
+
+// The lock-step walk over the tiles [colBegin, colEnd) (multiples of 32).  Returns the first column not scanned, the
+// same in all waves of the block: the walk ends early, at a tile boundary, when some row's log could overflow in the
+// next tile.  stopWords: 3 LDS words, zero on entry and on return.
+template <bool IDENTITY>
+__device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restrict__ fragments, const int32_t* snap,
+                                                    uint32_t colBegin, uint32_t colEnd, uint32_t rowFragmentBlock,
+                                                    float rowDot, uint32_t row, bool rowValid, uint32_t lane,
+                                                    Entry* myLog, uint32_t logCapacity, uint32_t& logCount,
+                                                    uint32_t& emitPos, uint32_t& emitEnd, FragmentWord4* tiles,
+                                                    volatile uint32_t* stopWords)
+{
+    const int scale = 0x7f7f7f7f;                // E8M0 127 = 2^0 in every byte
+    FragmentWord4 rows[2][kMatrixSteps];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+#pragma unroll
+        for (int s = 0; s < int(kMatrixSteps); s++) {
+            rows[t][s] = fragments[(size_t(rowFragmentBlock + uint32_t(t)) * kMatrixSteps + uint32_t(s)) * 64u + lane];
+        }
+    }
+    {
+        const FragmentWord4* src = fragments + size_t(colBegin / 32u) * kMatrixTileWords;
+#pragma unroll
+        for (int j = 0; j < 4; j++) tiles[threadIdx.x + j * 256] = src[threadIdx.x + j * 256];
+    }
+    __syncthreads();
+    uint32_t iteration = 0;
+    for (uint32_t colBase = colBegin; colBase < colEnd; colBase += 32u, ++iteration) {
+        const uint32_t cur = iteration & 1u;
+        const bool more = colBase + 32u < colEnd;
+        FragmentWord4 staged[4];
+        if (more) {
+            const FragmentWord4* src = fragments + size_t(colBase / 32u + 1u) * kMatrixTileWords;
+#pragma unroll
+            for (int j = 0; j < 4; j++) staged[j] = src[threadIdx.x + j * 256];
+        }
+        // bound of column (lane & 31) as a dot product: any value a cell published earlier is valid (they only tighten)
+        const float columnDotLane = kMatrixBits - 2.f * float(snap[colBase + (lane & 31u)]);
+        Accumulator16 acc0 = {}, acc1 = {};
+        const FragmentWord4* tile = tiles + cur * kMatrixTileWords;
+#pragma unroll
+        for (int s = 0; s < int(kMatrixSteps); s++) {
+            const FragmentWord4 a = tile[s * 64 + int(lane)];
+            const FragmentWord8 a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
+            const FragmentWord8 b0 = {rows[0][s].x, rows[0][s].y, rows[0][s].z, rows[0][s].w, 0, 0, 0, 0};
+            const FragmentWord8 b1 = {rows[1][s].x, rows[1][s].y, rows[1][s].z, rows[1][s].w, 0, 0, 0, 0};
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, acc0, 4, 4, 0, scale, 0, scale);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, acc1, 4, 4, 0, scale, 0, scale);
+        }
+        // lane = row: acc0[i] <- column (i&3) + 8*(i>>2), acc1[i] <- that + 4
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const auto swapped = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[i]), __float_as_uint(acc1[i]), false, false);
+            acc0[i] = __uint_as_float(swapped[0]);
+            acc1[i] = __uint_as_float(swapped[1]);
+        }
+#pragma unroll
+        for (int c = 0; c < 32; c++) {
+            const int g = c >> 3, w = c & 7;
+            const float dot = w < 4 ? acc0[4 * g + w] : acc1[4 * g + w - 4];
+            const float columnDot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(columnDotLane), c));
+            if (__builtin_amdgcn_ballot_w64(dot >= fminf(rowDot, columnDot)) != 0ull) {
+                const uint32_t col = colBase + uint32_t(c);
+                const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
+                emitColumn(rowValid && dot >= columnDot, col, row, m, lane, emitPos, emitEnd);
+                if (dot >= rowDot) {
+                    storeEntry(myLog + logCount, col, m);
+                    ++logCount;
+                }
+            }
+        }
+        if (more) {
+            FragmentWord4* next = tiles + (cur ^ 1u) * kMatrixTileWords;
+#pragma unroll
+            for (int j = 0; j < 4; j++) next[threadIdx.x + j * 256] = staged[j];
+        }
+        // a tile adds at most 32 entries to a row's log
+        const bool full = __builtin_amdgcn_ballot_w64(logCount + 32u > logCapacity) != 0ull;
+        const uint32_t slot = iteration % 3u;
+        if (full && lane == 0u) stopWords[slot] = 1u;
+        if (threadIdx.x == 0u) stopWords[(iteration + 1u) % 3u] = 0u;
+        __syncthreads();
+        if (stopWords[slot] != 0u) {
+            __syncthreads();
+            if (threadIdx.x == 0u) stopWords[slot] = 0u;
+            __syncthreads();
+            return colBase + 32u;
+        }
+    }
+    return colEnd;
+}
+
+template <bool IDENTITY>
+__global__ void __launch_bounds__(256, 2)
+fsp4ScanMatrixKernel(Fsp4Args args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    FragmentWord4* tiles = reinterpret_cast<FragmentWord4*>(ldsRaw + kernelArgs()->matrixLdsOffset);
+    volatile uint32_t* shared = reinterpret_cast<volatile uint32_t*>(ldsRaw + kernelArgs()->matrixLdsOffset + 2u * kMatrixTileWords * 16u);
+    // shared[0..2] stop words of the walk, shared[3] the block's ticket
+    if (threadIdx.x < 4u) shared[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t emitPos = 0, emitEnd = 0;
+
+    for (;;) {
+        if (threadIdx.x == 0u) {
+            // a hand-off that timed out anywhere ends the launch for everybody
+            const bool broken = __hip_atomic_load(kernelArgs()->control + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            shared[3] = broken ? 0xffffffffu
+                               : __hip_atomic_fetch_add(kernelArgs()->control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const uint32_t ticket = uint32_t(__builtin_amdgcn_readfirstlane(int(shared[3])));
+        __syncthreads();
+        ArgsPtr aux = kernelArgs();
+        if (ticket >= aux->totalTickets) break;
+
+        // ---- the item: segment seg, quad = 4 row blocks from quadBlock ----
+        const uint32_t segments = aux->segments;
+        const uint32_t* table = aux->segTable;
+        uint32_t seg = 0;
+        while (ticket >= table[seg + 1u]) ++seg;
+        const uint32_t quadBlock = table[segments + 1u + seg] + 4u * (ticket - table[seg]);
+        const uint32_t block = quadBlock + wave;
+        const bool idle = block >= aux->rowBlocks;              // the last quad may be short
+        const uint32_t listBlock = idle ? aux->rowBlocks - 1u : block;
+        const uint32_t quadRowBase = quadBlock * 64u;
+        const uint32_t rowBase = block * 64u;
+        const uint32_t row = rowBase + lane;
+        const bool rowValid = !idle && row < aux->cellCount;
+        const uint32_t twoK = 2u * aux->k;
+        uint32_t logCapacity = aux->logCapacity < 64u ? 64u : aux->logCapacity;
+        Entry* myList = aux->buffers + (size_t(listBlock) * 64u + lane) * twoK;
+        Entry* myLog = aux->logs + (size_t(blockIdx.x * 4u + wave) * 64u + lane) * logCapacity;
+        const uint32_t cps = aux->columnsPerSegment;
+        const uint32_t colBegin = seg * cps;
+        uint32_t colEnd = colBegin + cps;
+        if (colEnd > aux->columnLimit || seg + 1u == segments) colEnd = aux->columnLimit;
+        const bool last = quadRowBase < colEnd;                 // the segment that holds the quad's own cells
+        const uint32_t commonEnd = last ? quadRowBase : colEnd;
+        int32_t mMax = rowValid ? aux->mMaxInitial : -1;
+        uint32_t count = 0, logCount = 0;
+        bool haveState = seg == 0u;
+        if (seg != 0u && !idle) {
+            const uint32_t done = uint32_t(__builtin_amdgcn_readfirstlane(
+                int(__hip_atomic_load(aux->segmentsDone + block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+            if (done != 0u) {
+                if (done >= seg) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const uint64_t st = __hip_atomic_load(reinterpret_cast<const uint64_t*>(aux->rowState) + size_t(block) * 64u + lane,
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mMax = rowValid ? int32_t(uint32_t(st >> 32)) : -1;
+                if (done >= seg) {
+                    count = uint32_t(st);
+                    haveState = true;
+                }
+            }
+        }
+
+        // ---- the columns below the quad, in lock step ----
+        bool failed = false;
+        uint32_t at = colBegin;
+        for (;;) {
+            if (at < commonEnd) {
+                at = scanTilesMatrix<IDENTITY>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, at, commonEnd,
+                                               2u * listBlock, kMatrixBits - 2.f * float(mMax), row, rowValid, lane, myLog,
+                                               logCapacity, logCount, emitPos, emitEnd, tiles, shared);
+            }
+            if (!haveState && !idle && !failed) {
+                const uint32_t* flag = aux->segmentsDone + block;
+                const uint64_t start = __builtin_amdgcn_s_memrealtime();         // 100 MHz
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (__builtin_amdgcn_s_memrealtime() - start > 400000000ull ||
+                        __hip_atomic_load(aux->control + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                        failed = true;
+                        break;
+                    }
+                }
+                if (failed) {
+                    if (lane == 0u) __hip_atomic_store(aux->control + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    const uint64_t st = __hip_atomic_load(reinterpret_cast<const uint64_t*>(aux->rowState) + size_t(block) * 64u + lane,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    count = uint32_t(st);
+                    mMax = rowValid ? int32_t(uint32_t(st >> 32)) : -1;
+                    haveState = true;
+                }
+            }
+            // replay the log through the exact state machine (ascending column order per row)
+            if (!idle && !failed) {
+                for (uint32_t i = 0;; ++i) {
+                    const bool active = i < logCount;
+                    if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+                    uint32_t c = 0, m = 0;
+                    if (active) {
+                        const Entry e = myLog[i];
+                        c = e.cell;
+                        m = e.key;
+                    }
+                    const bool pass = active && int32_t(m) <= mMax;
+                    if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                        acceptColumn<IDENTITY>(pass, c, row, m, lane, listBlock, myList, twoK, count, mMax, ldsRaw);
+                    }
+                }
+            }
+            logCount = 0;
+            if (at >= commonEnd) break;
+        }
+        // (a wave whose hand-off failed keeps walking with its block -- the barriers need it -- and the launch ends at
+        // the next ticket)
+
+        // ---- the quad's own 256 columns: the band below this wave's rows and its diagonal, as in the other kernel ----
+        if (last && !idle && !failed) {
+            uint32_t r[32];
+            const uint32_t* rp = aux->sig32 + size_t(rowValid ? row : rowBase) * 32u;
+#pragma unroll
+            for (int w = 0; w < 32; ++w) r[w] = rp[w];
+            uint32_t diagEnd = rowBase + 64u;
+            if (diagEnd > aux->columnLimit) diagEnd = aux->columnLimit;
+            uint32_t from = quadRowBase;
+            while (from < rowBase) {
+                ensureInboxRoom(lane, emitPos, emitEnd);
+                uint32_t unusedLogCount = 0;
+                from = scanColumnsEmit<32, IDENTITY, false>(kernelArgs()->sig32, kernelArgs()->snap, from, rowBase, r, row,
+                                                            rowValid, lane, myList, twoK, count, mMax, myLog, logCapacity,
+                                                            unusedLogCount, emitPos, emitEnd);
+                acceptColumn<IDENTITY>(false, 0u, row, 0u, lane, listBlock, myList, twoK, count, mMax, ldsRaw);
+            }
+            uint32_t unusedLogCount = 0;
+            scanDiagonal<32, IDENTITY, false>(kernelArgs()->sig32, kernelArgs()->snap, rowBase, diagEnd, r, row, rowValid, lane,
+                                              listBlock, myList, twoK, count, mMax, myLog, logCapacity, unusedLogCount, emitPos,
+                                              emitEnd, ldsRaw);
+        }
+
+        // ---- publish the state: for the next segment, for the columns' snapshots, for the inbox replay ----
+        if (!idle && !failed) {
+            ArgsPtr aux2 = kernelArgs();
+            const uint64_t st = uint64_t(count) | (uint64_t(uint32_t(mMax)) << 32);
+            __hip_atomic_store(reinterpret_cast<uint64_t*>(aux2->rowState) + size_t(block) * 64u + lane, st,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rowValid) __hip_atomic_store(aux2->snap + row, mMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0u && !last) {
+                __hip_atomic_store(aux2->segmentsDone + block, seg + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+
+    // the unused tail of this wave's last inbox chunk becomes sentinels
+    {
+        const uint32_t p = uint32_t(__builtin_amdgcn_readfirstlane(int(emitPos)));
+        const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(emitEnd)));
+        if (p <= e) {
+            uint64_t* inbox = kernelArgs()->inbox;
+            for (uint32_t i = p + lane; i < e; i += 64u) inbox[i] = ~0ull;
+        }
+    }
+}
+
 // Second phase of the symmetric scan: one wave per triangle row block replays the sorted inbox entries of its 64
 // cells (ascending candidate id per cell) through the exact state machine and finishes the rows.
 template <bool IDENTITY>
@@ -748,6 +1064,8 @@ __global__ void maxReduceKernel(int32_t* __restrict__ arrays, uint32_t n, uint32
 // EM2_SCAN_MODE=persistent / simple disable it; by default it is used from kSymmetricMinCells cells on.
 constexpr uint32_t kSymmetricMinCells = 131072;
 constexpr uint32_t kMaxSegments = 64;
+constexpr uint32_t kMatrixMaxSegments = 256;     // matrix form: 4096-column segments are 2 MB of fragments, what an XCD's L2 holds
+constexpr uint32_t kTableWords = 2u * kMatrixMaxSegments + 2u;
 constexpr uint32_t kInboxChunk = 512;
 
 bool symmetricEligible(uint32_t cellCount, uint32_t rowCount)
@@ -781,7 +1099,7 @@ static size_t inboxSortTempBytes(uint64_t capacity)
 }
 
 struct SymmetricLayout {
-    size_t snap, table, control, poolA, poolB, temp, total, tempBytes;
+    size_t snap, table, tableMatrix, control, poolA, poolB, temp, fragments, total, tempBytes;
     uint64_t capacity;
 };
 
@@ -792,11 +1110,13 @@ static SymmetricLayout symmetricLayout(uint32_t cellCount)
     l.tempBytes = inboxSortTempBytes(l.capacity);
     size_t at = 0;
     l.snap = at;    at += align256(size_t(cellCount) * 4u);
-    l.table = at;   at += align256((2u * kMaxSegments + 2u) * 4u);
+    l.table = at;   at += align256(kTableWords * 4u);
+    l.tableMatrix = at; at += align256(kTableWords * 4u);
     l.control = at; at += 256u;
     l.poolA = at;   at += align256(size_t(l.capacity) * 8u);
     l.poolB = at;   at += align256(size_t(l.capacity) * 8u);
     l.temp = at;    at += align256(l.tempBytes);
+    l.fragments = at; at += align256(size_t((cellCount + 63u) / 64u) * 64u * 512u);     // FP4 fragments, matrix form
     l.total = at;
     return l;
 }
@@ -870,29 +1190,53 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     uint32_t fullRowBlocks = uint32_t((fullCells + 63u) / 64u);
     if (fullRowBlocks > rowBlocks) fullRowBlocks = rowBlocks;
 
+    // Matrix-core form of the triangle part (see fsp4ScanMatrixKernel): 1024-bit signatures, the plain single-GPU
+    // launch.  EM2_SCAN_MATRIX=0 keeps the v_xor/v_bcnt form.  Full-row and segment boundaries become multiples of 256
+    // cells so that the four waves of a block always walk the same columns.
+    bool matrix = paddedDw == 32u && wavesPerBlock == 4u && args.rowBlockStride == 1u && args.rowBlockOffset == 0u &&
+                  args.localBlockBase == 0u && args.shardFlags == 0u && args.columnLimit == cellCount && args.rowBegin == 0u &&
+                  envNumber("EM2_SCAN_MATRIX", 1) != 0 &&
+                  ((lds + 15u) & ~size_t(15)) + 2u * kMatrixTileWords * 16u + 64u <= 64u * 1024u;      // selection area + two tiles
+    if (matrix) {
+        fullRowBlocks = (fullRowBlocks + 3u) & ~3u;
+        if (fullRowBlocks >= rowBlocks) {
+            fullRowBlocks = rowBlocks;
+            matrix = false;             // nothing left for the triangle
+        }
+    }
+
     // Segments: as many as the column-count floor allows, up to kMaxSegments (EM2_SEGMENTS overrides): short
     // segments keep the column snapshots fresh and even out the triangle.
     uint64_t minSegmentColumns = envNumber("EM2_MIN_SEGMENT_COLUMNS", 4096);
     if (minSegmentColumns < 1) minSegmentColumns = 1;
+    const uint32_t maxSegments = matrix ? kMatrixMaxSegments : kMaxSegments;
     uint64_t segments = cellCount / minSegmentColumns;
-    if (segments > kMaxSegments) segments = kMaxSegments;
+    if (segments > maxSegments) segments = maxSegments;
     const uint64_t forcedSegments = envNumber("EM2_SEGMENTS", 0);
-    if (forcedSegments >= 1 && forcedSegments <= kMaxSegments) segments = forcedSegments;
+    if (forcedSegments >= 1 && forcedSegments <= maxSegments) segments = forcedSegments;
     if (segments < 1) segments = 1;
-    const uint32_t cps = uint32_t((uint64_t(cellCount) + segments - 1u) / segments);
+    uint32_t cps = uint32_t((uint64_t(cellCount) + segments - 1u) / segments);
+    if (matrix) cps = (cps + 255u) & ~255u;
     segments = (uint64_t(cellCount) + cps - 1u) / cps;
 
-    uint32_t table[2u * kMaxSegments + 2u];
-    uint64_t tickets = 0;
+    // Tickets of the v_xor/v_bcnt kernel: per segment the full-row blocks, then (unless the matrix kernel takes them)
+    // the triangle blocks that reach into the segment.  Tickets of the matrix kernel: per segment the quads likewise.
+    uint32_t table[kTableWords], tableMatrix[kTableWords];
+    uint64_t tickets = 0, ticketsMatrix = 0;
     for (uint32_t sIdx = 0; sIdx < segments; ++sIdx) {
         uint32_t firstTriangle = uint32_t((uint64_t(sIdx) * cps) / 64u);
         if (firstTriangle < fullRowBlocks) firstTriangle = fullRowBlocks;
+        if (firstTriangle > rowBlocks) firstTriangle = rowBlocks;
         table[sIdx] = uint32_t(tickets);
         table[segments + 1u + sIdx] = firstTriangle;
-        tickets += fullRowBlocks + (rowBlocks - firstTriangle);
-        if (tickets >= 0xffffffffull) return hipErrorInvalidValue;
+        tickets += fullRowBlocks + (matrix ? 0u : rowBlocks - firstTriangle);
+        tableMatrix[sIdx] = uint32_t(ticketsMatrix);
+        tableMatrix[segments + 1u + sIdx] = firstTriangle;              // a multiple of 4 in the matrix form
+        ticketsMatrix += (rowBlocks - firstTriangle + 3u) / 4u;
+        if (tickets >= 0xffffffffull || ticketsMatrix >= 0xffffffffull) return hipErrorInvalidValue;
     }
     table[segments] = uint32_t(tickets);
+    tableMatrix[segments] = uint32_t(ticketsMatrix);
 
     const SymmetricLayout layout = symmetricLayout(cellCount);
     char* ws = static_cast<char*>(symmetricWs);
@@ -938,19 +1282,58 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     e = hipMemcpyAsync(ws + layout.table, table, (2u * segments + 2u) * 4u, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return e;
 
-    uint64_t wavesWanted = tickets;
-    if (wavesWanted > slots) wavesWanted = slots;
-    if (wavesWanted > maxResidentWaves()) wavesWanted = maxResidentWaves();
     const dim3 block(64u * wavesPerBlock);
-    const dim3 grid(uint32_t((wavesWanted + wavesPerBlock - 1u) / wavesPerBlock));
-    void* kernelArgsArray[] = {&args};
     static thread_local hipEvent_t timing[2] = {nullptr, nullptr};
     if (!timing[0]) {
         if (hipEventCreate(&timing[0]) != hipSuccess || hipEventCreate(&timing[1]) != hipSuccess) timing[0] = timing[1] = nullptr;
     }
     if (timing[0]) (void)hipEventRecord(timing[0], stream);
-    e = hipLaunchKernel(kernel, grid, block, kernelArgsArray, lds, stream);
-    if (e != hipSuccess) return e;
+    if (tickets) {
+        uint64_t wavesWanted = tickets;
+        if (wavesWanted > slots) wavesWanted = slots;
+        if (wavesWanted > maxResidentWaves()) wavesWanted = maxResidentWaves();
+        const dim3 grid(uint32_t((wavesWanted + wavesPerBlock - 1u) / wavesPerBlock));
+        void* kernelArgsArray[] = {&args};
+        e = hipLaunchKernel(kernel, grid, block, kernelArgsArray, lds, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (matrix) {
+        // the full-row blocks are done (their launch above); now the triangle on the matrix cores
+        e = hipMemcpyAsync(ws + layout.tableMatrix, tableMatrix, (2u * segments + 2u) * 4u, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(args.control, 0, 4u, stream);                 // the ticket; the error word stays
+        if (e != hipSuccess) return e;
+        const uint32_t fragmentCount = rowBlocks * 2u * kMatrixSteps * 64u;
+        expandFragmentsKernel<<<dim3((fragmentCount + 255u) / 256u), dim3(256), 0, stream>>>(
+            args.sig32, cellCount, fragmentCount, reinterpret_cast<FragmentWord4*>(ws + layout.fragments));
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        Fsp4Args matrixArgs = args;
+        matrixArgs.segTable = reinterpret_cast<const uint32_t*>(ws + layout.tableMatrix);
+        matrixArgs.totalTickets = uint32_t(ticketsMatrix);
+        matrixArgs.fragments = ws + layout.fragments;
+        matrixArgs.matrixLdsOffset = uint32_t((lds + 15u) & ~size_t(15));
+        const size_t matrixLds = size_t(matrixArgs.matrixLdsOffset) + 2u * kMatrixTileWords * 16u + 64u;
+        const void* matrixKernel = identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<true>)
+                                            : reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<false>);
+        int device = 0, cuCount = 0, blocksPerCu = 0;
+        e = hipGetDevice(&device);
+        if (e != hipSuccess) return e;
+        e = hipDeviceGetAttribute(&cuCount, hipDeviceAttributeMultiprocessorCount, device);
+        if (e != hipSuccess) return e;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCu, matrixKernel, 256, matrixLds);
+        if (e != hipSuccess) return e;
+        blocksPerCu = blocksPerCu < 1 ? 1 : (blocksPerCu > 2 ? 2 : blocksPerCu);
+        if (const char* v = getenv("EM2_BLOCKS_PER_CU")) {
+            if (atoi(v) >= 1 && atoi(v) < blocksPerCu) blocksPerCu = atoi(v);
+        }
+        uint64_t blocksWanted = uint64_t(cuCount) * uint64_t(blocksPerCu);
+        if (blocksWanted * 4u > maxResidentWaves()) blocksWanted = maxResidentWaves() / 4u;      // the logs are sized for that
+        if (blocksWanted > ticketsMatrix) blocksWanted = ticketsMatrix;
+        void* matrixArgsArray[] = {&matrixArgs};
+        e = hipLaunchKernel(matrixKernel, dim3(uint32_t(blocksWanted)), dim3(256), matrixArgsArray, matrixLds, stream);
+        if (e != hipSuccess) return e;
+    }
     if (timing[0]) (void)hipEventRecord(timing[1], stream);
 
     // the number of inbox entries (incl. chunk tails), the overflow flag and the hand-off error word
@@ -976,7 +1359,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
             const uint64_t end = uint64_t(b) * 64u + 64u;
             steps += double(end < cellCount ? end : cellCount);
         }
-        lastLaunchInfo.form = 1;
+        lastLaunchInfo.form = matrix ? 2 : 1;
         lastLaunchInfo.scanKernelMs = double(ms);
         lastLaunchInfo.waveColumnSteps = steps;
         lastLaunchInfo.inboxEntries = double(used);
@@ -984,8 +1367,9 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         lastLaunchInfo.fullRowCells = double(fullCellsClamped);
     }
     if (const char* v = getenv("EM2_SCAN_VERBOSE")) {
-        if (v[0] == '1') fprintf(stderr, "[em2] symmetric scan: %u segments x %u columns, %u full-row blocks, %llu tickets, %llu inbox slots\n",
-                                 uint32_t(segments), cps, fullRowBlocks, (unsigned long long)tickets, (unsigned long long)used);
+        if (v[0] == '1') fprintf(stderr, "[em2] symmetric scan%s: %u segments x %u columns, %u full-row blocks, %llu + %llu tickets, %llu inbox slots\n",
+                                 matrix ? " (matrix cores)" : "", uint32_t(segments), cps, fullRowBlocks,
+                                 (unsigned long long)tickets, (unsigned long long)(matrix ? ticketsMatrix : 0), (unsigned long long)used);
     }
 
     const uint64_t* sorted = args.inbox;

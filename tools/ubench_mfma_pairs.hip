@@ -1,0 +1,362 @@
+// ubench_mfma_pairs.hip -- how fast could the all-pairs Hamming scan run on the matrix cores of gfx950?
+//
+// Not part of the product (DESIGN.md section 8 item 3 asks the question; this measures the answer).  A signature bit
+// b becomes the FP4 (E2M1) value +1 (0x2) or -1 (0xA); the dot product of two such vectors over L bits is L - 2*m with
+// m the mismatch count, exact in the f32 accumulator.  v_mfma_scale_f32_32x32x64_f8f6f4 (scales 2^0) contracts 64 bits
+// of 32 rows x 32 columns per instruction.
+//
+// Kernel shape (the one a product kernel would have): rows stationary in registers (a wave holds the fragments of 64
+// rows x 1024 bits = 128 VGPRs), a block of 4 waves = 256 rows streams 32-column tiles (16 KB each, stored in HBM in
+// fragment order so the copy is linear) through a double-buffered LDS image, 32 MFMAs per tile and wave, then the
+// epilogue every scan needs: compare each of the 2048 results of the tile with a per-row and a per-column bound and
+// leave the fast path only when one passes.
+//
+// Build:  hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench_mfma_pairs tools/ubench_mfma_pairs.hip
+// Run:    /tmp/ubench_mfma_pairs [cells=131072] [limit=226]
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(call)                                                                                   \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));               \
+            exit(1);                                                                                  \
+        }                                                                                             \
+    } while (0)
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kBits = 1024;
+constexpr int kWords = kBits / 32;      // 32-bit words per signature
+constexpr int kSteps = kBits / 64;      // MFMA k-steps per signature
+
+// ---- reference: one thread per row, XOR + popcount over all columns ----
+__global__ void __launch_bounds__(256)
+referenceKernel(const uint32_t* __restrict__ sig, uint32_t cells, uint32_t limit, unsigned long long* __restrict__ result)
+{
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= cells) return;
+    uint32_t mine[kWords];
+    for (int w = 0; w < kWords; w++) mine[w] = sig[size_t(row) * kWords + w];
+    unsigned long long count = 0, sum = 0;
+    for (uint32_t col = 0; col < cells; col++) {
+        uint32_t m = 0;
+        for (int w = 0; w < kWords; w++) m += __builtin_popcount(mine[w] ^ sig[size_t(col) * kWords + w]);
+        if (m <= limit && col != row) {
+            ++count;
+            sum += (unsigned long long)row * 31u + (unsigned long long)col * 17u + m;
+        }
+    }
+    atomicAdd(result, count);
+    atomicAdd(result + 1, sum);
+}
+
+// ---- bits -> FP4 +-1, in fragment order: [block of 32 cells][k-step][lane] x 16 bytes ----
+// lane l of k-step s holds cell (l & 31) of the block, bits s*64 + (l >> 5)*32 .. +31.
+__global__ void __launch_bounds__(256)
+expandKernel(const uint32_t* __restrict__ sig, uint32_t cells, v4i* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells / 32u * kSteps * 64u) return;
+    const uint32_t lane = i & 63u, step = (i >> 6) % kSteps, block = (i >> 6) / kSteps;
+    const uint32_t cell = block * 32u + (lane & 31u);
+    const uint32_t word = sig[size_t(cell) * kWords + step * 2u + (lane >> 5)];
+    v4i v;
+    for (int d = 0; d < 4; d++) {
+        uint32_t packed = 0;
+        for (int n = 0; n < 8; n++) packed |= (((word >> (d * 8 + n)) & 1u) ? 0xAu : 0x2u) << (4 * n);
+        v[d] = int(packed);
+    }
+    out[i] = v;
+}
+
+// ---- the scan on the matrix cores ----
+// EPILOGUE 0: none (MFMA + operand streaming only); 1: fast-path test of the tile, exact handling when it fires.
+template <int EPILOGUE>
+__global__ void __launch_bounds__(256, 2)
+mfmaPairsKernel(const v4i* __restrict__ fragments, uint32_t cells, const float* __restrict__ minDot, uint32_t limit,
+                unsigned long long* __restrict__ result)
+{
+    __shared__ v4i tile[2][kSteps * 64];                    // 2 x 16 KB
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t rowBlock0 = blockIdx.x * 8u + wave * 2u;  // this wave: row blocks rowBlock0, rowBlock0 + 1
+    const uint32_t columnBlocks = cells / 32u;
+    const int scale = 0x7f7f7f7f;                            // E8M0 127 = 2^0
+
+    v4i a[2][kSteps];
+    for (int t = 0; t < 2; t++)
+        for (int s = 0; s < kSteps; s++) a[t][s] = fragments[(size_t(rowBlock0 + t) * kSteps + s) * 64u + lane];
+
+    // Bounds in the accumulator layout: the row of register i is (i&3) + 8*(i>>2) + 4*(lane>>5).  A product kernel
+    // holds one bound per row; here all rows share minDot, but the registers and the instructions are the same.
+    float rowBound[2][16];
+    for (int t = 0; t < 2; t++)
+        for (int i = 0; i < 16; i++) {
+            rowBound[t][i] = minDot[(rowBlock0 + uint32_t(t)) * 32u + uint32_t(i & 3) + 8u * uint32_t(i >> 2) + 4u * (lane >> 5)];
+        }
+
+    unsigned long long count = 0, sum = 0;
+    // prologue: tile 0
+    {
+        const v4i* src = fragments + size_t(0) * kSteps * 64u;
+        for (int j = 0; j < 4; j++) tile[0][threadIdx.x + j * 256] = src[threadIdx.x + j * 256];
+    }
+    __syncthreads();
+    for (uint32_t cb = 0; cb < columnBlocks; cb++) {
+        const int cur = cb & 1u;
+        v4i staged[4];
+        const bool more = cb + 1u < columnBlocks;
+        if (more) {
+            const v4i* src = fragments + size_t(cb + 1u) * kSteps * 64u;
+            for (int j = 0; j < 4; j++) staged[j] = src[threadIdx.x + j * 256];
+        }
+        v16f acc0 = {}, acc1 = {};
+#pragma unroll
+        for (int s = 0; s < kSteps; s++) {
+            const v4i b = tile[cur][s * 64 + lane];
+            const v8i b8 = {b.x, b.y, b.z, b.w, 0, 0, 0, 0};
+            const v8i a0 = {a[0][s].x, a[0][s].y, a[0][s].z, a[0][s].w, 0, 0, 0, 0};
+            const v8i a1 = {a[1][s].x, a[1][s].y, a[1][s].z, a[1][s].w, 0, 0, 0, 0};
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b8, acc0, 4, 4, 0, scale, 0, scale);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b8, acc1, 4, 4, 0, scale, 0, scale);
+        }
+        if (EPILOGUE == 1) {
+            // Fast path: does any result reach its bound?  (column bound: one per lane; here the same value.)
+            const float columnBound = minDot[cb * 32u + (lane & 31u)];
+            float best = -4096.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                best = fmaxf(best, acc0[i] - fmaxf(rowBound[0][i], columnBound));
+                best = fmaxf(best, acc1[i] - fmaxf(rowBound[1][i], columnBound));
+            }
+            if (__builtin_amdgcn_ballot_w64(best >= 0.f) != 0ull) {
+                const uint32_t col = cb * 32u + (lane & 31u);
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t r = uint32_t(i & 3) + 8u * uint32_t(i >> 2) + 4u * (lane >> 5);
+                    for (int t = 0; t < 2; t++) {
+                        const float dot = t ? acc1[i] : acc0[i];
+                        const uint32_t row = (rowBlock0 + uint32_t(t)) * 32u + r;
+                        const uint32_t m = uint32_t((float(kBits) - dot) * 0.5f);
+                        if (m <= limit && row != col) {
+                            ++count;
+                            sum += (unsigned long long)row * 31u + (unsigned long long)col * 17u + m;
+                        }
+                    }
+                }
+            }
+        } else {
+            // keep the accumulators alive
+            if (acc0[0] + acc1[5] == 12345.f) ++count;
+        }
+        if (more) {
+            for (int j = 0; j < 4; j++) tile[cur ^ 1][threadIdx.x + j * 256] = staged[j];
+        }
+        __syncthreads();
+    }
+    if (count) {
+        atomicAdd(result, count);
+        atomicAdd(result + 1, sum);
+    }
+}
+
+// ---- the form a drop-in for the product's column loop would take ----
+// The wave's 64 rows are the B operand (so a row sits on lane & 31 of the result), the streamed columns the A operand;
+// 16 v_permlane32_swap turn the two 32x32 results into "lane = row, register = column", the layout of the product's
+// scan, and every column is then tested against max(row bound, column bound) exactly as there: one v_min, one v_cmp,
+// one branch.  DIRECT: each wave loads the column fragments itself (no LDS, no barrier: waves stay independent, which
+// is what the product's ticket / hand-off scheme needs); otherwise the block shares them through LDS.
+template <bool DIRECT>
+__global__ void __launch_bounds__(256, 2)
+mfmaRowLaneKernel(const v4i* __restrict__ fragments, uint32_t cells, const float* __restrict__ minDot, uint32_t limit,
+                  unsigned long long* __restrict__ result)
+{
+    __shared__ v4i tile[DIRECT ? 1 : 2][DIRECT ? 1 : kSteps * 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t rowBlock0 = blockIdx.x * 8u + wave * 2u;
+    const uint32_t row = rowBlock0 * 32u + lane;
+    const uint32_t columnBlocks = cells / 32u;
+    const int scale = 0x7f7f7f7f;
+
+    v4i rows[2][kSteps];
+    for (int t = 0; t < 2; t++)
+        for (int s = 0; s < kSteps; s++) rows[t][s] = fragments[(size_t(rowBlock0 + t) * kSteps + s) * 64u + lane];
+    const float rowBound = minDot[row];
+
+    unsigned long long count = 0, sum = 0;
+    if (!DIRECT) {
+        for (int j = 0; j < 4; j++) tile[0][threadIdx.x + j * 256] = fragments[threadIdx.x + j * 256];
+        __syncthreads();
+    }
+    v4i next[DIRECT ? kSteps : 4];
+    if (DIRECT) {
+        for (int s = 0; s < kSteps; s++) next[s] = fragments[size_t(s) * 64u + lane];
+    }
+    for (uint32_t cb = 0; cb < columnBlocks; cb++) {
+        const int cur = cb & 1u;
+        const bool more = cb + 1u < columnBlocks;
+        v4i columns[DIRECT ? kSteps : 1];
+        if (DIRECT) {
+            for (int s = 0; s < kSteps; s++) columns[s] = next[s];
+            if (more) {
+                for (int s = 0; s < kSteps; s++) next[s] = fragments[(size_t(cb + 1u) * kSteps + s) * 64u + lane];
+            }
+        } else if (more) {
+            const v4i* src = fragments + size_t(cb + 1u) * kSteps * 64u;
+            for (int j = 0; j < 4; j++) next[j] = src[threadIdx.x + j * 256];
+        }
+        v16f acc0 = {}, acc1 = {};
+#pragma unroll
+        for (int s = 0; s < kSteps; s++) {
+            const v4i a = DIRECT ? columns[s] : tile[DIRECT ? 0 : cur][DIRECT ? 0 : s * 64 + lane];
+            const v8i a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
+            const v8i b0 = {rows[0][s].x, rows[0][s].y, rows[0][s].z, rows[0][s].w, 0, 0, 0, 0};
+            const v8i b1 = {rows[1][s].x, rows[1][s].y, rows[1][s].z, rows[1][s].w, 0, 0, 0, 0};
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, acc0, 4, 4, 0, scale, 0, scale);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, acc1, 4, 4, 0, scale, 0, scale);
+        }
+        // lane = row: acc0[i] <- column (i&3) + 8*(i>>2), acc1[i] <- that + 4
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const auto swapped = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[i]), __float_as_uint(acc1[i]), false, false);
+            acc0[i] = __uint_as_float(swapped[0]);
+            acc1[i] = __uint_as_float(swapped[1]);
+        }
+        const float* columnBounds = minDot + cb * 32u;       // wave-uniform: scalar loads
+#pragma unroll
+        for (int c = 0; c < 32; c++) {
+            const int g = c >> 3, w = c & 7;
+            const float dot = w < 4 ? acc0[4 * g + w] : acc1[4 * g + w - 4];
+            const float bound = fminf(rowBound, columnBounds[c]);
+            if (__builtin_amdgcn_ballot_w64(dot >= bound) != 0ull) {
+                const uint32_t col = cb * 32u + uint32_t(c);
+                const uint32_t m = uint32_t((float(kBits) - dot) * 0.5f);
+                if (m <= limit && row != col) {
+                    ++count;
+                    sum += (unsigned long long)row * 31u + (unsigned long long)col * 17u + m;
+                }
+            }
+        }
+        if (!DIRECT) {
+            if (more) {
+                for (int j = 0; j < 4; j++) tile[DIRECT ? 0 : cur ^ 1][threadIdx.x + j * 256] = next[j];
+            }
+            __syncthreads();
+        }
+    }
+    atomicAdd(result, count);
+    atomicAdd(result + 1, sum);
+}
+
+static uint64_t splitmix(uint64_t& x)
+{
+    uint64_t z = (x += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+int main(int argc, char** argv)
+{
+    const uint32_t cells = argc > 1 ? uint32_t(atoi(argv[1])) : 131072u;
+    const uint32_t limit = argc > 2 ? uint32_t(atoi(argv[2])) : 226u;
+    if (cells % 256u) {
+        fprintf(stderr, "cells must be a multiple of 256\n");
+        return 1;
+    }
+    // 64 cluster centres, every bit flipped with probability 0.15 (the bench's scan-only input)
+    std::vector<uint32_t> sig(size_t(cells) * kWords);
+    uint64_t seed = 12345;
+    std::vector<uint32_t> centres(64 * kWords);
+    for (auto& w : centres) w = uint32_t(splitmix(seed));
+    for (uint32_t c = 0; c < cells; c++) {
+        const uint32_t cluster = uint32_t(splitmix(seed) & 63u);
+        for (int w = 0; w < kWords; w++) {
+            uint32_t flips = 0;
+            for (int b = 0; b < 32; b++) flips |= uint32_t((splitmix(seed) % 100u) < 15u) << b;
+            sig[size_t(c) * kWords + w] = centres[cluster * kWords + w] ^ flips;
+        }
+    }
+    uint32_t* dSig;
+    v4i* dFragments;
+    unsigned long long* dResult;
+    CHECK(hipMalloc(&dSig, sig.size() * 4));
+    CHECK(hipMalloc(&dFragments, size_t(cells) * kBits / 2));
+    CHECK(hipMalloc(&dResult, 6 * sizeof(unsigned long long)));
+    CHECK(hipMemcpy(dSig, sig.data(), sig.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemset(dResult, 0, 6 * sizeof(unsigned long long)));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    float ms = 0;
+    const double pairs = double(cells) * double(cells);
+
+    CHECK(hipEventRecord(e0));
+    referenceKernel<<<cells / 256u, 256>>>(dSig, cells, limit, dResult);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("reference (thread per row, VALU popcount): %.2f ms, %.3g ordered pairs/s\n", ms, pairs / ms * 1e3);
+
+    const uint32_t fragments = cells / 32u * kSteps * 64u;
+    CHECK(hipEventRecord(e0));
+    expandKernel<<<(fragments + 255u) / 256u, 256>>>(dSig, cells, dFragments);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("expand to FP4 fragments: %.3f ms (%zu MB)\n", ms, size_t(cells) * kBits / 2 >> 20);
+
+    float* minDot;
+    {
+        std::vector<float> bounds(cells, float(kBits) - 2.f * float(limit));
+        CHECK(hipMalloc(&minDot, size_t(cells) * sizeof(float)));
+        CHECK(hipMemcpy(minDot, bounds.data(), size_t(cells) * sizeof(float), hipMemcpyHostToDevice));
+    }
+    for (int rep = 0; rep < 3; rep++) {
+        CHECK(hipEventRecord(e0));
+        mfmaPairsKernel<0><<<cells / 256u, 256>>>(dFragments, cells, minDot, limit, dResult + 4);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("mfma fp4, no epilogue: %.3f ms, %.3g ordered pairs/s\n", ms, pairs / ms * 1e3);
+    }
+    for (int rep = 0; rep < 3; rep++) {
+        CHECK(hipMemset(dResult + 2, 0, 2 * sizeof(unsigned long long)));
+        CHECK(hipEventRecord(e0));
+        mfmaPairsKernel<1><<<cells / 256u, 256>>>(dFragments, cells, minDot, limit, dResult + 2);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("mfma fp4 + bound test: %.3f ms, %.3g ordered pairs/s\n", ms, pairs / ms * 1e3);
+    }
+    for (int direct = 0; direct < 2; direct++) {
+        for (int rep = 0; rep < 3; rep++) {
+            CHECK(hipMemset(dResult + 2, 0, 2 * sizeof(unsigned long long)));
+            CHECK(hipEventRecord(e0));
+            if (direct) mfmaRowLaneKernel<true><<<cells / 256u, 256>>>(dFragments, cells, minDot, limit, dResult + 2);
+            else mfmaRowLaneKernel<false><<<cells / 256u, 256>>>(dFragments, cells, minDot, limit, dResult + 2);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            printf("mfma fp4, lane = row, per-column test, columns %s: %.3f ms, %.3g ordered pairs/s\n",
+                   direct ? "loaded by each wave" : "through LDS", ms, pairs / ms * 1e3);
+        }
+        unsigned long long check[2];
+        CHECK(hipMemcpy(check, dResult + 2, sizeof(check), hipMemcpyDeviceToHost));
+        unsigned long long ref[2];
+        CHECK(hipMemcpy(ref, dResult, sizeof(ref), hipMemcpyDeviceToHost));
+        printf("    count %llu checksum %llu: %s\n", check[0], check[1], (check[0] == ref[0] && check[1] == ref[1]) ? "IDENTICAL" : "DIFFERENT");
+    }
+    unsigned long long result[6];
+    CHECK(hipMemcpy(result, dResult, sizeof(result), hipMemcpyDeviceToHost));
+    printf("pairs within %u mismatches: reference %llu (checksum %llu), mfma %llu (checksum %llu): %s\n", limit, result[0],
+           result[1], result[2], result[3], (result[0] == result[2] && result[1] == result[3]) ? "IDENTICAL" : "DIFFERENT");
+    return (result[0] == result[2] && result[1] == result[3]) ? 0 : 2;
+}
