@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_FP4_PEAK_TFLOPS = 10000.0   # MI355X_MICROARCH.md: FP4/FP6 block-scaled MFMA, ~10 PFLOP/s dense
 # v_xor_b32 / v_bcnt_u32_b32 issue one wave64 instruction per 4 clocks per SIMD on gfx950 (measured:
 # profiles/r01_pmc_1Mcells_scan_projection.json, SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles): 16 lanes/clk.
 VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9     # 256 CUs x 4 SIMD x 16 lanes/clk x 2.4 GHz
@@ -188,7 +189,8 @@ def main():
     # ordered form that is rows*C comparisons by the kernel; in the symmetric form (1 GPU, all rows in one launch)
     # every unordered pair is evaluated once.  The library reports what it ran.
     launch = capi.dev_find_similar_pairs4_last_launch()
-    symmetric = launch["form"] == 1
+    matrix = launch["form"] == 3                  # the symmetric form with its triangle part on the matrix cores
+    symmetric = launch["form"] in (1, 3)
     sharded_symmetric = launch["form"] == 2
     kernel_ms = launch["scan_kernel_ms"] if symmetric and launch["scan_kernel_ms"] > 0 else scan_ms
     launch_pairs = total_pairs / world if sharded_symmetric else pipe.rows * (C - 1) / 2.0
@@ -229,10 +231,12 @@ def main():
                         % (C, G, args.density * G, L, k, thr, world),
             "cells": C, "genes": G, "lsh_count": L, "k": k, "similarity_threshold": thr,
             "rows_per_gpu": pipe.shard, "nnz_rank0": nnz_local,
-            "scan": "sharded-symmetric" if sharded_symmetric else "symmetric" if symmetric else "row-shards",
+            "scan": "sharded-symmetric" if sharded_symmetric else "symmetric-matrix" if matrix else "symmetric" if symmetric else "row-shards",
         },
         "phases_ms_rank0": {"projection": proj_ms, "scan": scan_ms},
-        "roofline": {
+        "roofline": None,
+    }
+    hbm_roofline = {
             "kernel": ("fsp4ScanKernel<%d,...>" if os.environ.get("EM2_SCAN_MODE") == "simple"
                        else "fsp4ScanSymmetricKernel<%d,true>" if symmetric
                        else "fsp4ScanSymmetricKernel<%d,true> + fsp4TileKernel" if sharded_symmetric
@@ -261,9 +265,43 @@ def main():
                     "bounded by 1; valu_frac = (v_xor+v_bcnt lane-ops actually executed)/(256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz), "
                     "the measured issue rate of these ops; kernel_ms = HIP events on the launch stream around the scan kernel "
                     "(recorded inside the library for the symmetric form, around the call otherwise)",
-        },
-        "parity_check": check,
     }
+    if matrix:
+        result["dtype"] = "fp4 e2m1 +-1 products, f32 accumulate, exact (scan on the matrix cores) / u32 popcount (band, full rows) / f64 (projection)"
+    if matrix and launch["matrix_kernel_ms"] > 0:
+        # Dominant kernel: fsp4ScanMatrixKernel, bound by the matrix cores.  One (row, column) pair = a 1024-long dot
+        # product of FP4 +-1 values = 2 * 1024 flop on v_mfma_scale_f32_32x32x64_f8f6f4; peak = the dense FP4 MFMA
+        # figure of MI355X_MICROARCH.md (10 PFLOP/s).  The HBM / instruction view of the same launch rides along.
+        flops = launch["matrix_pairs"] * 2.0 * 1024.0
+        tflops = flops / (launch["matrix_kernel_ms"] * 1e-3) / 1e12
+        result["roofline"] = {
+            "kernel": "fsp4ScanMatrixKernel<true>",
+            "kernel_ms": launch["matrix_kernel_ms"],
+            "form": "symmetric, triangle part on the matrix cores: every unordered pair evaluated once as an FP4 +-1 dot "
+                    "product (1024 - 2 * mismatches, exact in f32); the first cells' full rows and each quad's own 256 columns "
+                    "stay on v_xor/v_bcnt; inbox sort + replay follow",
+            "bound": "mfma",
+            "achieved": tflops,
+            "peak": MFMA_FP4_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": tflops / MFMA_FP4_PEAK_TFLOPS,
+            "traffic": None,
+            "flop_per_launch": flops,
+            "pairs_on_matrix_cores": launch["matrix_pairs"],
+            "pairs_per_s_on_matrix_cores": launch["matrix_pairs"] / (launch["matrix_kernel_ms"] * 1e-3),
+            "inbox_entries": launch["inbox_entries"],
+            "scan_launches_ms": kernel_ms,
+            "hbm_view": {key: hbm_roofline[key] for key in ("achieved", "peak", "unit", "frac", "algorithmic_bytes")},
+            "note": "flop = 2 * 1024 per (row, column) pair contracted by fsp4ScanMatrixKernel (pairs counted by the launcher: "
+                    "64 rows x the columns below each quad); kernel_ms = HIP events on the launch stream around that kernel "
+                    "alone, scan_launches_ms = around all launches of the scan (full-row blocks on v_xor/v_bcnt, fragment "
+                    "expansion, the matrix kernel); hbm_view = the algorithmic 16*W bytes per unordered pair over "
+                    "scan_launches_ms, kept for comparison with earlier rounds (operands are cache resident, so it is not "
+                    "bounded by 1)",
+        }
+    else:
+        result["roofline"] = hbm_roofline
+    result["parity_check"] = check
 
     if rank == 0 and not args.no_cpu_baseline:
         m = min(args.cpu_baseline_cells, C)

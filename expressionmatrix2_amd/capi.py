@@ -310,11 +310,13 @@ def dev_find_similar_pairs4_form(cell_count, row_count):
 
 
 def dev_find_similar_pairs4_last_launch():
-    """dict(form, scan_kernel_ms, wave_column_steps, inbox_entries, segments, full_row_cells) of the last launch."""
-    v = np.zeros(6, dtype=np.float64)
-    check(load().em2_dev_find_similar_pairs4_last_launch(_ptr(v), 6))
+    """dict(form, scan_kernel_ms, wave_column_steps, inbox_entries, segments, full_row_cells, matrix_pairs,
+    matrix_kernel_ms) of the last launch; form 0 ordered, 1 symmetric, 2 sharded symmetric, 3 symmetric on the matrix cores."""
+    v = np.zeros(8, dtype=np.float64)
+    check(load().em2_dev_find_similar_pairs4_last_launch(_ptr(v), 8))
     return {"form": int(v[0]), "scan_kernel_ms": float(v[1]), "wave_column_steps": float(v[2]),
-            "inbox_entries": float(v[3]), "segments": int(v[4]), "full_row_cells": int(v[5])}
+            "inbox_entries": float(v[3]), "segments": int(v[4]), "full_row_cells": int(v[5]),
+            "matrix_pairs": float(v[6]), "matrix_kernel_ms": float(v[7])}
 
 
 def dev_find_similar_pairs4(sig_ptr, cell_count, row_begin, row_end, lsh_count, k, similarity_threshold,

@@ -57,12 +57,14 @@ size_t fsp4ControlBytes(uint32_t rowCount);
 size_t fsp4SymmetricBytes(uint32_t cellCount, uint32_t rowCount);
 bool fsp4UsesSymmetricScan(uint32_t cellCount, uint32_t rowCount);
 struct Fsp4LaunchInfo {
-    int form;                 // 0 ordered rows x columns, 1 symmetric
+    int form;                 // 0 ordered rows x columns, 1 symmetric, 2 sharded symmetric, 3 symmetric on the matrix cores
     double scanKernelMs;      // duration of the scan kernel proper when the launcher measured it (symmetric form), else -1
     double waveColumnSteps;   // (64-row wave, column) steps executed: x 64 lanes x 2*W32 = v_xor/v_bcnt lane-ops
     double inboxEntries;      // symmetric form: entries (incl. chunk padding) sorted and replayed
     double segments;
     double fullRowCells;
+    double matrixPairs;       // form 3: (row, column) pairs contracted on the matrix cores
+    double matrixKernelMs;    // form 3: duration of fsp4ScanMatrixKernel alone
 };
 Fsp4LaunchInfo fsp4LastLaunchInfo();      // of the calling thread's last launchFsp4Scan
 hipError_t readFsp4Error(const void* control, uint32_t rowCount, hipStream_t stream, uint32_t* error);

@@ -1283,9 +1283,10 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     if (e != hipSuccess) return e;
 
     const dim3 block(64u * wavesPerBlock);
-    static thread_local hipEvent_t timing[2] = {nullptr, nullptr};
+    static thread_local hipEvent_t timing[3] = {nullptr, nullptr, nullptr};
     if (!timing[0]) {
-        if (hipEventCreate(&timing[0]) != hipSuccess || hipEventCreate(&timing[1]) != hipSuccess) timing[0] = timing[1] = nullptr;
+        if (hipEventCreate(&timing[0]) != hipSuccess || hipEventCreate(&timing[1]) != hipSuccess ||
+            hipEventCreate(&timing[2]) != hipSuccess) timing[0] = timing[1] = timing[2] = nullptr;
     }
     if (timing[0]) (void)hipEventRecord(timing[0], stream);
     if (tickets) {
@@ -1331,6 +1332,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         if (blocksWanted * 4u > maxResidentWaves()) blocksWanted = maxResidentWaves() / 4u;      // the logs are sized for that
         if (blocksWanted > ticketsMatrix) blocksWanted = ticketsMatrix;
         void* matrixArgsArray[] = {&matrixArgs};
+        if (timing[0]) (void)hipEventRecord(timing[2], stream);
         e = hipLaunchKernel(matrixKernel, dim3(uint32_t(blocksWanted)), dim3(256), matrixArgsArray, matrixLds, stream);
         if (e != hipSuccess) return e;
     }
@@ -1354,12 +1356,19 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     {
         float ms = -1.0f;
         if (!timing[0] || hipEventElapsedTime(&ms, timing[0], timing[1]) != hipSuccess) ms = -1.0f;
-        double steps = double(fullRowBlocks) * double(cellCount);       // (wave, column) steps of the scan kernel
+        double steps = double(fullRowBlocks) * double(cellCount);       // (wave, column) steps of the v_xor/v_bcnt code
+        double matrixPairs = 0.0;
         for (uint32_t b = fullRowBlocks; b < rowBlocks; ++b) {
             const uint64_t end = uint64_t(b) * 64u + 64u;
-            steps += double(end < cellCount ? end : cellCount);
+            const uint64_t quadBase = matrix ? uint64_t(b & ~3u) * 64u : 0u;      // the matrix cores take the columns below the quad
+            steps += double((end < cellCount ? end : cellCount) - quadBase);
+            matrixPairs += 64.0 * double(quadBase);
         }
-        lastLaunchInfo.form = matrix ? 2 : 1;
+        float matrixMs = -1.0f;
+        if (matrix && (!timing[0] || hipEventElapsedTime(&matrixMs, timing[2], timing[1]) != hipSuccess)) matrixMs = -1.0f;
+        lastLaunchInfo.matrixPairs = matrixPairs;
+        lastLaunchInfo.matrixKernelMs = double(matrixMs);
+        lastLaunchInfo.form = matrix ? 3 : 1;
         lastLaunchInfo.scanKernelMs = double(ms);
         lastLaunchInfo.waveColumnSteps = steps;
         lastLaunchInfo.inboxEntries = double(used);

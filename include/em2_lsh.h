@@ -170,7 +170,9 @@ int em2_dev_find_similar_pairs4_form(uint32_t cellCount, uint32_t rowCount);
 /* Facts about the calling thread's last em2_dev_find_similar_pairs4 launch, for benchmarks: values[0] form (as above),
  * [1] duration in ms of the scan kernel proper when the launcher measured it with HIP events on the launch stream
  * (symmetric form, which synchronises anyway), else -1, [2] (64-row wave, column) steps executed, [3] symmetric
- * form: inbox entries sorted and replayed, [4] column segments, [5] cells whose rows scanned all columns. */
+ * form: inbox entries sorted and replayed, [4] column segments, [5] cells whose rows scanned all columns, [6] pairs
+ * contracted on the matrix cores and [7] the duration in ms of that kernel alone (form 3, the matrix-core form of the
+ * symmetric scan: FP4 +-1 contraction, 1024-bit signatures). */
 int em2_dev_find_similar_pairs4_last_launch(double* values, uint32_t valueCount);
 
 /* findSimilarPairs4 for the rows [rowBegin,rowEnd) of the cell set against all cellCount cells: the shard

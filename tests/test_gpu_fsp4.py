@@ -108,7 +108,7 @@ def scan_knobs():
     saved = {k: os.environ.get(k) for k in ("EM2_MIN_SEGMENT_COLUMNS", "EM2_LOG_CAPACITY", "EM2_SCAN_MODE",
                                              "EM2_BLOCKS_PER_CU", "EM2_FULL_ROW_CELLS", "EM2_SEGMENTS",
                                              "EM2_INBOX_CAPACITY", "EM2_SYMMETRIC_MIN_CELLS", "EM2_VIRTUAL_WORLD",
-                                             "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS")}
+                                             "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_SCAN_MATRIX")}
 
     def set_knobs(**kw):
         for key, value in kw.items():
@@ -313,4 +313,49 @@ def test_fsp4_symmetric_log_full_at_last_column_below_the_block(oracle, scan_kno
     scan_knobs(EM2_SCAN_MODE="triangle", EM2_MIN_SEGMENT_COLUMNS=257, EM2_LOG_CAPACITY=16, EM2_FULL_ROW_CELLS=200,
                EM2_BLOCKS_PER_CU=2)
     pairs, gused = capi.find_similar_pairs4(sig, L, 10, -0.5)
+    assert_same(pairs, gused, cell, sim, used)
+
+
+# ---- the matrix-core form of the symmetric scan (1024-bit signatures; EM2_SCAN_MATRIX=0 switches it off) ----
+
+def test_matrix_form_is_the_one_that_runs(oracle, scan_knobs):
+    """513..1024 bits, symmetric form, at least one quad of triangle rows: the launch reports form 3 and a non-zero
+    number of pairs contracted by v_mfma_scale_f32_32x32x64_f8f6f4; with EM2_SCAN_MATRIX=0 it is form 1 again."""
+    sig = make(3000, 1024, "clustered")
+    cell, sim, used = oracle.find_similar_pairs4(sig, 1024, 20, 0.2)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_FULL_ROW_CELLS=256)
+    pairs, gused = capi.find_similar_pairs4(sig, 1024, 20, 0.2)
+    info = capi.dev_find_similar_pairs4_last_launch()
+    assert info["form"] == 3 and info["matrix_pairs"] > 0
+    assert_same(pairs, gused, cell, sim, used)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_FULL_ROW_CELLS=256, EM2_SCAN_MATRIX=0)
+    pairs, gused = capi.find_similar_pairs4(sig, 1024, 20, 0.2)
+    assert capi.dev_find_similar_pairs4_last_launch()["form"] == 1
+    assert_same(pairs, gused, cell, sim, used)
+
+
+@pytest.mark.parametrize("n,L,k,thr,kind,knobs", [
+    (2500, 1024, 10, 0.2, "clustered", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=256)),      # no full rows: the first quad has only its band
+    (2500, 1000, 10, 0.2, "clustered", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=256)),      # padded bits count as equal
+    (2309, 600, 7, 0.0, "clustered", dict(EM2_FULL_ROW_CELLS=300, EM2_MIN_SEGMENT_COLUMNS=700)),         # cells % 256 != 0: a short last quad, an idle wave
+    (1700, 1024, 5, -1.0, "random", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=512)),         # everything passes: logs fill, the walk stops and resumes
+    (1700, 1024, 300, -0.5, "clustered", dict(EM2_FULL_ROW_CELLS=256, EM2_MIN_SEGMENT_COLUMNS=256, EM2_LOG_CAPACITY=1)),
+    (4000, 1024, 25, 0.5, "clustered", dict(EM2_FULL_ROW_CELLS=512, EM2_SEGMENTS=3, EM2_BLOCKS_PER_CU=1)),
+    (1300, 1024, 100, 0.2, "equal", dict(EM2_FULL_ROW_CELLS=256)),                                     # all cells identical: dot = 1024 everywhere
+])
+def test_matrix_form_matches_oracle(oracle, scan_knobs, n, L, k, thr, kind, knobs):
+    sig = np.tile(make(1, L, "random"), (n, 1)) if kind == "equal" else make(n, L, kind)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
+    scan_knobs(EM2_SCAN_MODE="triangle", **knobs)
+    pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    assert capi.dev_find_similar_pairs4_last_launch()["form"] == 3
+    assert_same(pairs, gused, cell, sim, used)
+
+
+def test_matrix_form_inbox_overflow_falls_back(oracle, scan_knobs):
+    sig = make(2000, 1024, "clustered")
+    cell, sim, used = oracle.find_similar_pairs4(sig, 1024, 10, -0.5)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_FULL_ROW_CELLS=0, EM2_INBOX_CAPACITY=1024)
+    pairs, gused = capi.find_similar_pairs4(sig, 1024, 10, -0.5)
+    assert capi.dev_find_similar_pairs4_last_launch()["form"] == 0          # the ordered scan ran instead
     assert_same(pairs, gused, cell, sim, used)
