@@ -268,6 +268,15 @@ def main():
     }
     if matrix:
         result["dtype"] = "fp4 e2m1 +-1 products, f32 accumulate, exact (scan on the matrix cores) / u32 popcount (band, full rows) / f64 (projection)"
+    matrix_traffic = None
+    matrix_traffic_file = os.path.join(ROOT, "profiles", "r01_pmc_matrix_scan_1Mcells.json")
+    if matrix and os.path.exists(matrix_traffic_file):
+        with open(matrix_traffic_file) as f:
+            prof = json.load(f)
+        cfg = prof.get("config", {})
+        if (cfg.get("cells"), cfg.get("genes"), cfg.get("lsh_count"), cfg.get("k"), cfg.get("n_gpus")) == (C, G, L, k, world):
+            t = prof["per_launch_bytes"]["fsp4ScanKernel"]
+            matrix_traffic = t["fetch"] + t["write"]
     if matrix and launch["matrix_kernel_ms"] > 0:
         # Dominant kernel: fsp4ScanMatrixKernel, bound by the matrix cores.  One (row, column) pair = a 1024-long dot
         # product of FP4 +-1 values = 2 * 1024 flop on v_mfma_scale_f32_32x32x64_f8f6f4; peak = the dense FP4 MFMA
@@ -285,7 +294,9 @@ def main():
             "peak": MFMA_FP4_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": tflops / MFMA_FP4_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": matrix_traffic,
+            "traffic_source": "profiles/r01_pmc_matrix_scan_1Mcells.json (FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE, bytes per launch)"
+                              if matrix_traffic is not None else None,
             "flop_per_launch": flops,
             "pairs_on_matrix_cores": launch["matrix_pairs"],
             "pairs_per_s_on_matrix_cores": launch["matrix_pairs"] / (launch["matrix_kernel_ms"] * 1e-3),
