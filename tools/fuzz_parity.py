@@ -16,7 +16,7 @@ from label_graphs import fast_graph  # noqa: E402
 from expressionmatrix2_amd import capi  # noqa: E402
 
 KNOBS = ("EM2_SCAN_MODE", "EM2_MIN_SEGMENT_COLUMNS", "EM2_LOG_CAPACITY", "EM2_FULL_ROW_CELLS", "EM2_VIRTUAL_WORLD",
-         "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_BLOCKS_PER_CU", "EM2_SEGMENTS")
+         "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_BLOCKS_PER_CU", "EM2_SEGMENTS", "EM2_SCAN_MATRIX")
 
 
 def main():
@@ -50,7 +50,7 @@ def main():
             runs["labels"] += 1
             continue
         n = int(rng.choice([1, 2, 63, 64, 65, 200, 500, 1000, 1500, 2500, 4000]))
-        L = int(rng.choice([1, 32, 64, 100, 128, 192, 256, 512, 1000, 1024, 2048, 4096]))
+        L = int(rng.choice([1, 32, 64, 100, 128, 192, 256, 512, 600, 1000, 1024, 1024, 1024, 2048, 4096]))
         k = int(rng.choice([1, 2, 5, 10, 33, 100, 300]))
         thr = float(rng.choice([-1.0, -0.5, 0.0, 0.1, 0.2, 0.5, 0.9]))
         clusters = int(rng.choice([1, 2, 5, 20]))
@@ -66,7 +66,8 @@ def main():
                      "EM2_VIRTUAL_WORLD": str(int(rng.choice([1, 2, 3, 4, 8]))),
                      "EM2_PREFIX_PERMILLE": str(int(rng.choice([50, 200, 500, 900]))),
                      "EM2_TILE_SEGMENTS": str(int(rng.choice([1, 3, 17, 256]))),
-                     "EM2_BLOCKS_PER_CU": str(int(rng.choice([1, 2, 4])))}
+                     "EM2_BLOCKS_PER_CU": str(int(rng.choice([1, 2, 4]))),
+                     "EM2_SCAN_MATRIX": str(int(rng.choice([0, 1, 1])))}
             os.environ.update(knobs)
             label.update(knobs)
             cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
