@@ -77,7 +77,7 @@ struct Fsp4ShardPlan {
     uint32_t blocks, prefixBlocks, prefixCells, ownBlocks, maxOwnBlocks, ownPrefixBlocks;
     uint64_t capLocal, capGathered;
     size_t sortTempBytes;
-    size_t offLists, offControl, offSnap, offTable, offInboxControl, offPool, rankBytes, offGathered, offSorted, offTemp, totalBytes;
+    size_t offLists, offControl, offSnap, offTable, offInboxControl, offPool, offFragments, rankBytes, offGathered, offSorted, offTemp, totalBytes;
 };
 Fsp4ShardPlan fsp4ShardPlan(uint32_t cellCount, uint32_t k, uint32_t rank, uint32_t world);
 hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint32_t* sig32, uint32_t paddedDw,

@@ -539,7 +539,9 @@ expandFragmentsKernel(const uint32_t* __restrict__ sig32, uint32_t cellCount, ui
 // The lock-step walk over the tiles [colBegin, colEnd) (multiples of 32).  Returns the first column not scanned, the
 // same in all waves of the block: the walk ends early, at a tile boundary, when some row's log could overflow in the
 // next tile.  stopWords: 3 LDS words, zero on entry and on return.
-template <bool IDENTITY>
+// BOTH (the tile kernel of the sharded scan): the row side is deferred to the inbox as well, nothing is logged and the
+// walk never stops early.
+template <bool IDENTITY, bool BOTH = false>
 __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restrict__ fragments, const int32_t* snap,
                                                     uint32_t colBegin, uint32_t colEnd, uint32_t rowFragmentBlock,
                                                     float rowDot, uint32_t row, bool rowValid, uint32_t lane,
@@ -601,7 +603,9 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
                 const uint32_t col = colBase + uint32_t(c);
                 const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
                 emitColumn(rowValid && dot >= columnDot, col, row, m, lane, emitPos, emitEnd);
-                if (dot >= rowDot) {
+                if (BOTH) {
+                    emitColumn(rowValid && dot >= rowDot, row, col, m, lane, emitPos, emitEnd);
+                } else if (dot >= rowDot) {
                     storeEntry(myLog + logCount, col, m);
                     ++logCount;
                 }
@@ -613,7 +617,7 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
             for (int j = 0; j < 4; j++) next[threadIdx.x + j * 256] = staged[j];
         }
         // a tile adds at most 32 entries to a row's log
-        const bool full = __builtin_amdgcn_ballot_w64(logCount + 32u > logCapacity) != 0ull;
+        const bool full = !BOTH && __builtin_amdgcn_ballot_w64(logCount + 32u > logCapacity) != 0ull;
         const uint32_t slot = iteration % 3u;
         if (full && lane == 0u) stopWords[slot] = 1u;
         if (threadIdx.x == 0u) stopWords[(iteration + 1u) % 3u] = 0u;
@@ -1046,6 +1050,97 @@ fsp4TileKernel(Fsp4Args args)
     }
 }
 
+// fsp4TileKernel on the matrix cores (1024-bit signatures): tiles are (segment, quad of 4 row blocks), a block of 4
+// waves walks the columns of the segment below the quad in lock step (scanTilesMatrix, both sides deferred); the
+// quad's own 256 columns are done by the v_xor/v_bcnt code.  Prefix and segment lengths are multiples of 256 cells.
+__global__ void __launch_bounds__(256, 2)
+fsp4TileMatrixKernel(Fsp4Args args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    FragmentWord4* tiles = reinterpret_cast<FragmentWord4*>(ldsRaw + kernelArgs()->matrixLdsOffset);
+    volatile uint32_t* shared = reinterpret_cast<volatile uint32_t*>(ldsRaw + kernelArgs()->matrixLdsOffset + 2u * kMatrixTileWords * 16u);
+    if (threadIdx.x < 4u) shared[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t emitPos = 0, emitEnd = 0;
+    for (;;) {
+        if (threadIdx.x == 0u) {
+            shared[3] = __hip_atomic_fetch_add(kernelArgs()->control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const uint32_t ticket = uint32_t(__builtin_amdgcn_readfirstlane(int(shared[3])));
+        __syncthreads();
+        ArgsPtr aux = kernelArgs();
+        if (ticket >= aux->totalTickets) break;
+        const uint32_t cellCount = aux->cellCount;
+        const uint32_t segments = aux->segments;
+        const uint32_t* table = aux->segTable;
+        const uint32_t tile = ticket * aux->rowBlockStride + aux->rowBlockOffset;         // round-robin over the ranks
+        uint32_t lo = 0, hi = segments;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) / 2u;
+            if (table[mid] <= tile) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t seg = lo;
+        const uint32_t quadBlock = table[segments + 1u + seg] + 4u * (tile - table[seg]);
+        const uint32_t block = quadBlock + wave;
+        const bool idle = block >= aux->rowBlocks;
+        const uint32_t fragmentBlock = idle ? aux->rowBlocks - 1u : block;
+        const uint32_t quadRowBase = quadBlock * 64u;
+        const uint32_t rowBase = block * 64u;
+        const uint32_t row = rowBase + lane;
+        const bool rowValid = !idle && row < cellCount;
+        const uint32_t colBegin = aux->columnLimit + seg * aux->columnsPerSegment;
+        uint32_t colEnd = colBegin + aux->columnsPerSegment;
+        if (colEnd > cellCount) colEnd = cellCount;
+        const bool last = quadRowBase < colEnd;
+        const uint32_t commonEnd = last ? quadRowBase : colEnd;
+        const int32_t snapRow = rowValid ? aux->snap[row] : -1;
+        if (colBegin < commonEnd) {
+            uint32_t unusedLogCount = 0;
+            scanTilesMatrix<true, true>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, colBegin, commonEnd,
+                                        2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), row, rowValid, lane, nullptr, 0u,
+                                        unusedLogCount, emitPos, emitEnd, tiles, shared);
+        }
+        if (last && !idle) {
+            uint32_t r[32];
+            const uint32_t* rp = kernelArgs()->sig32 + size_t(rowValid ? row : rowBase) * 32u;
+#pragma unroll
+            for (int w = 0; w < 32; ++w) r[w] = rp[w];
+            uint32_t at = quadRowBase;
+            while (at < rowBase) {
+                ensureInboxRoomForTile(lane, emitPos, emitEnd);
+                at = scanTileEmit<32>(kernelArgs()->sig32, kernelArgs()->snap, at, rowBase, r, row, rowValid, snapRow, lane, emitPos,
+                                      emitEnd);
+            }
+            uint32_t diagEnd = rowBase + 64u;
+            if (diagEnd > cellCount) diagEnd = cellCount;
+            const uint32_t* sig32 = kernelArgs()->sig32;
+            const int32_t* snap = kernelArgs()->snap;
+            for (uint32_t col = rowBase; col < diagEnd; ++col) {
+                ScalarPtr cp = (ScalarPtr)(uintptr_t)sig32 + size_t(col) * 32u;
+                uint32_t m = 0;
+#pragma unroll
+                for (int w = 0; w < 32; ++w) popcountAccumulate(m, r[w] ^ cp[w]);
+                const int32_t snapCol = snap[col];
+                const bool lower = rowValid && col < row;
+                emitColumn(lower && int32_t(m) <= snapCol, col, row, m, lane, emitPos, emitEnd);      // target col
+                emitColumn(lower && int32_t(m) <= snapRow, row, col, m, lane, emitPos, emitEnd);      // target row
+            }
+        }
+    }
+    {
+        const uint32_t p = uint32_t(__builtin_amdgcn_readfirstlane(int(emitPos)));
+        const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(emitEnd)));
+        if (p <= e) {
+            uint64_t* inbox = kernelArgs()->inbox;
+            for (uint32_t i = p + lane; i < e; i += 64u) inbox[i] = ~0ull;
+        }
+    }
+}
+
 // max over `count` arrays of `n` int32 laid out back to back (the emulation's stand-in for all_reduce(MAX))
 __global__ void maxReduceKernel(int32_t* __restrict__ arrays, uint32_t n, uint32_t count)
 {
@@ -1446,6 +1541,15 @@ Fsp4ShardPlan fsp4ShardPlan(uint32_t cellCount, uint32_t k, uint32_t rank, uint3
     uint64_t prefixBlocks = (uint64_t(p.blocks) * envNumber("EM2_PREFIX_PERMILLE", 200) / 1000u + world / 2u) / world * world;
     if (prefixBlocks < world) prefixBlocks = world;
     if (prefixBlocks > uint64_t(p.blocks) - world) prefixBlocks = (uint64_t(p.blocks) - world) / world * world;
+    {
+        // a multiple of 4 blocks (256 cells) as well where that fits: the matrix-core tile kernel wants it
+        uint64_t unit = world;
+        while (unit % 4u) unit += world;
+        uint64_t rounded = (prefixBlocks + unit / 2u) / unit * unit;
+        if (rounded < unit) rounded = unit;
+        while (rounded > unit && rounded > uint64_t(p.blocks) - world) rounded -= unit;
+        if (rounded <= uint64_t(p.blocks) - world) prefixBlocks = rounded;
+    }
     p.prefixBlocks = uint32_t(prefixBlocks);
     p.prefixCells = p.prefixBlocks * 64u;
     p.ownBlocks = (p.blocks - rank + world - 1u) / world;
@@ -1461,6 +1565,7 @@ Fsp4ShardPlan fsp4ShardPlan(uint32_t cellCount, uint32_t k, uint32_t rank, uint3
     p.offTable = at;        at += align256((2u * 256u + 2u) * 4u);
     p.offInboxControl = at; at += 256u;
     p.offPool = at;         at += align256(size_t(p.capLocal) * 8u);
+    p.offFragments = at;    at += align256(size_t(p.blocks) * 64u * 512u);      // FP4 fragments (matrix-core tile kernel)
     p.rankBytes = at;
     p.offGathered = at;     at += align256(size_t(p.capGathered) * 8u);
     p.offSorted = at;       at += align256(size_t(p.capGathered) * 8u);
@@ -1563,6 +1668,8 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
 
     hipError_t e = hipSuccess;
     if (phase == 0) {
+        lastLaunchInfo.matrixPairs = 0.0;
+        lastLaunchInfo.matrixKernelMs = -1.0;
         lastLaunchInfo.form = 2;
         lastLaunchInfo.scanKernelMs = -1.0;
         lastLaunchInfo.waveColumnSteps = 0.0;
@@ -1624,13 +1731,16 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
     if (phase == 2) {
         const void* kernel = tileKernelFor(paddedDw);
         if (!kernel) return hipErrorInvalidValue;
+        // 1024-bit signatures and a prefix of whole quads: the tiles go to the matrix cores (EM2_SCAN_MATRIX=0: never)
+        const bool matrix = paddedDw == 32u && M % 256u == 0u && envNumber("EM2_SCAN_MATRIX", 1) != 0;
         const uint32_t span = cellCount - M;
-        uint64_t segments = span / 1024u;
+        uint64_t segments = span / (matrix ? 4096u : 1024u);
         if (segments > 256) segments = 256;
         const uint64_t forced = envNumber("EM2_TILE_SEGMENTS", 0);
         if (forced >= 1 && forced <= 256) segments = forced;
         if (segments < 1) segments = 1;
-        const uint32_t cps = uint32_t((uint64_t(span) + segments - 1u) / segments);
+        uint32_t cps = uint32_t((uint64_t(span) + segments - 1u) / segments);
+        if (matrix) cps = (cps + 255u) & ~255u;
         segments = (uint64_t(span) + cps - 1u) / cps;
         uint32_t table[2u * 256u + 2u];
         uint64_t tiles = 0;
@@ -1638,19 +1748,22 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             const uint32_t firstBlock = (M + sIdx * cps) / 64u;
             table[sIdx] = uint32_t(tiles);
             table[segments + 1u + sIdx] = firstBlock;
-            tiles += plan.blocks - firstBlock;
+            tiles += matrix ? (plan.blocks - firstBlock + 3u) / 4u : plan.blocks - firstBlock;
             if (tiles >= 0xffffffffull) return hipErrorInvalidValue;
         }
         table[segments] = uint32_t(tiles);
         const uint64_t own = tiles > plan.rank ? (tiles - plan.rank + plan.world - 1u) / plan.world : 0u;
         if (own == 0) return hipSuccess;
         {
-            double steps = 0.0;         // this rank's share of the tiles' (wave, column) steps
+            double steps = 0.0, matrixPairs = 0.0;      // this rank's share of the tiles' work
             for (uint32_t b = plan.prefixBlocks; b < plan.blocks; ++b) {
                 const uint64_t end = uint64_t(b) * 64u + 64u;
-                steps += double((end < cellCount ? end : cellCount) - M);
+                const uint64_t from = matrix ? uint64_t(b & ~3u) * 64u : M;     // v_xor/v_bcnt: the quad's own columns only
+                steps += double((end < cellCount ? end : cellCount) - from);
+                matrixPairs += 64.0 * double(from - M);
             }
             lastLaunchInfo.waveColumnSteps += steps / double(plan.world);
+            lastLaunchInfo.matrixPairs += matrixPairs / double(plan.world);
         }
         args.segments = uint32_t(segments);
         args.columnsPerSegment = cps;
@@ -1665,6 +1778,21 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
         if (e != hipSuccess) return e;
         e = hipDeviceGetAttribute(&cuCount, hipDeviceAttributeMultiprocessorCount, device);
         if (e != hipSuccess) return e;
+        if (matrix) {
+            const uint32_t fragmentCount = plan.blocks * 2u * kMatrixSteps * 64u;
+            expandFragmentsKernel<<<dim3((fragmentCount + 255u) / 256u), dim3(256), 0, stream>>>(
+                sig32, cellCount, fragmentCount, reinterpret_cast<FragmentWord4*>(ws + plan.offFragments));
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            args.fragments = ws + plan.offFragments;
+            args.matrixLdsOffset = 0;
+            const size_t matrixLds = 2u * kMatrixTileWords * 16u + 64u;
+            uint64_t blocksWanted = uint64_t(cuCount) * 2u;
+            if (blocksWanted > own) blocksWanted = own;
+            void* matrixArgsArray[] = {&args};
+            return hipLaunchKernel(reinterpret_cast<const void*>(&fsp4TileMatrixKernel), dim3(uint32_t(blocksWanted)), dim3(256),
+                                   matrixArgsArray, matrixLds, stream);
+        }
         uint64_t wavesWanted = own;
         const uint64_t resident = uint64_t(cuCount) * 16u;
         if (wavesWanted > resident) wavesWanted = resident;

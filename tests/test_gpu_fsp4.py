@@ -359,3 +359,18 @@ def test_matrix_form_inbox_overflow_falls_back(oracle, scan_knobs):
     pairs, gused = capi.find_similar_pairs4(sig, 1024, 10, -0.5)
     assert capi.dev_find_similar_pairs4_last_launch()["form"] == 0          # the ordered scan ran instead
     assert_same(pairs, gused, cell, sim, used)
+
+
+@pytest.mark.parametrize("world,n,permille", [(2, 6000, 200), (4, 9000, 300), (3, 7000, 250), (8, 9000, 100)])
+def test_sharded_virtual_world_tiles_on_the_matrix_cores(oracle, scan_knobs, world, n, permille):
+    """The tile phase of the sharded scan with 1024-bit signatures: prefixes of whole quads, fsp4TileMatrixKernel; the
+    same run with EM2_SCAN_MATRIX=0 gives the same bytes."""
+    sig = make(n, 1024, "clustered")
+    cell, sim, used = oracle.find_similar_pairs4(sig, 1024, 20, 0.2)
+    for matrix in (1, 0):
+        scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=world, EM2_PREFIX_PERMILLE=permille, EM2_TILE_SEGMENTS=3,
+                   EM2_SCAN_MATRIX=matrix)
+        pairs, gused = capi.find_similar_pairs4(sig, 1024, 20, 0.2)
+        info = capi.dev_find_similar_pairs4_last_launch()
+        assert info["form"] == 2 and (info["matrix_pairs"] > 0) == bool(matrix)
+        assert_same(pairs, gused, cell, sim, used)
