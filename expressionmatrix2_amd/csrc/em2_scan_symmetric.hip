@@ -664,12 +664,15 @@ fsp4ScanMatrixKernel(Fsp4Args args)
         const uint32_t* table = aux->segTable;
         uint32_t seg = 0;
         while (ticket >= table[seg + 1u]) ++seg;
+        // block = list / state slot of the launch; its 64 cells start at (block * stride + offset) * 64 (block-cyclic in
+        // the sharded scan, where a quad is 4 slots whose cells are not adjacent -- but there every column lies below them)
         const uint32_t quadBlock = table[segments + 1u + seg] + 4u * (ticket - table[seg]);
         const uint32_t block = quadBlock + wave;
         const bool idle = block >= aux->rowBlocks;              // the last quad may be short
         const uint32_t listBlock = idle ? aux->rowBlocks - 1u : block;
-        const uint32_t quadRowBase = quadBlock * 64u;
-        const uint32_t rowBase = block * 64u;
+        const uint32_t quadRowBase = (quadBlock * aux->rowBlockStride + aux->rowBlockOffset) * 64u;
+        const uint32_t rowBase = (block * aux->rowBlockStride + aux->rowBlockOffset) * 64u;
+        const uint32_t rowFragmentBlock = 2u * (listBlock * aux->rowBlockStride + aux->rowBlockOffset);
         const uint32_t row = rowBase + lane;
         const bool rowValid = !idle && row < aux->cellCount;
         const uint32_t twoK = 2u * aux->k;
@@ -706,7 +709,7 @@ fsp4ScanMatrixKernel(Fsp4Args args)
         for (;;) {
             if (at < commonEnd) {
                 at = scanTilesMatrix<IDENTITY>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, at, commonEnd,
-                                               2u * listBlock, kMatrixBits - 2.f * float(mMax), row, rowValid, lane, myLog,
+                                               rowFragmentBlock, kMatrixBits - 2.f * float(mMax), row, rowValid, lane, myLog,
                                                logCapacity, logCount, emitPos, emitEnd, tiles, shared);
             }
             if (!haveState && !idle && !failed) {
@@ -1687,6 +1690,61 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
         const uint32_t slotBase = phase == 0 ? 0u : plan.ownPrefixBlocks;
         const uint32_t slotCount = phase == 0 ? plan.ownPrefixBlocks : plan.ownBlocks - plan.ownPrefixBlocks;
         if (slotCount == 0) return hipSuccess;
+        const size_t matrixLdsOffset = (lds + 15u) & ~size_t(15);
+        const size_t matrixLds = matrixLdsOffset + 2u * kMatrixTileWords * 16u + 64u;
+        if (phase == 1 && paddedDw == 32u && wavesPerBlock == 4u && M % 256u == 0u && matrixLds <= 64u * 1024u &&
+            envNumber("EM2_SCAN_MATRIX", 1) != 0) {
+            // the rows beyond the prefix against the prefix columns: all of it below the rows, so all of it for the matrix
+            // cores (fsp4ScanMatrixKernel over quads of slots; no quad ever reaches its own columns here)
+            uint64_t segments = M / 4096u;
+            if (segments > kMatrixMaxSegments) segments = kMatrixMaxSegments;
+            if (segments < 1) segments = 1;
+            uint32_t cps = uint32_t((uint64_t(M) + segments - 1u) / segments);
+            cps = (cps + 255u) & ~255u;
+            segments = (uint64_t(M) + cps - 1u) / cps;
+            const uint32_t quads = (slotCount + 3u) / 4u;
+            uint32_t table[kTableWords];
+            for (uint32_t sIdx = 0; sIdx < segments; ++sIdx) {
+                table[sIdx] = sIdx * quads;
+                table[segments + 1u + sIdx] = slotBase;
+            }
+            const uint64_t tickets = segments * quads;
+            if (tickets >= 0xffffffffull) return hipErrorInvalidValue;
+            table[segments] = uint32_t(tickets);
+            args.segments = uint32_t(segments);
+            args.columnsPerSegment = cps;
+            args.localBlockBase = slotBase;
+            args.rowBlocks = slotBase + slotCount;
+            args.fullRowBlocks = 0u;
+            args.totalTickets = uint32_t(tickets);
+            e = hipMemsetAsync(c + stateBytes, 0, doneBytes + 4u, stream);
+            if (e != hipSuccess) return e;
+            e = hipMemcpyAsync(ws + plan.offTable, table, (2u * segments + 2u) * 4u, hipMemcpyHostToDevice, stream);
+            if (e != hipSuccess) return e;
+            const uint32_t fragmentCount = plan.blocks * 2u * kMatrixSteps * 64u;
+            expandFragmentsKernel<<<dim3((fragmentCount + 255u) / 256u), dim3(256), 0, stream>>>(
+                sig32, cellCount, fragmentCount, reinterpret_cast<FragmentWord4*>(ws + plan.offFragments));
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            args.fragments = ws + plan.offFragments;
+            args.matrixLdsOffset = uint32_t(matrixLdsOffset);
+            lastLaunchInfo.matrixPairs += double(slotCount) * 64.0 * double(M);
+            const void* matrixKernel = t.identityKeys ? reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<true>)
+                                                      : reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<false>);
+            int device = 0, cuCount = 0;
+            e = hipGetDevice(&device);
+            if (e != hipSuccess) return e;
+            e = hipDeviceGetAttribute(&cuCount, hipDeviceAttributeMultiprocessorCount, device);
+            if (e != hipSuccess) return e;
+            uint64_t blocksWanted = uint64_t(cuCount) * 2u;
+            if (const char* v = getenv("EM2_BLOCKS_PER_CU")) {
+                if (atoi(v) == 1) blocksWanted = uint64_t(cuCount);
+            }
+            if (blocksWanted * 4u > maxResidentWaves()) blocksWanted = maxResidentWaves() / 4u;
+            if (blocksWanted > tickets) blocksWanted = tickets;
+            void* matrixArgsArray[] = {&args};
+            return hipLaunchKernel(matrixKernel, dim3(uint32_t(blocksWanted)), dim3(256), matrixArgsArray, matrixLds, stream);
+        }
         const void* kernel = symmetricKernelFor(paddedDw, t.identityKeys);
         if (!kernel) return hipErrorInvalidValue;
         uint32_t slots = 0;
