@@ -310,6 +310,30 @@ def main():
                     "scan_launches_ms, kept for comparison with earlier rounds (operands are cache resident, so it is not "
                     "bounded by 1)",
         }
+    elif sharded_symmetric and launch["matrix_pairs"] > 0 and scan_ms > 0:
+        # Sharded scan with phases 1 and 2 on the matrix cores: this rank's share of the FP4 contraction over the whole
+        # scan time of the rank (phases 0..3 and the collectives between them; no per-kernel events here).
+        flops = launch["matrix_pairs"] * 2.0 * 1024.0
+        tflops = flops / (scan_ms * 1e-3) / 1e12
+        result["dtype"] = "fp4 e2m1 +-1 products, f32 accumulate, exact (phases 1-2 on the matrix cores) / u32 popcount (phase 0, bands) / f64 (projection)"
+        result["roofline"] = {
+            "kernel": "fsp4ScanMatrixKernel<true> + fsp4TileMatrixKernel (rank 0)",
+            "kernel_ms": scan_ms,
+            "form": "sharded symmetric, phases 1 and 2 on the matrix cores: every unordered pair evaluated once across the ranks; "
+                    "2 all_reduce + the entry exchange are inside kernel_ms",
+            "bound": "mfma",
+            "achieved": tflops,
+            "peak": MFMA_FP4_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": tflops / MFMA_FP4_PEAK_TFLOPS,
+            "traffic": None,
+            "flop_per_launch": flops,
+            "pairs_on_matrix_cores": launch["matrix_pairs"],
+            "inbox_entries": launch["inbox_entries"],
+            "hbm_view": {key: hbm_roofline[key] for key in ("achieved", "peak", "unit", "frac", "algorithmic_bytes")},
+            "note": "per rank: flop = 2 * 1024 per (row, column) pair of this rank's share of phases 1 and 2; kernel_ms is the whole "
+                    "scan of the rank including the collectives, so frac understates the kernels",
+        }
     else:
         result["roofline"] = hbm_roofline
     result["parity_check"] = check
