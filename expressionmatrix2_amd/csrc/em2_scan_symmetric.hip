@@ -536,6 +536,25 @@ expandFragmentsKernel(const uint32_t* __restrict__ sig32, uint32_t cellCount, ui
     out[i] = v;
 }
 
+// emitColumn for the walk below: the pool pointer and the key layout arrive in registers (emitColumn re-reads them
+// from the kernarg segment on purpose, which costs the matrix kernel a scalar-load round trip per event); only a chunk
+// that is used up goes through the out-of-line path.
+__device__ __forceinline__ void emitColumnFast(bool emit, uint32_t target, uint32_t candidate, uint32_t m, uint32_t lane,
+                                               uint32_t& emitPos, uint32_t& emitEnd, uint64_t* inbox, uint32_t rowBits)
+{
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(emit);
+    if (mask == 0ull) return;
+    const uint32_t p = uint32_t(__builtin_amdgcn_readfirstlane(int(emitPos)));
+    const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(emitEnd)));
+    const uint32_t n = uint32_t(__builtin_popcountll(mask));
+    if (p > e || p + n > e) {
+        emitColumn(emit, target, candidate, m, lane, emitPos, emitEnd);      // disabled after an overflow, or a new chunk
+        return;
+    }
+    if (emit) inbox[p + lanesBelow(mask)] = (uint64_t(target) << (13u + rowBits)) | (uint64_t(candidate) << 13u) | uint64_t(m);
+    emitPos = p + n;
+}
+
 // The lock-step walk over the tiles [colBegin, colEnd) (multiples of 32).  Returns the first column not scanned, the
 // same in all waves of the block: the walk ends early, at a tile boundary, when some row's log could overflow in the
 // next tile.  stopWords: 3 LDS words, zero on entry and on return.
@@ -550,6 +569,8 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
                                                     volatile uint32_t* stopWords)
 {
     const int scale = 0x7f7f7f7f;                // E8M0 127 = 2^0 in every byte
+    uint64_t* const inbox = kernelArgs()->inbox;
+    const uint32_t rowBits = kernelArgs()->rowBits;
     FragmentWord4 rows[2][kMatrixSteps];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -558,35 +579,52 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
             rows[t][s] = fragments[(size_t(rowFragmentBlock + uint32_t(t)) * kMatrixSteps + uint32_t(s)) * 64u + lane];
         }
     }
-    {
-        const FragmentWord4* src = fragments + size_t(colBegin / 32u) * kMatrixTileWords;
-#pragma unroll
-        for (int j = 0; j < 4; j++) tiles[threadIdx.x + j * 256] = src[threadIdx.x + j * 256];
-    }
+    // A tile travels global -> LDS without touching registers (global_load_lds_dwordx4: the LDS address is the wave's
+    // base + lane * 16, which is exactly the fragment order), one tile ahead of the MFMAs.
+    const uint32_t waveSlot = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))) * 64u;
+#define EM2_STAGE_TILE(tileIndex, buffer)                                                                                     \
+    do {                                                                                                                      \
+        const FragmentWord4* src_ = fragments + size_t(tileIndex) * kMatrixTileWords + threadIdx.x;                          \
+        FragmentWord4* dst_ = tiles + (buffer) * kMatrixTileWords + waveSlot;                                                \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) {                                                                   \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + j_ * 256),              \
+                                             (__attribute__((address_space(3))) void*)(dst_ + j_ * 256), 16, 0, 0);          \
+        }                                                                                                                     \
+    } while (0)
+    EM2_STAGE_TILE(colBegin / 32u, 0u);
     __syncthreads();
     uint32_t iteration = 0;
+    // The bound of column (lane & 31), fetched one tile ahead like the fragments (the compiler sinks a load placed in
+    // front of the MFMAs to its first use behind them, and the wave then sits out a global-load latency per tile).  Any
+    // value a cell published earlier is valid: bounds only tighten.
+    int32_t snapAhead = snap[colBegin + (lane & 31u)];
     for (uint32_t colBase = colBegin; colBase < colEnd; colBase += 32u, ++iteration) {
         const uint32_t cur = iteration & 1u;
         const bool more = colBase + 32u < colEnd;
-        FragmentWord4 staged[4];
+        const int32_t snapLane = snapAhead;
         if (more) {
-            const FragmentWord4* src = fragments + size_t(colBase / 32u + 1u) * kMatrixTileWords;
-#pragma unroll
-            for (int j = 0; j < 4; j++) staged[j] = src[threadIdx.x + j * 256];
+            EM2_STAGE_TILE(colBase / 32u + 1u, cur ^ 1u);
+            snapAhead = snap[colBase + 32u + (lane & 31u)];
         }
-        // bound of column (lane & 31) as a dot product: any value a cell published earlier is valid (they only tighten)
-        const float columnDotLane = kMatrixBits - 2.f * float(snap[colBase + (lane & 31u)]);
+        const float columnDotLane = kMatrixBits - 2.f * float(snapLane);
         Accumulator16 acc0 = {}, acc1 = {};
         const FragmentWord4* tile = tiles + cur * kMatrixTileWords;
+        // column fragments four k-steps ahead of their MFMAs (the LDS latency of a read is two MFMA pairs long)
+        FragmentWord4 ahead[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) ahead[s] = tile[s * 64 + int(lane)];
+        __builtin_amdgcn_s_setprio(2);          // the SIMD's other wave is in its column tests: MFMAs first
 #pragma unroll
         for (int s = 0; s < int(kMatrixSteps); s++) {
-            const FragmentWord4 a = tile[s * 64 + int(lane)];
+            const FragmentWord4 a = ahead[s & 3];
+            if (s + 4 < int(kMatrixSteps)) ahead[s & 3] = tile[(s + 4) * 64 + int(lane)];
             const FragmentWord8 a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
             const FragmentWord8 b0 = {rows[0][s].x, rows[0][s].y, rows[0][s].z, rows[0][s].w, 0, 0, 0, 0};
             const FragmentWord8 b1 = {rows[1][s].x, rows[1][s].y, rows[1][s].z, rows[1][s].w, 0, 0, 0, 0};
             acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, acc0, 4, 4, 0, scale, 0, scale);
             acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, acc1, 4, 4, 0, scale, 0, scale);
         }
+        __builtin_amdgcn_s_setprio(0);
         // lane = row: acc0[i] <- column (i&3) + 8*(i>>2), acc1[i] <- that + 4
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -599,22 +637,18 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
             const int g = c >> 3, w = c & 7;
             const float dot = w < 4 ? acc0[4 * g + w] : acc1[4 * g + w - 4];
             const float columnDot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(columnDotLane), c));
-            if (__builtin_amdgcn_ballot_w64(dot >= fminf(rowDot, columnDot)) != 0ull) {
+            // min(rowDot, columnDot) as one v_med3_f32 (fminf would canonicalise both inputs first)
+            if (__builtin_amdgcn_ballot_w64(dot >= __builtin_amdgcn_fmed3f(rowDot, columnDot, -INFINITY)) != 0ull) {
                 const uint32_t col = colBase + uint32_t(c);
                 const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
-                emitColumn(rowValid && dot >= columnDot, col, row, m, lane, emitPos, emitEnd);
+                emitColumnFast(rowValid && dot >= columnDot, col, row, m, lane, emitPos, emitEnd, inbox, rowBits);
                 if (BOTH) {
-                    emitColumn(rowValid && dot >= rowDot, row, col, m, lane, emitPos, emitEnd);
+                    emitColumnFast(rowValid && dot >= rowDot, row, col, m, lane, emitPos, emitEnd, inbox, rowBits);
                 } else if (dot >= rowDot) {
                     storeEntry(myLog + logCount, col, m);
                     ++logCount;
                 }
             }
-        }
-        if (more) {
-            FragmentWord4* next = tiles + (cur ^ 1u) * kMatrixTileWords;
-#pragma unroll
-            for (int j = 0; j < 4; j++) next[threadIdx.x + j * 256] = staged[j];
         }
         // a tile adds at most 32 entries to a row's log
         const bool full = !BOTH && __builtin_amdgcn_ballot_w64(logCount + 32u > logCapacity) != 0ull;
@@ -629,6 +663,7 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
             return colBase + 32u;
         }
     }
+#undef EM2_STAGE_TILE
     return colEnd;
 }
 
