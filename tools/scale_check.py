@@ -149,11 +149,12 @@ def main():
                 times.append(time.perf_counter() - t0)
             ok = all(compare(d_pairs, d_used, c, s_, u, slice(b, b + 24)) for b, (c, s_, u) in zip(sample, expected))
             print(json.dumps({"check": "sweep", "cells": cells, "lsh_count": L, "knobs": knobs, "ms": [round(t * 1e3, 2) for t in times],
-                              "unordered_pairs_per_s": cells * (cells - 1) / 2 / min(times), "sampled_rows_bit_exact": ok}), flush=True)
+                              "unordered_pairs_per_s": cells * (cells - 1) / 2 / min(times), "sampled_rows_bit_exact": ok,
+                              "last_launch": capi.dev_find_similar_pairs4_last_launch()}), flush=True)
             del ws
             for key in knobs:
                 os.environ.pop(key, None)
-            if not ok:
+            if not ok and not os.environ.get("IGNORE_PARITY"):
                 raise SystemExit("PARITY FAILURE")
 
 
