@@ -70,6 +70,7 @@ SYMBOLS = {
                                                     _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_void_p,
                                                     _c.c_void_p]),
     "em2_dev_find_similar_pairs4_form": (_c.c_int, [_c.c_uint32, _c.c_uint32]),
+    "em2_dev_find_similar_pairs4_form_for": (_c.c_int, [_c.c_uint32, _c.c_uint32, _c.c_uint32]),
     "em2_dev_find_similar_pairs4_last_launch": (_c.c_int, [_c.c_void_p, _c.c_uint32]),
     "em2_dev_fsp4_sharded_plan": (_c.c_int, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                              _c.c_void_p, _c.c_uint32]),

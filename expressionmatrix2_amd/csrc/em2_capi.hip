@@ -321,14 +321,23 @@ size_t em2_dev_find_similar_pairs4_workspace(uint32_t cellCount, uint32_t rowCou
     size_t bytes = alignUp(size_t(rowCount) * 2u * k * sizeof(em2::Entry));
     if (padded != 2u * wordCountOf(lshCount)) bytes += alignUp(size_t(cellCount) * padded * sizeof(uint32_t));
     bytes += alignUp(em2::fsp4ControlBytes(rowCount));
-    bytes += alignUp(em2::fsp4SymmetricBytes(cellCount, rowCount));
+    bytes += alignUp(em2::fsp4SymmetricBytes(cellCount, rowCount, padded));
     return bytes + 256;
 }
 
 
 int em2_dev_find_similar_pairs4_form(uint32_t cellCount, uint32_t rowCount)
 {
-    return em2::fsp4UsesSymmetricScan(cellCount, rowCount) ? 1 : 0;
+    return em2::fsp4UsesSymmetricScan(cellCount, rowCount, 0) ? 1 : 0;
+}
+
+
+int em2_dev_find_similar_pairs4_form_for(uint32_t cellCount, uint32_t rowCount, uint32_t lshCount)
+{
+    if (lshCount == 0) return 0;
+    const uint32_t padded = em2::paddedDwords(lshCount);
+    if (!em2::fsp4UsesSymmetricScan(cellCount, rowCount, padded)) return 0;
+    return padded == 32u && !(getenv("EM2_SCAN_MATRIX") && getenv("EM2_SCAN_MATRIX")[0] == '0') ? 3 : 1;
 }
 
 
@@ -380,7 +389,7 @@ int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount
         sig32 = repacked;
         ws += alignUp(size_t(cellCount) * padded * sizeof(uint32_t));
     }
-    void* symmetricWs = em2::fsp4SymmetricBytes(cellCount, rows) ? ws : nullptr;
+    void* symmetricWs = em2::fsp4SymmetricBytes(cellCount, rows, padded) ? ws : nullptr;
     EM2_HIP(em2::launchFsp4Scan(sig32, padded, cellCount, rowBegin, rowEnd, k, tables, buffers,
                                 reinterpret_cast<em2::PairOut*>(d_pairs), d_usedCount, control, s, symmetricWs));
     return EM2_OK;

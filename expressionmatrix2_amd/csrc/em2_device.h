@@ -54,8 +54,8 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
 size_t fsp4ControlBytes(uint32_t rowCount);
 // Extra scratch for the symmetric (each unordered pair once) form of the scan, which launchFsp4Scan uses when all
 // rows of the problem are in one launch and this workspace is given; 0 when that form would not be used.
-size_t fsp4SymmetricBytes(uint32_t cellCount, uint32_t rowCount);
-bool fsp4UsesSymmetricScan(uint32_t cellCount, uint32_t rowCount);
+size_t fsp4SymmetricBytes(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw);
+bool fsp4UsesSymmetricScan(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw);
 struct Fsp4LaunchInfo {
     int form;                 // 0 ordered rows x columns, 1 symmetric, 2 sharded symmetric, 3 symmetric on the matrix cores
     double scanKernelMs;      // duration of the scan kernel proper when the launcher measured it (symmetric form), else -1

@@ -454,7 +454,7 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
         }
     }
 
-    if (control && symmetricWs && rowBegin == 0 && symmetricEligible(cellCount, rows)) {
+    if (control && symmetricWs && rowBegin == 0 && symmetricEligible(cellCount, rows, paddedDw)) {
         bool done = false;
         const hipError_t es = launchFsp4ScanSymmetric(args, paddedDw, identity, wavesPerBlock,
                                                       size_t(wavesPerBlock) * bytesPerWave, control, symmetricWs, stream, &done);

@@ -329,7 +329,7 @@ inline uint64_t envNumber(const char* name, uint64_t fallback)
 extern thread_local Fsp4LaunchInfo lastLaunchInfo;
 
 // em2_scan_symmetric.hip
-bool symmetricEligible(uint32_t cellCount, uint32_t rowCount);
+bool symmetricEligible(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw);
 hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identity, uint32_t wavesPerBlock, size_t lds,
                                    void* control, void* symmetricWs, hipStream_t stream, bool* done);
 hipError_t runFsp4ShardedEmulation(const uint32_t* sig32, uint32_t paddedDw, uint32_t cellCount, uint32_t k,

@@ -1196,19 +1196,23 @@ __global__ void maxReduceKernel(int32_t* __restrict__ arrays, uint32_t n, uint32
 // EM2_SCAN_MODE=triangle forces it wherever it is possible (all rows of the problem in one launch),
 // EM2_SCAN_MODE=persistent / simple disable it; by default it is used from kSymmetricMinCells cells on.
 constexpr uint32_t kSymmetricMinCells = 131072;
+constexpr uint32_t kSymmetricMatrixMinCells = 32768;
 constexpr uint32_t kMaxSegments = 64;
 constexpr uint32_t kMatrixMaxSegments = 256;     // matrix form: 4096-column segments are 2 MB of fragments, what an XCD's L2 holds
 constexpr uint32_t kTableWords = 2u * kMatrixMaxSegments + 2u;
 constexpr uint32_t kInboxChunk = 512;
 
-bool symmetricEligible(uint32_t cellCount, uint32_t rowCount)
+bool symmetricEligible(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
 {
     // inbox keys hold two cell ids and a mismatch count in 64 bits: 13 + 2 * bits(cellCount) <= 64
     if (rowCount != cellCount || cellCount < 128u || cellCount > (1u << 25)) return false;
     const char* v = getenv("EM2_SCAN_MODE");
     if (v && v[0] == 't') return true;
     if (v && (v[0] == 's' || v[0] == 'p')) return false;
-    return cellCount >= envNumber("EM2_SYMMETRIC_MIN_CELLS", kSymmetricMinCells);
+    // 1024-bit signatures take the matrix-core form, which wins much earlier (scan ms ordered / symmetric-matrix:
+    // 30k cells 2.5 / 2.4, 60k 8.2 / 4.2, 100k 20.1 / 7.5)
+    const bool matrix = paddedDw == 32u && envNumber("EM2_SCAN_MATRIX", 1) != 0;
+    return cellCount >= envNumber("EM2_SYMMETRIC_MIN_CELLS", matrix ? kSymmetricMatrixMinCells : kSymmetricMinCells);
 }
 
 static uint64_t inboxCapacity(uint32_t cellCount)
@@ -1254,14 +1258,14 @@ static SymmetricLayout symmetricLayout(uint32_t cellCount)
     return l;
 }
 
-bool fsp4UsesSymmetricScan(uint32_t cellCount, uint32_t rowCount)
+bool fsp4UsesSymmetricScan(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
 {
-    return symmetricEligible(cellCount, rowCount);
+    return symmetricEligible(cellCount, rowCount, paddedDw);
 }
 
-size_t fsp4SymmetricBytes(uint32_t cellCount, uint32_t rowCount)
+size_t fsp4SymmetricBytes(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
 {
-    if (!symmetricEligible(cellCount, rowCount)) return 0;
+    if (!symmetricEligible(cellCount, rowCount, paddedDw)) return 0;
     return symmetricLayout(cellCount).total;
 }
 

@@ -167,6 +167,11 @@ int em2_dev_subset_fill(const uint64_t* d_globalToc, const em2_count* d_globalDa
  * evaluated once, as in the reference's own loop (src/ExpressionMatrixLsh.cpp:218-263), and offered to both cells. */
 int em2_dev_find_similar_pairs4_form(uint32_t cellCount, uint32_t rowCount);
 
+/* The same question with the signature width: for 513..1024 bits the symmetric form contracts its pairs as FP4 +-1
+ * dot products on the matrix cores (3; 1024 - 2 * mismatches, exact in f32) and starts at 32768 cells instead of 131072.
+ * The last_launch query below reports what actually ran. */
+int em2_dev_find_similar_pairs4_form_for(uint32_t cellCount, uint32_t rowCount, uint32_t lshCount);
+
 /* Facts about the calling thread's last em2_dev_find_similar_pairs4 launch, for benchmarks: values[0] form (as above),
  * [1] duration in ms of the scan kernel proper when the launcher measured it with HIP events on the launch stream
  * (symmetric form, which synchronises anyway), else -1, [2] (64-row wave, column) steps executed, [3] symmetric
