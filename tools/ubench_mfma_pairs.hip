@@ -255,6 +255,92 @@ mfmaRowLaneKernel(const v4i* __restrict__ fragments, uint32_t cells, const float
     atomicAdd(result + 1, sum);
 }
 
+// ---- the same loop with the tiles three deep in LDS ----
+// global_load_lds_dwordx4 into a ring of three buffers, two tiles ahead; the end of an iteration waits with a counted
+// s_waitcnt vmcnt for the tile it needs next and passes a bare s_barrier, so the loads of the tile after that stay in
+// flight (a __syncthreads() would drain them).  Column bounds travel the same way.  The three buffers are three
+// distinct __shared__ objects and the loop is unrolled by three, so that the compiler can see that an LDS read of one
+// buffer does not depend on the LDS-DMA into another (it waits vmcnt(0) before any LDS read that may alias one).
+#define RING_STAGE(tileIndex, tileBuffer, boundBuffer)                                                                    \
+    do {                                                                                                                  \
+        const v4i* src_ = fragments + size_t(tileIndex) * kSteps * 64u + threadIdx.x;                                    \
+        v4i* dst_ = &tileBuffer[0] + waveSlot;                                                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) {                                                               \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + j_ * 256),          \
+                                             (__attribute__((address_space(3))) void*)(dst_ + j_ * 256), 16, 0, 0);      \
+        }                                                                                                                 \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(minDot + (tileIndex) * 32u + (lane & 31u)), \
+                                         (__attribute__((address_space(3))) void*)(&boundBuffer[0] + waveSlot), 4, 0, 0); \
+    } while (0)
+#define RING_BODY(cb, curTile, curBounds, nextTile, nextBounds)                                                           \
+    do {                                                                                                                  \
+        const bool more2_ = (cb) + 2u < columnBlocks;                                                                     \
+        if (more2_) RING_STAGE((cb) + 2u, nextTile, nextBounds);                                                          \
+        const float columnBoundLane = curBounds[wave * 64u + lane];                                                       \
+        v16f acc0 = {}, acc1 = {};                                                                                        \
+        _Pragma("unroll") for (int s = 0; s < kSteps; s++) {                                                             \
+            const v4i a = curTile[s * 64 + lane];                                                                         \
+            const v8i a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};                                                              \
+            const v8i b0 = {rows[0][s].x, rows[0][s].y, rows[0][s].z, rows[0][s].w, 0, 0, 0, 0};                          \
+            const v8i b1 = {rows[1][s].x, rows[1][s].y, rows[1][s].z, rows[1][s].w, 0, 0, 0, 0};                          \
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, acc0, 4, 4, 0, scale, 0, scale);               \
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, acc1, 4, 4, 0, scale, 0, scale);               \
+        }                                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 16; i++) {                                                                 \
+            const auto swapped = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[i]), __float_as_uint(acc1[i]), false, false); \
+            acc0[i] = __uint_as_float(swapped[0]);                                                                        \
+            acc1[i] = __uint_as_float(swapped[1]);                                                                        \
+        }                                                                                                                 \
+        _Pragma("unroll") for (int c = 0; c < 32; c++) {                                                                 \
+            const int g = c >> 3, w = c & 7;                                                                              \
+            const float dot = w < 4 ? acc0[4 * g + w] : acc1[4 * g + w - 4];                                              \
+            const float columnBound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(columnBoundLane), c));      \
+            if (__builtin_amdgcn_ballot_w64(dot >= __builtin_amdgcn_fmed3f(rowBound, columnBound, -INFINITY)) != 0ull) {  \
+                const uint32_t col = (cb) * 32u + uint32_t(c);                                                            \
+                const uint32_t m = uint32_t((float(kBits) - dot) * 0.5f);                                                 \
+                if (m <= limit && row != col) {                                                                           \
+                    ++count;                                                                                              \
+                    sum += (unsigned long long)row * 31u + (unsigned long long)col * 17u + m;                             \
+                }                                                                                                         \
+            }                                                                                                             \
+        }                                                                                                                 \
+        if (more2_) __builtin_amdgcn_s_waitcnt(0x0f75);                                                                   \
+        else __builtin_amdgcn_s_waitcnt(0x0f70);                                                                          \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                                                               \
+        __builtin_amdgcn_s_barrier();                                                                                     \
+    } while (0)
+
+__global__ void __launch_bounds__(256, 2)
+mfmaRingKernel(const v4i* __restrict__ fragments, uint32_t cells, const float* __restrict__ minDot, uint32_t limit,
+               unsigned long long* __restrict__ result)
+{
+    __shared__ v4i tileA[kSteps * 64], tileB[kSteps * 64], tileC[kSteps * 64];
+    __shared__ float boundsA[256], boundsB[256], boundsC[256];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t waveSlot = uint32_t(__builtin_amdgcn_readfirstlane(int(wave))) * 64u;
+    const uint32_t rowBlock0 = blockIdx.x * 8u + wave * 2u;
+    const uint32_t row = rowBlock0 * 32u + lane;
+    const uint32_t columnBlocks = cells / 32u;
+    const int scale = 0x7f7f7f7f;
+    v4i rows[2][kSteps];
+    for (int t = 0; t < 2; t++)
+        for (int s = 0; s < kSteps; s++) rows[t][s] = fragments[(size_t(rowBlock0 + t) * kSteps + s) * 64u + lane];
+    const float rowBound = minDot[row];
+    unsigned long long count = 0, sum = 0;
+    RING_STAGE(0u, tileA, boundsA);
+    if (columnBlocks > 1u) RING_STAGE(1u, tileB, boundsB);
+    if (columnBlocks > 1u) __builtin_amdgcn_s_waitcnt(0x0f75);      // vmcnt(5): tile 0 is in, tile 1 may still fly
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
+    __builtin_amdgcn_s_barrier();
+    for (uint32_t cb = 0; cb < columnBlocks; cb += 3u) {
+        RING_BODY(cb, tileA, boundsA, tileC, boundsC);
+        if (cb + 1u < columnBlocks) RING_BODY(cb + 1u, tileB, boundsB, tileA, boundsA);
+        if (cb + 2u < columnBlocks) RING_BODY(cb + 2u, tileC, boundsC, tileB, boundsB);
+    }
+    atomicAdd(result, count);
+    atomicAdd(result + 1, sum);
+}
+
 static uint64_t splitmix(uint64_t& x)
 {
     uint64_t z = (x += 0x9e3779b97f4a7c15ull);
@@ -351,6 +437,21 @@ int main(int argc, char** argv)
         unsigned long long check[2];
         CHECK(hipMemcpy(check, dResult + 2, sizeof(check), hipMemcpyDeviceToHost));
         unsigned long long ref[2];
+        CHECK(hipMemcpy(ref, dResult, sizeof(ref), hipMemcpyDeviceToHost));
+        printf("    count %llu checksum %llu: %s\n", check[0], check[1], (check[0] == ref[0] && check[1] == ref[1]) ? "IDENTICAL" : "DIFFERENT");
+    }
+    for (int rep = 0; rep < 3; rep++) {
+        CHECK(hipMemset(dResult + 2, 0, 2 * sizeof(unsigned long long)));
+        CHECK(hipEventRecord(e0));
+        mfmaRingKernel<<<cells / 256u, 256>>>(dFragments, cells, minDot, limit, dResult + 2);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("mfma fp4, lane = row, per-column test, ring of 3 tiles + counted waits: %.3f ms, %.3g ordered pairs/s\n", ms, pairs / ms * 1e3);
+    }
+    {
+        unsigned long long check[2], ref[2];
+        CHECK(hipMemcpy(check, dResult + 2, sizeof(check), hipMemcpyDeviceToHost));
         CHECK(hipMemcpy(ref, dResult, sizeof(ref), hipMemcpyDeviceToHost));
         printf("    count %llu checksum %llu: %s\n", check[0], check[1], (check[0] == ref[0] && check[1] == ref[1]) ? "IDENTICAL" : "DIFFERENT");
     }
