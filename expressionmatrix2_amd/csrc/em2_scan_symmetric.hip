@@ -632,21 +632,35 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
             acc0[i] = __uint_as_float(swapped[0]);
             acc1[i] = __uint_as_float(swapped[1]);
         }
+        // Eight columns per branch: the per-column compares are OR-ed as lane masks on the scalar unit, and only a group
+        // in which something passes looks at its columns one by one (a branch per column cost more than the compares:
+        // 1.6 -> 2.4 * 10^12 pairs/s in tools/ubench_mfma_pairs.hip).
 #pragma unroll
-        for (int c = 0; c < 32; c++) {
-            const int g = c >> 3, w = c & 7;
-            const float dot = w < 4 ? acc0[4 * g + w] : acc1[4 * g + w - 4];
-            const float columnDot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(columnDotLane), c));
-            // min(rowDot, columnDot) as one v_med3_f32 (fminf would canonicalise both inputs first)
-            if (__builtin_amdgcn_ballot_w64(dot >= __builtin_amdgcn_fmed3f(rowDot, columnDot, -INFINITY)) != 0ull) {
-                const uint32_t col = colBase + uint32_t(c);
-                const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
-                emitColumnFast(rowValid && dot >= columnDot, col, row, m, lane, emitPos, emitEnd, inbox, rowBits);
-                if (BOTH) {
-                    emitColumnFast(rowValid && dot >= rowDot, row, col, m, lane, emitPos, emitEnd, inbox, rowBits);
-                } else if (dot >= rowDot) {
-                    storeEntry(myLog + logCount, col, m);
-                    ++logCount;
+        for (int g = 0; g < 4; g++) {
+            float columnDots[8];
+            bool any = false;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                const float dot = w < 4 ? acc0[4 * g + w] : acc1[4 * g + w - 4];
+                columnDots[w] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(columnDotLane), 8 * g + w));
+                // min(rowDot, columnDot) as one v_med3_f32 (fminf would canonicalise both inputs first)
+                any |= dot >= __builtin_amdgcn_fmed3f(rowDot, columnDots[w], -INFINITY);
+            }
+            if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                const float dot = w < 4 ? acc0[4 * g + w] : acc1[4 * g + w - 4];
+                const float columnDot = columnDots[w];
+                if (__builtin_amdgcn_ballot_w64(dot >= __builtin_amdgcn_fmed3f(rowDot, columnDot, -INFINITY)) != 0ull) {
+                    const uint32_t col = colBase + uint32_t(8 * g + w);
+                    const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
+                    emitColumnFast(rowValid && dot >= columnDot, col, row, m, lane, emitPos, emitEnd, inbox, rowBits);
+                    if (BOTH) {
+                        emitColumnFast(rowValid && dot >= rowDot, row, col, m, lane, emitPos, emitEnd, inbox, rowBits);
+                    } else if (dot >= rowDot) {
+                        storeEntry(myLog + logCount, col, m);
+                        ++logCount;
+                    }
                 }
             }
         }

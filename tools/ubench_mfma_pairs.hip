@@ -173,7 +173,7 @@ mfmaPairsKernel(const v4i* __restrict__ fragments, uint32_t cells, const float* 
 // scan, and every column is then tested against max(row bound, column bound) exactly as there: one v_min, one v_cmp,
 // one branch.  DIRECT: each wave loads the column fragments itself (no LDS, no barrier: waves stay independent, which
 // is what the product's ticket / hand-off scheme needs); otherwise the block shares them through LDS.
-template <bool DIRECT>
+template <bool DIRECT, bool GROUPED = false>
 __global__ void __launch_bounds__(256, 2)
 mfmaRowLaneKernel(const v4i* __restrict__ fragments, uint32_t cells, const float* __restrict__ minDot, uint32_t limit,
                   unsigned long long* __restrict__ result)
@@ -230,6 +230,32 @@ mfmaRowLaneKernel(const v4i* __restrict__ fragments, uint32_t cells, const float
             acc1[i] = __uint_as_float(swapped[1]);
         }
         const float* columnBounds = minDot + cb * 32u;       // wave-uniform: scalar loads
+        if (GROUPED) {
+            // one branch per 8 columns: the per-column compares are OR-ed as lane masks (scalar unit)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                bool any = false;
+#pragma unroll
+                for (int w = 0; w < 8; w++) {
+                    const float dot = w < 4 ? acc0[4 * g + w] : acc1[4 * g + w - 4];
+                    any |= dot >= __builtin_amdgcn_fmed3f(rowBound, columnBounds[8 * g + w], -INFINITY);
+                }
+                if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+#pragma unroll
+                    for (int w = 0; w < 8; w++) {
+                        const float dot = w < 4 ? acc0[4 * g + w] : acc1[4 * g + w - 4];
+                        if (__builtin_amdgcn_ballot_w64(dot >= __builtin_amdgcn_fmed3f(rowBound, columnBounds[8 * g + w], -INFINITY)) != 0ull) {
+                            const uint32_t col = cb * 32u + uint32_t(8 * g + w);
+                            const uint32_t m = uint32_t((float(kBits) - dot) * 0.5f);
+                            if (m <= limit && row != col) {
+                                ++count;
+                                sum += (unsigned long long)row * 31u + (unsigned long long)col * 17u + m;
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < 32; c++) {
             const int g = c >> 3, w = c & 7;
@@ -243,6 +269,7 @@ mfmaRowLaneKernel(const v4i* __restrict__ fragments, uint32_t cells, const float
                     sum += (unsigned long long)row * 31u + (unsigned long long)col * 17u + m;
                 }
             }
+        }
         }
         if (!DIRECT) {
             if (more) {
@@ -422,17 +449,18 @@ int main(int argc, char** argv)
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         printf("mfma fp4 + bound test: %.3f ms, %.3g ordered pairs/s\n", ms, pairs / ms * 1e3);
     }
-    for (int direct = 0; direct < 2; direct++) {
+    for (int direct = 0; direct < 3; direct++) {
         for (int rep = 0; rep < 3; rep++) {
             CHECK(hipMemset(dResult + 2, 0, 2 * sizeof(unsigned long long)));
             CHECK(hipEventRecord(e0));
-            if (direct) mfmaRowLaneKernel<true><<<cells / 256u, 256>>>(dFragments, cells, minDot, limit, dResult + 2);
+            if (direct == 1) mfmaRowLaneKernel<true><<<cells / 256u, 256>>>(dFragments, cells, minDot, limit, dResult + 2);
+            else if (direct == 2) mfmaRowLaneKernel<false, true><<<cells / 256u, 256>>>(dFragments, cells, minDot, limit, dResult + 2);
             else mfmaRowLaneKernel<false><<<cells / 256u, 256>>>(dFragments, cells, minDot, limit, dResult + 2);
             CHECK(hipEventRecord(e1));
             CHECK(hipEventSynchronize(e1));
             CHECK(hipEventElapsedTime(&ms, e0, e1));
             printf("mfma fp4, lane = row, per-column test, columns %s: %.3f ms, %.3g ordered pairs/s\n",
-                   direct ? "loaded by each wave" : "through LDS", ms, pairs / ms * 1e3);
+                   direct == 1 ? "loaded by each wave" : direct == 2 ? "through LDS, one branch per 8 columns" : "through LDS", ms, pairs / ms * 1e3);
         }
         unsigned long long check[2];
         CHECK(hipMemcpy(check, dResult + 2, sizeof(check), hipMemcpyDeviceToHost));
