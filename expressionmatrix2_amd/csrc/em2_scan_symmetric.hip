@@ -1381,13 +1381,38 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         table[sIdx] = uint32_t(tickets);
         table[segments + 1u + sIdx] = firstTriangle;
         tickets += fullRowBlocks + (matrix ? 0u : rowBlocks - firstTriangle);
-        tableMatrix[sIdx] = uint32_t(ticketsMatrix);
-        tableMatrix[segments + 1u + sIdx] = firstTriangle;              // a multiple of 4 in the matrix form
-        ticketsMatrix += (rowBlocks - firstTriangle + 3u) / 4u;
-        if (tickets >= 0xffffffffull || ticketsMatrix >= 0xffffffffull) return hipErrorInvalidValue;
+        if (tickets >= 0xffffffffull) return hipErrorInvalidValue;
     }
     table[segments] = uint32_t(tickets);
-    tableMatrix[segments] = uint32_t(ticketsMatrix);
+    // The matrix kernel has segments of its own, and longer ones: every item starts by loading 32 KB of row fragments per
+    // wave and priming the tile pipeline, and its columns need not stay in one L2 (kernel ms at 1M cells with 4096 /
+    // 8192 / 16384 / 32768 / 131072 columns per segment: 289 / 278 / 273 / 270 / 274; 2048: 335).  The test knobs apply
+    // to both launches.
+    uint64_t segmentsMatrix = segments;
+    uint32_t cpsMatrix = cps;
+    if (matrix) {
+        uint64_t defaultColumns = cellCount / 24u;              // small problems keep enough items to fill the machine
+        defaultColumns = defaultColumns < 4096 ? 4096 : (defaultColumns > 16384 ? 16384 : defaultColumns);
+        uint64_t minColumns = envNumber("EM2_MIN_SEGMENT_COLUMNS", defaultColumns);
+        if (minColumns < 1) minColumns = 1;
+        segmentsMatrix = cellCount / minColumns;
+        if (segmentsMatrix > kMatrixMaxSegments) segmentsMatrix = kMatrixMaxSegments;
+        if (forcedSegments >= 1 && forcedSegments <= kMatrixMaxSegments) segmentsMatrix = forcedSegments;
+        if (segmentsMatrix < 1) segmentsMatrix = 1;
+        cpsMatrix = uint32_t((uint64_t(cellCount) + segmentsMatrix - 1u) / segmentsMatrix);
+        cpsMatrix = (cpsMatrix + 255u) & ~255u;
+        segmentsMatrix = (uint64_t(cellCount) + cpsMatrix - 1u) / cpsMatrix;
+        for (uint32_t sIdx = 0; sIdx < segmentsMatrix; ++sIdx) {
+            uint32_t firstQuad = uint32_t((uint64_t(sIdx) * cpsMatrix) / 64u);      // a multiple of 4
+            if (firstQuad < fullRowBlocks) firstQuad = fullRowBlocks;
+            if (firstQuad > rowBlocks) firstQuad = rowBlocks;
+            tableMatrix[sIdx] = uint32_t(ticketsMatrix);
+            tableMatrix[segmentsMatrix + 1u + sIdx] = firstQuad;
+            ticketsMatrix += (rowBlocks - firstQuad + 3u) / 4u;
+            if (ticketsMatrix >= 0xffffffffull) return hipErrorInvalidValue;
+        }
+        tableMatrix[segmentsMatrix] = uint32_t(ticketsMatrix);
+    }
 
     const SymmetricLayout layout = symmetricLayout(cellCount);
     char* ws = static_cast<char*>(symmetricWs);
@@ -1451,7 +1476,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     }
     if (matrix) {
         // the full-row blocks are done (their launch above); now the triangle on the matrix cores
-        e = hipMemcpyAsync(ws + layout.tableMatrix, tableMatrix, (2u * segments + 2u) * 4u, hipMemcpyHostToDevice, stream);
+        e = hipMemcpyAsync(ws + layout.tableMatrix, tableMatrix, (2u * segmentsMatrix + 2u) * 4u, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
         e = hipMemsetAsync(args.control, 0, 4u, stream);                 // the ticket; the error word stays
         if (e != hipSuccess) return e;
@@ -1462,6 +1487,8 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         if (e != hipSuccess) return e;
         Fsp4Args matrixArgs = args;
         matrixArgs.segTable = reinterpret_cast<const uint32_t*>(ws + layout.tableMatrix);
+        matrixArgs.segments = uint32_t(segmentsMatrix);
+        matrixArgs.columnsPerSegment = cpsMatrix;
         matrixArgs.totalTickets = uint32_t(ticketsMatrix);
         matrixArgs.fragments = ws + layout.fragments;
         matrixArgs.matrixLdsOffset = uint32_t((lds + 15u) & ~size_t(15));
@@ -1528,7 +1555,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     }
     if (const char* v = getenv("EM2_SCAN_VERBOSE")) {
         if (v[0] == '1') fprintf(stderr, "[em2] symmetric scan%s: %u segments x %u columns, %u full-row blocks, %llu + %llu tickets, %llu inbox slots\n",
-                                 matrix ? " (matrix cores)" : "", uint32_t(segments), cps, fullRowBlocks,
+                                 matrix ? " (matrix cores)" : "", uint32_t(matrix ? segmentsMatrix : segments), matrix ? cpsMatrix : cps, fullRowBlocks,
                                  (unsigned long long)tickets, (unsigned long long)(matrix ? ticketsMatrix : 0), (unsigned long long)used);
     }
 
