@@ -1776,7 +1776,7 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             envNumber("EM2_SCAN_MATRIX", 1) != 0) {
             // the rows beyond the prefix against the prefix columns: all of it below the rows, so all of it for the matrix
             // cores (fsp4ScanMatrixKernel over quads of slots; no quad ever reaches its own columns here)
-            uint64_t segments = M / 4096u;
+            uint64_t segments = M / 16384u;          // long segments: an item starts with 32 KB of row fragments per wave
             if (segments > kMatrixMaxSegments) segments = kMatrixMaxSegments;
             if (segments < 1) segments = 1;
             uint32_t cps = uint32_t((uint64_t(M) + segments - 1u) / segments);
@@ -1872,7 +1872,7 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
         // 1024-bit signatures and a prefix of whole quads: the tiles go to the matrix cores (EM2_SCAN_MATRIX=0: never)
         const bool matrix = paddedDw == 32u && M % 256u == 0u && envNumber("EM2_SCAN_MATRIX", 1) != 0;
         const uint32_t span = cellCount - M;
-        uint64_t segments = span / (matrix ? 4096u : 1024u);
+        uint64_t segments = span / (matrix ? 16384u : 1024u);
         if (segments > 256) segments = 256;
         const uint64_t forced = envNumber("EM2_TILE_SEGMENTS", 0);
         if (forced >= 1 && forced <= 256) segments = forced;
