@@ -509,6 +509,7 @@ typedef int FragmentWord4 __attribute__((ext_vector_type(4)));
 typedef int FragmentWord8 __attribute__((ext_vector_type(8)));
 typedef float Accumulator16 __attribute__((ext_vector_type(16)));
 
+constexpr int kColumnsPerBranch = 4;                        // kernel ms at 1M cells with 1 / 2 / 4 / 8 / 16: 289* / 261 / 260 / 273 / 297 (* before the longer segments)
 constexpr uint32_t kMatrixSteps = 16;                        // 1024 bits / 64 per MFMA
 constexpr uint32_t kMatrixTileWords = kMatrixSteps * 64u;    // FragmentWord4 per 32-cell tile (16 KB)
 constexpr float kMatrixBits = 1024.f;
@@ -632,27 +633,28 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
             acc0[i] = __uint_as_float(swapped[0]);
             acc1[i] = __uint_as_float(swapped[1]);
         }
-        // Eight columns per branch: the per-column compares are OR-ed as lane masks on the scalar unit, and only a group
+        // Four columns per branch: the per-column compares are OR-ed as lane masks on the scalar unit, and only a group
         // in which something passes looks at its columns one by one (a branch per column cost more than the compares:
-        // 1.6 -> 2.4 * 10^12 pairs/s in tools/ubench_mfma_pairs.hip).
+        // 1.6 -> 2.4 * 10^12 pairs/s in tools/ubench_mfma_pairs.hip, where nothing ever passes and groups are 8 wide; here
+        // about two events per tile make 4 the best width).
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            float columnDots[8];
+        for (int g = 0; g < 32 / kColumnsPerBranch; g++) {
+            float columnDots[kColumnsPerBranch];
             bool any = false;
 #pragma unroll
-            for (int w = 0; w < 8; w++) {
-                const float dot = w < 4 ? acc0[4 * g + w] : acc1[4 * g + w - 4];
-                columnDots[w] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(columnDotLane), 8 * g + w));
+            for (int w = 0; w < kColumnsPerBranch; w++) {
+                const int c = kColumnsPerBranch * g + w; const float dot = (c & 7) < 4 ? acc0[4 * (c >> 3) + (c & 7)] : acc1[4 * (c >> 3) + (c & 7) - 4];
+                columnDots[w] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(columnDotLane), c));
                 // min(rowDot, columnDot) as one v_med3_f32 (fminf would canonicalise both inputs first)
                 any |= dot >= __builtin_amdgcn_fmed3f(rowDot, columnDots[w], -INFINITY);
             }
             if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
 #pragma unroll
-            for (int w = 0; w < 8; w++) {
-                const float dot = w < 4 ? acc0[4 * g + w] : acc1[4 * g + w - 4];
+            for (int w = 0; w < kColumnsPerBranch; w++) {
+                const int c = kColumnsPerBranch * g + w; const float dot = (c & 7) < 4 ? acc0[4 * (c >> 3) + (c & 7)] : acc1[4 * (c >> 3) + (c & 7) - 4];
                 const float columnDot = columnDots[w];
                 if (__builtin_amdgcn_ballot_w64(dot >= __builtin_amdgcn_fmed3f(rowDot, columnDot, -INFINITY)) != 0ull) {
-                    const uint32_t col = colBase + uint32_t(8 * g + w);
+                    const uint32_t col = colBase + uint32_t(c);
                     const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
                     emitColumnFast(rowValid && dot >= columnDot, col, row, m, lane, emitPos, emitEnd, inbox, rowBits);
                     if (BOTH) {
