@@ -581,7 +581,9 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
         }
     }
     // A tile travels global -> LDS without touching registers (global_load_lds_dwordx4: the LDS address is the wave's
-    // base + lane * 16, which is exactly the fragment order), one tile ahead of the MFMAs.
+    // base + lane * 16, which is exactly the fragment order).  Two tiles (64 columns) per barrier: the four waves may
+    // drift by a tile, which absorbs the difference between a tile with events and one without; the pair after the one
+    // being contracted is on its way meanwhile.
     const uint32_t waveSlot = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))) * 64u;
 #define EM2_STAGE_TILE(tileIndex, buffer)                                                                                     \
     do {                                                                                                                      \
@@ -593,81 +595,92 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
         }                                                                                                                     \
     } while (0)
     EM2_STAGE_TILE(colBegin / 32u, 0u);
+    if (colBegin + 32u < colEnd) EM2_STAGE_TILE(colBegin / 32u + 1u, 1u);
     __syncthreads();
     uint32_t iteration = 0;
-    // The bound of column (lane & 31), fetched one tile ahead like the fragments (the compiler sinks a load placed in
-    // front of the MFMAs to its first use behind them, and the wave then sits out a global-load latency per tile).  Any
-    // value a cell published earlier is valid: bounds only tighten.
-    int32_t snapAhead = snap[colBegin + (lane & 31u)];
-    for (uint32_t colBase = colBegin; colBase < colEnd; colBase += 32u, ++iteration) {
-        const uint32_t cur = iteration & 1u;
-        const bool more = colBase + 32u < colEnd;
-        const int32_t snapLane = snapAhead;
-        if (more) {
-            EM2_STAGE_TILE(colBase / 32u + 1u, cur ^ 1u);
-            snapAhead = snap[colBase + 32u + (lane & 31u)];
+    // The bounds of columns (lane & 31) of the two tiles, fetched one pair ahead like the fragments (the compiler sinks
+    // a load placed in front of the MFMAs to its first use behind them, and the wave then sits out a global-load latency
+    // per tile).  Any value a cell published earlier is valid: bounds only tighten.
+    int32_t snapAhead[2];
+    snapAhead[0] = snap[colBegin + (lane & 31u)];
+    snapAhead[1] = colBegin + 32u < colEnd ? snap[colBegin + 32u + (lane & 31u)] : 0;
+    for (uint32_t colBase = colBegin; colBase < colEnd; colBase += 64u, ++iteration) {
+        const uint32_t pair = iteration & 1u;
+        const int32_t snapLane[2] = {snapAhead[0], snapAhead[1]};
+        if (colBase + 64u < colEnd) {
+            EM2_STAGE_TILE(colBase / 32u + 2u, 2u * (pair ^ 1u));
+            snapAhead[0] = snap[colBase + 64u + (lane & 31u)];
         }
-        const float columnDotLane = kMatrixBits - 2.f * float(snapLane);
-        Accumulator16 acc0 = {}, acc1 = {};
-        const FragmentWord4* tile = tiles + cur * kMatrixTileWords;
-        // column fragments four k-steps ahead of their MFMAs (the LDS latency of a read is two MFMA pairs long)
-        FragmentWord4 ahead[4];
-#pragma unroll
-        for (int s = 0; s < 4; s++) ahead[s] = tile[s * 64 + int(lane)];
-        __builtin_amdgcn_s_setprio(2);          // the SIMD's other wave is in its column tests: MFMAs first
-#pragma unroll
-        for (int s = 0; s < int(kMatrixSteps); s++) {
-            const FragmentWord4 a = ahead[s & 3];
-            if (s + 4 < int(kMatrixSteps)) ahead[s & 3] = tile[(s + 4) * 64 + int(lane)];
-            const FragmentWord8 a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
-            const FragmentWord8 b0 = {rows[0][s].x, rows[0][s].y, rows[0][s].z, rows[0][s].w, 0, 0, 0, 0};
-            const FragmentWord8 b1 = {rows[1][s].x, rows[1][s].y, rows[1][s].z, rows[1][s].w, 0, 0, 0, 0};
-            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, acc0, 4, 4, 0, scale, 0, scale);
-            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, acc1, 4, 4, 0, scale, 0, scale);
+        if (colBase + 96u < colEnd) {
+            EM2_STAGE_TILE(colBase / 32u + 3u, 2u * (pair ^ 1u) + 1u);
+            snapAhead[1] = snap[colBase + 96u + (lane & 31u)];
         }
-        __builtin_amdgcn_s_setprio(0);
-        // lane = row: acc0[i] <- column (i&3) + 8*(i>>2), acc1[i] <- that + 4
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const auto swapped = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[i]), __float_as_uint(acc1[i]), false, false);
-            acc0[i] = __uint_as_float(swapped[0]);
-            acc1[i] = __uint_as_float(swapped[1]);
-        }
-        // Four columns per branch: the per-column compares are OR-ed as lane masks on the scalar unit, and only a group
-        // in which something passes looks at its columns one by one (a branch per column cost more than the compares:
-        // 1.6 -> 2.4 * 10^12 pairs/s in tools/ubench_mfma_pairs.hip, where nothing ever passes and groups are 8 wide; here
-        // about two events per tile make 4 the best width).
-#pragma unroll
-        for (int g = 0; g < 32 / kColumnsPerBranch; g++) {
-            float columnDots[kColumnsPerBranch];
-            bool any = false;
-#pragma unroll
-            for (int w = 0; w < kColumnsPerBranch; w++) {
-                const int c = kColumnsPerBranch * g + w; const float dot = (c & 7) < 4 ? acc0[4 * (c >> 3) + (c & 7)] : acc1[4 * (c >> 3) + (c & 7) - 4];
-                columnDots[w] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(columnDotLane), c));
-                // min(rowDot, columnDot) as one v_med3_f32 (fminf would canonicalise both inputs first)
-                any |= dot >= __builtin_amdgcn_fmed3f(rowDot, columnDots[w], -INFINITY);
+        for (int sub = 0; sub < 2; sub++) {
+            const uint32_t tileBase = colBase + 32u * uint32_t(sub);
+            if (tileBase >= colEnd) break;
+            const float columnDotLane = kMatrixBits - 2.f * float(snapLane[sub]);
+            Accumulator16 acc0 = {}, acc1 = {};
+            const FragmentWord4* tile = tiles + (2u * pair + uint32_t(sub)) * kMatrixTileWords;
+            // column fragments four k-steps ahead of their MFMAs (the LDS latency of a read is two MFMA pairs long)
+            FragmentWord4 ahead[4];
+    #pragma unroll
+            for (int s = 0; s < 4; s++) ahead[s] = tile[s * 64 + int(lane)];
+            __builtin_amdgcn_s_setprio(2);          // the SIMD's other wave is in its column tests: MFMAs first
+    #pragma unroll
+            for (int s = 0; s < int(kMatrixSteps); s++) {
+                const FragmentWord4 a = ahead[s & 3];
+                if (s + 4 < int(kMatrixSteps)) ahead[s & 3] = tile[(s + 4) * 64 + int(lane)];
+                const FragmentWord8 a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
+                const FragmentWord8 b0 = {rows[0][s].x, rows[0][s].y, rows[0][s].z, rows[0][s].w, 0, 0, 0, 0};
+                const FragmentWord8 b1 = {rows[1][s].x, rows[1][s].y, rows[1][s].z, rows[1][s].w, 0, 0, 0, 0};
+                acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, acc0, 4, 4, 0, scale, 0, scale);
+                acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, acc1, 4, 4, 0, scale, 0, scale);
             }
-            if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
-#pragma unroll
-            for (int w = 0; w < kColumnsPerBranch; w++) {
-                const int c = kColumnsPerBranch * g + w; const float dot = (c & 7) < 4 ? acc0[4 * (c >> 3) + (c & 7)] : acc1[4 * (c >> 3) + (c & 7) - 4];
-                const float columnDot = columnDots[w];
-                if (__builtin_amdgcn_ballot_w64(dot >= __builtin_amdgcn_fmed3f(rowDot, columnDot, -INFINITY)) != 0ull) {
-                    const uint32_t col = colBase + uint32_t(c);
-                    const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
-                    emitColumnFast(rowValid && dot >= columnDot, col, row, m, lane, emitPos, emitEnd, inbox, rowBits);
-                    if (BOTH) {
-                        emitColumnFast(rowValid && dot >= rowDot, row, col, m, lane, emitPos, emitEnd, inbox, rowBits);
-                    } else if (dot >= rowDot) {
-                        storeEntry(myLog + logCount, col, m);
-                        ++logCount;
+            __builtin_amdgcn_s_setprio(0);
+            // lane = row: acc0[i] <- column (i&3) + 8*(i>>2), acc1[i] <- that + 4
+    #pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const auto swapped = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[i]), __float_as_uint(acc1[i]), false, false);
+                acc0[i] = __uint_as_float(swapped[0]);
+                acc1[i] = __uint_as_float(swapped[1]);
+            }
+            // Four columns per branch: the per-column compares are OR-ed as lane masks on the scalar unit, and only a group
+            // in which something passes looks at its columns one by one (a branch per column cost more than the compares:
+            // 1.6 -> 2.4 * 10^12 pairs/s in tools/ubench_mfma_pairs.hip, where nothing ever passes and groups are 8 wide; here
+            // about two events per tile make 4 the best width).
+    #pragma unroll
+            for (int g = 0; g < 32 / kColumnsPerBranch; g++) {
+                float columnDots[kColumnsPerBranch];
+                bool any = false;
+    #pragma unroll
+                for (int w = 0; w < kColumnsPerBranch; w++) {
+                    const int c = kColumnsPerBranch * g + w; const float dot = (c & 7) < 4 ? acc0[4 * (c >> 3) + (c & 7)] : acc1[4 * (c >> 3) + (c & 7) - 4];
+                    columnDots[w] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(columnDotLane), c));
+                    // min(rowDot, columnDot) as one v_med3_f32 (fminf would canonicalise both inputs first)
+                    any |= dot >= __builtin_amdgcn_fmed3f(rowDot, columnDots[w], -INFINITY);
+                }
+                if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
+    #pragma unroll
+                for (int w = 0; w < kColumnsPerBranch; w++) {
+                    const int c = kColumnsPerBranch * g + w; const float dot = (c & 7) < 4 ? acc0[4 * (c >> 3) + (c & 7)] : acc1[4 * (c >> 3) + (c & 7) - 4];
+                    const float columnDot = columnDots[w];
+                    if (__builtin_amdgcn_ballot_w64(dot >= __builtin_amdgcn_fmed3f(rowDot, columnDot, -INFINITY)) != 0ull) {
+                        const uint32_t col = tileBase + uint32_t(c);
+                        const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
+                        emitColumnFast(rowValid && dot >= columnDot, col, row, m, lane, emitPos, emitEnd, inbox, rowBits);
+                        if (BOTH) {
+                            emitColumnFast(rowValid && dot >= rowDot, row, col, m, lane, emitPos, emitEnd, inbox, rowBits);
+                        } else if (dot >= rowDot) {
+                            storeEntry(myLog + logCount, col, m);
+                            ++logCount;
+                        }
                     }
                 }
             }
         }
-        // a tile adds at most 32 entries to a row's log
-        const bool full = !BOTH && __builtin_amdgcn_ballot_w64(logCount + 32u > logCapacity) != 0ull;
+        // a pair of tiles adds at most 64 entries to a row's log
+        const bool full = !BOTH && __builtin_amdgcn_ballot_w64(logCount + 64u > logCapacity) != 0ull;
         const uint32_t slot = iteration % 3u;
         if (full && lane == 0u) stopWords[slot] = 1u;
         if (threadIdx.x == 0u) stopWords[(iteration + 1u) % 3u] = 0u;
@@ -676,7 +689,7 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
             __syncthreads();
             if (threadIdx.x == 0u) stopWords[slot] = 0u;
             __syncthreads();
-            return colBase + 32u;
+            return colBase + 64u < colEnd ? colBase + 64u : colEnd;
         }
     }
 #undef EM2_STAGE_TILE
@@ -691,7 +704,7 @@ fsp4ScanMatrixKernel(Fsp4Args args)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     FragmentWord4* tiles = reinterpret_cast<FragmentWord4*>(ldsRaw + kernelArgs()->matrixLdsOffset);
-    volatile uint32_t* shared = reinterpret_cast<volatile uint32_t*>(ldsRaw + kernelArgs()->matrixLdsOffset + 2u * kMatrixTileWords * 16u);
+    volatile uint32_t* shared = reinterpret_cast<volatile uint32_t*>(ldsRaw + kernelArgs()->matrixLdsOffset + 4u * kMatrixTileWords * 16u);
     // shared[0..2] stop words of the walk, shared[3] the block's ticket
     if (threadIdx.x < 4u) shared[threadIdx.x] = 0u;
     __syncthreads();
@@ -1114,7 +1127,7 @@ fsp4TileMatrixKernel(Fsp4Args args)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     FragmentWord4* tiles = reinterpret_cast<FragmentWord4*>(ldsRaw + kernelArgs()->matrixLdsOffset);
-    volatile uint32_t* shared = reinterpret_cast<volatile uint32_t*>(ldsRaw + kernelArgs()->matrixLdsOffset + 2u * kMatrixTileWords * 16u);
+    volatile uint32_t* shared = reinterpret_cast<volatile uint32_t*>(ldsRaw + kernelArgs()->matrixLdsOffset + 4u * kMatrixTileWords * 16u);
     if (threadIdx.x < 4u) shared[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t emitPos = 0, emitEnd = 0;
@@ -1349,7 +1362,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     bool matrix = paddedDw == 32u && wavesPerBlock == 4u && args.rowBlockStride == 1u && args.rowBlockOffset == 0u &&
                   args.localBlockBase == 0u && args.shardFlags == 0u && args.columnLimit == cellCount && args.rowBegin == 0u &&
                   envNumber("EM2_SCAN_MATRIX", 1) != 0 &&
-                  ((lds + 15u) & ~size_t(15)) + 2u * kMatrixTileWords * 16u + 64u <= 64u * 1024u;      // selection area + two tiles
+                  ((lds + 15u) & ~size_t(15)) + 4u * kMatrixTileWords * 16u + 64u <= 150u * 1024u;      // selection area + four tiles
     if (matrix) {
         fullRowBlocks = (fullRowBlocks + 3u) & ~3u;
         if (fullRowBlocks >= rowBlocks) {
@@ -1494,13 +1507,15 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         matrixArgs.totalTickets = uint32_t(ticketsMatrix);
         matrixArgs.fragments = ws + layout.fragments;
         matrixArgs.matrixLdsOffset = uint32_t((lds + 15u) & ~size_t(15));
-        const size_t matrixLds = size_t(matrixArgs.matrixLdsOffset) + 2u * kMatrixTileWords * 16u + 64u;
+        const size_t matrixLds = size_t(matrixArgs.matrixLdsOffset) + 4u * kMatrixTileWords * 16u + 64u;
         const void* matrixKernel = identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<true>)
                                             : reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<false>);
         int device = 0, cuCount = 0, blocksPerCu = 0;
         e = hipGetDevice(&device);
         if (e != hipSuccess) return e;
         e = hipDeviceGetAttribute(&cuCount, hipDeviceAttributeMultiprocessorCount, device);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(matrixKernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(matrixLds));       // more than 64 KB
         if (e != hipSuccess) return e;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCu, matrixKernel, 256, matrixLds);
         if (e != hipSuccess) return e;
@@ -1773,8 +1788,8 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
         const uint32_t slotCount = phase == 0 ? plan.ownPrefixBlocks : plan.ownBlocks - plan.ownPrefixBlocks;
         if (slotCount == 0) return hipSuccess;
         const size_t matrixLdsOffset = (lds + 15u) & ~size_t(15);
-        const size_t matrixLds = matrixLdsOffset + 2u * kMatrixTileWords * 16u + 64u;
-        if (phase == 1 && paddedDw == 32u && wavesPerBlock == 4u && M % 256u == 0u && matrixLds <= 64u * 1024u &&
+        const size_t matrixLds = matrixLdsOffset + 4u * kMatrixTileWords * 16u + 64u;
+        if (phase == 1 && paddedDw == 32u && wavesPerBlock == 4u && M % 256u == 0u && matrixLds <= 150u * 1024u &&
             envNumber("EM2_SCAN_MATRIX", 1) != 0) {
             // the rows beyond the prefix against the prefix columns: all of it below the rows, so all of it for the matrix
             // cores (fsp4ScanMatrixKernel over quads of slots; no quad ever reaches its own columns here)
@@ -1824,6 +1839,8 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             }
             if (blocksWanted * 4u > maxResidentWaves()) blocksWanted = maxResidentWaves() / 4u;
             if (blocksWanted > tickets) blocksWanted = tickets;
+            e = hipFuncSetAttribute(matrixKernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(matrixLds));
+            if (e != hipSuccess) return e;
             void* matrixArgsArray[] = {&args};
             return hipLaunchKernel(matrixKernel, dim3(uint32_t(blocksWanted)), dim3(256), matrixArgsArray, matrixLds, stream);
         }
@@ -1926,9 +1943,12 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             if (e != hipSuccess) return e;
             args.fragments = ws + plan.offFragments;
             args.matrixLdsOffset = 0;
-            const size_t matrixLds = 2u * kMatrixTileWords * 16u + 64u;
+            const size_t matrixLds = 4u * kMatrixTileWords * 16u + 64u;
             uint64_t blocksWanted = uint64_t(cuCount) * 2u;
             if (blocksWanted > own) blocksWanted = own;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fsp4TileMatrixKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    int(matrixLds));
+            if (e != hipSuccess) return e;
             void* matrixArgsArray[] = {&args};
             return hipLaunchKernel(reinterpret_cast<const void*>(&fsp4TileMatrixKernel), dim3(uint32_t(blocksWanted)), dim3(256),
                                    matrixArgsArray, matrixLds, stream);
