@@ -730,9 +730,14 @@ fsp4ScanMatrixKernel(Fsp4Args args)
         while (ticket >= table[seg + 1u]) ++seg;
         // block = list / state slot of the launch; its 64 cells start at (block * stride + offset) * 64 (block-cyclic in
         // the sharded scan, where a quad is 4 slots whose cells are not adjacent -- but there every column lies below them)
-        const uint32_t quadBlock = table[segments + 1u + seg] + 4u * (ticket - table[seg]);
+        // The first fullQuads items of a segment are quads of full-row blocks (the first cells of the problem, or the prefix
+        // blocks of the sharded scan): their rows take every column of the segment, emit nothing and finish themselves.
+        const uint32_t local = ticket - table[seg];
+        const uint32_t fullQuads = (aux->fullRowBlocks + 3u) / 4u;
+        const bool fullRows = local < fullQuads;
+        const uint32_t quadBlock = fullRows ? aux->localBlockBase + 4u * local : table[segments + 1u + seg] + 4u * (local - fullQuads);
         const uint32_t block = quadBlock + wave;
-        const bool idle = block >= aux->rowBlocks;              // the last quad may be short
+        const bool idle = block >= (fullRows ? aux->localBlockBase + aux->fullRowBlocks : aux->rowBlocks);      // a short last quad
         const uint32_t listBlock = idle ? aux->rowBlocks - 1u : block;
         const uint32_t quadRowBase = (quadBlock * aux->rowBlockStride + aux->rowBlockOffset) * 64u;
         const uint32_t rowBase = (block * aux->rowBlockStride + aux->rowBlockOffset) * 64u;
@@ -747,8 +752,9 @@ fsp4ScanMatrixKernel(Fsp4Args args)
         const uint32_t colBegin = seg * cps;
         uint32_t colEnd = colBegin + cps;
         if (colEnd > aux->columnLimit || seg + 1u == segments) colEnd = aux->columnLimit;
-        const bool last = quadRowBase < colEnd;                 // the segment that holds the quad's own cells
-        const uint32_t commonEnd = last ? quadRowBase : colEnd;
+        const bool last = !fullRows && quadRowBase < colEnd;    // the segment that holds the quad's own cells
+        // (a full row's last segment may end at a cell count that is no multiple of 32: the walk takes whole tiles)
+        const uint32_t commonEnd = last ? quadRowBase : (fullRows ? colEnd & ~31u : colEnd);
         int32_t mMax = rowValid ? aux->mMaxInitial : -1;
         uint32_t count = 0, logCount = 0;
         bool haveState = seg == 0u;
@@ -773,7 +779,7 @@ fsp4ScanMatrixKernel(Fsp4Args args)
         for (;;) {
             if (at < commonEnd) {
                 at = scanTilesMatrix<IDENTITY>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, at, commonEnd,
-                                               rowFragmentBlock, kMatrixBits - 2.f * float(mMax), row, rowValid, lane, myLog,
+                                               rowFragmentBlock, kMatrixBits - 2.f * float(mMax), row, rowValid && !fullRows, lane, myLog,
                                                logCapacity, logCount, emitPos, emitEnd, tiles, shared);
             }
             if (!haveState && !idle && !failed) {
@@ -821,6 +827,17 @@ fsp4ScanMatrixKernel(Fsp4Args args)
         // (a wave whose hand-off failed keeps walking with its block -- the barriers need it -- and the launch ends at
         // the next ticket)
 
+        // ---- full rows: the columns of a last, partial tile ----
+        if (fullRows && commonEnd < colEnd && !idle && !failed) {
+            uint32_t r[32];
+            const uint32_t* rp = aux->sig32 + size_t(rowValid ? row : rowBase) * 32u;
+#pragma unroll
+            for (int w = 0; w < 32; ++w) r[w] = rp[w];
+            uint32_t unusedLogCount = 0;
+            scanColumns<32, IDENTITY, false>(kernelArgs()->sig32, commonEnd, colEnd, r, row, lane, listBlock, myList, twoK, count, mMax,
+                                             myLog, logCapacity, unusedLogCount, ldsRaw);
+        }
+
         // ---- the quad's own 256 columns: the band below this wave's rows and its diagonal, as in the other kernel ----
         if (last && !idle && !failed) {
             uint32_t r[32];
@@ -844,18 +861,28 @@ fsp4ScanMatrixKernel(Fsp4Args args)
                                               emitEnd, ldsRaw);
         }
 
-        // ---- publish the state: for the next segment, for the columns' snapshots, for the inbox replay ----
+        // ---- full rows at their last segment: finish; otherwise publish the state: for the next segment, for the
+        // columns' snapshots, for the inbox replay ----
         if (!idle && !failed) {
             ArgsPtr aux2 = kernelArgs();
-            const uint64_t st = uint64_t(count) | (uint64_t(uint32_t(mMax)) << 32);
-            __hip_atomic_store(reinterpret_cast<uint64_t*>(aux2->rowState) + size_t(block) * 64u + lane, st,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (rowValid) __hip_atomic_store(aux2->snap + row, mMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0u && !last) {
-                __hip_atomic_store(aux2->segmentsDone + block, seg + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool finalSegment = seg + 1u == aux2->segments;
+            const uint32_t shardFlags = aux2->shardFlags;
+            if (fullRows && finalSegment && !(shardFlags & kShardNoFinish)) {
+                finishRows(lane, block, count, ldsRaw);
+            } else {
+                const uint64_t st = uint64_t(count) | (uint64_t(uint32_t(mMax)) << 32);
+                __hip_atomic_store(reinterpret_cast<uint64_t*>(aux2->rowState) + size_t(block) * 64u + lane, st,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // a full row's snapshot stays "never emit to this column" unless the sharded scan asks for it
+                if (rowValid && (!fullRows || (shardFlags & kShardPublishAll))) {
+                    __hip_atomic_store(aux2->snap + row, mMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0u && !(fullRows ? finalSegment : last)) {
+                    __hip_atomic_store(aux2->segmentsDone + block, seg + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     }
@@ -1395,7 +1422,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         if (firstTriangle > rowBlocks) firstTriangle = rowBlocks;
         table[sIdx] = uint32_t(tickets);
         table[segments + 1u + sIdx] = firstTriangle;
-        tickets += fullRowBlocks + (matrix ? 0u : rowBlocks - firstTriangle);
+        tickets += matrix ? 0u : fullRowBlocks + (rowBlocks - firstTriangle);         // the matrix kernel takes everything
         if (tickets >= 0xffffffffull) return hipErrorInvalidValue;
     }
     table[segments] = uint32_t(tickets);
@@ -1423,7 +1450,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
             if (firstQuad > rowBlocks) firstQuad = rowBlocks;
             tableMatrix[sIdx] = uint32_t(ticketsMatrix);
             tableMatrix[segmentsMatrix + 1u + sIdx] = firstQuad;
-            ticketsMatrix += (rowBlocks - firstQuad + 3u) / 4u;
+            ticketsMatrix += fullRowBlocks / 4u + (rowBlocks - firstQuad + 3u) / 4u;       // full-row quads, then the triangle's
             if (ticketsMatrix >= 0xffffffffull) return hipErrorInvalidValue;
         }
         tableMatrix[segmentsMatrix] = uint32_t(ticketsMatrix);
@@ -1490,7 +1517,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         if (e != hipSuccess) return e;
     }
     if (matrix) {
-        // the full-row blocks are done (their launch above); now the triangle on the matrix cores
+        // full-row quads and triangle quads in one launch of the matrix kernel
         e = hipMemcpyAsync(ws + layout.tableMatrix, tableMatrix, (2u * segmentsMatrix + 2u) * 4u, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
         e = hipMemsetAsync(args.control, 0, 4u, stream);                 // the ticket; the error word stays
@@ -1551,8 +1578,8 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     {
         float ms = -1.0f;
         if (!timing[0] || hipEventElapsedTime(&ms, timing[0], timing[1]) != hipSuccess) ms = -1.0f;
-        double steps = double(fullRowBlocks) * double(cellCount);       // (wave, column) steps of the v_xor/v_bcnt code
-        double matrixPairs = 0.0;
+        double steps = matrix ? 0.0 : double(fullRowBlocks) * double(cellCount);       // (wave, column) steps of the v_xor/v_bcnt code
+        double matrixPairs = matrix ? 64.0 * double(fullRowBlocks) * double(cellCount) : 0.0;
         for (uint32_t b = fullRowBlocks; b < rowBlocks; ++b) {
             const uint64_t end = uint64_t(b) * 64u + 64u;
             const uint64_t quadBase = matrix ? uint64_t(b & ~3u) * 64u : 0u;      // the matrix cores take the columns below the quad
@@ -1789,10 +1816,11 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
         if (slotCount == 0) return hipSuccess;
         const size_t matrixLdsOffset = (lds + 15u) & ~size_t(15);
         const size_t matrixLds = matrixLdsOffset + 4u * kMatrixTileWords * 16u + 64u;
-        if (phase == 1 && paddedDw == 32u && wavesPerBlock == 4u && M % 256u == 0u && matrixLds <= 150u * 1024u &&
+        if (paddedDw == 32u && wavesPerBlock == 4u && M % 256u == 0u && matrixLds <= 150u * 1024u &&
             envNumber("EM2_SCAN_MATRIX", 1) != 0) {
-            // the rows beyond the prefix against the prefix columns: all of it below the rows, so all of it for the matrix
-            // cores (fsp4ScanMatrixKernel over quads of slots; no quad ever reaches its own columns here)
+            // Phase 1, the rows beyond the prefix against the prefix columns: all of it below the rows, so all of it for the
+            // matrix cores (fsp4ScanMatrixKernel over quads of slots; no quad ever reaches its own columns here).  Phase 0,
+            // the prefix rows against the prefix columns from both sides: the same kernel's full-row items.
             uint64_t segments = M / 16384u;          // long segments: an item starts with 32 KB of row fragments per wave
             if (segments > kMatrixMaxSegments) segments = kMatrixMaxSegments;
             if (segments < 1) segments = 1;
@@ -1812,9 +1840,9 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             args.columnsPerSegment = cps;
             args.localBlockBase = slotBase;
             args.rowBlocks = slotBase + slotCount;
-            args.fullRowBlocks = 0u;
+            args.fullRowBlocks = phase == 0 ? slotCount : 0u;
             args.totalTickets = uint32_t(tickets);
-            e = hipMemsetAsync(c + stateBytes, 0, doneBytes + 4u, stream);
+            e = hipMemsetAsync(c + stateBytes, 0, doneBytes + (phase == 0 ? 256u : 4u), stream);
             if (e != hipSuccess) return e;
             e = hipMemcpyAsync(ws + plan.offTable, table, (2u * segments + 2u) * 4u, hipMemcpyHostToDevice, stream);
             if (e != hipSuccess) return e;
