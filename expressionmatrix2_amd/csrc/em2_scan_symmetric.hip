@@ -624,10 +624,10 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
             const FragmentWord4* tile = tiles + (2u * pair + uint32_t(sub)) * kMatrixTileWords;
             // column fragments four k-steps ahead of their MFMAs (the LDS latency of a read is two MFMA pairs long)
             FragmentWord4 ahead[4];
-    #pragma unroll
+#pragma unroll
             for (int s = 0; s < 4; s++) ahead[s] = tile[s * 64 + int(lane)];
             __builtin_amdgcn_s_setprio(2);          // the SIMD's other wave is in its column tests: MFMAs first
-    #pragma unroll
+#pragma unroll
             for (int s = 0; s < int(kMatrixSteps); s++) {
                 const FragmentWord4 a = ahead[s & 3];
                 if (s + 4 < int(kMatrixSteps)) ahead[s & 3] = tile[(s + 4) * 64 + int(lane)];
@@ -639,7 +639,7 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
             }
             __builtin_amdgcn_s_setprio(0);
             // lane = row: acc0[i] <- column (i&3) + 8*(i>>2), acc1[i] <- that + 4
-    #pragma unroll
+#pragma unroll
             for (int i = 0; i < 16; i++) {
                 const auto swapped = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[i]), __float_as_uint(acc1[i]), false, false);
                 acc0[i] = __uint_as_float(swapped[0]);
@@ -649,21 +649,23 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
             // in which something passes looks at its columns one by one (a branch per column cost more than the compares:
             // 1.6 -> 2.4 * 10^12 pairs/s in tools/ubench_mfma_pairs.hip, where nothing ever passes and groups are 8 wide; here
             // about two events per tile make 4 the best width).
-    #pragma unroll
+#pragma unroll
             for (int g = 0; g < 32 / kColumnsPerBranch; g++) {
                 float columnDots[kColumnsPerBranch];
                 bool any = false;
-    #pragma unroll
+#pragma unroll
                 for (int w = 0; w < kColumnsPerBranch; w++) {
-                    const int c = kColumnsPerBranch * g + w; const float dot = (c & 7) < 4 ? acc0[4 * (c >> 3) + (c & 7)] : acc1[4 * (c >> 3) + (c & 7) - 4];
+                    const int c = kColumnsPerBranch * g + w;       // column c sits in acc0 / acc1 as the swaps left it
+                    const float dot = (c & 7) < 4 ? acc0[4 * (c >> 3) + (c & 7)] : acc1[4 * (c >> 3) + (c & 7) - 4];
                     columnDots[w] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(columnDotLane), c));
                     // min(rowDot, columnDot) as one v_med3_f32 (fminf would canonicalise both inputs first)
                     any |= dot >= __builtin_amdgcn_fmed3f(rowDot, columnDots[w], -INFINITY);
                 }
                 if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
-    #pragma unroll
+#pragma unroll
                 for (int w = 0; w < kColumnsPerBranch; w++) {
-                    const int c = kColumnsPerBranch * g + w; const float dot = (c & 7) < 4 ? acc0[4 * (c >> 3) + (c & 7)] : acc1[4 * (c >> 3) + (c & 7) - 4];
+                    const int c = kColumnsPerBranch * g + w;       // column c sits in acc0 / acc1 as the swaps left it
+                    const float dot = (c & 7) < 4 ? acc0[4 * (c >> 3) + (c & 7)] : acc1[4 * (c >> 3) + (c & 7) - 4];
                     const float columnDot = columnDots[w];
                     if (__builtin_amdgcn_ballot_w64(dot >= __builtin_amdgcn_fmed3f(rowDot, columnDot, -INFINITY)) != 0ull) {
                         const uint32_t col = tileBase + uint32_t(c);
