@@ -577,7 +577,14 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
     clock.stage("adjacency");
 
     const uint64_t initialEntries = 2 * slots + 8ull * vertexCount;
-    const uint64_t arenaCapacity = initialEntries + std::max<uint64_t>(initialEntries, 1ull << 20);
+    // Tables only grow (the reference never removes an entry either) and a table that fills up moves to the tail, so
+    // the tail is sized generously and, should a graph whose labels keep churning outgrow it anyway, the whole run is
+    // repeated with four times the tail (the algorithm is deterministic).  EM2_LABEL_ARENA_TAIL (entries) is a test knob.
+    uint64_t arenaTail = std::max<uint64_t>(initialEntries, 1ull << 20);
+    if (const char* v = getenv("EM2_LABEL_ARENA_TAIL")) {
+        if (atoll(v) >= 0) arenaTail = uint64_t(atoll(v));
+    }
+    uint64_t arenaCapacity = initialEntries + arenaTail;
     Buffer dLabels, dState, dPositions, dOrder, dMeta, dArena, dControl, dScratch;
     EM2_TRY(dLabels.allocate(4 * size_t(vertexCount) * sizeof(uint32_t)));
     EM2_TRY(dState.allocate(size_t(vertexCount) * sizeof(uint64_t)));
@@ -610,6 +617,7 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
     std::vector<uint32_t> shuffled[2];
     clock.stage("allocate");
 
+    int arenaGrowths = 0;
     for (int attempt = 0;; ++attempt) {
         initialTablesKernel<<<grid, block, 0, stream>>>(vertexCount, dOffsets.as<uint64_t>(), dNeighbour.as<uint32_t>(),
                                                         dWeight.as<float>(), dCells.as<uint32_t>(), dMeta.as<TableMeta>(),
@@ -679,6 +687,23 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
         if (failure == 1 && ticketBatch == 0 && attempt == 0) {
             if (clock.on) fprintf(stderr, "[em2 timing]   label propagation: the strided schedule timed out, repeating with the ticket\n");
             ticketBatch = 4;
+            continue;
+        }
+        if (failure == 2 && arenaGrowths < 6) {
+            ++arenaGrowths;
+            arenaTail = std::max<uint64_t>(arenaTail, 1ull << 16) * 4u;
+            arenaCapacity = initialEntries + arenaTail;
+            if (clock.on) fprintf(stderr, "[em2 timing]   label propagation: tables outgrew the arena, repeating with %llu entries\n",
+                                  (unsigned long long)arenaCapacity);
+            (void)hipFree(dArena.p);
+            dArena.p = nullptr;
+            const hipError_t grown = dArena.allocate(arenaCapacity * sizeof(TableEntry));
+            if (grown != hipSuccess) {
+                *iterationCount = iterations;
+                *error = failure;           // no memory for a larger arena: report the exhaustion
+                (void)hipGetLastError();
+                return hipSuccess;
+            }
             continue;
         }
         *iterationCount = iterations;

@@ -113,3 +113,14 @@ def test_ticket_schedule_matches_too(lib, oracle, monkeypatch, batch):
     got, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim)
     expected, expected_iterations = oracle.label_propagation(cells, v0, v1, sim)
     assert iterations == expected_iterations and np.array_equal(got, expected)
+
+
+def test_tables_that_outgrow_the_arena_restart_with_a_larger_one(lib, oracle, monkeypatch):
+    # EM2_LABEL_ARENA_TAIL=0: no room at all for a table to move to; the run notices, takes a larger arena and starts
+    # again (twice here), with the same labels at the end.
+    monkeypatch.setenv("EM2_LABEL_ARENA_TAIL", "0")
+    rng = np.random.default_rng(5)
+    cells, v0, v1, sim = fast_graph(rng, 8000, 12, 10, 2, 400, 50, 4)
+    got, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim, 231, 3, 100)
+    expected, expected_iterations = oracle.label_propagation(cells, v0, v1, sim, 231, 3, 100)
+    assert iterations == expected_iterations and np.array_equal(got, expected)
