@@ -25,7 +25,8 @@
 // Layout: adjacency CSR in add_edge order (what out_edges() of adjacency_list<listS,listS,undirectedS> walks);
 // tables in one arena of (cluster, weight), 2*degree+8 entries per vertex to start with, relocated to the bump-
 // allocated tail when full (entries are never removed, as in the reference); labels of the last four iterations;
-// for vertices of degree > 64 the candidate events are staged in a scratch area addressed like the adjacency.
+// for vertices of degree > 64 the candidate events are staged in a scratch area addressed like the adjacency and
+// ordered by a wave-level bitonic sort.
 
 #include "em2_device.h"
 #include "em2_select_wave.h"
@@ -91,6 +92,8 @@ struct ClusterArgs {
     uint32_t ticketBatch;       // 0: wave w of W takes positions w, w+W, ..; else positions drawn from the ticket, this many at a time
     Candidate* scratchA;
     Candidate* scratchB;
+    uint64_t* sortKeys;         // 4 x adjacency slots: (event time << 32 | list index) of either list, padded to a power of two
+    uint64_t slots;
 };
 
 __device__ __forceinline__ uint32_t uniform(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
@@ -214,6 +217,28 @@ __device__ uint32_t labelAfterTurn(const ClusterArgs& args, uint32_t vertex, boo
         }
     }
     return uniform(uint32_t(s));
+}
+
+// Bitonic sort of n (a power of two) 64-bit keys in global memory by one wave: the candidate events of a vertex of
+// large degree, by event time.  (The repeated minimum search this replaces was quadratic: a hub of degree 3000 took
+// half a second per turn.)  A phase's pairs are disjoint, and a wave's loads follow its stores in order.
+__device__ void sortKeysByWave(uint64_t* keys, uint32_t n, uint32_t lane)
+{
+    for (uint32_t k = 2u; k <= n; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+            for (uint32_t i = lane; i < n; i += 64u) {
+                const uint32_t partner = i ^ j;
+                if (partner > i) {
+                    const uint64_t x = keys[i], y = keys[partner];
+                    const bool ascending = (i & k) == 0u;
+                    if ((x > y) == ascending) {
+                        keys[i] = y;
+                        keys[partner] = x;
+                    }
+                }
+            }
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
@@ -349,32 +374,18 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
             for (int phase = 0; phase < 2 && !error; ++phase) {
                 Candidate* list = phase ? listB : listA;
                 const uint32_t count = phase ? countB : countA;
-                while (!error) {
-                    uint32_t bestKey = kNone, bestIndex = kNone;
-                    for (uint32_t c = 0; c < count; c += 64u) {
-                        const uint32_t i = c + lane;
-                        if (i < count) {
-                            const uint32_t key = list[i].key;
-                            if (key < bestKey) {
-                                bestKey = key;
-                                bestIndex = i;
-                            }
-                        }
-                    }
-                    for (int offset = 32; offset; offset >>= 1) {
-                        const uint32_t otherKey = uint32_t(__shfl_xor(int(bestKey), offset));
-                        const uint32_t otherIndex = uint32_t(__shfl_xor(int(bestIndex), offset));
-                        if (otherKey < bestKey || (otherKey == bestKey && otherIndex < bestIndex)) {
-                            bestKey = otherKey;
-                            bestIndex = otherIndex;
-                        }
-                    }
-                    if (uniform(bestKey) == kNone) break;
-                    const uint32_t index = uniform(bestIndex);
+                if (count == 0u) continue;
+                // order of application = event time; equal times (parallel edges) keep the order of the adjacency
+                uint64_t* keys = args.sortKeys + (phase ? 2u * args.slots : 0u) + 2u * base;
+                uint32_t padded = 1u;
+                while (padded < count) padded <<= 1;
+                for (uint32_t i = lane; i < padded; i += 64u) keys[i] = i < count ? (uint64_t(list[i].key) << 32) | i : ~0ull;
+                sortKeysByWave(keys, padded, lane);
+                for (uint32_t n = 0; n < count && !error; ++n) {
+                    const uint32_t index = uniform(uint32_t(keys[n]));
                     const Candidate candidate = list[index];
                     const uint32_t a = uniform(candidate.a), b = uniform(candidate.b);
                     const float weight = uniform(candidate.weight);
-                    if (lane == 0u) list[index].key = kNone;
                     if (phase == 0) {
                         if (!applyEvent(t, args, a, b, weight, lane)) error = 2;
                     } else {
@@ -593,7 +604,11 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
     EM2_TRY(dMeta.allocate(size_t(vertexCount) * sizeof(TableMeta)));
     EM2_TRY(dArena.allocate(arenaCapacity * sizeof(TableEntry)));
     EM2_TRY(dControl.allocate(4 * sizeof(uint32_t) + sizeof(unsigned long long)));
-    if (maxDegree > 64u) EM2_TRY(dScratch.allocate(2 * slots * sizeof(Candidate)));
+    Buffer dSortKeys;
+    if (maxDegree > 64u) {
+        EM2_TRY(dScratch.allocate(2 * slots * sizeof(Candidate)));
+        EM2_TRY(dSortKeys.allocate(4 * slots * sizeof(uint64_t)));
+    }
 
     int device = 0, computeUnits = 0;
     EM2_TRY(hipGetDevice(&device));
@@ -666,6 +681,8 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
             args.ticketBatch = ticketBatch;
             args.scratchA = dScratch.as<Candidate>();
             args.scratchB = dScratch.as<Candidate>() + slots;
+            args.sortKeys = dSortKeys.as<uint64_t>();
+            args.slots = slots;
             labelPropagationKernel<<<grid, block, 0, stream>>>(args);
             EM2_TRY(hipGetLastError());
             ++iterations;
