@@ -173,7 +173,7 @@ mfmaPairsKernel(const v4i* __restrict__ fragments, uint32_t cells, const float* 
 // scan, and every column is then tested against max(row bound, column bound) exactly as there: one v_min, one v_cmp,
 // one branch.  DIRECT: each wave loads the column fragments itself (no LDS, no barrier: waves stay independent, which
 // is what the product's ticket / hand-off scheme needs); otherwise the block shares them through LDS.
-template <bool DIRECT, bool GROUPED = false>
+template <bool DIRECT, bool GROUPED = false, bool READLANE = false>
 __global__ void __launch_bounds__(256, 2)
 mfmaRowLaneKernel(const v4i* __restrict__ fragments, uint32_t cells, const float* __restrict__ minDot, uint32_t limit,
                   unsigned long long* __restrict__ result)
@@ -232,13 +232,18 @@ mfmaRowLaneKernel(const v4i* __restrict__ fragments, uint32_t cells, const float
         const float* columnBounds = minDot + cb * 32u;       // wave-uniform: scalar loads
         if (GROUPED) {
             // one branch per 8 columns: the per-column compares are OR-ed as lane masks (scalar unit)
+            // READLANE: the column bounds come from a per-lane register by v_readlane (as in the product, whose bounds are
+            // integers in memory) instead of scalar loads of ready-made floats
+            const float boundLane = READLANE ? minDot[cb * 32u + (lane & 31u)] : 0.f;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 bool any = false;
 #pragma unroll
                 for (int w = 0; w < 8; w++) {
                     const float dot = w < 4 ? acc0[4 * g + w] : acc1[4 * g + w - 4];
-                    any |= dot >= __builtin_amdgcn_fmed3f(rowBound, columnBounds[8 * g + w], -INFINITY);
+                    const float columnBound = READLANE ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(boundLane), 8 * g + w))
+                                                       : columnBounds[8 * g + w];
+                    any |= dot >= __builtin_amdgcn_fmed3f(rowBound, columnBound, -INFINITY);
                 }
                 if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
 #pragma unroll
@@ -449,18 +454,19 @@ int main(int argc, char** argv)
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         printf("mfma fp4 + bound test: %.3f ms, %.3g ordered pairs/s\n", ms, pairs / ms * 1e3);
     }
-    for (int direct = 0; direct < 3; direct++) {
+    for (int direct = 0; direct < 4; direct++) {
         for (int rep = 0; rep < 3; rep++) {
             CHECK(hipMemset(dResult + 2, 0, 2 * sizeof(unsigned long long)));
             CHECK(hipEventRecord(e0));
             if (direct == 1) mfmaRowLaneKernel<true><<<cells / 256u, 256>>>(dFragments, cells, minDot, limit, dResult + 2);
             else if (direct == 2) mfmaRowLaneKernel<false, true><<<cells / 256u, 256>>>(dFragments, cells, minDot, limit, dResult + 2);
+            else if (direct == 3) mfmaRowLaneKernel<false, true, true><<<cells / 256u, 256>>>(dFragments, cells, minDot, limit, dResult + 2);
             else mfmaRowLaneKernel<false><<<cells / 256u, 256>>>(dFragments, cells, minDot, limit, dResult + 2);
             CHECK(hipEventRecord(e1));
             CHECK(hipEventSynchronize(e1));
             CHECK(hipEventElapsedTime(&ms, e0, e1));
             printf("mfma fp4, lane = row, per-column test, columns %s: %.3f ms, %.3g ordered pairs/s\n",
-                   direct == 1 ? "loaded by each wave" : direct == 2 ? "through LDS, one branch per 8 columns" : "through LDS", ms, pairs / ms * 1e3);
+                   direct == 1 ? "loaded by each wave" : direct == 2 ? "through LDS, one branch per 8 columns" : direct == 3 ? "through LDS, one branch per 8 columns, bounds by v_readlane" : "through LDS", ms, pairs / ms * 1e3);
         }
         unsigned long long check[2];
         CHECK(hipMemcpy(check, dResult + 2, sizeof(check), hipMemcpyDeviceToHost));
