@@ -64,6 +64,40 @@ def parse_args():
     return p.parse_args()
 
 
+def parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host, check_rows):
+    """The result of the pipeline's LAST step against the CPU oracle, bit for bit: the signatures of a few of this
+    rank's cells and sampled SimilarPairs rows this rank owns against all columns.  Exits on a difference.
+    Returns (signature cells checked, rows checked)."""
+    C, G, L, k, thr = pipe.cell_count, pipe.gene_count, pipe.lsh_count, pipe.k, pipe.thr
+    if not pipe.rows:
+        return 0, 0
+    sample = min(64, pipe.rows)
+    t_h, g_h, c_h = synthetic.csr_to_host(toc[:sample + 1], data[:int(toc[sample].item())])
+    expect = oracle.compute_signatures(t_h, g_h, c_h, G, vectors_host, L)
+    got = sig_host[pipe.row_begin:pipe.row_begin + sample]
+    if not np.array_equal(expect, got):
+        raise SystemExit("PARITY FAILURE: signatures differ from the oracle")
+    rows_checked = 0
+    ranges = pipe.owned_ranges()
+    span = max(1, check_rows // 3)
+    picks = [ranges[i] for i in sorted(set([0, len(ranges) // 2, len(ranges) - 1]))] if ranges else []
+    for r_begin, r_end in picks:
+        for begin in sorted(set([r_begin, max(r_begin, (r_begin + r_end) // 2 - span // 2), max(r_begin, r_end - span)])):
+            end = min(r_end, begin + span)
+            if end <= begin:
+                continue
+            pairs, used = pipe.results_for(begin, end)
+            cell, sim, oused = oracle.find_similar_pairs4_rows(sig_host, L, k, thr, begin, end)
+            ok = (np.array_equal(used, oused) and np.array_equal(pairs["cell"], cell) and
+                  np.array_equal(pairs["similarity"].view(np.uint32), sim.view(np.uint32)))
+            if not ok:
+                raise SystemExit("PARITY FAILURE: SimilarPairs rows %d..%d differ from the oracle" % (begin, end))
+            rows_checked += end - begin
+            if len(picks) > 1:
+                break           # block-sized ranges: one sample each
+    return sample, rows_checked
+
+
 def main():
     args = parse_args()
     import torch
@@ -76,6 +110,7 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+        raise SystemExit("bench.py --gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path to benchmark)")
     # Dry-run aid for boxes with fewer GPUs than ranks (EM2_BENCH_SHARE_DEVICE=1 EM2_BENCH_BACKEND=gloo): all ranks
@@ -123,33 +158,8 @@ def main():
     pipe.step()
     torch.cuda.synchronize()
     sig_host = pipe.full_sig[:C].cpu().numpy().view(np.uint64)
-    if pipe.rows:
-        # projection: a few of this rank's cells
-        sample = min(64, pipe.rows)
-        t_h, g_h, c_h = synthetic.csr_to_host(toc[:sample + 1], data[:int(toc[sample].item())])
-        expect = oracle.compute_signatures(t_h, g_h, c_h, G, vectors_host, L)
-        got = sig_host[pipe.row_begin:pipe.row_begin + sample]
-        if not np.array_equal(expect, got):
-            raise SystemExit("PARITY FAILURE: signatures differ from the oracle")
-        check["signature_cells"] = sample
-        # scan: sampled rows this rank owns against all columns
-        ranges = pipe.owned_ranges()
-        span = max(1, args.check_rows // 3)
-        picks = [ranges[i] for i in sorted(set([0, len(ranges) // 2, len(ranges) - 1]))] if ranges else []
-        for r_begin, r_end in picks:
-            for begin in sorted(set([r_begin, max(r_begin, (r_begin + r_end) // 2 - span // 2), max(r_begin, r_end - span)])):
-                end = min(r_end, begin + span)
-                if end <= begin:
-                    continue
-                pairs, used = pipe.results_for(begin, end)
-                cell, sim, oused = oracle.find_similar_pairs4_rows(sig_host, L, k, thr, begin, end)
-                ok = (np.array_equal(used, oused) and np.array_equal(pairs["cell"], cell) and
-                      np.array_equal(pairs["similarity"].view(np.uint32), sim.view(np.uint32)))
-                if not ok:
-                    raise SystemExit("PARITY FAILURE: SimilarPairs rows %d..%d differ from the oracle" % (begin, end))
-                check["fsp4_rows"] += end - begin
-                if len(picks) > 1:
-                    break           # block-sized ranges: one sample each
+    check["signature_cells"], check["fsp4_rows"] = parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host,
+                                                               args.check_rows)
 
     # ---- warmup + timed steps ----
     for _ in range(args.warmup):
@@ -175,6 +185,13 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     pipe.check()                 # the scan's inter-wave hand-offs all completed (raises otherwise)
+    # The hand-off, speculation and inbox paths of the scan depend on timing, so the result of the LAST timed step is
+    # put through the same gate again: same signatures as before, sampled rows bit-identical to the oracle.
+    sig_after = pipe.full_sig[:C].cpu().numpy().view(np.uint64)
+    if not np.array_equal(sig_after, sig_host):
+        raise SystemExit("PARITY FAILURE: the signatures of the last timed step differ from the first pass")
+    check["after_timing_signature_cells"], check["after_timing_rows"] = parity_gate(
+        pipe, oracle, synthetic, sig_after, toc, data, vectors_host, args.check_rows)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

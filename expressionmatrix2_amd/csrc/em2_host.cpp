@@ -463,10 +463,12 @@ void Matrix::removeSimilarPairs(const std::string& similarPairsName) const
 // SimilarPairs / Lsh files
 // ---------------------------------------------------------------------------------------------------------
 
+static const char* const kTemporarySuffix = ".tmp";
+
 SimilarPairsWriter::SimilarPairsWriter(const std::string& directoryName, const std::string& similarPairsName,
                                        const std::string& geneSetName, const std::string& cellSetName, size_t k,
                                        uint32_t cellCount)
-    : cellCount_(cellCount)
+    : cellCount_(cellCount), finished_(false)
 {
     // accessGeneSet / accessCellSet (SimilarPairs.cpp:97-113)
     GeneSet genes;
@@ -478,16 +480,39 @@ SimilarPairsWriter::SimilarPairsWriter(const std::string& directoryName, const s
     if (!isSorted(static_cast<const uint32_t*>(cells.data()), cells.objectCount())) fail(EM2_ERROR_RUNTIME, "Cell set " + cellSetName + " is not sorted.");
     if (cells.objectCount() != cellCount) fail(EM2_ERROR_RUNTIME, "SimilarPairs: cell count is not the size of cell set " + cellSetName);
 
-    const std::string base = directoryName + "/SimilarPairs-" + similarPairsName;
-    infoFile_.createNew(base + "-Info", true, sizeof(SimilarPairsInfoRecord), 1);
+    // The reference builds its SimilarPairs object only after the pair loop has succeeded
+    // (ExpressionMatrixLsh.cpp:278-285); here the files exist while the device works (its result lands straight in
+    // the mapped -Pairs file), so they carry temporary names until finish(): a call that fails leaves an existing
+    // object of the same name untouched.
+    base_ = directoryName + "/SimilarPairs-" + similarPairsName;
+    const std::string base = base_;
+    removeStale();
+    infoFile_.createNew(base + "-Info" + kTemporarySuffix, true, sizeof(SimilarPairsInfoRecord), 1);
     SimilarPairsInfoRecord* info = static_cast<SimilarPairsInfoRecord*>(infoFile_.data());
     info->k = k;
     setStaticString(info->geneSetName, geneSetName);
     info->geneSetHash = hashOf(genes.globalIds, sizeof(uint32_t));
     setStaticString(info->cellSetName, cellSetName);
     info->cellSetHash = hashOf(cells, sizeof(uint32_t));
-    pairsFile_.createNew(base + "-Pairs", false, sizeof(em2_pair), k * size_t(cellCount));
-    cellInfoFile_.createNew(base + "-CellInfo", false, sizeof(CellInfoRecord), cellCount);
+    pairsFile_.createNew(base + "-Pairs" + kTemporarySuffix, false, sizeof(em2_pair), k * size_t(cellCount));
+    cellInfoFile_.createNew(base + "-CellInfo" + kTemporarySuffix, false, sizeof(CellInfoRecord), cellCount);
+}
+
+void SimilarPairsWriter::removeStale() const
+{
+    for (const char* part : {"-Info", "-Pairs", "-CellInfo"}) {
+        const std::string path = base_ + part + kTemporarySuffix;
+        if (fileExists(path)) ::unlink(path.c_str());
+    }
+}
+
+SimilarPairsWriter::~SimilarPairsWriter()
+{
+    if (finished_) return;
+    infoFile_.close();
+    pairsFile_.close();
+    cellInfoFile_.close();
+    removeStale();
 }
 
 em2_pair* SimilarPairsWriter::pairs() { return static_cast<em2_pair*>(pairsFile_.data()); }
@@ -500,6 +525,14 @@ void SimilarPairsWriter::finish(const uint32_t* usedCount)
         ci[c].lowestSimilarityIndex = 0xffffffffu;           // constructor values, never updated by copy (:36-40)
         ci[c].lowestSimilarity = FLT_MAX;
     }
+    // Info last: a reader opens it first (SimilarPairs.cpp:49-52)
+    for (const char* part : {"-Pairs", "-CellInfo", "-Info"}) {
+        const std::string final = base_ + part;
+        if (::rename((final + kTemporarySuffix).c_str(), final.c_str()) != 0) {
+            fail(EM2_ERROR_RUNTIME, "Error renaming " + final + kTemporarySuffix + " to " + final);
+        }
+    }
+    finished_ = true;
 }
 
 void writeSimilarPairs(const std::string& directoryName, const std::string& similarPairsName,

@@ -121,11 +121,15 @@ class SimilarPairsWriter {
 public:
     SimilarPairsWriter(const std::string& directoryName, const std::string& similarPairsName, const std::string& geneSetName,
                        const std::string& cellSetName, size_t k, uint32_t cellCount);
+    ~SimilarPairsWriter();                    // not finished: the temporary files go away, an existing object stays
     em2_pair* pairs();
-    void finish(const uint32_t* usedCount);
+    void finish(const uint32_t* usedCount);   // fills CellInfo, then renames the three files into place
 private:
+    void removeStale() const;
     MappedFile infoFile_, pairsFile_, cellInfoFile_;
     uint32_t cellCount_;
+    std::string base_;
+    bool finished_;
 };
 
 void writeSimilarPairs(const std::string& directoryName, const std::string& similarPairsName,

@@ -5,6 +5,7 @@
 // the CDNA4 mapping of the column loop, em2_scan_common.h for the shared device code.
 
 #include "em2_scan_common.h"
+#include "em2_matrix_step_asm.h"
 
 #include <vector>
 
@@ -698,7 +699,376 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
     return colEnd;
 }
 
-template <bool IDENTITY>
+// =========================================================================================================
+// The same walk with the tile step in hand-scheduled assembly (em2_matrix_step_asm.h, written by
+// tools/gen_matrix_step_asm.py) -- the form the kernels use; scanTilesMatrix above is kept for A/B runs
+// (EM2_MATRIX_WALK=0).  What changes against it:
+//  * the 32 MFMAs of a tile are fed through a four-deep ring of column fragments with counted lgkmcnt waits: one
+//    wave alone keeps the matrix pipe of its SIMD busy (the compiler's schedule of the loop above waits for
+//    lgkmcnt(0) in front of every second k-step);
+//  * the results stay in the accumulator layout -- lane l, register i of accumulator a = row 32a + (l & 31), column
+//    8 (i >> 2) + 4 (l >> 5) + (i & 3) -- and are tested there against min(row bound, column bound): no
+//    v_permlane32_swap, no v_readlane; the column bounds of a tile travel through 128 bytes of LDS per wave and come
+//    back as four 16-byte reads per lane half; the row state the events need (bound, validity, log count) is kept in
+//    that layout for the length of the walk;
+//  * two accumulator sets: the step of tile t carries the test of tile t-1 between its MFMAs (2 VALU + 1 SALU per
+//    result, 6 per k-step), so a wave never leaves the matrix pipe idle for its column tests; only groups of 8
+//    columns x 64 rows in which something passed are looked at again, by the compiler's code (matrixEvents).
+// Everything the step touches is pinned to physical registers by the asm constraints (register map in the generator).
+// A row's log must list its columns in ascending order (the replay offers them in that order): within a group the
+// lower lane half holds columns 8q .. 8q+3 and the upper half 8q+4 .. 8q+7, so the events of a group are logged half
+// by half.  The walk may stop only at a pair boundary, where one tile is still untested: the stop rule therefore
+// keeps room for three tiles (96 entries) instead of two.
+// =========================================================================================================
+
+// LDS byte address of a pointer into the block's dynamic LDS
+template <typename T>
+__device__ __forceinline__ uint32_t ldsAddress(T* p)
+{
+    return uint32_t(uintptr_t((__attribute__((address_space(3))) char*)(p)));
+}
+
+typedef __attribute__((address_space(3))) float* LdsFloatPtr;
+typedef __attribute__((address_space(3))) FragmentWord4* LdsFragmentPtr;
+typedef volatile __attribute__((address_space(3))) uint32_t* LdsWordPtr;
+typedef const __attribute__((address_space(1))) FragmentWord4* GlobalFragmentPtr;
+typedef const __attribute__((address_space(1))) int32_t* GlobalIntPtr;
+typedef __attribute__((address_space(1))) uint64_t* GlobalWord64Ptr;
+
+constexpr uint32_t kMatrixLogMargin = 96u;
+
+typedef const __attribute__((address_space(3))) int32_t* LdsIntPtr;
+
+// LDS byte address -> pointer (32 bits on the device; the detour keeps the host pass of the compiler quiet)
+template <typename P>
+__device__ __forceinline__ P ldsPointer(uint32_t address)
+{
+    return (P)(uintptr_t)address;
+}
+
+// Per-wave LDS block of the walk (byte offsets).  The per-lane state lives here and not in registers: see the
+// register discussion in tools/gen_matrix_step_asm.py.
+constexpr uint32_t kWalkRowDot = 0u;            // float[64]: bound of row r as a dot product (1024 - 2 mMax)
+constexpr uint32_t kWalkLogCount = 256u;        // uint32[64]: entries in row r's log
+constexpr uint32_t kWalkWords = 512u;           // uint32[16] wave-uniform words, indices below
+constexpr uint32_t kWalkBounds = 576u;          // float[4][32]: column bounds of the four tile buffers (as dot products)
+constexpr uint32_t kWalkSnapStage = 1088u;      // int32[2][64]: the published cut-offs of a pair of tiles, as loaded
+constexpr uint32_t kMatrixWalkLdsBytes = 1600u;
+enum : uint32_t { kWordEmitPos = 0, kWordEmitEnd, kWordValidLo, kWordValidHi, kWordRowBase, kWordLogCapacity, kWordLogBaseLo,
+                  kWordLogBaseHi, kWordRowBits, kWordInboxLo, kWordInboxHi };
+
+__device__ __forceinline__ uint32_t uniform(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    return uint64_t(uniform(uint32_t(v))) | (uint64_t(uniform(uint32_t(v >> 32))) << 32);
+}
+
+// The lane id, recomputed wherever it is used: a volatile asm is neither hoisted out of the walk's loop nor merged
+// with an earlier one, so nothing derived from it stays alive across a step or a call (where it would live in
+// scratch: the steps own the registers above v31, a callee those below).
+__device__ __forceinline__ uint32_t laneId()
+{
+    uint32_t lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    return lane;
+}
+
+// The events of the tile whose results sit in accumulator set X (IN_Y false) or Y: group q = the lanes in which a
+// result of group q passed its test.  A function of its own, all arguments wave-uniform: inlined into the walk its
+// code (which the compiler allocates as it likes) took registers of the steps -- there is no way to reserve v64..v255
+// other than not needing them -- and values of the walk that live across a call have no register to live in (the
+// steps own everything above v31, the callee everything below), so the walk keeps none: rows' bounds and log counts
+// are in the wave's LDS block.  The function itself must stay below v64 (tools/check_matrix_walk_registers.py).
+// One copy of the code serves the four groups (a run-time loop); the results are fetched from their fixed registers
+// as they are needed.  A row's log must list its columns in ascending order: within a group the lower lane half holds
+// columns 8q .. 8q+3 and the upper half 8q+4 .. 8q+7, so the row side goes half by half.
+// __builtin_amdgcn_kernarg_segment_ptr() is null outside a kernel: the kernarg pointer is an argument.
+template <bool BOTH, bool IN_Y>
+__device__ __attribute__((noinline)) void matrixEventsCall(uint64_t group0, uint64_t group1, uint64_t group2, uint64_t group3,
+                                                           uint32_t tileBaseArg, uint32_t slotArg, uint32_t walkLdsArg, const void* auxArg)
+{
+    const uint32_t walkLds = uniform(walkLdsArg);
+    const uint32_t tileBase = uniform(tileBaseArg), slot = uniform(slotArg);
+    const ArgsPtr aux = (ArgsPtr)uniform64(reinterpret_cast<uint64_t>(auxArg));
+    const uint64_t groups[4] = {uniform64(group0), uniform64(group1), uniform64(group2), uniform64(group3)};
+    const LdsFloatPtr rowDots = ldsPointer<LdsFloatPtr>(walkLds + kWalkRowDot);
+    const LdsWordPtr logCounts = ldsPointer<LdsWordPtr>(walkLds + kWalkLogCount);
+    const LdsWordPtr words = ldsPointer<LdsWordPtr>(walkLds + kWalkWords);
+    const LdsFloatPtr boundScratch = ldsPointer<LdsFloatPtr>(walkLds + kWalkBounds);
+    const uint32_t lane = laneId(), half = lane >> 5, lane31 = lane & 31u;
+    uint32_t emitPos = uniform(words[kWordEmitPos]), emitEnd = uniform(words[kWordEmitEnd]);
+    const uint64_t validRows = uint64_t(uniform(words[kWordValidLo])) | (uint64_t(uniform(words[kWordValidHi])) << 32);
+    const uint32_t row0 = uniform(words[kWordRowBase]) + lane31;
+    const uint32_t logCapacity = uniform(words[kWordLogCapacity]);
+    const GlobalWord64Ptr logBase = (GlobalWord64Ptr)(uint64_t(uniform(words[kWordLogBaseLo])) | (uint64_t(uniform(words[kWordLogBaseHi])) << 32));
+    const uint32_t rowBits = uniform(words[kWordRowBits]);
+    const GlobalWord64Ptr inbox = (GlobalWord64Ptr)(uint64_t(uniform(words[kWordInboxLo])) | (uint64_t(uniform(words[kWordInboxHi])) << 32));
+    const float rowDot[2] = {rowDots[lane31], rowDots[32u + lane31]};
+    uint32_t logCount[2] = {logCounts[lane31], logCounts[32u + lane31]};
+    const bool rowValid[2] = {((uint32_t(validRows) >> lane31) & 1u) != 0u, ((uint32_t(validRows >> 32) >> lane31) & 1u) != 0u};
+
+    // emitColumn: pool pointer and key layout in registers, the out-of-line refill through the explicit kernarg pointer
+    auto emit = [&](bool on, uint32_t target, uint32_t candidate, uint32_t m) {
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(on);
+        if (mask == 0ull) return;
+        uint32_t p = emitPos, e = emitEnd;
+        if (p > e) return;                                                      // disabled after an overflow
+        const uint32_t n = uint32_t(__builtin_popcountll(mask));
+        if (p + n > e) {
+            const uint64_t fresh = refillInboxChunk(aux->inbox, aux->inboxControl, aux->inboxCapacity, aux->inboxChunk, lane, p, e);
+            p = uniform(uint32_t(fresh));
+            e = uniform(uint32_t(fresh >> 32));
+            emitPos = p;
+            emitEnd = e;
+            if (p > e) return;
+        }
+        if (on) inbox[p + lanesBelow(mask)] = (uint64_t(target) << (13u + rowBits)) | (uint64_t(candidate) << 13u) | uint64_t(m);
+        emitPos = p + n;
+    };
+
+#pragma nounroll
+    for (uint32_t q = 0; q < 4u; q++) {
+        const uint64_t flagged = q == 0u ? groups[0] : q == 1u ? groups[1] : q == 2u ? groups[2] : groups[3];
+        if (flagged == 0ull) continue;
+        const uint32_t groupBase = tileBase + 8u * q;
+        const LdsFloatPtr bounds = boundScratch + slot * 32u + 8u * q + 4u * half;     // this lane's half: columns 8q + 4 half + 0..3
+        uint64_t rowMasks[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float dots[2];
+            if (IN_Y) { EM2_MATRIX_READ_Y(4u * q + uint32_t(j), dots[0], dots[1]); }
+            else { EM2_MATRIX_READ_X(4u * q + uint32_t(j), dots[0], dots[1]); }
+            const float columnDot = bounds[j];
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const float dot = dots[a];
+                const bool passRow = dot >= rowDot[a];
+                const bool passColumn = rowValid[a] && dot >= columnDot;
+                rowMasks[j][a] = __builtin_amdgcn_ballot_w64(passRow);
+                if (__builtin_amdgcn_ballot_w64(passColumn || (BOTH && passRow)) != 0ull) {
+                    const uint32_t col = groupBase + 4u * half + uint32_t(j);
+                    const uint32_t rowId = row0 + 32u * uint32_t(a);
+                    const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
+                    emit(passColumn, col, rowId, m);
+                    if (BOTH) emit(rowValid[a] && passRow, rowId, col, m);
+                }
+            }
+        }
+        if (BOTH) continue;
+        // the row side: ascending columns per row = lower lane half first
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if ((uint32_t(rowMasks[j][0] >> (32 * h)) | uint32_t(rowMasks[j][1] >> (32 * h))) == 0u) continue;
+                float dots[2];
+                if (IN_Y) { EM2_MATRIX_READ_Y(4u * q + uint32_t(j), dots[0], dots[1]); }
+                else { EM2_MATRIX_READ_X(4u * q + uint32_t(j), dots[0], dots[1]); }
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    const uint32_t mask = uint32_t(rowMasks[j][a] >> (32 * h));       // rows (by l & 31) with an event in this half
+                    if (mask == 0u) continue;
+                    const float dot = dots[a];
+                    if (half == uint32_t(h) && dot >= rowDot[a]) {
+                        const uint32_t col = groupBase + 4u * uint32_t(h) + uint32_t(j);
+                        const size_t at = size_t(32u * uint32_t(a) + lane31) * logCapacity + logCount[a];
+                        logBase[at] = uint64_t(col) | (uint64_t(uint32_t((kMatrixBits - dot) * 0.5f)) << 32);      // storeEntry
+                    }
+                    logCount[a] += (mask >> lane31) & 1u;            // both lanes that hold the row count it
+                }
+            }
+        }
+    }
+    if (!BOTH) {
+        logCounts[lane31] = logCount[0];                              // lanes l and l + 32 store the same values
+        logCounts[32u + lane31] = logCount[1];
+    }
+    words[kWordEmitPos] = emitPos;
+    words[kWordEmitEnd] = emitEnd;
+}
+
+// The lock-step walk over the tiles [colBegin, colEnd) with the hand-scheduled steps.  Out of line, with no vector
+// value of its own alive across a step: the steps own v32..v255.  Wave-uniform arguments arrive in vector registers
+// and are moved to the scalar file first; pointers get their address spaces back (a generic pointer would make the
+// compiler emit flat_ instructions, whose out-of-order completion would also break the counted LDS waits of the
+// steps).  LDS arguments are byte addresses.  io = {logCount, emitPos, emitEnd} of the calling lane.
+struct MatrixWalkIo {
+    uint32_t logCount, emitPos, emitEnd;
+};
+
+template <bool IDENTITY, bool BOTH = false>
+__device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* auxArg, const void* fragmentsArg, const void* snapArg,
+                                                                    uint32_t colBeginArg, uint32_t colEndArg,
+                                                                    uint32_t rowFragmentBlockArg, float rowDot, uint32_t row,
+                                                                    bool rowValid, Entry* myLog, uint32_t logCapacityArg,
+                                                                    MatrixWalkIo* io, uint32_t tilesLdsArg, uint32_t stopWordsLdsArg,
+                                                                    uint32_t walkLdsArg)
+{
+    const GlobalFragmentPtr fragments = (GlobalFragmentPtr)uniform64(reinterpret_cast<uint64_t>(fragmentsArg));
+    const GlobalIntPtr snap = (GlobalIntPtr)uniform64(reinterpret_cast<uint64_t>(snapArg));
+    const uint64_t auxBits = uniform64(reinterpret_cast<uint64_t>(auxArg));
+    const ArgsPtr aux = (ArgsPtr)auxBits;
+    const void* const auxUniform = reinterpret_cast<const void*>(auxBits);       // for the calls: out of scalar registers
+    const uint32_t colBegin = uniform(colBeginArg), colEnd = uniform(colEndArg);
+    const uint32_t rowFragmentBlock = uniform(rowFragmentBlockArg), logCapacity = uniform(logCapacityArg);
+    const uint32_t tilesLds = uniform(tilesLdsArg);
+    const LdsFragmentPtr tiles = ldsPointer<LdsFragmentPtr>(tilesLds);
+    const LdsWordPtr stopWords = ldsPointer<LdsWordPtr>(uniform(stopWordsLdsArg));
+    const uint32_t walkLds = uniform(walkLdsArg);
+    const LdsFloatPtr rowDots = ldsPointer<LdsFloatPtr>(walkLds + kWalkRowDot);
+    const LdsWordPtr logCounts = ldsPointer<LdsWordPtr>(walkLds + kWalkLogCount);
+    const LdsWordPtr words = ldsPointer<LdsWordPtr>(walkLds + kWalkWords);
+    const LdsFloatPtr boundScratch = ldsPointer<LdsFloatPtr>(walkLds + kWalkBounds);
+    const LdsIntPtr snapStage = ldsPointer<LdsIntPtr>(walkLds + kWalkSnapStage);
+    {
+        // the wave's state block
+        const uint32_t lane = laneId();
+        rowDots[lane] = rowDot;
+        logCounts[lane] = io->logCount;
+        const uint64_t valid = __builtin_amdgcn_ballot_w64(rowValid);
+        // the log of the wave's row 0: the calling lane's log is logCapacity * lane entries further on
+        const uint64_t logBase = myLog ? uniform64(reinterpret_cast<uint64_t>(myLog) - uint64_t(lane) * logCapacity * sizeof(Entry)) : 0ull;
+        const uint64_t inbox = reinterpret_cast<uint64_t>(aux->inbox);
+        if (lane == 0u) {
+            words[kWordEmitPos] = io->emitPos;
+            words[kWordEmitEnd] = io->emitEnd;
+            words[kWordValidLo] = uint32_t(valid);
+            words[kWordValidHi] = uint32_t(valid >> 32);
+            words[kWordRowBase] = row;                      // lane 0: the wave's first row
+            words[kWordLogCapacity] = logCapacity;
+            words[kWordLogBaseLo] = uint32_t(logBase);
+            words[kWordLogBaseHi] = uint32_t(logBase >> 32);
+            words[kWordRowBits] = aux->rowBits;
+            words[kWordInboxLo] = uint32_t(inbox);
+            words[kWordInboxHi] = uint32_t(inbox >> 32);
+        }
+        // the B operand: 2 x 16 fragments into their registers (v128..v255)
+#pragma unroll
+        for (int index = 0; index < 32; index++) {
+            const FragmentWord4 f = fragments[(size_t(rowFragmentBlock + uint32_t(index >> 4)) * kMatrixSteps + uint32_t(index & 15)) * 64u + lane];
+            EM2_MATRIX_SET_ROW_FRAGMENT(index, f);
+        }
+    }
+    const uint32_t waveSlot = uniform(threadIdx.x >> 6) * 64u;
+#define EM2_STAGE_TILE(tileIndex, buffer)                                                                                     \
+    do {                                                                                                                      \
+        const GlobalFragmentPtr src_ = fragments + size_t(tileIndex) * kMatrixTileWords + waveSlot + laneId();                       \
+        const LdsFragmentPtr dst_ = tiles + (buffer) * kMatrixTileWords + waveSlot;                                          \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) {                                                                   \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + j_ * 256),              \
+                                             (__attribute__((address_space(3))) void*)(dst_ + j_ * 256), 16, 0, 0);          \
+        }                                                                                                                     \
+    } while (0)
+    // The published cut-offs of the 64 columns of a pair of tiles (lane = column) travel global -> LDS one pair ahead
+    // (columns past the end repeat the last one: never tested).  Any value a cell published earlier is valid: bounds
+    // only tighten.
+#define EM2_STAGE_SNAP(firstColumn, buffer)                                                                                   \
+    do {                                                                                                                      \
+        uint32_t column_ = (firstColumn) + laneId();                                                                          \
+        column_ = column_ < colEnd ? column_ : colEnd - 1u;                                                                   \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(snap + column_),                    \
+                                         (__attribute__((address_space(3))) void*)(snapStage + (buffer) * 64u), 4, 0, 0);    \
+    } while (0)
+    EM2_STAGE_TILE(colBegin / 32u, 0u);
+    if (colBegin + 32u < colEnd) EM2_STAGE_TILE(colBegin / 32u + 1u, 1u);
+    EM2_STAGE_SNAP(colBegin, 0u);
+    __syncthreads();
+    uint64_t groups[4];
+    bool pending = false, pendingInY = false;
+    uint32_t pendingBase = 0, pendingSlot = 0;
+    uint32_t iteration = 0;
+    uint32_t result = colEnd;
+    for (uint32_t colBase = colBegin; colBase < colEnd; colBase += 64u, ++iteration) {
+        const uint32_t pair = iteration & 1u;
+        {
+            const uint32_t lane = laneId();
+            boundScratch[pair * 64u + lane] = kMatrixBits - 2.f * float(snapStage[pair * 64u + lane]);
+        }
+        if (colBase + 64u < colEnd) {
+            EM2_STAGE_TILE(colBase / 32u + 2u, 2u * (pair ^ 1u));
+            EM2_STAGE_SNAP(colBase + 64u, pair ^ 1u);
+        }
+        if (colBase + 96u < colEnd) EM2_STAGE_TILE(colBase / 32u + 3u, 2u * (pair ^ 1u) + 1u);
+        // ---- first tile of the pair -> X, under it the test of the pending tile (always in Y here) ----
+        {
+            const uint32_t tileBase = tilesLds + 2u * pair * (kMatrixTileWords * 16u);
+            if (pending) {
+                const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
+                asm volatile(EM2_MATRIX_STEP_X_TESTING_Y
+                             : "=&s"(groups[0]), "=&s"(groups[1]), "=&s"(groups[2]), "=&s"(groups[3])
+                             : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot)
+                             : EM2_MATRIX_STEP_CLOBBERS);
+                if ((groups[0] | groups[1] | groups[2] | groups[3]) != 0ull) {
+                    matrixEventsCall<BOTH, true>(groups[0], groups[1], groups[2], groups[3], pendingBase, pendingSlot, walkLds, auxUniform);
+                }
+            } else {
+                asm volatile(EM2_MATRIX_STEP_X : : "s"(tileBase) : EM2_MATRIX_STEP_CLOBBERS);
+            }
+            pending = true;
+            pendingInY = false;
+            pendingBase = colBase;
+            pendingSlot = 2u * pair;
+        }
+        // ---- second tile -> Y, under it the test of the first ----
+        if (colBase + 32u < colEnd) {
+            const uint32_t tileBase = tilesLds + (2u * pair + 1u) * (kMatrixTileWords * 16u);
+            const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
+            asm volatile(EM2_MATRIX_STEP_Y_TESTING_X
+                         : "=&s"(groups[0]), "=&s"(groups[1]), "=&s"(groups[2]), "=&s"(groups[3])
+                         : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot)
+                         : EM2_MATRIX_STEP_CLOBBERS);
+            if ((groups[0] | groups[1] | groups[2] | groups[3]) != 0ull) {
+                matrixEventsCall<BOTH, false>(groups[0], groups[1], groups[2], groups[3], pendingBase, pendingSlot, walkLds, auxUniform);
+            }
+            pendingInY = true;
+            pendingBase = colBase + 32u;
+            pendingSlot = 2u * pair + 1u;
+        }
+        // the untested tile and the next pair add at most 96 entries to a row's log before the next chance to stop
+        const bool full = !BOTH && __builtin_amdgcn_ballot_w64(logCounts[laneId()] + kMatrixLogMargin > logCapacity) != 0ull;
+        const uint32_t slot = iteration % 3u;
+        if (full && laneId() == 0u) stopWords[slot] = 1u;
+        if (waveSlot == 0u && laneId() == 0u) stopWords[(iteration + 1u) % 3u] = 0u;
+        __syncthreads();
+        if (stopWords[slot] != 0u) {
+            __syncthreads();
+            if (waveSlot == 0u && laneId() == 0u) stopWords[slot] = 0u;
+            __syncthreads();
+            result = colBase + 64u < colEnd ? colBase + 64u : colEnd;
+            break;
+        }
+    }
+#undef EM2_STAGE_TILE
+#undef EM2_STAGE_SNAP
+    // ---- the tile still untested ----
+    if (pending) {
+        const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
+        if (pendingInY) {
+            asm volatile(EM2_MATRIX_TEST_Y
+                         : "=&s"(groups[0]), "=&s"(groups[1]), "=&s"(groups[2]), "=&s"(groups[3])
+                         : "s"(boundBase), "s"(walkLds + kWalkRowDot)
+                         : EM2_MATRIX_STEP_CLOBBERS);
+            if ((groups[0] | groups[1] | groups[2] | groups[3]) != 0ull) {
+                matrixEventsCall<BOTH, true>(groups[0], groups[1], groups[2], groups[3], pendingBase, pendingSlot, walkLds, auxUniform);
+            }
+        } else {
+            asm volatile(EM2_MATRIX_TEST_X
+                         : "=&s"(groups[0]), "=&s"(groups[1]), "=&s"(groups[2]), "=&s"(groups[3])
+                         : "s"(boundBase), "s"(walkLds + kWalkRowDot)
+                         : EM2_MATRIX_STEP_CLOBBERS);
+            if ((groups[0] | groups[1] | groups[2] | groups[3]) != 0ull) {
+                matrixEventsCall<BOTH, false>(groups[0], groups[1], groups[2], groups[3], pendingBase, pendingSlot, walkLds, auxUniform);
+            }
+        }
+    }
+    io->logCount = logCounts[laneId()];
+    io->emitPos = uniform(words[kWordEmitPos]);
+    io->emitEnd = uniform(words[kWordEmitEnd]);
+    return result;
+}
+
+template <bool IDENTITY, bool PINNED>
 __global__ void __launch_bounds__(256, 2)
 fsp4ScanMatrixKernel(Fsp4Args args)
 {
@@ -707,6 +1077,12 @@ fsp4ScanMatrixKernel(Fsp4Args args)
     const uint32_t wave = threadIdx.x >> 6;
     FragmentWord4* tiles = reinterpret_cast<FragmentWord4*>(ldsRaw + kernelArgs()->matrixLdsOffset);
     volatile uint32_t* shared = reinterpret_cast<volatile uint32_t*>(ldsRaw + kernelArgs()->matrixLdsOffset + 4u * kMatrixTileWords * 16u);
+    // The wave's LDS block of the walk is its selection area (never needed at the same time) when that is large enough
+    // and 16-byte aligned, and sits behind the tiles otherwise (matrixWalkAliasesSelection on the host side).
+    const uint32_t selectionStride = 2u * kernelArgs()->k * kLdsBytesPerEntrySlot;
+    unsigned char* walkBlock = (selectionStride >= kMatrixWalkLdsBytes && selectionStride % 16u == 0u)
+                                   ? ldsRaw + wave * selectionStride
+                                   : ldsRaw + kernelArgs()->matrixLdsOffset + 4u * kMatrixTileWords * 16u + 64u + wave * kMatrixWalkLdsBytes;
     // shared[0..2] stop words of the walk, shared[3] the block's ticket
     if (threadIdx.x < 4u) shared[threadIdx.x] = 0u;
     __syncthreads();
@@ -747,7 +1123,8 @@ fsp4ScanMatrixKernel(Fsp4Args args)
         const uint32_t row = rowBase + lane;
         const bool rowValid = !idle && row < aux->cellCount;
         const uint32_t twoK = 2u * aux->k;
-        uint32_t logCapacity = aux->logCapacity < 64u ? 64u : aux->logCapacity;
+        const uint32_t minLogCapacity = PINNED ? kMatrixLogMargin : 64u;
+        uint32_t logCapacity = aux->logCapacity < minLogCapacity ? minLogCapacity : aux->logCapacity;
         Entry* myList = aux->buffers + (size_t(listBlock) * 64u + lane) * twoK;
         Entry* myLog = aux->logs + (size_t(blockIdx.x * 4u + wave) * 64u + lane) * logCapacity;
         const uint32_t cps = aux->columnsPerSegment;
@@ -780,9 +1157,20 @@ fsp4ScanMatrixKernel(Fsp4Args args)
         uint32_t at = colBegin;
         for (;;) {
             if (at < commonEnd) {
-                at = scanTilesMatrix<IDENTITY>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, at, commonEnd,
-                                               rowFragmentBlock, kMatrixBits - 2.f * float(mMax), row, rowValid && !fullRows, lane, myLog,
-                                               logCapacity, logCount, emitPos, emitEnd, tiles, shared);
+                if (PINNED) {
+                    MatrixWalkIo io = {logCount, emitPos, emitEnd};
+                    at = scanTilesMatrixPinned<IDENTITY>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
+                                                         rowFragmentBlock, kMatrixBits - 2.f * float(mMax), row, rowValid && !fullRows,
+                                                         myLog, logCapacity, &io, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
+                                                         ldsAddress(walkBlock));
+                    logCount = io.logCount;
+                    emitPos = io.emitPos;
+                    emitEnd = io.emitEnd;
+                } else {
+                    at = scanTilesMatrix<IDENTITY>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, at, commonEnd,
+                                                   rowFragmentBlock, kMatrixBits - 2.f * float(mMax), row, rowValid && !fullRows, lane, myLog,
+                                                   logCapacity, logCount, emitPos, emitEnd, tiles, shared);
+                }
             }
             if (!haveState && !idle && !failed) {
                 const uint32_t* flag = aux->segmentsDone + block;
@@ -1149,6 +1537,7 @@ fsp4TileKernel(Fsp4Args args)
 // fsp4TileKernel on the matrix cores (1024-bit signatures): tiles are (segment, quad of 4 row blocks), a block of 4
 // waves walks the columns of the segment below the quad in lock step (scanTilesMatrix, both sides deferred); the
 // quad's own 256 columns are done by the v_xor/v_bcnt code.  Prefix and segment lengths are multiples of 256 cells.
+template <bool PINNED>
 __global__ void __launch_bounds__(256, 2)
 fsp4TileMatrixKernel(Fsp4Args args)
 {
@@ -1157,6 +1546,7 @@ fsp4TileMatrixKernel(Fsp4Args args)
     const uint32_t wave = threadIdx.x >> 6;
     FragmentWord4* tiles = reinterpret_cast<FragmentWord4*>(ldsRaw + kernelArgs()->matrixLdsOffset);
     volatile uint32_t* shared = reinterpret_cast<volatile uint32_t*>(ldsRaw + kernelArgs()->matrixLdsOffset + 4u * kMatrixTileWords * 16u);
+    unsigned char* walkBlock = ldsRaw + kernelArgs()->matrixLdsOffset + 4u * kMatrixTileWords * 16u + 64u + wave * kMatrixWalkLdsBytes;
     if (threadIdx.x < 4u) shared[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t emitPos = 0, emitEnd = 0;
@@ -1196,9 +1586,19 @@ fsp4TileMatrixKernel(Fsp4Args args)
         const int32_t snapRow = rowValid ? aux->snap[row] : -1;
         if (colBegin < commonEnd) {
             uint32_t unusedLogCount = 0;
-            scanTilesMatrix<true, true>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, colBegin, commonEnd,
-                                        2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), row, rowValid, lane, nullptr, 0u,
-                                        unusedLogCount, emitPos, emitEnd, tiles, shared);
+            if (PINNED) {
+                MatrixWalkIo io = {0u, emitPos, emitEnd};
+                scanTilesMatrixPinned<true, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, colBegin, commonEnd,
+                                                  2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), row, rowValid, nullptr, 0u,
+                                                  &io, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
+                                                  ldsAddress(walkBlock));
+                emitPos = io.emitPos;
+                emitEnd = io.emitEnd;
+            } else {
+                scanTilesMatrix<true, true>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, colBegin, commonEnd,
+                                            2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), row, rowValid, lane, nullptr, 0u,
+                                            unusedLogCount, emitPos, emitEnd, tiles, shared);
+            }
         }
         if (last && !idle) {
             uint32_t r[32];
@@ -1253,6 +1653,34 @@ __global__ void maxReduceKernel(int32_t* __restrict__ arrays, uint32_t n, uint32
 // ---- symmetric (triangle) scan: eligibility and workspace ----
 // EM2_SCAN_MODE=triangle forces it wherever it is possible (all rows of the problem in one launch),
 // EM2_SCAN_MODE=persistent / simple disable it; by default it is used from kSymmetricMinCells cells on.
+// dynamic LDS of the matrix kernels behind matrixLdsOffset: four tiles, the stop words + ticket, the waves' walk blocks
+constexpr size_t kMatrixLdsBytes = 4u * kMatrixTileWords * 16u + 64u + 4u * kMatrixWalkLdsBytes;
+
+// fsp4ScanMatrixKernel: the waves' walk blocks alias their selection areas when those are large enough (see there)
+static bool matrixWalkAliasesSelection(uint32_t k)
+{
+    const uint32_t selectionStride = 2u * k * kLdsBytesPerEntrySlot;
+    return selectionStride >= kMatrixWalkLdsBytes && selectionStride % 16u == 0u;
+}
+
+static size_t scanMatrixLdsBytes(uint32_t k)
+{
+    return kMatrixLdsBytes - (matrixWalkAliasesSelection(k) ? 4u * kMatrixWalkLdsBytes : 0u);
+}
+
+// EM2_MATRIX_WALK=0 keeps the compiler-scheduled walk (scanTilesMatrix) for A/B runs.
+static bool matrixWalkPinned() { return envNumber("EM2_MATRIX_WALK", 1) != 0; }
+
+static const void* scanMatrixKernelFor(bool identity)
+{
+    if (matrixWalkPinned()) {
+        return identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<true, true>)
+                        : reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<false, true>);
+    }
+    return identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<true, false>)
+                    : reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<false, false>);
+}
+
 constexpr uint32_t kSymmetricMinCells = 131072;
 constexpr uint32_t kSymmetricMatrixMinCells = 32768;
 constexpr uint32_t kMaxSegments = 64;
@@ -1391,7 +1819,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     bool matrix = paddedDw == 32u && wavesPerBlock == 4u && args.rowBlockStride == 1u && args.rowBlockOffset == 0u &&
                   args.localBlockBase == 0u && args.shardFlags == 0u && args.columnLimit == cellCount && args.rowBegin == 0u &&
                   envNumber("EM2_SCAN_MATRIX", 1) != 0 &&
-                  ((lds + 15u) & ~size_t(15)) + 4u * kMatrixTileWords * 16u + 64u <= 150u * 1024u;      // selection area + four tiles
+                  ((lds + 15u) & ~size_t(15)) + scanMatrixLdsBytes(args.k) <= 150u * 1024u;      // selection area + four tiles
     if (matrix) {
         fullRowBlocks = (fullRowBlocks + 3u) & ~3u;
         if (fullRowBlocks >= rowBlocks) {
@@ -1536,9 +1964,8 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         matrixArgs.totalTickets = uint32_t(ticketsMatrix);
         matrixArgs.fragments = ws + layout.fragments;
         matrixArgs.matrixLdsOffset = uint32_t((lds + 15u) & ~size_t(15));
-        const size_t matrixLds = size_t(matrixArgs.matrixLdsOffset) + 4u * kMatrixTileWords * 16u + 64u;
-        const void* matrixKernel = identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<true>)
-                                            : reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<false>);
+        const size_t matrixLds = size_t(matrixArgs.matrixLdsOffset) + scanMatrixLdsBytes(args.k);
+        const void* matrixKernel = scanMatrixKernelFor(identity);
         int device = 0, cuCount = 0, blocksPerCu = 0;
         e = hipGetDevice(&device);
         if (e != hipSuccess) return e;
@@ -1817,7 +2244,7 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
         const uint32_t slotCount = phase == 0 ? plan.ownPrefixBlocks : plan.ownBlocks - plan.ownPrefixBlocks;
         if (slotCount == 0) return hipSuccess;
         const size_t matrixLdsOffset = (lds + 15u) & ~size_t(15);
-        const size_t matrixLds = matrixLdsOffset + 4u * kMatrixTileWords * 16u + 64u;
+        const size_t matrixLds = matrixLdsOffset + scanMatrixLdsBytes(args.k);
         if (paddedDw == 32u && wavesPerBlock == 4u && M % 256u == 0u && matrixLds <= 150u * 1024u &&
             envNumber("EM2_SCAN_MATRIX", 1) != 0) {
             // Phase 1, the rows beyond the prefix against the prefix columns: all of it below the rows, so all of it for the
@@ -1856,8 +2283,7 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             args.fragments = ws + plan.offFragments;
             args.matrixLdsOffset = uint32_t(matrixLdsOffset);
             lastLaunchInfo.matrixPairs += double(slotCount) * 64.0 * double(M);
-            const void* matrixKernel = t.identityKeys ? reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<true>)
-                                                      : reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<false>);
+            const void* matrixKernel = scanMatrixKernelFor(t.identityKeys);
             int device = 0, cuCount = 0;
             e = hipGetDevice(&device);
             if (e != hipSuccess) return e;
@@ -1973,15 +2399,15 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             if (e != hipSuccess) return e;
             args.fragments = ws + plan.offFragments;
             args.matrixLdsOffset = 0;
-            const size_t matrixLds = 4u * kMatrixTileWords * 16u + 64u;
+            const size_t matrixLds = kMatrixLdsBytes;
             uint64_t blocksWanted = uint64_t(cuCount) * 2u;
             if (blocksWanted > own) blocksWanted = own;
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fsp4TileMatrixKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    int(matrixLds));
+            const void* tileMatrixKernel = matrixWalkPinned() ? reinterpret_cast<const void*>(&fsp4TileMatrixKernel<true>)
+                                                              : reinterpret_cast<const void*>(&fsp4TileMatrixKernel<false>);
+            e = hipFuncSetAttribute(tileMatrixKernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(matrixLds));
             if (e != hipSuccess) return e;
             void* matrixArgsArray[] = {&args};
-            return hipLaunchKernel(reinterpret_cast<const void*>(&fsp4TileMatrixKernel), dim3(uint32_t(blocksWanted)), dim3(256),
-                                   matrixArgsArray, matrixLds, stream);
+            return hipLaunchKernel(tileMatrixKernel, dim3(uint32_t(blocksWanted)), dim3(256), matrixArgsArray, matrixLds, stream);
         }
         uint64_t wavesWanted = own;
         const uint64_t resident = uint64_t(cuCount) * 16u;

@@ -737,4 +737,54 @@ uint64_t em2o_label_propagation(const uint32_t* vertexCellIds, uint32_t vertexCo
 }
 
 
+// =====================================================================================================
+// ExpressionMatrixSubset::ExpressionMatrixSubset + computeSums
+// (ExpressionMatrixSubset.cpp:9-58), with GeneSet::getLocalGeneId (GeneSet.hpp:70-77).
+//   globalToc / globalGenes / globalCounts : the global CellExpressionCounts (ExpressionMatrix.hpp:734)
+//   geneSet[geneSetSize]                    : GeneSet::globalGeneIdVector (sorted ascending, GeneSet.cpp:84-98)
+//   localGeneIdVector[localGeneIdVectorSize]: GeneSet::localGeneIdVector, invalidGeneId = 0xffffffff outside the set
+//   cellSet[cellSetSize]                    : global cell ids of the subset
+// Two-step like a vector that grows: outGenes == NULL only counts.  Returns the number of entries, or -1 where
+// the reference's CZI_ASSERT(std::is_sorted(...)) (:17-18) throws.  outSums = Sum{double sum1, sum2} per cell (:47-58).
+// =====================================================================================================
+int64_t em2o_subset(const uint64_t* globalToc, const uint32_t* globalGenes, const float* globalCounts,
+                    const uint32_t* geneSet, uint32_t geneSetSize,
+                    const uint32_t* localGeneIdVector, uint32_t localGeneIdVectorSize,
+                    const uint32_t* cellSet, uint32_t cellSetSize,
+                    uint64_t* outToc, uint32_t* outGenes, float* outCounts, double* outSums)
+{
+    const uint32_t invalidGeneId = std::numeric_limits<uint32_t>::max();          // Ids.hpp
+    if (!std::is_sorted(geneSet, geneSet + geneSetSize)) return -1;               // :17
+    if (!std::is_sorted(cellSet, cellSet + cellSetSize)) return -1;               // :18
+    uint64_t n = 0;
+    if (outToc) outToc[0] = 0;
+    for (uint32_t localCellId = 0; localCellId != cellSetSize; localCellId++) {   // :23-42
+        const uint32_t globalCellId = cellSet[localCellId];
+        double sum1 = 0., sum2 = 0.;
+        for (uint64_t j = globalToc[globalCellId]; j < globalToc[globalCellId + 1]; j++) {
+            const uint32_t globalGeneId = globalGenes[j];
+            const uint32_t localGeneId =                                          // GeneSet.hpp:70-77
+                (globalGeneId < localGeneIdVectorSize) ? localGeneIdVector[globalGeneId] : invalidGeneId;
+            if (localGeneId == invalidGeneId) {
+                continue;
+            }
+            const float count = globalCounts[j];
+            if (outGenes) {
+                outGenes[n] = localGeneId;
+                outCounts[n] = count;
+            }
+            ++n;
+            sum1 += count;                                                        // :54
+            sum2 += count * count;                                                // :55 (float product)
+        }
+        if (outToc) outToc[localCellId + 1] = n;
+        if (outSums) {
+            outSums[2 * size_t(localCellId)] = sum1;
+            outSums[2 * size_t(localCellId) + 1] = sum2;
+        }
+    }
+    return int64_t(n);
+}
+
+
 }  // extern "C"

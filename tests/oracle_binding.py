@@ -58,6 +58,30 @@ class Oracle:
         lib.em2o_label_propagation.restype = c.c_uint64
         lib.em2o_murmur_hash_64a.argtypes = [P, c.c_int, c.c_uint64]
         lib.em2o_murmur_hash_64a.restype = c.c_uint64
+        lib.em2o_subset.argtypes = [P, P, P, P, c.c_uint32, P, c.c_uint32, P, c.c_uint32, P, P, P, P]
+        lib.em2o_subset.restype = c.c_int64
+
+    def subset(self, toc, genes, counts, gene_set, local_gene_ids, cell_set):
+        """ExpressionMatrixSubset ctor + computeSums -> (toc, genes, counts, sums[cells, 2]); ValueError where the
+        reference's CZI_ASSERT(is_sorted) throws."""
+        toc = np.ascontiguousarray(toc, dtype=np.uint64)
+        genes = np.ascontiguousarray(genes, dtype=np.uint32)
+        counts = np.ascontiguousarray(counts, dtype=np.float32)
+        gene_set = np.ascontiguousarray(gene_set, dtype=np.uint32)
+        local_gene_ids = np.ascontiguousarray(local_gene_ids, dtype=np.uint32)
+        cell_set = np.ascontiguousarray(cell_set, dtype=np.uint32)
+        args = (_ptr(toc), _ptr(genes), _ptr(counts), _ptr(gene_set), len(gene_set), _ptr(local_gene_ids),
+                len(local_gene_ids), _ptr(cell_set), len(cell_set))
+        n = self.lib.em2o_subset(*args, None, None, None, None)
+        if n < 0:
+            raise ValueError("gene set or cell set not sorted (ExpressionMatrixSubset.cpp:17-18)")
+        out_toc = np.zeros(len(cell_set) + 1, dtype=np.uint64)
+        out_genes = np.zeros(n, dtype=np.uint32)
+        out_counts = np.zeros(n, dtype=np.float32)
+        sums = np.zeros((len(cell_set), 2), dtype=np.float64)
+        n2 = self.lib.em2o_subset(*args, _ptr(out_toc), _ptr(out_genes), _ptr(out_counts), _ptr(sums))
+        assert n2 == n
+        return out_toc, out_genes, out_counts, sums
 
     def generate_lsh_vectors(self, gene_count, lsh_count, seed):
         out = np.empty((gene_count, lsh_count), dtype=np.float64)

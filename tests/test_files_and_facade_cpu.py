@@ -117,6 +117,68 @@ def test_subset_restricts_and_renumbers_like_reference(data_dir):
         assert np.array_equal(c[keep], got["count"])
 
 
+def _oracle_subset(oracle, toc, g, c, gene_count, gene_ids, cell_ids):
+    local_ids = np.full(int(gene_ids[-1]) + 1 if len(gene_ids) else 0, 0xffffffff, dtype=np.uint32)   # GeneSet.cpp:53-58
+    local_ids[gene_ids] = np.arange(len(gene_ids), dtype=np.uint32)
+    return oracle.subset(toc, g, c, gene_ids, local_ids, cell_ids)
+
+
+@pytest.mark.parametrize("gene_case,cell_case", [("all", "all"), ("some", "all"), ("all", "some"), ("some", "some"),
+                                                 ("one", "some"), ("tail", "all")])
+def test_host_subset_equals_oracle_subset(oracle, tmp_path, gene_case, cell_case):
+    """em2_matrix_subset against the oracle's restatement of the ExpressionMatrixSubset constructor
+    (src/ExpressionMatrixSubset.cpp:9-42): cells without counts, cells that lose all their counts, genes beyond the
+    end of the gene set's local-id vector (GeneSet.hpp:70-77), identity sets."""
+    d = str(tmp_path / "data")
+    cells, gene_count = 90, 70
+    toc, g, c = synth.expression_matrix(cells, gene_count, density=0.15, cluster_count=3, seed=11)
+    # cells 7 and 8 hold no counts at all
+    keep = np.ones(len(g), dtype=bool)
+    keep[int(toc[7]):int(toc[9])] = False
+    lengths = np.diff(toc.astype(np.int64))
+    lengths[7:9] = 0
+    toc = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    g, c = g[keep], c[keep]
+    files.create_directory(d, gene_count, toc, capi.make_counts(g, c))
+    gene_sets = {"all": np.arange(gene_count, dtype=np.uint32),
+                 "some": np.array([1, 2, 3, 5, 8, 13, 21, 34, 55], dtype=np.uint32),
+                 "one": np.array([4], dtype=np.uint32),
+                 "tail": np.arange(40, gene_count, dtype=np.uint32)}
+    cell_sets = {"all": np.arange(cells, dtype=np.uint32),
+                 "some": np.array([0, 6, 7, 8, 9, 50, 89], dtype=np.uint32)}
+    gene_name = "AllGenes" if gene_case == "all" else "G"
+    cell_name = "AllCells" if cell_case == "all" else "C"
+    if gene_case != "all":
+        files.add_gene_set(d, "G", gene_sets[gene_case])
+    if cell_case != "all":
+        files.add_cell_set(d, "C", cell_sets[cell_case])
+    e = ExpressionMatrix(d)
+    n_genes, stoc, sdata = e._subset(gene_name, cell_name)
+    otoc, ogenes, ocounts, sums = _oracle_subset(oracle, toc, g, c, gene_count, gene_sets[gene_case], cell_sets[cell_case])
+    assert n_genes == len(gene_sets[gene_case])
+    assert np.array_equal(stoc, otoc) and np.array_equal(sdata["gene"], ogenes)
+    assert np.array_equal(sdata["count"].view(np.uint32), ocounts.view(np.uint32))
+    assert e._subset_sizes(gene_name, cell_name) == (n_genes, len(cell_sets[cell_case]), len(ogenes))
+
+
+def test_unsorted_sets_are_rejected_like_the_reference_asserts(oracle, data_dir):
+    """CZI_ASSERT(std::is_sorted(...)) for both sets (src/ExpressionMatrixSubset.cpp:17-18): the oracle returns its
+    error, the host code raises.  (The tool refuses to write an unsorted set, so the file is patched.)"""
+    d, toc, g, c = data_dir
+    files.add_cell_set(d, "Some", np.array([1, 5, 9], dtype=np.uint32))
+    path = os.path.join(d, "CellSet-Some")
+    raw = bytearray(open(path, "rb").read())
+    raw[256:268] = struct.pack("<3I", 5, 1, 9)
+    open(path, "wb").write(bytes(raw))
+    e = ExpressionMatrix(d)
+    with pytest.raises(RuntimeError, match="not sorted"):
+        e._subset("AllGenes", "Some")
+    with pytest.raises(ValueError):
+        oracle.subset(toc, g, c, np.arange(50, dtype=np.uint32), np.arange(50, dtype=np.uint32), [5, 1, 9])
+    with pytest.raises(ValueError):
+        oracle.subset(toc, g, c, [3, 2], np.arange(50, dtype=np.uint32), [1, 5, 9])
+
+
 def test_reference_error_messages(data_dir):
     """src/ExpressionMatrixLsh.cpp:168-187, 349-351; src/ExpressionMatrixFindSimilarPairs.cpp:126-135."""
     d, toc, g, c = data_dir
@@ -149,3 +211,26 @@ def test_remove_similar_pairs(data_dir):
     e = ExpressionMatrix(d)
     e.removeSimilarPairs("P")
     assert not [f for f in os.listdir(d) if f.startswith("SimilarPairs-")]
+
+
+def test_failed_find_similar_pairs4_leaves_existing_object_untouched(data_dir):
+    """The reference creates SimilarPairs-<name>-* only after its pair loop has succeeded
+    (src/ExpressionMatrixLsh.cpp:278-285).  Here the files are mapped while the device works, under temporary names:
+    a call that fails (k above the supported maximum; on this box also: no GPU) must neither truncate an existing
+    object of that name nor leave temporary files behind."""
+    d, toc, g, c = data_dir
+    pairs = np.zeros((60, 2), dtype=capi.PAIR_DTYPE)
+    pairs["cell"] = 7
+    pairs["similarity"] = 0.5
+    files.write_similar_pairs(d, "P", "AllGenes", "AllCells", 2, pairs, np.full(60, 2, dtype=np.uint32))
+    before = {f: open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d)) if f.startswith("SimilarPairs-P-")}
+    assert len(before) == 3
+    e = ExpressionMatrix(d)
+    with pytest.raises(RuntimeError):
+        e.findSimilarPairs4(similarPairsName="P", k=5000)
+    with pytest.raises(RuntimeError):
+        e.findSimilarPairs4(similarPairsName="P", lshCount=8192)
+    after = {f: open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d)) if f.startswith("SimilarPairs-")}
+    assert after == before
+    k, p2, used = files.read_similar_pairs(d, "P")
+    assert k == 2 and (used == 2).all() and (p2["cell"] == 7).all()

@@ -58,38 +58,64 @@ def test_compute_lsh_signatures_persists_reference_format(oracle, data_dir):
     assert L == 512 and np.array_equal(sig, exp_sig)
 
 
-@pytest.mark.parametrize("gene_set,cell_set", [("AllGenes", "AllCells"), ("HighInformationGenes", "AllCells"),
-                                               ("AllGenes", "Subset"), ("HighInformationGenes", "Subset")])
-def test_device_subset_equals_host_subset(data_dir, gene_set, cell_set):
-    """ExpressionMatrixSubset on the device (em2_dev_subset_count / _fill) against the host restatement of
-    src/ExpressionMatrixSubset.cpp:9-42 (em2_matrix_subset): same offsets, same (local gene id, count) entries."""
+def _device_subset(toc, data, cells, local_ids, gene_count):
+    """em2_dev_subset_count / _fill on device copies of the arrays -> (toc, entries)."""
     import torch
-    e = ExpressionMatrix(data_dir)
-    n_genes, toc, data = e._subset(gene_set, cell_set)                       # host
-    _, g_toc, g_data = e._subset("AllGenes", "AllCells")                    # the global CSR
-    cells = e._cell_set(cell_set)
-    local_ids = np.full(900, 0xffffffff, dtype=np.uint32)
-    if gene_set == "AllGenes":
-        local_ids[:] = np.arange(900, dtype=np.uint32)
-    else:
-        genes = np.unique((np.arange(300) * 7) % 900).astype(np.uint32)
-        local_ids[genes] = np.arange(len(genes), dtype=np.uint32)
     lib = capi.load()
-    d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8)).cuda()
-    d_toc, d_data, d_cells, d_local = d(g_toc), d(g_data), d(cells), d(local_ids)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).copy()).cuda()
+    d_toc, d_data, d_cells, d_local = d(toc), d(data), d(cells), d(local_ids)
     ws_bytes = lib.em2_dev_subset_workspace(len(cells))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
     out_toc = torch.empty(len(cells) + 1, dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     capi.check(lib.em2_dev_subset_count(d_toc.data_ptr(), d_data.data_ptr(), d_cells.data_ptr(), len(cells), d_local.data_ptr(),
-                                        900, out_toc.data_ptr(), ws.data_ptr(), ws_bytes, stream))
+                                        gene_count, out_toc.data_ptr(), ws.data_ptr(), ws_bytes, stream))
     torch.cuda.synchronize()
-    assert np.array_equal(out_toc.cpu().numpy().view(np.uint64), toc)
-    out_data = torch.empty(max(1, int(toc[-1])) * 8, dtype=torch.uint8, device="cuda")
+    new_toc = out_toc.cpu().numpy().view(np.uint64)
+    out_data = torch.empty(max(1, int(new_toc[-1])) * 8, dtype=torch.uint8, device="cuda")
     capi.check(lib.em2_dev_subset_fill(d_toc.data_ptr(), d_data.data_ptr(), d_cells.data_ptr(), len(cells), d_local.data_ptr(),
-                                       900, out_toc.data_ptr(), out_data.data_ptr(), stream))
+                                       gene_count, out_toc.data_ptr(), out_data.data_ptr(), stream))
     torch.cuda.synchronize()
-    got = out_data.cpu().numpy()[:int(toc[-1]) * 8].view(capi.COUNT_DTYPE)
-    assert np.array_equal(got["gene"], data["gene"])
-    assert np.array_equal(got["count"].view(np.uint32), data["count"].view(np.uint32))
-    assert n_genes == (900 if gene_set == "AllGenes" else len(np.unique((np.arange(300) * 7) % 900)))
+    return new_toc, out_data.cpu().numpy()[:int(new_toc[-1]) * 8].view(capi.COUNT_DTYPE)
+
+
+@pytest.mark.parametrize("gene_set,cell_set", [("AllGenes", "AllCells"), ("HighInformationGenes", "AllCells"),
+                                               ("AllGenes", "Subset"), ("HighInformationGenes", "Subset")])
+def test_device_subset_equals_oracle_subset(oracle, data_dir, gene_set, cell_set):
+    """ExpressionMatrixSubset on the device (em2_dev_subset_count / _fill) and on the host (em2_matrix_subset) against
+    the oracle's restatement of src/ExpressionMatrixSubset.cpp:9-42: same offsets, same (local gene id, count)
+    entries."""
+    e = ExpressionMatrix(data_dir)
+    _, g_toc, g_data = e._subset("AllGenes", "AllCells")                    # the global CSR as stored
+    cells = e._cell_set(cell_set)
+    genes = np.arange(900, dtype=np.uint32) if gene_set == "AllGenes" else np.unique((np.arange(300) * 7) % 900).astype(np.uint32)
+    local_ids = np.full(900, 0xffffffff, dtype=np.uint32)
+    local_ids[genes] = np.arange(len(genes), dtype=np.uint32)
+    otoc, ogenes, ocounts, sums = oracle.subset(g_toc, g_data["gene"], g_data["count"], genes, local_ids, cells)
+    toc, got = _device_subset(g_toc, g_data, cells, local_ids, 900)
+    assert np.array_equal(toc, otoc) and np.array_equal(got["gene"], ogenes)
+    assert np.array_equal(got["count"].view(np.uint32), ocounts.view(np.uint32))
+    n_genes, htoc, hdata = e._subset(gene_set, cell_set)                    # host
+    assert n_genes == len(genes) and np.array_equal(htoc, otoc) and np.array_equal(hdata["gene"], ogenes)
+    assert np.array_equal(hdata["count"].view(np.uint32), ocounts.view(np.uint32))
+
+
+def test_device_subset_edge_cases_equal_oracle(oracle):
+    """Cells without counts, cells whose genes are all outside the set, a gene set whose local-id vector is shorter
+    than the global gene count (GeneSet.hpp:70-77), cells of more than one wave of counts, an empty result."""
+    rng = np.random.default_rng(3)
+    gene_count = 500
+    lengths = np.array([0, 1, 63, 64, 65, 200, 0, 0, 130, 5], dtype=np.int64)
+    toc = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    genes = np.concatenate([np.sort(rng.choice(gene_count, n, replace=False)) for n in lengths]).astype(np.uint32)
+    counts = rng.integers(1, 50, len(genes)).astype(np.float32)
+    data = capi.make_counts(genes, counts)
+    for gene_ids in (np.arange(gene_count, dtype=np.uint32), np.arange(0, 100, 3, dtype=np.uint32),
+                     np.array([499], dtype=np.uint32), np.arange(250, 260, dtype=np.uint32)):
+        for cells in (np.arange(len(lengths), dtype=np.uint32), np.array([0, 5, 6, 9], dtype=np.uint32), np.array([6], dtype=np.uint32)):
+            local_ids = np.full(gene_count, 0xffffffff, dtype=np.uint32)
+            local_ids[gene_ids] = np.arange(len(gene_ids), dtype=np.uint32)
+            otoc, ogenes, ocounts, _ = oracle.subset(toc, genes, counts, gene_ids, local_ids[:int(gene_ids[-1]) + 1], cells)
+            dtoc, got = _device_subset(toc, data, cells, local_ids, gene_count)
+            assert np.array_equal(dtoc, otoc) and np.array_equal(got["gene"], ogenes)
+            assert np.array_equal(got["count"].view(np.uint32), ocounts.view(np.uint32))

@@ -29,26 +29,31 @@ def test_signatures_match_oracle(oracle, cells, genes, L, density):
     assert 0.2 * cells * L < ones < 0.8 * cells * L
 
 
-def test_toytest1_matrix(oracle):
-    """tests/ToyTest1/ExpressionMatrix.csv of the reference: 3 genes x 3 cells (values restated as data)."""
-    # Cell0: Gene0=10, Gene1=20 ; Cell1: Gene0=20, Gene1=40(ish) ... dense 3x3 toy; exact values are not
-    # important for parity, the shape (3 cells, 3 genes, lshCount 128) is BASELINE config 1.
-    dense = np.array([[10., 20., 0.], [0., 30., 10.], [5., 25., 15.]], dtype=np.float32)
-    toc = [0]
-    genes = []
-    counts = []
-    for row in dense:
-        nz = np.nonzero(row)[0]
-        genes += nz.tolist()
-        counts += row[nz].tolist()
-        toc.append(len(genes))
-    vectors = oracle.generate_lsh_vectors(3, 128, 231)
-    expect = oracle.compute_signatures(toc, genes, counts, 3, vectors, 128)
-    got = capi.compute_signatures(np.array(toc), capi.make_counts(genes, counts), 3, vectors, 128)
+def test_toytest1_matrix(oracle, tmp_path):
+    """BASELINE configs[0]: the reference's tests/ToyTest1/ExpressionMatrix.csv (committed as a data fixture,
+    tests/golden/ToyTest1_ExpressionMatrix.csv) through ExpressionMatrix.findSimilarPairs4 at lshCount=128, against
+    the oracle.  Cell0 = {Gene0:10, Gene1:10}, Cell1 = {Gene1:10, Gene3:10}, Cell2 = {Gene3:20}."""
+    import toytest1
+    from expressionmatrix2_amd import ExpressionMatrix, files
+    gene_count, toc, genes, counts = toytest1.load()
+    assert gene_count == 3 and toc.tolist() == [0, 2, 4, 5]
+    assert genes.tolist() == [0, 1, 1, 2, 2] and counts.tolist() == [10., 10., 10., 10., 20.]
+    d = str(tmp_path / "data")
+    files.create_directory(d, gene_count, toc, capi.make_counts(genes, counts))
+    e = ExpressionMatrix(d)
+    e.findSimilarPairs4(similarPairsName="Lsh", lshCount=128)              # k=100, threshold 0.2, seed 231: the defaults
+    vectors = oracle.generate_lsh_vectors(gene_count, 128, 231)
+    expect = oracle.compute_signatures(toc, genes, counts, gene_count, vectors, 128)
+    got = capi.compute_signatures(toc, capi.make_counts(genes, counts), gene_count, vectors, 128)
     assert np.array_equal(got, expect)
-    cell, sim, used = oracle.find_similar_pairs4(got, 128, 100, 0.2)
-    pairs, gused = capi.find_similar_pairs4(got, 128, 100, 0.2)
-    assert np.array_equal(gused, used) and np.array_equal(pairs["cell"], cell)
+    cell, sim, used = oracle.find_similar_pairs4(expect, 128, 100, 0.2)
+    k, pairs, gused = files.read_similar_pairs(d, "Lsh")
+    assert k == 100 and np.array_equal(gused, used) and np.array_equal(pairs["cell"], cell)
+    assert np.array_equal(pairs["similarity"].view(np.uint32), sim.view(np.uint32))
+    # what the data says whatever the hyperplanes: Cell0 is exactly anti-correlated with Cell2 (all 128 bits differ)
+    # and finds nobody; Cell1 and Cell2 (exact similarity 0.5) find each other
+    assert oracle.mismatch_matrix(expect, 128)[0, 2] == 128
+    assert used.tolist() == [0, 1, 1] and cell[1, 0] == 2 and cell[2, 0] == 1
 
 
 def test_empty_cells_and_unsorted_free_rows(oracle):

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Checks the compiled matrix-core walk (scanTilesMatrixPinned, csrc/em2_scan_symmetric.hip): the hand-written steps
+keep the wave's rows and accumulators in v64..v255 without the compiler knowing (tools/gen_matrix_step_asm.py), so the
+compiler's own code inside that function must never touch those registers, must not spill inside the loop, and must
+not use flat_ instructions between the steps (their out-of-order completion would break the counted LDS waits).
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off --cuda-device-only -S -o /tmp/sym.s em2_scan_symmetric.hip
+    python3 tools/check_matrix_walk_registers.py /tmp/sym.s
+"""
+import re
+import sys
+
+OWNED_FIRST = 64          # v38..v63 are the steps' temporaries: dead between steps, the compiler may use them there
+
+
+def functions(lines):
+    name, start = None, 0
+    for i, line in enumerate(lines):
+        m = re.match(r"^(_Z\w*scanTilesMatrixPinned\w*):", line)
+        if m:
+            name, start = m.group(1), i
+        elif name and line.startswith(".Lfunc_end"):
+            yield name, lines[start:i]
+            name = None
+
+
+def registers(line):
+    text = line.split(";")[0]
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", text):
+        yield from range(int(m.group(1)), int(m.group(2)) + 1)
+    for m in re.finditer(r"\bv(\d+)\b", text):
+        yield int(m.group(1))
+
+
+def main():
+    lines = open(sys.argv[1]).read().split("\n")
+    failures = 0
+    found = 0
+    for name, body in functions(lines):
+        found += 1
+        in_asm = False
+        first_step = last_step = None
+        for i, line in enumerate(body):
+            if "v_mfma" in line:
+                first_step = i if first_step is None else first_step
+                last_step = i
+        for i, line in enumerate(body):
+            if "#ASMSTART" in line:
+                in_asm = True
+                continue
+            if "#ASMEND" in line:
+                in_asm = False
+                continue
+            if in_asm or first_step is None or not (first_step <= i <= last_step):
+                continue
+            bad = [r for r in registers(line) if r >= OWNED_FIRST]
+            if bad:
+                print("%s: compiler code touches v%d between the steps: %s" % (name, bad[0], line.strip()))
+                failures += 1
+            if "flat_" in line:
+                print("%s: flat instruction between the steps: %s" % (name, line.strip()))
+                failures += 1
+        spills = sum(1 for i, line in enumerate(body) if "scratch_" in line and first_step is not None and first_step <= i <= last_step)
+        print("%s: %d lines, %d scratch accesses between the first and the last step" % (name, len(body), spills))
+    # the events function is called between the steps: its own registers must stay below the owned ones
+    for i, line in enumerate(lines):
+        m = re.match(r"^(_Z\w*matrixEventsCall\w*):", line)
+        if not m:
+            continue
+        for later in lines[i:]:
+            n = re.match(r"^; NumVgprs: (\d+)", later)
+            if n:
+                print("%s: %s VGPRs" % (m.group(1), n.group(1)))
+                if int(n.group(1)) > OWNED_FIRST:
+                    print("%s: uses registers of the steps" % m.group(1))
+                    failures += 1
+                break
+    if not found:
+        print("no scanTilesMatrixPinned function found")
+        return 1
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

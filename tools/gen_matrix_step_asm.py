@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Writes expressionmatrix2_amd/csrc/em2_matrix_step_asm.h: the inline-assembly body of one tile step of the
+matrix-core walk (fsp4ScanMatrixKernel / fsp4TileMatrixKernel, csrc/em2_scan_symmetric.hip).
+
+    python3 tools/gen_matrix_step_asm.py > expressionmatrix2_amd/csrc/em2_matrix_step_asm.h
+
+One step = the 32 x 64 dot products of one 32-column tile with the wave's 64 rows: 16 k-steps x 2
+v_mfma_scale_f32_32x32x64_f8f6f4 (FP4 +-1 operands, f32 accumulate), the column fragments read from LDS through a
+four-deep register ring with COUNTED lgkmcnt waits (the compiler's own schedule reuses two registers and waits for
+lgkmcnt(0) in front of every second k-step, which exposes the LDS latency 8 times per tile), and -- interleaved with
+the MFMAs, two results per k-step -- the test of the PREVIOUS tile's results against min(row bound, column bound): the
+step of tile t hides the column tests of tile t-1 under its own matrix instructions.
+
+Everything the step touches sits in fixed physical registers that the compiler never sees as values: inline-asm
+operands cannot be indexed by sub-register, a step has more operands than the 30 an asm statement may carry, and with
+the tuples pinned by "{v[a:b]}" constraints the register allocator moved other values into them and reloaded 32 row
+registers from scratch in front of every step.  So v32..v255 belong to the walk: every asm statement of the walk
+lists them as clobbered (no value of the compiler's lives there across a step), the rows are written by
+EM2_MATRIX_SET_ROW_FRAGMENT, the results are read by EM2_MATRIX_READ_X / _Y, and the steps take scalar operands only
+(LDS base addresses): the per-lane state of the walk -- row bounds, log counts -- lives in LDS, so that the walk's
+loop holds no vector value of the compiler's across a step or across the call of the events function
+(tools/check_matrix_walk_registers.py checks the compiled code):
+
+    v[128:191]  B operand: rows 0..31 of the wave, k-steps 0..15 (4 registers each)
+    v[192:255]  B operand: rows 32..63
+    v[64:79] / v[80:95]     accumulator set X (rows 0..31 / 32..63)
+    v[96:111] / v[112:127]  accumulator set Y
+    v[48:63]    ring of four column fragments (A operand)
+    v[40:47]    two buffers of four column bounds (the previous tile's, this lane's half)
+    v32 lane, v33 / v34 / v35 LDS addresses (tile, bounds, row state), v36 scale, v37 / v38 row bounds, v39 threshold
+
+Accumulator layout (32x32 result, columns = A = M, rows = B = N): lane l, register i of a set's first / second
+accumulator holds row (l & 31) / 32 + (l & 31) and column 8 * (i >> 2) + 4 * (l >> 5) + (i & 3) of the tile.
+
+Test of register i = 4q + j of accumulator a of the previous tile (q = 0..3 is the "group": the four 64-bit lane
+masks the step returns, one per group):   pass = min(rowBound[a], columnBound[8q + 4 * (l >> 5) + j]) <= dot.
+The column bounds come from the wave's bound scratch in LDS (32 floats per tile), 16 bytes per group and lane half;
+the row bounds from the wave's state block (float rowDot[64], lane l reads [l & 31] and [32 + (l & 31)]).
+"""
+import sys
+
+SETS = {"X": (64, 80), "Y": (96, 112)}
+ROWS = (128, 192)
+RING = 48
+BOUNDS = 40
+LANE, TILE_ADDR, BOUND_ADDR, STATE_ADDR, SCALE, ROW_BOUND0, ROW_BOUND1, THR = 32, 33, 34, 35, 36, 37, 38, 39
+FIRST_OWNED = 32
+STEPS = 16
+
+
+def vreg(base, count=1):
+    return "v%d" % base if count == 1 else "v[%d:%d]" % (base, base + count - 1)
+
+
+class Stream:
+    def __init__(self):
+        self.lines = []
+        self.queue = []          # LDS operations in flight, oldest first (they complete in order)
+
+    def emit(self, text):
+        self.lines.append(text)
+
+    def lds(self, name, text):
+        self.lines.append(text)
+        self.queue.append(name)
+
+    def wait_for(self, name):
+        if name not in self.queue:
+            return
+        index = self.queue.index(name)
+        self.lines.append("s_waitcnt lgkmcnt(%d)" % (len(self.queue) - index - 1))
+        del self.queue[:index + 1]
+
+
+def prologue(s, o, tile, tests):
+    """lane id and the lane's LDS addresses from the scalar bases"""
+    s.emit("v_mbcnt_lo_u32_b32 %s, -1, 0" % vreg(LANE))
+    s.emit("v_mbcnt_hi_u32_b32 %s, -1, %s" % (vreg(LANE), vreg(LANE)))
+    if tile:
+        s.emit("v_lshl_add_u32 %s, %s, 4, %s" % (vreg(TILE_ADDR), vreg(LANE), o["tileBase"]))          # + 16 * lane
+        s.emit("v_mov_b32 %s, 0x7f7f7f7f" % vreg(SCALE))                                                 # E8M0 2^0 in every byte
+    if tests:
+        s.emit("v_and_b32 %s, 31, %s" % (vreg(STATE_ADDR), vreg(LANE)))
+        s.emit("v_lshl_add_u32 %s, %s, 2, %s" % (vreg(STATE_ADDR), vreg(STATE_ADDR), o["stateBase"]))     # + 4 * (lane & 31)
+        s.emit("v_lshrrev_b32 %s, 5, %s" % (vreg(BOUND_ADDR), vreg(LANE)))
+        s.emit("v_lshl_add_u32 %s, %s, 4, %s" % (vreg(BOUND_ADDR), vreg(BOUND_ADDR), o["boundBase"]))     # + 16 * (lane >> 5)
+        s.lds("rowBound0", "ds_read_b32 %s, %s" % (vreg(ROW_BOUND0), vreg(STATE_ADDR)))
+        s.lds("rowBound1", "ds_read_b32 %s, %s offset:128" % (vreg(ROW_BOUND1), vreg(STATE_ADDR)))
+        s.lds("bounds0", "ds_read_b128 %s, %s" % (vreg(BOUNDS, 4), vreg(BOUND_ADDR)))
+
+
+def tests_of(s, o, q, j, k, prev0, prev1):
+    bound = BOUNDS + 4 * (q & 1) + j
+    for a, (acc, row_bound) in enumerate(((prev0, ROW_BOUND0), (prev1, ROW_BOUND1))):
+        s.emit("v_min_f32 %s, %s, %s" % (vreg(THR), vreg(row_bound), vreg(bound)))
+        if j == 0 and a == 0:
+            s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["group%d" % q], vreg(THR), vreg(acc + k)))
+        else:
+            s.emit("v_cmp_le_f32 vcc, %s, %s" % (vreg(THR), vreg(acc + k)))
+            s.emit("s_or_b64 %s, %s, vcc" % (o["group%d" % q], o["group%d" % q]))
+
+
+def step(cur, prev, tests, operands):
+    """cur / prev: 'X' or 'Y'.  operands: placeholder names -> asm operand text."""
+    cur0, cur1 = SETS[cur]
+    prev0, prev1 = SETS[prev]
+    o = operands
+    s = Stream()
+    prologue(s, o, True, tests)
+    for k in range(4):
+        s.lds("a%d" % k, "ds_read_b128 %s, %s offset:%d" % (vreg(RING + 4 * k, 4), vreg(TILE_ADDR), 1024 * k))
+    for k in range(STEPS):
+        slot = RING + 4 * (k % 4)
+        s.wait_for("a%d" % k)
+        for a, (acc, rows) in enumerate(((cur0, ROWS[0]), (cur1, ROWS[1]))):
+            s.emit("v_mfma_scale_f32_32x32x64_f8f6f4 %s, %s, %s, %s, %s, %s op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+                   % (vreg(acc, 16), vreg(slot, 4), vreg(rows + 4 * k, 4), "0" if k == 0 else vreg(acc, 16),
+                      vreg(SCALE), vreg(SCALE)))
+        if k + 4 < STEPS:
+            s.lds("a%d" % (k + 4), "ds_read_b128 %s, %s offset:%d" % (vreg(slot, 4), vreg(TILE_ADDR), 1024 * (k + 4)))
+        if tests:
+            q, j = k >> 2, k & 3
+            if j == 0:
+                s.wait_for("bounds%d" % q)
+            if j == 1 and q < 3:
+                # the other buffer: group q - 1 was its last reader, and vector instructions issue in order
+                s.lds("bounds%d" % (q + 1), "ds_read_b128 %s, %s offset:%d"
+                      % (vreg(BOUNDS + 4 * ((q + 1) & 1), 4), vreg(BOUND_ADDR), 32 * (q + 1)))
+            tests_of(s, o, q, j, k, prev0, prev1)
+    assert not s.queue, s.queue
+    return s.lines
+
+
+def test_only(prev, operands):
+    """The test of set `prev` without a step: the last tile of a walk.  Its MFMAs may still be in flight and the
+    hardware does not interlock a VALU read of an MFMA result: wait them out first."""
+    prev0, prev1 = SETS[prev]
+    o = operands
+    s = Stream()
+    s.emit("s_nop 15")
+    s.emit("s_nop 15")
+    s.emit("s_nop 15")
+    prologue(s, o, False, True)
+    for q in range(4):
+        if q:
+            s.lds("bounds%d" % q, "ds_read_b128 %s, %s offset:%d" % (vreg(BOUNDS + 4 * (q & 1), 4), vreg(BOUND_ADDR), 32 * q))
+        s.wait_for("bounds%d" % q)
+        for j in range(4):
+            tests_of(s, o, q, j, 4 * q + j, prev0, prev1)
+    assert not s.queue, s.queue
+    return s.lines
+
+
+def c_string(lines, indent="    "):
+    return "\n".join('%s"%s\\n"' % (indent, line) for line in lines)
+
+
+def macro(name, lines):
+    return "#define %s \\\n%s\n\n" % (name, " \\\n".join(c_string(lines).split("\n")))
+
+
+def main():
+    out = sys.stdout
+    out.write("// em2_matrix_step_asm.h -- GENERATED by tools/gen_matrix_step_asm.py (see there for the register map); do not edit.\n")
+    out.write("#ifndef EM2_MATRIX_STEP_ASM_H\n#define EM2_MATRIX_STEP_ASM_H\n\n")
+    # Operand order of the asm statements in em2_scan_symmetric.hip:
+    #   step with tests:    %0..%3 group masks ("=&s"), then "s": %4 tileBase, %5 boundBase, %6 stateBase (LDS byte addresses)
+    #   step without tests: %0 tileBase
+    #   test only:          %0..%3 group masks, %4 boundBase, %5 stateBase
+    with_tests = {"group0": "%0", "group1": "%1", "group2": "%2", "group3": "%3", "tileBase": "%4", "boundBase": "%5",
+                  "stateBase": "%6"}
+    without = {"tileBase": "%0"}
+    only = {"group0": "%0", "group1": "%1", "group2": "%2", "group3": "%3", "boundBase": "%4", "stateBase": "%5"}
+    for cur, prev in (("X", "Y"), ("Y", "X")):
+        out.write(macro("EM2_MATRIX_STEP_%s_TESTING_%s" % (cur, prev), step(cur, prev, True, with_tests)))
+        out.write(macro("EM2_MATRIX_STEP_%s" % cur, step(cur, prev, False, without)))
+        out.write(macro("EM2_MATRIX_TEST_%s" % cur, test_only(cur, only)))
+    # every vector register the walk owns: no value of the compiler's may live there across any of its asm statements
+    owned = ", ".join('"v%d"' % r for r in range(FIRST_OWNED, 256))
+    out.write("#define EM2_MATRIX_OWNED_REGISTERS %s\n\n" % owned)
+    out.write("#define EM2_MATRIX_STEP_CLOBBERS \"memory\", \"vcc\", EM2_MATRIX_OWNED_REGISTERS\n\n")
+    # the B operand: fragment `index` (0..15 rows 0..31, 16..31 rows 32..63; k-step = index & 15) into its four registers
+    out.write("// B operand: fragment index (k-step index & 15 of rows 0..31 for index < 16, of rows 32..63 above) -> its registers\n")
+    out.write("#define EM2_MATRIX_SET_ROW_FRAGMENT(index, f) \\\n    switch (index) { \\\n")
+    for index in range(32):
+        base = ROWS[index >> 4] + 4 * (index & 15)
+        text = "\\n".join("v_mov_b32 v%d, %%%d" % (base + c, c) for c in range(4))
+        out.write('    case %d: asm volatile("%s" :: "v"((f).x), "v"((f).y), "v"((f).z), "v"((f).w) : EM2_MATRIX_OWNED_REGISTERS); break; \\\n'
+                  % (index, text))
+    out.write("    default: break; \\\n    }\n\n")
+    for name, (acc0, acc1) in SETS.items():
+        out.write("// results of register i of accumulator set %s: d0 = rows 0..31, d1 = rows 32..63\n" % name)
+        out.write("#define EM2_MATRIX_READ_%s(i, d0, d1) \\\n    switch (i) { \\\n" % name)
+        for i in range(16):
+            out.write('    case %d: asm volatile("v_mov_b32 %%0, v%d\\nv_mov_b32 %%1, v%d" : "=v"(d0), "=v"(d1)); break; \\\n'
+                      % (i, acc0 + i, acc1 + i))
+        out.write("    default: __builtin_unreachable(); \\\n    }\n\n")
+    out.write("#endif\n")
+
+
+if __name__ == "__main__":
+    main()
