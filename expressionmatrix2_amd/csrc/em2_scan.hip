@@ -440,6 +440,9 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     args.localBlockBase = 0;
     args.columnLimit = cellCount;
     args.shardFlags = 0;
+    args.fragments = nullptr;
+    args.matrixLdsOffset = 0;
+    args.pad2 = uint32_t(envNumber("EM2_MATRIX_DIAG", 0));       // measurements only (fsp4ScanMatrixKernel)
 
     {
         // EM2_SCAN_MODE=virtual + EM2_VIRTUAL_WORLD=P: the multi-GPU symmetric scan with all ranks played on this GPU

@@ -746,16 +746,13 @@ __device__ __forceinline__ P ldsPointer(uint32_t address)
     return (P)(uintptr_t)address;
 }
 
-// Per-wave LDS block of the walk (byte offsets).  The per-lane state lives here and not in registers: see the
-// register discussion in tools/gen_matrix_step_asm.py.
-constexpr uint32_t kWalkRowDot = 0u;            // float[64]: bound of row r as a dot product (1024 - 2 mMax)
-constexpr uint32_t kWalkLogCount = 256u;        // uint32[64]: entries in row r's log
-constexpr uint32_t kWalkWords = 512u;           // uint32[16] wave-uniform words, indices below
-constexpr uint32_t kWalkBounds = 576u;          // float[4][32]: column bounds of the four tile buffers (as dot products)
-constexpr uint32_t kWalkSnapStage = 1088u;      // int32[2][64]: the published cut-offs of a pair of tiles, as loaded
-constexpr uint32_t kMatrixWalkLdsBytes = 1600u;
-enum : uint32_t { kWordEmitPos = 0, kWordEmitEnd, kWordValidLo, kWordValidHi, kWordRowBase, kWordLogCapacity, kWordLogBaseLo,
-                  kWordLogBaseHi, kWordRowBits, kWordInboxLo, kWordInboxHi };
+// Per-wave LDS block of the walk (byte offsets).
+constexpr uint32_t kWalkRowDot = 0u;            // float[64]: bound of row r as a dot product (1024 - 2 mMax), read by the steps
+constexpr uint32_t kWalkBounds = 256u;          // float[4][32]: column bounds of the four tile buffers (as dot products)
+constexpr uint32_t kWalkSnapStage = 768u;       // int32[2][64]: the published cut-offs of a pair of tiles, as loaded
+constexpr uint32_t kWalkQueue = 1280u;          // uint32[64][4]: the lanes' event records of the tile under test
+constexpr uint32_t kMatrixWalkLdsBytes = 2304u;
+constexpr uint32_t kWalkQueueSlots = 4u;
 
 __device__ __forceinline__ uint32_t uniform(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
 
@@ -765,8 +762,8 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 }
 
 // The lane id, recomputed wherever it is used: a volatile asm is neither hoisted out of the walk's loop nor merged
-// with an earlier one, so nothing derived from it stays alive across a step or a call (where it would live in
-// scratch: the steps own the registers above v31, a callee those below).
+// with an earlier one, so nothing derived from it stays alive across a step (where it would need one of the few
+// registers the steps leave to the compiler).
 __device__ __forceinline__ uint32_t laneId()
 {
     uint32_t lane;
@@ -774,125 +771,212 @@ __device__ __forceinline__ uint32_t laneId()
     return lane;
 }
 
-// The events of the tile whose results sit in accumulator set X (IN_Y false) or Y: group q = the lanes in which a
-// result of group q passed its test.  A function of its own, all arguments wave-uniform: inlined into the walk its
-// code (which the compiler allocates as it likes) took registers of the steps -- there is no way to reserve v64..v255
-// other than not needing them -- and values of the walk that live across a call have no register to live in (the
-// steps own everything above v31, the callee everything below), so the walk keeps none: rows' bounds and log counts
-// are in the wave's LDS block.  The function itself must stay below v64 (tools/check_matrix_walk_registers.py).
-// One copy of the code serves the four groups (a run-time loop); the results are fetched from their fixed registers
-// as they are needed.  A row's log must list its columns in ascending order: within a group the lower lane half holds
-// columns 8q .. 8q+3 and the upper half 8q+4 .. 8q+7, so the row side goes half by half.
-// __builtin_amdgcn_kernarg_segment_ptr() is null outside a kernel: the kernarg pointer is an argument.
-template <bool BOTH, bool IN_Y>
-__device__ __attribute__((noinline)) void matrixEventsCall(uint64_t group0, uint64_t group1, uint64_t group2, uint64_t group3,
-                                                           uint32_t tileBaseArg, uint32_t slotArg, uint32_t walkLdsArg, const void* auxArg)
+// Result `index` of the accumulators: 0..15 / 16..31 = set X rows 0..31 / 32..63, 32..63 = set Y likewise (v64 + index).
+__device__ __forceinline__ float readAccumulator(uint32_t index)
 {
-    const uint32_t walkLds = uniform(walkLdsArg);
-    const uint32_t tileBase = uniform(tileBaseArg), slot = uniform(slotArg);
-    const ArgsPtr aux = (ArgsPtr)uniform64(reinterpret_cast<uint64_t>(auxArg));
-    const uint64_t groups[4] = {uniform64(group0), uniform64(group1), uniform64(group2), uniform64(group3)};
-    const LdsFloatPtr rowDots = ldsPointer<LdsFloatPtr>(walkLds + kWalkRowDot);
-    const LdsWordPtr logCounts = ldsPointer<LdsWordPtr>(walkLds + kWalkLogCount);
-    const LdsWordPtr words = ldsPointer<LdsWordPtr>(walkLds + kWalkWords);
-    const LdsFloatPtr boundScratch = ldsPointer<LdsFloatPtr>(walkLds + kWalkBounds);
+    float value;
+    // (gfx950 has no v_movrels: VGPR index mode, source 0 relative)
+    asm volatile("s_set_gpr_idx_on %1, 0x1\n\ts_nop 1\n\tv_mov_b32 %0, v64\n\ts_set_gpr_idx_off" : "=v"(value) : "s"(index) : "m0");
+    return value;
+}
+
+// What the events of a walk need, all wave-uniform (scalar registers).
+struct MatrixWalkUniform {
+    uint64_t validRows;             // bit r = row r of the wave is a cell of the problem (and takes part)
+    uint32_t rowBase;               // cell id of the wave's row 0
+    GlobalWord64Ptr logBase;        // the wave's 64 logs, logCapacity entries each
+    uint32_t logCapacity;
+    GlobalWord64Ptr inbox;
+    uint32_t rowBits;
+    uint32_t emitPos, emitEnd;
+    ArgsPtr aux;                    // for the out-of-line refill of the inbox chunk
+    uint32_t diag;                  // EM2_MATRIX_DIAG (measurements only, results are wrong): 1 no events, 4 no row side, 8 no column side, 16 no tiles, 32 no tests, 64 no barrier, 512 events one by one
+};
+
+// The events of the tile whose results sit in accumulator set X (IN_Y false) or Y.  registerMask: bit 31 - (2i + a) =
+// register i of accumulator a passed its test in some lane.  Lane l, register i = 4q + j of accumulator a = row
+// 32a + (l & 31), column 8q + 4 (l >> 5) + j of the tile.  One compact copy of the code (run-time loops, the result
+// fetched by v_movrels): what is executed is proportional to the events, and it stays in the instruction cache.
+// A row's log must list its columns in ascending order (the replay offers them in that order): within a group q the
+// lower lane half holds columns 8q .. 8q+3 and the upper half 8q+4 .. 8q+7, so a group's set bits are visited twice
+// when a row of the upper half has an event -- first the lower half's rows (and the column side of all), then the
+// upper half's.
+template <bool BOTH, bool IN_Y>
+__device__ __forceinline__ void matrixEvents(uint32_t registerMask, uint32_t tileBase, uint32_t boundLds, const float (&rowDot)[2],
+                                             uint32_t (&logCount)[2], MatrixWalkUniform& u)
+{
     const uint32_t lane = laneId(), half = lane >> 5, lane31 = lane & 31u;
-    uint32_t emitPos = uniform(words[kWordEmitPos]), emitEnd = uniform(words[kWordEmitEnd]);
-    const uint64_t validRows = uint64_t(uniform(words[kWordValidLo])) | (uint64_t(uniform(words[kWordValidHi])) << 32);
-    const uint32_t row0 = uniform(words[kWordRowBase]) + lane31;
-    const uint32_t logCapacity = uniform(words[kWordLogCapacity]);
-    const GlobalWord64Ptr logBase = (GlobalWord64Ptr)(uint64_t(uniform(words[kWordLogBaseLo])) | (uint64_t(uniform(words[kWordLogBaseHi])) << 32));
-    const uint32_t rowBits = uniform(words[kWordRowBits]);
-    const GlobalWord64Ptr inbox = (GlobalWord64Ptr)(uint64_t(uniform(words[kWordInboxLo])) | (uint64_t(uniform(words[kWordInboxHi])) << 32));
-    const float rowDot[2] = {rowDots[lane31], rowDots[32u + lane31]};
-    uint32_t logCount[2] = {logCounts[lane31], logCounts[32u + lane31]};
-    const bool rowValid[2] = {((uint32_t(validRows) >> lane31) & 1u) != 0u, ((uint32_t(validRows >> 32) >> lane31) & 1u) != 0u};
 
     // emitColumn: pool pointer and key layout in registers, the out-of-line refill through the explicit kernarg pointer
     auto emit = [&](bool on, uint32_t target, uint32_t candidate, uint32_t m) {
         const uint64_t mask = __builtin_amdgcn_ballot_w64(on);
         if (mask == 0ull) return;
-        uint32_t p = emitPos, e = emitEnd;
+        uint32_t p = u.emitPos, e = u.emitEnd;
         if (p > e) return;                                                      // disabled after an overflow
         const uint32_t n = uint32_t(__builtin_popcountll(mask));
         if (p + n > e) {
-            const uint64_t fresh = refillInboxChunk(aux->inbox, aux->inboxControl, aux->inboxCapacity, aux->inboxChunk, lane, p, e);
+            const uint64_t fresh = refillInboxChunk(u.aux->inbox, u.aux->inboxControl, u.aux->inboxCapacity, u.aux->inboxChunk, lane, p, e);
             p = uniform(uint32_t(fresh));
             e = uniform(uint32_t(fresh >> 32));
-            emitPos = p;
-            emitEnd = e;
+            u.emitPos = p;
+            u.emitEnd = e;
             if (p > e) return;
         }
-        if (on) inbox[p + lanesBelow(mask)] = (uint64_t(target) << (13u + rowBits)) | (uint64_t(candidate) << 13u) | uint64_t(m);
-        emitPos = p + n;
+        if (on) u.inbox[p + lanesBelow(mask)] = (uint64_t(target) << (13u + u.rowBits)) | (uint64_t(candidate) << 13u) | uint64_t(m);
+        u.emitPos = p + n;
     };
 
 #pragma nounroll
     for (uint32_t q = 0; q < 4u; q++) {
-        const uint64_t flagged = q == 0u ? groups[0] : q == 1u ? groups[1] : q == 2u ? groups[2] : groups[3];
-        if (flagged == 0ull) continue;
-        const uint32_t groupBase = tileBase + 8u * q;
-        const LdsFloatPtr bounds = boundScratch + slot * 32u + 8u * q + 4u * half;     // this lane's half: columns 8q + 4 half + 0..3
-        uint64_t rowMasks[4][2];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float dots[2];
-            if (IN_Y) { EM2_MATRIX_READ_Y(4u * q + uint32_t(j), dots[0], dots[1]); }
-            else { EM2_MATRIX_READ_X(4u * q + uint32_t(j), dots[0], dots[1]); }
-            const float columnDot = bounds[j];
-#pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const float dot = dots[a];
-                const bool passRow = dot >= rowDot[a];
-                const bool passColumn = rowValid[a] && dot >= columnDot;
-                rowMasks[j][a] = __builtin_amdgcn_ballot_w64(passRow);
-                if (__builtin_amdgcn_ballot_w64(passColumn || (BOTH && passRow)) != 0ull) {
-                    const uint32_t col = groupBase + 4u * half + uint32_t(j);
-                    const uint32_t rowId = row0 + 32u * uint32_t(a);
-                    const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
-                    emit(passColumn, col, rowId, m);
-                    if (BOTH) emit(rowValid[a] && passRow, rowId, col, m);
+        const uint32_t bits = (registerMask >> (24u - 8u * q)) & 0xffu;      // bit 7 - (2j + a): register 4q + j of accumulator a
+        if (bits == 0u) continue;
+        typedef float Float4 __attribute__((ext_vector_type(4)));
+        const Float4 groupBounds = *ldsPointer<const __attribute__((address_space(3))) Float4*>(boundLds + (8u * q + 4u * half) * 4u);
+        bool upperRows = false;
+#pragma nounroll
+        for (uint32_t pass = 0; pass < 2u; pass++) {
+            uint32_t rest = bits;
+#pragma nounroll
+            while (rest != 0u) {
+                const uint32_t e = uint32_t(__builtin_clz(rest)) - 24u;         // 2j + a, ascending
+                rest &= ~(0x80u >> e);
+                const uint32_t j = e >> 1, a = e & 1u;
+                float dot;
+                if (u.diag & 256u) {
+                    float d0, d1;
+                    if (IN_Y) { EM2_MATRIX_READ_Y(4u * q + j, d0, d1); }
+                    else { EM2_MATRIX_READ_X(4u * q + j, d0, d1); }
+                    dot = a ? d1 : d0;
+                } else {
+                    dot = readAccumulator((IN_Y ? 32u : 0u) + 16u * a + 4u * q + j);
                 }
-            }
-        }
-        if (BOTH) continue;
-        // the row side: ascending columns per row = lower lane half first
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if ((uint32_t(rowMasks[j][0] >> (32 * h)) | uint32_t(rowMasks[j][1] >> (32 * h))) == 0u) continue;
-                float dots[2];
-                if (IN_Y) { EM2_MATRIX_READ_Y(4u * q + uint32_t(j), dots[0], dots[1]); }
-                else { EM2_MATRIX_READ_X(4u * q + uint32_t(j), dots[0], dots[1]); }
-#pragma unroll
-                for (int a = 0; a < 2; a++) {
-                    const uint32_t mask = uint32_t(rowMasks[j][a] >> (32 * h));       // rows (by l & 31) with an event in this half
-                    if (mask == 0u) continue;
-                    const float dot = dots[a];
-                    if (half == uint32_t(h) && dot >= rowDot[a]) {
-                        const uint32_t col = groupBase + 4u * uint32_t(h) + uint32_t(j);
-                        const size_t at = size_t(32u * uint32_t(a) + lane31) * logCapacity + logCount[a];
-                        logBase[at] = uint64_t(col) | (uint64_t(uint32_t((kMatrixBits - dot) * 0.5f)) << 32);      // storeEntry
+                const bool passRow = dot >= (a ? rowDot[1] : rowDot[0]);
+                const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
+                const uint32_t col = tileBase + 8u * q + 4u * half + j;
+                if (pass == 0u) {
+                    const float columnDot = (u.diag & 128u) ? (j == 0u ? groupBounds.x : j == 1u ? groupBounds.y : j == 2u ? groupBounds.z : groupBounds.w)
+                                                            : ldsPointer<LdsFloatPtr>(boundLds)[8u * q + 4u * half + j];
+                    const bool rowValid = ((uint32_t(u.validRows >> (32u * a)) >> lane31) & 1u) != 0u;
+                    const bool passColumn = rowValid && dot >= columnDot;
+                    const uint32_t rowId = u.rowBase + 32u * a + lane31;
+                    if (!(u.diag & 8u)) {
+                        emit(passColumn, col, rowId, m);
+                        if (BOTH) emit(rowValid && passRow, rowId, col, m);
                     }
-                    logCount[a] += (mask >> lane31) & 1u;            // both lanes that hold the row count it
                 }
+                if (BOTH || (u.diag & 4u)) continue;
+                const uint64_t rows = __builtin_amdgcn_ballot_w64(passRow);
+                const uint32_t mine = pass == 0u ? uint32_t(rows) : uint32_t(rows >> 32);     // rows (by l & 31) with an event in this pass' half
+                if (pass == 0u && uint32_t(rows >> 32) != 0u) upperRows = true;
+                if (mine == 0u) continue;
+                const uint32_t count = a ? logCount[1] : logCount[0];
+                if (half == pass && passRow) {
+                    u.logBase[size_t(32u * a + lane31) * u.logCapacity + count] = uint64_t(col) | (uint64_t(m) << 32);      // storeEntry
+                }
+                const uint32_t increment = (mine >> lane31) & 1u;       // both lanes that hold the row count it
+                if (a) logCount[1] += increment;
+                else logCount[0] += increment;
             }
+            if (!upperRows) break;
         }
     }
-    if (!BOTH) {
-        logCounts[lane31] = logCount[0];                              // lanes l and l + 32 store the same values
-        logCounts[32u + lane31] = logCount[1];
-    }
-    words[kWordEmitPos] = emitPos;
-    words[kWordEmitEnd] = emitEnd;
 }
 
-// The lock-step walk over the tiles [colBegin, colEnd) with the hand-scheduled steps.  Out of line, with no vector
-// value of its own alive across a step: the steps own v32..v255.  Wave-uniform arguments arrive in vector registers
-// and are moved to the scalar file first; pointers get their address spaces back (a generic pointer would make the
-// compiler emit flat_ instructions, whose out-of-order completion would also break the counted LDS waits of the
-// steps).  LDS arguments are byte addresses.  io = {logCount, emitPos, emitEnd} of the calling lane.
+// The events of a tile, lane-parallel.  The step left every lane a queue of up to four records
+// (2i + a + 1) << 16 | (dot + 1024), one per register i = 4q + j of accumulator a that passed its test in that lane,
+// in ascending i; `count` = records per lane (more than four: the queue overflowed, the caller takes matrixEvents with
+// every register flagged instead).  First the column side of every record goes to the inbox (order is irrelevant
+// there: the inbox is sorted).  Then the row side, accumulator by accumulator: lanes l and l ^ 32 hold the same row
+// 32a + (l & 31) and different columns of it, each lane's records ascend in the column, and a row's log must ascend
+// too -- so every round the two lanes swap the column of their next record for that row and the smaller one is
+// appended (a two-way merge; both lanes count the appends of both).  Straight-line vector code: what the scalar,
+// one-event-at-a-time form spends per event this spends per round, and a tile rarely needs a second round.
+template <bool BOTH>
+__device__ __forceinline__ void matrixEventsQueued(uint32_t count, uint32_t tileBase, uint32_t boundLds, uint32_t queueLds,
+                                                   const float (&rowDot)[2], uint32_t (&logCount)[2], MatrixWalkUniform& u)
+{
+    typedef uint32_t Word4 __attribute__((ext_vector_type(4)));
+    const uint32_t lane = laneId(), half = lane >> 5, lane31 = lane & 31u;
+    const Word4 queue = *ldsPointer<const __attribute__((address_space(3))) Word4*>(queueLds + lane * (kWalkQueueSlots * 4u));
+    const LdsFloatPtr bounds = ldsPointer<LdsFloatPtr>(boundLds);
+    const bool valid0 = ((uint32_t(u.validRows) >> lane31) & 1u) != 0u, valid1 = ((uint32_t(u.validRows >> 32) >> lane31) & 1u) != 0u;
+    uint32_t rowEvents[2] = {0u, 0u};            // per accumulator: bit s = record s has an event for this lane's row of it
+    uint32_t columns[kWalkQueueSlots], mismatches[kWalkQueueSlots];
+#pragma unroll
+    for (uint32_t slot = 0; slot < kWalkQueueSlots; slot++) {
+        columns[slot] = mismatches[slot] = 0u;
+        const bool have = slot < count;
+        if (__builtin_amdgcn_ballot_w64(have) == 0ull) continue;
+        const uint32_t record = have ? queue[slot] : 0x10000u;
+        const uint32_t code = (record >> 16) - 1u, i = code >> 1, a = code & 1u;
+        const float dot = float(int32_t(record & 0xffffu) - 1024);
+        const uint32_t columnIndex = 8u * (i >> 2) + 4u * half + (i & 3u);       // in the tile
+        const float columnDot = bounds[columnIndex];
+        const uint32_t col = tileBase + columnIndex;
+        const uint32_t rowId = u.rowBase + 32u * a + lane31;
+        const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
+        const bool rowValid = a ? valid1 : valid0;
+        const bool passRow = have && dot >= (a ? rowDot[1] : rowDot[0]);
+        const bool passColumn = have && rowValid && dot >= columnDot;
+        columns[slot] = columnIndex;
+        mismatches[slot] = m;
+        if (passRow) {
+            if (a) rowEvents[1] |= 1u << slot;
+            else rowEvents[0] |= 1u << slot;
+        }
+        if (u.diag & 8u) continue;
+        // emitColumn, twice in the BOTH form: pool pointer and key layout in registers, the refill through the kernarg pointer
+#pragma unroll
+        for (int side = 0; side < (BOTH ? 2 : 1); side++) {
+            const bool on = side == 0 ? passColumn : (passRow && rowValid);
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(on);
+            if (mask == 0ull || u.emitPos > u.emitEnd) continue;
+            const uint32_t n = uint32_t(__builtin_popcountll(mask));
+            if (u.emitPos + n > u.emitEnd) {
+                const uint64_t fresh = refillInboxChunk(u.aux->inbox, u.aux->inboxControl, u.aux->inboxCapacity, u.aux->inboxChunk, lane,
+                                                        u.emitPos, u.emitEnd);
+                u.emitPos = uniform(uint32_t(fresh));
+                u.emitEnd = uniform(uint32_t(fresh >> 32));
+                if (u.emitPos > u.emitEnd) continue;
+            }
+            const uint32_t target = side == 0 ? col : rowId, candidate = side == 0 ? rowId : col;
+            if (on) u.inbox[u.emitPos + lanesBelow(mask)] = (uint64_t(target) << (13u + u.rowBits)) | (uint64_t(candidate) << 13u) | uint64_t(m);
+            u.emitPos += n;
+        }
+    }
+    if (BOTH || (u.diag & 4u)) return;
+#pragma unroll
+    for (uint32_t a = 0; a < 2u; a++) {
+        uint32_t pending = rowEvents[a];
+        while (__builtin_amdgcn_ballot_w64(pending != 0u) != 0ull) {
+            const bool mine = pending != 0u;
+            const uint32_t slot = mine ? uint32_t(__builtin_ctz(pending)) : 0u;      // the lane's next record for this row
+            const uint32_t column = slot == 0u ? columns[0] : slot == 1u ? columns[1] : slot == 2u ? columns[2] : columns[3];
+            const uint32_t m = slot == 0u ? mismatches[0] : slot == 1u ? mismatches[1] : slot == 2u ? mismatches[2] : mismatches[3];
+            const uint32_t wish = mine ? (1u | (column << 1)) : 0u;
+            const auto swapped = __builtin_amdgcn_permlane32_swap(wish, wish, false, false);       // {lower half twice, upper half twice}
+            const uint32_t partner = half ? swapped[0] : swapped[1];
+            const bool partnerToo = (partner & 1u) != 0u;
+            const bool append = mine && !(partnerToo && (partner >> 1) < column);          // the halves never hold the same column
+            const bool partnerAppends = partnerToo && !(mine && column < (partner >> 1));
+            if (append) {
+                u.logBase[size_t(32u * a + lane31) * u.logCapacity + logCount[a]] = uint64_t(tileBase + column) | (uint64_t(m) << 32);   // storeEntry
+                pending &= pending - 1u;
+            }
+            logCount[a] += uint32_t(append) + uint32_t(partnerAppends);           // both lanes count the appends of both
+        }
+    }
+}
+
+// The lock-step walk over the tiles [colBegin, colEnd) with the hand-scheduled steps.  Out of line: the steps own
+// v32..v255, and inlined into the kernels the values that live across the walk compete with them; as a function of its
+// own the walk keeps the few vector values it needs across a step (the rows' bounds and log counts in accumulator
+// layout) below v32, and nothing of the compiler's may ever sit at v64 or above (tools/check_matrix_walk_registers.py
+// checks the compiled code).  Wave-uniform arguments arrive in vector registers and are moved to the scalar file first;
+// pointers get their address spaces back (a generic pointer would make the compiler emit flat_ instructions, whose
+// out-of-order completion would also break the counted LDS waits of the steps).  LDS arguments are byte addresses.
+// __builtin_amdgcn_kernarg_segment_ptr() is null outside a kernel: the kernarg pointer is an argument.
+// io = {logCount, emitPos, emitEnd} of the calling lane.
 struct MatrixWalkIo {
     uint32_t logCount, emitPos, emitEnd;
 };
@@ -900,81 +984,103 @@ struct MatrixWalkIo {
 template <bool IDENTITY, bool BOTH = false>
 __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* auxArg, const void* fragmentsArg, const void* snapArg,
                                                                     uint32_t colBeginArg, uint32_t colEndArg,
-                                                                    uint32_t rowFragmentBlockArg, float rowDot, uint32_t row,
+                                                                    uint32_t rowFragmentBlockArg, float rowDotArg, uint32_t row,
                                                                     bool rowValid, Entry* myLog, uint32_t logCapacityArg,
                                                                     MatrixWalkIo* io, uint32_t tilesLdsArg, uint32_t stopWordsLdsArg,
                                                                     uint32_t walkLdsArg)
 {
     const GlobalFragmentPtr fragments = (GlobalFragmentPtr)uniform64(reinterpret_cast<uint64_t>(fragmentsArg));
     const GlobalIntPtr snap = (GlobalIntPtr)uniform64(reinterpret_cast<uint64_t>(snapArg));
-    const uint64_t auxBits = uniform64(reinterpret_cast<uint64_t>(auxArg));
-    const ArgsPtr aux = (ArgsPtr)auxBits;
-    const void* const auxUniform = reinterpret_cast<const void*>(auxBits);       // for the calls: out of scalar registers
     const uint32_t colBegin = uniform(colBeginArg), colEnd = uniform(colEndArg);
     const uint32_t rowFragmentBlock = uniform(rowFragmentBlockArg), logCapacity = uniform(logCapacityArg);
     const uint32_t tilesLds = uniform(tilesLdsArg);
-    const LdsFragmentPtr tiles = ldsPointer<LdsFragmentPtr>(tilesLds);
     const LdsWordPtr stopWords = ldsPointer<LdsWordPtr>(uniform(stopWordsLdsArg));
     const uint32_t walkLds = uniform(walkLdsArg);
-    const LdsFloatPtr rowDots = ldsPointer<LdsFloatPtr>(walkLds + kWalkRowDot);
-    const LdsWordPtr logCounts = ldsPointer<LdsWordPtr>(walkLds + kWalkLogCount);
-    const LdsWordPtr words = ldsPointer<LdsWordPtr>(walkLds + kWalkWords);
     const LdsFloatPtr boundScratch = ldsPointer<LdsFloatPtr>(walkLds + kWalkBounds);
     const LdsIntPtr snapStage = ldsPointer<LdsIntPtr>(walkLds + kWalkSnapStage);
+    MatrixWalkUniform u;
+    u.aux = (ArgsPtr)uniform64(reinterpret_cast<uint64_t>(auxArg));
+    u.inbox = (GlobalWord64Ptr)u.aux->inbox;
+    u.rowBits = u.aux->rowBits;
+    u.diag = u.aux->pad2;
+    u.logCapacity = logCapacity;
+    u.emitPos = uniform(io->emitPos);
+    u.emitEnd = uniform(io->emitEnd);
+    float rowDot[2];                // accumulator layout: [a] = bound of row 32a + (lane & 31)
+    uint32_t logCount[2];
     {
-        // the wave's state block
         const uint32_t lane = laneId();
-        rowDots[lane] = rowDot;
-        logCounts[lane] = io->logCount;
-        const uint64_t valid = __builtin_amdgcn_ballot_w64(rowValid);
+        ldsPointer<LdsFloatPtr>(walkLds + kWalkRowDot)[lane] = rowDotArg;         // for the steps: float[64], lane = row
+        // lane-per-row state -> accumulator layout: v_permlane32_swap(x, x) = {lower half twice, upper half twice}
+        const auto dots = __builtin_amdgcn_permlane32_swap(__float_as_uint(rowDotArg), __float_as_uint(rowDotArg), false, false);
+        rowDot[0] = __uint_as_float(dots[0]);
+        rowDot[1] = __uint_as_float(dots[1]);
+        const uint32_t count = io->logCount;
+        const auto counts = __builtin_amdgcn_permlane32_swap(count, count, false, false);
+        logCount[0] = counts[0];
+        logCount[1] = counts[1];
+        u.validRows = __builtin_amdgcn_ballot_w64(rowValid);
+        u.rowBase = uniform(row);                                                 // lane 0: the wave's first row
         // the log of the wave's row 0: the calling lane's log is logCapacity * lane entries further on
-        const uint64_t logBase = myLog ? uniform64(reinterpret_cast<uint64_t>(myLog) - uint64_t(lane) * logCapacity * sizeof(Entry)) : 0ull;
-        const uint64_t inbox = reinterpret_cast<uint64_t>(aux->inbox);
-        if (lane == 0u) {
-            words[kWordEmitPos] = io->emitPos;
-            words[kWordEmitEnd] = io->emitEnd;
-            words[kWordValidLo] = uint32_t(valid);
-            words[kWordValidHi] = uint32_t(valid >> 32);
-            words[kWordRowBase] = row;                      // lane 0: the wave's first row
-            words[kWordLogCapacity] = logCapacity;
-            words[kWordLogBaseLo] = uint32_t(logBase);
-            words[kWordLogBaseHi] = uint32_t(logBase >> 32);
-            words[kWordRowBits] = aux->rowBits;
-            words[kWordInboxLo] = uint32_t(inbox);
-            words[kWordInboxHi] = uint32_t(inbox >> 32);
-        }
-        // the B operand: 2 x 16 fragments into their registers (v128..v255)
-#pragma unroll
-        for (int index = 0; index < 32; index++) {
-            const FragmentWord4 f = fragments[(size_t(rowFragmentBlock + uint32_t(index >> 4)) * kMatrixSteps + uint32_t(index & 15)) * 64u + lane];
-            EM2_MATRIX_SET_ROW_FRAGMENT(index, f);
-        }
+        u.logBase = (GlobalWord64Ptr)(myLog ? uniform64(reinterpret_cast<uint64_t>(myLog) - uint64_t(lane) * logCapacity * sizeof(Entry)) : 0ull);
+        // the B operand: the 2 x 16 fragments of the wave's rows straight into their registers (v128..v255)
+        const uint64_t rowFragments = reinterpret_cast<uint64_t>(fragments) + size_t(rowFragmentBlock) * kMatrixTileWords * 16u;
+        asm volatile(EM2_MATRIX_LOAD_ROWS : : "s"(rowFragments) : EM2_MATRIX_STEP_CLOBBERS);
     }
+    const uint32_t diag = u.diag;
     const uint32_t waveSlot = uniform(threadIdx.x >> 6) * 64u;
+    // A tile travels global -> LDS without touching registers (global_load_lds_dwordx4: LDS address = M0 + 16 * lane,
+    // which is exactly the fragment order; this wave moves its quarter, 4 x 1 KB).  Issued from inline asm: the compiler
+    // must not know of these transfers -- it orders every LDS access of its own behind an LDS-DMA it has seen with
+    // s_waitcnt vmcnt(0), and the events of a tile (which read the tile's bounds from LDS) would sit out the latency of
+    // the next pair's tiles every time.  What needs the tiles waits for them explicitly in front of the barrier.
 #define EM2_STAGE_TILE(tileIndex, buffer)                                                                                     \
     do {                                                                                                                      \
-        const GlobalFragmentPtr src_ = fragments + size_t(tileIndex) * kMatrixTileWords + waveSlot + laneId();                       \
-        const LdsFragmentPtr dst_ = tiles + (buffer) * kMatrixTileWords + waveSlot;                                          \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) {                                                                   \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + j_ * 256),              \
-                                             (__attribute__((address_space(3))) void*)(dst_ + j_ * 256), 16, 0, 0);          \
-        }                                                                                                                     \
+        if (diag & 16u) break;                                                                                                \
+        const uint64_t src_ = reinterpret_cast<uint64_t>(fragments) + (size_t(tileIndex) * kMatrixTileWords + waveSlot) * 16u + \
+                              laneId() * 16u;                                                                                 \
+        const uint32_t dst_ = tilesLds + ((buffer) * kMatrixTileWords + waveSlot) * 16u;                                     \
+        asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"                                      \
+                     "s_add_u32 m0, %4, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"                              \
+                     "s_add_u32 m0, %4, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"                              \
+                     "s_add_u32 m0, %4, 0x3000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off"                                  \
+                     :                                                                                                        \
+                     : "v"(src_), "v"(src_ + 0x1000u), "v"(src_ + 0x2000u), "v"(src_ + 0x3000u), "s"(dst_)                   \
+                     : "memory", "m0", "scc");                                                                                \
     } while (0)
-    // The published cut-offs of the 64 columns of a pair of tiles (lane = column) travel global -> LDS one pair ahead
+    // The published cut-offs of the 64 columns of a pair of tiles (lane = column) travel the same way one pair ahead
     // (columns past the end repeat the last one: never tested).  Any value a cell published earlier is valid: bounds
     // only tighten.
 #define EM2_STAGE_SNAP(firstColumn, buffer)                                                                                   \
     do {                                                                                                                      \
         uint32_t column_ = (firstColumn) + laneId();                                                                          \
         column_ = column_ < colEnd ? column_ : colEnd - 1u;                                                                   \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(snap + column_),                    \
-                                         (__attribute__((address_space(3))) void*)(snapStage + (buffer) * 64u), 4, 0, 0);    \
+        const uint64_t address_ = reinterpret_cast<uint64_t>(snap) + uint64_t(column_) * 4u;                                 \
+        const uint32_t dst_ = walkLds + kWalkSnapStage + (buffer) * 256u;                                                     \
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"                                           \
+                     :                                                                                                        \
+                     : "v"(address_), "s"(dst_)                                                                               \
+                     : "memory", "m0");                                                                                       \
     } while (0)
+#define EM2_WAIT_STAGED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
     EM2_STAGE_TILE(colBegin / 32u, 0u);
     if (colBegin + 32u < colEnd) EM2_STAGE_TILE(colBegin / 32u + 1u, 1u);
     EM2_STAGE_SNAP(colBegin, 0u);
+    EM2_WAIT_STAGED();
     __syncthreads();
-    uint64_t groups[4];
+    uint32_t recordCount;           // per lane: records the step left in the lane's queue (more than kWalkQueueSlots: overflow)
+    uint64_t passScratch[5];        // scalar pairs for the steps: pass masks in flight, saved exec
+    const uint32_t queueLds = walkLds + kWalkQueue;
+    // the events of the tile just tested (IN_Y: its results are in accumulator set Y)
+#define EM2_MATRIX_EVENTS(IN_Y)                                                                                               \
+    do {                                                                                                                      \
+        if ((diag & 1u) || __builtin_amdgcn_ballot_w64(recordCount != 0u) == 0ull) break;                                     \
+        if (__builtin_amdgcn_ballot_w64(recordCount > kWalkQueueSlots) != 0ull || (diag & 512u)) {                            \
+            matrixEvents<BOTH, IN_Y>(0xffffffffu, pendingBase, boundBase, rowDot, logCount, u);     /* every register */       \
+        } else {                                                                                                              \
+            matrixEventsQueued<BOTH>(recordCount, pendingBase, boundBase, queueLds, rowDot, logCount, u);                     \
+        }                                                                                                                     \
+    } while (0)
     bool pending = false, pendingInY = false;
     uint32_t pendingBase = 0, pendingSlot = 0;
     uint32_t iteration = 0;
@@ -993,15 +1099,13 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         // ---- first tile of the pair -> X, under it the test of the pending tile (always in Y here) ----
         {
             const uint32_t tileBase = tilesLds + 2u * pair * (kMatrixTileWords * 16u);
-            if (pending) {
+            if (pending && !(diag & 32u)) {
                 const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
                 asm volatile(EM2_MATRIX_STEP_X_TESTING_Y
-                             : "=&s"(groups[0]), "=&s"(groups[1]), "=&s"(groups[2]), "=&s"(groups[3])
-                             : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot)
+                             : "=v"(recordCount), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                             : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(queueLds)
                              : EM2_MATRIX_STEP_CLOBBERS);
-                if ((groups[0] | groups[1] | groups[2] | groups[3]) != 0ull) {
-                    matrixEventsCall<BOTH, true>(groups[0], groups[1], groups[2], groups[3], pendingBase, pendingSlot, walkLds, auxUniform);
-                }
+                EM2_MATRIX_EVENTS(true);
             } else {
                 asm volatile(EM2_MATRIX_STEP_X : : "s"(tileBase) : EM2_MATRIX_STEP_CLOBBERS);
             }
@@ -1011,26 +1115,30 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
             pendingSlot = 2u * pair;
         }
         // ---- second tile -> Y, under it the test of the first ----
-        if (colBase + 32u < colEnd) {
+        if (colBase + 32u < colEnd && (diag & 32u)) {
+            const uint32_t tileBase = tilesLds + (2u * pair + 1u) * (kMatrixTileWords * 16u);
+            asm volatile(EM2_MATRIX_STEP_Y : : "s"(tileBase) : EM2_MATRIX_STEP_CLOBBERS);
+            pendingInY = true;
+        } else if (colBase + 32u < colEnd) {
             const uint32_t tileBase = tilesLds + (2u * pair + 1u) * (kMatrixTileWords * 16u);
             const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
             asm volatile(EM2_MATRIX_STEP_Y_TESTING_X
-                         : "=&s"(groups[0]), "=&s"(groups[1]), "=&s"(groups[2]), "=&s"(groups[3])
-                         : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot)
+                         : "=v"(recordCount), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                         : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(queueLds)
                          : EM2_MATRIX_STEP_CLOBBERS);
-            if ((groups[0] | groups[1] | groups[2] | groups[3]) != 0ull) {
-                matrixEventsCall<BOTH, false>(groups[0], groups[1], groups[2], groups[3], pendingBase, pendingSlot, walkLds, auxUniform);
-            }
+            EM2_MATRIX_EVENTS(false);
             pendingInY = true;
             pendingBase = colBase + 32u;
             pendingSlot = 2u * pair + 1u;
         }
         // the untested tile and the next pair add at most 96 entries to a row's log before the next chance to stop
-        const bool full = !BOTH && __builtin_amdgcn_ballot_w64(logCounts[laneId()] + kMatrixLogMargin > logCapacity) != 0ull;
+        const uint32_t worst = logCount[0] > logCount[1] ? logCount[0] : logCount[1];
+        const bool full = !BOTH && __builtin_amdgcn_ballot_w64(worst + kMatrixLogMargin > logCapacity) != 0ull;
         const uint32_t slot = iteration % 3u;
         if (full && laneId() == 0u) stopWords[slot] = 1u;
         if (waveSlot == 0u && laneId() == 0u) stopWords[(iteration + 1u) % 3u] = 0u;
-        __syncthreads();
+        EM2_WAIT_STAGED();
+        if (!(diag & 64u)) __syncthreads();
         if (stopWords[slot] != 0u) {
             __syncthreads();
             if (waveSlot == 0u && laneId() == 0u) stopWords[slot] = 0u;
@@ -1041,38 +1149,33 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     }
 #undef EM2_STAGE_TILE
 #undef EM2_STAGE_SNAP
+#undef EM2_WAIT_STAGED
     // ---- the tile still untested ----
     if (pending) {
         const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
         if (pendingInY) {
             asm volatile(EM2_MATRIX_TEST_Y
-                         : "=&s"(groups[0]), "=&s"(groups[1]), "=&s"(groups[2]), "=&s"(groups[3])
-                         : "s"(boundBase), "s"(walkLds + kWalkRowDot)
-                         : EM2_MATRIX_STEP_CLOBBERS);
-            if ((groups[0] | groups[1] | groups[2] | groups[3]) != 0ull) {
-                matrixEventsCall<BOTH, true>(groups[0], groups[1], groups[2], groups[3], pendingBase, pendingSlot, walkLds, auxUniform);
-            }
+                         : "=v"(recordCount), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4]) : "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(queueLds) : EM2_MATRIX_STEP_CLOBBERS);
+            EM2_MATRIX_EVENTS(true);
         } else {
             asm volatile(EM2_MATRIX_TEST_X
-                         : "=&s"(groups[0]), "=&s"(groups[1]), "=&s"(groups[2]), "=&s"(groups[3])
-                         : "s"(boundBase), "s"(walkLds + kWalkRowDot)
-                         : EM2_MATRIX_STEP_CLOBBERS);
-            if ((groups[0] | groups[1] | groups[2] | groups[3]) != 0ull) {
-                matrixEventsCall<BOTH, false>(groups[0], groups[1], groups[2], groups[3], pendingBase, pendingSlot, walkLds, auxUniform);
-            }
+                         : "=v"(recordCount), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4]) : "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(queueLds) : EM2_MATRIX_STEP_CLOBBERS);
+            EM2_MATRIX_EVENTS(false);
         }
     }
-    io->logCount = logCounts[laneId()];
-    io->emitPos = uniform(words[kWordEmitPos]);
-    io->emitEnd = uniform(words[kWordEmitEnd]);
+#undef EM2_MATRIX_EVENTS
+    // a row's log entries were stored by two lanes and are read back by a third (the row's own): the stores must have
+    // left the wave before the caller replays the log (it reads past the L1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    io->logCount = laneId() < 32u ? logCount[0] : logCount[1];
+    io->emitPos = u.emitPos;
+    io->emitEnd = u.emitEnd;
     return result;
 }
 
 template <bool IDENTITY, bool PINNED>
-__global__ void __launch_bounds__(256, 2)
-fsp4ScanMatrixKernel(Fsp4Args args)
+__device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     FragmentWord4* tiles = reinterpret_cast<FragmentWord4*>(ldsRaw + kernelArgs()->matrixLdsOffset);
@@ -1201,7 +1304,9 @@ fsp4ScanMatrixKernel(Fsp4Args args)
                     if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
                     uint32_t c = 0, m = 0;
                     if (active) {
-                        const Entry e = myLog[i];
+                        // (the hand-scheduled walk writes a row's entries from two lanes: read them past the L1, like the
+                        // row lists)
+                        const Entry e = PINNED ? loadEntryCoherent(myLog + i) : myLog[i];
                         c = e.cell;
                         m = e.key;
                     }
@@ -1286,6 +1391,26 @@ fsp4ScanMatrixKernel(Fsp4Args args)
             for (uint32_t i = p + lane; i < e; i += 64u) inbox[i] = ~0ull;
         }
     }
+}
+
+// The two entry points.  The kernel of the hand-scheduled walk lets the compiler allocate 64 vector registers only
+// (amdgpu_num_vgpr): v64..v255 hold the rows and the accumulators of the steps, which the compiler does not know
+// of -- this is what keeps its own code, the events of a tile included, out of them (the kernel descriptor still
+// asks for 256: the clobber lists of the steps count).
+template <bool IDENTITY>
+__global__ void __launch_bounds__(256, 2)
+fsp4ScanMatrixKernel(Fsp4Args args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    scanMatrixBody<IDENTITY, false>(ldsRaw);
+}
+
+template <bool IDENTITY>
+__global__ void __launch_bounds__(256, 2)
+fsp4ScanMatrixPinnedKernel(Fsp4Args args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    scanMatrixBody<IDENTITY, true>(ldsRaw);
 }
 
 // Second phase of the symmetric scan: one wave per triangle row block replays the sorted inbox entries of its 64
@@ -1538,10 +1663,8 @@ fsp4TileKernel(Fsp4Args args)
 // waves walks the columns of the segment below the quad in lock step (scanTilesMatrix, both sides deferred); the
 // quad's own 256 columns are done by the v_xor/v_bcnt code.  Prefix and segment lengths are multiples of 256 cells.
 template <bool PINNED>
-__global__ void __launch_bounds__(256, 2)
-fsp4TileMatrixKernel(Fsp4Args args)
+__device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     FragmentWord4* tiles = reinterpret_cast<FragmentWord4*>(ldsRaw + kernelArgs()->matrixLdsOffset);
@@ -1637,6 +1760,20 @@ fsp4TileMatrixKernel(Fsp4Args args)
     }
 }
 
+__global__ void __launch_bounds__(256, 2)
+fsp4TileMatrixKernel(Fsp4Args args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    tileMatrixBody<false>(ldsRaw);
+}
+
+__global__ void __launch_bounds__(256, 2)
+fsp4TileMatrixPinnedKernel(Fsp4Args args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    tileMatrixBody<true>(ldsRaw);
+}
+
 // max over `count` arrays of `n` int32 laid out back to back (the emulation's stand-in for all_reduce(MAX))
 __global__ void maxReduceKernel(int32_t* __restrict__ arrays, uint32_t n, uint32_t count)
 {
@@ -1669,16 +1806,17 @@ static size_t scanMatrixLdsBytes(uint32_t k)
 }
 
 // EM2_MATRIX_WALK=0 keeps the compiler-scheduled walk (scanTilesMatrix) for A/B runs.
-static bool matrixWalkPinned() { return envNumber("EM2_MATRIX_WALK", 1) != 0; }
+// (bit 0: fsp4ScanMatrixKernel, bit 1: fsp4TileMatrixKernel; default both)
+static bool matrixWalkPinned(uint32_t which = 1u) { return (envNumber("EM2_MATRIX_WALK", 3) & which) != 0; }
 
 static const void* scanMatrixKernelFor(bool identity)
 {
     if (matrixWalkPinned()) {
-        return identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<true, true>)
-                        : reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<false, true>);
+        return identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixPinnedKernel<true>)
+                        : reinterpret_cast<const void*>(&fsp4ScanMatrixPinnedKernel<false>);
     }
-    return identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<true, false>)
-                    : reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<false, false>);
+    return identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<true>)
+                    : reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<false>);
 }
 
 constexpr uint32_t kSymmetricMinCells = 131072;
@@ -1982,6 +2120,10 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         uint64_t blocksWanted = uint64_t(cuCount) * uint64_t(blocksPerCu);
         if (blocksWanted * 4u > maxResidentWaves()) blocksWanted = maxResidentWaves() / 4u;      // the logs are sized for that
         if (blocksWanted > ticketsMatrix) blocksWanted = ticketsMatrix;
+        if (const char* v = getenv("EM2_SCAN_VERBOSE")) {
+            if (v[0] == '1') fprintf(stderr, "[em2] matrix kernel: %d blocks per CU, %llu blocks, %zu bytes of LDS, walk %s\n", blocksPerCu,
+                                     (unsigned long long)blocksWanted, matrixLds, matrixWalkPinned() ? "pinned" : "compiler");
+        }
         void* matrixArgsArray[] = {&matrixArgs};
         if (timing[0]) (void)hipEventRecord(timing[2], stream);
         e = hipLaunchKernel(matrixKernel, dim3(uint32_t(blocksWanted)), dim3(256), matrixArgsArray, matrixLds, stream);
@@ -2398,12 +2540,12 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             args.fragments = ws + plan.offFragments;
-            args.matrixLdsOffset = 0;
-            const size_t matrixLds = kMatrixLdsBytes;
+            args.matrixLdsOffset = uint32_t(envNumber("EM2_TILE_LDS_PAD", 0));          // debugging aid
+            const size_t matrixLds = args.matrixLdsOffset + kMatrixLdsBytes;
             uint64_t blocksWanted = uint64_t(cuCount) * 2u;
             if (blocksWanted > own) blocksWanted = own;
-            const void* tileMatrixKernel = matrixWalkPinned() ? reinterpret_cast<const void*>(&fsp4TileMatrixKernel<true>)
-                                                              : reinterpret_cast<const void*>(&fsp4TileMatrixKernel<false>);
+            const void* tileMatrixKernel = matrixWalkPinned(2u) ? reinterpret_cast<const void*>(&fsp4TileMatrixPinnedKernel)
+                                                              : reinterpret_cast<const void*>(&fsp4TileMatrixKernel);
             e = hipFuncSetAttribute(tileMatrixKernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(matrixLds));
             if (e != hipSuccess) return e;
             void* matrixArgsArray[] = {&args};

@@ -108,7 +108,7 @@ def scan_knobs():
     saved = {k: os.environ.get(k) for k in ("EM2_MIN_SEGMENT_COLUMNS", "EM2_LOG_CAPACITY", "EM2_SCAN_MODE",
                                              "EM2_BLOCKS_PER_CU", "EM2_FULL_ROW_CELLS", "EM2_SEGMENTS",
                                              "EM2_INBOX_CAPACITY", "EM2_SYMMETRIC_MIN_CELLS", "EM2_VIRTUAL_WORLD",
-                                             "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_SCAN_MATRIX")}
+                                             "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_SCAN_MATRIX", "EM2_MATRIX_WALK")}
 
     def set_knobs(**kw):
         for key, value in kw.items():
@@ -374,3 +374,20 @@ def test_sharded_virtual_world_tiles_on_the_matrix_cores(oracle, scan_knobs, wor
         info = capi.dev_find_similar_pairs4_last_launch()
         assert info["form"] == 2 and (info["matrix_pairs"] > 0) == bool(matrix)
         assert_same(pairs, gused, cell, sim, used)
+
+
+def test_sharded_tile_walk_repeats_bit_identically(scan_knobs):
+    """The deferred square of the sharded scan on the matrix cores (hand-scheduled walk, both sides deferred) against
+    the compiler-scheduled walk on a problem of a few thousand tiles, many times over: a tile piece that reaches LDS
+    late or in the wrong place shows as a handful of mismatch counts that are off by one or two (found this way:
+    global_load_lds with a scalar base and a 32-bit lane offset left a 1 KB piece of a tile stale in about every
+    second run; the 64-bit lane address form does not)."""
+    sig = synth.clustered_signatures(24000, 1024, cluster_count=12, flip=0.2, seed=77)
+    scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=4, EM2_MATRIX_WALK=0)
+    reference = capi.find_similar_pairs4(sig, 1024, 40, 0.2)
+    scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=4, EM2_MATRIX_WALK=3)
+    for attempt in range(25):
+        again = capi.find_similar_pairs4(sig, 1024, 40, 0.2)
+        assert np.array_equal(reference[1], again[1]), attempt
+        assert np.array_equal(reference[0]["cell"], again[0]["cell"]), attempt
+        assert np.array_equal(reference[0]["similarity"].view(np.uint32), again[0]["similarity"].view(np.uint32)), attempt

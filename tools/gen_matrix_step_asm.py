@@ -27,13 +27,19 @@ loop holds no vector value of the compiler's across a step or across the call of
     v[96:111] / v[112:127]  accumulator set Y
     v[48:63]    ring of four column fragments (A operand)
     v[40:47]    two buffers of four column bounds (the previous tile's, this lane's half)
-    v32 lane, v33 / v34 / v35 LDS addresses (tile, bounds, row state), v36 scale, v37 / v38 row bounds, v39 threshold
+    v28 record count, v29 queue address, v30 / v31 record and its address (stubs);
+    v32 lane, then a threshold; v33 / v34 / v35 LDS addresses (tile, bounds, row state), v36 scale, v37 / v38 row bounds,
+    v39 the other threshold
 
 Accumulator layout (32x32 result, columns = A = M, rows = B = N): lane l, register i of a set's first / second
 accumulator holds row (l & 31) / 32 + (l & 31) and column 8 * (i >> 2) + 4 * (l >> 5) + (i & 3) of the tile.
 
-Test of register i = 4q + j of accumulator a of the previous tile (q = 0..3 is the "group": the four 64-bit lane
-masks the step returns, one per group):   pass = min(rowBound[a], columnBound[8q + 4 * (l >> 5) + j]) <= dot.
+Test of register i = 4q + j of accumulator a of the previous tile:
+    pass = min(rowBound[a], columnBound[8q + 4 * (l >> 5) + j]) <= dot            (q = the "group" of 8 columns)
+A register that passes in some lane (rare) branches to its stub behind the body: the passing lanes append a record
+(2i + a + 1) << 16 | (dot + 1024) to their own four-slot queue in LDS (v28 counts, v29 = the lane's queue address);
+the step returns the counts.  The events of a tile are then handled lane-parallel, one record per lane and round,
+by the compiler's code (matrixEventsQueued) -- straight-line vector code instead of a scalar chain per event.
 The column bounds come from the wave's bound scratch in LDS (32 floats per tile), 16 bytes per group and lane half;
 the row bounds from the wave's state block (float rowDot[64], lane l reads [l & 31] and [32 + (l & 31)]).
 """
@@ -43,8 +49,11 @@ SETS = {"X": (64, 80), "Y": (96, 112)}
 ROWS = (128, 192)
 RING = 48
 BOUNDS = 40
-LANE, TILE_ADDR, BOUND_ADDR, STATE_ADDR, SCALE, ROW_BOUND0, ROW_BOUND1, THR = 32, 33, 34, 35, 36, 37, 38, 39
-FIRST_OWNED = 32
+LANE, TILE_ADDR, BOUND_ADDR, STATE_ADDR, SCALE, ROW_BOUND0, ROW_BOUND1, THR0 = 32, 33, 34, 35, 36, 37, 38, 39
+THR1 = LANE          # the lane id is dead once the addresses are formed
+COUNT, QUEUE_ADDR, RECORD, RECORD_ADDR = 28, 29, 30, 31
+FIRST_OWNED = 28
+QUEUE_SLOTS = 4
 STEPS = 16
 
 
@@ -56,6 +65,7 @@ class Stream:
     def __init__(self):
         self.lines = []
         self.queue = []          # LDS operations in flight, oldest first (they complete in order)
+        self.stubs = []          # (register, accumulator) of the tests, in order
 
     def emit(self, text):
         self.lines.append(text)
@@ -80,6 +90,8 @@ def prologue(s, o, tile, tests):
         s.emit("v_lshl_add_u32 %s, %s, 4, %s" % (vreg(TILE_ADDR), vreg(LANE), o["tileBase"]))          # + 16 * lane
         s.emit("v_mov_b32 %s, 0x7f7f7f7f" % vreg(SCALE))                                                 # E8M0 2^0 in every byte
     if tests:
+        s.emit("v_lshl_add_u32 %s, %s, 4, %s" % (vreg(QUEUE_ADDR), vreg(LANE), o["queueBase"]))       # + 4 slots x 4 bytes per lane
+        s.emit("v_mov_b32 %s, 0" % vreg(COUNT))
         s.emit("v_and_b32 %s, 31, %s" % (vreg(STATE_ADDR), vreg(LANE)))
         s.emit("v_lshl_add_u32 %s, %s, 2, %s" % (vreg(STATE_ADDR), vreg(STATE_ADDR), o["stateBase"]))     # + 4 * (lane & 31)
         s.emit("v_lshrrev_b32 %s, 5, %s" % (vreg(BOUND_ADDR), vreg(LANE)))
@@ -90,14 +102,47 @@ def prologue(s, o, tile, tests):
 
 
 def tests_of(s, o, q, j, k, prev0, prev1):
+    """Vector half of the test of register k of the two accumulators: the pass masks go to the scalar pairs
+    pass0 / pass1 of parity k & 1; their scalar half (shift_in) follows one k-step later, when the masks have long
+    arrived -- a scalar instruction that reads a mask a vector compare has just written stalls the wave for the length
+    of the vector pipeline, twice per k-step."""
     bound = BOUNDS + 4 * (q & 1) + j
-    for a, (acc, row_bound) in enumerate(((prev0, ROW_BOUND0), (prev1, ROW_BOUND1))):
-        s.emit("v_min_f32 %s, %s, %s" % (vreg(THR), vreg(row_bound), vreg(bound)))
-        if j == 0 and a == 0:
-            s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["group%d" % q], vreg(THR), vreg(acc + k)))
-        else:
-            s.emit("v_cmp_le_f32 vcc, %s, %s" % (vreg(THR), vreg(acc + k)))
-            s.emit("s_or_b64 %s, %s, vcc" % (o["group%d" % q], o["group%d" % q]))
+    s.emit("v_min_f32 %s, %s, %s" % (vreg(THR0), vreg(ROW_BOUND0), vreg(bound)))
+    s.emit("v_min_f32 %s, %s, %s" % (vreg(THR1), vreg(ROW_BOUND1), vreg(bound)))
+    s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass0_%d" % (k & 1)], vreg(THR0), vreg(prev0 + k)))
+    s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass1_%d" % (k & 1)], vreg(THR1), vreg(prev1 + k)))
+
+
+def shift_in(s, o, k):
+    """Scalar half: a register whose test passed in some lane goes through its stub (out of line, behind the body)."""
+    for a in range(2):
+        s.emit("s_cmp_lg_u64 %s, 0" % o["pass%d_%d" % (a, k & 1)])
+        s.emit("s_cbranch_scc1 L_stub_%d_%d_%%=" % (k, a))
+        s.emit("L_back_%d_%d_%%=:" % (k, a))
+        s.stubs.append((k, a))
+
+
+def stubs(s, o, prev0, prev1):
+    """The lanes in which register k of accumulator a passed append one record to their queue in LDS:
+    (2k + a + 1) << 16 | (dot + 1024); a lane's fifth record is dropped, its count says so."""
+    s.emit("s_branch L_end_%=")
+    for k, a in s.stubs:
+        acc = (prev0, prev1)[a] + k
+        s.emit("L_stub_%d_%d_%%=:" % (k, a))
+        s.emit("s_mov_b64 %s, exec" % o["save"])
+        s.emit("s_mov_b64 exec, %s" % o["pass%d_%d" % (a, k & 1)])
+        s.emit("v_cvt_i32_f32 %s, %s" % (vreg(RECORD), vreg(acc)))
+        s.emit("v_add_u32 %s, 0x%x, %s" % (vreg(RECORD), ((2 * k + a + 1) << 16) + 1024, vreg(RECORD)))
+        s.emit("v_cmp_gt_u32 vcc, %d, %s" % (QUEUE_SLOTS, vreg(COUNT)))
+        s.emit("v_lshl_add_u32 %s, %s, 2, %s" % (vreg(RECORD_ADDR), vreg(COUNT), vreg(QUEUE_ADDR)))
+        s.emit("v_add_u32 %s, 1, %s" % (vreg(COUNT), vreg(COUNT)))
+        s.emit("s_and_b64 exec, exec, vcc")
+        s.emit("ds_write_b32 %s, %s" % (vreg(RECORD_ADDR), vreg(RECORD)))
+        s.emit("s_mov_b64 exec, %s" % o["save"])
+        s.emit("s_branch L_back_%d_%d_%%=" % (k, a))
+    s.emit("L_end_%=:")
+    s.emit("s_waitcnt lgkmcnt(0)")
+    s.emit("v_mov_b32 %s, %s" % (o["count"], vreg(COUNT)))
 
 
 def step(cur, prev, tests, operands):
@@ -126,8 +171,13 @@ def step(cur, prev, tests, operands):
                 # the other buffer: group q - 1 was its last reader, and vector instructions issue in order
                 s.lds("bounds%d" % (q + 1), "ds_read_b128 %s, %s offset:%d"
                       % (vreg(BOUNDS + 4 * ((q + 1) & 1), 4), vreg(BOUND_ADDR), 32 * (q + 1)))
+            if k:
+                shift_in(s, o, k - 1)
             tests_of(s, o, q, j, k, prev0, prev1)
     assert not s.queue, s.queue
+    if tests:
+        shift_in(s, o, STEPS - 1)
+        stubs(s, o, prev0, prev1)
     return s.lines
 
 
@@ -146,8 +196,12 @@ def test_only(prev, operands):
             s.lds("bounds%d" % q, "ds_read_b128 %s, %s offset:%d" % (vreg(BOUNDS + 4 * (q & 1), 4), vreg(BOUND_ADDR), 32 * q))
         s.wait_for("bounds%d" % q)
         for j in range(4):
+            if 4 * q + j:
+                shift_in(s, o, 4 * q + j - 1)
             tests_of(s, o, q, j, 4 * q + j, prev0, prev1)
     assert not s.queue, s.queue
+    shift_in(s, o, STEPS - 1)
+    stubs(s, o, prev0, prev1)
     return s.lines
 
 
@@ -164,13 +218,15 @@ def main():
     out.write("// em2_matrix_step_asm.h -- GENERATED by tools/gen_matrix_step_asm.py (see there for the register map); do not edit.\n")
     out.write("#ifndef EM2_MATRIX_STEP_ASM_H\n#define EM2_MATRIX_STEP_ASM_H\n\n")
     # Operand order of the asm statements in em2_scan_symmetric.hip:
-    #   step with tests:    %0..%3 group masks ("=&s"), then "s": %4 tileBase, %5 boundBase, %6 stateBase (LDS byte addresses)
+    #   step with tests:    %0 the lanes' record counts ("=v"), %1..%5 five scratch pairs ("=&s", 64 bits: the pass masks in
+    #                       flight, the saved exec), then "s": %6 tileBase, %7 boundBase, %8 stateBase, %9 queueBase
+    #                       (LDS byte addresses)
     #   step without tests: %0 tileBase
-    #   test only:          %0..%3 group masks, %4 boundBase, %5 stateBase
-    with_tests = {"group0": "%0", "group1": "%1", "group2": "%2", "group3": "%3", "tileBase": "%4", "boundBase": "%5",
-                  "stateBase": "%6"}
+    #   test only:          %0 record counts, %1..%5 scratch pairs, %6 boundBase, %7 stateBase, %8 queueBase
+    passes = {"pass0_0": "%1", "pass1_0": "%2", "pass0_1": "%3", "pass1_1": "%4", "save": "%5"}
+    with_tests = dict(passes, count="%0", tileBase="%6", boundBase="%7", stateBase="%8", queueBase="%9")
     without = {"tileBase": "%0"}
-    only = {"group0": "%0", "group1": "%1", "group2": "%2", "group3": "%3", "boundBase": "%4", "stateBase": "%5"}
+    only = dict(passes, count="%0", boundBase="%6", stateBase="%7", queueBase="%8")
     for cur, prev in (("X", "Y"), ("Y", "X")):
         out.write(macro("EM2_MATRIX_STEP_%s_TESTING_%s" % (cur, prev), step(cur, prev, True, with_tests)))
         out.write(macro("EM2_MATRIX_STEP_%s" % cur, step(cur, prev, False, without)))
@@ -178,7 +234,19 @@ def main():
     # every vector register the walk owns: no value of the compiler's may live there across any of its asm statements
     owned = ", ".join('"v%d"' % r for r in range(FIRST_OWNED, 256))
     out.write("#define EM2_MATRIX_OWNED_REGISTERS %s\n\n" % owned)
-    out.write("#define EM2_MATRIX_STEP_CLOBBERS \"memory\", \"vcc\", EM2_MATRIX_OWNED_REGISTERS\n\n")
+    out.write("#define EM2_MATRIX_STEP_CLOBBERS \"memory\", \"vcc\", \"scc\", EM2_MATRIX_OWNED_REGISTERS\n\n")
+    # the B operand in one go: 32 loads straight into the registers, one wait.  %0 = address of the wave's first row
+    # fragment (scalar pair); the fragments of a 32-row block are 1 KB apart (64 lanes x 16 bytes), the second block
+    # follows the first
+    lines = ["v_mbcnt_lo_u32_b32 %s, -1, 0" % vreg(LANE), "v_mbcnt_hi_u32_b32 %s, -1, %s" % (vreg(LANE), vreg(LANE)),
+             "v_lshlrev_b32 %s, 4, %s" % (vreg(TILE_ADDR), vreg(LANE))]
+    for index in range(32):
+        base = ROWS[index >> 4] + 4 * (index & 15)
+        if index and index % 4 == 0:
+            lines.append("v_add_u32 %s, 0x1000, %s" % (vreg(TILE_ADDR), vreg(TILE_ADDR)))
+        lines.append("global_load_dwordx4 %s, %s, %%0 offset:%d" % (vreg(base, 4), vreg(TILE_ADDR), 1024 * (index % 4)))
+    lines.append("s_waitcnt vmcnt(0)")
+    out.write(macro("EM2_MATRIX_LOAD_ROWS", lines))
     # the B operand: fragment `index` (0..15 rows 0..31, 16..31 rows 32..63; k-step = index & 15) into its four registers
     out.write("// B operand: fragment index (k-step index & 15 of rows 0..31 for index < 16, of rows 32..63 above) -> its registers\n")
     out.write("#define EM2_MATRIX_SET_ROW_FRAGMENT(index, f) \\\n    switch (index) { \\\n")
