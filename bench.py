@@ -61,6 +61,7 @@ def parse_args():
     p.add_argument("--cpu-baseline-cells", type=int, default=50000)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--check-rows", type=int, default=384)
+    p.add_argument("--no-extra", action="store_true", help="skip the configs[1] block")
     p.add_argument("--no-check", action="store_true",
                    help="diagnostic runs only (EM2_MATRIX_DIAG makes results wrong on purpose): skip the parity gates; "
                         "the line says so and is not a measurement")
@@ -99,6 +100,36 @@ def parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host, chec
             if len(picks) > 1:
                 break           # block-sized ranges: one sample each
     return sample, rows_checked
+
+
+def small_config(args, capi, sharded, synthetic, oracle, device, torch, cells=100000, genes=20000, steps=10, warmup=2):
+    """BASELINE configs[1] on one GPU: ms per step and pairs/s, gated like the headline."""
+    L, k, thr = args.lsh_count, args.k, args.threshold
+    pipe = sharded.DevicePipeline(cells, genes, L, k, thr, world_size=1, rank=0, dist=None, device=device)
+    toc, data = synthetic.expression_shard(0, cells, genes, density=args.density, device=device)
+    vectors_host = capi.lsh_generate_vectors(genes, L, args.seed)
+    pipe.set_inputs(toc, data, torch.from_numpy(vectors_host).to(device))
+    pipe.step()
+    torch.cuda.synchronize()
+    sig_host = pipe.full_sig[:cells].cpu().numpy().view(np.uint64)
+    before = parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host, args.check_rows)
+    for _ in range(warmup):
+        pipe.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pipe.check()
+    after = parity_gate(pipe, oracle, synthetic, pipe.full_sig[:cells].cpu().numpy().view(np.uint64), toc, data, vectors_host,
+                        args.check_rows)
+    launch = capi.dev_find_similar_pairs4_last_launch()
+    return {"workload": "%d cells x %d genes (%.3g nnz/cell), %d-bit signatures, findSimilarPairs4 k=%d threshold=%g, 1 GPU"
+                        % (cells, genes, args.density * genes, L, k, thr),
+            "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
+            "value": cells * (cells - 1) / 2.0 * steps / elapsed, "unit": "pairs/s", "scan_form": launch["form"],
+            "parity_check": {"signature_cells": before[0], "fsp4_rows": before[1], "after_timing_rows": after[1]}}
 
 
 def main():
@@ -293,14 +324,20 @@ def main():
     if matrix:
         result["dtype"] = "fp4 e2m1 +-1 products, f32 accumulate, exact (scan on the matrix cores) / u32 popcount (band, full rows) / f64 (projection)"
     matrix_traffic = None
-    matrix_traffic_file = os.path.join(ROOT, "profiles", "r01_pmc_matrix_scan_1Mcells.json")
-    if matrix and os.path.exists(matrix_traffic_file):
+    matrix_traffic_source = None
+    pinned_walk = os.environ.get("EM2_MATRIX_WALK", "3") not in ("0",)
+    for name in (("r02_pmc_matrix_scan_1Mcells.json",) if pinned_walk else ()) + ("r01_pmc_matrix_scan_1Mcells.json",):
+        matrix_traffic_file = os.path.join(ROOT, "profiles", name)
+        if not (matrix and os.path.exists(matrix_traffic_file)):
+            continue
         with open(matrix_traffic_file) as f:
             prof = json.load(f)
         cfg = prof.get("config", {})
         if (cfg.get("cells"), cfg.get("genes"), cfg.get("lsh_count"), cfg.get("k"), cfg.get("n_gpus")) == (C, G, L, k, world):
             t = prof["per_launch_bytes"]["fsp4ScanKernel"]
             matrix_traffic = t["fetch"] + t["write"]
+            matrix_traffic_source = "profiles/%s (FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE, bytes per launch)" % name
+            break
     if matrix and launch["matrix_kernel_ms"] > 0:
         # Dominant kernel: fsp4ScanMatrixKernel, bound by the matrix cores.  One (row, column) pair = a 1024-long dot
         # product of FP4 +-1 values = 2 * 1024 flop on v_mfma_scale_f32_32x32x64_f8f6f4; peak = the dense FP4 MFMA
@@ -308,7 +345,7 @@ def main():
         flops = launch["matrix_pairs"] * 2.0 * 1024.0
         tflops = flops / (launch["matrix_kernel_ms"] * 1e-3) / 1e12
         result["roofline"] = {
-            "kernel": "fsp4ScanMatrixKernel<true>",
+            "kernel": "fsp4ScanMatrixPinnedKernel<true>" if pinned_walk else "fsp4ScanMatrixKernel<true>",
             "kernel_ms": launch["matrix_kernel_ms"],
             "form": "symmetric, triangle part on the matrix cores: every unordered pair evaluated once as an FP4 +-1 dot "
                     "product (1024 - 2 * mismatches, exact in f32); the first cells' full rows and each quad's own 256 columns "
@@ -319,8 +356,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": tflops / MFMA_FP4_PEAK_TFLOPS,
             "traffic": matrix_traffic,
-            "traffic_source": "profiles/r01_pmc_matrix_scan_1Mcells.json (FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE, bytes per launch)"
-                              if matrix_traffic is not None else None,
+            "traffic_source": matrix_traffic_source,
             "flop_per_launch": flops,
             "pairs_on_matrix_cores": launch["matrix_pairs"],
             "pairs_per_s_on_matrix_cores": launch["matrix_pairs"] / (launch["matrix_kernel_ms"] * 1e-3),
@@ -361,6 +397,19 @@ def main():
     else:
         result["roofline"] = hbm_roofline
     result["parity_check"] = check
+    # The other kernel of the step: the signature projection.  Algorithmic bytes per SURVEY.md 8(d): the CSR once
+    # (8 B per expression count), the hyperplanes once (8 B x genes x bits), the signatures out; flop = 2 x counts x
+    # bits (the reference's own formula, src/Lsh.cpp:222).  Bound: HBM.
+    if proj_ms > 0 and pipe.rows:
+        proj_bytes = 8.0 * nnz_local + 8.0 * G * L + pipe.rows * L / 8.0
+        result["roofline_projection"] = {
+            "kernel": "projectionScreenSlicedKernel<32> + projectionExactItemsKernel (rank 0)",
+            "kernel_ms": proj_ms, "bound": "hbm", "achieved": proj_bytes / (proj_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": proj_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": proj_bytes,
+            "flop_per_launch": 2.0 * nnz_local * L, "tflops": 2.0 * nnz_local * L / (proj_ms * 1e-3) / 1e12,
+            "note": "kernel_ms = HIP events around em2_dev_compute_signatures on the launch stream (screening pass + exact "
+                    "recomputation of the undecided words); its measured fabric traffic is in profiles/ and DESIGN.md",
+        }
 
     if rank == 0 and not args.no_cpu_baseline:
         m = min(args.cpu_baseline_cells, C)
@@ -395,6 +444,12 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
 
+    if rank == 0 and world == 1 and not args.no_extra and (C, G) == (1000000, 30000):
+        # BASELINE configs[1] (100k cells x 20k genes, 1% nnz, 1024 bit, 1 GPU): a second, small measurement on the same
+        # line -- never the headline.  Same pipeline, same gates (sampled rows against the oracle before and after).
+        del pipe, toc, data, vectors
+        torch.cuda.empty_cache()
+        result["extra"] = {"configs[1]": small_config(args, capi, sharded, synthetic, oracle, device, torch)}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -1,6 +1,6 @@
 # scratch script of the current GPU round (edited per call)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r35; mkdir -p $O
+O=gpurun_out/r36; mkdir -p $O
 run() { # name, env...
   name=$1; shift
   env "$@" EM2_SCAN_VERBOSE=1 timeout 600 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-check > $O/$name.json 2> $O/$name.err
@@ -19,10 +19,8 @@ four() { # name ranks cells env...
   env "$@" EM2_BENCH_SHARE_DEVICE=1 EM2_BENCH_BACKEND=gloo MASTER_ADDR=127.0.0.1 EM2_BLOCKS_PER_CU=1 EM2_SHARDED_MIN_CELLS=1000 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $ranks --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus $ranks --steps 1 --warmup 0 --cells $cells --genes 3000 --no-cpu-baseline --check-rows 96 > $O/$name.out 2> $O/$name.err
   echo "$name rc $? $(grep -h PARITY $O/$name.err | head -2)"
 }
-echo "emulation, 100 attempts: $(python tools/debug_ragged.py 40064 EM2_SCAN_MODE=virtual,EM2_VIRTUAL_WORLD=4 3 100 2>&1 | grep -c 'bad rows') failures"
-python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
-run full EM2_MATRIX_WALK=3
-run old EM2_MATRIX_WALK=0
+python bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json; tail -3 $O/bench.err
+bash tools/profile_bench.sh r36/profile 2>&1 | tail -12
 exit 0
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
