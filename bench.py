@@ -62,6 +62,13 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--check-rows", type=int, default=384)
     p.add_argument("--no-extra", action="store_true", help="skip the configs[1] block")
+    p.add_argument("--workload", choices=["fsp4", "fsp5", "chain"], default="fsp4",
+                   help="fsp4 (default): the headline, BASELINE configs[2]; fsp5: configs[3], bucketed findSimilarPairs5 at 2048 "
+                        "bits; chain: configs[4], findSimilarPairs4 -> createCellGraph -> label propagation.  fsp5 and chain "
+                        "print secondary lines (1 GPU), never the headline")
+    p.add_argument("--slice-length", type=int, default=20)
+    p.add_argument("--bucket-overflow", type=int, default=1000)
+    p.add_argument("--graph-k", type=int, default=20)
     p.add_argument("--no-check", action="store_true",
                    help="diagnostic runs only (EM2_MATRIX_DIAG makes results wrong on purpose): skip the parity gates; "
                         "the line says so and is not a measurement")
@@ -132,6 +139,159 @@ def small_config(args, capi, sharded, synthetic, oracle, device, torch, cells=10
             "parity_check": {"signature_cells": before[0], "fsp4_rows": before[1], "after_timing_rows": after[1]}}
 
 
+def synthetic_signatures(torch, cells, lsh_count, device, cluster_count=64, flip=0.15, seed=4321, chunk=65536):
+    """SURVEY.md 8(d), scan-only variant: signature = its cluster's centre (random bits) with every bit flipped with
+    probability `flip`; packed MSB-first into uint64 words like src/BitSet.hpp:48-62.  Returns int64 [cells, words]."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    words = (lsh_count - 1) // 64 + 1
+    centres = torch.randint(0, 2, (cluster_count, words * 64), generator=gen, device=device, dtype=torch.int8)
+    centres[:, lsh_count:] = 0
+    weights = (1 << torch.arange(63, -1, -1, device=device, dtype=torch.int64))
+    out = torch.empty((cells, words), dtype=torch.int64, device=device)
+    for begin in range(0, cells, chunk):
+        end = min(cells, begin + chunk)
+        cluster = torch.randint(0, cluster_count, (end - begin,), generator=gen, device=device)
+        flips = (torch.rand((end - begin, words * 64), generator=gen, device=device) < flip).to(torch.int8)
+        flips[:, lsh_count:] = 0
+        bits = (centres[cluster] ^ flips).to(torch.int64).view(end - begin, words, 64)
+        out[begin:end] = (bits * weights).sum(dim=2)
+    return out
+
+
+def bench_fsp5(args, capi, oracle, device, torch):
+    """BASELINE configs[3] on one GPU: bucketed findSimilarPairs5, 2048-bit signatures, lshSliceLength 20, bucketOverflow
+    1000, k=100.  One step = em2_dev_find_similar_pairs5 over all cells (tables + candidate filter + selection)."""
+    C, L, k, thr, q = args.cells, 2048 if args.lsh_count == 1024 else args.lsh_count, args.k, args.threshold, args.slice_length
+    W = capi.word_count(L)
+    sig = synthetic_signatures(torch, C, L, device)
+    pairs = torch.zeros((C, k, 2), dtype=torch.int32, device=device)
+    used = torch.zeros(C, dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        capi.dev_find_similar_pairs5(sig.data_ptr(), C, 0, C, L, k, thr, q, args.bucket_overflow, pairs.data_ptr(), used.data_ptr(), stream)
+
+    step()
+    torch.cuda.synchronize()
+    check = {"skipped": "--no-check"}
+    if not args.no_check:
+        sig_host = sig.cpu().numpy().view(np.uint64)
+        rows = 0
+        for begin in (0, C // 2, max(0, C - 8)):
+            end = min(C, begin + 8)
+            cell, sim, oused = oracle.find_similar_pairs5_rows(sig_host, L, k, thr, q, args.bucket_overflow, begin, end)
+            got = pairs[begin:end].cpu().numpy().view(np.uint32)
+            ok = (np.array_equal(used[begin:end].cpu().numpy().view(np.uint32), oused) and np.array_equal(got[:, :, 0], cell) and
+                  np.array_equal(got[:, :, 1], sim.view(np.uint32)))
+            if not ok:
+                raise SystemExit("PARITY FAILURE: findSimilarPairs5 rows %d..%d differ from the oracle" % (begin, end))
+            rows += end - begin
+        check = {"fsp5_rows": rows}
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    filter_ms = select_ms = 0.0
+    for _ in range(args.steps):
+        step()
+        info = capi.dev_find_similar_pairs5_last_launch()
+        filter_ms += info["filter_ms"]
+        select_ms += info["select_ms"]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    info = capi.dev_find_similar_pairs5_last_launch()
+    filter_ms /= args.steps
+    select_ms /= args.steps
+    algorithmic = info["gathered_candidates"] * 8.0 * W + 4.0 * C * info["slice_count"]
+    achieved = algorithmic / (filter_ms * 1e-3) / 1e9 if filter_ms > 0 else 0.0
+    return {
+        "metric": "cells/sec through findSimilarPairs5 (bucketed LSH, tables + candidate filter + selection)",
+        "value": C * args.steps / elapsed, "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64 popcount", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3]: %d synthetic cells, %d-bit signatures, findSimilarPairs5 lshSliceLength=%d "
+                               "bucketOverflow=%d k=%d threshold=%g, 1 GPU" % (C, L, q, args.bucket_overflow, k, thr),
+                   "cells": C, "lsh_count": L, "k": k, "slices": info["slice_count"], "batches": info["batches"]},
+        "phases_ms": {"candidate_filter": filter_ms, "selection": select_ms,
+                      "tables_and_candidate_lists": elapsed / args.steps * 1e3 - filter_ms - select_ms},
+        "roofline": {"kernel": "filterCooperativeKernel (all batches)", "kernel_ms": filter_ms, "bound": "hbm", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes": algorithmic, "gathered_candidates": info["gathered_candidates"],
+                     "note": "SURVEY.md 8(d): candidates x 8*W bytes of signature gathers + 4*N*sliceCount bytes of tables; candidates "
+                             "= ids gathered from the buckets (duplicates included: an upper bound of the distinct ones the filter "
+                             "reads); kernel_ms = HIP events around the filter kernels on the launch stream"},
+        "parity_check": check,
+    }
+
+
+def bench_chain(args, capi, sharded, synthetic, oracle, device, torch):
+    """BASELINE configs[4] on one GPU: findSimilarPairs4 (k=100) -> createCellGraph (threshold 0.2, k=20) -> label
+    propagation, the SimilarPairs content staying on the device between the first two."""
+    C, G, L, k, thr = args.cells, args.genes, args.lsh_count, args.k, args.threshold
+    pipe = sharded.DevicePipeline(C, G, L, k, thr, world_size=1, rank=0, dist=None, device=device)
+    toc, data = synthetic.expression_shard(0, C, G, density=args.density, device=device)
+    vectors_host = capi.lsh_generate_vectors(G, L, args.seed)
+    pipe.set_inputs(toc, data, torch.from_numpy(vectors_host).to(device))
+    cells = np.arange(C, dtype=np.uint32)
+    times = {"findSimilarPairs4": 0.0, "createCellGraph": 0.0, "labelPropagationClustering": 0.0}
+
+    def step(record):
+        t0 = time.perf_counter()
+        pipe.step()
+        pipe.check()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        v0, v1, sim = capi.dev_cell_graph_edges(pipe.pairs.data_ptr(), pipe.used.data_ptr(), C, k, cells, cells, thr, args.graph_k)
+        t2 = time.perf_counter()
+        clusters, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim)
+        t3 = time.perf_counter()
+        if record:
+            times["findSimilarPairs4"] += t1 - t0
+            times["createCellGraph"] += t2 - t1
+            times["labelPropagationClustering"] += t3 - t2
+        return v0, v1, sim, clusters, iterations
+
+    v0, v1, sim, clusters, iterations = step(False)
+    check = {"skipped": "--no-check"}
+    if not args.no_check:
+        p, u = pipe.results_for(0, C)
+        sample = min(C, 200000)
+        if C <= 250000:
+            ev0, ev1, es = oracle.cell_graph_edges(p["cell"], p["similarity"], u, cells, cells, thr, args.graph_k)
+            if not (np.array_equal(ev0, v0) and np.array_equal(ev1, v1) and np.array_equal(es.view(np.uint32), sim.view(np.uint32))):
+                raise SystemExit("PARITY FAILURE: cell graph edges differ from the oracle")
+            oc, oit = oracle.label_propagation(cells, v0, v1, sim)
+            if not (np.array_equal(oc, clusters) and oit == iterations):
+                raise SystemExit("PARITY FAILURE: clusters differ from the oracle")
+            check = {"edges": int(len(v0)), "labels": int(C), "iterations": int(iterations)}
+        else:
+            check = {"edges": "not checked above 250000 cells (the oracle's map/set restatement takes minutes); "
+                              "tests/test_gpu_cell_graph.py and tests/test_gpu_label_propagation.py cover them",
+                     "sample": sample}
+    for _ in range(args.warmup):
+        step(False)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        v0, v1, sim, clusters, iterations = step(True)
+    elapsed = time.perf_counter() - t0
+    return {
+        "metric": "cells/sec through findSimilarPairs4 -> createCellGraph -> labelPropagationClustering",
+        "value": C * args.steps / elapsed, "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64 popcount / f32 similarities", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: %d synthetic cells x %d genes, %d-bit signatures, findSimilarPairs4 k=%d "
+                               "threshold=%g -> createCellGraph(threshold %g, k=%d) -> label propagation, 1 GPU"
+                               % (C, G, L, k, thr, thr, args.graph_k),
+                   "cells": C, "edges": int(len(v0)), "iterations": int(iterations), "clusters": int(clusters.max()) + 1 if len(clusters) else 0},
+        "phases_ms": {key: value / args.steps * 1e3 for key, value in times.items()},
+        "roofline": None,
+        "note": "SimilarPairs stay device-resident between findSimilarPairs4 and createCellGraph (em2_dev_cell_graph_edges); label "
+                "propagation is latency-bound pointer chasing, no roofline is attached to it (DESIGN.md 3.6)",
+        "parity_check": check,
+    }
+
+
 def main():
     args = parse_args()
     import torch
@@ -164,6 +324,16 @@ def main():
     C, G, L, k, thr = args.cells, args.genes, args.lsh_count, args.k, args.threshold
     W = capi.word_count(L)
     device = torch.device("cuda", local_rank)
+    if args.workload != "fsp4":
+        if world != 1:
+            raise SystemExit("bench.py --workload %s is a 1-GPU secondary line" % args.workload)
+        import oracle_binding
+        oracle = oracle_binding.load_oracle()
+        if args.workload == "fsp5":
+            print(json.dumps(bench_fsp5(args, capi, oracle, device, torch)))
+        else:
+            print(json.dumps(bench_chain(args, capi, sharded, synthetic, oracle, device, torch)))
+        return
 
     # ---- synthetic inputs, resident in HBM ----
     pipe = sharded.DevicePipeline(C, G, L, k, thr, world_size=world, rank=rank, dist=dist if world > 1 else None,

@@ -72,6 +72,7 @@ SYMBOLS = {
     "em2_dev_find_similar_pairs4_form": (_c.c_int, [_c.c_uint32, _c.c_uint32]),
     "em2_dev_find_similar_pairs4_form_for": (_c.c_int, [_c.c_uint32, _c.c_uint32, _c.c_uint32]),
     "em2_dev_find_similar_pairs4_last_launch": (_c.c_int, [_c.c_void_p, _c.c_uint32]),
+    "em2_dev_find_similar_pairs5_last_launch": (_c.c_int, [_c.c_void_p, _c.c_uint32]),
     "em2_dev_fsp4_sharded_plan": (_c.c_int, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                              _c.c_void_p, _c.c_uint32]),
     "em2_dev_fsp4_sharded_phase": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_double,
@@ -104,6 +105,9 @@ SYMBOLS = {
     "em2_cell_graph_edges": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p,
                                         _c.c_void_p, _c.c_uint32, _c.c_double, _c.c_uint32, _c.c_void_p,
                                         _c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_uint64)]),
+    "em2_dev_cell_graph_edges": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p,
+                                            _c.c_void_p, _c.c_uint32, _c.c_double, _c.c_uint32, _c.c_void_p,
+                                            _c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_uint64)]),
     "em2_lsh_write": (_c.c_int, [_c.c_char_p, _c.c_char_p, _c.c_uint64, _c.c_uint64, _c.c_void_p]),
     "em2_lsh_read": (_c.c_int, [_c.c_char_p, _c.c_char_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64),
                                 _c.c_void_p]),
@@ -269,6 +273,25 @@ def cell_graph_edges(pairs, used_count, similar_pairs_cell_set, graph_cell_set, 
     return v0[:n].copy(), v1[:n].copy(), sim[:n].copy()
 
 
+def dev_cell_graph_edges(pairs_ptr, used_ptr, cell_count, k, similar_pairs_cell_set, graph_cell_set, similarity_threshold,
+                         max_connectivity):
+    """cell_graph_edges with the SimilarPairs content still on the device (device pointers as
+    dev_find_similar_pairs4 left them); cell sets in, edges out as host arrays."""
+    sp_cells = np.ascontiguousarray(similar_pairs_cell_set, dtype=np.uint32)
+    graph_cells = np.ascontiguousarray(graph_cell_set, dtype=np.uint32)
+    per_vertex = k if (max_connectivity == 0 or max_connectivity > k) else int(max_connectivity)
+    capacity = max(1, len(graph_cells) * per_vertex)
+    v0 = np.zeros(capacity, dtype=np.uint32)
+    v1 = np.zeros(capacity, dtype=np.uint32)
+    sim = np.zeros(capacity, dtype=np.float32)
+    count = ctypes.c_uint64(0)
+    check(load().em2_dev_cell_graph_edges(pairs_ptr, used_ptr, cell_count, k, _ptr(sp_cells), _ptr(graph_cells),
+                                          len(graph_cells), similarity_threshold, min(int(max_connectivity), 0xffffffff),
+                                          _ptr(v0), _ptr(v1), _ptr(sim), ctypes.byref(count)))
+    n = int(count.value)
+    return v0[:n].copy(), v1[:n].copy(), sim[:n].copy()
+
+
 def cell_graph_label_propagation(vertex_cell_ids, edge_vertex0, edge_vertex1, edge_similarity, seed=231,
                                  stable_iteration_count_threshold=3, max_iteration_count=100):
     """CellGraph::labelPropagationClustering (src/CellGraph.cpp:443-612) -> (clusterId per vertex, iterations run).
@@ -318,6 +341,14 @@ def dev_find_similar_pairs4_last_launch():
     return {"form": int(v[0]), "scan_kernel_ms": float(v[1]), "wave_column_steps": float(v[2]),
             "inbox_entries": float(v[3]), "segments": int(v[4]), "full_row_cells": int(v[5]),
             "matrix_pairs": float(v[6]), "matrix_kernel_ms": float(v[7])}
+
+
+def dev_find_similar_pairs5_last_launch():
+    """dict(gathered_candidates, cells, slice_count, batches, filter_ms, select_ms) of the last findSimilarPairs5 launch."""
+    v = np.zeros(6, dtype=np.float64)
+    check(load().em2_dev_find_similar_pairs5_last_launch(_ptr(v), 6))
+    return {"gathered_candidates": float(v[0]), "cells": int(v[1]), "slice_count": int(v[2]), "batches": int(v[3]),
+            "filter_ms": float(v[4]), "select_ms": float(v[5])}
 
 
 def dev_find_similar_pairs4(sig_ptr, cell_count, row_begin, row_end, lsh_count, k, similarity_threshold,

@@ -352,6 +352,15 @@ int em2_dev_find_similar_pairs4_last_launch(double* values, uint32_t valueCount)
 }
 
 
+int em2_dev_find_similar_pairs5_last_launch(double* values, uint32_t valueCount)
+{
+    if (!values && valueCount) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs5_last_launch: null pointer");
+    const em2::Fsp5LaunchInfo info = em2::fsp5LastLaunchInfo();
+    const double all[6] = {info.gatheredCandidates, info.cells, info.sliceCount, info.batches, info.filterMs, info.selectMs};
+    for (uint32_t i = 0; i < valueCount; i++) values[i] = i < 6 ? all[i] : 0.0;
+    return EM2_OK;
+}
+
 int em2_dev_find_similar_pairs4(const uint64_t* d_signatures, uint32_t cellCount, uint32_t rowBegin,
                                 uint32_t rowEnd, uint32_t lshCount, uint32_t k, double similarityThreshold,
                                 em2_pair* d_pairs, uint32_t* d_usedCount, void* d_workspace,
@@ -844,23 +853,26 @@ int em2_find_similar_pairs5(const uint64_t* signatures, uint32_t cellCount, uint
 
 
 
-int em2_cell_graph_edges(const em2_pair* pairs, const uint32_t* usedCount, uint32_t similarPairsCellCount, uint32_t k,
-                         const uint32_t* similarPairsCellSet, const uint32_t* graphCellSet, uint32_t graphCellCount,
-                         double similarityThreshold, uint32_t maxConnectivity, uint32_t* edgeVertex0,
-                         uint32_t* edgeVertex1, float* edgeSimilarity, uint64_t* edgeCount)
+// pairs / usedCount on the host (em2_cell_graph_edges) or already on the device (em2_dev_cell_graph_edges: the
+// SimilarPairs of a device-resident findSimilarPairs4 go straight into the graph, 0.8 GB less over PCIe at 1M cells)
+static int cellGraphEdges(const char* what, bool pairsOnDevice, const em2_pair* pairs, const uint32_t* usedCount,
+                          uint32_t similarPairsCellCount, uint32_t k, const uint32_t* similarPairsCellSet,
+                          const uint32_t* graphCellSet, uint32_t graphCellCount, double similarityThreshold,
+                          uint32_t maxConnectivity, uint32_t* edgeVertex0, uint32_t* edgeVertex1, float* edgeSimilarity,
+                          uint64_t* edgeCount)
 {
-    if (!edgeCount) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_cell_graph_edges: null edgeCount");
+    if (!edgeCount) return fail(EM2_ERROR_INVALID_ARGUMENT, std::string(what) + ": null edgeCount");
     *edgeCount = 0;
     // CellGraph.cpp:101 tests pairs.size() == maxConnectivity after a push_back, so 0 never matches and means
     // "no limit"; a vertex never selects more than the k stored pairs either way.
     if (maxConnectivity == 0 || maxConnectivity > k) maxConnectivity = k;
     if (graphCellCount == 0 || maxConnectivity == 0) return EM2_OK;
     if (!usedCount || !similarPairsCellSet || !graphCellSet || (!pairs && k && similarPairsCellCount) || !edgeVertex0 || !edgeVertex1 || !edgeSimilarity) {
-        return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_cell_graph_edges: null pointer");
+        return fail(EM2_ERROR_INVALID_ARGUMENT, std::string(what) + ": null pointer");
     }
-    if (!haveDevice()) return fail(EM2_ERROR_NO_DEVICE, "em2_cell_graph_edges: no HIP device is visible (this library has no CPU path)");
+    if (!haveDevice()) return fail(EM2_ERROR_NO_DEVICE, std::string(what) + ": no HIP device is visible (this library has no CPU path)");
     for (uint32_t i = 1; i < similarPairsCellCount; i++) {
-        if (similarPairsCellSet[i - 1] > similarPairsCellSet[i]) return fail(EM2_ERROR_RUNTIME, "em2_cell_graph_edges: the SimilarPairs cell set is not sorted.");
+        if (similarPairsCellSet[i - 1] > similarPairsCellSet[i]) return fail(EM2_ERROR_RUNTIME, std::string(what) + ": the SimilarPairs cell set is not sorted.");
     }
     // vertexTable of the reference (cell id -> vertex): the graph cell set sorted by id + the vertex of each entry.
     std::vector<uint32_t> order(graphCellCount);
@@ -869,12 +881,14 @@ int em2_cell_graph_edges(const em2_pair* pairs, const uint32_t* usedCount, uint3
     std::vector<uint32_t> sortedIds(graphCellCount);
     for (uint32_t i = 0; i < graphCellCount; i++) sortedIds[i] = graphCellSet[order[i]];
     for (uint32_t i = 1; i < graphCellCount; i++) {
-        if (sortedIds[i] == sortedIds[i - 1]) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_cell_graph_edges: duplicate cell id in the graph cell set");
+        if (sortedIds[i] == sortedIds[i - 1]) return fail(EM2_ERROR_INVALID_ARGUMENT, std::string(what) + ": duplicate cell id in the graph cell set");
     }
     const size_t slots = size_t(graphCellCount) * maxConnectivity;
     DeviceBuffer dPairs, dUsed, dSp, dGraph, dSorted, dOrder, dE0, dE1, dEs;
-    EM2_HIP(dPairs.allocate(size_t(similarPairsCellCount) * k * sizeof(em2_pair)));
-    EM2_HIP(dUsed.allocate(size_t(similarPairsCellCount) * sizeof(uint32_t)));
+    if (!pairsOnDevice) {
+        EM2_HIP(dPairs.allocate(size_t(similarPairsCellCount) * k * sizeof(em2_pair)));
+        EM2_HIP(dUsed.allocate(size_t(similarPairsCellCount) * sizeof(uint32_t)));
+    }
     EM2_HIP(dSp.allocate(size_t(similarPairsCellCount) * sizeof(uint32_t)));
     EM2_HIP(dGraph.allocate(size_t(graphCellCount) * sizeof(uint32_t)));
     EM2_HIP(dSorted.allocate(size_t(graphCellCount) * sizeof(uint32_t)));
@@ -883,15 +897,19 @@ int em2_cell_graph_edges(const em2_pair* pairs, const uint32_t* usedCount, uint3
     EM2_HIP(dE1.allocate(slots * sizeof(uint32_t)));
     EM2_HIP(dEs.allocate(slots * sizeof(float)));
     if (similarPairsCellCount) {
-        if (k) EM2_HIP(hipMemcpy(dPairs.p, pairs, size_t(similarPairsCellCount) * k * sizeof(em2_pair), hipMemcpyHostToDevice));
-        EM2_HIP(hipMemcpy(dUsed.p, usedCount, size_t(similarPairsCellCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!pairsOnDevice) {
+            if (k) EM2_HIP(hipMemcpy(dPairs.p, pairs, size_t(similarPairsCellCount) * k * sizeof(em2_pair), hipMemcpyHostToDevice));
+            EM2_HIP(hipMemcpy(dUsed.p, usedCount, size_t(similarPairsCellCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
         EM2_HIP(hipMemcpy(dSp.p, similarPairsCellSet, size_t(similarPairsCellCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    const em2::PairOut* devicePairs = pairsOnDevice ? reinterpret_cast<const em2::PairOut*>(pairs) : dPairs.as<em2::PairOut>();
+    const uint32_t* deviceUsed = pairsOnDevice ? usedCount : dUsed.as<uint32_t>();
     EM2_HIP(hipMemcpy(dGraph.p, graphCellSet, size_t(graphCellCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
     EM2_HIP(hipMemcpy(dSorted.p, sortedIds.data(), size_t(graphCellCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
     EM2_HIP(hipMemcpy(dOrder.p, order.data(), size_t(graphCellCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
     uint64_t count = 0;
-    EM2_HIP(em2::runCellGraphEdges(dPairs.as<em2::PairOut>(), dUsed.as<uint32_t>(), similarPairsCellCount, k, dSp.as<uint32_t>(),
+    EM2_HIP(em2::runCellGraphEdges(devicePairs, deviceUsed, similarPairsCellCount, k, dSp.as<uint32_t>(),
                                    dGraph.as<uint32_t>(), dSorted.as<uint32_t>(), dOrder.as<uint32_t>(), graphCellCount,
                                    similarityThreshold, maxConnectivity, dE0.as<uint32_t>(), dE1.as<uint32_t>(), dEs.as<float>(),
                                    &count, nullptr));
@@ -902,6 +920,25 @@ int em2_cell_graph_edges(const em2_pair* pairs, const uint32_t* usedCount, uint3
     }
     *edgeCount = count;
     return EM2_OK;
+}
+
+int em2_cell_graph_edges(const em2_pair* pairs, const uint32_t* usedCount, uint32_t similarPairsCellCount, uint32_t k,
+                         const uint32_t* similarPairsCellSet, const uint32_t* graphCellSet, uint32_t graphCellCount,
+                         double similarityThreshold, uint32_t maxConnectivity, uint32_t* edgeVertex0,
+                         uint32_t* edgeVertex1, float* edgeSimilarity, uint64_t* edgeCount)
+{
+    return cellGraphEdges("em2_cell_graph_edges", false, pairs, usedCount, similarPairsCellCount, k, similarPairsCellSet, graphCellSet,
+                          graphCellCount, similarityThreshold, maxConnectivity, edgeVertex0, edgeVertex1, edgeSimilarity, edgeCount);
+}
+
+int em2_dev_cell_graph_edges(const em2_pair* d_pairs, const uint32_t* d_usedCount, uint32_t similarPairsCellCount, uint32_t k,
+                             const uint32_t* similarPairsCellSet, const uint32_t* graphCellSet, uint32_t graphCellCount,
+                             double similarityThreshold, uint32_t maxConnectivity, uint32_t* edgeVertex0,
+                             uint32_t* edgeVertex1, float* edgeSimilarity, uint64_t* edgeCount)
+{
+    return cellGraphEdges("em2_dev_cell_graph_edges", true, d_pairs, d_usedCount, similarPairsCellCount, k, similarPairsCellSet,
+                          graphCellSet, graphCellCount, similarityThreshold, maxConnectivity, edgeVertex0, edgeVertex1, edgeSimilarity,
+                          edgeCount);
 }
 
 int em2_cell_graph_label_propagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,

@@ -112,6 +112,14 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
 
 // findSimilarPairs5 (src/ExpressionMatrixLsh.cpp:355-496): bucket tables over all cells, results for the cells
 // [rowBegin,rowEnd).  Allocates its own scratch and synchronises the stream.  q = lshSliceLength in [1,32].
+// What the calling thread's last runFsp5 did (benchmarks): candidate ids gathered from the buckets (duplicates and the
+// cell itself included), cells queried, slices, batches, and the HIP-event durations of the candidate filter (the
+// gather of candidate signatures + popcounts) and of the selection over all batches.
+struct Fsp5LaunchInfo {
+    double gatheredCandidates, cells, sliceCount, batches, filterMs, selectMs;
+};
+Fsp5LaunchInfo fsp5LastLaunchInfo();
+
 hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin, uint32_t rowEnd, uint32_t lshCount,
                    uint32_t k, uint32_t q, uint64_t bucketOverflow, const DeviceTables& tables, PairOut* d_pairs,
                    uint32_t* d_used, hipStream_t stream);

@@ -354,6 +354,12 @@ uint32_t bitsFor(uint64_t maxValue)
 // Host driver: allocates its own scratch and synchronises the stream.  The bucket tables are built over ALL
 // cellCount cells; candidates are generated and selected for the cells [rowBegin,rowEnd) only (the shard one
 // rank owns).  d_pairs / d_used are device arrays of (rowEnd-rowBegin)*k and (rowEnd-rowBegin) elements.
+namespace {
+thread_local Fsp5LaunchInfo lastFsp5Info = {0., 0., 0., 0., -1., -1.};
+}
+
+Fsp5LaunchInfo fsp5LastLaunchInfo() { return lastFsp5Info; }
+
 hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin, uint32_t rowEnd, uint32_t lshCount,
                    uint32_t k, uint32_t q, uint64_t bucketOverflow, const DeviceTables& tables, PairOut* d_pairs,
                    uint32_t* d_used, hipStream_t stream)
@@ -441,6 +447,20 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
         batches.push_back(std::move(batch));
         batchBegin = batchEnd;
     }
+    {
+        double gathered = 0.;
+        for (uint32_t c = rowBegin; c < rowEnd; c++) gathered += double(hostCounts[c]);
+        lastFsp5Info.gatheredCandidates = gathered;
+        lastFsp5Info.cells = double(rowCount);
+        lastFsp5Info.sliceCount = double(sliceCount);
+        lastFsp5Info.batches = double(batches.size());
+        lastFsp5Info.filterMs = lastFsp5Info.selectMs = 0.;
+    }
+    static thread_local hipEvent_t timing[3] = {nullptr, nullptr, nullptr};
+    if (!timing[0]) {
+        if (hipEventCreate(&timing[0]) != hipSuccess || hipEventCreate(&timing[1]) != hipSuccess ||
+            hipEventCreate(&timing[2]) != hipSuccess) timing[0] = timing[1] = timing[2] = nullptr;
+    }
     Buffer segBegin, candA, candB, lists, sortTemp, listCounts;
     EM2_TRY(segBegin.allocate((size_t(maxCells) + 1u) * sizeof(uint32_t)));
     EM2_TRY(candA.allocate(size_t(maxTotal) * sizeof(uint32_t)));
@@ -475,6 +495,7 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
                                                        segBegin.as<uint32_t>(), segBegin.as<uint32_t>() + 1, 0u, idBits, stream));
             sorted = candB.as<uint32_t>();
         }
+        if (timing[0]) (void)hipEventRecord(timing[0], stream);
         if (cooperative) {
             filterCooperativeKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(),
                                                                                 sorted, lists.as<Entry>(), tables.mGlobal,
@@ -485,6 +506,7 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
                                                                      listCounts.as<uint32_t>());
         }
         EM2_TRY(hipGetLastError());
+        if (timing[0]) (void)hipEventRecord(timing[1], stream);
         selectKernel<kSelectLdsEntries, 0u><<<batchCells, 64, 0, stream>>>(batchCells, segBegin.as<uint32_t>(), lists.as<Entry>(),
                                                                            listCounts.as<uint32_t>(), tables.keySimilarity, k,
                                                                            d_pairs + size_t(batchBegin - rowBegin) * k,
@@ -496,7 +518,15 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
                                                                                              d_pairs + size_t(batchBegin - rowBegin) * k,
                                                                                              d_used + (batchBegin - rowBegin));
         EM2_TRY(hipGetLastError());
+        if (timing[0]) (void)hipEventRecord(timing[2], stream);
         EM2_TRY(hipStreamSynchronize(stream));       // the batch's offsets (pageable host memory) and scratch are reused
+        if (timing[0]) {
+            float a = 0.f, b = 0.f;
+            if (hipEventElapsedTime(&a, timing[0], timing[1]) == hipSuccess && hipEventElapsedTime(&b, timing[1], timing[2]) == hipSuccess) {
+                lastFsp5Info.filterMs += double(a);
+                lastFsp5Info.selectMs += double(b);
+            }
+        }
     }
     return hipSuccess;
 }

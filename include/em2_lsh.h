@@ -242,6 +242,13 @@ int em2_dev_find_similar_pairs5(const uint64_t* d_signatures, uint32_t cellCount
                                 uint32_t lshSliceLength, uint64_t bucketOverflow, em2_pair* d_pairs,
                                 uint32_t* d_usedCount, void* stream);
 
+/* Facts about the calling thread's last em2_dev_find_similar_pairs5 / em2_find_similar_pairs5, for benchmarks:
+ * values[0] candidate ids gathered from the buckets (duplicates and the cell itself included: each costs the filter
+ * one look at the sorted list, each distinct one a gather of 8*W signature bytes), [1] cells queried, [2] slices
+ * (lshCount / lshSliceLength, src/ExpressionMatrixLsh.cpp:355), [3] batches, [4] / [5] ms of the candidate filter and
+ * of the selection, summed over the batches (HIP events on the launch stream). */
+int em2_dev_find_similar_pairs5_last_launch(double* values, uint32_t valueCount);
+
 /* ------------------------------------------------------------------------------------------------------
  * SURVEY.md 8(f), first "next" row: the consumer of SimilarPairs.
  * ------------------------------------------------------------------------------------------------------ */
@@ -257,6 +264,14 @@ int em2_cell_graph_edges(const em2_pair* pairs, const uint32_t* usedCount, uint3
                          const uint32_t* similarPairsCellSet, const uint32_t* graphCellSet, uint32_t graphCellCount,
                          double similarityThreshold, uint32_t maxConnectivity, uint32_t* edgeVertex0,
                          uint32_t* edgeVertex1, float* edgeSimilarity, uint64_t* edgeCount);
+
+/* The same with the SimilarPairs content still on the device (d_pairs / d_usedCount as em2_dev_find_similar_pairs4
+ * left them; the cell sets and the edge arrays are host arrays as above): the consumer of a device-resident
+ * findSimilarPairs4 does not move 8 * k * cells bytes over PCIe twice. */
+int em2_dev_cell_graph_edges(const em2_pair* d_pairs, const uint32_t* d_usedCount, uint32_t similarPairsCellCount, uint32_t k,
+                             const uint32_t* similarPairsCellSet, const uint32_t* graphCellSet, uint32_t graphCellCount,
+                             double similarityThreshold, uint32_t maxConnectivity, uint32_t* edgeVertex0,
+                             uint32_t* edgeVertex1, float* edgeSimilarity, uint64_t* edgeCount);
 
 /* CellGraph::labelPropagationClustering (src/CellGraph.cpp:443-612, ClusterTable src/CellGraph.hpp:50-121; reached
  * from ExpressionMatrix::createClusterGraph, src/ExpressionMatrix.cpp:2145-2149) over the graph em2_cell_graph_edges

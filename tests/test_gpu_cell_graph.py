@@ -41,6 +41,40 @@ def test_edges_match_oracle_same_cell_set(oracle, cells, L, k, thr, max_conn):
         assert len(exp[0]) > 0
 
 
+def device_edges(sig, L, k, pair_thr, sp_cells, graph_cells, thr, max_conn):
+    """findSimilarPairs4 on the device, its SimilarPairs content handed to em2_dev_cell_graph_edges without leaving HBM."""
+    import torch
+    n = len(sig)
+    d_sig = torch.from_numpy(sig.view(np.int64).copy()).cuda()
+    pairs = torch.zeros((n, k, 2), dtype=torch.int32, device="cuda")
+    used = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ws_bytes = capi.dev_find_similar_pairs4_workspace(n, n, L, k)
+    ws = torch.empty(max(1, ws_bytes), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    capi.dev_find_similar_pairs4(d_sig.data_ptr(), n, 0, n, L, k, pair_thr, pairs.data_ptr(), used.data_ptr(), ws.data_ptr(),
+                                 ws_bytes, stream)
+    torch.cuda.synchronize()
+    return capi.dev_cell_graph_edges(pairs.data_ptr(), used.data_ptr(), n, k, sp_cells, graph_cells, thr, max_conn)
+
+
+@pytest.mark.parametrize("cells,L,k,thr,max_conn", [(300, 128, 10, 0.5, 20), (2500, 256, 40, 0.3, 7), (1000, 1024, 100, 0.2, 20)])
+def test_device_resident_pairs_give_the_same_edges(oracle, cells, L, k, thr, max_conn):
+    """BASELINE configs[4]'s hand-over: the pairs findSimilarPairs4 left on the device go into createCellGraph's edge
+    construction in place (em2_dev_cell_graph_edges); same edges as the oracle's from the oracle's own pairs."""
+    sig = synth.clustered_signatures(cells, L, cluster_count=9, flip=0.12, seed=cells + k)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, k, 0.2)
+    ids = np.arange(cells, dtype=np.uint32)
+    exp = oracle.cell_graph_edges(cell, sim, used, ids, ids, thr, max_conn)
+    assert_same(device_edges(sig, L, k, 0.2, ids, ids, thr, max_conn), exp)
+    assert len(exp[0]) > 0
+    # two cell sets, vertex order arbitrary
+    rng = np.random.default_rng(cells)
+    sp_cells = np.sort(rng.choice(3 * cells, cells, replace=False)).astype(np.uint32)
+    graph_cells = rng.permutation(3 * cells)[:cells].astype(np.uint32)
+    exp = oracle.cell_graph_edges(cell, sim, used, sp_cells, graph_cells, thr, max_conn)
+    assert_same(device_edges(sig, L, k, 0.2, sp_cells, graph_cells, thr, max_conn), exp)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_edges_match_oracle_two_cell_sets_unsorted_graph_set(oracle, seed):
     rng = np.random.default_rng(seed)

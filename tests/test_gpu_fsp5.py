@@ -112,3 +112,24 @@ def test_fsp5_row_shard_through_device_api(oracle):
         p = d_pairs.cpu().numpy().view(np.uint32)
         assert np.array_equal(d_used.cpu().numpy().view(np.uint32), used)
         assert np.array_equal(p[:, :, 0], cell) and np.array_equal(p[:, :, 1], sim.view(np.uint32))
+
+
+def test_fsp5_last_launch_reports_what_the_filter_read(oracle):
+    """em2_dev_find_similar_pairs5_last_launch (bench.py's fsp5 roofline input): gathered candidates = the sum over
+    cells and slices of the sizes of the non-overflowing buckets the cell falls in, the cell itself included
+    (src/ExpressionMatrixLsh.cpp:417-433: the union is taken first, the cell dropped after)."""
+    n, L, k, thr, q, ovf = 3000, 256, 10, 0.2, 9, 40
+    sig = synth.clustered_signatures(n, L, cluster_count=12, flip=0.1, seed=77)
+    check(oracle, sig, L, k, thr, q, ovf)
+    info = capi.dev_find_similar_pairs5_last_launch()
+    slices = L // q
+    assert info["cells"] == n and info["slice_count"] == slices and info["batches"] >= 1
+    assert info["filter_ms"] > 0 and info["select_ms"] > 0
+    bits = np.unpackbits(sig.view(np.uint8).reshape(n, -1, 8)[:, :, ::-1].reshape(n, -1), axis=1)[:, :L]
+    expected = 0
+    for s in range(slices):
+        keys = bits[:, s * q:(s + 1) * q].astype(np.uint64) @ (1 << np.arange(q - 1, -1, -1, dtype=np.uint64))
+        _, inverse, counts = np.unique(keys, return_inverse=True, return_counts=True)
+        size = counts[inverse]
+        expected += int(size[size <= ovf].sum())
+    assert info["gathered_candidates"] == expected
