@@ -69,6 +69,11 @@ SYMBOLS = {
     "em2_cell_graph_label_propagation": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                     _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_void_p,
                                                     _c.c_void_p]),
+    "em2_analyze_lsh": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p, _c.c_uint32, _c.c_void_p,
+                                   _c.c_uint32, _c.c_double, _c.c_char_p, _c.c_char_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                   _c.c_void_p, _c.c_void_p]),
+    "em2_matrix_analyze_lsh": (_c.c_int, [_c.c_void_p, _c.c_char_p, _c.c_char_p, _c.c_size_t, _c.c_uint, _c.c_double,
+                                          _c.c_char_p]),
     "em2_dev_find_similar_pairs4_form": (_c.c_int, [_c.c_uint32, _c.c_uint32]),
     "em2_dev_find_similar_pairs4_form_for": (_c.c_int, [_c.c_uint32, _c.c_uint32, _c.c_uint32]),
     "em2_dev_find_similar_pairs4_last_launch": (_c.c_int, [_c.c_void_p, _c.c_uint32]),
@@ -309,6 +314,28 @@ def cell_graph_label_propagation(vertex_cell_ids, edge_vertex0, edge_vertex1, ed
                                                   seed, stable_iteration_count_threshold, max_iteration_count,
                                                   _ptr(clusters), ctypes.byref(iterations)))
     return clusters, int(iterations.value)
+
+
+def analyze_lsh(toc, data, gene_count, signatures, lsh_count, global_cell_ids, seed, csv_downsample, pairs_csv_path,
+                statistics_csv_path=None, per_pair=False):
+    """ExpressionMatrix::analyzeLsh on a subset's counts and signatures (em2_analyze_lsh) -> dict(sum0, sum1, sum2[, exact,
+    lsh]); writes the two csv files."""
+    toc = np.ascontiguousarray(toc, dtype=np.uint64)
+    data = np.ascontiguousarray(data, dtype=COUNT_DTYPE)
+    signatures = np.ascontiguousarray(signatures, dtype=np.uint64)
+    ids = np.ascontiguousarray(global_cell_ids, dtype=np.uint32)
+    n = len(toc) - 1
+    out = {"sum0": np.zeros(200, dtype=np.uint64), "sum1": np.zeros(200, dtype=np.float64), "sum2": np.zeros(200, dtype=np.float64)}
+    pairs = n * (n - 1) // 2
+    if per_pair:
+        out["exact"] = np.zeros(pairs, dtype=np.float64)
+        out["lsh"] = np.zeros(pairs, dtype=np.float64)
+    check(load().em2_analyze_lsh(_ptr(toc), _ptr(data), n, gene_count, _ptr(signatures), lsh_count, _ptr(ids), seed,
+                                 csv_downsample, os.fsencode(pairs_csv_path),
+                                 os.fsencode(statistics_csv_path) if statistics_csv_path else None,
+                                 _ptr(out["sum0"]), _ptr(out["sum1"]), _ptr(out["sum2"]),
+                                 _ptr(out["exact"]) if per_pair else None, _ptr(out["lsh"]) if per_pair else None))
+    return out
 
 
 def find_similar_pairs7(signatures, lsh_count, k, similarity_threshold, lsh_slice_lengths, max_check, log2_bucket_count):

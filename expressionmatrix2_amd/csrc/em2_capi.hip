@@ -337,7 +337,7 @@ int em2_dev_find_similar_pairs4_form_for(uint32_t cellCount, uint32_t rowCount, 
     if (lshCount == 0) return 0;
     const uint32_t padded = em2::paddedDwords(lshCount);
     if (!em2::fsp4UsesSymmetricScan(cellCount, rowCount, padded)) return 0;
-    return padded == 32u && !(getenv("EM2_SCAN_MATRIX") && getenv("EM2_SCAN_MATRIX")[0] == '0') ? 3 : 1;
+    return em2::fsp4MatrixFormWanted(padded) ? 3 : 1;
 }
 
 
@@ -940,6 +940,94 @@ int em2_dev_cell_graph_edges(const em2_pair* d_pairs, const uint32_t* d_usedCoun
                           graphCellSet, graphCellCount, similarityThreshold, maxConnectivity, edgeVertex0, edgeVertex1, edgeSimilarity,
                           edgeCount);
 }
+
+int em2_analyze_lsh(const uint64_t* toc, const em2_count* data, uint32_t cellCount, uint32_t geneCount,
+                    const uint64_t* signatures, uint32_t lshCount, const uint32_t* globalCellIds, uint32_t seed,
+                    double csvDownsample, const char* pairsCsvPath, const char* statisticsCsvPath,
+                    uint64_t* sum0, double* sum1, double* sum2, double* exactSimilarity, double* lshSimilarity)
+{
+    if (lshCount == 0 || geneCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_analyze_lsh: lshCount and geneCount must be positive");
+    if (cellCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_analyze_lsh: the cell set is empty");
+    if (!toc || !signatures || !globalCellIds || !pairsCsvPath) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_analyze_lsh: null pointer");
+    if (!haveDevice()) return fail(EM2_ERROR_NO_DEVICE, "em2_analyze_lsh: no HIP device is visible (this library has no CPU path)");
+    const uint64_t nnz = toc[cellCount];
+    if (nnz && !data) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_analyze_lsh: null data");
+    for (uint64_t i = 0; i < nnz; ++i) {
+        if (data[i].gene >= geneCount) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_analyze_lsh: a local gene id is not below geneCount");
+    }
+    const uint32_t words = wordCountOf(lshCount);
+
+    // ExpressionMatrixSubset::computeSums (src/ExpressionMatrixSubset.cpp:47-58)
+    std::vector<double> sums(2 * size_t(cellCount), 0.);
+    for (uint32_t c = 0; c < cellCount; ++c) {
+        double s1 = 0., s2 = 0.;
+        for (uint64_t i = toc[c]; i < toc[c + 1]; ++i) {
+            const float count = data[i].count;
+            s1 += count;
+            s2 += count * count;
+        }
+        sums[2 * size_t(c)] = s1;
+        sums[2 * size_t(c) + 1] = s2;
+    }
+
+    em2::AnalyzeLshState* state = em2::analyzeLshBegin(lshCount, seed, pairsCsvPath);
+    if (!state) return fail(EM2_ERROR_RUNTIME, std::string("em2_analyze_lsh: cannot open ") + pairsCsvPath);
+    struct Closer {
+        em2::AnalyzeLshState*& s;
+        ~Closer() { if (s) em2::analyzeLshEnd(s, 1, nullptr, nullptr, nullptr, nullptr); }
+    } closer{state};
+
+    // rows in chunks of about 16M pairs: 192 MB of device output per chunk, walked by the host in order
+    const uint64_t chunkPairs = 1ull << 24;
+    uint32_t maxRows = 0;
+    uint64_t maxPairs = 0;
+    for (uint32_t begin = 0; begin + 1 < cellCount;) {
+        uint32_t end = begin;
+        uint64_t pairs = 0;
+        while (end + 1 < cellCount && (end == begin || pairs + (cellCount - 1 - end) <= chunkPairs)) pairs += cellCount - 1 - end++;
+        if (end - begin > maxRows) maxRows = end - begin;
+        if (pairs > maxPairs) maxPairs = pairs;
+        begin = end;
+    }
+    DeviceBuffer dToc, dData, dSig, dProducts, dMismatches, dScratch;
+    EM2_HIP(dToc.allocate((size_t(cellCount) + 1) * sizeof(uint64_t)));
+    EM2_HIP(dData.allocate(nnz * sizeof(em2_count)));
+    EM2_HIP(dSig.allocate(size_t(cellCount) * words * sizeof(uint64_t)));
+    EM2_HIP(dProducts.allocate(maxPairs * sizeof(double)));
+    EM2_HIP(dMismatches.allocate(maxPairs * sizeof(uint32_t)));
+    EM2_HIP(dScratch.allocate(em2::analyzeScratchBytes(geneCount, maxRows)));
+    EM2_HIP(hipMemcpy(dToc.p, toc, (size_t(cellCount) + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (nnz) EM2_HIP(hipMemcpy(dData.p, data, nnz * sizeof(em2_count), hipMemcpyHostToDevice));
+    EM2_HIP(hipMemcpy(dSig.p, signatures, size_t(cellCount) * words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    std::vector<double> products(maxPairs);
+    std::vector<uint32_t> mismatches(maxPairs);
+    uint64_t done = 0;
+    for (uint32_t begin = 0; begin + 1 < cellCount;) {
+        uint32_t end = begin;
+        uint64_t pairs = 0;
+        while (end + 1 < cellCount && (end == begin || pairs + (cellCount - 1 - end) <= chunkPairs)) pairs += cellCount - 1 - end++;
+        EM2_HIP(em2::launchAnalyzePairs(dToc.as<uint64_t>(), dData.as<em2::CountIn>(), cellCount, geneCount, dSig.as<uint64_t>(), words,
+                                        begin, end, dScratch.p, dProducts.as<double>(), dMismatches.as<uint32_t>(), nullptr));
+        EM2_HIP(hipStreamSynchronize(nullptr));
+        EM2_HIP(hipMemcpy(products.data(), dProducts.p, pairs * sizeof(double), hipMemcpyDeviceToHost));
+        EM2_HIP(hipMemcpy(mismatches.data(), dMismatches.p, pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (!em2::analyzeLshRows(state, sums.data(), cellCount, geneCount, globalCellIds, begin, end, products.data(), mismatches.data(),
+                                 csvDownsample, exactSimilarity ? exactSimilarity + done : nullptr,
+                                 lshSimilarity ? lshSimilarity + done : nullptr)) {
+            return fail(EM2_ERROR_RUNTIME, "em2_analyze_lsh: Assertion failed: bin < binCount (a pair of cells with exact similarity 1, or a "
+                                           "cell without variance; src/ExpressionMatrixLsh.cpp:1322)");
+        }
+        done += pairs;
+        begin = end;
+    }
+    em2::AnalyzeLshState* finished = state;
+    state = nullptr;
+    if (!em2::analyzeLshEnd(finished, lshCount, statisticsCsvPath, sum0, sum1, sum2)) {
+        return fail(EM2_ERROR_RUNTIME, std::string("em2_analyze_lsh: cannot write ") + (statisticsCsvPath ? statisticsCsvPath : ""));
+    }
+    return EM2_OK;
+}
+
 
 int em2_cell_graph_label_propagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
                                      const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount,

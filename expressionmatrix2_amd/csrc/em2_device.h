@@ -56,6 +56,8 @@ size_t fsp4ControlBytes(uint32_t rowCount);
 // rows of the problem are in one launch and this workspace is given; 0 when that form would not be used.
 size_t fsp4SymmetricBytes(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw);
 bool fsp4UsesSymmetricScan(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw);
+// Whether signatures of this padded width take the matrix-core form of the symmetric scan (EM2_SCAN_MATRIX included).
+bool fsp4MatrixFormWanted(uint32_t paddedDw);
 struct Fsp4LaunchInfo {
     int form;                 // 0 ordered rows x columns, 1 symmetric, 2 sharded symmetric, 3 symmetric on the matrix cores
     double scanKernelMs;      // duration of the scan kernel proper when the launcher measured it (symmetric form), else -1
@@ -155,6 +157,21 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
                                const uint32_t* shuffleInput, uint64_t seed, uint64_t stableIterationCountThreshold,
                                uint64_t maxIterationCount, uint32_t* labels, uint64_t* iterationCount, uint32_t* error,
                                hipStream_t stream);
+
+// em2_analyze.hip: ExpressionMatrix::analyzeLsh (src/ExpressionMatrixLsh.cpp:1244-1367).  Device half: per unordered pair
+// of rows [rowBegin, rowEnd) x the cells above each, the sparse scalar product of the two cells' counts (float products,
+// double sum, ascending gene order) and the mismatch count of their signatures.  Host half: the order-defined rest.
+uint64_t analyzePairCount(uint32_t cellCount, uint32_t rowBegin, uint32_t rowEnd);
+size_t analyzeScratchBytes(uint32_t geneCount, uint32_t rowCount);
+hipError_t launchAnalyzePairs(const uint64_t* toc, const CountIn* data, uint32_t cellCount, uint32_t geneCount,
+                              const uint64_t* signatures, uint32_t words, uint32_t rowBegin, uint32_t rowEnd, void* scratch,
+                              double* scalarProducts, uint32_t* mismatches, hipStream_t stream);
+struct AnalyzeLshState;
+AnalyzeLshState* analyzeLshBegin(uint32_t lshCount, uint32_t seed, const char* pairsCsvPath);
+bool analyzeLshRows(AnalyzeLshState* s, const double* sums, uint32_t cellCount, uint32_t geneCount, const uint32_t* globalCellIds,
+                    uint32_t rowBegin, uint32_t rowEnd, const double* scalarProducts, const uint32_t* mismatches, double csvDownsample,
+                    double* exactOut, double* lshOut);
+bool analyzeLshEnd(AnalyzeLshState* s, uint32_t lshCount, const char* statisticsCsvPath, uint64_t* sum0, double* sum1, double* sum2);
 
 }  // namespace em2
 

@@ -387,6 +387,24 @@ void Matrix::computeLshSignatures(const std::string& geneSetName, const std::str
     writeLsh(directoryName_ + "/Lsh-" + lshName, cellCount, lshCount, signatures.data());       // ExpressionMatrixLsh.cpp:1189
 }
 
+void Matrix::analyzeLsh(const std::string& geneSetName, const std::string& cellSetName, size_t lshCount, unsigned int seed,
+                        double csvDownsample, const std::string& outputDirectory) const
+{
+    // ExpressionMatrixLsh.cpp:1253-1283: the subset and its Lsh object (signatures of the same gene set, cell set, seed)
+    uint32_t cellCount = 0, geneCount = 0;
+    std::vector<uint64_t> toc;
+    std::vector<em2_count> data;
+    subset(geneSetName, cellSetName, toc, data, geneCount, cellCount);
+    std::vector<uint64_t> signatures;
+    runLshPath("analyzeLsh", geneSetName, cellSetName, lshCount, seed, cellCount, &signatures, 0, 0., nullptr, nullptr);
+    const uint32_t* cellIds = static_cast<const uint32_t*>(cellSet(cellSetName).data());
+    const std::string prefix = outputDirectory.empty() ? std::string() : outputDirectory + "/";
+    const int rc = em2_analyze_lsh(toc.data(), data.data(), cellCount, geneCount, signatures.data(), uint32_t(lshCount), cellIds, seed,
+                                   csvDownsample, (prefix + "Lsh-analysis.csv").c_str(), (prefix + "LSH-analysis-statistics.csv").c_str(),
+                                   nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc != EM2_OK) fail(rc, em2_last_error());
+}
+
 void Matrix::findSimilarPairs5(const std::string& geneSetName, const std::string& cellSetName,
                                const std::string& lshName, const std::string& similarPairsName, size_t k,
                                double similarityThreshold, size_t lshSliceLength, size_t bucketOverflow) const

@@ -102,6 +102,10 @@ public:
                            const std::string& similarPairsName, size_t k, double similarityThreshold,
                            const std::vector<int32_t>& lshSliceLengths, uint32_t maxCheck, size_t log2BucketCount) const;
     void removeSimilarPairs(const std::string& similarPairsName) const;
+    // ExpressionMatrix::analyzeLsh (src/ExpressionMatrixLsh.cpp:1244-1367): writes Lsh-analysis.csv and
+    // LSH-analysis-statistics.csv into outputDirectory (the reference: the working directory, "").
+    void analyzeLsh(const std::string& geneSetName, const std::string& cellSetName, size_t lshCount, unsigned int seed,
+                    double csvDownsample, const std::string& outputDirectory) const;
 
     const GeneSet& geneSet(const std::string& name) const;                 // throws "Gene set X does not exist."
     const MappedFile& cellSet(const std::string& name) const;              // throws "Cell set X does not exist."

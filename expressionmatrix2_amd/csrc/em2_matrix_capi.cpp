@@ -77,6 +77,15 @@ int em2_matrix_compute_lsh_signatures(em2_matrix* matrix, const char* geneSetNam
     return guarded([&] { matrix->impl->computeLshSignatures(geneSetName, cellSetName, lshName, lshCount, seed); });
 }
 
+int em2_matrix_analyze_lsh(em2_matrix* matrix, const char* geneSetName, const char* cellSetName, size_t lshCount,
+                           unsigned int seed, double csvDownsample, const char* outputDirectory)
+{
+    if (!matrix || !geneSetName || !cellSetName) return nullArgument("em2_matrix_analyze_lsh");
+    return guarded([&] {
+        matrix->impl->analyzeLsh(geneSetName, cellSetName, lshCount, seed, csvDownsample, outputDirectory ? outputDirectory : "");
+    });
+}
+
 int em2_matrix_find_similar_pairs5(em2_matrix* matrix, const char* geneSetName, const char* cellSetName,
                                    const char* lshName, const char* similarPairsName, size_t k,
                                    double similarityThreshold, size_t lshSliceLength, size_t bucketOverflow)

@@ -514,6 +514,9 @@ constexpr int kColumnsPerBranch = 4;                        // kernel ms at 1M c
 constexpr uint32_t kMatrixSteps = 16;                        // 1024 bits / 64 per MFMA
 constexpr uint32_t kMatrixTileWords = kMatrixSteps * 64u;    // FragmentWord4 per 32-cell tile (16 KB)
 constexpr float kMatrixBits = 1024.f;
+// Narrowest padded width (dwords) that takes the matrix form by default.  Scan kernel ms at 1M cells, v_xor/v_bcnt form /
+// matrix form: 512 bits 486 / 274, 256 bits 349 / 302 (the zero-extended fragments cost the full 16 k-steps).
+constexpr uint32_t kMatrixMinPaddedDw = 8;
 
 // sig32 [cell][32] -> fragments [cell / 32][k-step][lane]: lane l of k-step s holds cell (l & 31) of the block, bits
 // s*64 + (l >> 5)*32 .. +31, one nibble per bit (0x2 = +1, 0xA = -1).  Cells past the end repeat the last one.
@@ -536,6 +539,17 @@ expandFragmentsKernel(const uint32_t* __restrict__ sig32, uint32_t cellCount, ui
         v[d] = int(packed);
     }
     out[i] = v;
+}
+
+// sig32 [cell][paddedDw] -> [cell][32], zero-extended: what the matrix kernel's v_xor/v_bcnt parts and the fragment
+// expansion read when the signatures are narrower than 1024 bits.
+__global__ void __launch_bounds__(256)
+widenSignaturesKernel(const uint32_t* __restrict__ sig32, uint32_t paddedDw, uint32_t cellCount, uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cellCount * 32u) return;
+    const uint32_t cell = i >> 5, word = i & 31u;
+    out[i] = word < paddedDw ? sig32[size_t(cell) * paddedDw + word] : 0u;
 }
 
 // emitColumn for the walk below: the pool pointer and the key layout arrive in registers (emitColumn re-reads them
@@ -1826,6 +1840,17 @@ constexpr uint32_t kMatrixMaxSegments = 256;     // matrix form: 4096-column seg
 constexpr uint32_t kTableWords = 2u * kMatrixMaxSegments + 2u;
 constexpr uint32_t kInboxChunk = 512;
 
+// Which signature widths take the matrix-core form of the triangle.  The fragments are always 1024 bits wide: a
+// narrower signature is zero-extended (a zero bit is +1 on both sides, so the dot product stays 1024 - 2 * mismatches),
+// which costs the full 16 k-steps per tile whatever the width.  EM2_SCAN_MATRIX: 0 never, 1 (default) the widths it
+// is faster for (129..1024 bits, kMatrixMinPaddedDw), 2 every width up to 1024 bits (tests).
+static bool matrixFormWanted(uint32_t paddedDw)
+{
+    const uint64_t mode = envNumber("EM2_SCAN_MATRIX", 1);
+    if (mode == 0 || paddedDw > 32u) return false;
+    return mode >= 2 || paddedDw >= kMatrixMinPaddedDw;
+}
+
 bool symmetricEligible(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
 {
     // inbox keys hold two cell ids and a mismatch count in 64 bits: 13 + 2 * bits(cellCount) <= 64
@@ -1835,7 +1860,7 @@ bool symmetricEligible(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
     if (v && (v[0] == 's' || v[0] == 'p')) return false;
     // 1024-bit signatures take the matrix-core form, which wins much earlier (scan ms ordered / symmetric-matrix:
     // 30k cells 2.5 / 2.4, 60k 8.2 / 4.2, 100k 20.1 / 7.5)
-    const bool matrix = paddedDw == 32u && envNumber("EM2_SCAN_MATRIX", 1) != 0;
+    const bool matrix = matrixFormWanted(paddedDw);
     return cellCount >= envNumber("EM2_SYMMETRIC_MIN_CELLS", matrix ? kSymmetricMatrixMinCells : kSymmetricMinCells);
 }
 
@@ -1860,11 +1885,11 @@ static size_t inboxSortTempBytes(uint64_t capacity)
 }
 
 struct SymmetricLayout {
-    size_t snap, table, tableMatrix, control, poolA, poolB, temp, fragments, total, tempBytes;
+    size_t snap, table, tableMatrix, control, poolA, poolB, temp, fragments, widened, total, tempBytes;
     uint64_t capacity;
 };
 
-static SymmetricLayout symmetricLayout(uint32_t cellCount)
+static SymmetricLayout symmetricLayout(uint32_t cellCount, uint32_t paddedDw)
 {
     SymmetricLayout l;
     l.capacity = inboxCapacity(cellCount);
@@ -1878,8 +1903,16 @@ static SymmetricLayout symmetricLayout(uint32_t cellCount)
     l.poolB = at;   at += align256(size_t(l.capacity) * 8u);
     l.temp = at;    at += align256(l.tempBytes);
     l.fragments = at; at += align256(size_t((cellCount + 63u) / 64u) * 64u * 512u);     // FP4 fragments, matrix form
+    // signatures zero-extended to 1024 bits for the v_xor/v_bcnt parts of the matrix kernel (a quad's own 256 columns)
+    l.widened = at;
+    if (paddedDw < 32u && matrixFormWanted(paddedDw)) at += align256(size_t(cellCount) * 128u);
     l.total = at;
     return l;
+}
+
+bool fsp4MatrixFormWanted(uint32_t paddedDw)
+{
+    return matrixFormWanted(paddedDw);
 }
 
 bool fsp4UsesSymmetricScan(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
@@ -1890,7 +1923,7 @@ bool fsp4UsesSymmetricScan(uint32_t cellCount, uint32_t rowCount, uint32_t padde
 size_t fsp4SymmetricBytes(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
 {
     if (!symmetricEligible(cellCount, rowCount, paddedDw)) return 0;
-    return symmetricLayout(cellCount).total;
+    return symmetricLayout(cellCount, paddedDw).total;
 }
 
 // Resident waves of a persistent-style launch of `kernel` (min(occupancy, 4 waves per SIMD) x CUs).
@@ -1954,9 +1987,8 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     // Matrix-core form of the triangle part (see fsp4ScanMatrixKernel): 1024-bit signatures, the plain single-GPU
     // launch.  EM2_SCAN_MATRIX=0 keeps the v_xor/v_bcnt form.  Full-row and segment boundaries become multiples of 256
     // cells so that the four waves of a block always walk the same columns.
-    bool matrix = paddedDw == 32u && wavesPerBlock == 4u && args.rowBlockStride == 1u && args.rowBlockOffset == 0u &&
+    bool matrix = matrixFormWanted(paddedDw) && wavesPerBlock == 4u && args.rowBlockStride == 1u && args.rowBlockOffset == 0u &&
                   args.localBlockBase == 0u && args.shardFlags == 0u && args.columnLimit == cellCount && args.rowBegin == 0u &&
-                  envNumber("EM2_SCAN_MATRIX", 1) != 0 &&
                   ((lds + 15u) & ~size_t(15)) + scanMatrixLdsBytes(args.k) <= 150u * 1024u;      // selection area + four tiles
     if (matrix) {
         fullRowBlocks = (fullRowBlocks + 3u) & ~3u;
@@ -2024,7 +2056,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         tableMatrix[segmentsMatrix] = uint32_t(ticketsMatrix);
     }
 
-    const SymmetricLayout layout = symmetricLayout(cellCount);
+    const SymmetricLayout layout = symmetricLayout(cellCount, paddedDw);
     char* ws = static_cast<char*>(symmetricWs);
     char* c = static_cast<char*>(control);
     const size_t stateBytes = align256(size_t(rowBlocks) * 64u * 8u);
@@ -2091,11 +2123,18 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         e = hipMemsetAsync(args.control, 0, 4u, stream);                 // the ticket; the error word stays
         if (e != hipSuccess) return e;
         const uint32_t fragmentCount = rowBlocks * 2u * kMatrixSteps * 64u;
+        Fsp4Args matrixArgs = args;
+        if (paddedDw < 32u) {
+            uint32_t* widened = reinterpret_cast<uint32_t*>(ws + layout.widened);
+            widenSignaturesKernel<<<dim3((cellCount * 32u + 255u) / 256u), dim3(256), 0, stream>>>(args.sig32, paddedDw, cellCount, widened);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            matrixArgs.sig32 = widened;
+        }
         expandFragmentsKernel<<<dim3((fragmentCount + 255u) / 256u), dim3(256), 0, stream>>>(
-            args.sig32, cellCount, fragmentCount, reinterpret_cast<FragmentWord4*>(ws + layout.fragments));
+            matrixArgs.sig32, cellCount, fragmentCount, reinterpret_cast<FragmentWord4*>(ws + layout.fragments));
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        Fsp4Args matrixArgs = args;
         matrixArgs.segTable = reinterpret_cast<const uint32_t*>(ws + layout.tableMatrix);
         matrixArgs.segments = uint32_t(segmentsMatrix);
         matrixArgs.columnsPerSegment = cpsMatrix;

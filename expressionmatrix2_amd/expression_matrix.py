@@ -78,6 +78,13 @@ class ExpressionMatrix:
         capi.check(capi.load().em2_matrix_compute_lsh_signatures(self._handle, _b(geneSetName), _b(cellSetName),
                                                                  _b(lshName), lshCount, seed))
 
+    # ---- src/PythonModule.cpp:940-944: bound without argument names or defaults ("Only intended to be used for testing") ----
+    def analyzeLsh(self, geneSetName, cellSetName, lshCount, seed, csvDownsample):
+        """Writes Lsh-analysis.csv and LSH-analysis-statistics.csv into the working directory
+        (src/ExpressionMatrixLsh.cpp:1303, :1345)."""
+        capi.check(capi.load().em2_matrix_analyze_lsh(self._handle, _b(geneSetName), _b(cellSetName), lshCount, seed,
+                                                      csvDownsample, None))
+
     # ---- src/PythonModule.cpp:852-865 ----
     def findSimilarPairs5(self, geneSetName="AllGenes", cellSetName="AllCells", lshName=_REQUIRED,
                           similarPairsName=_REQUIRED, k=100, similarityThreshold=0.2, lshSliceLength=_REQUIRED,

@@ -273,6 +273,29 @@ int em2_dev_cell_graph_edges(const em2_pair* d_pairs, const uint32_t* d_usedCoun
                              double similarityThreshold, uint32_t maxConnectivity, uint32_t* edgeVertex0,
                              uint32_t* edgeVertex1, float* edgeSimilarity, uint64_t* edgeCount);
 
+/* ExpressionMatrix::analyzeLsh (src/ExpressionMatrixLsh.cpp:1244-1367; Python: src/PythonModule.cpp:940-944): the
+ * quality of the LSH similarity against the exact one, over every unordered pair of cells of an expression matrix
+ * subset.  SURVEY.md 8(f).
+ *   toc / data      : the subset's counts (what em2_matrix_subset / em2_dev_subset_* produce: local gene ids ascending)
+ *   geneCount       : size of the gene set -- the n of the correlation coefficient (src/ExpressionMatrixSubset.cpp:115)
+ *   signatures      : the cells' LSH signatures (em2_compute_signatures), lshCount bits each
+ *   globalCellIds   : the cell set (column 3 and 4 of the pairs csv)
+ *   seed            : seeds the mt19937 that downsamples the pairs csv (one draw per pair, in pair order)
+ *   pairsCsvPath / statisticsCsvPath : the reference writes "Lsh-analysis.csv" and "LSH-analysis-statistics.csv" into
+ *                     the working directory; statisticsCsvPath may be NULL
+ *   sum0 / sum1 / sum2 (each 200 entries, may be NULL): per bin of exact similarity the number of pairs, the sum of
+ *                     (lsh - exact) and the sum of its square, accumulated in the reference's pair order
+ *   exactSimilarity / lshSimilarity (cellCount * (cellCount - 1) / 2 entries, may be NULL): the values per pair
+ * The scalar products of the pairs and the mismatch counts are computed on the device (bit-identical to the
+ * reference's merge loop: float products, double sum, ascending gene); what the reference's pair order defines (the
+ * bins' double sums, the random draws, the csv) is walked on the host in that order.  Bit-exact in all outputs.
+ * Errors: EM2_ERROR_RUNTIME "bin < binCount" where the reference's CZI_ASSERT (:1322) throws (a pair with exact
+ * similarity 1, or without variance); the files are then incomplete, as the reference's are. */
+int em2_analyze_lsh(const uint64_t* toc, const em2_count* data, uint32_t cellCount, uint32_t geneCount,
+                    const uint64_t* signatures, uint32_t lshCount, const uint32_t* globalCellIds, uint32_t seed,
+                    double csvDownsample, const char* pairsCsvPath, const char* statisticsCsvPath,
+                    uint64_t* sum0, double* sum1, double* sum2, double* exactSimilarity, double* lshSimilarity);
+
 /* CellGraph::labelPropagationClustering (src/CellGraph.cpp:443-612, ClusterTable src/CellGraph.hpp:50-121; reached
  * from ExpressionMatrix::createClusterGraph, src/ExpressionMatrix.cpp:2145-2149) over the graph em2_cell_graph_edges
  * built.  SURVEY.md 8(f) row 2.  vertexCellIds[v] is the cell id of vertex v, in add_vertex order with removed
@@ -309,6 +332,13 @@ int em2_matrix_find_similar_pairs4(em2_matrix* matrix, const char* geneSetName, 
 /* ExpressionMatrix::computeLshSignatures (src/ExpressionMatrixLsh.cpp:1150-1192; src/PythonModule.cpp:945-953). */
 int em2_matrix_compute_lsh_signatures(em2_matrix* matrix, const char* geneSetName, const char* cellSetName,
                                       const char* lshName, size_t lshCount, unsigned int seed);
+
+/* ExpressionMatrix::analyzeLsh(geneSetName, cellSetName, lshCount, seed, csvDownsample) (src/ExpressionMatrixLsh.cpp:
+ * 1244-1367, bound without defaults at src/PythonModule.cpp:940-944): subset + signatures + em2_analyze_lsh.  The
+ * reference writes "Lsh-analysis.csv" and "LSH-analysis-statistics.csv" into the working directory; outputDirectory
+ * (NULL or "": the working directory) says where. */
+int em2_matrix_analyze_lsh(em2_matrix* matrix, const char* geneSetName, const char* cellSetName, size_t lshCount,
+                           unsigned int seed, double csvDownsample, const char* outputDirectory);
 
 /* ExpressionMatrix::findSimilarPairs5 (src/ExpressionMatrixLsh.cpp:312-501; src/PythonModule.cpp:852-865,
  * default bucketOverflow=1000). */

@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <fstream>
 #include <random>
 #include <utility>
 #include <map>
@@ -784,6 +785,124 @@ int64_t em2o_subset(const uint64_t* globalToc, const uint32_t* globalGenes, cons
         }
     }
     return int64_t(n);
+}
+
+
+// =====================================================================================================
+// ExpressionMatrix::analyzeLsh (ExpressionMatrixLsh.cpp:1244-1367): for every unordered pair of
+// cells of the subset the exact similarity (ExpressionMatrixSubset::computeCellSimilarity,
+// ExpressionMatrixSubset.cpp:83-133) against the LSH one (Lsh::computeCellSimilarity, Lsh.cpp:254-265), 200 bins of
+// the exact similarity with count / sum of errors / sum of squared errors, a downsampled csv of the pairs and a csv
+// of bias, rms and theoretical rms per bin.
+//   toc / genes / counts : the subset's CellExpressionCounts (local gene ids ascending per cell), sums = Sum{sum1, sum2}
+//   geneCount            : geneSet.size() (the n of the correlation coefficient, :115)
+//   globalCellIds        : cellSet[localCellId]
+//   pairsCsvPath / statisticsCsvPath : "Lsh-analysis.csv" / "LSH-analysis-statistics.csv" of :1303, :1345
+//   sum0 / sum1 / sum2   : the 200 bins (:1297-1301); exactOut / lshOut (optional): the values per pair, pair order
+// The downsampling draws boost::uniform_01<> on boost::mt19937(seed) once per pair (:1286-1292, :1329): one 32-bit
+// draw times 2^-32 (Boost's new_uniform_01 over a 32-bit integer engine), boost::mt19937 == std::mt19937.
+// Returns the number of pairs, or -1 where CZI_ASSERT(bin < binCount) (:1322) throws (a similarity of exactly 1
+// lands in bin 200; so does a NaN from a cell without variance).
+// =====================================================================================================
+int64_t em2o_analyze_lsh(const uint64_t* toc, const uint32_t* genes, const float* counts, const double* sums,
+                         uint32_t cellCount, uint32_t geneCount, const uint64_t* signatures, uint32_t lshCount,
+                         const uint32_t* globalCellIds, uint32_t seed, double csvDownsample,
+                         const char* pairsCsvPath, const char* statisticsCsvPath,
+                         uint64_t* sum0Out, double* sum1Out, double* sum2Out, double* exactOut, double* lshOut)
+{
+    const uint64_t W = (uint64_t(lshCount) - 1) / 64 + 1;
+    std::vector<double> table;
+    similarityTable(lshCount, table);
+    std::mt19937 randomSource(seed);                                                     // :1288
+    const double factor = 1.0 / (double(0xffffffffu) + 1.0);
+
+    const size_t binCount = 200;                                                         // :1297
+    const double binWidth = 2. / binCount;
+    std::vector<size_t> sum0(binCount, 0);
+    std::vector<double> sum1(binCount, 0.);
+    std::vector<double> sum2(binCount, 0.);
+
+    std::ofstream csvOut(pairsCsvPath);                                                  // :1303
+    csvOut << "LocalCellId0,LocalCellId1,GlobalCellId0,GlobalCellId1,ExactSimilarity,LshSimilarity\n";
+
+    int64_t pairIndex = 0;
+    for (uint32_t localCellId0 = 0; localCellId0 + 1 < cellCount; localCellId0++) {      // :1308
+        for (uint32_t localCellId1 = localCellId0 + 1; localCellId1 < cellCount; localCellId1++) {
+            // ExpressionMatrixSubset.cpp:86-108
+            uint64_t it0 = toc[localCellId0], end0 = toc[localCellId0 + 1];
+            uint64_t it1 = toc[localCellId1], end1 = toc[localCellId1 + 1];
+            double scalarProduct = 0.;
+            while ((it0 != end0) && (it1 != end1)) {
+                const uint32_t localGeneId0 = genes[it0];
+                const uint32_t localGeneId1 = genes[it1];
+                if (localGeneId0 < localGeneId1) {
+                    ++it0;
+                } else if (localGeneId1 < localGeneId0) {
+                    ++it1;
+                } else {
+                    scalarProduct += counts[it0] * counts[it1];                          // float product, double sum
+                    ++it0;
+                    ++it1;
+                }
+            }
+            // :115-122
+            const double n = double(geneCount);
+            const double s10 = sums[2 * size_t(localCellId0)], s20 = sums[2 * size_t(localCellId0) + 1];
+            const double s11 = sums[2 * size_t(localCellId1)], s21 = sums[2 * size_t(localCellId1) + 1];
+            const double numerator = n * scalarProduct - s10 * s11;
+            const double denominator = std::sqrt((n * s20 - s10 * s10) * (n * s21 - s11 * s11));
+            const double exactSimilarity = numerator / denominator;
+
+            const double lshSimilarity = table[countMismatches(signatures + localCellId0 * W, signatures + localCellId1 * W, W)];
+
+            const double delta = lshSimilarity - exactSimilarity;                        // :1320
+            const size_t bin = size_t(std::floor((exactSimilarity + 1.) / binWidth));
+            if (!(bin < binCount)) return -1;                                            // :1322
+            ++(sum0[bin]);
+            sum1[bin] += delta;
+            sum2[bin] += delta * delta;
+            if (exactOut) exactOut[pairIndex] = exactSimilarity;
+            if (lshOut) lshOut[pairIndex] = lshSimilarity;
+            ++pairIndex;
+
+            const double draw = double(randomSource()) * factor;
+            if (draw < csvDownsample) {                                                  // :1329
+                csvOut << localCellId0 << ",";
+                csvOut << localCellId1 << ",";
+                csvOut << globalCellIds[localCellId0] << ",";
+                csvOut << globalCellIds[localCellId1] << ",";
+                csvOut << exactSimilarity << ",";
+                csvOut << lshSimilarity << ",\n";
+            }
+        }
+    }
+
+    std::ofstream statsOut(statisticsCsvPath);                                           // :1345
+    statsOut << "Similarity,Bias,Rms,RmsTheory\n";
+    for (size_t bin = 0; bin < binCount; bin++) {
+        if (sum0Out) sum0Out[bin] = sum0[bin];
+        if (sum1Out) sum1Out[bin] = sum1[bin];
+        if (sum2Out) sum2Out[bin] = sum2[bin];
+        if (sum0[bin] < 2) {
+            continue;
+        }
+        const double pi = 3.141592653589793238462643383279502884;                       // boost::math::double_constants::pi
+        const double similarity = (double(bin) + 0.5) * binWidth - 1.;
+        const double sinTheta = std::sqrt(1. - similarity * similarity);
+        const double theta = std::acos(similarity);
+        const double p = 1. - theta / pi;
+        const double theoreticalSigma = pi * sinTheta * std::sqrt(p * (1. - p) / double(lshCount));
+        const double s0 = double(sum0[bin]);
+        const double s1 = sum1[bin];
+        const double s2 = sum2[bin];
+        const double average = s1 / s0;
+        const double sigma = std::sqrt(s2 / s0);
+        statsOut << similarity << ",";
+        statsOut << average << ",";
+        statsOut << sigma << ",";
+        statsOut << theoreticalSigma << "\n";
+    }
+    return pairIndex;
 }
 
 

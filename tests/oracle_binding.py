@@ -83,6 +83,37 @@ class Oracle:
         assert n2 == n
         return out_toc, out_genes, out_counts, sums
 
+    def analyze_lsh(self, toc, genes, counts, gene_count, sig, lsh_count, global_cell_ids, seed, csv_downsample,
+                    pairs_csv_path, statistics_csv_path):
+        """ExpressionMatrix::analyzeLsh -> dict(sum0, sum1, sum2, exact, lsh), or None where CZI_ASSERT(bin < binCount) throws."""
+        toc = np.ascontiguousarray(toc, dtype=np.uint64)
+        genes = np.ascontiguousarray(genes, dtype=np.uint32)
+        counts = np.ascontiguousarray(counts, dtype=np.float32)
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        ids = np.ascontiguousarray(global_cell_ids, dtype=np.uint32)
+        n = len(toc) - 1
+        sums = np.zeros(2 * n, dtype=np.float64)
+        for c in range(n):                       # ExpressionMatrixSubset::computeSums (:47-58): float values, sequential double sums
+            v = counts[int(toc[c]):int(toc[c + 1])]
+            if len(v):
+                sums[2 * c] = np.cumsum(v.astype(np.float64))[-1]                 # cumsum adds left to right
+                sums[2 * c + 1] = np.cumsum((v * v).astype(np.float64))[-1]       # float product, then double
+        pairs = n * (n - 1) // 2
+        out = {"sum0": np.zeros(200, dtype=np.uint64), "sum1": np.zeros(200), "sum2": np.zeros(200),
+               "exact": np.zeros(max(1, pairs)), "lsh": np.zeros(max(1, pairs))}
+        self.lib.em2o_analyze_lsh.restype = ctypes.c_int64
+        self.lib.em2o_analyze_lsh.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32,
+                                              ctypes.c_void_p, ctypes.c_uint32, ctypes.c_double, ctypes.c_char_p, ctypes.c_char_p] + \
+                                             [ctypes.c_void_p] * 5
+        done = self.lib.em2o_analyze_lsh(_ptr(toc), _ptr(genes), _ptr(counts), _ptr(sums), n, gene_count, _ptr(sig), lsh_count, _ptr(ids),
+                                         seed, csv_downsample, os.fsencode(pairs_csv_path), os.fsencode(statistics_csv_path),
+                                         _ptr(out["sum0"]), _ptr(out["sum1"]), _ptr(out["sum2"]), _ptr(out["exact"]), _ptr(out["lsh"]))
+        if done < 0:
+            return None
+        assert done == pairs
+        out["exact"], out["lsh"] = out["exact"][:pairs], out["lsh"][:pairs]
+        return out
+
     def generate_lsh_vectors(self, gene_count, lsh_count, seed):
         out = np.empty((gene_count, lsh_count), dtype=np.float64)
         self.lib.em2o_generate_lsh_vectors(gene_count, lsh_count, seed, _ptr(out))

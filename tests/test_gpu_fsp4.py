@@ -352,6 +352,26 @@ def test_matrix_form_matches_oracle(oracle, scan_knobs, n, L, k, thr, kind, knob
     assert_same(pairs, gused, cell, sim, used)
 
 
+@pytest.mark.parametrize("n,L,k,thr,kind", [(2500, 64, 10, 0.2, "clustered"), (2309, 192, 7, 0.0, "clustered"),
+                                             (3000, 512, 20, 0.2, "clustered"), (1700, 300, 5, -1.0, "random"),
+                                             (2600, 100, 30, 0.1, "clustered"), (2100, 33, 4, 0.3, "random")])
+def test_matrix_form_of_narrow_signatures(oracle, scan_knobs, n, L, k, thr, kind):
+    """EM2_SCAN_MATRIX=2: every width up to 1024 bits on the matrix cores (the default, 1, takes 129 bits and up) (the signatures zero-extended to 1024 bits: a
+    padded bit is +1 on both sides, the dot product is still 1024 - 2 * mismatches).  Same bytes as the oracle and as
+    the v_xor/v_bcnt form."""
+    sig = make(n, L, kind)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_FULL_ROW_CELLS=256, EM2_MIN_SEGMENT_COLUMNS=512, EM2_SCAN_MATRIX=2)
+    pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    info = capi.dev_find_similar_pairs4_last_launch()
+    assert info["form"] == 3 and info["matrix_pairs"] > 0
+    assert_same(pairs, gused, cell, sim, used)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_FULL_ROW_CELLS=256, EM2_MIN_SEGMENT_COLUMNS=512, EM2_SCAN_MATRIX=0)
+    pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    assert capi.dev_find_similar_pairs4_last_launch()["form"] == 1
+    assert_same(pairs, gused, cell, sim, used)
+
+
 def test_matrix_form_inbox_overflow_falls_back(oracle, scan_knobs):
     sig = make(2000, 1024, "clustered")
     cell, sim, used = oracle.find_similar_pairs4(sig, 1024, 10, -0.5)
