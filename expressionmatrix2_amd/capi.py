@@ -74,6 +74,14 @@ SYMBOLS = {
                                    _c.c_void_p, _c.c_void_p]),
     "em2_matrix_analyze_lsh": (_c.c_int, [_c.c_void_p, _c.c_char_p, _c.c_char_p, _c.c_size_t, _c.c_uint, _c.c_double,
                                           _c.c_char_p]),
+    "em2_dist_find_similar_pairs4_workspace": (_c.c_size_t, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32]),
+    "em2_dist_find_similar_pairs4_form": (_c.c_int, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32]),
+    "em2_dist_find_similar_pairs4": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_double,
+                                                _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p,
+                                                _c.c_void_p]),
+    "em2_dist_find_similar_pairs4_with": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_double,
+                                                     _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p,
+                                                     _c.c_void_p]),
     "em2_dev_find_similar_pairs4_form": (_c.c_int, [_c.c_uint32, _c.c_uint32]),
     "em2_dev_find_similar_pairs4_form_for": (_c.c_int, [_c.c_uint32, _c.c_uint32, _c.c_uint32]),
     "em2_dev_find_similar_pairs4_last_launch": (_c.c_int, [_c.c_void_p, _c.c_uint32]),
@@ -368,6 +376,45 @@ def dev_find_similar_pairs4_last_launch():
     return {"form": int(v[0]), "scan_kernel_ms": float(v[1]), "wave_column_steps": float(v[2]),
             "inbox_entries": float(v[3]), "segments": int(v[4]), "full_row_cells": int(v[5]),
             "matrix_pairs": float(v[6]), "matrix_kernel_ms": float(v[7])}
+
+
+# ---- em2_collectives (include/em2_lsh.h): the transport table of em2_dist_find_similar_pairs4_with ----
+ALL_GATHER_FN = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p)
+ALL_REDUCE_MAX_I32_FN = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p)
+ALL_TO_ALL_V_FN = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64), _c.c_void_p,
+                               _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64), _c.c_void_p)
+
+
+class Collectives(_c.Structure):
+    _fields_ = [("context", _c.c_void_p), ("world", _c.c_int), ("rank", _c.c_int), ("all_gather", ALL_GATHER_FN),
+                ("all_reduce_max_i32", ALL_REDUCE_MAX_I32_FN), ("all_to_all_v", ALL_TO_ALL_V_FN)]
+
+
+DIST_STAGES = ("gather_signatures", "scan", "all_reduce", "exchange", "redistribute")
+
+
+def dist_find_similar_pairs4_workspace(cell_count, lsh_count, k, rank, world):
+    return int(load().em2_dist_find_similar_pairs4_workspace(cell_count, lsh_count, k, rank, world))
+
+
+def dist_find_similar_pairs4_form(cell_count, lsh_count, k, world):
+    return int(load().em2_dist_find_similar_pairs4_form(cell_count, lsh_count, k, world))
+
+
+def dist_find_similar_pairs4(comm_or_table, local_sig_ptr, cell_count, lsh_count, k, similarity_threshold, all_sig_ptr, pairs_ptr,
+                             used_ptr, workspace_ptr, workspace_bytes, stream, timed=False):
+    """em2_dist_find_similar_pairs4 (comm_or_table: an ncclComm_t as int) or ..._with (a Collectives table); returns the
+    per-stage wall ms as a dict when timed."""
+    ms = (_c.c_double * len(DIST_STAGES))() if timed else None
+    if isinstance(comm_or_table, Collectives):
+        rc = load().em2_dist_find_similar_pairs4_with(_c.addressof(comm_or_table), local_sig_ptr, cell_count, lsh_count, k,
+                                                      similarity_threshold, all_sig_ptr, pairs_ptr, used_ptr, workspace_ptr,
+                                                      workspace_bytes, stream, ms)
+    else:
+        rc = load().em2_dist_find_similar_pairs4(comm_or_table, local_sig_ptr, cell_count, lsh_count, k, similarity_threshold,
+                                                 all_sig_ptr, pairs_ptr, used_ptr, workspace_ptr, workspace_bytes, stream, ms)
+    check(rc)
+    return dict(zip(DIST_STAGES, ms)) if timed else None
 
 
 def dev_find_similar_pairs5_last_launch():

@@ -228,6 +228,59 @@ int em2_dev_fsp4_sharded_phase(int phase, const uint64_t* d_signatures, uint32_t
 int em2_dev_fsp4_sharded_status(uint32_t cellCount, uint32_t k, uint32_t rank, uint32_t world, const void* d_workspace,
                                 void* stream, uint64_t* usedEntries, uint32_t* overflow);
 
+/* ---- findSimilarPairs4 across the GPUs of a node from C or C++ (csrc/em2_dist.hip) ----
+ * One process per GPU.  Every rank calls with the same arguments and its own shard of the signatures -- the cells
+ * [rank * shard, min(cellCount, (rank + 1) * shard)), shard = ceil(cellCount / world), the contiguous ranges of north_star --
+ * and ends with the SimilarPairs rows of exactly those cells.  The function issues every collective itself:
+ *   rows form       all_gather of the signature shards, then em2_dev_find_similar_pairs4 on the rank's rows;
+ *   symmetric form  (large problems; every unordered pair once across the ranks) all_gather, phases 0-3 of
+ *                   em2_dev_fsp4_sharded_phase with two all_reduce(MAX) of the snapshots, one small all_gather by which the
+ *                   ranks agree on entry counts and overflow, the all_to_all of the deferred candidates (all_gather when
+ *                   world is not a power of two), and an all_to_all that moves the finished rows from the block-cyclic
+ *                   owners to the contiguous ranges.  A pool overflow on any rank sends all ranks to the rows form.
+ * em2_dist_find_similar_pairs4_form: 2 if a problem of this shape takes the symmetric form, else 0 (EM2_SHARDED_SCAN=0 and
+ * EM2_SHARDED_MIN_CELLS as in expressionmatrix2_amd/sharded.py, whose DevicePipeline is this choreography in Python).
+ *   d_localSignatures  [shard][words] device: the rank's signatures (the last rank's unused tail is ignored)
+ *   d_allSignatures    [shard * world][words] device: receives all signatures (rows [0, cellCount) are the cells)
+ *   d_pairs / d_usedCount  [rows][k] / [rows] device, rows = the rank's range
+ *   d_workspace        em2_dist_find_similar_pairs4_workspace(...) bytes, device
+ *   stageMs            NULL, or EM2_DIST_MS_COUNT doubles that receive the wall time per kind of stage; asking for them
+ *                      synchronises the stream after every stage (measurements), NULL leaves the call asynchronous up to
+ *                      the read-backs the exchange needs
+ * em2_dist_find_similar_pairs4 takes an RCCL communicator (ncclComm_t, passed as void*: this header does not include
+ * rccl.h).  RCCL is bound at run time -- the nccl* symbols already in the process (the library that made the communicator),
+ * else librccl.so.1 -- so libem2lsh.so has no link-time dependency on it.  em2_dist_find_similar_pairs4_with takes the
+ * transport as a table instead (MPI, a test harness, ...): every function works on DEVICE buffers, is called by all ranks
+ * in the same order, is ordered after earlier work on `stream` and before later work on it, and returns 0 or an error.
+ * all_gather's send buffer may be the rank's own slot of the receive buffer.  all_to_all_v gets byte counts and byte
+ * offsets per peer (host arrays of `world` entries).
+ * A HIP or transport error on one rank ends that rank's call with an error while the others may wait in a collective:
+ * abort the communicator (ncclCommAbort), as in any RCCL program.  No reference counterpart (the reference is one thread). */
+typedef struct em2_collectives {
+    void* context;
+    int world;
+    int rank;
+    int (*all_gather)(void* context, const void* d_send, void* d_recv, size_t bytesPerRank, void* stream);
+    int (*all_reduce_max_i32)(void* context, void* d_buffer, size_t count, void* stream);
+    int (*all_to_all_v)(void* context, const void* d_send, const uint64_t* sendBytes, const uint64_t* sendOffsets,
+                        void* d_recv, const uint64_t* recvBytes, const uint64_t* recvOffsets, void* stream);
+} em2_collectives;
+#define EM2_DIST_MS_GATHER_SIGNATURES 0
+#define EM2_DIST_MS_SCAN 1
+#define EM2_DIST_MS_ALL_REDUCE 2
+#define EM2_DIST_MS_EXCHANGE 3
+#define EM2_DIST_MS_REDISTRIBUTE 4
+#define EM2_DIST_MS_COUNT 5
+size_t em2_dist_find_similar_pairs4_workspace(uint32_t cellCount, uint32_t lshCount, uint32_t k, uint32_t rank, uint32_t world);
+int em2_dist_find_similar_pairs4_form(uint32_t cellCount, uint32_t lshCount, uint32_t k, uint32_t world);
+int em2_dist_find_similar_pairs4(void* ncclCommunicator, const uint64_t* d_localSignatures, uint32_t cellCount, uint32_t lshCount,
+                                 uint32_t k, double similarityThreshold, uint64_t* d_allSignatures, em2_pair* d_pairs,
+                                 uint32_t* d_usedCount, void* d_workspace, size_t workspaceBytes, void* stream, double* stageMs);
+int em2_dist_find_similar_pairs4_with(const em2_collectives* collectives, const uint64_t* d_localSignatures, uint32_t cellCount,
+                                      uint32_t lshCount, uint32_t k, double similarityThreshold, uint64_t* d_allSignatures,
+                                      em2_pair* d_pairs, uint32_t* d_usedCount, void* d_workspace, size_t workspaceBytes,
+                                      void* stream, double* stageMs);
+
 /* Synchronises `stream` and reports whether the last em2_dev_find_similar_pairs4 on this workspace completed: the
  * scan hands per-row state from one column segment to the next between waves, and a hand-off wait that exceeds
  * ~4 s raises an error word instead of hanging the GPU (never observed).  rowCount and k as in that call. */

@@ -1,0 +1,70 @@
+"""The C-level multi-GPU entry (include/em2_lsh.h: em2_dist_find_similar_pairs4 / _with, csrc/em2_dist.hip).
+ * world 2 and 4, all ranks on the one GPU of the test box, the transport table filled by tests/dist_entry_worker.py with
+   host-staged gloo collectives (RCCL refuses two ranks on one device): rows form, symmetric form with either exchange,
+   overflow -> rows form together; every rank checks its contiguous rows against the oracle.
+ * world 1 through REAL RCCL from a C++ program (tests/native/em2_dist_rccl.cpp, built here with hipcc): the RCCL binding
+   (dlsym), ncclAllGather / ncclAllReduce / grouped ncclSend+ncclRecv on one rank, both forms, against
+   em2_dev_find_similar_pairs4 on the same signatures."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_ranks(ranks, cells, L, k, thr, port, extra_env):
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "EM2_BLOCKS_PER_CU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    env.update(extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_entry_worker.py"), str(cells), str(L), str(k), str(thr)]
+    done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
+    lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1
+    result = json.loads(lines[0])
+    assert result["ranks_ok"] == ranks
+    return result
+
+
+def test_rows_form_two_ranks():
+    result = run_ranks(2, 5000, 1024, 20, 0.2, 29641, {"EM2_SHARDED_SCAN": "0"})
+    assert result["form"] == 0 and result["calls"] == {"all_gather": 2, "all_reduce": 0, "all_to_all": 0}
+
+
+@pytest.mark.parametrize("exchange,ranks,cells", [("alltoall", 2, 30000), ("gather", 2, 30000), ("alltoall", 4, 40003), ("alltoall", 3, 20001)])
+def test_symmetric_form(exchange, ranks, cells):
+    result = run_ranks(ranks, cells, 1024, 20, 0.2, 29642 + ranks + (10 if exchange == "gather" else 0),
+                       {"EM2_SHARDED_MIN_CELLS": "1000", "EM2_SHARDED_EXCHANGE": exchange})
+    assert result["form"] == 2
+    routed = exchange == "alltoall" and ranks & (ranks - 1) == 0
+    # per call: signatures + counts (+ the pool when gathered); two snapshot reductions; candidates (routed) + rows + used counts
+    assert result["calls"]["all_reduce"] == 4
+    assert result["calls"]["all_gather"] == (4 if routed else 6)
+    assert result["calls"]["all_to_all"] == (6 if routed else 4)
+    assert result["stages_ms"]["scan"] > 0 and result["stages_ms"]["redistribute"] > 0
+
+
+def test_overflow_sends_all_ranks_to_the_rows_form():
+    result = run_ranks(2, 30000, 1024, 20, 0.2, 29660, {"EM2_SHARDED_MIN_CELLS": "1000", "EM2_INBOX_CAPACITY": "2048"})
+    assert result["form"] == 2 and result["calls"]["all_to_all"] == 0
+
+
+def test_rccl_transport_world_one(tmp_path):
+    source = os.path.join(ROOT, "tests", "native", "em2_dist_rccl.cpp")
+    binary = str(tmp_path / "em2_dist_rccl")
+    build = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-w", "-I", os.path.join(ROOT, "include"), "-o", binary,
+                            source, "-L", os.path.join(ROOT, "expressionmatrix2_amd"), "-lem2lsh", "-lrccl",
+                            "-Wl,-rpath," + os.path.join(ROOT, "expressionmatrix2_amd")], capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-3000:]
+    for env, expect in (({"EM2_SHARDED_SCAN": "0"}, "form 0"), ({"EM2_SHARDED_MIN_CELLS": "1000", "EM2_SHARDED_WORLD_ONE": "1"}, "form 2")):
+        full = dict(os.environ)
+        full.update(env)
+        done = subprocess.run([binary, "20000", "1024", "20"], env=full, capture_output=True, text=True, timeout=600)
+        assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
+        assert "OK" in done.stdout and expect in done.stdout, done.stdout
