@@ -620,6 +620,60 @@ def main():
         del pipe, toc, data, vectors
         torch.cuda.empty_cache()
         result["extra"] = {"configs[1]": small_config(args, capi, sharded, synthetic, oracle, device, torch)}
+    if world > 1:
+        # ---- diagnostics of the multi-GPU step, outside the timed region: wall ms per stage and per collective with a device
+        # synchronisation after each (so the stages do not overlap as they do in the measurement), MAX over the ranks ----
+        pipe.start_timing()
+        for _ in range(2):
+            pipe.step()
+        stages = pipe.stop_timing()
+        names = sorted(stages)
+        t = torch.tensor([stages[n] for n in names], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        result["stages_ms_max_over_ranks"] = {"form": result["config"]["scan"], "backend": dist.get_backend(),
+                                              "note": "diagnostic pass with a synchronisation after every stage; not the measurement",
+                                              **{n: float(v) for n, v in zip(names, t.tolist())}}
+        if pipe.sharded:
+            # ---- second leg: north_star's own partitioning (contiguous row shards, one all_gather, every rank scans its
+            # rows against all columns), timed like the first, so the scaling curve exists for both forms ----
+            saved = os.environ.get("EM2_SHARDED_SCAN")
+            os.environ["EM2_SHARDED_SCAN"] = "0"
+            rows_pipe = sharded.DevicePipeline(C, G, L, k, thr, world_size=world, rank=rank, dist=dist, device=device)
+            if saved is None:
+                os.environ.pop("EM2_SHARDED_SCAN", None)
+            else:
+                os.environ["EM2_SHARDED_SCAN"] = saved
+            rows_pipe.set_inputs(toc, data, vectors)
+            rows_pipe.step()
+            leg_steps = max(1, min(args.steps, 5))
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(leg_steps):
+                rows_pipe.step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            leg = time.perf_counter() - t0
+            rows_pipe.check()
+            leg_check = {"skipped": "--no-check"}
+            if not args.no_check:
+                cells_checked, rows_checked = parity_gate(rows_pipe, oracle, synthetic, sig_host, toc, data, vectors_host, args.check_rows)
+                leg_check = {"signature_cells": cells_checked, "fsp4_rows": rows_checked}
+            t = torch.tensor([leg], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            leg = float(t.item())
+            rows_pipe.start_timing()
+            rows_pipe.step()
+            leg_stages = rows_pipe.stop_timing()
+            names = sorted(leg_stages)
+            t = torch.tensor([leg_stages[n] for n in names], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            result["row_shard_leg"] = {"value": total_pairs * leg_steps / leg, "unit": "pairs/s", "ms_per_step": leg / leg_steps * 1e3,
+                                       "steps": leg_steps, "scan": "row-shards", "parity_check": leg_check,
+                                       "stages_ms_max_over_ranks": {n: float(v) for n, v in zip(names, t.tolist())},
+                                       "note": "the same job with north_star's partitioning: every rank scans its contiguous rows "
+                                               "against all columns (each unordered pair evaluated twice across the node)"}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -112,6 +112,29 @@ class DevicePipeline:
         self.vector_aux = torch.empty(capi.dev_vector_aux_bytes(gene_count, lsh_count), dtype=torch.uint8,
                                       device=device)
         self.scan_events = []
+        self.timing = None          # dict name -> [ms, ...] while bench.py's diagnostic leg runs (synchronises at every mark)
+        self._mark_time = None
+
+    def start_timing(self):
+        """Diagnostics: from now on every stage of step() ends with a device synchronisation and its wall time is appended to
+        self.timing[name] (NOT for measured runs: the stages no longer overlap)."""
+        import time
+        self.timing = {}
+        self.torch.cuda.synchronize()
+        self._mark_time = time.perf_counter()
+
+    def stop_timing(self):
+        timing, self.timing = self.timing, None
+        return {name: sum(values) / len(values) for name, values in (timing or {}).items()}
+
+    def _mark(self, name):
+        if self.timing is None:
+            return
+        import time
+        self.torch.cuda.synchronize()
+        now = time.perf_counter()
+        self.timing.setdefault(name, []).append((now - self._mark_time) * 1e3)
+        self._mark_time = now
 
     def _allocate_row_shard_scan(self):
         torch = self.torch
@@ -137,10 +160,12 @@ class DevicePipeline:
                                         self.vectors.data_ptr(), self.vector_aux.data_ptr(), self.lsh_count,
                                         self.local_sig.data_ptr(), self.proj_ws.data_ptr(), self.proj_ws_bytes,
                                         stream)
+        self._mark("projection")
 
     def exchange(self):
         if self.world_size > 1:
             self.dist.all_gather_into_tensor(self.full_sig, self.local_sig)
+        self._mark("all_gather_signatures")
 
     def scan(self, record_events=False):
         torch = self.torch
@@ -149,17 +174,11 @@ class DevicePipeline:
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
         if self.sharded:
-            # A pool overflow (reported by the scan itself, agreed between the ranks) or an exception raised on this
-            # rank before any rank could be left waiting in a collective (argument / view / dtype errors are raised
-            # on every rank alike) sends all ranks to row shards together, for this and all later steps.
-            try:
-                ok = self._scan_sharded()
-            except (RuntimeError, TypeError, ValueError) as error:
-                import sys
-                print("[em2] sharded symmetric scan failed on rank %d (%s); using row shards" % (self.rank, error),
-                      file=sys.stderr)
-                ok = False
-            if not ok:
+            # A pool overflow, a hand-off time-out or an exception in one of this rank's first three phases is folded into
+            # the flag the ranks reduce before the exchange (_scan_sharded keeps issuing the collectives until then), so all
+            # ranks leave the sharded form TOGETHER, for this and all later steps.  An exception after that agreement is not
+            # caught: the process ends, and the launcher ends the job (a rank that skipped collectives must not go on).
+            if not self._scan_sharded():
                 self.sharded = None
                 self._allocate_row_shard_scan()
         if not self.sharded and self.rows:
@@ -167,6 +186,7 @@ class DevicePipeline:
             capi.dev_find_similar_pairs4(self.full_sig.data_ptr(), self.cell_count, self.row_begin, self.row_end,
                                          self.lsh_count, self.k, self.thr, self.pairs.data_ptr(),
                                          self.used.data_ptr(), self.scan_ws.data_ptr(), self.scan_ws_bytes, stream)
+        self._mark("scan_rows" if not self.sharded else "scan_tail")
         if record_events:
             e1.record()
             self.scan_events.append((e0, e1))
@@ -182,32 +202,57 @@ class DevicePipeline:
                                         self.rank, world, self.global_pairs.data_ptr(), self.global_used.data_ptr(),
                                         self.shard_ws.data_ptr(), plan["workspace_bytes"], gathered_count, stream)
 
-        phase(0)
+        broken = None
+
+        def guarded(number):
+            nonlocal broken
+            if broken is None:
+                try:
+                    phase(number)
+                except (RuntimeError, TypeError, ValueError) as error:
+                    broken = error
+
+        guarded(0)
+        self._mark("phase0_prefix_full_rows")
         dist.all_reduce(self.snap, op=dist.ReduceOp.MAX)
-        phase(1)
+        self._mark("all_reduce_snapshots")
+        guarded(1)
+        self._mark("phase1_prefix_columns")
         dist.all_reduce(self.snap, op=dist.ReduceOp.MAX)
-        phase(2)
-        try:
-            used, overflow = capi.dev_fsp4_sharded_status(self.cell_count, self.k, self.rank, world,
-                                                          self.shard_ws.data_ptr(), stream)
-        except RuntimeError as error:            # a hand-off timed out: keep the collectives in step, report in check()
-            self.scan_error = error
-            used, overflow = 0, 1
+        self._mark("all_reduce_snapshots")
+        guarded(2)
+        used, overflow = 0, 1
+        if broken is None:
+            try:
+                used, overflow = capi.dev_fsp4_sharded_status(self.cell_count, self.k, self.rank, world,
+                                                              self.shard_ws.data_ptr(), stream)
+            except RuntimeError as error:            # a hand-off timed out: keep the collectives in step, report in check()
+                self.scan_error = error
+        else:
+            import sys
+            print("[em2] sharded symmetric scan failed on rank %d (%s); all ranks use row shards" % (self.rank, broken),
+                  file=sys.stderr)
+        self._mark("phase2_tiles")
         self.count_buf[0] = used
         self.count_buf[1] = overflow
         dist.all_reduce(self.count_buf, op=dist.ReduceOp.MAX)
-        max_used, any_overflow = (int(x) for x in self.count_buf.tolist())
+        max_used, any_overflow = (int(x) for x in self.count_buf.cpu())         # the one agreement point of the step
+        self._mark("agree_counts")
         if any_overflow:
             return False
         if self.exchange_all_to_all:
             received = self._exchange_all_to_all(used, phase)
+            self._mark("exchange_candidates")
             phase(3, received)
+            self._mark("phase3_sort_replay")
             return True
         if max_used:
             if used < max_used:
                 self.pool[used:max_used].fill_(-1)           # ~0: sentinels sort behind every real entry
             dist.all_gather_into_tensor(self.gathered[:world * max_used], self.pool[:max_used])
+        self._mark("exchange_candidates")
         phase(3, world * max_used)
+        self._mark("phase3_sort_replay")
         return True
 
     def _exchange_all_to_all(self, used, phase):
@@ -219,11 +264,13 @@ class DevicePipeline:
         owners = (send >> plan["owner_shift"]) & (world - 1)
         send_counts = torch.bincount(owners, minlength=world) if used else torch.zeros(world, dtype=torch.int64, device=send.device)
         staged = dist.get_backend() != "nccl"               # gloo has no all_to_all on device tensors: go through the host
+        # every rank's counts to every rank in ONE collective and ONE read-back (row r = what rank r sends to each rank)
         counts_in = send_counts.cpu() if staged else send_counts
-        counts_out = torch.empty_like(counts_in)
-        dist.all_to_all_single(counts_out, counts_in)
-        send_list = [int(x) for x in send_counts.tolist()]
-        recv_list = [int(x) for x in counts_out.tolist()]
+        matrix = torch.empty(world * world, dtype=torch.int64, device=counts_in.device)
+        dist.all_gather_into_tensor(matrix, counts_in)
+        matrix = matrix.cpu().view(world, world)
+        send_list = [int(x) for x in matrix[self.rank]]
+        recv_list = [int(x) for x in matrix[:, self.rank]]
         received = sum(recv_list)
         if received > plan["gathered_capacity"]:
             raise RuntimeError("sharded scan: received more entries than the exchange area holds")
