@@ -60,6 +60,7 @@ struct CachedTables {
 };
 std::mutex cacheMutex;
 std::vector<CachedTables> tableCache;
+constexpr size_t kTableCacheEntries = 16;
 
 int getDeviceTables(uint32_t lshCount, double similarityThreshold, em2::DeviceTables& out)
 {
@@ -68,8 +69,12 @@ int getDeviceTables(uint32_t lshCount, double similarityThreshold, em2::DeviceTa
     uint64_t bits;
     std::memcpy(&bits, &similarityThreshold, sizeof(bits));
     std::lock_guard<std::mutex> lock(cacheMutex);
-    for (const CachedTables& c : tableCache) {
+    for (size_t i = 0; i < tableCache.size(); i++) {
+        const CachedTables c = tableCache[i];
         if (c.device == device && c.lshCount == lshCount && c.thresholdBits == bits) {
+            // most recently used last
+            tableCache.erase(tableCache.begin() + long(i));
+            tableCache.push_back(c);
             out = c.tables;
             return EM2_OK;
         }
@@ -102,6 +107,19 @@ int getDeviceTables(uint32_t lshCount, double similarityThreshold, em2::DeviceTa
     c.tables.mGlobal = host.mGlobal;
     c.tables.mMaxInitial = host.mMaxInitial;
     c.tables.identityKeys = host.keySimilarity.size() == host.keyOfMismatch.size();
+    // At most kTableCacheEntries sets of tables per device stay allocated (a caller that sweeps thresholds would otherwise
+    // grow the cache without bound): the least recently used one goes.  Its kernels have long been enqueued -- hipFree
+    // waits for the device -- and tables are copied by value into every launch's arguments.
+    size_t onThisDevice = 0;
+    for (const CachedTables& other : tableCache) onThisDevice += other.device == device ? 1u : 0u;
+    if (onThisDevice >= kTableCacheEntries) {
+        for (size_t i = 0; i < tableCache.size(); i++) {
+            if (tableCache[i].device != device) continue;
+            (void)hipFree(const_cast<uint32_t*>(tableCache[i].tables.keyOfMismatch));       // the block's base pointer
+            tableCache.erase(tableCache.begin() + long(i));
+            break;
+        }
+    }
     tableCache.push_back(c);
     out = c.tables;
     return EM2_OK;

@@ -250,15 +250,14 @@ filterCooperativeKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32
 }
 
 // One wave per cell: keepBest(cellNeighbors, k) (:457), then SimilarPairs::copy + sort (:489-496), store.
-// CAPACITY entries are staged in LDS (12 bytes each).  The kernel is launched twice per batch: CAPACITY 4096 (48 KB,
-// 3 waves per CU) takes the cells with up to 4096 candidates, CAPACITY 12288 (144 KB, one wave per CU) the longer
-// lists; only lists beyond that are cut by a single lane in HBM (at 1M cells x 2048 bits, q = 20, a few per cent of
-// the cells have more than 4096 candidates, and cutting those in HBM took half of the whole run).
+// CAPACITY entries are staged in LDS (12 bytes each).  The kernel is launched once per tier and batch and takes the
+// cells with ABOVE < candidates <= min(CAPACITY, upTo): the smaller the tier, the more waves a CU holds (see the launch
+// site).  (Without upTo the largest tier also cuts longer lists, by a single lane in HBM: round 1's form, kept for A/B.)
 template <uint32_t CAPACITY, uint32_t ABOVE>
 __global__ void __launch_bounds__(64)
 selectKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegin, Entry* __restrict__ lists,
              const uint32_t* __restrict__ listCounts, const float* __restrict__ keySimilarity, uint32_t k,
-             PairOut* __restrict__ outPairs, uint32_t* __restrict__ outUsed)
+             PairOut* __restrict__ outPairs, uint32_t* __restrict__ outUsed, uint32_t upTo = 0xffffffffu)
 {
     __shared__ Entry lds[CAPACITY];
     __shared__ uint16_t ldsL[CAPACITY];
@@ -270,6 +269,7 @@ selectKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegin, Ent
     uint32_t n = listCounts[local];
     if (n <= ABOVE && ABOVE != 0u) return;              // the other launch's cells
     if (ABOVE == 0u && n > CAPACITY) return;
+    if (n > upTo) return;                               // selectGlobalKernel's cells
 
     Entry* work = list;
     const bool inLds = n <= CAPACITY;
@@ -305,6 +305,51 @@ selectKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegin, Ent
                 o.cell = uint32_t(v);
                 o.key = uint32_t(v >> 32);
             }
+            rank += uint32_t((o.key < e.key) || (o.key == e.key && o.cell < e.cell));
+        }
+        PairOut po;
+        po.cell = e.cell;
+        po.similarity = keySimilarity[e.key];
+        out[rank] = po;
+    }
+    for (uint32_t i = n + lane; i < k; i += 64u) {
+        PairOut zero;
+        zero.cell = 0u;
+        zero.similarity = 0.0f;
+        out[i] = zero;
+    }
+    if (lane == 0u) outUsed[local] = n;
+}
+
+// The same for lists of any length, left where the filter wrote them: one wave per cell runs the wave-parallel selection
+// (em2_select_wave.h) on global memory; its two position arrays are the cell's segments of the candidate arrays, which the
+// filter has finished with.  Takes the cells with
+// more than `above` candidates.  The lists of a batch are L2-resident between the filter and this kernel, and unlike the
+// LDS forms this one keeps every wave slot of a CU busy.
+__global__ void __launch_bounds__(256)
+selectGlobalKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegin, Entry* __restrict__ lists,
+                   const uint32_t* __restrict__ listCounts, const float* __restrict__ keySimilarity, uint32_t k, uint32_t above,
+                   uint32_t* __restrict__ positionsL, uint32_t* __restrict__ positionsR, PairOut* __restrict__ outPairs,
+                   uint32_t* __restrict__ outUsed)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t local = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (local >= batchCells) return;
+    uint32_t n = listCounts[local];
+    if (n <= above) return;
+    const uint32_t begin = segmentBegin[local];
+    Entry* work = lists + begin;
+    if (n > k) {
+        waveSyncGlobal();           // the filter's stores came from another kernel; start from clean lines all the same
+        nthElementWaveT<uint32_t, true>(work, positionsL + begin, positionsR + begin, int(k), int(n), lane);
+        n = k;
+    }
+    PairOut* out = outPairs + size_t(local) * k;
+    for (uint32_t i = lane; i < n; i += 64u) {
+        const Entry e = work[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            const Entry o = work[j];
             rank += uint32_t((o.key < e.key) || (o.key == e.key && o.cell < e.cell));
         }
         PairOut po;
@@ -507,17 +552,38 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
         }
         EM2_TRY(hipGetLastError());
         if (timing[0]) (void)hipEventRecord(timing[1], stream);
-        selectKernel<kSelectLdsEntries, 0u><<<batchCells, 64, 0, stream>>>(batchCells, segBegin.as<uint32_t>(), lists.as<Entry>(),
-                                                                           listCounts.as<uint32_t>(), tables.keySimilarity, k,
-                                                                           d_pairs + size_t(batchBegin - rowBegin) * k,
-                                                                           d_used + (batchBegin - rowBegin));
-        EM2_TRY(hipGetLastError());
-        selectKernel<kSelectLdsEntriesBig, kSelectLdsEntries><<<batchCells, 64, 0, stream>>>(batchCells, segBegin.as<uint32_t>(),
-                                                                                             lists.as<Entry>(), listCounts.as<uint32_t>(),
-                                                                                             tables.keySimilarity, k,
-                                                                                             d_pairs + size_t(batchBegin - rowBegin) * k,
-                                                                                             d_used + (batchBegin - rowBegin));
-        EM2_TRY(hipGetLastError());
+        // keepBest + sort + store, by list length: LDS tiers of 4096 / 5120 / 6656 / 12288 entries (12 bytes each: 3, 2, 2
+        // and 1 wave per CU), beyond that the same wave-parallel selection on global memory.  EM2_FSP5_SELECT (A/B
+        // measurements): "lds" = round 1's form (4096 and 12288, longer lists by a single lane in HBM), "global" =
+        // everything above 4096 in global memory (3.8x slower than the LDS tiers on config D: its fences are agent-scope).
+        const char* selectMode = getenv("EM2_FSP5_SELECT");
+        const char mode = selectMode ? selectMode[0] : 't';
+        PairOut* outPairs = d_pairs + size_t(batchBegin - rowBegin) * k;
+        uint32_t* outUsed = d_used + (batchBegin - rowBegin);
+#define EM2_SELECT_TIER(CAPACITY, ABOVE, UP_TO)                                                                                  \
+        selectKernel<CAPACITY, ABOVE><<<batchCells, 64, 0, stream>>>(batchCells, segBegin.as<uint32_t>(), lists.as<Entry>(),    \
+                                                                    listCounts.as<uint32_t>(), tables.keySimilarity, k, outPairs, \
+                                                                    outUsed, UP_TO);                                             \
+        EM2_TRY(hipGetLastError())
+        uint32_t globalAbove = kSelectLdsEntriesBig;
+        EM2_SELECT_TIER(kSelectLdsEntries, 0u, 0xffffffffu);
+        if (mode == 'l') {
+            EM2_SELECT_TIER(kSelectLdsEntriesBig, kSelectLdsEntries, 0xffffffffu);
+            globalAbove = 0xffffffffu;
+        } else if (mode == 'g') {
+            globalAbove = kSelectLdsEntries;
+        } else {
+            EM2_SELECT_TIER(5120u, kSelectLdsEntries, 5120u);
+            EM2_SELECT_TIER(6656u, 5120u, 6656u);
+            EM2_SELECT_TIER(kSelectLdsEntriesBig, 6656u, kSelectLdsEntriesBig);
+        }
+#undef EM2_SELECT_TIER
+        if (globalAbove != 0xffffffffu) {
+            selectGlobalKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(
+                batchCells, segBegin.as<uint32_t>(), lists.as<Entry>(), listCounts.as<uint32_t>(), tables.keySimilarity, k, globalAbove,
+                candA.as<uint32_t>(), candB.as<uint32_t>(), outPairs, outUsed);
+            EM2_TRY(hipGetLastError());
+        }
         if (timing[0]) (void)hipEventRecord(timing[2], stream);
         EM2_TRY(hipStreamSynchronize(stream));       // the batch's offsets (pageable host memory) and scratch are reused
         if (timing[0]) {

@@ -24,13 +24,31 @@ __device__ __forceinline__ void waveSync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// The same for arrays in global memory: what one lane stored must be what another lane of the wave loads next, and a
+// lane's loads may not come from a line its L1 fetched before that store -- the agent-scope fence writes back and
+// invalidates.
+__device__ __forceinline__ void waveSyncGlobal()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool GLOBAL>
+__device__ __forceinline__ void waveSyncFor()
+{
+    if (GLOBAL) waveSyncGlobal();
+    else waveSync();
+}
+
 __device__ __forceinline__ uint32_t lanesBelow(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
 
-// __unguarded_partition(a+lo, a+hi, pivot = a[lo-1]); returns the cut (wave-uniform).
-__device__ inline int partitionWave(Entry* a, int lo, int hi, uint16_t* Lpos, uint16_t* Rpos, uint32_t lane)
+// __unguarded_partition(a+lo, a+hi, pivot = a[lo-1]); returns the cut (wave-uniform).  Index: uint16_t positions for lists
+// staged in LDS, uint32_t with GLOBAL for lists of any length left in global memory.
+template <class Index, bool GLOBAL>
+__device__ inline int partitionWaveT(Entry* a, int lo, int hi, Index* Lpos, Index* Rpos, uint32_t lane)
 {
     const uint32_t pk = a[lo - 1].key;
     int nL = 0, nR = 0;
@@ -42,12 +60,12 @@ __device__ inline int partitionWave(Entry* a, int lo, int hi, uint16_t* Lpos, ui
         const bool isR = valid && key <= pk;
         const uint64_t mL = __builtin_amdgcn_ballot_w64(isL);
         const uint64_t mR = __builtin_amdgcn_ballot_w64(isR);
-        if (isL) Lpos[nL + int(lanesBelow(mL))] = uint16_t(x);
-        if (isR) Rpos[nR + int(lanesBelow(mR))] = uint16_t(x);
+        if (isL) Lpos[nL + int(lanesBelow(mL))] = Index(x);
+        if (isR) Rpos[nR + int(lanesBelow(mR))] = Index(x);
         nL += __builtin_popcountll(mL);
         nR += __builtin_popcountll(mR);
     }
-    waveSync();
+    waveSyncFor<GLOBAL>();
     int T = 0;
     for (int base = 0; base < nL; base += 64) {
         const int t = base + int(lane);
@@ -55,7 +73,7 @@ __device__ inline int partitionWave(Entry* a, int lo, int hi, uint16_t* Lpos, ui
         int x = 0, y = 0;
         bool c = false;
         if (valid) {
-            x = Lpos[t];
+            x = int(Lpos[t]);
             y = t < nR ? int(Rpos[nR - 1 - t]) : lo - 1;
             c = x < y;
         }
@@ -65,7 +83,7 @@ __device__ inline int partitionWave(Entry* a, int lo, int hi, uint16_t* Lpos, ui
             ex = a[x];
             ey = a[y];
         }
-        waveSync();
+        waveSyncFor<GLOBAL>();
         if (c) {
             a[x] = ey;
             a[y] = ex;
@@ -74,15 +92,22 @@ __device__ inline int partitionWave(Entry* a, int lo, int hi, uint16_t* Lpos, ui
         T += __builtin_popcountll(mc);
         if (mc != __builtin_amdgcn_ballot_w64(valid)) break;
     }
-    waveSync();
+    waveSyncFor<GLOBAL>();
     int cut;
-    if (T < nL && (T == 0 || int(Lpos[T]) < int(Rpos[nR - T]))) cut = Lpos[T];
-    else cut = Rpos[nR - T];
+    if (T < nL && (T == 0 || int(Lpos[T]) < int(Rpos[nR - T]))) cut = int(Lpos[T]);
+    else cut = int(Rpos[nR - T]);
     return __builtin_amdgcn_readfirstlane(cut);
 }
 
-// std::nth_element(a, a+nth, a+n, cmp) by one wave; a, Lpos, Rpos in LDS (Lpos/Rpos: n uint16 each, n <= 65535).
-__device__ inline void nthElementWave(Entry* a, uint16_t* Lpos, uint16_t* Rpos, int nth, int n, uint32_t lane)
+__device__ inline int partitionWave(Entry* a, int lo, int hi, uint16_t* Lpos, uint16_t* Rpos, uint32_t lane)
+{
+    return partitionWaveT<uint16_t, false>(a, lo, hi, Lpos, Rpos, lane);
+}
+
+// std::nth_element(a, a+nth, a+n, cmp) by one wave; a, Lpos, Rpos in LDS (Lpos/Rpos: n uint16 each, n <= 65535), or all
+// three in global memory (GLOBAL, Index = uint32_t).
+template <class Index, bool GLOBAL>
+__device__ inline void nthElementWaveT(Entry* a, Index* Lpos, Index* Rpos, int nth, int n, uint32_t lane)
 {
     if (n == 0 || nth == n) return;
     int first = 0, last = n;
@@ -93,18 +118,23 @@ __device__ inline void nthElementWave(Entry* a, uint16_t* Lpos, uint16_t* Rpos, 
                 heapSelect(a, first, nth + 1, last);
                 entrySwap(a, first, nth);
             }
-            waveSync();
+            waveSyncFor<GLOBAL>();
             return;
         }
         --depthLimit;
         if (lane == 0u) medianToFirst(a, first, first + 1, first + (last - first) / 2, last - 1);
-        waveSync();
-        const int cut = partitionWave(a, first + 1, last, Lpos, Rpos, lane);
+        waveSyncFor<GLOBAL>();
+        const int cut = partitionWaveT<Index, GLOBAL>(a, first + 1, last, Lpos, Rpos, lane);
         if (cut <= nth) first = cut;
         else last = cut;
     }
     if (lane == 0u) insertionSort(a, first, last);
-    waveSync();
+    waveSyncFor<GLOBAL>();
+}
+
+__device__ inline void nthElementWave(Entry* a, uint16_t* Lpos, uint16_t* Rpos, int nth, int n, uint32_t lane)
+{
+    nthElementWaveT<uint16_t, false>(a, Lpos, Rpos, nth, n, lane);
 }
 
 }  // namespace em2

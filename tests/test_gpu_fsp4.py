@@ -411,3 +411,14 @@ def test_sharded_tile_walk_repeats_bit_identically(scan_knobs):
         assert np.array_equal(reference[1], again[1]), attempt
         assert np.array_equal(reference[0]["cell"], again[0]["cell"]), attempt
         assert np.array_equal(reference[0]["similarity"].view(np.uint32), again[0]["similarity"].view(np.uint32)), attempt
+
+
+def test_threshold_sweep_evicts_cached_tables(oracle):
+    """The per-device cache of lookup tables keeps 16 (lshCount, threshold) sets; a sweep over more thresholds frees the least
+    recently used ones, and coming back to an evicted threshold rebuilds it."""
+    sig = make(400, 128, "clustered")
+    thresholds = [round(-0.9 + 0.09 * i, 3) for i in range(20)] + [-0.9, 0.0]
+    for thr in thresholds:
+        cell, sim, used = oracle.find_similar_pairs4(sig, 128, 5, thr)
+        pairs, gused = capi.find_similar_pairs4(sig, 128, 5, thr)
+        assert_same(pairs, gused, cell, sim, used)

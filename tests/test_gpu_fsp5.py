@@ -133,3 +133,26 @@ def test_fsp5_last_launch_reports_what_the_filter_read(oracle):
         size = counts[inverse]
         expected += int(size[size <= ovf].sum())
     assert info["gathered_candidates"] == expected
+
+
+@pytest.mark.parametrize("mode", ["tiers", "global", "lds"])
+def test_fsp5_long_lists_all_selection_tiers(oracle, mode, monkeypatch):
+    """Lists of 4097.., 12289.. candidates with few distinct keys (ties decide who survives keepBest) and with many: the
+    wave-parallel selection in global memory (default), the 144 KB LDS tier + global memory, and round 1's LDS tier + one
+    lane in HBM must all reproduce libstdc++'s nth_element."""
+    monkeypatch.setenv("EM2_FSP5_SELECT", mode)
+    rng = np.random.default_rng(17)
+    for cells, L, k, flips in ((5000, 64, 7, 3), (13000, 128, 25, 10), (7000, 256, 100, 40)):
+        base = synth.random_signatures(1, L, seed=cells)
+        sig = np.tile(base, (cells, 1))
+        # flip up to `flips` random bits per cell outside the first slice: one bucket holds everybody, keys vary
+        for c in range(cells):
+            for bit in rng.integers(16, L, rng.integers(0, flips + 1)):
+                sig[c, bit // 64] ^= np.uint64(1) << np.uint64(63 - bit % 64)
+        rows = (0, 40)
+        cell, sim, oused = oracle.find_similar_pairs5_rows(sig, L, k, 0.2, 16, 0, *rows)
+        pairs, gused = capi.find_similar_pairs5(sig, L, k, 0.2, 16, 0)
+        assert np.array_equal(gused[:40], oused) and np.array_equal(pairs["cell"][:40], cell)
+        assert np.array_equal(pairs["similarity"][:40].view(np.uint32), sim.view(np.uint32))
+        cell, sim, oused = oracle.find_similar_pairs5_rows(sig, L, k, 0.2, 16, 0, cells - 30, cells)
+        assert np.array_equal(gused[-30:], oused) and np.array_equal(pairs["cell"][-30:], cell)
