@@ -764,9 +764,7 @@ __device__ __forceinline__ P ldsPointer(uint32_t address)
 constexpr uint32_t kWalkRowDot = 0u;            // float[64]: bound of row r as a dot product (1024 - 2 mMax), read by the steps
 constexpr uint32_t kWalkBounds = 256u;          // float[4][32]: column bounds of the four tile buffers (as dot products)
 constexpr uint32_t kWalkSnapStage = 768u;       // int32[2][64]: the published cut-offs of a pair of tiles, as loaded
-constexpr uint32_t kWalkQueue = 1280u;          // uint32[64][4]: the lanes' event records of the tile under test
-constexpr uint32_t kMatrixWalkLdsBytes = 2304u;
-constexpr uint32_t kWalkQueueSlots = 4u;
+constexpr uint32_t kMatrixWalkLdsBytes = 1280u;
 
 __device__ __forceinline__ uint32_t uniform(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
 
@@ -785,223 +783,45 @@ __device__ __forceinline__ uint32_t laneId()
     return lane;
 }
 
-// Result `index` of the accumulators: 0..15 / 16..31 = set X rows 0..31 / 32..63, 32..63 = set Y likewise (v64 + index).
-__device__ __forceinline__ float readAccumulator(uint32_t index)
-{
-    float value;
-    // (gfx950 has no v_movrels: VGPR index mode, source 0 relative)
-    asm volatile("s_set_gpr_idx_on %1, 0x1\n\ts_nop 1\n\tv_mov_b32 %0, v64\n\ts_set_gpr_idx_off" : "=v"(value) : "s"(index) : "m0");
-    return value;
-}
-
-// What the events of a walk need, all wave-uniform (scalar registers).
-struct MatrixWalkUniform {
-    uint64_t validRows;             // bit r = row r of the wave is a cell of the problem (and takes part)
-    uint32_t rowBase;               // cell id of the wave's row 0
-    GlobalWord64Ptr logBase;        // the wave's 64 logs, logCapacity entries each
-    uint32_t logCapacity;
-    GlobalWord64Ptr inbox;
-    uint32_t rowBits;
-    uint32_t emitPos, emitEnd;
-    ArgsPtr aux;                    // for the out-of-line refill of the inbox chunk
-    uint32_t diag;                  // EM2_MATRIX_DIAG (measurements only, results are wrong): 1 no events, 4 no row side, 8 no column side, 16 no tiles, 32 no tests, 64 no barrier, 512 events one by one
+// A record of the walk: the step's stub wrote {first column of the tile | 2i + a, dot} into the log of the LANE in which
+// register i of accumulator a passed its test (em2_matrix_step_asm.h).  Lane s = 32 h + t holds rows t and 32 + t of the
+// wave and the columns 8q + 4h + j of a tile (i = 4q + j): its records ascend in the column.
+struct WalkRecord {
+    uint32_t code;                  // tile's first column (a multiple of 32) | 2i + a
+    float dot;                      // 1024 - 2 * mismatches
 };
-
-// The events of the tile whose results sit in accumulator set X (IN_Y false) or Y.  registerMask: bit 31 - (2i + a) =
-// register i of accumulator a passed its test in some lane.  Lane l, register i = 4q + j of accumulator a = row
-// 32a + (l & 31), column 8q + 4 (l >> 5) + j of the tile.  One compact copy of the code (run-time loops, the result
-// fetched by v_movrels): what is executed is proportional to the events, and it stays in the instruction cache.
-// A row's log must list its columns in ascending order (the replay offers them in that order): within a group q the
-// lower lane half holds columns 8q .. 8q+3 and the upper half 8q+4 .. 8q+7, so a group's set bits are visited twice
-// when a row of the upper half has an event -- first the lower half's rows (and the column side of all), then the
-// upper half's.
-template <bool BOTH, bool IN_Y>
-__device__ __forceinline__ void matrixEvents(uint32_t registerMask, uint32_t tileBase, uint32_t boundLds, const float (&rowDot)[2],
-                                             uint32_t (&logCount)[2], MatrixWalkUniform& u)
+__device__ __forceinline__ uint32_t walkRecordColumn(uint32_t code, uint32_t half)
 {
-    const uint32_t lane = laneId(), half = lane >> 5, lane31 = lane & 31u;
-
-    // emitColumn: pool pointer and key layout in registers, the out-of-line refill through the explicit kernarg pointer
-    auto emit = [&](bool on, uint32_t target, uint32_t candidate, uint32_t m) {
-        const uint64_t mask = __builtin_amdgcn_ballot_w64(on);
-        if (mask == 0ull) return;
-        uint32_t p = u.emitPos, e = u.emitEnd;
-        if (p > e) return;                                                      // disabled after an overflow
-        const uint32_t n = uint32_t(__builtin_popcountll(mask));
-        if (p + n > e) {
-            const uint64_t fresh = refillInboxChunk(u.aux->inbox, u.aux->inboxControl, u.aux->inboxCapacity, u.aux->inboxChunk, lane, p, e);
-            p = uniform(uint32_t(fresh));
-            e = uniform(uint32_t(fresh >> 32));
-            u.emitPos = p;
-            u.emitEnd = e;
-            if (p > e) return;
-        }
-        if (on) u.inbox[p + lanesBelow(mask)] = (uint64_t(target) << (13u + u.rowBits)) | (uint64_t(candidate) << 13u) | uint64_t(m);
-        u.emitPos = p + n;
-    };
-
-#pragma nounroll
-    for (uint32_t q = 0; q < 4u; q++) {
-        const uint32_t bits = (registerMask >> (24u - 8u * q)) & 0xffu;      // bit 7 - (2j + a): register 4q + j of accumulator a
-        if (bits == 0u) continue;
-        typedef float Float4 __attribute__((ext_vector_type(4)));
-        const Float4 groupBounds = *ldsPointer<const __attribute__((address_space(3))) Float4*>(boundLds + (8u * q + 4u * half) * 4u);
-        bool upperRows = false;
-#pragma nounroll
-        for (uint32_t pass = 0; pass < 2u; pass++) {
-            uint32_t rest = bits;
-#pragma nounroll
-            while (rest != 0u) {
-                const uint32_t e = uint32_t(__builtin_clz(rest)) - 24u;         // 2j + a, ascending
-                rest &= ~(0x80u >> e);
-                const uint32_t j = e >> 1, a = e & 1u;
-                float dot;
-                if (u.diag & 256u) {
-                    float d0, d1;
-                    if (IN_Y) { EM2_MATRIX_READ_Y(4u * q + j, d0, d1); }
-                    else { EM2_MATRIX_READ_X(4u * q + j, d0, d1); }
-                    dot = a ? d1 : d0;
-                } else {
-                    dot = readAccumulator((IN_Y ? 32u : 0u) + 16u * a + 4u * q + j);
-                }
-                const bool passRow = dot >= (a ? rowDot[1] : rowDot[0]);
-                const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
-                const uint32_t col = tileBase + 8u * q + 4u * half + j;
-                if (pass == 0u) {
-                    const float columnDot = (u.diag & 128u) ? (j == 0u ? groupBounds.x : j == 1u ? groupBounds.y : j == 2u ? groupBounds.z : groupBounds.w)
-                                                            : ldsPointer<LdsFloatPtr>(boundLds)[8u * q + 4u * half + j];
-                    const bool rowValid = ((uint32_t(u.validRows >> (32u * a)) >> lane31) & 1u) != 0u;
-                    const bool passColumn = rowValid && dot >= columnDot;
-                    const uint32_t rowId = u.rowBase + 32u * a + lane31;
-                    if (!(u.diag & 8u)) {
-                        emit(passColumn, col, rowId, m);
-                        if (BOTH) emit(rowValid && passRow, rowId, col, m);
-                    }
-                }
-                if (BOTH || (u.diag & 4u)) continue;
-                const uint64_t rows = __builtin_amdgcn_ballot_w64(passRow);
-                const uint32_t mine = pass == 0u ? uint32_t(rows) : uint32_t(rows >> 32);     // rows (by l & 31) with an event in this pass' half
-                if (pass == 0u && uint32_t(rows >> 32) != 0u) upperRows = true;
-                if (mine == 0u) continue;
-                const uint32_t count = a ? logCount[1] : logCount[0];
-                if (half == pass && passRow) {
-                    u.logBase[size_t(32u * a + lane31) * u.logCapacity + count] = uint64_t(col) | (uint64_t(m) << 32);      // storeEntry
-                }
-                const uint32_t increment = (mine >> lane31) & 1u;       // both lanes that hold the row count it
-                if (a) logCount[1] += increment;
-                else logCount[0] += increment;
-            }
-            if (!upperRows) break;
-        }
-    }
+    const uint32_t i = (code & 31u) >> 1;
+    return (code & ~31u) + 8u * (i >> 2) + 4u * half + (i & 3u);
 }
-
-// The events of a tile, lane-parallel.  The step left every lane a queue of up to four records
-// (2i + a + 1) << 16 | (dot + 1024), one per register i = 4q + j of accumulator a that passed its test in that lane,
-// in ascending i; `count` = records per lane (more than four: the queue overflowed, the caller takes matrixEvents with
-// every register flagged instead).  First the column side of every record goes to the inbox (order is irrelevant
-// there: the inbox is sorted).  Then the row side, accumulator by accumulator: lanes l and l ^ 32 hold the same row
-// 32a + (l & 31) and different columns of it, each lane's records ascend in the column, and a row's log must ascend
-// too -- so every round the two lanes swap the column of their next record for that row and the smaller one is
-// appended (a two-way merge; both lanes count the appends of both).  Straight-line vector code: what the scalar,
-// one-event-at-a-time form spends per event this spends per round, and a tile rarely needs a second round.
-template <bool BOTH>
-__device__ __forceinline__ void matrixEventsQueued(uint32_t count, uint32_t tileBase, uint32_t boundLds, uint32_t queueLds,
-                                                   const float (&rowDot)[2], uint32_t (&logCount)[2], MatrixWalkUniform& u)
+// (the records of a lane are written by that lane and read by others: past the L1, like the row lists)
+__device__ __forceinline__ WalkRecord loadWalkRecord(const Entry* log, uint32_t index)
 {
-    typedef uint32_t Word4 __attribute__((ext_vector_type(4)));
-    const uint32_t lane = laneId(), half = lane >> 5, lane31 = lane & 31u;
-    const Word4 queue = *ldsPointer<const __attribute__((address_space(3))) Word4*>(queueLds + lane * (kWalkQueueSlots * 4u));
-    const LdsFloatPtr bounds = ldsPointer<LdsFloatPtr>(boundLds);
-    const bool valid0 = ((uint32_t(u.validRows) >> lane31) & 1u) != 0u, valid1 = ((uint32_t(u.validRows >> 32) >> lane31) & 1u) != 0u;
-    uint32_t rowEvents[2] = {0u, 0u};            // per accumulator: bit s = record s has an event for this lane's row of it
-    uint32_t columns[kWalkQueueSlots], mismatches[kWalkQueueSlots];
-#pragma unroll
-    for (uint32_t slot = 0; slot < kWalkQueueSlots; slot++) {
-        columns[slot] = mismatches[slot] = 0u;
-        const bool have = slot < count;
-        if (__builtin_amdgcn_ballot_w64(have) == 0ull) continue;
-        const uint32_t record = have ? queue[slot] : 0x10000u;
-        const uint32_t code = (record >> 16) - 1u, i = code >> 1, a = code & 1u;
-        const float dot = float(int32_t(record & 0xffffu) - 1024);
-        const uint32_t columnIndex = 8u * (i >> 2) + 4u * half + (i & 3u);       // in the tile
-        const float columnDot = bounds[columnIndex];
-        const uint32_t col = tileBase + columnIndex;
-        const uint32_t rowId = u.rowBase + 32u * a + lane31;
-        const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
-        const bool rowValid = a ? valid1 : valid0;
-        const bool passRow = have && dot >= (a ? rowDot[1] : rowDot[0]);
-        const bool passColumn = have && rowValid && dot >= columnDot;
-        columns[slot] = columnIndex;
-        mismatches[slot] = m;
-        if (passRow) {
-            if (a) rowEvents[1] |= 1u << slot;
-            else rowEvents[0] |= 1u << slot;
-        }
-        if (u.diag & 8u) continue;
-        // emitColumn, twice in the BOTH form: pool pointer and key layout in registers, the refill through the kernarg pointer
-#pragma unroll
-        for (int side = 0; side < (BOTH ? 2 : 1); side++) {
-            const bool on = side == 0 ? passColumn : (passRow && rowValid);
-            const uint64_t mask = __builtin_amdgcn_ballot_w64(on);
-            if (mask == 0ull || u.emitPos > u.emitEnd) continue;
-            const uint32_t n = uint32_t(__builtin_popcountll(mask));
-            if (u.emitPos + n > u.emitEnd) {
-                const uint64_t fresh = refillInboxChunk(u.aux->inbox, u.aux->inboxControl, u.aux->inboxCapacity, u.aux->inboxChunk, lane,
-                                                        u.emitPos, u.emitEnd);
-                u.emitPos = uniform(uint32_t(fresh));
-                u.emitEnd = uniform(uint32_t(fresh >> 32));
-                if (u.emitPos > u.emitEnd) continue;
-            }
-            const uint32_t target = side == 0 ? col : rowId, candidate = side == 0 ? rowId : col;
-            if (on) u.inbox[u.emitPos + lanesBelow(mask)] = (uint64_t(target) << (13u + u.rowBits)) | (uint64_t(candidate) << 13u) | uint64_t(m);
-            u.emitPos += n;
-        }
-    }
-    if (BOTH || (u.diag & 4u)) return;
-#pragma unroll
-    for (uint32_t a = 0; a < 2u; a++) {
-        uint32_t pending = rowEvents[a];
-        while (__builtin_amdgcn_ballot_w64(pending != 0u) != 0ull) {
-            const bool mine = pending != 0u;
-            const uint32_t slot = mine ? uint32_t(__builtin_ctz(pending)) : 0u;      // the lane's next record for this row
-            const uint32_t column = slot == 0u ? columns[0] : slot == 1u ? columns[1] : slot == 2u ? columns[2] : columns[3];
-            const uint32_t m = slot == 0u ? mismatches[0] : slot == 1u ? mismatches[1] : slot == 2u ? mismatches[2] : mismatches[3];
-            const uint32_t wish = mine ? (1u | (column << 1)) : 0u;
-            const auto swapped = __builtin_amdgcn_permlane32_swap(wish, wish, false, false);       // {lower half twice, upper half twice}
-            const uint32_t partner = half ? swapped[0] : swapped[1];
-            const bool partnerToo = (partner & 1u) != 0u;
-            const bool append = mine && !(partnerToo && (partner >> 1) < column);          // the halves never hold the same column
-            const bool partnerAppends = partnerToo && !(mine && column < (partner >> 1));
-            if (append) {
-                u.logBase[size_t(32u * a + lane31) * u.logCapacity + logCount[a]] = uint64_t(tileBase + column) | (uint64_t(m) << 32);   // storeEntry
-                pending &= pending - 1u;
-            }
-            logCount[a] += uint32_t(append) + uint32_t(partnerAppends);           // both lanes count the appends of both
-        }
-    }
+    const Entry e = loadEntryCoherent(log + index);
+    WalkRecord r;
+    r.code = e.cell;
+    r.dot = __uint_as_float(e.key);
+    return r;
 }
 
 // The lock-step walk over the tiles [colBegin, colEnd) with the hand-scheduled steps.  Out of line: the steps own
-// v32..v255, and inlined into the kernels the values that live across the walk compete with them; as a function of its
-// own the walk keeps the few vector values it needs across a step (the rows' bounds and log counts in accumulator
-// layout) below v32, and nothing of the compiler's may ever sit at v64 or above (tools/check_matrix_walk_registers.py
-// checks the compiled code).  Wave-uniform arguments arrive in vector registers and are moved to the scalar file first;
-// pointers get their address spaces back (a generic pointer would make the compiler emit flat_ instructions, whose
-// out-of-order completion would also break the counted LDS waits of the steps).  LDS arguments are byte addresses.
-// __builtin_amdgcn_kernarg_segment_ptr() is null outside a kernel: the kernarg pointer is an argument.
-// io = {logCount, emitPos, emitEnd} of the calling lane.
-struct MatrixWalkIo {
-    uint32_t logCount, emitPos, emitEnd;
-};
-
+// v28..v255, and inlined into the kernels the values that live across the walk compete with them; as a function of its
+// own the walk keeps next to nothing in vector registers across a step, and nothing of the compiler's may ever sit at
+// v64 or above (tools/check_matrix_walk_registers.py checks the compiled code).  Wave-uniform arguments arrive in vector
+// registers and are moved to the scalar file first; pointers get their address spaces back (a generic pointer would make
+// the compiler emit flat_ instructions, whose out-of-order completion would also break the counted LDS waits of the
+// steps).  LDS arguments are byte addresses.
+// The walk only LOGS what passes min(row bound, column bound): `waveLog` is the wave's log area, 64 logs of logCapacity
+// records, one per lane; recordCount (in / out) = the calling lane's number of records.  It returns the first column not
+// scanned, the same in all waves of the block: it ends early, at a pair boundary, when some lane's log could overflow
+// within the next three tiles.  The caller replays the logs (replayWalkLogs / drainWalkLogs) and calls again.
 template <bool IDENTITY, bool BOTH = false>
 __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* auxArg, const void* fragmentsArg, const void* snapArg,
                                                                     uint32_t colBeginArg, uint32_t colEndArg,
-                                                                    uint32_t rowFragmentBlockArg, float rowDotArg, uint32_t row,
-                                                                    bool rowValid, Entry* myLog, uint32_t logCapacityArg,
-                                                                    MatrixWalkIo* io, uint32_t tilesLdsArg, uint32_t stopWordsLdsArg,
-                                                                    uint32_t walkLdsArg)
+                                                                    uint32_t rowFragmentBlockArg, float rowDotArg,
+                                                                    Entry* waveLogArg, uint32_t logCapacityArg, uint32_t* recordCount,
+                                                                    uint32_t tilesLdsArg, uint32_t stopWordsLdsArg, uint32_t walkLdsArg)
 {
     const GlobalFragmentPtr fragments = (GlobalFragmentPtr)uniform64(reinterpret_cast<uint64_t>(fragmentsArg));
     const GlobalIntPtr snap = (GlobalIntPtr)uniform64(reinterpret_cast<uint64_t>(snapArg));
@@ -1012,42 +832,26 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     const uint32_t walkLds = uniform(walkLdsArg);
     const LdsFloatPtr boundScratch = ldsPointer<LdsFloatPtr>(walkLds + kWalkBounds);
     const LdsIntPtr snapStage = ldsPointer<LdsIntPtr>(walkLds + kWalkSnapStage);
-    MatrixWalkUniform u;
-    u.aux = (ArgsPtr)uniform64(reinterpret_cast<uint64_t>(auxArg));
-    u.inbox = (GlobalWord64Ptr)u.aux->inbox;
-    u.rowBits = u.aux->rowBits;
-    u.diag = u.aux->pad2;
-    u.logCapacity = logCapacity;
-    u.emitPos = uniform(io->emitPos);
-    u.emitEnd = uniform(io->emitEnd);
-    float rowDot[2];                // accumulator layout: [a] = bound of row 32a + (lane & 31)
-    uint32_t logCount[2];
+    const uint64_t logBase = uniform64(reinterpret_cast<uint64_t>(waveLogArg));
+    const uint32_t diag = ((ArgsPtr)uniform64(reinterpret_cast<uint64_t>(auxArg)))->pad2;
+    const uint32_t initialCount = *recordCount;
     {
         const uint32_t lane = laneId();
         ldsPointer<LdsFloatPtr>(walkLds + kWalkRowDot)[lane] = rowDotArg;         // for the steps: float[64], lane = row
-        // lane-per-row state -> accumulator layout: v_permlane32_swap(x, x) = {lower half twice, upper half twice}
-        const auto dots = __builtin_amdgcn_permlane32_swap(__float_as_uint(rowDotArg), __float_as_uint(rowDotArg), false, false);
-        rowDot[0] = __uint_as_float(dots[0]);
-        rowDot[1] = __uint_as_float(dots[1]);
-        const uint32_t count = io->logCount;
-        const auto counts = __builtin_amdgcn_permlane32_swap(count, count, false, false);
-        logCount[0] = counts[0];
-        logCount[1] = counts[1];
-        u.validRows = __builtin_amdgcn_ballot_w64(rowValid);
-        u.rowBase = uniform(row);                                                 // lane 0: the wave's first row
-        // the log of the wave's row 0: the calling lane's log is logCapacity * lane entries further on
-        u.logBase = (GlobalWord64Ptr)(myLog ? uniform64(reinterpret_cast<uint64_t>(myLog) - uint64_t(lane) * logCapacity * sizeof(Entry)) : 0ull);
+        // the lane's next record: byte offset into the wave's log area, kept in a register of the walk
+        const uint32_t offset = (lane * logCapacity + initialCount) * uint32_t(sizeof(Entry));
+        asm volatile(EM2_MATRIX_SET_RECORD_OFFSET : : "v"(offset) : EM2_MATRIX_OWNED_REGISTERS);
         // the B operand: the 2 x 16 fragments of the wave's rows straight into their registers (v128..v255)
         const uint64_t rowFragments = reinterpret_cast<uint64_t>(fragments) + size_t(rowFragmentBlock) * kMatrixTileWords * 16u;
         asm volatile(EM2_MATRIX_LOAD_ROWS : : "s"(rowFragments) : EM2_MATRIX_STEP_CLOBBERS);
     }
-    const uint32_t diag = u.diag;
     const uint32_t waveSlot = uniform(threadIdx.x >> 6) * 64u;
     // A tile travels global -> LDS without touching registers (global_load_lds_dwordx4: LDS address = M0 + 16 * lane,
     // which is exactly the fragment order; this wave moves its quarter, 4 x 1 KB).  Issued from inline asm: the compiler
     // must not know of these transfers -- it orders every LDS access of its own behind an LDS-DMA it has seen with
-    // s_waitcnt vmcnt(0), and the events of a tile (which read the tile's bounds from LDS) would sit out the latency of
-    // the next pair's tiles every time.  What needs the tiles waits for them explicitly in front of the barrier.
+    // s_waitcnt vmcnt(0).  What needs the tiles waits for them explicitly in front of the barrier.  The lane addresses are
+    // 64-bit vector registers: the form with a scalar base and a 32-bit lane offset left 1 KB pieces of a tile stale now
+    // and then (tests/test_gpu_fsp4.py::test_sharded_tile_walk_repeats_bit_identically).
 #define EM2_STAGE_TILE(tileIndex, buffer)                                                                                     \
     do {                                                                                                                      \
         if (diag & 16u) break;                                                                                                \
@@ -1082,19 +886,9 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     EM2_STAGE_SNAP(colBegin, 0u);
     EM2_WAIT_STAGED();
     __syncthreads();
-    uint32_t recordCount;           // per lane: records the step left in the lane's queue (more than kWalkQueueSlots: overflow)
+    uint32_t recordOffset = 0;      // per lane: where its next record goes, as the last step with tests left it
+    bool tested = false;
     uint64_t passScratch[5];        // scalar pairs for the steps: pass masks in flight, saved exec
-    const uint32_t queueLds = walkLds + kWalkQueue;
-    // the events of the tile just tested (IN_Y: its results are in accumulator set Y)
-#define EM2_MATRIX_EVENTS(IN_Y)                                                                                               \
-    do {                                                                                                                      \
-        if ((diag & 1u) || __builtin_amdgcn_ballot_w64(recordCount != 0u) == 0ull) break;                                     \
-        if (__builtin_amdgcn_ballot_w64(recordCount > kWalkQueueSlots) != 0ull || (diag & 512u)) {                            \
-            matrixEvents<BOTH, IN_Y>(0xffffffffu, pendingBase, boundBase, rowDot, logCount, u);     /* every register */       \
-        } else {                                                                                                              \
-            matrixEventsQueued<BOTH>(recordCount, pendingBase, boundBase, queueLds, rowDot, logCount, u);                     \
-        }                                                                                                                     \
-    } while (0)
     bool pending = false, pendingInY = false;
     uint32_t pendingBase = 0, pendingSlot = 0;
     uint32_t iteration = 0;
@@ -1116,10 +910,10 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
             if (pending && !(diag & 32u)) {
                 const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
                 asm volatile(EM2_MATRIX_STEP_X_TESTING_Y
-                             : "=v"(recordCount), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
-                             : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(queueLds)
+                             : "=v"(recordOffset), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                             : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(logBase), "s"(pendingBase)
                              : EM2_MATRIX_STEP_CLOBBERS);
-                EM2_MATRIX_EVENTS(true);
+                tested = true;
             } else {
                 asm volatile(EM2_MATRIX_STEP_X : : "s"(tileBase) : EM2_MATRIX_STEP_CLOBBERS);
             }
@@ -1137,17 +931,22 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
             const uint32_t tileBase = tilesLds + (2u * pair + 1u) * (kMatrixTileWords * 16u);
             const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
             asm volatile(EM2_MATRIX_STEP_Y_TESTING_X
-                         : "=v"(recordCount), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
-                         : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(queueLds)
+                         : "=v"(recordOffset), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                         : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(logBase), "s"(pendingBase)
                          : EM2_MATRIX_STEP_CLOBBERS);
-            EM2_MATRIX_EVENTS(false);
+            tested = true;
             pendingInY = true;
             pendingBase = colBase + 32u;
             pendingSlot = 2u * pair + 1u;
         }
-        // the untested tile and the next pair add at most 96 entries to a row's log before the next chance to stop
-        const uint32_t worst = logCount[0] > logCount[1] ? logCount[0] : logCount[1];
-        const bool full = !BOTH && __builtin_amdgcn_ballot_w64(worst + kMatrixLogMargin > logCapacity) != 0ull;
+        if (diag & 1u) {            // (measurements: the records are written, then dropped)
+            const uint32_t offset = laneId() * logCapacity * uint32_t(sizeof(Entry));
+            asm volatile(EM2_MATRIX_SET_RECORD_OFFSET : : "v"(offset) : EM2_MATRIX_OWNED_REGISTERS);
+            recordOffset = offset;
+        }
+        // the untested tile and the next pair add at most 96 records to a lane's log before the next chance to stop
+        const uint32_t records = tested ? recordOffset / uint32_t(sizeof(Entry)) - laneId() * logCapacity : initialCount;
+        const bool full = __builtin_amdgcn_ballot_w64(records + kMatrixLogMargin > logCapacity) != 0ull;
         const uint32_t slot = iteration % 3u;
         if (full && laneId() == 0u) stopWords[slot] = 1u;
         if (waveSlot == 0u && laneId() == 0u) stopWords[(iteration + 1u) % 3u] = 0u;
@@ -1165,26 +964,109 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
 #undef EM2_STAGE_SNAP
 #undef EM2_WAIT_STAGED
     // ---- the tile still untested ----
-    if (pending) {
+    if (pending && !(diag & 32u)) {
         const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
         if (pendingInY) {
             asm volatile(EM2_MATRIX_TEST_Y
-                         : "=v"(recordCount), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4]) : "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(queueLds) : EM2_MATRIX_STEP_CLOBBERS);
-            EM2_MATRIX_EVENTS(true);
+                         : "=v"(recordOffset), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                         : "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(logBase), "s"(pendingBase) : EM2_MATRIX_STEP_CLOBBERS);
         } else {
             asm volatile(EM2_MATRIX_TEST_X
-                         : "=v"(recordCount), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4]) : "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(queueLds) : EM2_MATRIX_STEP_CLOBBERS);
-            EM2_MATRIX_EVENTS(false);
+                         : "=v"(recordOffset), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                         : "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(logBase), "s"(pendingBase) : EM2_MATRIX_STEP_CLOBBERS);
+        }
+        tested = true;
+    }
+    // the records were stored by one lane and are read back by others: the stores must have left the wave before the
+    // caller replays the logs (it reads past the L1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tested && !(diag & 1u)) *recordCount = recordOffset / uint32_t(sizeof(Entry)) - laneId() * logCapacity;
+    return result;
+}
+
+// The replay of the walk's logs for the rows of the wave (lane = row, as everywhere outside the walk).  Row r = 32a + t
+// finds its records in the logs of lanes t (columns 8q .. 8q+3 of every group) and 32 + t (columns 8q+4 .. 8q+7), mixed
+// with those of row 32 (1 - a) + t; both logs ascend in the column, and the row's candidates must be offered in ascending
+// order: a two-way merge, every lane its own, all lanes in step.  Per record: the row side through the exact state
+// machine (acceptColumn), the column side -- unless the rows scan all columns themselves (full rows) -- to the inbox if it
+// passes the column's published cut-off, read now (fresher than the one the walk tested against: fewer entries).
+template <bool IDENTITY>
+__device__ __forceinline__ void replayWalkLogs(const Entry* waveLog, uint32_t logCapacity, uint32_t recordCount, uint32_t lane,
+                                               uint32_t row, bool rowValid, bool emitColumns, uint32_t listBlock, Entry* myList,
+                                               uint32_t twoK, uint32_t& count, int32_t& mMax, uint32_t& emitPos, uint32_t& emitEnd,
+                                               unsigned char* ldsRaw)
+{
+    const uint32_t t = lane & 31u, a = lane >> 5;
+    const Entry* logs[2] = {waveLog + size_t(t) * logCapacity, waveLog + size_t(t + 32u) * logCapacity};
+    const uint32_t n[2] = {uint32_t(__shfl(int(recordCount), int(t), 64)), uint32_t(__shfl(int(recordCount), int(t + 32u), 64))};
+    uint32_t i[2] = {0u, 0u};
+    WalkRecord next[2];
+    next[0].code = next[1].code = 0u;
+    next[0].dot = next[1].dot = 0.f;
+    // the source's next record of this row's accumulator
+#define EM2_SEEK(h)                                                         \
+    while (i[h] < n[h]) {                                                   \
+        next[h] = loadWalkRecord(logs[h], i[h]);                            \
+        if ((next[h].code & 1u) == a) break;                                \
+        ++i[h];                                                             \
+    }
+    EM2_SEEK(0)
+    EM2_SEEK(1)
+    const int32_t* snap = kernelArgs()->snap;
+    for (;;) {
+        const bool have0 = i[0] < n[0], have1 = i[1] < n[1];
+        const bool active = have0 || have1;
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+        const uint32_t col0 = have0 ? walkRecordColumn(next[0].code, 0u) : 0xffffffffu;
+        const uint32_t col1 = have1 ? walkRecordColumn(next[1].code, 1u) : 0xffffffffu;
+        const bool take0 = col0 < col1;                   // (the halves never hold the same column)
+        const uint32_t col = take0 ? col0 : col1;
+        const float dot = take0 ? next[0].dot : next[1].dot;
+        const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
+        if (active) {
+            if (take0) {
+                ++i[0];
+                EM2_SEEK(0)
+            } else {
+                ++i[1];
+                EM2_SEEK(1)
+            }
+        }
+        const bool passRow = active && int32_t(m) <= mMax;
+        if (__builtin_amdgcn_ballot_w64(passRow) != 0ull) {
+            acceptColumn<IDENTITY>(passRow, col, row, m, lane, listBlock, myList, twoK, count, mMax, ldsRaw);
+        }
+        if (emitColumns) {
+            const bool passColumn = active && rowValid && int32_t(m) <= __hip_atomic_load(snap + (active ? col : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            emitColumn(passColumn, col, row, m, lane, emitPos, emitEnd);
         }
     }
-#undef EM2_MATRIX_EVENTS
-    // a row's log entries were stored by two lanes and are read back by a third (the row's own): the stores must have
-    // left the wave before the caller replays the log (it reads past the L1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    io->logCount = laneId() < 32u ? logCount[0] : logCount[1];
-    io->emitPos = u.emitPos;
-    io->emitEnd = u.emitEnd;
-    return result;
+#undef EM2_SEEK
+}
+
+// The tile kernel of the sharded scan defers both sides: every lane empties its own log, order is irrelevant (the inbox
+// is sorted).  rowBase = cell id of the wave's row 0.
+__device__ __forceinline__ void drainWalkLogs(const Entry* waveLog, uint32_t logCapacity, uint32_t recordCount, uint32_t lane,
+                                              uint32_t rowBase, uint32_t cellCount, uint32_t& emitPos, uint32_t& emitEnd)
+{
+    const Entry* log = waveLog + size_t(lane) * logCapacity;
+    const int32_t* snap = kernelArgs()->snap;
+    for (uint32_t i = 0;; ++i) {
+        const bool active = i < recordCount;
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+        WalkRecord r;
+        r.code = 0u;
+        r.dot = 0.f;
+        if (active) r = loadWalkRecord(log, i);
+        const uint32_t col = walkRecordColumn(r.code, lane >> 5);
+        const uint32_t rowId = rowBase + 32u * (r.code & 1u) + (lane & 31u);
+        const uint32_t m = uint32_t((kMatrixBits - r.dot) * 0.5f);
+        const bool valid = active && rowId < cellCount;
+        const int32_t snapCol = valid ? snap[col] : -1;
+        const int32_t snapOfRow = valid ? snap[rowId] : -1;
+        emitColumn(valid && int32_t(m) <= snapCol, col, rowId, m, lane, emitPos, emitEnd);        // target col
+        emitColumn(valid && int32_t(m) <= snapOfRow, rowId, col, m, lane, emitPos, emitEnd);      // target row
+    }
 }
 
 template <bool IDENTITY, bool PINNED>
@@ -1275,14 +1157,11 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         for (;;) {
             if (at < commonEnd) {
                 if (PINNED) {
-                    MatrixWalkIo io = {logCount, emitPos, emitEnd};
+                    // (logCount counts the calling LANE's records here, see replayWalkLogs)
                     at = scanTilesMatrixPinned<IDENTITY>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
-                                                         rowFragmentBlock, kMatrixBits - 2.f * float(mMax), row, rowValid && !fullRows,
-                                                         myLog, logCapacity, &io, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
+                                                         rowFragmentBlock, kMatrixBits - 2.f * float(mMax), myLog - size_t(lane) * logCapacity,
+                                                         logCapacity, &logCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                          ldsAddress(walkBlock));
-                    logCount = io.logCount;
-                    emitPos = io.emitPos;
-                    emitEnd = io.emitEnd;
                 } else {
                     at = scanTilesMatrix<IDENTITY>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, at, commonEnd,
                                                    rowFragmentBlock, kMatrixBits - 2.f * float(mMax), row, rowValid && !fullRows, lane, myLog,
@@ -1312,15 +1191,18 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                 }
             }
             // replay the log through the exact state machine (ascending column order per row)
-            if (!idle && !failed) {
+            if (PINNED) {
+                if (!idle && !failed) {
+                    replayWalkLogs<IDENTITY>(myLog - size_t(lane) * logCapacity, logCapacity, logCount, lane, row, rowValid, !fullRows,
+                                             listBlock, myList, twoK, count, mMax, emitPos, emitEnd, ldsRaw);
+                }
+            } else if (!idle && !failed) {
                 for (uint32_t i = 0;; ++i) {
                     const bool active = i < logCount;
                     if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
                     uint32_t c = 0, m = 0;
                     if (active) {
-                        // (the hand-scheduled walk writes a row's entries from two lanes: read them past the L1, like the
-                        // row lists)
-                        const Entry e = PINNED ? loadEntryCoherent(myLog + i) : myLog[i];
+                        const Entry e = myLog[i];
                         c = e.cell;
                         m = e.key;
                     }
@@ -1724,13 +1606,18 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
         if (colBegin < commonEnd) {
             uint32_t unusedLogCount = 0;
             if (PINNED) {
-                MatrixWalkIo io = {0u, emitPos, emitEnd};
-                scanTilesMatrixPinned<true, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, colBegin, commonEnd,
-                                                  2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), row, rowValid, nullptr, 0u,
-                                                  &io, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
-                                                  ldsAddress(walkBlock));
-                emitPos = io.emitPos;
-                emitEnd = io.emitEnd;
+                // the walk logs what passes either bound; both sides of every record go to the inbox afterwards
+                const uint32_t logCapacity = aux->logCapacity < kMatrixLogMargin ? kMatrixLogMargin : aux->logCapacity;
+                Entry* waveLog = aux->logs + size_t(blockIdx.x * 4u + wave) * 64u * logCapacity;
+                uint32_t at = colBegin;
+                while (at < commonEnd) {
+                    uint32_t records = 0;
+                    at = scanTilesMatrixPinned<true, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
+                                                           2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), waveLog, logCapacity,
+                                                           &records, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
+                                                           ldsAddress(walkBlock));
+                    if (!idle) drainWalkLogs(waveLog, logCapacity, records, lane, rowBase, cellCount, emitPos, emitEnd);
+                }
             } else {
                 scanTilesMatrix<true, true>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, colBegin, commonEnd,
                                             2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), row, rowValid, lane, nullptr, 0u,

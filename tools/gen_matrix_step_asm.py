@@ -27,7 +27,7 @@ loop holds no vector value of the compiler's across a step or across the call of
     v[96:111] / v[112:127]  accumulator set Y
     v[48:63]    ring of four column fragments (A operand)
     v[40:47]    two buffers of four column bounds (the previous tile's, this lane's half)
-    v28 record count, v29 queue address, v30 / v31 record and its address (stubs);
+    v28 byte offset of the lane's next record in the wave's log; v30 / v31 the record (stubs);
     v32 lane, then a threshold; v33 / v34 / v35 LDS addresses (tile, bounds, row state), v36 scale, v37 / v38 row bounds,
     v39 the other threshold
 
@@ -36,10 +36,12 @@ accumulator holds row (l & 31) / 32 + (l & 31) and column 8 * (i >> 2) + 4 * (l 
 
 Test of register i = 4q + j of accumulator a of the previous tile:
     pass = min(rowBound[a], columnBound[8q + 4 * (l >> 5) + j]) <= dot            (q = the "group" of 8 columns)
-A register that passes in some lane (rare) branches to its stub behind the body: the passing lanes append a record
-(2i + a + 1) << 16 | (dot + 1024) to their own four-slot queue in LDS (v28 counts, v29 = the lane's queue address);
-the step returns the counts.  The events of a tile are then handled lane-parallel, one record per lane and round,
-by the compiler's code (matrixEventsQueued) -- straight-line vector code instead of a scalar chain per event.
+A register that passes in some lane branches to its stub behind the body: the passing lanes append a record
+{first column of the tile | 2i + a, dot} (8 bytes) to their OWN log in global memory (v28 = the lane's byte offset into
+the wave's log area, which the step returns; it persists from step to step).  That is all a step does about an event:
+which side of the pair the record is for (row, column, both), the exact state machine and the inbox are the business
+of the replay that follows the walk (csrc/em2_scan_symmetric.hip), which reads the logs lane-parallel, many records per
+lane, instead of a few per step.
 The column bounds come from the wave's bound scratch in LDS (32 floats per tile), 16 bytes per group and lane half;
 the row bounds from the wave's state block (float rowDot[64], lane l reads [l & 31] and [32 + (l & 31)]).
 """
@@ -51,9 +53,8 @@ RING = 48
 BOUNDS = 40
 LANE, TILE_ADDR, BOUND_ADDR, STATE_ADDR, SCALE, ROW_BOUND0, ROW_BOUND1, THR0 = 32, 33, 34, 35, 36, 37, 38, 39
 THR1 = LANE          # the lane id is dead once the addresses are formed
-COUNT, QUEUE_ADDR, RECORD, RECORD_ADDR = 28, 29, 30, 31
+OFFSET, RECORD = 28, 30          # v28, v[30:31]
 FIRST_OWNED = 28
-QUEUE_SLOTS = 4
 STEPS = 16
 
 
@@ -90,8 +91,6 @@ def prologue(s, o, tile, tests):
         s.emit("v_lshl_add_u32 %s, %s, 4, %s" % (vreg(TILE_ADDR), vreg(LANE), o["tileBase"]))          # + 16 * lane
         s.emit("v_mov_b32 %s, 0x7f7f7f7f" % vreg(SCALE))                                                 # E8M0 2^0 in every byte
     if tests:
-        s.emit("v_lshl_add_u32 %s, %s, 4, %s" % (vreg(QUEUE_ADDR), vreg(LANE), o["queueBase"]))       # + 4 slots x 4 bytes per lane
-        s.emit("v_mov_b32 %s, 0" % vreg(COUNT))
         s.emit("v_and_b32 %s, 31, %s" % (vreg(STATE_ADDR), vreg(LANE)))
         s.emit("v_lshl_add_u32 %s, %s, 2, %s" % (vreg(STATE_ADDR), vreg(STATE_ADDR), o["stateBase"]))     # + 4 * (lane & 31)
         s.emit("v_lshrrev_b32 %s, 5, %s" % (vreg(BOUND_ADDR), vreg(LANE)))
@@ -123,26 +122,22 @@ def shift_in(s, o, k):
 
 
 def stubs(s, o, prev0, prev1):
-    """The lanes in which register k of accumulator a passed append one record to their queue in LDS:
-    (2k + a + 1) << 16 | (dot + 1024); a lane's fifth record is dropped, its count says so."""
+    """The lanes in which register k of accumulator a passed append one record to their log in global memory:
+    {tile's first column | 2k + a, dot as it stands in the accumulator}."""
     s.emit("s_branch L_end_%=")
     for k, a in s.stubs:
         acc = (prev0, prev1)[a] + k
         s.emit("L_stub_%d_%d_%%=:" % (k, a))
         s.emit("s_mov_b64 %s, exec" % o["save"])
         s.emit("s_mov_b64 exec, %s" % o["pass%d_%d" % (a, k & 1)])
-        s.emit("v_cvt_i32_f32 %s, %s" % (vreg(RECORD), vreg(acc)))
-        s.emit("v_add_u32 %s, 0x%x, %s" % (vreg(RECORD), ((2 * k + a + 1) << 16) + 1024, vreg(RECORD)))
-        s.emit("v_cmp_gt_u32 vcc, %d, %s" % (QUEUE_SLOTS, vreg(COUNT)))
-        s.emit("v_lshl_add_u32 %s, %s, 2, %s" % (vreg(RECORD_ADDR), vreg(COUNT), vreg(QUEUE_ADDR)))
-        s.emit("v_add_u32 %s, 1, %s" % (vreg(COUNT), vreg(COUNT)))
-        s.emit("s_and_b64 exec, exec, vcc")
-        s.emit("ds_write_b32 %s, %s" % (vreg(RECORD_ADDR), vreg(RECORD)))
+        s.emit("v_or_b32_e64 %s, %s, %d" % (vreg(RECORD), o["tileCode"], 2 * k + a))
+        s.emit("v_mov_b32 %s, %s" % (vreg(RECORD + 1), vreg(acc)))
+        s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET), vreg(RECORD, 2), o["logBase"]))
+        s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET), vreg(OFFSET)))
         s.emit("s_mov_b64 exec, %s" % o["save"])
         s.emit("s_branch L_back_%d_%d_%%=" % (k, a))
     s.emit("L_end_%=:")
-    s.emit("s_waitcnt lgkmcnt(0)")
-    s.emit("v_mov_b32 %s, %s" % (o["count"], vreg(COUNT)))
+    s.emit("v_mov_b32 %s, %s" % (o["count"], vreg(OFFSET)))
 
 
 def step(cur, prev, tests, operands):
@@ -218,15 +213,15 @@ def main():
     out.write("// em2_matrix_step_asm.h -- GENERATED by tools/gen_matrix_step_asm.py (see there for the register map); do not edit.\n")
     out.write("#ifndef EM2_MATRIX_STEP_ASM_H\n#define EM2_MATRIX_STEP_ASM_H\n\n")
     # Operand order of the asm statements in em2_scan_symmetric.hip:
-    #   step with tests:    %0 the lanes' record counts ("=v"), %1..%5 five scratch pairs ("=&s", 64 bits: the pass masks in
-    #                       flight, the saved exec), then "s": %6 tileBase, %7 boundBase, %8 stateBase, %9 queueBase
-    #                       (LDS byte addresses)
+    #   step with tests:    %0 the lanes' record offsets ("=v"), %1..%5 five scratch pairs ("=&s", 64 bits: the pass masks in
+    #                       flight, the saved exec), then "s": %6 tileBase, %7 boundBase, %8 stateBase (LDS byte addresses),
+    #                       %9 logBase (64 bits: the wave's log area), %10 tileCode (first column of the tile under test)
     #   step without tests: %0 tileBase
-    #   test only:          %0 record counts, %1..%5 scratch pairs, %6 boundBase, %7 stateBase, %8 queueBase
+    #   test only:          %0 record offsets, %1..%5 scratch pairs, %6 boundBase, %7 stateBase, %8 logBase, %9 tileCode
     passes = {"pass0_0": "%1", "pass1_0": "%2", "pass0_1": "%3", "pass1_1": "%4", "save": "%5"}
-    with_tests = dict(passes, count="%0", tileBase="%6", boundBase="%7", stateBase="%8", queueBase="%9")
+    with_tests = dict(passes, count="%0", tileBase="%6", boundBase="%7", stateBase="%8", logBase="%9", tileCode="%10")
     without = {"tileBase": "%0"}
-    only = dict(passes, count="%0", boundBase="%6", stateBase="%7", queueBase="%8")
+    only = dict(passes, count="%0", boundBase="%6", stateBase="%7", logBase="%8", tileCode="%9")
     for cur, prev in (("X", "Y"), ("Y", "X")):
         out.write(macro("EM2_MATRIX_STEP_%s_TESTING_%s" % (cur, prev), step(cur, prev, True, with_tests)))
         out.write(macro("EM2_MATRIX_STEP_%s" % cur, step(cur, prev, False, without)))
@@ -235,6 +230,8 @@ def main():
     owned = ", ".join('"v%d"' % r for r in range(FIRST_OWNED, 256))
     out.write("#define EM2_MATRIX_OWNED_REGISTERS %s\n\n" % owned)
     out.write("#define EM2_MATRIX_STEP_CLOBBERS \"memory\", \"vcc\", \"scc\", EM2_MATRIX_OWNED_REGISTERS\n\n")
+    # the lane's record offset lives in a register of the walk from step to step
+    out.write("#define EM2_MATRIX_SET_RECORD_OFFSET \"v_mov_b32 v%d, %%0\\n\"\n\n" % OFFSET)
     # the B operand in one go: 32 loads straight into the registers, one wait.  %0 = address of the wave's first row
     # fragment (scalar pair); the fragments of a 32-row block are 1 KB apart (64 lanes x 16 bytes), the second block
     # follows the first

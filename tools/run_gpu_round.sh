@@ -1,11 +1,17 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r42; mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_fsp5.py tests/test_gpu_fsp4.py -x -q -k "fsp5 or evict" 2>&1 | tail -15
-for mode in tiers lds; do
-EM2_FSP5_SELECT=$mode timeout 600 python bench.py --workload fsp5 --steps 3 --warmup 1 > $O/fsp5_$mode.json 2> $O/fsp5_$mode.err
-python - <<PY
+O=gpurun_out/r43; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_fsp4.py -x -q 2>&1 | tail -15
+run() { # name, env...
+  name=$1; shift
+  env "$@" EM2_SCAN_VERBOSE=1 timeout 600 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra --check-rows 64 > $O/$name.json 2> $O/$name.err
+  python - <<PY
 import json
-d=json.loads(open("$O/fsp5_$mode.json").read().strip().splitlines()[-1])
-print("$mode", round(d["ms_per_step"],1), d["phases_ms"], d["parity_check"])
+try:
+    d=json.loads(open("$O/$name.json").read().strip().splitlines()[-1])
+    print("$name", round(d["ms_per_step"],1), d["phases_ms_rank0"], round(d["roofline"]["kernel_ms"],1), d["roofline"]["inbox_entries"], d["parity_check"])
+except Exception as e:
+    print("$name no json", e); print(open("$O/$name.err").read()[-1500:])
 PY
-done
+}
+run full A=1
+run norecords EM2_MATRIX_DIAG=1
