@@ -295,7 +295,15 @@ fsp4ScanSymmetricKernel(Fsp4Args args)
             const uint32_t segments = aux->segments;
             const uint32_t* table = aux->segTable;
             uint32_t seg = 0;
-            while (ticket >= table[seg + 1u]) ++seg;
+            {
+                uint32_t lo = 0, hi = segments;           // table[lo] <= ticket < table[hi]
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) / 2u;
+                    if (table[mid] <= ticket) lo = mid;
+                    else hi = mid;
+                }
+                seg = lo;
+            }
             const uint32_t local = ticket - table[seg];
             const uint32_t fullBlocks = aux->fullRowBlocks;
             // slot = list / state slot of the launch; its 64 cells start at rowBase (block-cyclic in the sharded scan)
@@ -950,7 +958,7 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         const uint32_t slot = iteration % 3u;
         if (full && laneId() == 0u) stopWords[slot] = 1u;
         if (waveSlot == 0u && laneId() == 0u) stopWords[(iteration + 1u) % 3u] = 0u;
-        EM2_WAIT_STAGED();
+        if (!(diag & 128u)) EM2_WAIT_STAGED();          // (128: measurements only -- the tiles are used before they have arrived)
         if (!(diag & 64u)) __syncthreads();
         if (stopWords[slot] != 0u) {
             __syncthreads();
@@ -1103,8 +1111,18 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         // ---- the item: segment seg, quad = 4 row blocks from quadBlock ----
         const uint32_t segments = aux->segments;
         const uint32_t* table = aux->segTable;
+        // (binary search: the table has up to 256 segments, and a linear walk through it -- one dependent scalar load per
+        // segment -- cost an item of a late segment some 25 us, as much as two dozen tiles)
         uint32_t seg = 0;
-        while (ticket >= table[seg + 1u]) ++seg;
+        {
+            uint32_t lo = 0, hi = segments;               // table[lo] <= ticket < table[hi]
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) / 2u;
+                if (table[mid] <= ticket) lo = mid;
+                else hi = mid;
+            }
+            seg = lo;
+        }
         // block = list / state slot of the launch; its 64 cells start at (block * stride + offset) * 64 (block-cyclic in
         // the sharded scan, where a quad is 4 slots whose cells are not adjacent -- but there every column lies below them)
         // The first fullQuads items of a segment are quads of full-row blocks (the first cells of the problem, or the prefix

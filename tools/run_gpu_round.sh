@@ -1,17 +1,20 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r43; mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_fsp4.py -x -q 2>&1 | tail -15
+O=gpurun_out/r46; mkdir -p $O
 run() { # name, env...
   name=$1; shift
-  env "$@" EM2_SCAN_VERBOSE=1 timeout 600 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra --check-rows 64 > $O/$name.json 2> $O/$name.err
+  env "$@" EM2_SCAN_VERBOSE=1 timeout 600 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra --no-check > $O/$name.json 2> $O/$name.err
   python - <<PY
 import json
 try:
     d=json.loads(open("$O/$name.json").read().strip().splitlines()[-1])
-    print("$name", round(d["ms_per_step"],1), d["phases_ms_rank0"], round(d["roofline"]["kernel_ms"],1), d["roofline"]["inbox_entries"], d["parity_check"])
+    print("$name", round(d["ms_per_step"],1), round(d["phases_ms_rank0"]["scan"],1), round(d["roofline"]["kernel_ms"],1), d["roofline"]["inbox_entries"])
 except Exception as e:
     print("$name no json", e); print(open("$O/$name.err").read()[-1500:])
 PY
 }
 run full A=1
+run seg8k EM2_MIN_SEGMENT_COLUMNS=8192
+run seg4k EM2_MIN_SEGMENT_COLUMNS=4096
+run nowait_norecords EM2_MATRIX_DIAG=129
 run norecords EM2_MATRIX_DIAG=1
+run norecords_hi EM2_MATRIX_DIAG=1 EM2_BENCH_THRESHOLD=0.95
