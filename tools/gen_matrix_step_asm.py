@@ -89,7 +89,6 @@ def prologue(s, o, tile, tests):
     s.emit("v_mbcnt_hi_u32_b32 %s, -1, %s" % (vreg(LANE), vreg(LANE)))
     if tile:
         s.emit("v_lshl_add_u32 %s, %s, 4, %s" % (vreg(TILE_ADDR), vreg(LANE), o["tileBase"]))          # + 16 * lane
-        s.emit("v_mov_b32 %s, 0x7f7f7f7f" % vreg(SCALE))                                                 # E8M0 2^0 in every byte
     if tests:
         s.emit("v_and_b32 %s, 31, %s" % (vreg(STATE_ADDR), vreg(LANE)))
         s.emit("v_lshl_add_u32 %s, %s, 2, %s" % (vreg(STATE_ADDR), vreg(STATE_ADDR), o["stateBase"]))     # + 4 * (lane & 31)
@@ -153,9 +152,10 @@ def step(cur, prev, tests, operands):
         slot = RING + 4 * (k % 4)
         s.wait_for("a%d" % k)
         for a, (acc, rows) in enumerate(((cur0, ROWS[0]), (cur1, ROWS[1]))):
-            s.emit("v_mfma_scale_f32_32x32x64_f8f6f4 %s, %s, %s, %s, %s, %s op_sel_hi:[0,0,0] cbsz:4 blgp:4"
-                   % (vreg(acc, 16), vreg(slot, 4), vreg(rows + 4 * k, 4), "0" if k == 0 else vreg(acc, 16),
-                      vreg(SCALE), vreg(SCALE)))
+            # (the form without block scales: scale 2^0 is what the operands want, and v_mfma_scale_* is two instructions --
+            # a v_mfma_ld_scale_b32 in front of this one -- 16 bytes instead of 8 and an issue slot more per MFMA)
+            s.emit("v_mfma_f32_32x32x64_f8f6f4 %s, %s, %s, %s cbsz:4 blgp:4"
+                   % (vreg(acc, 16), vreg(slot, 4), vreg(rows + 4 * k, 4), "0" if k == 0 else vreg(acc, 16)))
         if k + 4 < STEPS:
             s.lds("a%d" % (k + 4), "ds_read_b128 %s, %s offset:%d" % (vreg(slot, 4), vreg(TILE_ADDR), 1024 * (k + 4)))
         if tests:
