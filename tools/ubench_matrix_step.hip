@@ -1,0 +1,145 @@
+// Microbenchmark: the generated tile step of the matrix-core walk (csrc/em2_matrix_step_asm.h) alone, back to back,
+// 4 waves per block, 1 or 2 blocks per CU, no DMA, no barriers:
+//   plain    32 MFMAs + their 16 fragment reads from LDS through the register ring (what the step's structure costs against
+//            the raw MFMA rate of tools/ubench_mfma_issue.hip);
+//   tests    the same with the test of the previous tile between the MFMAs, bounds that nothing passes;
+//   events   the same with random +-1 operands and bounds at `sigmas` standard deviations of the dot product (sigma = 32):
+//            3.0 gives the scan's rate of about four records per wave and tile; the stubs store their records.
+//   hipcc --offload-arch=gfx950 -O2 -I expressionmatrix2_amd/csrc -o ubench_matrix_step tools/ubench_matrix_step.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "em2_matrix_step_asm.h"
+
+// LDS: 4 tiles (64 KB), then per wave: rowDot float[64] (256 B) + bounds float[4][32] (512 B)
+__global__ void __launch_bounds__(256) stepLoop(int rounds, int mode, float bound, const unsigned* tiles, const unsigned* rows,
+                                                unsigned long long* logs, unsigned* counts, float* out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    for (unsigned i = threadIdx.x; i < 65536 / 4; i += 256) reinterpret_cast<unsigned*>(lds)[i] = tiles[i];
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* walk = reinterpret_cast<float*>(lds + 65536 + wave * 768);
+    walk[lane] = bound;
+    for (int i = lane; i < 128; i += 64) walk[64 + i] = bound;
+    __syncthreads();
+    const unsigned base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
+    const unsigned walkLds = unsigned(__builtin_amdgcn_readfirstlane(int(base + 65536 + wave * 768)));
+    auto uniform64 = [](unsigned long long v) {
+        return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(int(unsigned(v))) |
+               ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(int(unsigned(v >> 32))) << 32);
+    };
+    const unsigned long long rowAddress = uniform64(reinterpret_cast<unsigned long long>(rows) + size_t(blockIdx.x * 4 + wave) * 32768);
+    const unsigned long long logBase = uniform64(reinterpret_cast<unsigned long long>(logs) + size_t(blockIdx.x * 4 + wave) * 64 * 4096 * 8);
+    asm volatile(EM2_MATRIX_LOAD_ROWS : : "s"(rowAddress) : EM2_MATRIX_STEP_CLOBBERS);
+    unsigned offset = lane * 4096 * 8;
+    asm volatile(EM2_MATRIX_SET_RECORD_OFFSET : : "v"(offset) : EM2_MATRIX_OWNED_REGISTERS);
+    unsigned long long scratch[5];
+    unsigned recordOffset = offset;
+    for (int r = 0; r < rounds; r++) {
+        const unsigned t0 = unsigned(__builtin_amdgcn_readfirstlane(int(base + ((2 * r) & 3) * 16384)));
+        const unsigned t1 = unsigned(__builtin_amdgcn_readfirstlane(int(base + ((2 * r + 1) & 3) * 16384)));
+        if (mode == 0) {
+            asm volatile(EM2_MATRIX_STEP_X : : "s"(t0) : EM2_MATRIX_STEP_CLOBBERS);
+            asm volatile(EM2_MATRIX_STEP_Y : : "s"(t1) : EM2_MATRIX_STEP_CLOBBERS);
+#ifdef EM2_MATRIX_PAIR_TESTING
+        } else if (mode == 2) {
+            // the two steps as one statement (tiles of a pair are adjacent in LDS: pairs 0/1 and 2/3)
+            const unsigned pairBase = unsigned(__builtin_amdgcn_readfirstlane(int(base + (r & 1) * 32768)));
+            asm volatile(EM2_MATRIX_PAIR_TESTING
+                         : "=v"(recordOffset), "=&s"(scratch[0]), "=&s"(scratch[1]), "=&s"(scratch[2]), "=&s"(scratch[3]), "=&s"(scratch[4])
+                         : "s"(pairBase), "s"(walkLds + 256), "s"(walkLds + 256 + 128), "s"(walkLds), "s"(logBase), "s"(unsigned(r) * 64u),
+                           "s"(unsigned(r) * 64u + 32u)
+                         : EM2_MATRIX_STEP_CLOBBERS);
+            if ((r & 15) == 15) {
+                counts[(blockIdx.x * 4 + wave) * 64 + lane] += (recordOffset - offset) / 8;
+                asm volatile(EM2_MATRIX_SET_RECORD_OFFSET : : "v"(offset) : EM2_MATRIX_OWNED_REGISTERS);
+            }
+#endif
+        } else {
+            asm volatile(EM2_MATRIX_STEP_X_TESTING_Y
+                         : "=v"(recordOffset), "=&s"(scratch[0]), "=&s"(scratch[1]), "=&s"(scratch[2]), "=&s"(scratch[3]), "=&s"(scratch[4])
+                         : "s"(t0), "s"(walkLds + 256), "s"(walkLds), "s"(logBase), "s"(unsigned(r) * 64u)
+                         : EM2_MATRIX_STEP_CLOBBERS);
+            asm volatile(EM2_MATRIX_STEP_Y_TESTING_X
+                         : "=v"(recordOffset), "=&s"(scratch[0]), "=&s"(scratch[1]), "=&s"(scratch[2]), "=&s"(scratch[3]), "=&s"(scratch[4])
+                         : "s"(t1), "s"(walkLds + 256 + 128), "s"(walkLds), "s"(logBase), "s"(unsigned(r) * 64u + 32u)
+                         : EM2_MATRIX_STEP_CLOBBERS);
+            if ((r & 15) == 15) {       // (the log of a lane holds 4096 records: start over)
+                counts[(blockIdx.x * 4 + wave) * 64 + lane] += (recordOffset - offset) / 8;
+                asm volatile(EM2_MATRIX_SET_RECORD_OFFSET : : "v"(offset) : EM2_MATRIX_OWNED_REGISTERS);
+            }
+        }
+    }
+    float acc;
+    asm volatile("s_nop 15\n s_nop 15\n v_mov_b32 %0, v64" : "=v"(acc));
+    if (acc == 12345.f) out[0] = acc;
+}
+
+static void run(const char* name, int blocksPerCu, int rounds, int mode, float bound, const unsigned* tiles, const unsigned* rows,
+                unsigned long long* logs, unsigned* counts)
+{
+    int cus = 0;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    float* out;
+    hipMalloc(&out, 4);
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    const size_t ldsBytes = 65536 + 4 * 768;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&stepLoop), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+    stepLoop<<<cus * blocksPerCu, 256, ldsBytes>>>(16, mode, bound, tiles, rows, logs, counts, out);
+    hipDeviceSynchronize();
+    hipMemset(counts, 0, size_t(cus) * 2 * 4 * 64 * 4);
+    hipEventRecord(a);
+    stepLoop<<<cus * blocksPerCu, 256, ldsBytes>>>(rounds, mode, bound, tiles, rows, logs, counts, out);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    std::vector<unsigned> host(size_t(cus) * 2 * 4 * 64);
+    hipMemcpy(host.data(), counts, host.size() * 4, hipMemcpyDeviceToHost);
+    double records = 0;
+    for (unsigned c : host) records += c;
+    const double waveSteps = double(rounds) * 2.0 * 4.0 * blocksPerCu * cus;
+    const double mfmaPerSimd = double(rounds) * 64.0 * blocksPerCu;
+    const double flops = mfmaPerSimd * 4.0 * cus * 131072.0;
+    printf("%-28s %d block(s) per CU: %.2f ms, %.1f cycles (2.4 GHz) per MFMA per SIMD, %.2f PFLOP/s, %.2f records per wave and tile\n", name,
+           blocksPerCu, ms, ms * 1e6 / mfmaPerSimd * 2.4, flops / (ms * 1e-3) / 1e15, records / waveSteps);
+    hipFree(out);
+}
+
+int main(int argc, char** argv)
+{
+    int cus = 0;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    const size_t waves = size_t(cus) * 2 * 4;
+    std::vector<unsigned> tiles(65536 / 4), rows(waves * 32768 / 4);
+    unsigned long long state = 88172645463325252ull;
+    auto next = [&]() { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return state; };
+    auto nibbles = [&]() { unsigned w = 0; const unsigned long long r = next(); for (int n = 0; n < 8; n++) w |= (((r >> n) & 1u) ? 0xAu : 0x2u) << (4 * n); return w; };
+    for (auto& w : tiles) w = nibbles();
+    for (auto& w : rows) w = nibbles();
+    unsigned *dTiles, *dRows, *dCounts;
+    unsigned long long* dLogs;
+    hipMalloc(&dTiles, 65536);
+    hipMalloc(&dRows, rows.size() * 4);
+    hipMalloc(&dLogs, waves * 64 * 4096 * 8);
+    hipMalloc(&dCounts, waves * 64 * 4);
+    hipMemcpy(dTiles, tiles.data(), 65536, hipMemcpyHostToDevice);
+    hipMemcpy(dRows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice);
+    const int rounds = 20000;
+    run("plain", 1, rounds, 0, 0.f, dTiles, dRows, dLogs, dCounts);
+    run("plain", 2, rounds, 0, 0.f, dTiles, dRows, dLogs, dCounts);
+    run("tests, nothing passes", 2, rounds, 1, 1e9f, dTiles, dRows, dLogs, dCounts);
+    run("pair: tests, nothing passes", 2, rounds, 2, 1e9f, dTiles, dRows, dLogs, dCounts);
+    const float sigmas[] = {3.5f, 3.0f, 2.5f};
+    for (float s : sigmas) {
+        char name[64];
+        snprintf(name, sizeof(name), "events, bound %.1f sigma", s);
+        run(name, 2, rounds, 1, 32.f * s, dTiles, dRows, dLogs, dCounts);
+        snprintf(name, sizeof(name), "pair: events, %.1f sigma", s);
+        run(name, 2, rounds, 2, 32.f * s, dTiles, dRows, dLogs, dCounts);
+    }
+    return 0;
+}
