@@ -820,10 +820,11 @@ __device__ __forceinline__ WalkRecord loadWalkRecord(const Entry* log, uint32_t 
 // registers and are moved to the scalar file first; pointers get their address spaces back (a generic pointer would make
 // the compiler emit flat_ instructions, whose out-of-order completion would also break the counted LDS waits of the
 // steps).  LDS arguments are byte addresses.
-// The walk only LOGS what passes min(row bound, column bound): `waveLog` is the wave's log area, 64 logs of logCapacity
-// records, one per lane; recordCount (in / out) = the calling lane's number of records.  It returns the first column not
-// scanned, the same in all waves of the block: it ends early, at a pair boundary, when some lane's log could overflow
-// within the next three tiles.  The caller replays the logs (replayWalkLogs / drainWalkLogs) and calls again.
+// The walk only LOGS what passes min(row bound, column bound): `waveLog` is the wave's log area, per lane two logs of
+// logCapacity / 2 records, one per accumulator (walkLogOf); recordCount[a] (in / out) = the calling lane's number of
+// records in its log of accumulator a.  It returns the first column not scanned, the same in all waves of the block: it
+// ends early, at a pair boundary, when some log could overflow within the next three tiles (48 records: a tile has 16
+// registers per accumulator).  The caller replays the logs (replayWalkLogs / drainWalkLogs) and calls again.
 template <bool IDENTITY, bool BOTH = false>
 __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* auxArg, const void* fragmentsArg, const void* snapArg,
                                                                     uint32_t colBeginArg, uint32_t colEndArg,
@@ -842,13 +843,15 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     const LdsIntPtr snapStage = ldsPointer<LdsIntPtr>(walkLds + kWalkSnapStage);
     const uint64_t logBase = uniform64(reinterpret_cast<uint64_t>(waveLogArg));
     const uint32_t diag = ((ArgsPtr)uniform64(reinterpret_cast<uint64_t>(auxArg)))->pad2;
-    const uint32_t initialCount = *recordCount;
+    const uint32_t halfCapacity = logCapacity / 2u;
+    const uint32_t initialCount0 = recordCount[0], initialCount1 = recordCount[1];
     {
         const uint32_t lane = laneId();
         ldsPointer<LdsFloatPtr>(walkLds + kWalkRowDot)[lane] = rowDotArg;         // for the steps: float[64], lane = row
-        // the lane's next record: byte offset into the wave's log area, kept in a register of the walk
-        const uint32_t offset = (lane * logCapacity + initialCount) * uint32_t(sizeof(Entry));
-        asm volatile(EM2_MATRIX_SET_RECORD_OFFSET : : "v"(offset) : EM2_MATRIX_OWNED_REGISTERS);
+        // the lane's next records: byte offsets into the wave's log area, kept in two registers of the walk
+        const uint32_t offset0 = (lane * logCapacity + initialCount0) * uint32_t(sizeof(Entry));
+        const uint32_t offset1 = (lane * logCapacity + halfCapacity + initialCount1) * uint32_t(sizeof(Entry));
+        asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(offset0), "v"(offset1) : EM2_MATRIX_OWNED_REGISTERS);
         // the B operand: the 2 x 16 fragments of the wave's rows straight into their registers (v128..v255)
         const uint64_t rowFragments = reinterpret_cast<uint64_t>(fragments) + size_t(rowFragmentBlock) * kMatrixTileWords * 16u;
         asm volatile(EM2_MATRIX_LOAD_ROWS : : "s"(rowFragments) : EM2_MATRIX_STEP_CLOBBERS);
@@ -894,7 +897,7 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     EM2_STAGE_SNAP(colBegin, 0u);
     EM2_WAIT_STAGED();
     __syncthreads();
-    uint32_t recordOffset = 0;      // per lane: where its next record goes, as the last step with tests left it
+    uint32_t recordOffset = 0, recordOffset1 = 0;       // per lane: where its next records go, as the last step with tests left them
     bool tested = false;
     uint64_t passScratch[5];        // scalar pairs for the steps: pass masks in flight, saved exec
     bool pending = false, pendingInY = false;
@@ -918,7 +921,7 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
             if (pending && !(diag & 32u)) {
                 const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
                 asm volatile(EM2_MATRIX_STEP_X_TESTING_Y
-                             : "=v"(recordOffset), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                             : "=v"(recordOffset), "=v"(recordOffset1), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
                              : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(logBase), "s"(pendingBase)
                              : EM2_MATRIX_STEP_CLOBBERS);
                 tested = true;
@@ -939,7 +942,7 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
             const uint32_t tileBase = tilesLds + (2u * pair + 1u) * (kMatrixTileWords * 16u);
             const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
             asm volatile(EM2_MATRIX_STEP_Y_TESTING_X
-                         : "=v"(recordOffset), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                         : "=v"(recordOffset), "=v"(recordOffset1), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
                          : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(logBase), "s"(pendingBase)
                          : EM2_MATRIX_STEP_CLOBBERS);
             tested = true;
@@ -948,13 +951,17 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
             pendingSlot = 2u * pair + 1u;
         }
         if (diag & 1u) {            // (measurements: the records are written, then dropped)
-            const uint32_t offset = laneId() * logCapacity * uint32_t(sizeof(Entry));
-            asm volatile(EM2_MATRIX_SET_RECORD_OFFSET : : "v"(offset) : EM2_MATRIX_OWNED_REGISTERS);
-            recordOffset = offset;
+            const uint32_t offset0 = laneId() * logCapacity * uint32_t(sizeof(Entry));
+            const uint32_t offset1 = offset0 + halfCapacity * uint32_t(sizeof(Entry));
+            asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(offset0), "v"(offset1) : EM2_MATRIX_OWNED_REGISTERS);
+            recordOffset = offset0;
+            recordOffset1 = offset1;
         }
-        // the untested tile and the next pair add at most 96 records to a lane's log before the next chance to stop
-        const uint32_t records = tested ? recordOffset / uint32_t(sizeof(Entry)) - laneId() * logCapacity : initialCount;
-        const bool full = __builtin_amdgcn_ballot_w64(records + kMatrixLogMargin > logCapacity) != 0ull;
+        // the untested tile and the next pair add at most 48 records to a log before the next chance to stop
+        const uint32_t records0 = tested ? recordOffset / uint32_t(sizeof(Entry)) - laneId() * logCapacity : initialCount0;
+        const uint32_t records1 = tested ? recordOffset1 / uint32_t(sizeof(Entry)) - laneId() * logCapacity - halfCapacity : initialCount1;
+        const uint32_t records = records0 > records1 ? records0 : records1;
+        const bool full = __builtin_amdgcn_ballot_w64(records + kMatrixLogMargin / 2u > halfCapacity) != 0ull;
         const uint32_t slot = iteration % 3u;
         if (full && laneId() == 0u) stopWords[slot] = 1u;
         if (waveSlot == 0u && laneId() == 0u) stopWords[(iteration + 1u) % 3u] = 0u;
@@ -976,11 +983,11 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
         if (pendingInY) {
             asm volatile(EM2_MATRIX_TEST_Y
-                         : "=v"(recordOffset), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                         : "=v"(recordOffset), "=v"(recordOffset1), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
                          : "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(logBase), "s"(pendingBase) : EM2_MATRIX_STEP_CLOBBERS);
         } else {
             asm volatile(EM2_MATRIX_TEST_X
-                         : "=v"(recordOffset), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                         : "=v"(recordOffset), "=v"(recordOffset1), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
                          : "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(logBase), "s"(pendingBase) : EM2_MATRIX_STEP_CLOBBERS);
         }
         tested = true;
@@ -988,57 +995,87 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     // the records were stored by one lane and are read back by others: the stores must have left the wave before the
     // caller replays the logs (it reads past the L1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tested && !(diag & 1u)) *recordCount = recordOffset / uint32_t(sizeof(Entry)) - laneId() * logCapacity;
+    if (tested && !(diag & 1u)) {
+        recordCount[0] = recordOffset / uint32_t(sizeof(Entry)) - laneId() * logCapacity;
+        recordCount[1] = recordOffset1 / uint32_t(sizeof(Entry)) - laneId() * logCapacity - halfCapacity;
+    }
     return result;
 }
 
+// The log of `lane` for accumulator a in the wave's log area.
+__device__ __forceinline__ const Entry* walkLogOf(const Entry* waveLog, uint32_t logCapacity, uint32_t lane, uint32_t a)
+{
+    return waveLog + size_t(lane) * logCapacity + a * (logCapacity / 2u);
+}
+
+// A log read a few records ahead of its use (the records were written by another lane: every load goes past the L1, and
+// a replay that waited for each one -- the next record is needed to decide which stream to take from -- spent most of its
+// time in that latency).
+struct WalkLogReader {
+    const Entry* log;
+    uint32_t count, fetched, taken;
+    WalkRecord ahead[4];
+    __device__ __forceinline__ void start(const Entry* l, uint32_t n)
+    {
+        log = l;
+        count = n;
+        fetched = taken = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            ahead[i].code = 0u;
+            ahead[i].dot = 0.f;
+            if (uint32_t(i) < count) ahead[i] = loadWalkRecord(log, uint32_t(i));
+        }
+        fetched = count < 4u ? count : 4u;
+    }
+    __device__ __forceinline__ bool have() const { return taken < count; }
+    __device__ __forceinline__ WalkRecord front() const { return ahead[0]; }
+    __device__ __forceinline__ void pop()
+    {
+        ahead[0] = ahead[1];
+        ahead[1] = ahead[2];
+        ahead[2] = ahead[3];
+        if (fetched < count) ahead[3] = loadWalkRecord(log, fetched);
+        fetched += fetched < count ? 1u : 0u;
+        ++taken;
+    }
+};
+
 // The replay of the walk's logs for the rows of the wave (lane = row, as everywhere outside the walk).  Row r = 32a + t
-// finds its records in the logs of lanes t (columns 8q .. 8q+3 of every group) and 32 + t (columns 8q+4 .. 8q+7), mixed
-// with those of row 32 (1 - a) + t; both logs ascend in the column, and the row's candidates must be offered in ascending
-// order: a two-way merge, every lane its own, all lanes in step.  Per record: the row side through the exact state
-// machine (acceptColumn), the column side -- unless the rows scan all columns themselves (full rows) -- to the inbox if it
-// passes the column's published cut-off, read now (fresher than the one the walk tested against: fewer entries).
+// finds its records in the accumulator-a logs of lanes t (columns 8q .. 8q+3 of every group) and 32 + t (columns 8q+4 ..
+// 8q+7); both ascend in the column, and the row's candidates must be offered in ascending order: a two-way merge, every
+// lane its own, all lanes in step.  Per record: the row side through the exact state machine (acceptColumn), the column
+// side -- unless the rows scan all columns themselves (full rows) -- to the inbox if it passes the column's published
+// cut-off, read now (fresher than the one the walk tested against: fewer entries).
+// recordCount[a] = the calling lane's number of records in its log of accumulator a.
 template <bool IDENTITY>
-__device__ __forceinline__ void replayWalkLogs(const Entry* waveLog, uint32_t logCapacity, uint32_t recordCount, uint32_t lane,
+__device__ __forceinline__ void replayWalkLogs(const Entry* waveLog, uint32_t logCapacity, const uint32_t (&recordCount)[2], uint32_t lane,
                                                uint32_t row, bool rowValid, bool emitColumns, uint32_t listBlock, Entry* myList,
                                                uint32_t twoK, uint32_t& count, int32_t& mMax, uint32_t& emitPos, uint32_t& emitEnd,
                                                unsigned char* ldsRaw)
 {
     const uint32_t t = lane & 31u, a = lane >> 5;
-    const Entry* logs[2] = {waveLog + size_t(t) * logCapacity, waveLog + size_t(t + 32u) * logCapacity};
-    const uint32_t n[2] = {uint32_t(__shfl(int(recordCount), int(t), 64)), uint32_t(__shfl(int(recordCount), int(t + 32u), 64))};
-    uint32_t i[2] = {0u, 0u};
-    WalkRecord next[2];
-    next[0].code = next[1].code = 0u;
-    next[0].dot = next[1].dot = 0.f;
-    // the source's next record of this row's accumulator
-#define EM2_SEEK(h)                                                         \
-    while (i[h] < n[h]) {                                                   \
-        next[h] = loadWalkRecord(logs[h], i[h]);                            \
-        if ((next[h].code & 1u) == a) break;                                \
-        ++i[h];                                                             \
-    }
-    EM2_SEEK(0)
-    EM2_SEEK(1)
+    // the counts of the two source logs: accumulator a of lanes t and 32 + t
+    const uint32_t mine0 = uint32_t(__shfl(int(recordCount[0]), int(t), 64)), mine1 = uint32_t(__shfl(int(recordCount[1]), int(t), 64));
+    const uint32_t theirs0 = uint32_t(__shfl(int(recordCount[0]), int(t + 32u), 64)), theirs1 = uint32_t(__shfl(int(recordCount[1]), int(t + 32u), 64));
+    WalkLogReader lower, upper;
+    lower.start(walkLogOf(waveLog, logCapacity, t, a), a ? mine1 : mine0);
+    upper.start(walkLogOf(waveLog, logCapacity, t + 32u, a), a ? theirs1 : theirs0);
     const int32_t* snap = kernelArgs()->snap;
     for (;;) {
-        const bool have0 = i[0] < n[0], have1 = i[1] < n[1];
+        const bool have0 = lower.have(), have1 = upper.have();
         const bool active = have0 || have1;
         if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
-        const uint32_t col0 = have0 ? walkRecordColumn(next[0].code, 0u) : 0xffffffffu;
-        const uint32_t col1 = have1 ? walkRecordColumn(next[1].code, 1u) : 0xffffffffu;
+        const WalkRecord r0 = lower.front(), r1 = upper.front();
+        const uint32_t col0 = have0 ? walkRecordColumn(r0.code, 0u) : 0xffffffffu;
+        const uint32_t col1 = have1 ? walkRecordColumn(r1.code, 1u) : 0xffffffffu;
         const bool take0 = col0 < col1;                   // (the halves never hold the same column)
         const uint32_t col = take0 ? col0 : col1;
-        const float dot = take0 ? next[0].dot : next[1].dot;
+        const float dot = take0 ? r0.dot : r1.dot;
         const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
         if (active) {
-            if (take0) {
-                ++i[0];
-                EM2_SEEK(0)
-            } else {
-                ++i[1];
-                EM2_SEEK(1)
-            }
+            if (take0) lower.pop();
+            else upper.pop();
         }
         const bool passRow = active && int32_t(m) <= mMax;
         if (__builtin_amdgcn_ballot_w64(passRow) != 0ull) {
@@ -1049,31 +1086,33 @@ __device__ __forceinline__ void replayWalkLogs(const Entry* waveLog, uint32_t lo
             emitColumn(passColumn, col, row, m, lane, emitPos, emitEnd);
         }
     }
-#undef EM2_SEEK
 }
 
-// The tile kernel of the sharded scan defers both sides: every lane empties its own log, order is irrelevant (the inbox
-// is sorted).  rowBase = cell id of the wave's row 0.
-__device__ __forceinline__ void drainWalkLogs(const Entry* waveLog, uint32_t logCapacity, uint32_t recordCount, uint32_t lane,
+// The tile kernel of the sharded scan defers both sides: every lane empties its own two logs, order is irrelevant (the
+// inbox is sorted).  rowBase = cell id of the wave's row 0.
+__device__ __forceinline__ void drainWalkLogs(const Entry* waveLog, uint32_t logCapacity, const uint32_t (&recordCount)[2], uint32_t lane,
                                               uint32_t rowBase, uint32_t cellCount, uint32_t& emitPos, uint32_t& emitEnd)
 {
-    const Entry* log = waveLog + size_t(lane) * logCapacity;
     const int32_t* snap = kernelArgs()->snap;
-    for (uint32_t i = 0;; ++i) {
-        const bool active = i < recordCount;
-        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
-        WalkRecord r;
-        r.code = 0u;
-        r.dot = 0.f;
-        if (active) r = loadWalkRecord(log, i);
-        const uint32_t col = walkRecordColumn(r.code, lane >> 5);
-        const uint32_t rowId = rowBase + 32u * (r.code & 1u) + (lane & 31u);
-        const uint32_t m = uint32_t((kMatrixBits - r.dot) * 0.5f);
-        const bool valid = active && rowId < cellCount;
-        const int32_t snapCol = valid ? snap[col] : -1;
-        const int32_t snapOfRow = valid ? snap[rowId] : -1;
-        emitColumn(valid && int32_t(m) <= snapCol, col, rowId, m, lane, emitPos, emitEnd);        // target col
-        emitColumn(valid && int32_t(m) <= snapOfRow, rowId, col, m, lane, emitPos, emitEnd);      // target row
+#pragma unroll
+    for (uint32_t a = 0; a < 2u; a++) {
+        const Entry* log = walkLogOf(waveLog, logCapacity, lane, a);
+        const uint32_t rowId = rowBase + 32u * a + (lane & 31u);
+        const int32_t snapOfRow = rowId < cellCount ? snap[rowId] : -1;
+        for (uint32_t i = 0;; ++i) {
+            const bool active = i < recordCount[a];
+            if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+            WalkRecord r;
+            r.code = 0u;
+            r.dot = 0.f;
+            if (active) r = loadWalkRecord(log, i);
+            const uint32_t col = walkRecordColumn(r.code, lane >> 5);
+            const uint32_t m = uint32_t((kMatrixBits - r.dot) * 0.5f);
+            const bool valid = active && rowId < cellCount;
+            const int32_t snapCol = valid ? snap[col] : -1;
+            emitColumn(valid && int32_t(m) <= snapCol, col, rowId, m, lane, emitPos, emitEnd);        // target col
+            emitColumn(valid && int32_t(m) <= snapOfRow, rowId, col, m, lane, emitPos, emitEnd);      // target row
+        }
     }
 }
 
@@ -1153,6 +1192,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         const uint32_t commonEnd = last ? quadRowBase : (fullRows ? colEnd & ~31u : colEnd);
         int32_t mMax = rowValid ? aux->mMaxInitial : -1;
         uint32_t count = 0, logCount = 0;
+        uint32_t recordCount[2] = {0u, 0u};          // (hand-scheduled walk: the calling lane's records per accumulator)
         bool haveState = seg == 0u;
         if (seg != 0u && !idle) {
             const uint32_t done = uint32_t(__builtin_amdgcn_readfirstlane(
@@ -1175,10 +1215,9 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         for (;;) {
             if (at < commonEnd) {
                 if (PINNED) {
-                    // (logCount counts the calling LANE's records here, see replayWalkLogs)
                     at = scanTilesMatrixPinned<IDENTITY>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
                                                          rowFragmentBlock, kMatrixBits - 2.f * float(mMax), myLog - size_t(lane) * logCapacity,
-                                                         logCapacity, &logCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
+                                                         logCapacity, recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                          ldsAddress(walkBlock));
                 } else {
                     at = scanTilesMatrix<IDENTITY>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, at, commonEnd,
@@ -1211,9 +1250,10 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
             // replay the log through the exact state machine (ascending column order per row)
             if (PINNED) {
                 if (!idle && !failed) {
-                    replayWalkLogs<IDENTITY>(myLog - size_t(lane) * logCapacity, logCapacity, logCount, lane, row, rowValid, !fullRows,
+                    replayWalkLogs<IDENTITY>(myLog - size_t(lane) * logCapacity, logCapacity, recordCount, lane, row, rowValid, !fullRows,
                                              listBlock, myList, twoK, count, mMax, emitPos, emitEnd, ldsRaw);
                 }
+                recordCount[0] = recordCount[1] = 0u;
             } else if (!idle && !failed) {
                 for (uint32_t i = 0;; ++i) {
                     const bool active = i < logCount;
@@ -1629,10 +1669,10 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
                 Entry* waveLog = aux->logs + size_t(blockIdx.x * 4u + wave) * 64u * logCapacity;
                 uint32_t at = colBegin;
                 while (at < commonEnd) {
-                    uint32_t records = 0;
+                    uint32_t records[2] = {0u, 0u};
                     at = scanTilesMatrixPinned<true, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
                                                            2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), waveLog, logCapacity,
-                                                           &records, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
+                                                           records, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                            ldsAddress(walkBlock));
                     if (!idle) drainWalkLogs(waveLog, logCapacity, records, lane, rowBase, cellCount, emitPos, emitEnd);
                 }

@@ -27,7 +27,8 @@ loop holds no vector value of the compiler's across a step or across the call of
     v[96:111] / v[112:127]  accumulator set Y
     v[48:63]    ring of four column fragments (A operand)
     v[40:47]    two buffers of four column bounds (the previous tile's, this lane's half)
-    v28 byte offset of the lane's next record in the wave's log; v30 / v31 the record (stubs);
+    v28 / v29 byte offsets of the lane's next record for accumulator 0 / 1 in the wave's log area; v30 / v31 the record
+    (stubs);
     v32 lane, then a threshold; v33 / v34 / v35 LDS addresses (tile, bounds, row state), v36 scale, v37 / v38 row bounds,
     v39 the other threshold
 
@@ -37,8 +38,9 @@ accumulator holds row (l & 31) / 32 + (l & 31) and column 8 * (i >> 2) + 4 * (l 
 Test of register i = 4q + j of accumulator a of the previous tile:
     pass = min(rowBound[a], columnBound[8q + 4 * (l >> 5) + j]) <= dot            (q = the "group" of 8 columns)
 A register that passes in some lane branches to its stub behind the body: the passing lanes append a record
-{first column of the tile | 2i + a, dot} (8 bytes) to their OWN log in global memory (v28 = the lane's byte offset into
-the wave's log area, which the step returns; it persists from step to step).  That is all a step does about an event:
+{first column of the tile | 2i + a, dot} (8 bytes) to their OWN log in global memory -- one log per lane and accumulator,
+so that a log holds the records of one row only (v28 / v29 = the lane's byte offsets into the wave's log area, which the
+step returns; they persist from step to step).  That is all a step does about an event:
 which side of the pair the record is for (row, column, both), the exact state machine and the inbox are the business
 of the replay that follows the walk (csrc/em2_scan_symmetric.hip), which reads the logs lane-parallel, many records per
 lane, instead of a few per step.
@@ -53,7 +55,7 @@ RING = 48
 BOUNDS = 40
 LANE, TILE_ADDR, BOUND_ADDR, STATE_ADDR, SCALE, ROW_BOUND0, ROW_BOUND1, THR0 = 32, 33, 34, 35, 36, 37, 38, 39
 THR1 = LANE          # the lane id is dead once the addresses are formed
-OFFSET, RECORD = 28, 30          # v28, v[30:31]
+OFFSET, RECORD = 28, 30          # v28 (accumulator 0) and v29 (accumulator 1), v[30:31]
 FIRST_OWNED = 28
 STEPS = 16
 
@@ -131,12 +133,13 @@ def stubs(s, o, prev0, prev1):
         s.emit("s_mov_b64 exec, %s" % o["pass%d_%d" % (a, k & 1)])
         s.emit("v_or_b32_e64 %s, %s, %d" % (vreg(RECORD), o["tileCode"], 2 * k + a))
         s.emit("v_mov_b32 %s, %s" % (vreg(RECORD + 1), vreg(acc)))
-        s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET), vreg(RECORD, 2), o["logBase"]))
-        s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET), vreg(OFFSET)))
+        s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET + a), vreg(RECORD, 2), o["logBase"]))
+        s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET + a), vreg(OFFSET + a)))
         s.emit("s_mov_b64 exec, %s" % o["save"])
         s.emit("s_branch L_back_%d_%d_%%=" % (k, a))
     s.emit("L_end_%=:")
     s.emit("v_mov_b32 %s, %s" % (o["count"], vreg(OFFSET)))
+    s.emit("v_mov_b32 %s, %s" % (o["count1"], vreg(OFFSET + 1)))
 
 
 def step(cur, prev, tests, operands):
@@ -213,15 +216,16 @@ def main():
     out.write("// em2_matrix_step_asm.h -- GENERATED by tools/gen_matrix_step_asm.py (see there for the register map); do not edit.\n")
     out.write("#ifndef EM2_MATRIX_STEP_ASM_H\n#define EM2_MATRIX_STEP_ASM_H\n\n")
     # Operand order of the asm statements in em2_scan_symmetric.hip:
-    #   step with tests:    %0 the lanes' record offsets ("=v"), %1..%5 five scratch pairs ("=&s", 64 bits: the pass masks in
-    #                       flight, the saved exec), then "s": %6 tileBase, %7 boundBase, %8 stateBase (LDS byte addresses),
-    #                       %9 logBase (64 bits: the wave's log area), %10 tileCode (first column of the tile under test)
+    #   step with tests:    %0 / %1 the lanes' record offsets for accumulator 0 / 1 ("=v"), %2..%6 five scratch pairs ("=&s",
+    #                       64 bits: the pass masks in flight, the saved exec), then "s": %7 tileBase, %8 boundBase,
+    #                       %9 stateBase (LDS byte addresses), %10 logBase (64 bits: the wave's log area), %11 tileCode (first
+    #                       column of the tile under test)
     #   step without tests: %0 tileBase
-    #   test only:          %0 record offsets, %1..%5 scratch pairs, %6 boundBase, %7 stateBase, %8 logBase, %9 tileCode
-    passes = {"pass0_0": "%1", "pass1_0": "%2", "pass0_1": "%3", "pass1_1": "%4", "save": "%5"}
-    with_tests = dict(passes, count="%0", tileBase="%6", boundBase="%7", stateBase="%8", logBase="%9", tileCode="%10")
+    #   test only:          %0 / %1 record offsets, %2..%6 scratch pairs, %7 boundBase, %8 stateBase, %9 logBase, %10 tileCode
+    passes = {"pass0_0": "%2", "pass1_0": "%3", "pass0_1": "%4", "pass1_1": "%5", "save": "%6"}
+    with_tests = dict(passes, count="%0", count1="%1", tileBase="%7", boundBase="%8", stateBase="%9", logBase="%10", tileCode="%11")
     without = {"tileBase": "%0"}
-    only = dict(passes, count="%0", boundBase="%6", stateBase="%7", logBase="%8", tileCode="%9")
+    only = dict(passes, count="%0", count1="%1", boundBase="%7", stateBase="%8", logBase="%9", tileCode="%10")
     for cur, prev in (("X", "Y"), ("Y", "X")):
         out.write(macro("EM2_MATRIX_STEP_%s_TESTING_%s" % (cur, prev), step(cur, prev, True, with_tests)))
         out.write(macro("EM2_MATRIX_STEP_%s" % cur, step(cur, prev, False, without)))
@@ -231,7 +235,7 @@ def main():
     out.write("#define EM2_MATRIX_OWNED_REGISTERS %s\n\n" % owned)
     out.write("#define EM2_MATRIX_STEP_CLOBBERS \"memory\", \"vcc\", \"scc\", EM2_MATRIX_OWNED_REGISTERS\n\n")
     # the lane's record offset lives in a register of the walk from step to step
-    out.write("#define EM2_MATRIX_SET_RECORD_OFFSET \"v_mov_b32 v%d, %%0\\n\"\n\n" % OFFSET)
+    out.write("#define EM2_MATRIX_SET_RECORD_OFFSETS \"v_mov_b32 v%d, %%0\\nv_mov_b32 v%d, %%1\\n\"\n\n" % (OFFSET, OFFSET + 1))
     # the B operand in one go: 32 loads straight into the registers, one wait.  %0 = address of the wave's first row
     # fragment (scalar pair); the fragments of a 32-row block are 1 KB apart (64 lanes x 16 bytes), the second block
     # follows the first

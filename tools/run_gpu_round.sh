@@ -1,2 +1,17 @@
 cd $GRAFT_REPO_ROOT
-for b in ubench_matrix_step ubench_matrix_step_inline; do echo $b; timeout 120 ./tools/ubench/$b | grep -v "^pair"; done
+O=gpurun_out/r52; mkdir -p $O
+run() { # name, env...
+  name=$1; shift
+  env "$@" EM2_SCAN_VERBOSE=1 timeout 600 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra --no-check > $O/$name.json 2> $O/$name.err
+  python - <<PY
+import json
+try:
+    d=json.loads(open("$O/$name.json").read().strip().splitlines()[-1])
+    print("$name", round(d["ms_per_step"],1), round(d["phases_ms_rank0"]["scan"],1), round(d["roofline"]["kernel_ms"],1), d["roofline"]["inbox_entries"])
+except Exception as e:
+    print("$name no json", e); print(open("$O/$name.err").read()[-1500:])
+PY
+}
+run full A=1
+run norecords EM2_MATRIX_DIAG=1
+run full2 A=1
