@@ -32,10 +32,10 @@ __global__ void __launch_bounds__(256) stepLoop(int rounds, int mode, float boun
     const unsigned long long rowAddress = uniform64(reinterpret_cast<unsigned long long>(rows) + size_t(blockIdx.x * 4 + wave) * 32768);
     const unsigned long long logBase = uniform64(reinterpret_cast<unsigned long long>(logs) + size_t(blockIdx.x * 4 + wave) * 64 * 4096 * 8);
     asm volatile(EM2_MATRIX_LOAD_ROWS : : "s"(rowAddress) : EM2_MATRIX_STEP_CLOBBERS);
-    unsigned offset = lane * 4096 * 8;
-    asm volatile(EM2_MATRIX_SET_RECORD_OFFSET : : "v"(offset) : EM2_MATRIX_OWNED_REGISTERS);
+    unsigned offset = lane * 4096 * 8, offset1 = lane * 4096 * 8 + 2048 * 8;
+    asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(offset), "v"(offset1) : EM2_MATRIX_OWNED_REGISTERS);
     unsigned long long scratch[5];
-    unsigned recordOffset = offset;
+    unsigned recordOffset = offset, recordOffset1 = offset1;
     for (int r = 0; r < rounds; r++) {
         const unsigned t0 = unsigned(__builtin_amdgcn_readfirstlane(int(base + ((2 * r) & 3) * 16384)));
         const unsigned t1 = unsigned(__builtin_amdgcn_readfirstlane(int(base + ((2 * r + 1) & 3) * 16384)));
@@ -47,27 +47,27 @@ __global__ void __launch_bounds__(256) stepLoop(int rounds, int mode, float boun
             // the two steps as one statement (tiles of a pair are adjacent in LDS: pairs 0/1 and 2/3)
             const unsigned pairBase = unsigned(__builtin_amdgcn_readfirstlane(int(base + (r & 1) * 32768)));
             asm volatile(EM2_MATRIX_PAIR_TESTING
-                         : "=v"(recordOffset), "=&s"(scratch[0]), "=&s"(scratch[1]), "=&s"(scratch[2]), "=&s"(scratch[3]), "=&s"(scratch[4])
+                         : "=v"(recordOffset), "=v"(recordOffset1), "=&s"(scratch[0]), "=&s"(scratch[1]), "=&s"(scratch[2]), "=&s"(scratch[3]), "=&s"(scratch[4])
                          : "s"(pairBase), "s"(walkLds + 256), "s"(walkLds + 256 + 128), "s"(walkLds), "s"(logBase), "s"(unsigned(r) * 64u),
                            "s"(unsigned(r) * 64u + 32u)
                          : EM2_MATRIX_STEP_CLOBBERS);
             if ((r & 15) == 15) {
-                counts[(blockIdx.x * 4 + wave) * 64 + lane] += (recordOffset - offset) / 8;
-                asm volatile(EM2_MATRIX_SET_RECORD_OFFSET : : "v"(offset) : EM2_MATRIX_OWNED_REGISTERS);
+                counts[(blockIdx.x * 4 + wave) * 64 + lane] += (recordOffset - offset) / 8 + (recordOffset1 - offset1) / 8;
+                asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(offset), "v"(offset1) : EM2_MATRIX_OWNED_REGISTERS);
             }
 #endif
         } else {
             asm volatile(EM2_MATRIX_STEP_X_TESTING_Y
-                         : "=v"(recordOffset), "=&s"(scratch[0]), "=&s"(scratch[1]), "=&s"(scratch[2]), "=&s"(scratch[3]), "=&s"(scratch[4])
+                         : "=v"(recordOffset), "=v"(recordOffset1), "=&s"(scratch[0]), "=&s"(scratch[1]), "=&s"(scratch[2]), "=&s"(scratch[3]), "=&s"(scratch[4])
                          : "s"(t0), "s"(walkLds + 256), "s"(walkLds), "s"(logBase), "s"(unsigned(r) * 64u)
                          : EM2_MATRIX_STEP_CLOBBERS);
             asm volatile(EM2_MATRIX_STEP_Y_TESTING_X
-                         : "=v"(recordOffset), "=&s"(scratch[0]), "=&s"(scratch[1]), "=&s"(scratch[2]), "=&s"(scratch[3]), "=&s"(scratch[4])
+                         : "=v"(recordOffset), "=v"(recordOffset1), "=&s"(scratch[0]), "=&s"(scratch[1]), "=&s"(scratch[2]), "=&s"(scratch[3]), "=&s"(scratch[4])
                          : "s"(t1), "s"(walkLds + 256 + 128), "s"(walkLds), "s"(logBase), "s"(unsigned(r) * 64u + 32u)
                          : EM2_MATRIX_STEP_CLOBBERS);
             if ((r & 15) == 15) {       // (the log of a lane holds 4096 records: start over)
-                counts[(blockIdx.x * 4 + wave) * 64 + lane] += (recordOffset - offset) / 8;
-                asm volatile(EM2_MATRIX_SET_RECORD_OFFSET : : "v"(offset) : EM2_MATRIX_OWNED_REGISTERS);
+                counts[(blockIdx.x * 4 + wave) * 64 + lane] += (recordOffset - offset) / 8 + (recordOffset1 - offset1) / 8;
+                asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(offset), "v"(offset1) : EM2_MATRIX_OWNED_REGISTERS);
             }
         }
     }
