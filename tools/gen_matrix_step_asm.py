@@ -142,6 +142,38 @@ def stubs(s, o, prev0, prev1):
     s.emit("v_mov_b32 %s, %s" % (o["count1"], vreg(OFFSET + 1)))
 
 
+import os
+# Where a k-step's other work goes: the first group between its two MFMAs, the second behind them.  S = scalar half of
+# the previous register's test, M = the two v_min, C = the two v_cmp (after M), D = the fragment read for four k-steps on
+# (behind the second MFMA, which reads the slot it refills) and the bound reads.  The second MFMA cannot issue before the
+# first has left the pipe, and everything behind it waits with it; spreading the work over both shadows is worth 5 % on
+# the step with records (tools/ubench_matrix_step.hip: ",DSMC" 57.1 ms, "M,DCS" 57.4, "SMC,D" 55.7, "S,DMC" 54.5,
+# "SM,DC" 54.1-54.9, "MC,DS" 53.6).  EM2_GEN_PLACE overrides for such experiments.
+PLACE = os.environ.get("EM2_GEN_PLACE", "SM,DC").split(",")
+
+
+def place(s, o, k, what, prev0, prev1, slot):
+    q, j = k >> 2, k & 3
+    bound = BOUNDS + 4 * (q & 1) + j
+    for letter in what:
+        if letter == "S" and k:
+            shift_in(s, o, k - 1)
+        if letter == "M":
+            if j == 0:
+                s.wait_for("bounds%d" % q)
+            s.emit("v_min_f32 %s, %s, %s" % (vreg(THR0), vreg(ROW_BOUND0), vreg(bound)))
+            s.emit("v_min_f32 %s, %s, %s" % (vreg(THR1), vreg(ROW_BOUND1), vreg(bound)))
+        if letter == "D":
+            if k + 4 < STEPS:
+                s.lds("a%d" % (k + 4), "ds_read_b128 %s, %s offset:%d" % (vreg(slot, 4), vreg(TILE_ADDR), 1024 * (k + 4)))
+            if j == 1 and q < 3:
+                s.lds("bounds%d" % (q + 1), "ds_read_b128 %s, %s offset:%d"
+                      % (vreg(BOUNDS + 4 * ((q + 1) & 1), 4), vreg(BOUND_ADDR), 32 * (q + 1)))
+        if letter == "C":
+            s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass0_%d" % (k & 1)], vreg(THR0), vreg(prev0 + k)))
+            s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass1_%d" % (k & 1)], vreg(THR1), vreg(prev1 + k)))
+
+
 def step(cur, prev, tests, operands):
     """cur / prev: 'X' or 'Y'.  operands: placeholder names -> asm operand text."""
     cur0, cur1 = SETS[cur]
@@ -160,28 +192,11 @@ def step(cur, prev, tests, operands):
             s.emit("v_mfma_f32_32x32x64_f8f6f4 %s, %s, %s, %s cbsz:4 blgp:4"
                    % (vreg(acc, 16), vreg(slot, 4), vreg(rows + 4 * k, 4), "0" if k == 0 else vreg(acc, 16)))
             if a == 0 and tests:
-                # part of the k-step's other work goes between its two MFMAs instead of all of it behind the second (the
-                # second cannot issue before the first has left the pipe, and everything behind it waits with it): the
-                # scalar half of the previous register's test and the two v_min here, the fragment read and the compares
-                # behind the second -- 3 % on the step with records in tools/ubench_matrix_step.hip
-                q, j = k >> 2, k & 3
-                if j == 0:
-                    s.wait_for("bounds%d" % q)
-                if k:
-                    shift_in(s, o, k - 1)
-                bound = BOUNDS + 4 * (q & 1) + j
-                s.emit("v_min_f32 %s, %s, %s" % (vreg(THR0), vreg(ROW_BOUND0), vreg(bound)))
-                s.emit("v_min_f32 %s, %s, %s" % (vreg(THR1), vreg(ROW_BOUND1), vreg(bound)))
-        if k + 4 < STEPS:
-            s.lds("a%d" % (k + 4), "ds_read_b128 %s, %s offset:%d" % (vreg(slot, 4), vreg(TILE_ADDR), 1024 * (k + 4)))
+                place(s, o, k, PLACE[0], prev0, prev1, slot)
         if tests:
-            q, j = k >> 2, k & 3
-            if j == 1 and q < 3:
-                # the other buffer: group q - 1 was its last reader, and vector instructions issue in order
-                s.lds("bounds%d" % (q + 1), "ds_read_b128 %s, %s offset:%d"
-                      % (vreg(BOUNDS + 4 * ((q + 1) & 1), 4), vreg(BOUND_ADDR), 32 * (q + 1)))
-            s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass0_%d" % (k & 1)], vreg(THR0), vreg(prev0 + k)))
-            s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass1_%d" % (k & 1)], vreg(THR1), vreg(prev1 + k)))
+            place(s, o, k, PLACE[1], prev0, prev1, slot)
+        elif k + 4 < STEPS:
+            s.lds("a%d" % (k + 4), "ds_read_b128 %s, %s offset:%d" % (vreg(slot, 4), vreg(TILE_ADDR), 1024 * (k + 4)))
     assert not s.queue, s.queue
     if tests:
         shift_in(s, o, STEPS - 1)
