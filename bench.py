@@ -573,7 +573,7 @@ def main():
     if proj_ms > 0 and pipe.rows:
         proj_bytes = 8.0 * nnz_local + 8.0 * G * L + pipe.rows * L / 8.0
         result["roofline_projection"] = {
-            "kernel": "projectionScreenSlicedKernel<32> + projectionExactItemsKernel (rank 0)",
+            "kernel": "projectionScreenQuantizedKernel + projectionScreenItemsKernel + projectionExactItemsKernel (rank 0)",
             "kernel_ms": proj_ms, "bound": "hbm", "achieved": proj_bytes / (proj_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": proj_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": proj_bytes,
             "flop_per_launch": 2.0 * nnz_local * L, "tflops": 2.0 * nnz_local * L / (proj_ms * 1e-3) / 1e12,

@@ -162,6 +162,164 @@ vectorsToFloatKernel(const double* __restrict__ vectors, uint32_t geneCount, uin
 // The float copy of the hyperplanes is slice-major whenever the signature is a whole number of 32-bit slices.
 __host__ __device__ inline bool floatCopyIsSliceMajor(uint32_t lshCount) { return lshCount % 32u == 0u; }
 
+// A 16-bit fixed-point copy of the hyperplanes for the first screening tier, whenever the signature is a whole number
+// of 64-bit words: q[slice of 64 bits][gene][64] = round(U[g][i] / scale_i), scale_i = max_g |U[g][i]| / 32767, so that
+// |U[g][i] - q * scale_i| <= scale_i / 2.  A slice is one contiguous geneCount x 128 B block, like the float copy's.
+__host__ __device__ inline bool haveQuantizedCopy(uint32_t lshCount) { return lshCount % 64u == 0u; }
+
+__global__ void __launch_bounds__(256)
+vectorsToQuantizedKernel(const double* __restrict__ vectors, uint32_t geneCount, uint32_t lshCount,
+                         const double* __restrict__ maxAbs, int16_t* __restrict__ out, double* __restrict__ scales)
+{
+    const uint64_t count = uint64_t(geneCount) * lshCount;
+    for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += uint64_t(gridDim.x) * blockDim.x) {
+        const uint32_t gene = uint32_t(i / lshCount);
+        const uint32_t bit = uint32_t(i % lshCount);
+        const double scale = maxAbs[bit] / 32767.;
+        if (gene == 0u) scales[bit] = scale;
+        double q = scale > 0. ? rint(vectors[i] / scale) : 0.;
+        q = q > 32767. ? 32767. : (q < -32767. ? -32767. : q);
+        out[(uint64_t(bit >> 6) * geneCount + gene) * 64u + (bit & 63u)] = int16_t(int(q));
+    }
+}
+
+// First screening tier on the 16-bit copy, XCD-sliced like projectionScreenSlicedKernel: blockIdx.x & 7 picks the 64-bit
+// word of the signature a block works on, one 128-byte line per entry holds the word's 64 hyperplane values, so the tier
+// gathers HALF the lines of the float tier.  lane = (entry group g = lane / 8, 8 bits sub = lane % 8), one 16-byte load
+// per lane.  The products count * q are exact in double (24 + 15 bits), the sum is scaled once at the end.  Its value
+// differs from the reference's sequentially rounded sum by at most
+//     (n + 12) 2^-52 (|mean| |S_i| + sum|x| max|U_i|)   (rounding on both sides)   +   0.501 scale_i sum|x|   (quantisation)
+// and a bit whose |value| exceeds that has the reference's sign.  The quantisation term is ~250 times the float copy's,
+// so this tier leaves several per cent of the 64-bit words undecided (the float tier: a few 1e-4); those go to the work
+// list like the float tier's, for the exact arithmetic.
+__global__ void __launch_bounds__(256, 4)
+projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t cellCount,
+                                uint32_t geneCount, const int16_t* __restrict__ quantized, const double* __restrict__ scales,
+                                const double* __restrict__ vectorSums, const double* __restrict__ vectorMaxAbs,
+                                const double* __restrict__ means, const double* __restrict__ sumAbs, uint32_t lshCount,
+                                uint32_t wordCount, uint64_t* __restrict__ signatures, uint64_t* __restrict__ workList,
+                                uint32_t* __restrict__ workCount)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t word = blockIdx.y * 8u + (blockIdx.x & 7u);
+    if (word >= wordCount) return;
+    const uint32_t sub = lane & 7u;
+    const uint32_t group = lane >> 3;
+    const int16_t* column = quantized + size_t(word) * geneCount * 64u + sub * 8u;
+    // The 24 per-bit constants of a lane (sum, largest magnitude and scale of its 8 hyperplane columns) are only needed
+    // once per cell, after the gathers: they wait in LDS and are read there through an index the compiler cannot see
+    // through, so that they do not become 48 registers held across the gather loop (146 registers, three waves per SIMD:
+    // the loop lives on latency).
+    __shared__ double bitConstants[3][64];
+    if (threadIdx.x < 64u) {
+        bitConstants[0][threadIdx.x] = vectorSums[word * 64u + threadIdx.x];
+        bitConstants[1][threadIdx.x] = vectorMaxAbs[word * 64u + threadIdx.x];
+        bitConstants[2][threadIdx.x] = scales[word * 64u + threadIdx.x];
+    }
+    __syncthreads();
+    const double* allConstants = &bitConstants[0][0];
+    const uint64_t* entries = reinterpret_cast<const uint64_t*>(data);
+    const uint32_t cellBegin = (blockIdx.x >> 3) * kCellsPerBlock;
+    const uint32_t cellEnd = min(cellBegin + kCellsPerBlock, cellCount);
+    for (uint32_t c = cellBegin + wave; c < cellEnd; c += 4u) {
+        const uint64_t jBegin = toc[c];
+        const uint64_t jEnd = toc[c + 1];
+        double a[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+#define EM2_ACCUMULATE(xv, uv)                                                     \
+        a[0] = __fma_rn(xv, double(int(uv.x << 16) >> 16), a[0]);                   \
+        a[1] = __fma_rn(xv, double(int(uv.x) >> 16), a[1]);                         \
+        a[2] = __fma_rn(xv, double(int(uv.y << 16) >> 16), a[2]);                   \
+        a[3] = __fma_rn(xv, double(int(uv.y) >> 16), a[3]);                         \
+        a[4] = __fma_rn(xv, double(int(uv.z << 16) >> 16), a[4]);                   \
+        a[5] = __fma_rn(xv, double(int(uv.z) >> 16), a[5]);                         \
+        a[6] = __fma_rn(xv, double(int(uv.w << 16) >> 16), a[6]);                   \
+        a[7] = __fma_rn(xv, double(int(uv.w) >> 16), a[7]);
+        uint64_t j = jBegin + group;
+        for (; j + 3u * 8u < jEnd; j += 4u * 8u) {      // 4 entries per lane in flight
+            // The four entries' products are summed in single precision first (packed: two bits per instruction) and that
+            // chunk sum goes into the double accumulator: a quarter of the conversions and double additions.  A product
+            // count * q has 39 significant bits, so it is rounded (2^-24 relative), as are the three additions of a chunk:
+            // at most 8 * 2^-24 * sum|count * q| in all, 3 % of the quantisation term of the bound below.
+            typedef float Float2 __attribute__((ext_vector_type(2)));
+            uint4 u[4];
+            float x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t e = entries[j + 8u * q];
+                u[q] = *reinterpret_cast<const uint4*>(column + size_t(uint32_t(e)) * 64u);
+                x[q] = __uint_as_float(uint32_t(e >> 32));
+            }
+            Float2 chunk[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t w[4] = {u[q].x, u[q].y, u[q].z, u[q].w};
+                const Float2 xx = {x[q], x[q]};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const Float2 qf = {float(int(w[m] << 16) >> 16), float(int(w[m]) >> 16)};
+                    chunk[m] = __builtin_elementwise_fma(xx, qf, chunk[m]);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                a[2 * m] += double(chunk[m].x);
+                a[2 * m + 1] += double(chunk[m].y);
+            }
+        }
+        for (; j < jEnd; j += 8u) {
+            const uint64_t e = entries[j];
+            const uint4 u = *reinterpret_cast<const uint4*>(column + size_t(uint32_t(e)) * 64u);
+            const double x = double(__uint_as_float(uint32_t(e >> 32)));
+            EM2_ACCUMULATE(x, u)
+        }
+#undef EM2_ACCUMULATE
+#pragma unroll
+        for (int d = 8; d < 64; d <<= 1) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a[t] += __shfl_xor(a[t], d, 64);
+        }
+        const double mean = means[c];
+        const double n = double(jEnd - jBegin);
+        const double factor = (n + 12.) * 2.220446049250313e-16 * 1.000001;
+        const double absMean = fabs(mean);
+        const double absX = sumAbs[c];
+        uint32_t byte = 0;
+        bool ambiguous = false;
+        uint32_t firstConstant = sub * 8u;
+        asm volatile("" : "+v"(firstConstant));          // (not loop-invariant as far as the compiler knows)
+        const double* constantsOfLane = allConstants + firstConstant;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const double sT = constantsOfLane[t], mxT = constantsOfLane[64 + t], scaleT = constantsOfLane[128 + t];
+            const double total = __fma_rn(a[t], scaleT, __dmul_rn(-mean, sT));
+            // (+ the single-precision chunks: 8 * 2^-24 * sum|count * q| * scale <= 4.8e-7 * sum|x| * max|U_i|, and a
+            // subnormal slack for them)
+            const double bound = factor * (absMean * fabs(sT) + absX * mxT) + 0.501 * scaleT * absX + 4.8e-7 * absX * mxT +
+                                 n * 1.5e-45 * scaleT + 1e-300;
+            // (a single-precision chunk that overflowed makes the total infinite: undecided as well)
+            ambiguous |= !(fabs(total) > bound) || !(fabs(total) <= 1.7976931348623157e308);
+            byte |= (total > 0.) ? (0x80u >> t) : 0u;                  // first bit most significant
+        }
+        // 8 lanes x 8 bits -> one MSB-first 64-bit word
+        uint64_t w = uint64_t(byte) << (56u - 8u * sub);
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) {
+            const uint32_t lo = uint32_t(__shfl_xor(int(uint32_t(w)), d, 8));
+            const uint32_t hi = uint32_t(__shfl_xor(int(uint32_t(w >> 32)), d, 8));
+            w |= uint64_t(lo) | (uint64_t(hi) << 32);
+        }
+        const uint64_t ambMask = __builtin_amdgcn_ballot_w64(ambiguous);
+        if (lane == 0u) {
+            signatures[size_t(c) * wordCount + word] = w;
+            if ((ambMask & 0xffull) != 0ull) {
+                const uint32_t slot = atomicAdd(workCount, 1u);
+                workList[slot] = (uint64_t(c) << 32) | word;
+            }
+        }
+    }
+}
+
 // Screening pass: one wave = 256 consecutive bits of one cell (4 per lane, one 16-byte load per count).
 __global__ void __launch_bounds__(256)
 projectionScreenKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t cellCount,
@@ -369,6 +527,66 @@ projectionScreenSlicedKernel(const uint64_t* __restrict__ toc, const CountIn* __
     }
 }
 
+// Second screening tier: the (cell, word) items the 16-bit tier could not decide, on the float copy, one wave per item
+// (lane = bit of the word: two 128-byte lines per entry).  Sequential FP64 accumulation in stored order, so the bound of
+// projectionScreenKernel applies ((n + 2) half-ulps).  What is still undecided goes to a second list, for the exact
+// arithmetic.  Requires the slice-major float copy (lshCount % 32 == 0).
+__global__ void __launch_bounds__(256)
+projectionScreenItemsKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t geneCount,
+                            const float* __restrict__ vectors32, const double* __restrict__ vectorSums,
+                            const double* __restrict__ vectorMaxAbs, const double* __restrict__ means,
+                            const double* __restrict__ sumAbs, uint32_t lshCount, uint32_t wordCount,
+                            uint64_t* __restrict__ signatures, const uint64_t* __restrict__ workList,
+                            const uint32_t* __restrict__ workCount, uint64_t* __restrict__ nextList,
+                            uint32_t* __restrict__ nextCount)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t count = *workCount;
+    ScalarPtr64 entries = (ScalarPtr64)(uintptr_t)data;
+    for (uint32_t item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); item < count; item += waves) {
+        const uint64_t it = workList[item];
+        const uint32_t c = uint32_t(it >> 32);
+        const uint32_t word = uint32_t(it);
+        const uint32_t bit = word * 64u + lane;           // < lshCount: the signature is whole words here
+        const float* column = vectors32 + size_t(bit >> 5) * geneCount * 32u + (bit & 31u);
+        const double s = vectorSums[bit];
+        const uint64_t jBegin = toc[c];
+        const uint64_t jEnd = toc[c + 1];
+        const double mean = means[c];
+        double a = __dmul_rn(-mean, s);
+        uint64_t j = jBegin;
+        for (; j + 8u <= jEnd; j += 8u) {            // eight loads in flight, the additions in stored order
+            double u[8], x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint64_t e = entries[j + q];
+                u[q] = double(column[size_t(uint32_t(e)) * 32u]);
+                x[q] = double(__uint_as_float(uint32_t(e >> 32)));
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a = __fma_rn(x[q], u[q], a);
+        }
+        for (; j < jEnd; ++j) {
+            const uint64_t e = entries[j];
+            const double u = double(column[size_t(uint32_t(e)) * 32u]);
+            const double x = double(__uint_as_float(uint32_t(e >> 32)));
+            a = __fma_rn(x, u, a);
+        }
+        const double n = double(jEnd - jBegin);
+        const double factor = (1.01 * 5.9604644775390625e-08 + (n + 2.) * 2.220446049250313e-16) * 1.000001;
+        const double absX = sumAbs[c];
+        const double bound = factor * (fabs(mean) * fabs(s) + absX * vectorMaxAbs[bit]) + absX * 1.5e-45 + 1e-300;
+        const bool ambiguous = !(fabs(a) > bound);
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(a > 0.);
+        const uint64_t ambMask = __builtin_amdgcn_ballot_w64(ambiguous);
+        if (lane == 0u) {
+            signatures[size_t(c) * wordCount + word] = __brevll(mask);
+            if (ambMask != 0ull) nextList[atomicAdd(nextCount, 1u)] = it;
+        }
+    }
+}
+
 // Exact recomputation of the listed (cell, word) items: the arithmetic of projectionKernel, one wave per item.
 __global__ void __launch_bounds__(256)
 projectionExactItemsKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data,
@@ -437,7 +655,10 @@ hipError_t launchProjection(const uint64_t* toc, const CountIn* data, uint32_t c
 
 size_t vectorAuxBytes(uint32_t geneCount, uint32_t lshCount)
 {
-    return 2u * size_t(lshCount) * sizeof(double) + size_t(geneCount) * lshCount * sizeof(float);
+    size_t bytes = 2u * size_t(lshCount) * sizeof(double) + size_t(geneCount) * lshCount * sizeof(float);
+    // the 16-bit copy and its scales (first screening tier)
+    if (haveQuantizedCopy(lshCount)) bytes += size_t(lshCount) * sizeof(double) + size_t(geneCount) * lshCount * sizeof(int16_t);
+    return bytes;
 }
 
 hipError_t launchPrepareVectors(const double* vectors, uint32_t geneCount, uint32_t lshCount, void* aux, hipStream_t stream)
@@ -455,6 +676,11 @@ hipError_t launchPrepareVectors(const double* vectors, uint32_t geneCount, uint3
         if (blocks > 16384) blocks = 16384;
         vectorsToFloatKernel<<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(vectors, geneCount, lshCount,
                                                                                floatCopyIsSliceMajor(lshCount), vectors32);
+        if (haveQuantizedCopy(lshCount)) {
+            double* scales = reinterpret_cast<double*>(vectors32 + count);
+            int16_t* quantized = reinterpret_cast<int16_t*>(scales + lshCount);
+            vectorsToQuantizedKernel<<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(vectors, geneCount, lshCount, maxAbs, quantized, scales);
+        }
     }
     return hipGetLastError();
 }
@@ -491,7 +717,18 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
     // whenever the signature is a whole number of 32-bit slices.
     const char* mode = getenv("EM2_PROJECTION");
     const bool sliced = lshCount % 32u == 0u && !(mode && mode[0] == 's' && mode[1] == 'c');
-    if (sliced) {
+    // Default whenever the signature is a whole number of 64-bit words: the first tier on the 16-bit fixed-point copy (half
+    // the gathers), what it cannot decide to the float tier on the listed words, the rest of that to the exact arithmetic.
+    // EM2_PROJECTION=sliced / sliced16 / screen keep the float forms as the first tier (A/B measurements).
+    const bool quantizedTier = haveQuantizedCopy(lshCount) && (!mode || mode[0] == 'q');
+    if (quantizedTier) {
+        const double* scales = reinterpret_cast<const double*>(vectors32 + size_t(geneCount) * lshCount);
+        const int16_t* quantized = reinterpret_cast<const int16_t*>(scales + lshCount);
+        const uint32_t cellBlocks = (cellCount + kCellsPerBlock - 1u) / kCellsPerBlock;
+        const dim3 grid(cellBlocks * 8u, (wordCount + 7u) / 8u);
+        projectionScreenQuantizedKernel<<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, quantized, scales, sums, maxAbs, means,
+                                                                        sumAbs, lshCount, wordCount, signatures, workList, workCount);
+    } else if (sliced) {
         e = hipMemsetAsync(signatures, 0, size_t(cellCount) * wordCount * sizeof(uint64_t), stream);    // halves nobody owns
         if (e != hipSuccess) return e;
         const bool narrow = mode && mode[0] == 's' && mode[1] == 'l' && strstr(mode, "16") != nullptr;      // EM2_PROJECTION=sliced16
@@ -512,6 +749,18 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (quantizedTier) {
+        // second tier on the float copy for what the 16-bit tier left; its own leftovers form a second list (the work
+        // area holds 4 slots per word: the second list starts at slot cellCount * wordCount)
+        uint64_t* nextList = workList + size_t(cellCount) * wordCount;
+        uint32_t* nextCount = workCount + 16;
+        projectionScreenItemsKernel<<<dim3(2048), dim3(256), 0, stream>>>(toc, data, geneCount, vectors32, sums, maxAbs, means, sumAbs, lshCount,
+                                                                          wordCount, signatures, workList, workCount, nextList, nextCount);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        workList = nextList;
+        workCount = nextCount;
+    }
     projectionExactItemsKernel<<<dim3(1024), dim3(256), 0, stream>>>(toc, data, vectors, sums, means, lshCount, wordCount,
                                                                      signatures, workList, workCount);
     return hipGetLastError();

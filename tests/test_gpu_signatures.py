@@ -84,16 +84,44 @@ def test_screening_pass_defers_to_exact_arithmetic_when_it_cannot_decide(oracle)
     assert 0.3 * cells * L < ones < 0.7 * cells * L            # the signs are genuinely mixed
 
 
-@pytest.mark.parametrize("mode", ["exact", "screened"])
+@pytest.mark.parametrize("mode", ["exact", "default", "sliced", "sliced16", "screen"])
 def test_exact_only_and_screened_paths_agree_with_oracle(oracle, mode, monkeypatch):
+    """default = 16-bit fixed-point first tier -> float tier on the undecided words -> exact arithmetic; sliced / sliced16 /
+    screen = the float forms as first tier; exact = no screening at all."""
     cells, genes, L = 800, 3000, 1024
     toc, g, c = synth.expression_matrix(cells, genes, density=0.02, cluster_count=6, seed=9)
     vectors = oracle.generate_lsh_vectors(genes, L, 231)
     expect = oracle.compute_signatures(toc, g, c, genes, vectors, L)
-    if mode == "exact":
-        monkeypatch.setenv("EM2_PROJECTION", "exact")
+    if mode != "default":
+        monkeypatch.setenv("EM2_PROJECTION", mode)
     got = capi.compute_signatures(toc, capi.make_counts(g, c), genes, vectors, L)
     assert np.array_equal(got, expect)
+
+
+@pytest.mark.parametrize("cells,genes,L,density,count_scale", [
+    (40000, 20000, 1024, 0.01, 1.0),          # BASELINE configs[1]-like rows: ~200 counts per cell
+    (20000, 5000, 512, 0.2, 1.0),             # 1000 counts per cell
+    (30000, 2000, 256, 0.0015, 1.0),          # three counts per cell, many cells with one or none
+    (5000, 3000, 1024, 0.05, 1e30),           # counts whose products overflow single precision in the 16-bit tier
+    (5000, 3000, 1024, 0.05, 1e-36),          # ... and underflow it
+])
+def test_tiers_equal_exact_arithmetic_on_many_cells(cells, genes, L, density, count_scale, monkeypatch):
+    """The screening tiers only ever decide a bit when their bound says the exact sequential FP64 sum has that sign: on
+    tens of millions of bits the default path (16-bit tier, float tier, exact) must reproduce the exact-arithmetic kernel
+    (EM2_PROJECTION=exact, itself bit-exact against the oracle in the tests above) everywhere."""
+    toc, g, c = synth.expression_matrix(cells, genes, density=density, cluster_count=7, seed=cells + L)
+    c = (c.astype(np.float64) * count_scale).astype(np.float32)
+    idx = np.arange(genes * L, dtype=np.uint64).reshape(genes, L)
+    vectors = synth.uniform01(11, idx) - 0.5
+    vectors /= np.sqrt((vectors * vectors).sum(axis=0))
+    data = capi.make_counts(g, c)
+    monkeypatch.setenv("EM2_PROJECTION", "exact")
+    exact = capi.compute_signatures(toc, data, genes, vectors, L)
+    monkeypatch.delenv("EM2_PROJECTION")
+    got = capi.compute_signatures(toc, data, genes, vectors, L)
+    assert np.array_equal(got, exact)
+    monkeypatch.setenv("EM2_PROJECTION", "sliced")
+    assert np.array_equal(capi.compute_signatures(toc, data, genes, vectors, L), exact)
 
 
 def test_screening_with_huge_and_tiny_magnitudes(oracle):
