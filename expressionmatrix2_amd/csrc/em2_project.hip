@@ -166,6 +166,7 @@ __host__ __device__ inline bool floatCopyIsSliceMajor(uint32_t lshCount) { retur
 // of 64-bit words: q[slice of 64 bits][gene][64] = round(U[g][i] / scale_i), scale_i = max_g |U[g][i]| / 32767, so that
 // |U[g][i] - q * scale_i| <= scale_i / 2.  A slice is one contiguous geneCount x 128 B block, like the float copy's.
 __host__ __device__ inline bool haveQuantizedCopy(uint32_t lshCount) { return lshCount % 64u == 0u; }
+constexpr uint32_t kQuantizedInFlight = 4;       // entries per lane in flight in the 16-bit tier (8: 124 registers, four waves per SIMD instead of five, 44 ms instead of 40.6)
 
 __global__ void __launch_bounds__(256)
 vectorsToQuantizedKernel(const double* __restrict__ vectors, uint32_t geneCount, uint32_t lshCount,
@@ -236,35 +237,39 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
         a[6] = __fma_rn(xv, double(int(uv.w << 16) >> 16), a[6]);                   \
         a[7] = __fma_rn(xv, double(int(uv.w) >> 16), a[7]);
         uint64_t j = jBegin + group;
-        for (; j + 3u * 8u < jEnd; j += 4u * 8u) {      // 4 entries per lane in flight
-            // The four entries' products are summed in single precision first (packed: two bits per instruction) and that
-            // chunk sum goes into the double accumulator: a quarter of the conversions and double additions.  A product
-            // count * q has 39 significant bits, so it is rounded (2^-24 relative), as are the three additions of a chunk:
-            // at most 8 * 2^-24 * sum|count * q| in all, 3 % of the quantisation term of the bound below.
-            typedef float Float2 __attribute__((ext_vector_type(2)));
-            uint4 u[4];
-            float x[4];
+        typedef float Float2 __attribute__((ext_vector_type(2)));
+        // The products of four entries are summed in single precision first (packed: two bits per instruction) and that
+        // chunk sum goes into the double accumulator: a quarter of the conversions and double additions.  A product
+        // count * q has 39 significant bits, so it is rounded (2^-24 relative), as are the three additions of a chunk:
+        // at most 8 * 2^-24 * sum|count * q| in all, 3 % of the quantisation term of the bound below.
+        // kQuantizedInFlight entries per lane are in flight (one or two chunks).
+        for (; j + (kQuantizedInFlight - 1u) * 8u < jEnd; j += kQuantizedInFlight * 8u) {
+            uint4 u[kQuantizedInFlight];
+            float x[kQuantizedInFlight];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (uint32_t q = 0; q < kQuantizedInFlight; ++q) {
                 const uint64_t e = entries[j + 8u * q];
                 u[q] = *reinterpret_cast<const uint4*>(column + size_t(uint32_t(e)) * 64u);
                 x[q] = __uint_as_float(uint32_t(e >> 32));
             }
-            Float2 chunk[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t w[4] = {u[q].x, u[q].y, u[q].z, u[q].w};
-                const Float2 xx = {x[q], x[q]};
+            for (uint32_t first = 0; first < kQuantizedInFlight; first += 4u) {
+                Float2 chunk[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+                for (uint32_t q = first; q < first + 4u; ++q) {
+                    const uint32_t w[4] = {u[q].x, u[q].y, u[q].z, u[q].w};
+                    const Float2 xx = {x[q], x[q]};
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const Float2 qf = {float(int(w[m] << 16) >> 16), float(int(w[m]) >> 16)};
+                        chunk[m] = __builtin_elementwise_fma(xx, qf, chunk[m]);
+                    }
+                }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    const Float2 qf = {float(int(w[m] << 16) >> 16), float(int(w[m]) >> 16)};
-                    chunk[m] = __builtin_elementwise_fma(xx, qf, chunk[m]);
+                    a[2 * m] += double(chunk[m].x);
+                    a[2 * m + 1] += double(chunk[m].y);
                 }
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                a[2 * m] += double(chunk[m].x);
-                a[2 * m + 1] += double(chunk[m].y);
             }
         }
         for (; j < jEnd; j += 8u) {
