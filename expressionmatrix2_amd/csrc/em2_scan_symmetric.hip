@@ -781,13 +781,13 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
     return uint64_t(uniform(uint32_t(v))) | (uint64_t(uniform(uint32_t(v >> 32))) << 32);
 }
 
-// The lane id, recomputed wherever it is used: a volatile asm is neither hoisted out of the walk's loop nor merged
-// with an earlier one, so nothing derived from it stays alive across a step (where it would need one of the few
-// registers the steps leave to the compiler).
+// The lane id.  (While the walk still handled its events between the steps this was a volatile asm, recomputed wherever it
+// was used, so that nothing derived from it stayed alive across a step, where it would have needed one of the few
+// registers the steps leave to the compiler; the walk's own code is small now and keeps it.)
 __device__ __forceinline__ uint32_t laneId()
 {
     uint32_t lane;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    asm("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
     return lane;
 }
 
@@ -844,14 +844,19 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     const uint64_t logBase = uniform64(reinterpret_cast<uint64_t>(waveLogArg));
     const uint32_t diag = ((ArgsPtr)uniform64(reinterpret_cast<uint64_t>(auxArg)))->pad2;
     const uint32_t halfCapacity = logCapacity / 2u;
-    const uint32_t initialCount0 = recordCount[0], initialCount1 = recordCount[1];
+    // byte offsets into the wave's log area: where the lane's two logs begin, where its next records go (kept in two
+    // registers of the walk; the steps return them), and beyond which the walk has to stop
+    const uint32_t firstOffset0 = laneId() * logCapacity * uint32_t(sizeof(Entry));
+    const uint32_t firstOffset1 = firstOffset0 + halfCapacity * uint32_t(sizeof(Entry));
+    const uint32_t stopRecords = halfCapacity > kMatrixLogMargin / 2u ? halfCapacity - kMatrixLogMargin / 2u : 0u;
+    const uint32_t stopOffset0 = firstOffset0 + stopRecords * uint32_t(sizeof(Entry));
+    const uint32_t stopOffset1 = firstOffset1 + stopRecords * uint32_t(sizeof(Entry));
+    uint32_t recordOffset = firstOffset0 + recordCount[0] * uint32_t(sizeof(Entry));
+    uint32_t recordOffset1 = firstOffset1 + recordCount[1] * uint32_t(sizeof(Entry));
     {
         const uint32_t lane = laneId();
         ldsPointer<LdsFloatPtr>(walkLds + kWalkRowDot)[lane] = rowDotArg;         // for the steps: float[64], lane = row
-        // the lane's next records: byte offsets into the wave's log area, kept in two registers of the walk
-        const uint32_t offset0 = (lane * logCapacity + initialCount0) * uint32_t(sizeof(Entry));
-        const uint32_t offset1 = (lane * logCapacity + halfCapacity + initialCount1) * uint32_t(sizeof(Entry));
-        asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(offset0), "v"(offset1) : EM2_MATRIX_OWNED_REGISTERS);
+        asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(recordOffset), "v"(recordOffset1) : EM2_MATRIX_OWNED_REGISTERS);
         // the B operand: the 2 x 16 fragments of the wave's rows straight into their registers (v128..v255)
         const uint64_t rowFragments = reinterpret_cast<uint64_t>(fragments) + size_t(rowFragmentBlock) * kMatrixTileWords * 16u;
         asm volatile(EM2_MATRIX_LOAD_ROWS : : "s"(rowFragments) : EM2_MATRIX_STEP_CLOBBERS);
@@ -897,7 +902,6 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     EM2_STAGE_SNAP(colBegin, 0u);
     EM2_WAIT_STAGED();
     __syncthreads();
-    uint32_t recordOffset = 0, recordOffset1 = 0;       // per lane: where its next records go, as the last step with tests left them
     bool tested = false;
     uint64_t passScratch[5];        // scalar pairs for the steps: pass masks in flight, saved exec
     bool pending = false, pendingInY = false;
@@ -951,17 +955,12 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
             pendingSlot = 2u * pair + 1u;
         }
         if (diag & 1u) {            // (measurements: the records are written, then dropped)
-            const uint32_t offset0 = laneId() * logCapacity * uint32_t(sizeof(Entry));
-            const uint32_t offset1 = offset0 + halfCapacity * uint32_t(sizeof(Entry));
-            asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(offset0), "v"(offset1) : EM2_MATRIX_OWNED_REGISTERS);
-            recordOffset = offset0;
-            recordOffset1 = offset1;
+            asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(firstOffset0), "v"(firstOffset1) : EM2_MATRIX_OWNED_REGISTERS);
+            recordOffset = firstOffset0;
+            recordOffset1 = firstOffset1;
         }
         // the untested tile and the next pair add at most 48 records to a log before the next chance to stop
-        const uint32_t records0 = tested ? recordOffset / uint32_t(sizeof(Entry)) - laneId() * logCapacity : initialCount0;
-        const uint32_t records1 = tested ? recordOffset1 / uint32_t(sizeof(Entry)) - laneId() * logCapacity - halfCapacity : initialCount1;
-        const uint32_t records = records0 > records1 ? records0 : records1;
-        const bool full = __builtin_amdgcn_ballot_w64(records + kMatrixLogMargin / 2u > halfCapacity) != 0ull;
+        const bool full = __builtin_amdgcn_ballot_w64(recordOffset > stopOffset0 || recordOffset1 > stopOffset1) != 0ull;
         const uint32_t slot = iteration % 3u;
         if (full && laneId() == 0u) stopWords[slot] = 1u;
         if (waveSlot == 0u && laneId() == 0u) stopWords[(iteration + 1u) % 3u] = 0u;
@@ -996,8 +995,8 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     // caller replays the logs (it reads past the L1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tested && !(diag & 1u)) {
-        recordCount[0] = recordOffset / uint32_t(sizeof(Entry)) - laneId() * logCapacity;
-        recordCount[1] = recordOffset1 / uint32_t(sizeof(Entry)) - laneId() * logCapacity - halfCapacity;
+        recordCount[0] = (recordOffset - firstOffset0) / uint32_t(sizeof(Entry));
+        recordCount[1] = (recordOffset1 - firstOffset1) / uint32_t(sizeof(Entry));
     }
     return result;
 }

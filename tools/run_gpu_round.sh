@@ -1,12 +1,17 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r59; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_signatures.py -x -q 2>&1 | tail -3
-R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --check-rows 64 > $R/$O/prof.log 2>&1
-f=$(find $R/$O/prof -name "*kernel_stats.csv" | head -1); python3 - <<PY
-import csv
-rows=list(csv.DictReader(open("$f")))
-for r in rows[:5]: print(r["Name"][:70], r["Calls"], round(float(r["AverageNs"])/1e6,2))
+O=gpurun_out/r60; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_fsp4.py -x -q 2>&1 | tail -3
+run() { # name, env...
+  name=$1; shift
+  env "$@" timeout 600 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra --check-rows 64 > $O/$name.json 2> $O/$name.err
+  python - <<PY
+import json
+try:
+    d=json.loads(open("$O/$name.json").read().strip().splitlines()[-1])
+    print("$name", round(d["ms_per_step"],1), d["phases_ms_rank0"], round(d["roofline"]["kernel_ms"],1), d["parity_check"])
+except Exception as e:
+    print("$name no json", e); print(open("$O/$name.err").read()[-1500:])
 PY
-find $R/$O/prof -name "*kernel_trace.csv" -delete
+}
+run full A=1
+run full2 A=1
