@@ -786,9 +786,7 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 // registers the steps leave to the compiler; the walk's own code is small now and keeps it.)
 __device__ __forceinline__ uint32_t laneId()
 {
-    uint32_t lane;
-    asm("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-    return lane;
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
 // A record of the walk: the step's stub wrote {first column of the tile | 2i + a, dot} into the log of the LANE in which
@@ -825,7 +823,7 @@ __device__ __forceinline__ WalkRecord loadWalkRecord(const Entry* log, uint32_t 
 // records in its log of accumulator a.  It returns the first column not scanned, the same in all waves of the block: it
 // ends early, at a pair boundary, when some log could overflow within the next three tiles (48 records: a tile has 16
 // registers per accumulator).  The caller replays the logs (replayWalkLogs / drainWalkLogs) and calls again.
-template <bool IDENTITY, bool BOTH = false>
+template <bool IDENTITY, bool BOTH = false, bool DIAG = false>
 __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* auxArg, const void* fragmentsArg, const void* snapArg,
                                                                     uint32_t colBeginArg, uint32_t colEndArg,
                                                                     uint32_t rowFragmentBlockArg, float rowDotArg,
@@ -842,7 +840,9 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     const LdsFloatPtr boundScratch = ldsPointer<LdsFloatPtr>(walkLds + kWalkBounds);
     const LdsIntPtr snapStage = ldsPointer<LdsIntPtr>(walkLds + kWalkSnapStage);
     const uint64_t logBase = uniform64(reinterpret_cast<uint64_t>(waveLogArg));
-    const uint32_t diag = ((ArgsPtr)uniform64(reinterpret_cast<uint64_t>(auxArg)))->pad2;
+    // (EM2_MATRIX_DIAG, measurements only: the walk that looks at the bits is an instantiation of its own, so that the
+    // one that runs in production has none of their branches between its steps)
+    const uint32_t diag = DIAG ? ((ArgsPtr)uniform64(reinterpret_cast<uint64_t>(auxArg)))->pad2 : 0u;
     const uint32_t halfCapacity = logCapacity / 2u;
     // byte offsets into the wave's log area: where the lane's two logs begin, where its next records go (kept in two
     // registers of the walk; the steps return them), and beyond which the walk has to stop
@@ -908,12 +908,12 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     uint32_t pendingBase = 0, pendingSlot = 0;
     uint32_t iteration = 0;
     uint32_t result = colEnd;
+    // the staged cut-offs of the pair about to be walked (lane = column); those of the next pair are read right behind
+    // the barrier that ends a pair, together with the stop word: one LDS round trip there instead of two
+    int32_t stagedSnap = snapStage[laneId()];
     for (uint32_t colBase = colBegin; colBase < colEnd; colBase += 64u, ++iteration) {
         const uint32_t pair = iteration & 1u;
-        {
-            const uint32_t lane = laneId();
-            boundScratch[pair * 64u + lane] = kMatrixBits - 2.f * float(snapStage[pair * 64u + lane]);
-        }
+        boundScratch[pair * 64u + laneId()] = kMatrixBits - 2.f * float(stagedSnap);
         if (colBase + 64u < colEnd) {
             EM2_STAGE_TILE(colBase / 32u + 2u, 2u * (pair ^ 1u));
             EM2_STAGE_SNAP(colBase + 64u, pair ^ 1u);
@@ -966,7 +966,9 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         if (waveSlot == 0u && laneId() == 0u) stopWords[(iteration + 1u) % 3u] = 0u;
         if (!(diag & 128u)) EM2_WAIT_STAGED();          // (128: measurements only -- the tiles are used before they have arrived)
         if (!(diag & 64u)) __syncthreads();
-        if (stopWords[slot] != 0u) {
+        const uint32_t stop = stopWords[slot];
+        stagedSnap = snapStage[(pair ^ 1u) * 64u + laneId()];
+        if (stop != 0u) {
             __syncthreads();
             if (waveSlot == 0u && laneId() == 0u) stopWords[slot] = 0u;
             __syncthreads();
@@ -1214,10 +1216,17 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         for (;;) {
             if (at < commonEnd) {
                 if (PINNED) {
-                    at = scanTilesMatrixPinned<IDENTITY>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
+                    if (aux->pad2) {
+                        at = scanTilesMatrixPinned<IDENTITY, false, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
                                                          rowFragmentBlock, kMatrixBits - 2.f * float(mMax), myLog - size_t(lane) * logCapacity,
                                                          logCapacity, recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                          ldsAddress(walkBlock));
+                    } else {
+                        at = scanTilesMatrixPinned<IDENTITY, false, false>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
+                                                         rowFragmentBlock, kMatrixBits - 2.f * float(mMax), myLog - size_t(lane) * logCapacity,
+                                                         logCapacity, recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
+                                                         ldsAddress(walkBlock));
+                    }
                 } else {
                     at = scanTilesMatrix<IDENTITY>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, at, commonEnd,
                                                    rowFragmentBlock, kMatrixBits - 2.f * float(mMax), row, rowValid && !fullRows, lane, myLog,
@@ -1669,10 +1678,17 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
                 uint32_t at = colBegin;
                 while (at < commonEnd) {
                     uint32_t records[2] = {0u, 0u};
-                    at = scanTilesMatrixPinned<true, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
+                    if (aux->pad2) {
+                        at = scanTilesMatrixPinned<true, true, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
                                                            2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), waveLog, logCapacity,
                                                            records, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                            ldsAddress(walkBlock));
+                    } else {
+                        at = scanTilesMatrixPinned<true, true, false>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
+                                                           2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), waveLog, logCapacity,
+                                                           records, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
+                                                           ldsAddress(walkBlock));
+                    }
                     if (!idle) drainWalkLogs(waveLog, logCapacity, records, lane, rowBase, cellCount, emitPos, emitEnd);
                 }
             } else {
