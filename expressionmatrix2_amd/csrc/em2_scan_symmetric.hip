@@ -731,16 +731,14 @@ __device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restr
 //  * the results stay in the accumulator layout -- lane l, register i of accumulator a = row 32a + (l & 31), column
 //    8 (i >> 2) + 4 (l >> 5) + (i & 3) -- and are tested there against min(row bound, column bound): no
 //    v_permlane32_swap, no v_readlane; the column bounds of a tile travel through 128 bytes of LDS per wave and come
-//    back as four 16-byte reads per lane half; the row state the events need (bound, validity, log count) is kept in
-//    that layout for the length of the walk;
+//    back as four 16-byte reads per lane half;
 //  * two accumulator sets: the step of tile t carries the test of tile t-1 between its MFMAs (2 VALU + 1 SALU per
-//    result, 6 per k-step), so a wave never leaves the matrix pipe idle for its column tests; only groups of 8
-//    columns x 64 rows in which something passed are looked at again, by the compiler's code (matrixEvents).
-// Everything the step touches is pinned to physical registers by the asm constraints (register map in the generator).
-// A row's log must list its columns in ascending order (the replay offers them in that order): within a group the
-// lower lane half holds columns 8q .. 8q+3 and the upper half 8q+4 .. 8q+7, so the events of a group are logged half
-// by half.  The walk may stop only at a pair boundary, where one tile is still untested: the stop rule therefore
-// keeps room for three tiles (96 entries) instead of two.
+//    result), so a wave never leaves the matrix pipe idle for its column tests;
+//  * a result that passes is only LOGGED by the step (one 8-byte record into the log of the lane and accumulator it
+//    passed in); which side of the pair it is for, the exact state machine and the inbox are the replay's
+//    (replayWalkLogs, drainWalkLogs), which handles many records per lane at a time instead of a few per step.
+// Everything the step touches is pinned to physical registers (register map in the generator).  The walk may stop only
+// at a pair boundary, where one tile is still untested: the stop rule keeps room for three tiles.
 // =========================================================================================================
 
 // LDS byte address of a pointer into the block's dynamic LDS
