@@ -159,7 +159,7 @@ def synthetic_signatures(torch, cells, lsh_count, device, cluster_count=64, flip
     return out
 
 
-def bench_fsp5(args, capi, oracle, device, torch):
+def bench_fsp5(args, capi, oracle, device, torch, check_ranges=3):
     """BASELINE configs[3] on one GPU: bucketed findSimilarPairs5, 2048-bit signatures, lshSliceLength 20, bucketOverflow
     1000, k=100.  One step = em2_dev_find_similar_pairs5 over all cells (tables + candidate filter + selection)."""
     C, L, k, thr, q = args.cells, 2048 if args.lsh_count == 1024 else args.lsh_count, args.k, args.threshold, args.slice_length
@@ -178,7 +178,7 @@ def bench_fsp5(args, capi, oracle, device, torch):
     if not args.no_check:
         sig_host = sig.cpu().numpy().view(np.uint64)
         rows = 0
-        for begin in (0, C // 2, max(0, C - 8)):
+        for begin in (0, C // 2, max(0, C - 8))[:check_ranges]:
             end = min(C, begin + 8)
             cell, sim, oused = oracle.find_similar_pairs5_rows(sig_host, L, k, thr, q, args.bucket_overflow, begin, end)
             got = pairs[begin:end].cpu().numpy().view(np.uint32)
@@ -620,6 +620,19 @@ def main():
         del pipe, toc, data, vectors
         torch.cuda.empty_cache()
         result["extra"] = {"configs[1]": small_config(args, capi, sharded, synthetic, oracle, device, torch)}
+        # BASELINE configs[3] (bucketed findSimilarPairs5, 2048 bit) and configs[4] (findSimilarPairs4 -> createCellGraph ->
+        # label propagation) at their 1-GPU sizes, a few steps each: the secondary lines of --workload fsp5 / chain,
+        # abridged, so that they are on the line the driver records (never the headline)
+        import copy
+        small = copy.copy(args)
+        small.steps, small.warmup = 2, 1
+        line = bench_fsp5(small, capi, oracle, device, torch, check_ranges=1)
+        result["extra"]["configs[3]"] = {key: line[key] for key in ("metric", "value", "unit", "ms_per_step", "steps", "config",
+                                                                     "phases_ms", "roofline", "parity_check")}
+        torch.cuda.empty_cache()
+        line = bench_chain(small, capi, sharded, synthetic, oracle, device, torch)
+        result["extra"]["configs[4]"] = {key: line[key] for key in ("metric", "value", "unit", "ms_per_step", "steps", "config",
+                                                                     "phases_ms", "parity_check", "note")}
     if world > 1:
         # ---- diagnostics of the multi-GPU step, outside the timed region: wall ms per stage and per collective with a device
         # synchronisation after each (so the stages do not overlap as they do in the measurement), MAX over the ranks ----
