@@ -2,8 +2,8 @@
 """Checks the compiled kernels of the hand-scheduled matrix-core walk (fsp4ScanMatrixPinnedKernel,
 fsp4TileMatrixPinnedKernel, csrc/em2_scan_symmetric.hip): the steps keep the wave's rows and accumulators in v64..v255
 without the compiler knowing (tools/gen_matrix_step_asm.py), so the compiler's own code in those kernels must never
-touch those registers (amdgpu_num_vgpr(64) is what should guarantee it), should not spill between the steps, and must
-not use flat_ instructions there (their out-of-order completion would break the counted LDS waits).
+touch those registers -- nor v28 / v29, which hold the lane's record offsets from step to step --, should not spill between
+the steps, and must not use flat_ instructions there (their out-of-order completion would break the counted LDS waits).
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off --cuda-device-only -S -o /tmp/sym.s em2_scan_symmetric.hip
     python3 tools/check_matrix_walk_registers.py /tmp/sym.s
@@ -11,7 +11,8 @@ not use flat_ instructions there (their out-of-order completion would break the 
 import re
 import sys
 
-OWNED_FIRST = 64          # v38..v63 are the steps' temporaries: dead between steps, the compiler may use them there
+OWNED_FIRST = 64          # v30..v63 are the steps' temporaries: dead between steps, the compiler may use them there
+PERSISTENT = (28, 29)     # ... but v28 / v29 hold the lane's record offsets from step to step
 
 
 def functions(lines):
@@ -54,7 +55,8 @@ def main():
                 continue
             if in_asm or line.lstrip().startswith((";", ".")):
                 continue
-            bad = [r for r in registers(line) if r >= OWNED_FIRST]
+            between = first_step is not None and first_step <= i <= last_step
+            bad = [r for r in registers(line) if r >= OWNED_FIRST or (between and r in PERSISTENT)]
             if bad:
                 print("%s: compiler code touches v%d between the steps: %s" % (name, bad[0], line.strip()))
                 failures += 1
