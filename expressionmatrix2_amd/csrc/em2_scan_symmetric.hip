@@ -872,6 +872,7 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         const uint64_t src_ = reinterpret_cast<uint64_t>(fragments) + (size_t(tileIndex) * kMatrixTileWords + waveSlot) * 16u + \
                               laneId() * 16u;                                                                                 \
         const uint32_t dst_ = tilesLds + ((buffer) * kMatrixTileWords + waveSlot) * 16u;                                     \
+        /* (one address register per piece: the instruction's offset field would move the LDS address as well) */            \
         asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"                                      \
                      "s_add_u32 m0, %4, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"                              \
                      "s_add_u32 m0, %4, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"                              \
@@ -904,7 +905,7 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     uint64_t passScratch[5];        // scalar pairs for the steps: pass masks in flight, saved exec
     bool pending = false, pendingInY = false;
     uint32_t pendingBase = 0, pendingSlot = 0;
-    uint32_t iteration = 0;
+    uint32_t iteration = 0, stopSlot = 0;
     uint32_t result = colEnd;
     // the staged cut-offs of the pair about to be walked (lane = column); those of the next pair are read right behind
     // the barrier that ends a pair, together with the stop word: one LDS round trip there instead of two
@@ -959,9 +960,10 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         }
         // the untested tile and the next pair add at most 48 records to a log before the next chance to stop
         const bool full = __builtin_amdgcn_ballot_w64(recordOffset > stopOffset0 || recordOffset1 > stopOffset1) != 0ull;
-        const uint32_t slot = iteration % 3u;
+        const uint32_t slot = stopSlot;
+        stopSlot = stopSlot == 2u ? 0u : stopSlot + 1u;              // (iteration % 3, without the division)
         if (full && laneId() == 0u) stopWords[slot] = 1u;
-        if (waveSlot == 0u && laneId() == 0u) stopWords[(iteration + 1u) % 3u] = 0u;
+        if (waveSlot == 0u && laneId() == 0u) stopWords[stopSlot] = 0u;
         if (!(diag & 128u)) EM2_WAIT_STAGED();          // (128: measurements only -- the tiles are used before they have arrived)
         if (!(diag & 64u)) __syncthreads();
         const uint32_t stop = stopWords[slot];
