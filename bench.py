@@ -236,23 +236,33 @@ def bench_chain(args, capi, sharded, synthetic, oracle, device, torch):
     cells = np.arange(C, dtype=np.uint32)
     times = {"findSimilarPairs4": 0.0, "createCellGraph": 0.0, "labelPropagationClustering": 0.0}
 
-    def step(record):
+    per_vertex = min(args.graph_k, k) if args.graph_k else k
+    d_v0 = torch.empty(C * per_vertex, dtype=torch.int32, device=device)
+    d_v1 = torch.empty(C * per_vertex, dtype=torch.int32, device=device)
+    d_sim = torch.empty(C * per_vertex, dtype=torch.float32, device=device)
+
+    def step(record, fetch=False):
+        # pairs and edges stay on the device from the scan to the clusters; what comes back is the cluster of every cell
         t0 = time.perf_counter()
         pipe.step()
         pipe.check()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        v0, v1, sim = capi.dev_cell_graph_edges(pipe.pairs.data_ptr(), pipe.used.data_ptr(), C, k, cells, cells, thr, args.graph_k)
+        edges = capi.dev_cell_graph_edges_to_device(pipe.pairs.data_ptr(), pipe.used.data_ptr(), C, k, cells, cells, thr, args.graph_k,
+                                                    d_v0.data_ptr(), d_v1.data_ptr(), d_sim.data_ptr())
         t2 = time.perf_counter()
-        clusters, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim)
+        clusters, iterations = capi.dev_cell_graph_label_propagation(cells, d_v0.data_ptr(), d_v1.data_ptr(), d_sim.data_ptr(), edges)
         t3 = time.perf_counter()
         if record:
             times["findSimilarPairs4"] += t1 - t0
             times["createCellGraph"] += t2 - t1
             times["labelPropagationClustering"] += t3 - t2
-        return v0, v1, sim, clusters, iterations
+        v0 = d_v0[:edges].cpu().numpy().view(np.uint32) if fetch else None          # (for the oracle check only)
+        v1 = d_v1[:edges].cpu().numpy().view(np.uint32) if fetch else None
+        sim = d_sim[:edges].cpu().numpy() if fetch else None
+        return v0, v1, sim, clusters, iterations, edges
 
-    v0, v1, sim, clusters, iterations = step(False)
+    v0, v1, sim, clusters, iterations, edge_count = step(False, fetch=True)
     check = {"skipped": "--no-check"}
     if not args.no_check:
         p, u = pipe.results_for(0, C)
@@ -273,7 +283,7 @@ def bench_chain(args, capi, sharded, synthetic, oracle, device, torch):
         step(False)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        v0, v1, sim, clusters, iterations = step(True)
+        _, _, _, clusters, iterations, edge_count = step(True)
     elapsed = time.perf_counter() - t0
     return {
         "metric": "cells/sec through findSimilarPairs4 -> createCellGraph -> labelPropagationClustering",
@@ -283,11 +293,12 @@ def bench_chain(args, capi, sharded, synthetic, oracle, device, torch):
         "config": {"workload": "BASELINE configs[4]: %d synthetic cells x %d genes, %d-bit signatures, findSimilarPairs4 k=%d "
                                "threshold=%g -> createCellGraph(threshold %g, k=%d) -> label propagation, 1 GPU"
                                % (C, G, L, k, thr, thr, args.graph_k),
-                   "cells": C, "edges": int(len(v0)), "iterations": int(iterations), "clusters": int(clusters.max()) + 1 if len(clusters) else 0},
+                   "cells": C, "edges": int(edge_count), "iterations": int(iterations), "clusters": int(clusters.max()) + 1 if len(clusters) else 0},
         "phases_ms": {key: value / args.steps * 1e3 for key, value in times.items()},
         "roofline": None,
-        "note": "SimilarPairs stay device-resident between findSimilarPairs4 and createCellGraph (em2_dev_cell_graph_edges); label "
-                "propagation is latency-bound pointer chasing, no roofline is attached to it (DESIGN.md 3.6)",
+        "note": "SimilarPairs and the graph's edges stay device-resident from findSimilarPairs4 through createCellGraph "
+                "(em2_dev_cell_graph_edges) to the clusters (em2_dev_cell_graph_label_propagation); label propagation is "
+                "latency-bound pointer chasing, no roofline is attached to it (DESIGN.md 3.6)",
         "parity_check": check,
     }
 

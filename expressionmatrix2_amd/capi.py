@@ -69,6 +69,9 @@ SYMBOLS = {
     "em2_cell_graph_label_propagation": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                     _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_void_p,
                                                     _c.c_void_p]),
+    "em2_dev_cell_graph_label_propagation": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                                        _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_void_p,
+                                                        _c.c_void_p]),
     "em2_analyze_lsh": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p, _c.c_uint32, _c.c_void_p,
                                    _c.c_uint32, _c.c_double, _c.c_char_p, _c.c_char_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                    _c.c_void_p, _c.c_void_p]),
@@ -303,6 +306,31 @@ def dev_cell_graph_edges(pairs_ptr, used_ptr, cell_count, k, similar_pairs_cell_
                                           _ptr(v0), _ptr(v1), _ptr(sim), ctypes.byref(count)))
     n = int(count.value)
     return v0[:n].copy(), v1[:n].copy(), sim[:n].copy()
+
+
+def dev_cell_graph_edges_to_device(pairs_ptr, used_ptr, cell_count, k, similar_pairs_cell_set, graph_cell_set, similarity_threshold,
+                                   max_connectivity, v0_ptr, v1_ptr, sim_ptr):
+    """dev_cell_graph_edges with the three edge arrays in DEVICE memory (pointers; room for
+    len(graph_cell_set) * min(max_connectivity or k, k) edges each); returns the number of edges."""
+    sp_cells = np.ascontiguousarray(similar_pairs_cell_set, dtype=np.uint32)
+    graph_cells = np.ascontiguousarray(graph_cell_set, dtype=np.uint32)
+    count = ctypes.c_uint64(0)
+    check(load().em2_dev_cell_graph_edges(pairs_ptr, used_ptr, cell_count, k, _ptr(sp_cells), _ptr(graph_cells),
+                                          len(graph_cells), similarity_threshold, min(int(max_connectivity), 0xffffffff),
+                                          v0_ptr, v1_ptr, sim_ptr, ctypes.byref(count)))
+    return int(count.value)
+
+
+def dev_cell_graph_label_propagation(vertex_cell_ids, v0_ptr, v1_ptr, sim_ptr, edge_count, seed=231,
+                                     stable_iteration_count_threshold=3, max_iteration_count=100):
+    """cell_graph_label_propagation over edge arrays in device memory (as dev_cell_graph_edges_to_device left them)."""
+    cells = np.ascontiguousarray(vertex_cell_ids, dtype=np.uint32)
+    clusters = np.zeros(len(cells), dtype=np.uint32)
+    iterations = ctypes.c_uint64(0)
+    check(load().em2_dev_cell_graph_label_propagation(_ptr(cells), len(cells), v0_ptr, v1_ptr, sim_ptr, edge_count, seed,
+                                                      stable_iteration_count_threshold, max_iteration_count, _ptr(clusters),
+                                                      ctypes.byref(iterations)))
+    return clusters, int(iterations.value)
 
 
 def cell_graph_label_propagation(vertex_cell_ids, edge_vertex0, edge_vertex1, edge_similarity, seed=231,

@@ -895,7 +895,10 @@ static int cellGraphEdges(const char* what, bool pairsOnDevice, const em2_pair* 
     // vertexTable of the reference (cell id -> vertex): the graph cell set sorted by id + the vertex of each entry.
     std::vector<uint32_t> order(graphCellCount);
     for (uint32_t i = 0; i < graphCellCount; i++) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return graphCellSet[a] < graphCellSet[b]; });
+    // (a cell set in ascending order -- AllCells, any set as stored -- needs no sort: 1M ids cost it some 25 ms)
+    if (!std::is_sorted(graphCellSet, graphCellSet + graphCellCount)) {
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return graphCellSet[a] < graphCellSet[b]; });
+    }
     std::vector<uint32_t> sortedIds(graphCellCount);
     for (uint32_t i = 0; i < graphCellCount; i++) sortedIds[i] = graphCellSet[order[i]];
     for (uint32_t i = 1; i < graphCellCount; i++) {
@@ -932,9 +935,10 @@ static int cellGraphEdges(const char* what, bool pairsOnDevice, const em2_pair* 
                                    similarityThreshold, maxConnectivity, dE0.as<uint32_t>(), dE1.as<uint32_t>(), dEs.as<float>(),
                                    &count, nullptr));
     if (count) {
-        EM2_HIP(hipMemcpy(edgeVertex0, dE0.p, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        EM2_HIP(hipMemcpy(edgeVertex1, dE1.p, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        EM2_HIP(hipMemcpy(edgeSimilarity, dEs.p, count * sizeof(float), hipMemcpyDeviceToHost));
+        // (hipMemcpyDefault: the three output arrays may be host or device memory)
+        EM2_HIP(hipMemcpy(edgeVertex0, dE0.p, count * sizeof(uint32_t), hipMemcpyDefault));
+        EM2_HIP(hipMemcpy(edgeVertex1, dE1.p, count * sizeof(uint32_t), hipMemcpyDefault));
+        EM2_HIP(hipMemcpy(edgeSimilarity, dEs.p, count * sizeof(float), hipMemcpyDefault));
     }
     *edgeCount = count;
     return EM2_OK;
@@ -1047,17 +1051,18 @@ int em2_analyze_lsh(const uint64_t* toc, const em2_count* data, uint32_t cellCou
 }
 
 
-int em2_cell_graph_label_propagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
-                                     const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount,
-                                     uint64_t seed, uint64_t stableIterationCountThreshold,
-                                     uint64_t maxIterationCount, uint32_t* clusterIds, uint64_t* iterationCount)
+static int labelPropagation(bool edgesOnDevice, const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
+                            const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount, uint64_t seed,
+                            uint64_t stableIterationCountThreshold, uint64_t maxIterationCount, uint32_t* clusterIds,
+                            uint64_t* iterationCount)
 {
     if (iterationCount) *iterationCount = 0;
     if (vertexCount == 0) return EM2_OK;
     if (!vertexCellIds || !clusterIds || (edgeCount && (!edgeVertex0 || !edgeVertex1 || !edgeSimilarity))) {
         return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_cell_graph_label_propagation: null pointer");
     }
-    for (uint64_t e = 0; e < edgeCount; e++) {
+    // (edges on the device are what em2_dev_cell_graph_edges wrote there: valid by construction, not read here)
+    for (uint64_t e = 0; e < (edgesOnDevice ? 0 : edgeCount); e++) {
         if (edgeVertex0[e] >= vertexCount || edgeVertex1[e] >= vertexCount) {
             return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_cell_graph_label_propagation: an edge names a vertex that does not exist");
         }
@@ -1068,7 +1073,9 @@ int em2_cell_graph_label_propagation(const uint32_t* vertexCellIds, uint32_t ver
     // The vector the reference shuffles: the vertices in the order of its std::map vertexTable (CellGraph.cpp:484-489).
     std::vector<uint32_t> byCellId(vertexCount);
     for (uint32_t v = 0; v < vertexCount; v++) byCellId[v] = v;
-    std::stable_sort(byCellId.begin(), byCellId.end(), [&](uint32_t a, uint32_t b) { return vertexCellIds[a] < vertexCellIds[b]; });
+    if (!std::is_sorted(vertexCellIds, vertexCellIds + vertexCount)) {       // (vertices in cell-id order need no sort)
+        std::stable_sort(byCellId.begin(), byCellId.end(), [&](uint32_t a, uint32_t b) { return vertexCellIds[a] < vertexCellIds[b]; });
+    }
     for (uint32_t i = 1; i < vertexCount; i++) {
         if (vertexCellIds[byCellId[i]] == vertexCellIds[byCellId[i - 1]]) {
             return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_cell_graph_label_propagation: duplicate cell id among the vertices");
@@ -1088,30 +1095,59 @@ int em2_cell_graph_label_propagation(const uint32_t* vertexCellIds, uint32_t ver
 
     // CellGraph.cpp:561-596: clusters renumbered from 0 by decreasing size; equal sizes by decreasing label
     // (std::greater on (size, label)).
-    std::vector<uint32_t> sortedLabels(clusterIds, clusterIds + vertexCount);
-    std::sort(sortedLabels.begin(), sortedLabels.end());
+    // A label is the cell id of a vertex: count the vertices per label through the vertex that owns the id (the sorted
+    // cell ids are at hand), instead of sorting a million labels.
     struct Cluster {
         uint64_t size;
         uint32_t label;
     };
+    std::vector<uint32_t> sortedCellIds(vertexCount);
+    for (uint32_t i = 0; i < vertexCount; i++) sortedCellIds[i] = vertexCellIds[byCellId[i]];
+    const bool contiguous = uint64_t(sortedCellIds.back()) - sortedCellIds.front() + 1u == vertexCount;
+    std::vector<uint32_t> owner(vertexCount);            // position of the label of vertex v among the sorted cell ids
+    std::vector<uint32_t> sizeOf(vertexCount, 0u);
+    for (uint32_t v = 0; v < vertexCount; v++) {
+        const uint32_t label = clusterIds[v];
+        const uint32_t at = contiguous ? label - sortedCellIds.front()
+                                       : uint32_t(std::lower_bound(sortedCellIds.begin(), sortedCellIds.end(), label) - sortedCellIds.begin());
+        if (at >= vertexCount || sortedCellIds[at] != label) return fail(EM2_ERROR_RUNTIME, "em2_cell_graph_label_propagation: a label is no cell id of the graph");
+        owner[v] = at;
+        ++sizeOf[at];
+    }
     std::vector<Cluster> clusters;
-    for (size_t i = 0; i < sortedLabels.size();) {
-        size_t j = i;
-        while (j < sortedLabels.size() && sortedLabels[j] == sortedLabels[i]) ++j;
-        clusters.push_back(Cluster{uint64_t(j - i), sortedLabels[i]});
-        i = j;
+    for (uint32_t at = 0; at < vertexCount; at++) {
+        if (sizeOf[at]) clusters.push_back(Cluster{uint64_t(sizeOf[at]), sortedCellIds[at]});
     }
     std::sort(clusters.begin(), clusters.end(), [](const Cluster& a, const Cluster& b) {
         return a.size != b.size ? a.size > b.size : a.label > b.label;
     });
-    std::vector<std::pair<uint32_t, uint32_t>> renumber(clusters.size());
-    for (uint32_t i = 0; i < clusters.size(); i++) renumber[i] = std::make_pair(clusters[i].label, i);
-    std::sort(renumber.begin(), renumber.end());
-    for (uint32_t v = 0; v < vertexCount; v++) {
-        clusterIds[v] = std::lower_bound(renumber.begin(), renumber.end(), std::make_pair(clusterIds[v], 0u))->second;
+    std::vector<uint32_t>& clusterOf = sizeOf;           // reused: position among the sorted cell ids -> new cluster id
+    for (uint32_t i = 0; i < clusters.size(); i++) {
+        const uint32_t at = contiguous ? clusters[i].label - sortedCellIds.front()
+                                       : uint32_t(std::lower_bound(sortedCellIds.begin(), sortedCellIds.end(), clusters[i].label) - sortedCellIds.begin());
+        clusterOf[at] = i;
     }
+    for (uint32_t v = 0; v < vertexCount; v++) clusterIds[v] = clusterOf[owner[v]];
     timer.stage("cluster renumbering");
     return EM2_OK;
+}
+
+int em2_cell_graph_label_propagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
+                                     const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount,
+                                     uint64_t seed, uint64_t stableIterationCountThreshold,
+                                     uint64_t maxIterationCount, uint32_t* clusterIds, uint64_t* iterationCount)
+{
+    return labelPropagation(false, vertexCellIds, vertexCount, edgeVertex0, edgeVertex1, edgeSimilarity, edgeCount, seed,
+                            stableIterationCountThreshold, maxIterationCount, clusterIds, iterationCount);
+}
+
+int em2_dev_cell_graph_label_propagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* d_edgeVertex0,
+                                         const uint32_t* d_edgeVertex1, const float* d_edgeSimilarity, uint64_t edgeCount,
+                                         uint64_t seed, uint64_t stableIterationCountThreshold,
+                                         uint64_t maxIterationCount, uint32_t* clusterIds, uint64_t* iterationCount)
+{
+    return labelPropagation(true, vertexCellIds, vertexCount, d_edgeVertex0, d_edgeVertex1, d_edgeSimilarity, edgeCount, seed,
+                            stableIterationCountThreshold, maxIterationCount, clusterIds, iterationCount);
 }
 
 }  // extern "C"

@@ -553,9 +553,9 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
         EM2_TRY(dEnds.allocate(slots * sizeof(uint32_t)));
         EM2_TRY(dEndsSorted.allocate(slots * sizeof(uint32_t)));
         EM2_TRY(dMax.allocate(sizeof(uint32_t)));
-        EM2_TRY(hipMemcpyAsync(dEdge0.p, edgeVertex0, edgeCount * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        EM2_TRY(hipMemcpyAsync(dEdge1.p, edgeVertex1, edgeCount * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        EM2_TRY(hipMemcpyAsync(dSimilarity.p, edgeSimilarity, edgeCount * sizeof(float), hipMemcpyHostToDevice, stream));
+        EM2_TRY(hipMemcpyAsync(dEdge0.p, edgeVertex0, edgeCount * sizeof(uint32_t), hipMemcpyDefault, stream));       // (host or device arrays)
+        EM2_TRY(hipMemcpyAsync(dEdge1.p, edgeVertex1, edgeCount * sizeof(uint32_t), hipMemcpyDefault, stream));       // (host or device arrays)
+        EM2_TRY(hipMemcpyAsync(dSimilarity.p, edgeSimilarity, edgeCount * sizeof(float), hipMemcpyDefault, stream));       // (host or device arrays)
         const dim3 endGrid(uint32_t((slots + 255u) / 256u));
         edgeEndsKernel<<<endGrid, block, 0, stream>>>(dEdge0.as<uint32_t>(), dEdge1.as<uint32_t>(), uint32_t(slots),
                                                       dKeys.as<uint32_t>(), dEnds.as<uint32_t>(), dDegree.as<uint32_t>());

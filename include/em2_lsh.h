@@ -319,8 +319,9 @@ int em2_cell_graph_edges(const em2_pair* pairs, const uint32_t* usedCount, uint3
                          uint32_t* edgeVertex1, float* edgeSimilarity, uint64_t* edgeCount);
 
 /* The same with the SimilarPairs content still on the device (d_pairs / d_usedCount as em2_dev_find_similar_pairs4
- * left them; the cell sets and the edge arrays are host arrays as above): the consumer of a device-resident
- * findSimilarPairs4 does not move 8 * k * cells bytes over PCIe twice. */
+ * left them; the cell sets are host arrays as above; the three edge arrays may be host OR device memory): the consumer of a
+ * device-resident findSimilarPairs4 does not move 8 * k * cells bytes over PCIe twice, and with device edge arrays handed on
+ * to em2_cell_graph_label_propagation (which takes host or device edge arrays as well) the edges never leave the device. */
 int em2_dev_cell_graph_edges(const em2_pair* d_pairs, const uint32_t* d_usedCount, uint32_t similarPairsCellCount, uint32_t k,
                              const uint32_t* similarPairsCellSet, const uint32_t* graphCellSet, uint32_t graphCellCount,
                              double similarityThreshold, uint32_t maxConnectivity, uint32_t* edgeVertex0,
@@ -356,9 +357,17 @@ int em2_analyze_lsh(const uint64_t* toc, const em2_count* data, uint32_t cellCou
  * of vertex v after the reference's renumbering (0 = largest; equal sizes by decreasing original label).
  * *iterationCount (may be NULL) receives the number of iterations that ran.  The reference's schedule is serial by
  * definition (each update reads labels written earlier in the same std::shuffle(std::mt19937(seed)) order, and
- * the float weights accumulate in that order), so this is host code over host buffers and needs no device. */
+ * the float weights accumulate in that order); the device runs it with a schedule that reproduces exactly those labels
+ * (csrc/em2_cluster.hip).  Host buffers.  em2_dev_cell_graph_label_propagation takes the three edge arrays in DEVICE memory,
+ * as em2_dev_cell_graph_edges left them when given device output arrays (they are not validated again): with the pairs of
+ * em2_dev_find_similar_pairs4 the chain findSimilarPairs4 -> createCellGraph -> labelPropagationClustering then keeps pairs
+ * and edges on the device from end to end; vertexCellIds and clusterIds stay host arrays. */
 int em2_cell_graph_label_propagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
                                      const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount,
+                                     uint64_t seed, uint64_t stableIterationCountThreshold,
+                                     uint64_t maxIterationCount, uint32_t* clusterIds, uint64_t* iterationCount);
+int em2_dev_cell_graph_label_propagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* d_edgeVertex0,
+                                     const uint32_t* d_edgeVertex1, const float* d_edgeSimilarity, uint64_t edgeCount,
                                      uint64_t seed, uint64_t stableIterationCountThreshold,
                                      uint64_t maxIterationCount, uint32_t* clusterIds, uint64_t* iterationCount);
 

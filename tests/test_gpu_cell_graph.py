@@ -75,6 +75,37 @@ def test_device_resident_pairs_give_the_same_edges(oracle, cells, L, k, thr, max
     assert_same(device_edges(sig, L, k, 0.2, sp_cells, graph_cells, thr, max_conn), exp)
 
 
+def test_chain_with_pairs_and_edges_on_the_device(oracle):
+    """findSimilarPairs4 -> createCellGraph -> labelPropagationClustering with pairs and edges in device memory from end to
+    end (em2_dev_cell_graph_edges with device edge arrays, em2_dev_cell_graph_label_propagation): the oracle's clusters."""
+    import torch
+    cells, L, k, thr, max_conn = 3000, 256, 30, 0.3, 8
+    sig = synth.clustered_signatures(cells, L, cluster_count=7, flip=0.1, seed=99)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, k, 0.2)
+    ids = np.arange(cells, dtype=np.uint32)
+    ev0, ev1, es = oracle.cell_graph_edges(cell, sim, used, ids, ids, thr, max_conn)
+    expected, expected_iterations = oracle.label_propagation(ids, ev0, ev1, es)
+    d_sig = torch.from_numpy(sig.view(np.int64).copy()).cuda()
+    pairs = torch.zeros((cells, k, 2), dtype=torch.int32, device="cuda")
+    d_used = torch.zeros(cells, dtype=torch.int32, device="cuda")
+    ws_bytes = capi.dev_find_similar_pairs4_workspace(cells, cells, L, k)
+    ws = torch.empty(max(1, ws_bytes), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    capi.dev_find_similar_pairs4(d_sig.data_ptr(), cells, 0, cells, L, k, 0.2, pairs.data_ptr(), d_used.data_ptr(), ws.data_ptr(),
+                                 ws_bytes, stream)
+    torch.cuda.synchronize()
+    v0 = torch.empty(cells * max_conn, dtype=torch.int32, device="cuda")
+    v1 = torch.empty(cells * max_conn, dtype=torch.int32, device="cuda")
+    vs = torch.empty(cells * max_conn, dtype=torch.float32, device="cuda")
+    edges = capi.dev_cell_graph_edges_to_device(pairs.data_ptr(), d_used.data_ptr(), cells, k, ids, ids, thr, max_conn,
+                                                v0.data_ptr(), v1.data_ptr(), vs.data_ptr())
+    assert edges == len(ev0) > 0
+    assert np.array_equal(v0[:edges].cpu().numpy().view(np.uint32), ev0)
+    assert np.array_equal(vs[:edges].cpu().numpy().view(np.uint32), es.view(np.uint32))
+    clusters, iterations = capi.dev_cell_graph_label_propagation(ids, v0.data_ptr(), v1.data_ptr(), vs.data_ptr(), edges)
+    assert iterations == expected_iterations and np.array_equal(clusters, expected)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_edges_match_oracle_two_cell_sets_unsorted_graph_set(oracle, seed):
     rng = np.random.default_rng(seed)
