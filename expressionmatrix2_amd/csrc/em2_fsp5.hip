@@ -321,6 +321,78 @@ selectKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegin, Ent
     if (lane == 0u) outUsed[local] = n;
 }
 
+// The LDS tiers again with 8 bytes per entry instead of 12: what is staged is {key, position in the list} in four bytes
+// (keys are mismatch classes, at most lshCount + 1 of them; a tier holds fewer than 65536 entries), the selection permutes
+// those exactly as it would permute the entries -- only keys are ever compared -- and the cells of the k survivors are
+// fetched from the list in global memory afterwards.  A third more waves per CU at every tier (the kernel lives on LDS
+// latency): 4096 entries take 32 KB (five waves per CU instead of three), 6144 take 48 KB (three), 8192 take 64 KB (two),
+// 16384 take 128 KB (one).
+struct PackedEntry {
+    uint16_t key;
+    uint16_t index;
+};
+constexpr uint32_t kSelectPackedMaxK = 2048;        // the survivors are gathered into the smallest tier's position arrays
+
+template <uint32_t CAPACITY, uint32_t ABOVE>
+__global__ void __launch_bounds__(64)
+selectPackedKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegin, const Entry* __restrict__ lists,
+                   const uint32_t* __restrict__ listCounts, const float* __restrict__ keySimilarity, uint32_t k,
+                   PairOut* __restrict__ outPairs, uint32_t* __restrict__ outUsed)
+{
+    __shared__ PackedEntry lds[CAPACITY];
+    __shared__ __attribute__((aligned(8))) uint16_t positions[2u * CAPACITY];         // the two position arrays of the selection
+    uint16_t* ldsL = positions;
+    uint16_t* ldsR = positions + CAPACITY;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t local = blockIdx.x;
+    if (local >= batchCells) return;
+    uint32_t n = listCounts[local];
+    if (n <= ABOVE || n > CAPACITY) return;             // another tier's cells
+    const Entry* list = lists + segmentBegin[local];
+    for (uint32_t i = lane; i < n; i += 64u) {
+        PackedEntry e;
+        e.key = uint16_t(list[i].key);
+        e.index = uint16_t(i);
+        lds[i] = e;
+    }
+    waveFence();
+    if (n > k) {
+        nthElementWaveT<uint16_t, false, PackedEntry>(lds, ldsL, ldsR, int(k), int(n), lane);
+        n = k;
+        waveFence();
+    }
+    // the survivors' cells, then the rank sort of SimilarPairs::copy + sort (:489-496) on (key, cell)
+    Entry* kept = reinterpret_cast<Entry*>(positions);     // (the position arrays are free now; k <= kSelectPackedMaxK entries of 8 bytes)
+    static_assert(CAPACITY * 4u >= kSelectPackedMaxK * 8u, "the position arrays must hold k entries");
+    for (uint32_t i = lane; i < n; i += 64u) {
+        Entry e;
+        e.key = lds[i].key;
+        e.cell = list[lds[i].index].cell;
+        kept[i] = e;
+    }
+    waveFence();
+    PairOut* out = outPairs + size_t(local) * k;
+    for (uint32_t i = lane; i < n; i += 64u) {
+        const Entry e = kept[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            const Entry o = kept[j];
+            rank += uint32_t((o.key < e.key) || (o.key == e.key && o.cell < e.cell));
+        }
+        PairOut po;
+        po.cell = e.cell;
+        po.similarity = keySimilarity[e.key];
+        out[rank] = po;
+    }
+    for (uint32_t i = n + lane; i < k; i += 64u) {
+        PairOut zero;
+        zero.cell = 0u;
+        zero.similarity = 0.0f;
+        out[i] = zero;
+    }
+    if (lane == 0u) outUsed[local] = n;
+}
+
 // The same for lists of any length, left where the filter wrote them: one wave per cell runs the wave-parallel selection
 // (em2_select_wave.h) on global memory; its two position arrays are the cell's segments of the candidate arrays, which the
 // filter has finished with.  Takes the cells with
@@ -552,10 +624,11 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
         }
         EM2_TRY(hipGetLastError());
         if (timing[0]) (void)hipEventRecord(timing[1], stream);
-        // keepBest + sort + store, by list length: LDS tiers of 4096 / 5120 / 6656 / 12288 entries (12 bytes each: 3, 2, 2
-        // and 1 wave per CU), beyond that the same wave-parallel selection on global memory.  EM2_FSP5_SELECT (A/B
-        // measurements): "lds" = round 1's form (4096 and 12288, longer lists by a single lane in HBM), "global" =
-        // everything above 4096 in global memory (3.8x slower than the LDS tiers on config D: its fences are agent-scope).
+        // keepBest + sort + store, by list length: LDS tiers of 4096 / 6144 / 8192 / 16384 entries with {key, position} in
+        // 4 bytes + two position arrays (8 bytes per entry: 5, 3, 2 and 1 wave per CU), beyond that the same wave-parallel
+        // selection on global memory.  EM2_FSP5_SELECT (A/B measurements): "unpacked" = tiers of 4096 / 5120 / 6656 / 12288
+        // whole entries (12 bytes each), "lds" = round 1's form (4096 and 12288, longer lists by a single lane in HBM),
+        // "global" = everything above 4096 in global memory (3.8x slower than the LDS tiers on config D: agent-scope fences).
         const char* selectMode = getenv("EM2_FSP5_SELECT");
         const char mode = selectMode ? selectMode[0] : 't';
         PairOut* outPairs = d_pairs + size_t(batchBegin - rowBegin) * k;
@@ -566,16 +639,31 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
                                                                     outUsed, UP_TO);                                             \
         EM2_TRY(hipGetLastError())
         uint32_t globalAbove = kSelectLdsEntriesBig;
-        EM2_SELECT_TIER(kSelectLdsEntries, 0u, 0xffffffffu);
-        if (mode == 'l') {
-            EM2_SELECT_TIER(kSelectLdsEntriesBig, kSelectLdsEntries, 0xffffffffu);
-            globalAbove = 0xffffffffu;
-        } else if (mode == 'g') {
-            globalAbove = kSelectLdsEntries;
+        const bool packed = mode != 'l' && mode != 'g' && mode != 'u' && k <= kSelectPackedMaxK;
+        if (packed) {
+#define EM2_SELECT_PACKED(CAPACITY, ABOVE)                                                                                        \
+            selectPackedKernel<CAPACITY, ABOVE><<<batchCells, 64, 0, stream>>>(batchCells, segBegin.as<uint32_t>(), lists.as<Entry>(), \
+                                                                              listCounts.as<uint32_t>(), tables.keySimilarity, k, \
+                                                                              outPairs, outUsed);                                 \
+            EM2_TRY(hipGetLastError())
+            EM2_SELECT_PACKED(4096u, 0u);
+            EM2_SELECT_PACKED(6144u, 4096u);
+            EM2_SELECT_PACKED(8192u, 6144u);
+            EM2_SELECT_PACKED(16384u, 8192u);
+#undef EM2_SELECT_PACKED
+            globalAbove = 16384u;
         } else {
-            EM2_SELECT_TIER(5120u, kSelectLdsEntries, 5120u);
-            EM2_SELECT_TIER(6656u, 5120u, 6656u);
-            EM2_SELECT_TIER(kSelectLdsEntriesBig, 6656u, kSelectLdsEntriesBig);
+            EM2_SELECT_TIER(kSelectLdsEntries, 0u, 0xffffffffu);
+            if (mode == 'l') {
+                EM2_SELECT_TIER(kSelectLdsEntriesBig, kSelectLdsEntries, 0xffffffffu);
+                globalAbove = 0xffffffffu;
+            } else if (mode == 'g') {
+                globalAbove = kSelectLdsEntries;
+            } else {                                    // "unpacked", or k beyond what the packed tiers gather: whole entries
+                EM2_SELECT_TIER(5120u, kSelectLdsEntries, 5120u);
+                EM2_SELECT_TIER(6656u, 5120u, 6656u);
+                EM2_SELECT_TIER(kSelectLdsEntriesBig, 6656u, kSelectLdsEntriesBig);
+            }
         }
 #undef EM2_SELECT_TIER
         if (globalAbove != 0xffffffffu) {

@@ -33,11 +33,13 @@ struct Entry {
     uint32_t key;
 };
 
-EM2_HD bool entryBefore(const Entry& x, const Entry& y) { return x.key < y.key; }
+// The functions below are templates over the element type E: anything with a `key` member that orders it (Entry here and in
+// the scan kernels; the 4-byte {key, index} element findSimilarPairs5 stages in LDS).
+template <class E> EM2_HD bool entryBefore(const E& x, const E& y) { return x.key < y.key; }
 
-EM2_HD void entrySwap(Entry* a, int i, int j)
+template <class E> EM2_HD void entrySwap(E* a, int i, int j)
 {
-    const Entry t = a[i];
+    const E t = a[i];
     a[i] = a[j];
     a[j] = t;
 }
@@ -51,7 +53,7 @@ EM2_HD int floorLog2(uint32_t n)
 }
 
 // Swap the median of a[ia], a[ib], a[ic] into a[result].
-EM2_HD void medianToFirst(Entry* a, int result, int ia, int ib, int ic)
+template <class E> EM2_HD void medianToFirst(E* a, int result, int ia, int ib, int ic)
 {
     if (entryBefore(a[ia], a[ib])) {
         if (entryBefore(a[ib], a[ic])) entrySwap(a, result, ib);
@@ -64,9 +66,9 @@ EM2_HD void medianToFirst(Entry* a, int result, int ia, int ib, int ic)
 }
 
 // Hoare partition of [first,last) around the value at pivot (which lies outside the range).
-EM2_HD int unguardedPartition(Entry* a, int first, int last, int pivot)
+template <class E> EM2_HD int unguardedPartition(E* a, int first, int last, int pivot)
 {
-    const Entry p = a[pivot];
+    const E p = a[pivot];
     for (;;) {
         while (entryBefore(a[first], p)) ++first;
         --last;
@@ -77,7 +79,7 @@ EM2_HD int unguardedPartition(Entry* a, int first, int last, int pivot)
     }
 }
 
-EM2_HD int unguardedPartitionPivot(Entry* a, int first, int last)
+template <class E> EM2_HD int unguardedPartitionPivot(E* a, int first, int last)
 {
     const int mid = first + (last - first) / 2;
     medianToFirst(a, first, first + 1, mid, last - 1);
@@ -85,7 +87,7 @@ EM2_HD int unguardedPartitionPivot(Entry* a, int first, int last)
 }
 
 // Sift `value` up from hole towards top in the heap a[base ...).
-EM2_HD void pushHeap(Entry* a, int base, int hole, int top, Entry value)
+template <class E> EM2_HD void pushHeap(E* a, int base, int hole, int top, E value)
 {
     int parent = (hole - 1) / 2;
     while (hole > top && entryBefore(a[base + parent], value)) {
@@ -96,7 +98,7 @@ EM2_HD void pushHeap(Entry* a, int base, int hole, int top, Entry value)
     a[base + hole] = value;
 }
 
-EM2_HD void adjustHeap(Entry* a, int base, int hole, int len, Entry value)
+template <class E> EM2_HD void adjustHeap(E* a, int base, int hole, int len, E value)
 {
     const int top = hole;
     int child = hole;
@@ -115,13 +117,13 @@ EM2_HD void adjustHeap(Entry* a, int base, int hole, int len, Entry value)
 }
 
 // Heap of the best (middle-first) elements of [first,last), worst of them at a[first].
-EM2_HD void heapSelect(Entry* a, int first, int middle, int last)
+template <class E> EM2_HD void heapSelect(E* a, int first, int middle, int last)
 {
     const int len = middle - first;
     if (len >= 2) {
         int parent = (len - 2) / 2;
         for (;;) {
-            const Entry value = a[first + parent];
+            const E value = a[first + parent];
             adjustHeap(a, first, parent, len, value);
             if (parent == 0) break;
             parent--;
@@ -129,18 +131,18 @@ EM2_HD void heapSelect(Entry* a, int first, int middle, int last)
     }
     for (int i = middle; i < last; ++i) {
         if (entryBefore(a[i], a[first])) {
-            const Entry value = a[i];
+            const E value = a[i];
             a[i] = a[first];
             adjustHeap(a, first, 0, len, value);
         }
     }
 }
 
-EM2_HD void insertionSort(Entry* a, int first, int last)
+template <class E> EM2_HD void insertionSort(E* a, int first, int last)
 {
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
-        const Entry value = a[i];
+        const E value = a[i];
         if (entryBefore(value, a[first])) {
             for (int j = i; j > first; --j) a[j] = a[j - 1];
             a[first] = value;
@@ -156,7 +158,7 @@ EM2_HD void insertionSort(Entry* a, int first, int last)
 }
 
 // std::nth_element(a+0, a+nth, a+n, cmp).  depthLimit < 0 selects the library's own 2*floor(log2(n)).
-EM2_HD void nthElement(Entry* a, int nth, int n, int depthLimit = -1)
+template <class E> EM2_HD void nthElement(E* a, int nth, int n, int depthLimit = -1)
 {
     if (n == 0 || nth == n) return;
     int first = 0, last = n;
@@ -176,7 +178,7 @@ EM2_HD void nthElement(Entry* a, int nth, int n, int depthLimit = -1)
 }
 
 // keepBest (src/heap.hpp:116-126): returns the new element count.
-EM2_HD int keepBest(Entry* a, int n, int k)
+template <class E> EM2_HD int keepBest(E* a, int n, int k)
 {
     if (n > k) {
         nthElement(a, k, n);

@@ -47,8 +47,8 @@ __device__ __forceinline__ uint32_t lanesBelow(uint64_t mask)
 
 // __unguarded_partition(a+lo, a+hi, pivot = a[lo-1]); returns the cut (wave-uniform).  Index: uint16_t positions for lists
 // staged in LDS, uint32_t with GLOBAL for lists of any length left in global memory.
-template <class Index, bool GLOBAL>
-__device__ inline int partitionWaveT(Entry* a, int lo, int hi, Index* Lpos, Index* Rpos, uint32_t lane)
+template <class Index, bool GLOBAL, class E = Entry>
+__device__ inline int partitionWaveT(E* a, int lo, int hi, Index* Lpos, Index* Rpos, uint32_t lane)
 {
     const uint32_t pk = a[lo - 1].key;
     int nL = 0, nR = 0;
@@ -77,8 +77,7 @@ __device__ inline int partitionWaveT(Entry* a, int lo, int hi, Index* Lpos, Inde
             y = t < nR ? int(Rpos[nR - 1 - t]) : lo - 1;
             c = x < y;
         }
-        Entry ex, ey;
-        ex.cell = ex.key = ey.cell = ey.key = 0u;
+        E ex = E(), ey = E();
         if (c) {
             ex = a[x];
             ey = a[y];
@@ -106,8 +105,8 @@ __device__ inline int partitionWave(Entry* a, int lo, int hi, uint16_t* Lpos, ui
 
 // std::nth_element(a, a+nth, a+n, cmp) by one wave; a, Lpos, Rpos in LDS (Lpos/Rpos: n uint16 each, n <= 65535), or all
 // three in global memory (GLOBAL, Index = uint32_t).
-template <class Index, bool GLOBAL>
-__device__ inline void nthElementWaveT(Entry* a, Index* Lpos, Index* Rpos, int nth, int n, uint32_t lane)
+template <class Index, bool GLOBAL, class E = Entry>
+__device__ inline void nthElementWaveT(E* a, Index* Lpos, Index* Rpos, int nth, int n, uint32_t lane)
 {
     if (n == 0 || nth == n) return;
     int first = 0, last = n;
@@ -124,7 +123,7 @@ __device__ inline void nthElementWaveT(Entry* a, Index* Lpos, Index* Rpos, int n
         --depthLimit;
         if (lane == 0u) medianToFirst(a, first, first + 1, first + (last - first) / 2, last - 1);
         waveSyncFor<GLOBAL>();
-        const int cut = partitionWaveT<Index, GLOBAL>(a, first + 1, last, Lpos, Rpos, lane);
+        const int cut = partitionWaveT<Index, GLOBAL, E>(a, first + 1, last, Lpos, Rpos, lane);
         if (cut <= nth) first = cut;
         else last = cut;
     }

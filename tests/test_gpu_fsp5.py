@@ -135,14 +135,14 @@ def test_fsp5_last_launch_reports_what_the_filter_read(oracle):
     assert info["gathered_candidates"] == expected
 
 
-@pytest.mark.parametrize("mode", ["tiers", "global", "lds"])
+@pytest.mark.parametrize("mode", ["tiers", "unpacked", "global", "lds"])
 def test_fsp5_long_lists_all_selection_tiers(oracle, mode, monkeypatch):
     """Lists of 4097.., 12289.. candidates with few distinct keys (ties decide who survives keepBest) and with many: the
     wave-parallel selection in global memory (default), the 144 KB LDS tier + global memory, and round 1's LDS tier + one
     lane in HBM must all reproduce libstdc++'s nth_element."""
     monkeypatch.setenv("EM2_FSP5_SELECT", mode)
     rng = np.random.default_rng(17)
-    for cells, L, k, flips in ((5000, 64, 7, 3), (13000, 128, 25, 10), (7000, 256, 100, 40)):
+    for cells, L, k, flips in ((5000, 64, 7, 3), (13000, 128, 25, 10), (7000, 256, 100, 40), (17000, 64, 3, 6), (5000, 128, 2500, 30)):
         base = synth.random_signatures(1, L, seed=cells)
         sig = np.tile(base, (cells, 1))
         # flip up to `flips` random bits per cell outside the first slice: one bucket holds everybody, keys vary
