@@ -588,8 +588,9 @@ def main():
             "kernel_ms": proj_ms, "bound": "hbm", "achieved": proj_bytes / (proj_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": proj_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": proj_bytes,
             "flop_per_launch": 2.0 * nnz_local * L, "tflops": 2.0 * nnz_local * L / (proj_ms * 1e-3) / 1e12,
-            "note": "kernel_ms = HIP events around em2_dev_compute_signatures on the launch stream (screening pass + exact "
-                    "recomputation of the undecided words); its measured fabric traffic is in profiles/ and DESIGN.md",
+            "note": "kernel_ms = HIP events around em2_dev_compute_signatures on the launch stream (16-bit fixed-point screening "
+                    "tier, float tier on the words it left, exact recomputation of the rest); its measured fabric traffic is in "
+                    "profiles/ and DESIGN.md",
         }
 
     if rank == 0 and not args.no_cpu_baseline:
