@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r69; mkdir -p $O
-EM2_BENCH_SHARE_DEVICE=1 EM2_BENCH_BACKEND=gloo MASTER_ADDR=127.0.0.1 EM2_BLOCKS_PER_CU=1 timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29681 bench.py --gpus 2 --steps 3 --warmup 1 --cells 400000 --genes 10000 --no-cpu-baseline --check-rows 96 > $O/two.json 2> $O/two.err; tail -c 2500 $O/two.json; grep -i "error\|PARITY" $O/two.err | head
+for rep in 1 2; do for b in ub_SM_DC ub_MS_DC ub_MC_DS ub_MC_SD ub_M_DSC ub_M_SDC ub_S_DMC ub_SMC_D ub_MSC_D ub_MCS_D ub_SM_CD; do echo -n "$b "; timeout 120 ./tools/ubench/$b | grep "3.0 sigma" | grep -v "^pair" | awk '{print $9}' ; done; done
