@@ -526,18 +526,19 @@ constexpr float kMatrixBits = 1024.f;
 // matrix form: 512 bits 486 / 274, 256 bits 349 / 302 (the zero-extended fragments cost the full 16 k-steps).
 constexpr uint32_t kMatrixMinPaddedDw = 8;
 
-// sig32 [cell][32] -> fragments [cell / 32][k-step][lane]: lane l of k-step s holds cell (l & 31) of the block, bits
+// sig32 [cell][2 * steps] -> fragments [cell / 32][k-step][lane]: lane l of k-step s holds cell (l & 31) of the block, bits
 // s*64 + (l >> 5)*32 .. +31, one nibble per bit (0x2 = +1, 0xA = -1).  Cells past the end repeat the last one.
+// steps = 16 (1024 bits) or 32 (2048 bits).
 __global__ void __launch_bounds__(256)
 expandFragmentsKernel(const uint32_t* __restrict__ sig32, uint32_t cellCount, uint32_t fragmentCount,
-                      FragmentWord4* __restrict__ out)
+                      FragmentWord4* __restrict__ out, uint32_t steps = kMatrixSteps)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= fragmentCount) return;
-    const uint32_t lane = i & 63u, step = (i >> 6) % kMatrixSteps, block = (i >> 6) / kMatrixSteps;
+    const uint32_t lane = i & 63u, step = (i >> 6) % steps, block = (i >> 6) / steps;
     uint32_t cell = block * 32u + (lane & 31u);
     if (cell >= cellCount) cell = cellCount - 1u;
-    const uint32_t word = sig32[size_t(cell) * 32u + step * 2u + (lane >> 5)];
+    const uint32_t word = sig32[size_t(cell) * (2u * steps) + step * 2u + (lane >> 5)];
     FragmentWord4 v;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
@@ -1003,6 +1004,144 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     return result;
 }
 
+// The same walk for 2048-bit signatures (EM2_MATRIX_WIDE_*: the registers hold 32 rows x 32 k-steps, a tile is 32 columns x
+// 32 k-steps = two 16 KB slots side by side, a step is one tile).  One call walks the columns for ONE half of the wave's 64
+// rows: rowHalf a = rows 32a .. 32a+31, whose fragments are the 32 KB block rowFragmentBlock (in 32-cell blocks), whose
+// records go to the lanes' logs of accumulator a (recordCount[a]).  The walk may stop at any tile boundary, where one tile
+// is still untested: a log needs room for two tiles (32 records).
+template <bool IDENTITY>
+__device__ __attribute__((noinline)) uint32_t scanTilesMatrixWide(const void* fragmentsArg, const void* snapArg, uint32_t colBeginArg,
+                                                                  uint32_t colEndArg, uint32_t rowFragmentBlockArg, float rowDotArg,
+                                                                  uint32_t rowHalfArg, Entry* waveLogArg, uint32_t logCapacityArg,
+                                                                  uint32_t* recordCount, uint32_t tilesLdsArg, uint32_t stopWordsLdsArg,
+                                                                  uint32_t walkLdsArg)
+{
+    const GlobalFragmentPtr fragments = (GlobalFragmentPtr)uniform64(reinterpret_cast<uint64_t>(fragmentsArg));
+    const GlobalIntPtr snap = (GlobalIntPtr)uniform64(reinterpret_cast<uint64_t>(snapArg));
+    const uint32_t colBegin = uniform(colBeginArg), colEnd = uniform(colEndArg);
+    const uint32_t rowFragmentBlock = uniform(rowFragmentBlockArg), logCapacity = uniform(logCapacityArg);
+    const uint32_t rowHalf = uniform(rowHalfArg);
+    const uint32_t tilesLds = uniform(tilesLdsArg);
+    const LdsWordPtr stopWords = ldsPointer<LdsWordPtr>(uniform(stopWordsLdsArg));
+    const uint32_t walkLds = uniform(walkLdsArg);
+    const LdsFloatPtr boundScratch = ldsPointer<LdsFloatPtr>(walkLds + kWalkBounds);
+    const LdsIntPtr snapStage = ldsPointer<LdsIntPtr>(walkLds + kWalkSnapStage);
+    const uint64_t logBase = uniform64(reinterpret_cast<uint64_t>(waveLogArg));
+    const uint32_t halfCapacity = logCapacity / 2u;
+    const uint32_t firstOffset = (laneId() * logCapacity + rowHalf * halfCapacity) * uint32_t(sizeof(Entry));
+    const uint32_t stopRecords = halfCapacity > kMatrixLogMargin / 2u ? halfCapacity - kMatrixLogMargin / 2u : 0u;
+    const uint32_t stopOffset = firstOffset + stopRecords * uint32_t(sizeof(Entry));
+    uint32_t recordOffset = firstOffset + recordCount[rowHalf] * uint32_t(sizeof(Entry));
+    uint32_t unusedOffset = 0;
+    const uint32_t stateBase = walkLds + kWalkRowDot + 128u * rowHalf;       // the half's 32 row bounds
+    {
+        ldsPointer<LdsFloatPtr>(walkLds + kWalkRowDot)[laneId()] = rowDotArg;     // float[64], lane = row
+        asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(recordOffset), "v"(recordOffset) : EM2_MATRIX_OWNED_REGISTERS);
+        const uint64_t rowFragments = reinterpret_cast<uint64_t>(fragments) + size_t(rowFragmentBlock) * (2u * kMatrixTileWords * 16u);
+        asm volatile(EM2_MATRIX_LOAD_ROWS : : "s"(rowFragments) : EM2_MATRIX_STEP_CLOBBERS);
+    }
+    const uint32_t waveSlot = uniform(threadIdx.x >> 6) * 64u;
+    // (global -> LDS as in scanTilesMatrixPinned, in units of 16 KB: unit u of the fragment array into slot `buffer`)
+#define EM2_STAGE_UNIT(unitIndex, buffer)                                                                                     \
+    do {                                                                                                                      \
+        const uint64_t src_ = reinterpret_cast<uint64_t>(fragments) + (size_t(unitIndex) * kMatrixTileWords + waveSlot) * 16u + \
+                              laneId() * 16u;                                                                                 \
+        const uint32_t dst_ = tilesLds + ((buffer) * kMatrixTileWords + waveSlot) * 16u;                                     \
+        asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"                                      \
+                     "s_add_u32 m0, %4, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"                              \
+                     "s_add_u32 m0, %4, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"                              \
+                     "s_add_u32 m0, %4, 0x3000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off"                                  \
+                     :                                                                                                        \
+                     : "v"(src_), "v"(src_ + 0x1000u), "v"(src_ + 0x2000u), "v"(src_ + 0x3000u), "s"(dst_)                   \
+                     : "memory", "m0", "scc");                                                                                \
+    } while (0)
+#define EM2_STAGE_WIDE_TILE(firstColumn, parity)                                                                              \
+    do {                                                                                                                      \
+        EM2_STAGE_UNIT((firstColumn) / 16u, 2u * (parity));                                                                   \
+        EM2_STAGE_UNIT((firstColumn) / 16u + 1u, 2u * (parity) + 1u);                                                         \
+        uint32_t column_ = (firstColumn) + (laneId() & 31u);                                                                  \
+        column_ = column_ < colEnd ? column_ : colEnd - 1u;                                                                   \
+        const uint64_t address_ = reinterpret_cast<uint64_t>(snap) + uint64_t(column_) * 4u;                                 \
+        const uint32_t dstSnap_ = walkLds + kWalkSnapStage + (parity) * 256u;                                                 \
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"                                           \
+                     :                                                                                                        \
+                     : "v"(address_), "s"(dstSnap_)                                                                           \
+                     : "memory", "m0");                                                                                       \
+    } while (0)
+    EM2_STAGE_WIDE_TILE(colBegin, 0u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bool tested = false;
+    uint64_t passScratch[5];
+    bool pending = false;
+    uint32_t pendingBase = 0, pendingParity = 0;
+    uint32_t iteration = 0, stopSlot = 0;
+    uint32_t result = colEnd;
+    int32_t stagedSnap = snapStage[laneId()];
+    for (uint32_t colBase = colBegin; colBase < colEnd; colBase += 32u, ++iteration) {
+        const uint32_t parity = iteration & 1u;
+        boundScratch[parity * 32u + (laneId() & 31u)] = 2.f * kMatrixBits - 2.f * float(stagedSnap);
+        if (colBase + 32u < colEnd) EM2_STAGE_WIDE_TILE(colBase + 32u, parity ^ 1u);
+        const uint32_t tileBase = tilesLds + 2u * parity * (kMatrixTileWords * 16u);
+        const uint32_t boundBase = walkLds + kWalkBounds + pendingParity * 128u;
+        const uint32_t tileCode = pendingBase | rowHalf;
+        if (!pending) {
+            asm volatile(EM2_MATRIX_WIDE_STEP_X : : "s"(tileBase) : EM2_MATRIX_STEP_CLOBBERS);        // (the first tile: parity 0)
+        } else if (parity == 0u) {
+            asm volatile(EM2_MATRIX_WIDE_STEP_X_TESTING_Y
+                         : "=v"(recordOffset), "=v"(unusedOffset), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                         : "s"(tileBase), "s"(boundBase), "s"(stateBase), "s"(logBase), "s"(tileCode)
+                         : EM2_MATRIX_STEP_CLOBBERS);
+            tested = true;
+        } else {
+            asm volatile(EM2_MATRIX_WIDE_STEP_Y_TESTING_X
+                         : "=v"(recordOffset), "=v"(unusedOffset), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                         : "s"(tileBase), "s"(boundBase), "s"(stateBase), "s"(logBase), "s"(tileCode)
+                         : EM2_MATRIX_STEP_CLOBBERS);
+            tested = true;
+        }
+        pending = true;
+        pendingBase = colBase;
+        pendingParity = parity;
+        // the untested tile and the next one add at most 32 records to a log before the next chance to stop
+        const bool full = __builtin_amdgcn_ballot_w64(recordOffset > stopOffset) != 0ull;
+        const uint32_t slot = stopSlot;
+        stopSlot = stopSlot == 2u ? 0u : stopSlot + 1u;
+        if (full && laneId() == 0u) stopWords[slot] = 1u;
+        if (waveSlot == 0u && laneId() == 0u) stopWords[stopSlot] = 0u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const uint32_t stop = stopWords[slot];
+        stagedSnap = snapStage[(parity ^ 1u) * 64u + laneId()];
+        if (stop != 0u) {
+            __syncthreads();
+            if (waveSlot == 0u && laneId() == 0u) stopWords[slot] = 0u;
+            __syncthreads();
+            result = colBase + 32u;
+            break;
+        }
+    }
+#undef EM2_STAGE_WIDE_TILE
+#undef EM2_STAGE_UNIT
+    if (pending) {
+        const uint32_t boundBase = walkLds + kWalkBounds + pendingParity * 128u;
+        const uint32_t tileCode = pendingBase | rowHalf;
+        if (pendingParity == 1u) {
+            asm volatile(EM2_MATRIX_WIDE_TEST_Y
+                         : "=v"(recordOffset), "=v"(unusedOffset), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                         : "s"(boundBase), "s"(stateBase), "s"(logBase), "s"(tileCode) : EM2_MATRIX_STEP_CLOBBERS);
+        } else {
+            asm volatile(EM2_MATRIX_WIDE_TEST_X
+                         : "=v"(recordOffset), "=v"(unusedOffset), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                         : "s"(boundBase), "s"(stateBase), "s"(logBase), "s"(tileCode) : EM2_MATRIX_STEP_CLOBBERS);
+        }
+        tested = true;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tested) recordCount[rowHalf] = (recordOffset - firstOffset) / uint32_t(sizeof(Entry));
+    return result;
+}
+
 // The log of `lane` for accumulator a in the wave's log area.
 __device__ __forceinline__ const Entry* walkLogOf(const Entry* waveLog, uint32_t logCapacity, uint32_t lane, uint32_t a)
 {
@@ -1049,7 +1188,7 @@ struct WalkLogReader {
 // side -- unless the rows scan all columns themselves (full rows) -- to the inbox if it passes the column's published
 // cut-off, read now (fresher than the one the walk tested against: fewer entries).
 // recordCount[a] = the calling lane's number of records in its log of accumulator a.
-template <bool IDENTITY>
+template <bool IDENTITY, bool WIDE = false>
 __device__ __forceinline__ void replayWalkLogs(const Entry* waveLog, uint32_t logCapacity, const uint32_t (&recordCount)[2], uint32_t lane,
                                                uint32_t row, bool rowValid, bool emitColumns, uint32_t listBlock, Entry* myList,
                                                uint32_t twoK, uint32_t& count, int32_t& mMax, uint32_t& emitPos, uint32_t& emitEnd,
@@ -1073,7 +1212,7 @@ __device__ __forceinline__ void replayWalkLogs(const Entry* waveLog, uint32_t lo
         const bool take0 = col0 < col1;                   // (the halves never hold the same column)
         const uint32_t col = take0 ? col0 : col1;
         const float dot = take0 ? r0.dot : r1.dot;
-        const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
+        const uint32_t m = uint32_t(((WIDE ? 2.f : 1.f) * kMatrixBits - dot) * 0.5f);
         if (active) {
             if (take0) lower.pop();
             else upper.pop();
@@ -1117,9 +1256,12 @@ __device__ __forceinline__ void drainWalkLogs(const Entry* waveLog, uint32_t log
     }
 }
 
-template <bool IDENTITY, bool PINNED>
+template <bool IDENTITY, bool PINNED, bool WIDE = false>
 __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
 {
+    static_assert(!WIDE || PINNED, "the 2048-bit form has the hand-scheduled walk only");
+    constexpr int W32 = WIDE ? 64 : 32;                          // dwords per signature as the v_xor/v_bcnt parts read them
+    constexpr float bits = WIDE ? 2.f * kMatrixBits : kMatrixBits;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     FragmentWord4* tiles = reinterpret_cast<FragmentWord4*>(ldsRaw + kernelArgs()->matrixLdsOffset);
@@ -1213,9 +1355,15 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         // ---- the columns below the quad, in lock step ----
         bool failed = false;
         uint32_t at = colBegin;
+        uint32_t rowHalf = 0;           // (2048 bits: the columns are walked once per half of the wave's rows)
         for (;;) {
             if (at < commonEnd) {
-                if (PINNED) {
+                if (WIDE) {
+                    at = scanTilesMatrixWide<IDENTITY>(aux->fragments, aux->snap, at, commonEnd, rowFragmentBlock + rowHalf,
+                                                       bits - 2.f * float(mMax), rowHalf, myLog - size_t(lane) * logCapacity, logCapacity,
+                                                       recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
+                                                       ldsAddress(walkBlock));
+                } else if (PINNED) {
                     if (aux->pad2) {
                         at = scanTilesMatrixPinned<IDENTITY, false, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
                                                          rowFragmentBlock, kMatrixBits - 2.f * float(mMax), myLog - size_t(lane) * logCapacity,
@@ -1258,8 +1406,8 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
             // replay the log through the exact state machine (ascending column order per row)
             if (PINNED) {
                 if (!idle && !failed) {
-                    replayWalkLogs<IDENTITY>(myLog - size_t(lane) * logCapacity, logCapacity, recordCount, lane, row, rowValid, !fullRows,
-                                             listBlock, myList, twoK, count, mMax, emitPos, emitEnd, ldsRaw);
+                    replayWalkLogs<IDENTITY, WIDE>(myLog - size_t(lane) * logCapacity, logCapacity, recordCount, lane, row, rowValid, !fullRows,
+                                                   listBlock, myList, twoK, count, mMax, emitPos, emitEnd, ldsRaw);
                 }
                 recordCount[0] = recordCount[1] = 0u;
             } else if (!idle && !failed) {
@@ -1279,43 +1427,47 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                 }
             }
             logCount = 0;
-            if (at >= commonEnd) break;
+            if (at >= commonEnd) {
+                if (!WIDE || rowHalf == 1u || colBegin >= commonEnd) break;
+                rowHalf = 1u;
+                at = colBegin;
+            }
         }
         // (a wave whose hand-off failed keeps walking with its block -- the barriers need it -- and the launch ends at
         // the next ticket)
 
         // ---- full rows: the columns of a last, partial tile ----
         if (fullRows && commonEnd < colEnd && !idle && !failed) {
-            uint32_t r[32];
-            const uint32_t* rp = aux->sig32 + size_t(rowValid ? row : rowBase) * 32u;
+            uint32_t r[W32];
+            const uint32_t* rp = aux->sig32 + size_t(rowValid ? row : rowBase) * uint32_t(W32);
 #pragma unroll
-            for (int w = 0; w < 32; ++w) r[w] = rp[w];
+            for (int w = 0; w < W32; ++w) r[w] = rp[w];
             uint32_t unusedLogCount = 0;
-            scanColumns<32, IDENTITY, false>(kernelArgs()->sig32, commonEnd, colEnd, r, row, lane, listBlock, myList, twoK, count, mMax,
+            scanColumns<W32, IDENTITY, false>(kernelArgs()->sig32, commonEnd, colEnd, r, row, lane, listBlock, myList, twoK, count, mMax,
                                              myLog, logCapacity, unusedLogCount, ldsRaw);
         }
 
         // ---- the quad's own 256 columns: the band below this wave's rows and its diagonal, as in the other kernel ----
         if (last && !idle && !failed) {
-            uint32_t r[32];
-            const uint32_t* rp = aux->sig32 + size_t(rowValid ? row : rowBase) * 32u;
+            uint32_t r[W32];
+            const uint32_t* rp = aux->sig32 + size_t(rowValid ? row : rowBase) * uint32_t(W32);
 #pragma unroll
-            for (int w = 0; w < 32; ++w) r[w] = rp[w];
+            for (int w = 0; w < W32; ++w) r[w] = rp[w];
             uint32_t diagEnd = rowBase + 64u;
             if (diagEnd > aux->columnLimit) diagEnd = aux->columnLimit;
             uint32_t from = quadRowBase;
             while (from < rowBase) {
                 ensureInboxRoom(lane, emitPos, emitEnd);
                 uint32_t unusedLogCount = 0;
-                from = scanColumnsEmit<32, IDENTITY, false>(kernelArgs()->sig32, kernelArgs()->snap, from, rowBase, r, row,
+                from = scanColumnsEmit<W32, IDENTITY, false>(kernelArgs()->sig32, kernelArgs()->snap, from, rowBase, r, row,
                                                             rowValid, lane, myList, twoK, count, mMax, myLog, logCapacity,
                                                             unusedLogCount, emitPos, emitEnd);
                 acceptColumn<IDENTITY>(false, 0u, row, 0u, lane, listBlock, myList, twoK, count, mMax, ldsRaw);
             }
             uint32_t unusedLogCount = 0;
-            scanDiagonal<32, IDENTITY, false>(kernelArgs()->sig32, kernelArgs()->snap, rowBase, diagEnd, r, row, rowValid, lane,
-                                              listBlock, myList, twoK, count, mMax, myLog, logCapacity, unusedLogCount, emitPos,
-                                              emitEnd, ldsRaw);
+            scanDiagonal<W32, IDENTITY, false>(kernelArgs()->sig32, kernelArgs()->snap, rowBase, diagEnd, r, row, rowValid, lane,
+                                               listBlock, myList, twoK, count, mMax, myLog, logCapacity, unusedLogCount, emitPos,
+                                               emitEnd, ldsRaw);
         }
 
         // ---- full rows at their last segment: finish; otherwise publish the state: for the next segment, for the
@@ -1373,6 +1525,15 @@ fsp4ScanMatrixPinnedKernel(Fsp4Args args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     scanMatrixBody<IDENTITY, true>(ldsRaw);
+}
+
+// 2048-bit signatures (scanTilesMatrixWide)
+template <bool IDENTITY>
+__global__ void __launch_bounds__(256, 2)
+fsp4ScanMatrixWideKernel(Fsp4Args args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    scanMatrixBody<IDENTITY, true, true>(ldsRaw);
 }
 
 // Second phase of the symmetric scan: one wave per triangle row block replays the sorted inbox entries of its 64
@@ -1783,8 +1944,12 @@ static size_t scanMatrixLdsBytes(uint32_t k)
 // (bit 0: fsp4ScanMatrixKernel, bit 1: fsp4TileMatrixKernel; default both)
 static bool matrixWalkPinned(uint32_t which = 1u) { return (envNumber("EM2_MATRIX_WALK", 3) & which) != 0; }
 
-static const void* scanMatrixKernelFor(bool identity)
+static const void* scanMatrixKernelFor(bool identity, bool wide = false)
 {
+    if (wide) {
+        return identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixWideKernel<true>)
+                        : reinterpret_cast<const void*>(&fsp4ScanMatrixWideKernel<false>);
+    }
     if (matrixWalkPinned()) {
         return identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixPinnedKernel<true>)
                         : reinterpret_cast<const void*>(&fsp4ScanMatrixPinnedKernel<false>);
@@ -1811,6 +1976,14 @@ static bool matrixFormWanted(uint32_t paddedDw)
     return mode >= 2 || paddedDw >= kMatrixMinPaddedDw;
 }
 
+// 1025..2048-bit signatures (64 dwords as the scan sees them): the 2048-bit form of the matrix kernel
+// (fsp4ScanMatrixWideKernel: 32 rows per wave and pass, two passes).  EM2_SCAN_MATRIX=0 / EM2_SCAN_MATRIX_WIDE=0 keep
+// the v_xor/v_bcnt form.
+static bool matrixWideWanted(uint32_t paddedDw)
+{
+    return paddedDw == 64u && envNumber("EM2_SCAN_MATRIX", 1) != 0 && envNumber("EM2_SCAN_MATRIX_WIDE", 1) != 0;
+}
+
 bool symmetricEligible(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
 {
     // inbox keys hold two cell ids and a mismatch count in 64 bits: 13 + 2 * bits(cellCount) <= 64
@@ -1820,7 +1993,7 @@ bool symmetricEligible(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
     if (v && (v[0] == 's' || v[0] == 'p')) return false;
     // 1024-bit signatures take the matrix-core form, which wins much earlier (scan ms ordered / symmetric-matrix:
     // 30k cells 2.5 / 2.4, 60k 8.2 / 4.2, 100k 20.1 / 7.5)
-    const bool matrix = matrixFormWanted(paddedDw);
+    const bool matrix = matrixFormWanted(paddedDw) || matrixWideWanted(paddedDw);
     return cellCount >= envNumber("EM2_SYMMETRIC_MIN_CELLS", matrix ? kSymmetricMatrixMinCells : kSymmetricMinCells);
 }
 
@@ -1862,7 +2035,8 @@ static SymmetricLayout symmetricLayout(uint32_t cellCount, uint32_t paddedDw)
     l.poolA = at;   at += align256(size_t(l.capacity) * 8u);
     l.poolB = at;   at += align256(size_t(l.capacity) * 8u);
     l.temp = at;    at += align256(l.tempBytes);
-    l.fragments = at; at += align256(size_t((cellCount + 63u) / 64u) * 64u * 512u);     // FP4 fragments, matrix form
+    // FP4 fragments, matrix form: 4 bits per signature bit
+    l.fragments = at; at += align256(size_t((cellCount + 63u) / 64u) * 64u * (matrixWideWanted(paddedDw) ? 1024u : 512u));
     // signatures zero-extended to 1024 bits for the v_xor/v_bcnt parts of the matrix kernel (a quad's own 256 columns)
     l.widened = at;
     if (paddedDw < 32u && matrixFormWanted(paddedDw)) at += align256(size_t(cellCount) * 128u);
@@ -1872,7 +2046,7 @@ static SymmetricLayout symmetricLayout(uint32_t cellCount, uint32_t paddedDw)
 
 bool fsp4MatrixFormWanted(uint32_t paddedDw)
 {
-    return matrixFormWanted(paddedDw);
+    return matrixFormWanted(paddedDw) || matrixWideWanted(paddedDw);
 }
 
 bool fsp4UsesSymmetricScan(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
@@ -1947,7 +2121,8 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     // Matrix-core form of the triangle part (see fsp4ScanMatrixKernel): 1024-bit signatures, the plain single-GPU
     // launch.  EM2_SCAN_MATRIX=0 keeps the v_xor/v_bcnt form.  Full-row and segment boundaries become multiples of 256
     // cells so that the four waves of a block always walk the same columns.
-    bool matrix = matrixFormWanted(paddedDw) && wavesPerBlock == 4u && args.rowBlockStride == 1u && args.rowBlockOffset == 0u &&
+    const bool wide = matrixWideWanted(paddedDw);
+    bool matrix = (matrixFormWanted(paddedDw) || wide) && wavesPerBlock == 4u && args.rowBlockStride == 1u && args.rowBlockOffset == 0u &&
                   args.localBlockBase == 0u && args.shardFlags == 0u && args.columnLimit == cellCount && args.rowBegin == 0u &&
                   ((lds + 15u) & ~size_t(15)) + scanMatrixLdsBytes(args.k) <= 150u * 1024u;      // selection area + four tiles
     if (matrix) {
@@ -2082,7 +2257,8 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         if (e != hipSuccess) return e;
         e = hipMemsetAsync(args.control, 0, 4u, stream);                 // the ticket; the error word stays
         if (e != hipSuccess) return e;
-        const uint32_t fragmentCount = rowBlocks * 2u * kMatrixSteps * 64u;
+        const uint32_t matrixSteps = wide ? 2u * kMatrixSteps : kMatrixSteps;
+        const uint32_t fragmentCount = rowBlocks * 2u * matrixSteps * 64u;
         Fsp4Args matrixArgs = args;
         if (paddedDw < 32u) {
             uint32_t* widened = reinterpret_cast<uint32_t*>(ws + layout.widened);
@@ -2092,7 +2268,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
             matrixArgs.sig32 = widened;
         }
         expandFragmentsKernel<<<dim3((fragmentCount + 255u) / 256u), dim3(256), 0, stream>>>(
-            matrixArgs.sig32, cellCount, fragmentCount, reinterpret_cast<FragmentWord4*>(ws + layout.fragments));
+            matrixArgs.sig32, cellCount, fragmentCount, reinterpret_cast<FragmentWord4*>(ws + layout.fragments), matrixSteps);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         matrixArgs.segTable = reinterpret_cast<const uint32_t*>(ws + layout.tableMatrix);
@@ -2102,7 +2278,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         matrixArgs.fragments = ws + layout.fragments;
         matrixArgs.matrixLdsOffset = uint32_t((lds + 15u) & ~size_t(15));
         const size_t matrixLds = size_t(matrixArgs.matrixLdsOffset) + scanMatrixLdsBytes(args.k);
-        const void* matrixKernel = scanMatrixKernelFor(identity);
+        const void* matrixKernel = scanMatrixKernelFor(identity, wide);
         int device = 0, cuCount = 0, blocksPerCu = 0;
         e = hipGetDevice(&device);
         if (e != hipSuccess) return e;

@@ -108,7 +108,8 @@ def scan_knobs():
     saved = {k: os.environ.get(k) for k in ("EM2_MIN_SEGMENT_COLUMNS", "EM2_LOG_CAPACITY", "EM2_SCAN_MODE",
                                              "EM2_BLOCKS_PER_CU", "EM2_FULL_ROW_CELLS", "EM2_SEGMENTS",
                                              "EM2_INBOX_CAPACITY", "EM2_SYMMETRIC_MIN_CELLS", "EM2_VIRTUAL_WORLD",
-                                             "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_SCAN_MATRIX", "EM2_MATRIX_WALK")}
+                                             "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_SCAN_MATRIX", "EM2_MATRIX_WALK",
+                                             "EM2_SCAN_MATRIX_WIDE")}
 
     def set_knobs(**kw):
         for key, value in kw.items():
@@ -367,6 +368,31 @@ def test_matrix_form_of_narrow_signatures(oracle, scan_knobs, n, L, k, thr, kind
     assert info["form"] == 3 and info["matrix_pairs"] > 0
     assert_same(pairs, gused, cell, sim, used)
     scan_knobs(EM2_SCAN_MODE="triangle", EM2_FULL_ROW_CELLS=256, EM2_MIN_SEGMENT_COLUMNS=512, EM2_SCAN_MATRIX=0)
+    pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    assert capi.dev_find_similar_pairs4_last_launch()["form"] == 1
+    assert_same(pairs, gused, cell, sim, used)
+
+
+@pytest.mark.parametrize("n,L,k,thr,kind,knobs", [
+    (2500, 2048, 10, 0.2, "clustered", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=256)),
+    (2500, 1500, 10, 0.2, "clustered", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=256)),      # padded bits count as equal
+    (2309, 1025, 7, 0.0, "clustered", dict(EM2_FULL_ROW_CELLS=300, EM2_MIN_SEGMENT_COLUMNS=700)),     # a short last quad, an idle wave
+    (1700, 2048, 5, -1.0, "random", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=512)),         # everything passes: the walk stops and resumes
+    (1700, 2048, 300, -0.5, "clustered", dict(EM2_FULL_ROW_CELLS=256, EM2_MIN_SEGMENT_COLUMNS=256, EM2_LOG_CAPACITY=1)),
+    (4000, 2000, 25, 0.5, "clustered", dict(EM2_FULL_ROW_CELLS=512, EM2_SEGMENTS=3, EM2_BLOCKS_PER_CU=1)),
+    (1300, 2048, 100, 0.2, "equal", dict(EM2_FULL_ROW_CELLS=256)),                                     # all cells identical: dot = 2048 everywhere
+])
+def test_matrix_form_of_2048_bit_signatures(oracle, scan_knobs, n, L, k, thr, kind, knobs):
+    """1025..2048 bits: the 2048-bit form of the matrix kernel (fsp4ScanMatrixWideKernel: 32 rows per wave and pass, two
+    passes over the columns).  Same bytes as the oracle and as the v_xor/v_bcnt form (EM2_SCAN_MATRIX_WIDE=0)."""
+    sig = np.tile(make(1, L, "random"), (n, 1)) if kind == "equal" else make(n, L, kind)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
+    scan_knobs(EM2_SCAN_MODE="triangle", **knobs)
+    pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    info = capi.dev_find_similar_pairs4_last_launch()
+    assert info["form"] == 3 and info["matrix_pairs"] > 0
+    assert_same(pairs, gused, cell, sim, used)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_SCAN_MATRIX_WIDE=0, **knobs)
     pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
     assert capi.dev_find_similar_pairs4_last_launch()["form"] == 1
     assert_same(pairs, gused, cell, sim, used)

@@ -18,7 +18,7 @@ PERSISTENT = (28, 29)     # ... but v28 / v29 hold the lane's record offsets fro
 def functions(lines):
     name, start = None, 0
     for i, line in enumerate(lines):
-        m = re.match(r"^(_Z\w*scanTilesMatrixPinned\w*):", line)
+        m = re.match(r"^(_Z\w*scanTilesMatrix(?:Pinned|Wide)\w*):", line)
         if m:
             name, start = m.group(1), i
         elif name and (line.startswith(".Lfunc_end") or ".end_amdhsa_kernel" in line):

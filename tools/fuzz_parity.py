@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on a GPU box (not part of pytest): random shapes, thresholds, k and scan-form knobs, every
-result compared bit for bit with the CPU oracle.  SECONDS=300 python3 tools/fuzz_parity.py [seed]"""
+result compared bit for bit with the CPU oracle.  SECONDS=300 python3 tools/fuzz_parity.py [seed]
+FUZZ_ONLY=fsp4 restricts the sweep to one path, FUZZ_WIDTHS=1100,1500,2048 to those signature widths."""
 import os
 import sys
 import time
@@ -28,7 +29,7 @@ def main():
     while time.time() < deadline:
         for key in KNOBS:
             os.environ.pop(key, None)
-        if rng.random() < 0.15:
+        if rng.random() < 0.15 and not os.environ.get("FUZZ_ONLY"):
             # label propagation over a random k-NN-like graph: every schedule against the serial oracle
             vertices = int(rng.choice([2, 3, 50, 64, 65, 1000, 5000, 30000]))
             degree = int(rng.choice([1, 2, 5, 12, 30]))
@@ -50,13 +51,16 @@ def main():
             runs["labels"] += 1
             continue
         n = int(rng.choice([1, 2, 63, 64, 65, 200, 500, 1000, 1500, 2500, 4000]))
-        L = int(rng.choice([1, 32, 64, 100, 128, 192, 256, 512, 600, 1000, 1024, 1024, 1024, 2048, 4096]))
+        L = int(rng.choice([1, 32, 64, 100, 128, 192, 256, 512, 600, 1000, 1024, 1024, 1024, 1100, 2000, 2048, 2048, 4096]))
+        if os.environ.get("FUZZ_WIDTHS"):
+            L = int(rng.choice([int(x) for x in os.environ["FUZZ_WIDTHS"].split(",")]))
         k = int(rng.choice([1, 2, 5, 10, 33, 100, 300]))
         thr = float(rng.choice([-1.0, -0.5, 0.0, 0.1, 0.2, 0.5, 0.9]))
         clusters = int(rng.choice([1, 2, 5, 20]))
         flip = float(rng.choice([0.0, 0.02, 0.1, 0.3, 0.5]))
         sig = synth.clustered_signatures(n, L, cluster_count=clusters, flip=flip, seed=int(rng.integers(1 << 30)))
         what = rng.choice(["fsp4", "fsp4", "fsp4", "fsp5", "fsp7", "signatures", "graph"])
+        what = os.environ.get("FUZZ_ONLY", what)
         label = dict(n=n, L=L, k=k, thr=thr, clusters=clusters, flip=flip)
         if what == "fsp4":
             knobs = {"EM2_SCAN_MODE": str(rng.choice(["persistent", "triangle", "virtual", "simple"])),

@@ -228,6 +228,106 @@ def test_only(prev, operands):
     return s.lines
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The WIDE step: 2048-bit signatures.  The registers hold 32 rows x 32 k-steps (the rows of ONE accumulator, v[128:255]),
+# a tile is 32 columns x 32 k-steps = 32 KB of LDS (two 16 KB slots side by side), a step is 32 k-steps x one MFMA into the
+# first accumulator of a set, and a wave walks its columns twice, once per half of its 64 rows.  Everything else is the
+# step above: the ring of four fragments, the test of the previous tile's 16 registers (one per two k-steps) against
+# min(row bound, column bound), the records {tileCode | 2i, dot} into the log at v28 (the caller puts the half of the
+# rows into bit 0 of tileCode, its log's offset into v28 and the half's 32 row bounds at stateBase).
+WIDE_STEPS = 32
+
+
+def wide_prologue(s, o, tile, tests):
+    s.emit("v_mbcnt_lo_u32_b32 %s, -1, 0" % vreg(LANE))
+    s.emit("v_mbcnt_hi_u32_b32 %s, -1, %s" % (vreg(LANE), vreg(LANE)))
+    if tile:
+        s.emit("v_lshl_add_u32 %s, %s, 4, %s" % (vreg(TILE_ADDR), vreg(LANE), o["tileBase"]))
+    if tests:
+        s.emit("v_and_b32 %s, 31, %s" % (vreg(STATE_ADDR), vreg(LANE)))
+        s.emit("v_lshl_add_u32 %s, %s, 2, %s" % (vreg(STATE_ADDR), vreg(STATE_ADDR), o["stateBase"]))
+        s.emit("v_lshrrev_b32 %s, 5, %s" % (vreg(BOUND_ADDR), vreg(LANE)))
+        s.emit("v_lshl_add_u32 %s, %s, 4, %s" % (vreg(BOUND_ADDR), vreg(BOUND_ADDR), o["boundBase"]))
+        s.lds("rowBound0", "ds_read_b32 %s, %s" % (vreg(ROW_BOUND0), vreg(STATE_ADDR)))
+        s.lds("bounds0", "ds_read_b128 %s, %s" % (vreg(BOUNDS, 4), vreg(BOUND_ADDR)))
+
+
+def wide_shift_in(s, o, i):
+    s.emit("s_cmp_lg_u64 %s, 0" % o["pass0_%d" % (i & 1)])
+    s.emit("s_cbranch_scc1 L_stub_%d_0_%%=" % i)
+    s.emit("L_back_%d_0_%%=:" % i)
+    s.stubs.append((i, 0))
+
+
+def wide_min(s, i):
+    q, j = i >> 2, i & 3
+    if j == 0:
+        s.wait_for("bounds%d" % q)
+    s.emit("v_min_f32 %s, %s, %s" % (vreg(THR0), vreg(ROW_BOUND0), vreg(BOUNDS + 4 * (q & 1) + j)))
+
+
+def wide_cmp(s, o, i, prev0):
+    s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass0_%d" % (i & 1)], vreg(THR0), vreg(prev0 + i)))
+
+
+def wide_bounds_ahead(s, i):
+    q, j = i >> 2, i & 3
+    if j == 1 and q < 3:
+        s.lds("bounds%d" % (q + 1), "ds_read_b128 %s, %s offset:%d"
+              % (vreg(BOUNDS + 4 * ((q + 1) & 1), 4), vreg(BOUND_ADDR), 32 * (q + 1)))
+
+
+def wide_step(cur, prev, tests, operands):
+    cur0 = SETS[cur][0]
+    prev0 = SETS[prev][0]
+    o = operands
+    s = Stream()
+    wide_prologue(s, o, True, tests)
+    for k in range(4):
+        s.lds("a%d" % k, "ds_read_b128 %s, %s offset:%d" % (vreg(RING + 4 * k, 4), vreg(TILE_ADDR), 1024 * k))
+    for k in range(WIDE_STEPS):
+        slot = RING + 4 * (k % 4)
+        i = k >> 1
+        s.wait_for("a%d" % k)
+        s.emit("v_mfma_f32_32x32x64_f8f6f4 %s, %s, %s, %s cbsz:4 blgp:4"
+               % (vreg(cur0, 16), vreg(slot, 4), vreg(ROWS[0] + 4 * k, 4), "0" if k == 0 else vreg(cur0, 16)))
+        if k + 4 < WIDE_STEPS:
+            s.lds("a%d" % (k + 4), "ds_read_b128 %s, %s offset:%d" % (vreg(slot, 4), vreg(TILE_ADDR), 1024 * (k + 4)))
+        if tests:
+            if k % 2 == 0:
+                if i:
+                    wide_shift_in(s, o, i - 1)
+                wide_min(s, i)
+            else:
+                wide_bounds_ahead(s, i)
+                wide_cmp(s, o, i, prev0)
+    assert not s.queue, s.queue
+    if tests:
+        wide_shift_in(s, o, 15)
+        stubs(s, o, prev0, prev0)
+    return s.lines
+
+
+def wide_test_only(prev, operands):
+    prev0 = SETS[prev][0]
+    o = operands
+    s = Stream()
+    s.emit("s_nop 15")
+    s.emit("s_nop 15")
+    s.emit("s_nop 15")
+    wide_prologue(s, o, False, True)
+    for i in range(16):
+        if i:
+            wide_shift_in(s, o, i - 1)
+        wide_min(s, i)
+        wide_bounds_ahead(s, i)
+        wide_cmp(s, o, i, prev0)
+    assert not s.queue, s.queue
+    wide_shift_in(s, o, 15)
+    stubs(s, o, prev0, prev0)
+    return s.lines
+
+
 def c_string(lines, indent="    "):
     return "\n".join('%s"%s\\n"' % (indent, line) for line in lines)
 
@@ -255,6 +355,11 @@ def main():
         out.write(macro("EM2_MATRIX_STEP_%s_TESTING_%s" % (cur, prev), step(cur, prev, True, with_tests)))
         out.write(macro("EM2_MATRIX_STEP_%s" % cur, step(cur, prev, False, without)))
         out.write(macro("EM2_MATRIX_TEST_%s" % cur, test_only(cur, only)))
+    # the same three for 2048-bit signatures (operand lists as above; %1, %3 and %5 are unused)
+    for cur, prev in (("X", "Y"), ("Y", "X")):
+        out.write(macro("EM2_MATRIX_WIDE_STEP_%s_TESTING_%s" % (cur, prev), wide_step(cur, prev, True, with_tests)))
+        out.write(macro("EM2_MATRIX_WIDE_STEP_%s" % cur, wide_step(cur, prev, False, without)))
+        out.write(macro("EM2_MATRIX_WIDE_TEST_%s" % cur, wide_test_only(cur, only)))
     # every vector register the walk owns: no value of the compiler's may live there across any of its asm statements
     owned = ", ".join('"v%d"' % r for r in range(FIRST_OWNED, 256))
     out.write("#define EM2_MATRIX_OWNED_REGISTERS %s\n\n" % owned)

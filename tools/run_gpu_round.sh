@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do timeout 2400 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -1; done
+FUZZ_ONLY=fsp4 FUZZ_WIDTHS=1025,1100,1500,2000,2048 SECONDS=240 timeout 600 python tools/fuzz_parity.py 11 2>&1 | tail -3
+timeout 2400 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -3
