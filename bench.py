@@ -523,14 +523,17 @@ def main():
         # Dominant kernel: fsp4ScanMatrixKernel, bound by the matrix cores.  One (row, column) pair = a 1024-long dot
         # product of FP4 +-1 values = 2 * 1024 flop on v_mfma_scale_f32_32x32x64_f8f6f4; peak = the dense FP4 MFMA
         # figure of MI355X_MICROARCH.md (10 PFLOP/s).  The HBM / instruction view of the same launch rides along.
-        flops = launch["matrix_pairs"] * 2.0 * 1024.0
+        # (signatures of 1025..2048 bits: fsp4ScanMatrixWideKernel, a 2048-long contraction per pair)
+        contraction = 2048.0 if L > 1024 else 1024.0
+        flops = launch["matrix_pairs"] * 2.0 * contraction
         tflops = flops / (launch["matrix_kernel_ms"] * 1e-3) / 1e12
         result["roofline"] = {
-            "kernel": "fsp4ScanMatrixPinnedKernel<true>" if pinned_walk else "fsp4ScanMatrixKernel<true>",
+            "kernel": "fsp4ScanMatrixWideKernel<true>" if L > 1024 else
+                      ("fsp4ScanMatrixPinnedKernel<true>" if pinned_walk else "fsp4ScanMatrixKernel<true>"),
             "kernel_ms": launch["matrix_kernel_ms"],
             "form": "symmetric, triangle part on the matrix cores: every unordered pair evaluated once as an FP4 +-1 dot "
-                    "product (1024 - 2 * mismatches, exact in f32); the first cells' full rows and each quad's own 256 columns "
-                    "stay on v_xor/v_bcnt; inbox sort + replay follow",
+                    "product (%d - 2 * mismatches, exact in f32); the first cells' full rows and each quad's own 256 columns "
+                    "stay on v_xor/v_bcnt; inbox sort + replay follow" % int(contraction),
             "bound": "mfma",
             "achieved": tflops,
             "peak": MFMA_FP4_PEAK_TFLOPS,
@@ -544,12 +547,12 @@ def main():
             "inbox_entries": launch["inbox_entries"],
             "scan_launches_ms": kernel_ms,
             "hbm_view": {key: hbm_roofline[key] for key in ("achieved", "peak", "unit", "frac", "algorithmic_bytes")},
-            "note": "flop = 2 * 1024 per (row, column) pair contracted by fsp4ScanMatrixKernel (pairs counted by the launcher: "
+            "note": "flop = 2 * %d per (row, column) pair contracted by fsp4ScanMatrixKernel (pairs counted by the launcher: "
                     "64 rows x the columns below each quad); kernel_ms = HIP events on the launch stream around that kernel "
                     "alone, scan_launches_ms = around all launches of the scan (full-row blocks on v_xor/v_bcnt, fragment "
                     "expansion, the matrix kernel); hbm_view = the algorithmic 16*W bytes per unordered pair over "
                     "scan_launches_ms, kept for comparison with earlier rounds (operands are cache resident, so it is not "
-                    "bounded by 1)",
+                    "bounded by 1)" % int(contraction),
         }
     elif sharded_symmetric and launch["matrix_pairs"] > 0 and scan_ms > 0:
         # Sharded scan with phases 1 and 2 on the matrix cores: this rank's share of the FP4 contraction over the whole

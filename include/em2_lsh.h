@@ -167,8 +167,9 @@ int em2_dev_subset_fill(const uint64_t* d_globalToc, const em2_count* d_globalDa
  * evaluated once, as in the reference's own loop (src/ExpressionMatrixLsh.cpp:218-263), and offered to both cells. */
 int em2_dev_find_similar_pairs4_form(uint32_t cellCount, uint32_t rowCount);
 
-/* The same question with the signature width: for 513..1024 bits the symmetric form contracts its pairs as FP4 +-1
- * dot products on the matrix cores (3; 1024 - 2 * mismatches, exact in f32) and starts at 32768 cells instead of 131072.
+/* The same question with the signature width: for 129..2048 bits the symmetric form contracts its pairs as FP4 +-1
+ * dot products on the matrix cores (3; 1024 - 2 * mismatches up to 1024 bits, 2048 - 2 * mismatches above; exact in f32)
+ * and starts at 32768 cells instead of 131072.
  * The last_launch query below reports what actually ran. */
 int em2_dev_find_similar_pairs4_form_for(uint32_t cellCount, uint32_t rowCount, uint32_t lshCount);
 
@@ -177,7 +178,7 @@ int em2_dev_find_similar_pairs4_form_for(uint32_t cellCount, uint32_t rowCount, 
  * (symmetric form, which synchronises anyway), else -1, [2] (64-row wave, column) steps executed, [3] symmetric
  * form: inbox entries sorted and replayed, [4] column segments, [5] cells whose rows scanned all columns, [6] pairs
  * contracted on the matrix cores and [7] the duration in ms of that kernel alone (form 3, the matrix-core form of the
- * symmetric scan: FP4 +-1 contraction, 1024-bit signatures). */
+ * symmetric scan: FP4 +-1 contraction, signatures zero-extended to 1024 or 2048 bits). */
 int em2_dev_find_similar_pairs4_last_launch(double* values, uint32_t valueCount);
 
 /* findSimilarPairs4 for the rows [rowBegin,rowEnd) of the cell set against all cellCount cells: the shard

@@ -92,19 +92,24 @@ def test_device_paths_fail_loudly_without_gpu(lib):
 
 
 def test_scan_form_query_knows_about_the_matrix_cores(lib, monkeypatch):
-    # em2_dev_find_similar_pairs4_form_for: 129..1024-bit signatures take the symmetric form on the matrix cores (3) from
-    # 32768 cells on (EM2_SCAN_MATRIX=2: every width up to 1024), other widths the v_xor/v_bcnt symmetric form (1) from
-    # 131072 cells on; a row shard is never symmetric.
+    # em2_dev_find_similar_pairs4_form_for: 129..2048-bit signatures take the symmetric form on the matrix cores (3) from
+    # 32768 cells on (EM2_SCAN_MATRIX=2: every width up to 2048; EM2_SCAN_MATRIX_WIDE=0: none above 1024), other widths the
+    # v_xor/v_bcnt symmetric form (1) from 131072 cells on; a row shard is never symmetric.
     monkeypatch.delenv("EM2_SCAN_MODE", raising=False)
     monkeypatch.delenv("EM2_SCAN_MATRIX", raising=False)
+    monkeypatch.delenv("EM2_SCAN_MATRIX_WIDE", raising=False)
     monkeypatch.delenv("EM2_SYMMETRIC_MIN_CELLS", raising=False)
     f = lib.em2_dev_find_similar_pairs4_form_for
     assert f(100000, 100000, 1024) == 3 and f(100000, 100000, 600) == 3
     assert f(20000, 20000, 1024) == 0
     assert f(100000, 100000, 512) == 3 and f(100000, 100000, 129) == 3
-    assert f(100000, 100000, 128) == 0 and f(200000, 200000, 128) == 1 and f(200000, 200000, 2048) == 1
+    assert f(100000, 100000, 128) == 0 and f(200000, 200000, 128) == 1 and f(200000, 200000, 4096) == 1
+    assert f(100000, 100000, 2048) == 3 and f(100000, 100000, 1025) == 3 and f(20000, 20000, 2048) == 0
+    monkeypatch.setenv("EM2_SCAN_MATRIX_WIDE", "0")
+    assert f(100000, 100000, 2048) == 0 and f(200000, 200000, 2048) == 1 and f(100000, 100000, 1024) == 3
+    monkeypatch.delenv("EM2_SCAN_MATRIX_WIDE")
     monkeypatch.setenv("EM2_SCAN_MATRIX", "2")
-    assert f(100000, 100000, 64) == 3 and f(200000, 200000, 2048) == 1
+    assert f(100000, 100000, 64) == 3 and f(200000, 200000, 2048) == 3 and f(200000, 200000, 3000) == 1
     assert f(200000, 100000, 1024) == 0
     monkeypatch.setenv("EM2_SCAN_MATRIX", "0")
     assert f(100000, 100000, 1024) == 0 and f(200000, 200000, 1024) == 1
