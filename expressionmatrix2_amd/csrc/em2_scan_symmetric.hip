@@ -1256,9 +1256,22 @@ __device__ __forceinline__ void drainWalkLogs(const Entry* waveLog, uint32_t log
     }
 }
 
-template <bool IDENTITY, bool PINNED, bool WIDE = false>
+// TIMED (EM2_MATRIX_DIAG bit 2048, measurements only): every wave sums the shader-clock cycles it spends in the phases of
+// its items -- ticket, set-up, walk, hand-off wait, replay, the quad's own columns, publication -- and adds them to eight
+// 64-bit counters behind the inbox control words (printed by the launcher with EM2_SCAN_VERBOSE=1).
+#define EM2_PHASE(index)                                                                                                       \
+    do {                                                                                                                      \
+        if (TIMED) {                                                                                                          \
+            const uint64_t now_ = __builtin_readcyclecounter();                                                               \
+            phaseCycles[index] += now_ - phaseStart;                                                                          \
+            phaseStart = now_;                                                                                                \
+        }                                                                                                                     \
+    } while (0)
+template <bool IDENTITY, bool PINNED, bool WIDE = false, bool TIMED = false>
 __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
 {
+    uint64_t phaseCycles[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t phaseStart = TIMED ? __builtin_readcyclecounter() : 0ull;
     static_assert(!WIDE || PINNED, "the 2048-bit form has the hand-scheduled walk only");
     constexpr int W32 = WIDE ? 64 : 32;                          // dwords per signature as the v_xor/v_bcnt parts read them
     constexpr float bits = WIDE ? 2.f * kMatrixBits : kMatrixBits;
@@ -1288,6 +1301,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         const uint32_t ticket = uint32_t(__builtin_amdgcn_readfirstlane(int(shared[3])));
         __syncthreads();
         ArgsPtr aux = kernelArgs();
+        EM2_PHASE(0);
         if (ticket >= aux->totalTickets) break;
 
         // ---- the item: segment seg, quad = 4 row blocks from quadBlock ----
@@ -1341,7 +1355,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
             const uint32_t done = uint32_t(__builtin_amdgcn_readfirstlane(
                 int(__hip_atomic_load(aux->segmentsDone + block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
             if (done != 0u) {
-                if (done >= seg) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (done >= seg && !(aux->pad2 & 512u)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 const uint64_t st = __hip_atomic_load(reinterpret_cast<const uint64_t*>(aux->rowState) + size_t(block) * 64u + lane,
                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 mMax = rowValid ? int32_t(uint32_t(st >> 32)) : -1;
@@ -1356,6 +1370,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         bool failed = false;
         uint32_t at = colBegin;
         uint32_t rowHalf = 0;           // (2048 bits: the columns are walked once per half of the wave's rows)
+        EM2_PHASE(1);
         for (;;) {
             if (at < commonEnd) {
                 if (WIDE) {
@@ -1381,6 +1396,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                                                    logCapacity, logCount, emitPos, emitEnd, tiles, shared);
                 }
             }
+            EM2_PHASE(2);
             if (!haveState && !idle && !failed) {
                 const uint32_t* flag = aux->segmentsDone + block;
                 const uint64_t start = __builtin_amdgcn_s_memrealtime();         // 100 MHz
@@ -1395,7 +1411,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                 if (failed) {
                     if (lane == 0u) __hip_atomic_store(aux->control + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (!(aux->pad2 & 512u)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     const uint64_t st = __hip_atomic_load(reinterpret_cast<const uint64_t*>(aux->rowState) + size_t(block) * 64u + lane,
                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     count = uint32_t(st);
@@ -1403,6 +1419,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                     haveState = true;
                 }
             }
+            EM2_PHASE(3);
             // replay the log through the exact state machine (ascending column order per row)
             if (PINNED) {
                 if (!idle && !failed) {
@@ -1427,6 +1444,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                 }
             }
             logCount = 0;
+            EM2_PHASE(4);
             if (at >= commonEnd) {
                 if (!WIDE || rowHalf == 1u || colBegin >= commonEnd) break;
                 rowHalf = 1u;
@@ -1470,6 +1488,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                                                emitEnd, ldsRaw);
         }
 
+        EM2_PHASE(5);
         // ---- full rows at their last segment: finish; otherwise publish the state: for the next segment, for the
         // columns' snapshots, for the inbox replay ----
         if (!idle && !failed) {
@@ -1487,13 +1506,15 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                     __hip_atomic_store(aux2->snap + row, mMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                // (EM2_MATRIX_DIAG bits 256 / 512, measurements only: no release / no acquire -- results may be wrong)
+                if (!(aux2->pad2 & 256u)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0u && !(fullRows ? finalSegment : last)) {
                     __hip_atomic_store(aux2->segmentsDone + block, seg + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
+        EM2_PHASE(6);
     }
 
     // the unused tail of this wave's last inbox chunk becomes sentinels
@@ -1505,7 +1526,12 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
             for (uint32_t i = p + lane; i < e; i += 64u) inbox[i] = ~0ull;
         }
     }
+    if (TIMED && lane == 0u) {
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(kernelArgs()->inboxControl + 16);
+        for (int i = 0; i < 8; i++) atomicAdd(counters + i, (unsigned long long)phaseCycles[i]);
+    }
 }
+#undef EM2_PHASE
 
 // The two entry points.  The kernel of the hand-scheduled walk lets the compiler allocate 64 vector registers only
 // (amdgpu_num_vgpr): v64..v255 hold the rows and the accumulators of the steps, which the compiler does not know
@@ -1534,6 +1560,15 @@ fsp4ScanMatrixWideKernel(Fsp4Args args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     scanMatrixBody<IDENTITY, true, true>(ldsRaw);
+}
+
+// (EM2_MATRIX_DIAG bit 2048: the same kernels with the phase timers, identity keys only)
+template <bool WIDE>
+__global__ void __launch_bounds__(256, 2)
+fsp4ScanMatrixTimedKernel(Fsp4Args args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    scanMatrixBody<true, true, WIDE, true>(ldsRaw);
 }
 
 // Second phase of the symmetric scan: one wave per triangle row block replays the sorted inbox entries of its 64
@@ -1946,6 +1981,10 @@ static bool matrixWalkPinned(uint32_t which = 1u) { return (envNumber("EM2_MATRI
 
 static const void* scanMatrixKernelFor(bool identity, bool wide = false)
 {
+    if (identity && (envNumber("EM2_MATRIX_DIAG", 0) & 2048u) && (wide || matrixWalkPinned())) {
+        return wide ? reinterpret_cast<const void*>(&fsp4ScanMatrixTimedKernel<true>)
+                    : reinterpret_cast<const void*>(&fsp4ScanMatrixTimedKernel<false>);
+    }
     if (wide) {
         return identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixWideKernel<true>)
                         : reinterpret_cast<const void*>(&fsp4ScanMatrixWideKernel<false>);
@@ -1961,7 +2000,7 @@ static const void* scanMatrixKernelFor(bool identity, bool wide = false)
 constexpr uint32_t kSymmetricMinCells = 131072;
 constexpr uint32_t kSymmetricMatrixMinCells = 32768;
 constexpr uint32_t kMaxSegments = 64;
-constexpr uint32_t kMatrixMaxSegments = 256;     // matrix form: 4096-column segments are 2 MB of fragments, what an XCD's L2 holds
+constexpr uint32_t kMatrixMaxSegments = 1024;    // (room for short segments: 2048 columns of 2048-bit fragments are the 2 MB an XCD's L2 holds)
 constexpr uint32_t kTableWords = 2u * kMatrixMaxSegments + 2u;
 constexpr uint32_t kInboxChunk = 512;
 
@@ -2305,6 +2344,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         if (e != hipSuccess) return e;
     }
     if (timing[0]) (void)hipEventRecord(timing[1], stream);
+    const uint64_t ticketsMatrixCount = matrix ? ticketsMatrix : 0u;
 
     // the number of inbox entries (incl. chunk tails), the overflow flag and the hand-off error word
     uint32_t inboxWords[4] = {0, 0, 0, 0};
@@ -2321,6 +2361,18 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     }
     const uint64_t used = uint64_t(inboxWords[0]) | (uint64_t(inboxWords[1]) << 32);
     if (inboxWords[2] != 0u || used > layout.capacity) return hipSuccess;      // overflow: *done stays false
+    if (matrix && (envNumber("EM2_MATRIX_DIAG", 0) & 2048u)) {
+        unsigned long long cycles[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpy(cycles, ws + layout.control + 64u, sizeof(cycles), hipMemcpyDeviceToHost) == hipSuccess) {
+            double total = 0;
+            for (int i = 0; i < 7; i++) total += double(cycles[i]);
+            const char* names[7] = {"ticket", "set-up", "walk", "hand-off wait", "replay", "own columns", "publication"};
+            fprintf(stderr, "[em2] matrix kernel, wave cycles by phase (%llu items):", (unsigned long long)ticketsMatrixCount);
+            for (int i = 0; i < 7; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * double(cycles[i]) / (total > 0 ? total : 1));
+            fprintf(stderr, "; %.0f cycles per item and wave outside the walk\n",
+                    (total - double(cycles[2])) / (4.0 * double(ticketsMatrixCount ? ticketsMatrixCount : 1)));
+        }
+    }
     {
         float ms = -1.0f;
         if (!timing[0] || hipEventElapsedTime(&ms, timing[0], timing[1]) != hipSuccess) ms = -1.0f;
