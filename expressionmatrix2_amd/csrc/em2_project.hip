@@ -108,22 +108,51 @@ projectionKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ d
 }
 
 
-// Per-cell inputs of the screening pass: mean (as cellMeansKernel) and sum of |count|.
+// Per-cell inputs of the screening pass: mean (as cellMeansKernel: the counts added in stored order, every addition
+// rounded) and sum of |count|.  One wave per cell, coalesced.  The lanes' partial sums in any order equal the sequential
+// sum whenever no addition can round at all: every count is a multiple of u = 2^e (e = the smallest exponent of a count's
+// last mantissa bit) and sum|count| < 2^53 u, so every partial sum is a multiple of u below 2^53 u, which a double holds
+// exactly.  That is the case for integer counts and for any float counts within ~2^20 of each other; a cell where it is
+// not is summed again by one lane in stored order.
 __global__ void __launch_bounds__(256)
 cellStatsKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t cellCount,
                 uint32_t geneCount, double* __restrict__ means, double* __restrict__ sumAbs)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= cellCount) return;
+    const uint64_t begin = toc[c], end = toc[c + 1];
     double sum1 = 0., abs1 = 0.;
-    const uint64_t end = toc[c + 1];
-    for (uint64_t j = toc[c]; j < end; ++j) {
-        const double x = double(data[j].count);
-        sum1 = __dadd_rn(sum1, x);
+    int lowest = 1000;                              // exponent of the last mantissa bit of the smallest count seen
+    for (uint64_t j = begin + lane; j < end; j += 64u) {
+        const float value = data[j].count;
+        const double x = double(value);
+        sum1 += x;
         abs1 += fabs(x);
+        const int exponentField = int((__float_as_uint(value) >> 23) & 0xffu);
+        if (value != 0.f) lowest = min(lowest, (exponentField ? exponentField : 1) - 150);
     }
-    means[c] = sum1 / double(geneCount);
-    sumAbs[c] = abs1 * (1. + 1e-12);             // upper bound of the exact sum of magnitudes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        sum1 += __shfl_xor(sum1, d, 64);
+        abs1 += __shfl_xor(abs1, d, 64);
+        lowest = min(lowest, __shfl_xor(lowest, d, 64));
+    }
+    // (abs1 is exact under the same condition; a value that is not finite fails the test)
+    const bool exact = lowest == 1000 || abs1 < ldexp(1., 53 + lowest);
+    if (!exact) {
+        sum1 = 0.;
+        abs1 = 0.;
+        for (uint64_t j = begin; j < end; ++j) {    // (all lanes the same walk: uniform loads)
+            const double x = double(data[j].count);
+            sum1 = __dadd_rn(sum1, x);
+            abs1 += fabs(x);
+        }
+    }
+    if (lane == 0u) {
+        means[c] = sum1 / double(geneCount);
+        sumAbs[c] = abs1 * (1. + 1e-12);             // upper bound of the exact sum of magnitudes
+    }
 }
 
 // aux layout: [lshCount doubles: S_i][lshCount doubles: max_g |U[g][i]|][geneCount*lshCount floats: float(U)]
@@ -166,7 +195,7 @@ __host__ __device__ inline bool floatCopyIsSliceMajor(uint32_t lshCount) { retur
 // of 64-bit words: q[slice of 64 bits][gene][64] = round(U[g][i] / scale_i), scale_i = max_g |U[g][i]| / 32767, so that
 // |U[g][i] - q * scale_i| <= scale_i / 2.  A slice is one contiguous geneCount x 128 B block, like the float copy's.
 __host__ __device__ inline bool haveQuantizedCopy(uint32_t lshCount) { return lshCount % 64u == 0u; }
-constexpr uint32_t kQuantizedInFlight = 4;       // entries per lane in flight in the 16-bit tier (8: 124 registers, four waves per SIMD instead of five, 44 ms instead of 40.6)
+constexpr uint32_t kQuantizedInFlight = 4;       // entries per lane in flight in the 16-bit tier (8, in the earlier form of its loop: 124 registers, four waves per SIMD instead of five, 44 ms instead of 40.6)
 
 __global__ void __launch_bounds__(256)
 vectorsToQuantizedKernel(const double* __restrict__ vectors, uint32_t geneCount, uint32_t lshCount,
@@ -193,6 +222,9 @@ vectorsToQuantizedKernel(const double* __restrict__ vectors, uint32_t geneCount,
 // and a bit whose |value| exceeds that has the reference's sign.  The quantisation term is ~250 times the float copy's,
 // so this tier leaves several per cent of the 64-bit words undecided (the float tier: a few 1e-4); those go to the work
 // list like the float tier's, for the exact arithmetic.
+// DIAG (EM2_PROJECTION_DIAG, measurements only, wrong results, nothing listed for the later tiers): 1 = the gathers
+// without the arithmetic, 2 = the arithmetic without the row gathers.
+template <int DIAG = 0>
 __global__ void __launch_bounds__(256, 4)
 projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t cellCount,
                                 uint32_t geneCount, const int16_t* __restrict__ quantized, const double* __restrict__ scales,
@@ -207,7 +239,9 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
     if (word >= wordCount) return;
     const uint32_t sub = lane & 7u;
     const uint32_t group = lane >> 3;
-    const int16_t* column = quantized + size_t(word) * geneCount * 64u + sub * 8u;
+    // the word's slice of the 16-bit copy (wave-uniform: a scalar base) and the lane's 16 bytes of a gene's 128-byte line
+    const char* slice = reinterpret_cast<const char*>(quantized + size_t(word) * geneCount * 64u);
+    const uint32_t laneBytes = sub * 16u;
     // The 24 per-bit constants of a lane (sum, largest magnitude and scale of its 8 hyperplane columns) are only needed
     // once per cell, after the gathers: they wait in LDS and are read there through an index the compiler cannot see
     // through, so that they do not become 48 registers held across the gather loop (146 registers, three waves per SIMD:
@@ -223,40 +257,75 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
     const uint64_t* entries = reinterpret_cast<const uint64_t*>(data);
     const uint32_t cellBegin = (blockIdx.x >> 3) * kCellsPerBlock;
     const uint32_t cellEnd = min(cellBegin + kCellsPerBlock, cellCount);
-    for (uint32_t c = cellBegin + wave; c < cellEnd; c += 4u) {
+    const uint32_t firstCell = uint32_t(__builtin_amdgcn_readfirstlane(int(cellBegin + wave)));      // (the wave's cells are uniform)
+    for (uint32_t c = firstCell; c < cellEnd; c += 4u) {
         const uint64_t jBegin = toc[c];
         const uint64_t jEnd = toc[c + 1];
+        const uint32_t entryCount = uint32_t(jEnd - jBegin);
+        const uint64_t* cellEntries = entries + jBegin;
         double a[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
-#define EM2_ACCUMULATE(xv, uv)                                                     \
-        a[0] = __fma_rn(xv, double(int(uv.x << 16) >> 16), a[0]);                   \
-        a[1] = __fma_rn(xv, double(int(uv.x) >> 16), a[1]);                         \
-        a[2] = __fma_rn(xv, double(int(uv.y << 16) >> 16), a[2]);                   \
-        a[3] = __fma_rn(xv, double(int(uv.y) >> 16), a[3]);                         \
-        a[4] = __fma_rn(xv, double(int(uv.z << 16) >> 16), a[4]);                   \
-        a[5] = __fma_rn(xv, double(int(uv.z) >> 16), a[5]);                         \
-        a[6] = __fma_rn(xv, double(int(uv.w << 16) >> 16), a[6]);                   \
-        a[7] = __fma_rn(xv, double(int(uv.w) >> 16), a[7]);
-        uint64_t j = jBegin + group;
         typedef float Float2 __attribute__((ext_vector_type(2)));
-        // The products of four entries are summed in single precision first (packed: two bits per instruction) and that
-        // chunk sum goes into the double accumulator: a quarter of the conversions and double additions.  A product
-        // count * q has 39 significant bits, so it is rounded (2^-24 relative), as are the three additions of a chunk:
-        // at most 8 * 2^-24 * sum|count * q| in all, 3 % of the quantisation term of the bound below.
-        // kQuantizedInFlight entries per lane are in flight (one or two chunks).
-        for (; j + (kQuantizedInFlight - 1u) * 8u < jEnd; j += kQuantizedInFlight * 8u) {
-            uint4 u[kQuantizedInFlight];
-            float x[kQuantizedInFlight];
+        // The products of up to sixteen entries are summed in single precision first (packed: two bits per instruction) and
+        // that chunk sum goes into the double accumulator: a sixteenth of the conversions and double additions, which run
+        // at half rate.  A product count * q has 39 significant bits, so every fma of a chunk rounds (2^-24 relative): at
+        // most 16 * 2^-24 * sum|count * q| in all, 6 % of the quantisation term of the bound below.
+        // The 8 entry groups of the wave take every 8th entry; kQuantizedInFlight entries per lane are in flight; an
+        // entry past the cell's end is the cell's first one with count 0 (its products are exact zeros), so there is no
+        // remainder loop.  Addresses are 32-bit offsets from scalar bases (one shift-or per entry).
+        // The entries: one coalesced load per 64 of them (lane l takes entry first + l; the next 64 are loaded while these
+        // are used), handed to the groups through the LDS crossbar (ds_bpermute: group g, slot q of half h reads lane
+        // 32 h + 8 q + g) -- eight lanes loading the same 8 bytes cost the vector memory path as much as 64 different ones,
+        // a third of what the rows cost it, and that path is what bounds this kernel (the gathers alone: 34 of 38 ms).
+        constexpr uint32_t kPart = kQuantizedInFlight * 8u;              // entries of the wave per part
+        static_assert(kQuantizedInFlight == 4u, "two parts per 64 entries");
+        const uint32_t sourceLane = group << 2;                          // (byte address of a lane for ds_bpermute)
+        uint64_t nextEntry = 0;
+#define EM2_LOAD_ENTRIES(first_)                                                                                              \
+        {                                                                                                                     \
+            const uint32_t index_ = (first_) + lane;                                                                          \
+            const uint64_t e_ = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(cellEntries) +               \
+                                                                   (index_ < entryCount ? index_ * 8u : 0u));                 \
+            nextEntry = index_ < entryCount ? e_ : uint64_t(uint32_t(e_));           /* count 0 past the end */               \
+        }
+        if (entryCount) EM2_LOAD_ENTRIES(0u)
+        Float2 chunk[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        uint32_t partsInChunk = 0;
+        for (uint32_t first = 0; first < entryCount; first += 2u * kPart) {
+            const int entryGene = int(uint32_t(nextEntry)), entryCountBits = int(uint32_t(nextEntry >> 32));
+            if (first + 2u * kPart < entryCount) EM2_LOAD_ENTRIES(first + 2u * kPart)
 #pragma unroll
-            for (uint32_t q = 0; q < kQuantizedInFlight; ++q) {
-                const uint64_t e = entries[j + 8u * q];
-                u[q] = *reinterpret_cast<const uint4*>(column + size_t(uint32_t(e)) * 64u);
-                x[q] = __uint_as_float(uint32_t(e >> 32));
-            }
+            for (uint32_t half = 0; half < 2u; ++half) {
+                if (half && first + kPart >= entryCount) break;          // (uniform)
+                uint4 u[kQuantizedInFlight];
+                float x[kQuantizedInFlight];
+                uint32_t gene[kQuantizedInFlight];
 #pragma unroll
-            for (uint32_t first = 0; first < kQuantizedInFlight; first += 4u) {
-                Float2 chunk[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+                for (uint32_t q = 0; q < kQuantizedInFlight; ++q) {
+                    const int from = int(sourceLane + 4u * (32u * half + 8u * q));
+                    gene[q] = uint32_t(__builtin_amdgcn_ds_bpermute(from, entryGene));
+                    x[q] = __int_as_float(__builtin_amdgcn_ds_bpermute(from, entryCountBits));
+                }
 #pragma unroll
-                for (uint32_t q = first; q < first + 4u; ++q) {
+                for (uint32_t q = 0; q < kQuantizedInFlight; ++q) {
+                    if (DIAG == 2) u[q] = uint4{gene[q], gene[q] + 1u, gene[q] + 2u, gene[q] + 3u};
+                    else u[q] = *reinterpret_cast<const uint4*>(slice + ((gene[q] << 7) | laneBytes));
+                }
+                const bool lastPart = first + (half + 1u) * kPart >= entryCount;
+                if (DIAG == 1) {
+#pragma unroll
+                    for (uint32_t q = 0; q < kQuantizedInFlight; ++q) {
+                        chunk[q & 3u].x += __uint_as_float((u[q].x ^ u[q].y ^ u[q].z ^ u[q].w) & 0x3fffffffu);
+                        chunk[q & 3u].y += x[q];
+                    }
+                    if (++partsInChunk == 4u || lastPart) {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) a[2 * m] += double(chunk[m].x) + double(chunk[m].y);
+                        partsInChunk = 0;
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < kQuantizedInFlight; ++q) {
                     const uint32_t w[4] = {u[q].x, u[q].y, u[q].z, u[q].w};
                     const Float2 xx = {x[q], x[q]};
 #pragma unroll
@@ -265,20 +334,18 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
                         chunk[m] = __builtin_elementwise_fma(xx, qf, chunk[m]);
                     }
                 }
+                if (++partsInChunk == 4u || lastPart) {          // (uniform) sixteen entries per lane at most
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    a[2 * m] += double(chunk[m].x);
-                    a[2 * m + 1] += double(chunk[m].y);
+                    for (int m = 0; m < 4; ++m) {
+                        a[2 * m] += double(chunk[m].x);
+                        a[2 * m + 1] += double(chunk[m].y);
+                        chunk[m] = Float2{0.f, 0.f};
+                    }
+                    partsInChunk = 0;
                 }
             }
         }
-        for (; j < jEnd; j += 8u) {
-            const uint64_t e = entries[j];
-            const uint4 u = *reinterpret_cast<const uint4*>(column + size_t(uint32_t(e)) * 64u);
-            const double x = double(__uint_as_float(uint32_t(e >> 32)));
-            EM2_ACCUMULATE(x, u)
-        }
-#undef EM2_ACCUMULATE
+#undef EM2_LOAD_ENTRIES
 #pragma unroll
         for (int d = 8; d < 64; d <<= 1) {
 #pragma unroll
@@ -298,9 +365,9 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
         for (int t = 0; t < 8; ++t) {
             const double sT = constantsOfLane[t], mxT = constantsOfLane[64 + t], scaleT = constantsOfLane[128 + t];
             const double total = __fma_rn(a[t], scaleT, __dmul_rn(-mean, sT));
-            // (+ the single-precision chunks: 8 * 2^-24 * sum|count * q| * scale <= 4.8e-7 * sum|x| * max|U_i|, and a
+            // (+ the single-precision chunks: 16 * 2^-24 * sum|count * q| * scale <= 9.6e-7 * sum|x| * max|U_i|, and a
             // subnormal slack for them)
-            const double bound = factor * (absMean * fabs(sT) + absX * mxT) + 0.501 * scaleT * absX + 4.8e-7 * absX * mxT +
+            const double bound = factor * (absMean * fabs(sT) + absX * mxT) + 0.501 * scaleT * absX + 9.6e-7 * absX * mxT +
                                  n * 1.5e-45 * scaleT + 1e-300;
             // (a single-precision chunk that overflowed makes the total infinite: undecided as well)
             ambiguous |= !(fabs(total) > bound) || !(fabs(total) <= 1.7976931348623157e308);
@@ -317,7 +384,7 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
         const uint64_t ambMask = __builtin_amdgcn_ballot_w64(ambiguous);
         if (lane == 0u) {
             signatures[size_t(c) * wordCount + word] = w;
-            if ((ambMask & 0xffull) != 0ull) {
+            if ((ambMask & 0xffull) != 0ull && DIAG == 0) {
                 const uint32_t slot = atomicAdd(workCount, 1u);
                 workList[slot] = (uint64_t(c) << 32) | word;
             }
@@ -715,7 +782,7 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
     uint64_t* workList = reinterpret_cast<uint64_t*>(ws + 2u * a + 256u);
     hipError_t e = hipMemsetAsync(workCount, 0, 256, stream);
     if (e != hipSuccess) return e;
-    cellStatsKernel<<<dim3((cellCount + 255u) / 256u), dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, means, sumAbs);
+    cellStatsKernel<<<dim3((cellCount + 3u) / 4u), dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, means, sumAbs);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // EM2_PROJECTION=screen keeps the one-block-per-1024-bits form (A/B measurements); default is the XCD-sliced form
@@ -731,7 +798,10 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
         const int16_t* quantized = reinterpret_cast<const int16_t*>(scales + lshCount);
         const uint32_t cellBlocks = (cellCount + kCellsPerBlock - 1u) / kCellsPerBlock;
         const dim3 grid(cellBlocks * 8u, (wordCount + 7u) / 8u);
-        projectionScreenQuantizedKernel<<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, quantized, scales, sums, maxAbs, means,
+        const char* diagText = getenv("EM2_PROJECTION_DIAG");
+        const int diag = diagText ? atoi(diagText) : 0;
+        auto kernel = diag == 1 ? &projectionScreenQuantizedKernel<1> : (diag == 2 ? &projectionScreenQuantizedKernel<2> : &projectionScreenQuantizedKernel<0>);
+        kernel<<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, quantized, scales, sums, maxAbs, means,
                                                                         sumAbs, lshCount, wordCount, signatures, workList, workCount);
     } else if (sliced) {
         e = hipMemsetAsync(signatures, 0, size_t(cellCount) * wordCount * sizeof(uint64_t), stream);    // halves nobody owns

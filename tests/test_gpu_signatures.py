@@ -135,3 +135,18 @@ def test_screening_with_huge_and_tiny_magnitudes(oracle):
     expect = oracle.compute_signatures(toc, g, c, genes, vectors, L)
     got = capi.compute_signatures(toc, capi.make_counts(g, c), genes, vectors, L)
     assert np.array_equal(got, expect)
+
+
+@pytest.mark.parametrize("spread", [0.0, 6.0, 30.0])
+def test_fractional_counts_and_the_cell_mean(oracle, spread):
+    """The per-cell mean must be the reference's sequentially rounded sum (src/Lsh.cpp:160-170).  cellStatsKernel adds a
+    cell's counts lane-parallel when no addition can round (integer counts, or float counts within ~2^20 of each other)
+    and in stored order otherwise: non-integer counts with a spread of 0, 6 and 30 decimal orders of magnitude."""
+    cells, genes, L = 300, 400, 256
+    toc, g, c = synth.expression_matrix(cells, genes, density=0.3, cluster_count=3, seed=11)
+    idx = np.arange(len(c), dtype=np.uint64)
+    c = (c.astype(np.float64) * 0.37 * np.power(10.0, spread * (synth.uniform01(7, idx) - 0.5))).astype(np.float32)
+    vectors = oracle.generate_lsh_vectors(genes, L, 5)
+    expect = oracle.compute_signatures(toc, g, c, genes, vectors, L)
+    got = capi.compute_signatures(toc, capi.make_counts(g, c), genes, vectors, L)
+    assert np.array_equal(got, expect)
