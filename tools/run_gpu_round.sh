@@ -1,10 +1,13 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_signatures.py -m gpu -x -q -p no:cacheprovider 2>&1 | tail -2
-FUZZ_ONLY=signatures SECONDS=60 timeout 300 python tools/fuzz_parity.py 19 2>&1 | tail -1
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -2
+timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 200 gpurun_out/bench_default.err
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/projtrace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-extra --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/projtrace_bench.json 2>/dev/null
-find $GRAFT_REPO_ROOT/gpurun_out/projtrace -name "*kernel_stats.csv" | head -1 | xargs -I{} python3 -c "
-import csv
-for r in list(csv.DictReader(open('{}')))[:12]: print(r['Name'][:90].ljust(90), r['Calls'], float(r['AverageNs'])/1e6)"
-find $GRAFT_REPO_ROOT/gpurun_out/projtrace -name "*kernel_trace.csv" -delete
-cut -c1-400 $GRAFT_REPO_ROOT/gpurun_out/projtrace_bench.json | tail -1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-extra > /dev/null 2>&1
+find $GRAFT_REPO_ROOT/gpurun_out/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $GRAFT_REPO_ROOT/gpurun_out/kernel_stats_default.csv
+find $GRAFT_REPO_ROOT/gpurun_out/trace -name "*kernel_trace.csv" -delete
+python3 -c "
+import json
+d=json.loads(open('$GRAFT_REPO_ROOT/gpurun_out/bench_default.json').read().strip().splitlines()[-1])
+print(d['ms_per_step'], d['value'], d['phases_ms_rank0'], d['roofline']['kernel_ms'], d['roofline']['frac'], d['roofline_projection']['kernel_ms'])
+print({k:(v.get('ms_per_step') if isinstance(v,dict) else v) for k,v in d.get('extra',{}).items()})"
