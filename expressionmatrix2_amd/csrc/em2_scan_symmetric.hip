@@ -1230,6 +1230,7 @@ __device__ __forceinline__ void replayWalkLogs(const Entry* waveLog, uint32_t lo
 
 // The tile kernel of the sharded scan defers both sides: every lane empties its own two logs, order is irrelevant (the
 // inbox is sorted).  rowBase = cell id of the wave's row 0.
+template <bool WIDE = false>
 __device__ __forceinline__ void drainWalkLogs(const Entry* waveLog, uint32_t logCapacity, const uint32_t (&recordCount)[2], uint32_t lane,
                                               uint32_t rowBase, uint32_t cellCount, uint32_t& emitPos, uint32_t& emitEnd)
 {
@@ -1247,7 +1248,7 @@ __device__ __forceinline__ void drainWalkLogs(const Entry* waveLog, uint32_t log
             r.dot = 0.f;
             if (active) r = loadWalkRecord(log, i);
             const uint32_t col = walkRecordColumn(r.code, lane >> 5);
-            const uint32_t m = uint32_t((kMatrixBits - r.dot) * 0.5f);
+            const uint32_t m = uint32_t(((WIDE ? 2.f : 1.f) * kMatrixBits - r.dot) * 0.5f);
             const bool valid = active && rowId < cellCount;
             const int32_t snapCol = valid ? snap[col] : -1;
             emitColumn(valid && int32_t(m) <= snapCol, col, rowId, m, lane, emitPos, emitEnd);        // target col
@@ -1820,9 +1821,11 @@ fsp4TileKernel(Fsp4Args args)
 // fsp4TileKernel on the matrix cores (1024-bit signatures): tiles are (segment, quad of 4 row blocks), a block of 4
 // waves walks the columns of the segment below the quad in lock step (scanTilesMatrix, both sides deferred); the
 // quad's own 256 columns are done by the v_xor/v_bcnt code.  Prefix and segment lengths are multiples of 256 cells.
-template <bool PINNED>
+template <bool PINNED, bool WIDE = false>
 __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
 {
+    static_assert(!WIDE || PINNED, "the 2048-bit form has the hand-scheduled walk only");
+    constexpr int W32 = WIDE ? 64 : 32;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     FragmentWord4* tiles = reinterpret_cast<FragmentWord4*>(ldsRaw + kernelArgs()->matrixLdsOffset);
@@ -1872,7 +1875,20 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
                 const uint32_t logCapacity = aux->logCapacity < kMatrixLogMargin ? kMatrixLogMargin : aux->logCapacity;
                 Entry* waveLog = aux->logs + size_t(blockIdx.x * 4u + wave) * 64u * logCapacity;
                 uint32_t at = colBegin;
-                while (at < commonEnd) {
+                if (WIDE) {
+                    // (2048 bits: the columns once per half of the wave's rows, see scanTilesMatrixWide)
+                    for (uint32_t rowHalf = 0; rowHalf < 2u; ++rowHalf) {
+                        at = colBegin;
+                        while (at < commonEnd) {
+                            uint32_t records[2] = {0u, 0u};
+                            at = scanTilesMatrixWide<true>(aux->fragments, aux->snap, at, commonEnd, 2u * fragmentBlock + rowHalf,
+                                                           2.f * kMatrixBits - 2.f * float(snapRow), rowHalf, waveLog, logCapacity, records,
+                                                           ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)), ldsAddress(walkBlock));
+                            if (!idle) drainWalkLogs<true>(waveLog, logCapacity, records, lane, rowBase, cellCount, emitPos, emitEnd);
+                        }
+                    }
+                }
+                while (!WIDE && at < commonEnd) {
                     uint32_t records[2] = {0u, 0u};
                     if (aux->pad2) {
                         at = scanTilesMatrixPinned<true, true, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
@@ -1894,14 +1910,14 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
             }
         }
         if (last && !idle) {
-            uint32_t r[32];
-            const uint32_t* rp = kernelArgs()->sig32 + size_t(rowValid ? row : rowBase) * 32u;
+            uint32_t r[W32];
+            const uint32_t* rp = kernelArgs()->sig32 + size_t(rowValid ? row : rowBase) * uint32_t(W32);
 #pragma unroll
-            for (int w = 0; w < 32; ++w) r[w] = rp[w];
+            for (int w = 0; w < W32; ++w) r[w] = rp[w];
             uint32_t at = quadRowBase;
             while (at < rowBase) {
                 ensureInboxRoomForTile(lane, emitPos, emitEnd);
-                at = scanTileEmit<32>(kernelArgs()->sig32, kernelArgs()->snap, at, rowBase, r, row, rowValid, snapRow, lane, emitPos,
+                at = scanTileEmit<W32>(kernelArgs()->sig32, kernelArgs()->snap, at, rowBase, r, row, rowValid, snapRow, lane, emitPos,
                                       emitEnd);
             }
             uint32_t diagEnd = rowBase + 64u;
@@ -1909,10 +1925,10 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
             const uint32_t* sig32 = kernelArgs()->sig32;
             const int32_t* snap = kernelArgs()->snap;
             for (uint32_t col = rowBase; col < diagEnd; ++col) {
-                ScalarPtr cp = (ScalarPtr)(uintptr_t)sig32 + size_t(col) * 32u;
+                ScalarPtr cp = (ScalarPtr)(uintptr_t)sig32 + size_t(col) * uint32_t(W32);
                 uint32_t m = 0;
 #pragma unroll
-                for (int w = 0; w < 32; ++w) popcountAccumulate(m, r[w] ^ cp[w]);
+                for (int w = 0; w < W32; ++w) popcountAccumulate(m, r[w] ^ cp[w]);
                 const int32_t snapCol = snap[col];
                 const bool lower = rowValid && col < row;
                 emitColumn(lower && int32_t(m) <= snapCol, col, row, m, lane, emitPos, emitEnd);      // target col
@@ -1942,6 +1958,14 @@ fsp4TileMatrixPinnedKernel(Fsp4Args args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     tileMatrixBody<true>(ldsRaw);
+}
+
+// 2048-bit signatures
+__global__ void __launch_bounds__(256, 2)
+fsp4TileMatrixWideKernel(Fsp4Args args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    tileMatrixBody<true, true>(ldsRaw);
 }
 
 // max over `count` arrays of `n` int32 laid out back to back (the emulation's stand-in for all_reduce(MAX))
@@ -2487,10 +2511,10 @@ Fsp4ShardPlan fsp4ShardPlan(uint32_t cellCount, uint32_t k, uint32_t rank, uint3
     p.offLists = at;        at += align256(size_t(p.maxOwnBlocks) * 64u * 2u * k * sizeof(Entry));
     p.offControl = at;      at += align256(fsp4ControlBytes(p.maxOwnBlocks * 64u));
     p.offSnap = at;         at += align256(size_t(cellCount) * 4u);
-    p.offTable = at;        at += align256((2u * 256u + 2u) * 4u);
+    p.offTable = at;        at += align256(kTableWords * 4u);
     p.offInboxControl = at; at += 256u;
     p.offPool = at;         at += align256(size_t(p.capLocal) * 8u);
-    p.offFragments = at;    at += align256(size_t(p.blocks) * 64u * 512u);      // FP4 fragments (matrix-core tile kernel)
+    p.offFragments = at;    at += align256(size_t(p.blocks) * 64u * 1024u);     // FP4 fragments of up to 2048 bits (matrix-core kernels)
     p.rankBytes = at;
     p.offGathered = at;     at += align256(size_t(p.capGathered) * 8u);
     p.offSorted = at;       at += align256(size_t(p.capGathered) * 8u);
@@ -2614,7 +2638,8 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
         if (slotCount == 0) return hipSuccess;
         const size_t matrixLdsOffset = (lds + 15u) & ~size_t(15);
         const size_t matrixLds = matrixLdsOffset + scanMatrixLdsBytes(args.k);
-        if (paddedDw == 32u && wavesPerBlock == 4u && M % 256u == 0u && matrixLds <= 150u * 1024u &&
+        const bool wide = matrixWideWanted(paddedDw);
+        if ((paddedDw == 32u || wide) && wavesPerBlock == 4u && M % 256u == 0u && matrixLds <= 150u * 1024u &&
             envNumber("EM2_SCAN_MATRIX", 1) != 0) {
             // Phase 1, the rows beyond the prefix against the prefix columns: all of it below the rows, so all of it for the
             // matrix cores (fsp4ScanMatrixKernel over quads of slots; no quad ever reaches its own columns here).  Phase 0,
@@ -2644,15 +2669,16 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             if (e != hipSuccess) return e;
             e = hipMemcpyAsync(ws + plan.offTable, table, (2u * segments + 2u) * 4u, hipMemcpyHostToDevice, stream);
             if (e != hipSuccess) return e;
-            const uint32_t fragmentCount = plan.blocks * 2u * kMatrixSteps * 64u;
+            const uint32_t matrixSteps = wide ? 2u * kMatrixSteps : kMatrixSteps;
+            const uint32_t fragmentCount = plan.blocks * 2u * matrixSteps * 64u;
             expandFragmentsKernel<<<dim3((fragmentCount + 255u) / 256u), dim3(256), 0, stream>>>(
-                sig32, cellCount, fragmentCount, reinterpret_cast<FragmentWord4*>(ws + plan.offFragments));
+                sig32, cellCount, fragmentCount, reinterpret_cast<FragmentWord4*>(ws + plan.offFragments), matrixSteps);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             args.fragments = ws + plan.offFragments;
             args.matrixLdsOffset = uint32_t(matrixLdsOffset);
             lastLaunchInfo.matrixPairs += double(slotCount) * 64.0 * double(M);
-            const void* matrixKernel = scanMatrixKernelFor(t.identityKeys);
+            const void* matrixKernel = scanMatrixKernelFor(t.identityKeys, wide);
             int device = 0, cuCount = 0;
             e = hipGetDevice(&device);
             if (e != hipSuccess) return e;
@@ -2714,7 +2740,8 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
         const void* kernel = tileKernelFor(paddedDw);
         if (!kernel) return hipErrorInvalidValue;
         // 1024-bit signatures and a prefix of whole quads: the tiles go to the matrix cores (EM2_SCAN_MATRIX=0: never)
-        const bool matrix = paddedDw == 32u && M % 256u == 0u && envNumber("EM2_SCAN_MATRIX", 1) != 0;
+        const bool wide = matrixWideWanted(paddedDw);
+        const bool matrix = (paddedDw == 32u || wide) && M % 256u == 0u && envNumber("EM2_SCAN_MATRIX", 1) != 0;
         const uint32_t span = cellCount - M;
         uint64_t segments = span / (matrix ? 16384u : 1024u);
         if (segments > 256) segments = 256;
@@ -2761,9 +2788,10 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
         e = hipDeviceGetAttribute(&cuCount, hipDeviceAttributeMultiprocessorCount, device);
         if (e != hipSuccess) return e;
         if (matrix) {
-            const uint32_t fragmentCount = plan.blocks * 2u * kMatrixSteps * 64u;
+            const uint32_t matrixSteps = wide ? 2u * kMatrixSteps : kMatrixSteps;
+            const uint32_t fragmentCount = plan.blocks * 2u * matrixSteps * 64u;
             expandFragmentsKernel<<<dim3((fragmentCount + 255u) / 256u), dim3(256), 0, stream>>>(
-                sig32, cellCount, fragmentCount, reinterpret_cast<FragmentWord4*>(ws + plan.offFragments));
+                sig32, cellCount, fragmentCount, reinterpret_cast<FragmentWord4*>(ws + plan.offFragments), matrixSteps);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             args.fragments = ws + plan.offFragments;
@@ -2771,8 +2799,9 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             const size_t matrixLds = args.matrixLdsOffset + kMatrixLdsBytes;
             uint64_t blocksWanted = uint64_t(cuCount) * 2u;
             if (blocksWanted > own) blocksWanted = own;
-            const void* tileMatrixKernel = matrixWalkPinned(2u) ? reinterpret_cast<const void*>(&fsp4TileMatrixPinnedKernel)
-                                                              : reinterpret_cast<const void*>(&fsp4TileMatrixKernel);
+            const void* tileMatrixKernel = wide ? reinterpret_cast<const void*>(&fsp4TileMatrixWideKernel)
+                                                : (matrixWalkPinned(2u) ? reinterpret_cast<const void*>(&fsp4TileMatrixPinnedKernel)
+                                                                        : reinterpret_cast<const void*>(&fsp4TileMatrixKernel));
             e = hipFuncSetAttribute(tileMatrixKernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(matrixLds));
             if (e != hipSuccess) return e;
             void* matrixArgsArray[] = {&args};

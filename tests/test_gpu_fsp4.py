@@ -422,6 +422,21 @@ def test_sharded_virtual_world_tiles_on_the_matrix_cores(oracle, scan_knobs, wor
         assert_same(pairs, gused, cell, sim, used)
 
 
+@pytest.mark.parametrize("world,n,L,permille", [(2, 6000, 2048, 200), (4, 9000, 1500, 300), (3, 5000, 2048, 250), (8, 9000, 1025, 100)])
+def test_sharded_virtual_world_2048_bit_tiles_on_the_matrix_cores(oracle, scan_knobs, world, n, L, permille):
+    """The same with 1025..2048-bit signatures: phases 0 / 1 on fsp4ScanMatrixWideKernel, the tiles on
+    fsp4TileMatrixWideKernel; EM2_SCAN_MATRIX_WIDE=0 (v_xor/v_bcnt everywhere) gives the same bytes."""
+    sig = make(n, L, "clustered")
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, 20, 0.2)
+    for wide in (1, 0):
+        scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=world, EM2_PREFIX_PERMILLE=permille, EM2_TILE_SEGMENTS=3,
+                   EM2_SCAN_MATRIX_WIDE=wide)
+        pairs, gused = capi.find_similar_pairs4(sig, L, 20, 0.2)
+        info = capi.dev_find_similar_pairs4_last_launch()
+        assert info["form"] == 2 and (info["matrix_pairs"] > 0) == bool(wide)
+        assert_same(pairs, gused, cell, sim, used)
+
+
 def test_sharded_tile_walk_repeats_bit_identically(scan_knobs):
     """The deferred square of the sharded scan on the matrix cores (hand-scheduled walk, both sides deferred) against
     the compiler-scheduled walk on a problem of a few thousand tiles, many times over: a tile piece that reaches LDS

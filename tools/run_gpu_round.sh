@@ -1,13 +1,19 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -2
-timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 200 gpurun_out/bench_default.err
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-extra > /dev/null 2>&1
-find $GRAFT_REPO_ROOT/gpurun_out/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $GRAFT_REPO_ROOT/gpurun_out/kernel_stats_default.csv
-find $GRAFT_REPO_ROOT/gpurun_out/trace -name "*kernel_trace.csv" -delete
-python3 -c "
-import json
-d=json.loads(open('$GRAFT_REPO_ROOT/gpurun_out/bench_default.json').read().strip().splitlines()[-1])
-print(d['ms_per_step'], d['value'], d['phases_ms_rank0'], d['roofline']['kernel_ms'], d['roofline']['frac'], d['roofline_projection']['kernel_ms'])
-print({k:(v.get('ms_per_step') if isinstance(v,dict) else v) for k,v in d.get('extra',{}).items()})"
+timeout 600 python - <<'P'
+import os, sys, time
+sys.path.insert(0, "tests")
+import numpy as np, synth
+from expressionmatrix2_amd import capi
+n, L = 300000, 2048
+sig = synth.clustered_signatures(n, L, cluster_count=64, flip=0.15, seed=3)
+os.environ["EM2_SCAN_MODE"] = "virtual"; os.environ["EM2_VIRTUAL_WORLD"] = "4"
+res = {}
+for wide in ("1", "0"):
+    os.environ["EM2_SCAN_MATRIX_WIDE"] = wide
+    for rep in range(2):
+        t = time.time(); pairs, used = capi.find_similar_pairs4(sig, L, 100, 0.2); dt = time.time() - t
+        info = capi.dev_find_similar_pairs4_last_launch()
+    print("virtual world 4, wide", wide, "wall %.3f s" % dt, {k: info[k] for k in ("form", "matrix_pairs", "inbox_entries")})
+    res[wide] = (pairs["cell"].copy(), pairs["similarity"].copy(), used.copy())
+print("same bytes:", all(np.array_equal(a, b) for a, b in zip(res["1"], res["0"])))
+P
