@@ -1593,19 +1593,36 @@ fsp4InboxReplayKernel(Fsp4Args args, const uint64_t* __restrict__ sorted, uint64
     int32_t mMax = rowValid ? int32_t(uint32_t(st >> 32)) : -1;
     const uint32_t nb = args.rowBits;
     const uint64_t fieldMask = (1ull << (2u * nb)) - 1ull;
+    const bool timed = (args.pad2 & 4096u) != 0u;
+    uint64_t clock0 = timed ? __builtin_readcyclecounter() : 0ull, clock1 = 0, clock2 = 0;
     uint64_t bound[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const uint64_t target = uint64_t(row + uint32_t(j)) << nb;
-        uint64_t lo = 0, hi = sortedCount;
-        while (lo < hi) {
-            const uint64_t mid = lo + (hi - lo) / 2u;
-            if (((sorted[mid] >> 13u) & fieldMask) < target) lo = mid + 1u;
-            else hi = mid;
+    {
+        // the two lower bounds in one loop: two independent chains of dependent loads instead of one after the other
+        const uint64_t target0 = uint64_t(row) << nb, target1 = uint64_t(row + 1u) << nb;
+        uint64_t lo0 = 0, hi0 = sortedCount, lo1 = 0, hi1 = sortedCount;
+        while (__builtin_amdgcn_ballot_w64(lo0 < hi0 || lo1 < hi1) != 0ull) {
+            const uint64_t mid0 = lo0 + (hi0 - lo0) / 2u, mid1 = lo1 + (hi1 - lo1) / 2u;
+            const uint64_t v0 = lo0 < hi0 ? sorted[mid0] : 0ull, v1 = lo1 < hi1 ? sorted[mid1] : 0ull;
+            if (lo0 < hi0) {
+                if (((v0 >> 13u) & fieldMask) < target0) lo0 = mid0 + 1u;
+                else hi0 = mid0;
+            }
+            if (lo1 < hi1) {
+                if (((v1 >> 13u) & fieldMask) < target1) lo1 = mid1 + 1u;
+                else hi1 = mid1;
+            }
         }
-        bound[j] = lo;
+        bound[0] = lo0;
+        bound[1] = lo1;
     }
     if (!rowValid) bound[1] = bound[0];
+    if (args.pad2 & 4096u) {        // (EM2_MATRIX_DIAG bit 4096: the longest inbox of a cell and of a wave's 64 cells, for EM2_SCAN_VERBOSE)
+        uint32_t longest = uint32_t(bound[1] - bound[0]);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) longest = max(longest, uint32_t(__shfl_xor(int(longest), d, 64)));
+        if (lane == 0u) atomicMax(args.inboxControl + 8, longest);
+        clock1 = __builtin_readcyclecounter();
+    }
     const uint32_t idMask = (1u << nb) - 1u;
     // Entries are fetched four at a time (independent loads in flight: the loop is latency-bound otherwise) and then
     // offered one by one, in order.
@@ -1626,7 +1643,14 @@ fsp4InboxReplayKernel(Fsp4Args args, const uint64_t* __restrict__ sorted, uint64
             }
         }
     }
+    if (timed) clock2 = __builtin_readcyclecounter();
     finishRows(lane, block, count, ldsRaw);
+    if (timed && lane == 0u) {
+        unsigned long long* cycles = reinterpret_cast<unsigned long long*>(args.inboxControl + 10);
+        atomicAdd(cycles, (unsigned long long)(clock1 - clock0));
+        atomicAdd(cycles + 1, (unsigned long long)(clock2 - clock1));
+        atomicAdd(cycles + 2, (unsigned long long)(__builtin_readcyclecounter() - clock2));
+    }
 }
 
 // =========================================================================================================
@@ -2440,6 +2464,18 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         else fsp4InboxReplayKernel<false><<<rgrid, block, lds, stream>>>(args, sorted, used);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
+    }
+    if (envNumber("EM2_MATRIX_DIAG", 0) & 4096u) {
+        uint32_t longest = 0;
+        if (hipMemcpy(&longest, ws + layout.control + 32u, 4u, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long cycles[3] = {0, 0, 0};
+            (void)hipMemcpy(cycles, ws + layout.control + 40u, sizeof(cycles), hipMemcpyDeviceToHost);
+            const double waves = double(rowBlocks - fullRowBlocks);
+            fprintf(stderr, "[em2] inbox replay: %llu entries, %.1f per cell on average, longest inbox of a cell %u; cycles per wave: "
+                            "search %.0f, replay %.0f, finish %.0f\n",
+                    (unsigned long long)used, double(used) / double(cellCount), longest, double(cycles[0]) / waves,
+                    double(cycles[1]) / waves, double(cycles[2]) / waves);
+        }
     }
     *done = true;
     return hipSuccess;
