@@ -372,17 +372,31 @@ selectPackedKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegi
     }
     waveFence();
     PairOut* out = outPairs + size_t(local) * k;
-    for (uint32_t i = lane; i < n; i += 64u) {
-        const Entry e = kept[i];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < n; ++j) {
-            const Entry o = kept[j];
-            rank += uint32_t((o.key < e.key) || (o.key == e.key && o.cell < e.cell));
+    uint32_t padded = 1;
+    while (padded < n) padded <<= 1;
+    if (padded * 8u <= CAPACITY * 4u) {
+        // (the bitonic network of em2_select_wave.h whenever the position arrays hold the padded list: k <= 1024 at every tier)
+        sortListWave(kept, n, lane);
+        for (uint32_t i = lane; i < n; i += 64u) {
+            const Entry e = kept[i];
+            PairOut po;
+            po.cell = e.cell;
+            po.similarity = keySimilarity[e.key];
+            out[i] = po;
         }
-        PairOut po;
-        po.cell = e.cell;
-        po.similarity = keySimilarity[e.key];
-        out[rank] = po;
+    } else {
+        for (uint32_t i = lane; i < n; i += 64u) {
+            const Entry e = kept[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; ++j) {
+                const Entry o = kept[j];
+                rank += uint32_t((o.key < e.key) || (o.key == e.key && o.cell < e.cell));
+            }
+            PairOut po;
+            po.cell = e.cell;
+            po.similarity = keySimilarity[e.key];
+            out[rank] = po;
+        }
     }
     for (uint32_t i = n + lane; i < k; i += 64u) {
         PairOut zero;

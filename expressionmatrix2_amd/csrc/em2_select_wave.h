@@ -33,6 +33,39 @@ __device__ __forceinline__ void waveSyncGlobal()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Sorts lds[0, n) ascending by (key, cell) -- the order of the reference's final sort by similarity, ties by cell id
+// (src/ExpressionMatrixLsh.cpp:330-340 via keepBest) -- with a bitonic network over the next power of two (< 2n <= 2k
+// slots, which the wave's area has), sentinels behind the entries.  (It was a rank count, n^2 comparisons: 2.8 of the
+// 9.5 ms of the inbox replay kernel at 1M cells, k = 100.)
+__device__ __forceinline__ void sortListWave(Entry* lds, uint32_t n, uint32_t lane)
+{
+    uint32_t padded = 1;
+    while (padded < n) padded <<= 1;
+    for (uint32_t i = n + lane; i < padded; i += 64u) {
+        Entry sentinel;
+        sentinel.cell = 0xffffffffu;
+        sentinel.key = 0xffffffffu;
+        lds[i] = sentinel;
+    }
+    waveSync();
+    for (uint32_t size = 2; size <= padded; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = lane; t < (padded >> 1); t += 64u) {
+                const uint32_t a = ((t & ~(stride - 1u)) << 1) | (t & (stride - 1u));
+                const uint32_t b = a | stride;
+                const Entry ea = lds[a], eb = lds[b];
+                const bool bFirst = (eb.key < ea.key) || (eb.key == ea.key && eb.cell < ea.cell);
+                const bool ascending = (a & size) == 0u;
+                if (bFirst == ascending) {
+                    lds[a] = eb;
+                    lds[b] = ea;
+                }
+            }
+            waveSync();
+        }
+    }
+}
+
 template <bool GLOBAL>
 __device__ __forceinline__ void waveSyncFor()
 {
