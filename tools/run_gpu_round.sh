@@ -1,7 +1,9 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_gpu_fsp5.py tests/test_gpu_fsp4.py -m gpu -x -q -p no:cacheprovider 2>&1 | tail -2
-FUZZ_ONLY=fsp5 SECONDS=90 timeout 400 python tools/fuzz_parity.py 55 2>&1 | tail -1
-timeout 900 python bench.py --workload fsp5 --steps 3 --warmup 1 2>/dev/null | python -c "
-import json,sys
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(d['ms_per_step'], d['phases_ms'], d['parity_check'])"
+mkdir -p gpurun_out
+for i in 1 2 3; do
+timeout 900 python bench.py --workload fsp5 --steps 3 --warmup 1 > gpurun_out/bench_fsp5_$i.json 2>/dev/null
+python3 -c "
+import json
+d=json.loads(open('gpurun_out/bench_fsp5_$i.json').read().strip().splitlines()[-1])
+print(d['ms_per_step'], d['phases_ms'], d['roofline']['frac'])"
+done
