@@ -12,7 +12,9 @@ import re
 import sys
 
 OWNED_FIRST = 64          # v30..v63 are the steps' temporaries: dead between steps, the compiler may use them there
-PERSISTENT = (28, 29)     # ... but v28 / v29 hold the lane's record offsets from step to step
+# ... but v28 / v29 hold the lane's record offsets from step to step, and v48..v63 are the ring of column fragments, which
+# the step of a pair's first tile leaves IN FLIGHT for the step of the second (gen_matrix_step_asm.py, CARRY)
+PERSISTENT = (28, 29) + tuple(range(48, 64))
 
 
 def functions(lines):
@@ -59,6 +61,10 @@ def main():
             bad = [r for r in registers(line) if r >= OWNED_FIRST or (between and r in PERSISTENT)]
             if bad:
                 print("%s: compiler code touches v%d between the steps: %s" % (name, bad[0], line.strip()))
+                failures += 1
+            if between and re.search(r"\bs_(buffer_)?load_", line):
+                # the steps count their LDS waits (lgkmcnt); scalar loads share the counter and return out of order
+                print("%s: scalar load between the steps: %s" % (name, line.strip()))
                 failures += 1
             if "flat_" in line and first_step is not None and first_step <= i <= last_step:
                 print("%s: flat instruction between the steps: %s" % (name, line.strip()))

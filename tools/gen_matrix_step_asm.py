@@ -152,7 +152,17 @@ import os
 PLACE = os.environ.get("EM2_GEN_PLACE", "SM,DC").split(",")
 
 
-def place(s, o, k, what, prev0, prev1, slot):
+def fragment_read(s, k, slot, carry):
+    """The ring's refill behind k-step k: fragment k + 4 of this tile -- or, in a step that hands the ring over to the step
+    of the next tile (carry: the first tile of a pair; its partner sits 16 KB further in LDS), fragment k - 12 of that."""
+    if k + 4 < STEPS:
+        s.lds("a%d" % (k + 4), "ds_read_b128 %s, %s offset:%d" % (vreg(slot, 4), vreg(TILE_ADDR), 1024 * (k + 4)))
+    elif carry:
+        s.lds("n%d" % (k + 4 - STEPS), "ds_read_b128 %s, %s offset:%d"
+              % (vreg(slot, 4), vreg(TILE_ADDR), 16384 + 1024 * (k + 4 - STEPS)))
+
+
+def place(s, o, k, what, prev0, prev1, slot, carry=False):
     q, j = k >> 2, k & 3
     bound = BOUNDS + 4 * (q & 1) + j
     for letter in what:
@@ -164,8 +174,7 @@ def place(s, o, k, what, prev0, prev1, slot):
             s.emit("v_min_f32 %s, %s, %s" % (vreg(THR0), vreg(ROW_BOUND0), vreg(bound)))
             s.emit("v_min_f32 %s, %s, %s" % (vreg(THR1), vreg(ROW_BOUND1), vreg(bound)))
         if letter == "D":
-            if k + 4 < STEPS:
-                s.lds("a%d" % (k + 4), "ds_read_b128 %s, %s offset:%d" % (vreg(slot, 4), vreg(TILE_ADDR), 1024 * (k + 4)))
+            fragment_read(s, k, slot, carry)
             if j == 1 and q < 3:
                 s.lds("bounds%d" % (q + 1), "ds_read_b128 %s, %s offset:%d"
                       % (vreg(BOUNDS + 4 * ((q + 1) & 1), 4), vreg(BOUND_ADDR), 32 * (q + 1)))
@@ -174,15 +183,29 @@ def place(s, o, k, what, prev0, prev1, slot):
             s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass1_%d" % (k & 1)], vreg(THR1), vreg(prev1 + k)))
 
 
+# The ring of fragments runs through a PAIR of tiles: the step of a pair's first tile (X) ends by reading the first four
+# fragments of the second (16 KB further in LDS: the slots of a pair are adjacent and both were staged before the pair's
+# barrier), and the step of the second tile (Y) starts with them in flight -- no LDS round trip in front of its first MFMA.
+# EM2_GEN_CARRY=0 generates the steps without it (every step fills the ring itself).
+CARRY = os.environ.get("EM2_GEN_CARRY", "1") != "0"
+
+
 def step(cur, prev, tests, operands):
     """cur / prev: 'X' or 'Y'.  operands: placeholder names -> asm operand text."""
     cur0, cur1 = SETS[cur]
     prev0, prev1 = SETS[prev]
     o = operands
     s = Stream()
+    carry_out = CARRY and cur == "X"
+    carry_in = CARRY and cur == "Y"
+    if carry_in:
+        # (in flight since the previous step; whatever the compiler put between the two steps is younger, and LDS
+        # operations complete in order: a wait that leaves this many outstanding has the fragment it needs)
+        s.queue.extend("a%d" % k for k in range(4))
     prologue(s, o, True, tests)
     for k in range(4):
-        s.lds("a%d" % k, "ds_read_b128 %s, %s offset:%d" % (vreg(RING + 4 * k, 4), vreg(TILE_ADDR), 1024 * k))
+        if not carry_in:
+            s.lds("a%d" % k, "ds_read_b128 %s, %s offset:%d" % (vreg(RING + 4 * k, 4), vreg(TILE_ADDR), 1024 * k))
     for k in range(STEPS):
         slot = RING + 4 * (k % 4)
         s.wait_for("a%d" % k)
@@ -192,11 +215,13 @@ def step(cur, prev, tests, operands):
             s.emit("v_mfma_f32_32x32x64_f8f6f4 %s, %s, %s, %s cbsz:4 blgp:4"
                    % (vreg(acc, 16), vreg(slot, 4), vreg(rows + 4 * k, 4), "0" if k == 0 else vreg(acc, 16)))
             if a == 0 and tests:
-                place(s, o, k, PLACE[0], prev0, prev1, slot)
+                place(s, o, k, PLACE[0], prev0, prev1, slot, carry_out)
         if tests:
-            place(s, o, k, PLACE[1], prev0, prev1, slot)
-        elif k + 4 < STEPS:
-            s.lds("a%d" % (k + 4), "ds_read_b128 %s, %s offset:%d" % (vreg(slot, 4), vreg(TILE_ADDR), 1024 * (k + 4)))
+            place(s, o, k, PLACE[1], prev0, prev1, slot, carry_out)
+        else:
+            fragment_read(s, k, slot, carry_out)
+    # (the next tile's fragments stay in flight: the next step waits for them)
+    s.queue = [name for name in s.queue if not name.startswith("n")]
     assert not s.queue, s.queue
     if tests:
         shift_in(s, o, STEPS - 1)
