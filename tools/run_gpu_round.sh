@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT
-FUZZ_ONLY=fsp4 SECONDS=400 timeout 700 python tools/fuzz_parity.py 31337 2>&1 | tail -1
-FUZZ_ONLY=fsp4 FUZZ_WIDTHS=1025,1100,1500,2000,2048 SECONDS=300 timeout 600 python tools/fuzz_parity.py 271828 2>&1 | tail -1
-FUZZ_ONLY=signatures SECONDS=200 timeout 500 python tools/fuzz_parity.py 1618 2>&1 | tail -1
-FUZZ_ONLY=fsp5 SECONDS=200 timeout 500 python tools/fuzz_parity.py 1414 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_gpu_fsp5.py -m gpu -x -q -p no:cacheprovider 2>&1 | tail -2
+FUZZ_ONLY=fsp5 SECONDS=100 timeout 400 python tools/fuzz_parity.py 77 2>&1 | tail -1
+timeout 900 python bench.py --workload fsp5 --steps 3 --warmup 1 2>/dev/null | python -c "
+import json,sys
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(d['ms_per_step'], d['phases_ms'], d['parity_check'])"
