@@ -163,9 +163,22 @@ vectorStatsKernel(const double* __restrict__ vectors, uint32_t geneCount, uint32
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= lshCount) return;
     double s = 0., m = 0.;
-    for (uint32_t g = 0; g < geneCount; ++g) {
+    // (sixteen loads in flight, the additions in gene order: with one load per addition the kernel sat in memory latency
+    // 30,000 times per column, 12 ms)
+    uint32_t g = 0;
+    for (; g + 16u <= geneCount; g += 16u) {
+        double u[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) u[q] = vectors[size_t(g + uint32_t(q)) * lshCount + i];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            s = __dadd_rn(s, u[q]);                               // Lsh.cpp:137-144
+            m = fmax(m, fabs(u[q]));
+        }
+    }
+    for (; g < geneCount; ++g) {
         const double u = vectors[size_t(g) * lshCount + i];
-        s = __dadd_rn(s, u);                                      // Lsh.cpp:137-144
+        s = __dadd_rn(s, u);
         m = fmax(m, fabs(u));
     }
     sums[i] = s;
