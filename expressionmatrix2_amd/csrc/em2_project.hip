@@ -811,9 +811,13 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
         const int16_t* quantized = reinterpret_cast<const int16_t*>(scales + lshCount);
         const uint32_t cellBlocks = (cellCount + kCellsPerBlock - 1u) / kCellsPerBlock;
         const dim3 grid(cellBlocks * 8u, (wordCount + 7u) / 8u);
+#ifdef EM2_DIAG
         const char* diagText = getenv("EM2_PROJECTION_DIAG");
         const int diag = diagText ? atoi(diagText) : 0;
         auto kernel = diag == 1 ? &projectionScreenQuantizedKernel<1> : (diag == 2 ? &projectionScreenQuantizedKernel<2> : &projectionScreenQuantizedKernel<0>);
+#else
+        auto kernel = &projectionScreenQuantizedKernel<0>;
+#endif
         kernel<<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, quantized, scales, sums, maxAbs, means,
                                                                         sumAbs, lshCount, wordCount, signatures, workList, workCount);
     } else if (sliced) {

@@ -442,7 +442,11 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     args.shardFlags = 0;
     args.fragments = nullptr;
     args.matrixLdsOffset = 0;
+#ifdef EM2_DIAG
     args.pad2 = uint32_t(envNumber("EM2_MATRIX_DIAG", 0));       // measurements only (fsp4ScanMatrixKernel)
+#else
+    args.pad2 = 0;
+#endif
 
     {
         // EM2_SCAN_MODE=virtual + EM2_VIRTUAL_WORLD=P: the multi-GPU symmetric scan with all ranks played on this GPU

@@ -61,8 +61,19 @@ struct Fsp4Args {
     // matrix-core form of the symmetric scan only (em2_scan_symmetric.hip)
     const void* fragments;      // the signatures as FP4 +-1 in MFMA fragment order, 512 B per cell
     uint32_t matrixLdsOffset;   // where the column tiles start in the block's dynamic LDS
-    uint32_t pad2;
+    uint32_t pad2;              // diagnostic build only (EM2_DIAG_WORD below): the EM2_MATRIX_DIAG bits; 0 in the product
 };
+
+// Measurement knobs that switch parts of the kernels off (EM2_MATRIX_DIAG, EM2_PROJECTION_DIAG) give wrong results by
+// design.  They exist only in the diagnostic build (`make diag` -> libem2lsh_diag.so, compiled with -DEM2_DIAG, loaded by
+// the tools through EM2_LIBRARY); the product library neither reads the variables nor contains the branches.
+#ifdef EM2_DIAG
+#define EM2_DIAG_WORD(args) ((args)->pad2)
+#define EM2_DIAG_WORD_OF(args) ((args).pad2)
+#else
+#define EM2_DIAG_WORD(args) 0u
+#define EM2_DIAG_WORD_OF(args) 0u
+#endif
 
 constexpr uint32_t kShardNoFinish = 1u;       // full-row blocks publish their state instead of finishing the rows
 constexpr uint32_t kShardPublishAll = 2u;     // full-row blocks publish snapshots as well
@@ -320,6 +331,17 @@ inline uint64_t envNumber(const char* name, uint64_t fallback)
     return end == v ? fallback : uint64_t(x);
 }
 
+
+// The value of a measurement knob: 0 in the product, the environment variable in the diagnostic build.
+inline uint64_t diagNumber(const char* name)
+{
+#ifdef EM2_DIAG
+    return envNumber(name, 0);
+#else
+    (void)name;
+    return 0;
+#endif
+}
 
 // What the last launch on the calling thread did (defined in em2_scan.hip).
 extern thread_local Fsp4LaunchInfo lastLaunchInfo;

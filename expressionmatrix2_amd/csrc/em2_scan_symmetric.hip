@@ -841,7 +841,7 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     const uint64_t logBase = uniform64(reinterpret_cast<uint64_t>(waveLogArg));
     // (EM2_MATRIX_DIAG, measurements only: the walk that looks at the bits is an instantiation of its own, so that the
     // one that runs in production has none of their branches between its steps)
-    const uint32_t diag = DIAG ? ((ArgsPtr)uniform64(reinterpret_cast<uint64_t>(auxArg)))->pad2 : 0u;
+    const uint32_t diag = DIAG ? EM2_DIAG_WORD((ArgsPtr)uniform64(reinterpret_cast<uint64_t>(auxArg))) : 0u;
     const uint32_t halfCapacity = logCapacity / 2u;
     // byte offsets into the wave's log area: where the lane's two logs begin, where its next records go (kept in two
     // registers of the walk; the steps return them), and beyond which the walk has to stop
@@ -1356,7 +1356,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
             const uint32_t done = uint32_t(__builtin_amdgcn_readfirstlane(
                 int(__hip_atomic_load(aux->segmentsDone + block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
             if (done != 0u) {
-                if (done >= seg && !(aux->pad2 & 512u)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (done >= seg && !(EM2_DIAG_WORD(aux) & 512u)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 const uint64_t st = __hip_atomic_load(reinterpret_cast<const uint64_t*>(aux->rowState) + size_t(block) * 64u + lane,
                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 mMax = rowValid ? int32_t(uint32_t(st >> 32)) : -1;
@@ -1380,7 +1380,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                                                        recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                        ldsAddress(walkBlock));
                 } else if (PINNED) {
-                    if (aux->pad2) {
+                    if (EM2_DIAG_WORD(aux)) {
                         at = scanTilesMatrixPinned<IDENTITY, false, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
                                                          rowFragmentBlock, kMatrixBits - 2.f * float(mMax), myLog - size_t(lane) * logCapacity,
                                                          logCapacity, recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
@@ -1412,7 +1412,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                 if (failed) {
                     if (lane == 0u) __hip_atomic_store(aux->control + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
-                    if (!(aux->pad2 & 512u)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (!(EM2_DIAG_WORD(aux) & 512u)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     const uint64_t st = __hip_atomic_load(reinterpret_cast<const uint64_t*>(aux->rowState) + size_t(block) * 64u + lane,
                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     count = uint32_t(st);
@@ -1508,7 +1508,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 // (EM2_MATRIX_DIAG bits 256 / 512, measurements only: no release / no acquire -- results may be wrong)
-                if (!(aux2->pad2 & 256u)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (!(EM2_DIAG_WORD(aux2) & 256u)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0u && !(fullRows ? finalSegment : last)) {
                     __hip_atomic_store(aux2->segmentsDone + block, seg + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1593,7 +1593,7 @@ fsp4InboxReplayKernel(Fsp4Args args, const uint64_t* __restrict__ sorted, uint64
     int32_t mMax = rowValid ? int32_t(uint32_t(st >> 32)) : -1;
     const uint32_t nb = args.rowBits;
     const uint64_t fieldMask = (1ull << (2u * nb)) - 1ull;
-    const bool timed = (args.pad2 & 4096u) != 0u;
+    const bool timed = (EM2_DIAG_WORD_OF(args) & 4096u) != 0u;
     uint64_t clock0 = timed ? __builtin_readcyclecounter() : 0ull, clock1 = 0, clock2 = 0;
     uint64_t bound[2];
     {
@@ -1616,7 +1616,7 @@ fsp4InboxReplayKernel(Fsp4Args args, const uint64_t* __restrict__ sorted, uint64
         bound[1] = lo1;
     }
     if (!rowValid) bound[1] = bound[0];
-    if (args.pad2 & 4096u) {        // (EM2_MATRIX_DIAG bit 4096: the longest inbox of a cell and of a wave's 64 cells, for EM2_SCAN_VERBOSE)
+    if (EM2_DIAG_WORD_OF(args) & 4096u) {        // (EM2_MATRIX_DIAG bit 4096: the longest inbox of a cell and of a wave's 64 cells, for EM2_SCAN_VERBOSE)
         uint32_t longest = uint32_t(bound[1] - bound[0]);
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) longest = max(longest, uint32_t(__shfl_xor(int(longest), d, 64)));
@@ -1914,7 +1914,7 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
                 }
                 while (!WIDE && at < commonEnd) {
                     uint32_t records[2] = {0u, 0u};
-                    if (aux->pad2) {
+                    if (EM2_DIAG_WORD(aux)) {
                         at = scanTilesMatrixPinned<true, true, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
                                                            2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), waveLog, logCapacity,
                                                            records, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
@@ -2029,7 +2029,7 @@ static bool matrixWalkPinned(uint32_t which = 1u) { return (envNumber("EM2_MATRI
 
 static const void* scanMatrixKernelFor(bool identity, bool wide = false)
 {
-    if (identity && (envNumber("EM2_MATRIX_DIAG", 0) & 2048u) && (wide || matrixWalkPinned())) {
+    if (identity && (diagNumber("EM2_MATRIX_DIAG") & 2048u) && (wide || matrixWalkPinned())) {
         return wide ? reinterpret_cast<const void*>(&fsp4ScanMatrixTimedKernel<true>)
                     : reinterpret_cast<const void*>(&fsp4ScanMatrixTimedKernel<false>);
     }
@@ -2409,7 +2409,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     }
     const uint64_t used = uint64_t(inboxWords[0]) | (uint64_t(inboxWords[1]) << 32);
     if (inboxWords[2] != 0u || used > layout.capacity) return hipSuccess;      // overflow: *done stays false
-    if (matrix && (envNumber("EM2_MATRIX_DIAG", 0) & 2048u)) {
+    if (matrix && (diagNumber("EM2_MATRIX_DIAG") & 2048u)) {
         unsigned long long cycles[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpy(cycles, ws + layout.control + 64u, sizeof(cycles), hipMemcpyDeviceToHost) == hipSuccess) {
             double total = 0;
@@ -2465,7 +2465,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    if (envNumber("EM2_MATRIX_DIAG", 0) & 4096u) {
+    if (diagNumber("EM2_MATRIX_DIAG") & 4096u) {
         uint32_t longest = 0;
         if (hipMemcpy(&longest, ws + layout.control + 32u, 4u, hipMemcpyDeviceToHost) == hipSuccess) {
             unsigned long long cycles[3] = {0, 0, 0};

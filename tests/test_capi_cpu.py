@@ -41,6 +41,15 @@ def test_library_holds_gfx950_code(lib):
     assert b"fsp4ScanKernel" in blob and b"projectionKernel" in blob
 
 
+def test_product_library_has_no_measurement_knobs(lib):
+    """EM2_MATRIX_DIAG / EM2_PROJECTION_DIAG switch parts of kernels off and give wrong SimilarPairs by design: they are
+    compiled only into libem2lsh_diag.so (make diag, -DEM2_DIAG).  The product library must not even contain the names."""
+    blob = open(capi.LIBRARY_PATH, "rb").read()
+    assert b"EM2_MATRIX_DIAG" not in blob and b"EM2_PROJECTION_DIAG" not in blob
+    makefile = open(os.path.join(ROOT, "expressionmatrix2_amd", "csrc", "Makefile")).read()
+    assert "-DEM2_DIAG" in makefile and "libem2lsh_diag.so" in makefile
+
+
 def test_generate_vectors_matches_oracle(lib, oracle):
     for genes, L, seed in [(7, 64, 231), (50, 128, 231), (33, 100, 5), (1, 1, 9)]:
         a = capi.lsh_generate_vectors(genes, L, seed)

@@ -463,3 +463,24 @@ def test_threshold_sweep_evicts_cached_tables(oracle):
         cell, sim, used = oracle.find_similar_pairs4(sig, 128, 5, thr)
         pairs, gused = capi.find_similar_pairs4(sig, 128, 5, thr)
         assert_same(pairs, gused, cell, sim, used)
+
+
+@pytest.mark.parametrize("name,value", [("EM2_MATRIX_DIAG", v) for v in (1, 16, 32, 64, 128, 256, 512, 2048, 4096)] +
+                         [("EM2_PROJECTION_DIAG", v) for v in (1, 2)])
+def test_measurement_knobs_do_nothing_in_the_product_library(oracle, monkeypatch, name, value):
+    """The knobs that switch parts of the kernels off exist in libem2lsh_diag.so only (csrc/Makefile, -DEM2_DIAG): with the
+    product library every one of them leaves signatures and SimilarPairs bit-identical to the oracle -- in the matrix-core
+    form of the scan (forced at this size), where EM2_MATRIX_DIAG used to act, and in the 16-bit projection tier."""
+    cells, genes, L, k, thr = 3000, 800, 1024, 10, 0.2
+    toc, g, c = synth.expression_matrix(cells, genes, density=0.03, cluster_count=6, seed=17)
+    vectors = capi.lsh_generate_vectors(genes, L, 231)
+    expected_sig = oracle.compute_signatures(toc, g, c, genes, vectors, L)
+    cell, sim, used = oracle.find_similar_pairs4(expected_sig, L, k, thr)
+    monkeypatch.setenv(name, str(value))
+    monkeypatch.setenv("EM2_SCAN_MODE", "triangle")
+    monkeypatch.setenv("EM2_FULL_ROW_CELLS", "256")
+    sig = capi.compute_signatures(toc, capi.make_counts(g, c), genes, vectors, L)
+    assert np.array_equal(sig, expected_sig)
+    pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    assert capi.dev_find_similar_pairs4_last_launch()["form"] == 3
+    assert_same(pairs, gused, cell, sim, used)
