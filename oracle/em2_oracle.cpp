@@ -36,6 +36,8 @@
 #include <utility>
 #include <map>
 #include <set>
+#include <unordered_map>
+#include <unordered_set>
 #include <functional>
 #include <limits>
 #include <vector>
@@ -379,35 +381,47 @@ int em2o_find_similar_pairs5(
 }
 
 
-// findSimilarPairs5 for the cells [rowBegin,rowEnd) only (tables over all cells): the checker for shards and for
-// sampled cells of problems too large to run in full.  Same code path as above per cell.
-int em2o_find_similar_pairs5_rows(
+// findSimilarPairs5 for a LIST of cells (tables over all cells): the checker for shards and for sampled cells of
+// problems too large to run in full -- the tables are built once, then the loop body of em2o_find_similar_pairs5 runs
+// per listed cell.  The tables are the reference's (:377-389: per slice one vector per slice value, cells ascending)
+// in a flat form: per slice the cells ordered by (value, cell id) with the offsets of the values' runs -- the same
+// buckets with the same content in the same order, without 2^q vector headers per slice (2.6 GB at q = 20, 102 slices).
+int em2o_find_similar_pairs5_cells(
     const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount,
     uint32_t k, double similarityThreshold, uint32_t lshSliceLength, uint64_t bucketOverflow,
-    uint32_t rowBegin, uint32_t rowEnd, uint32_t* outCell, float* outSim, uint32_t* outUsed)
+    const uint32_t* cells, uint32_t listed, uint32_t* outCell, float* outSim, uint32_t* outUsed)
 {
     if (lshSliceLength == 0 || lshSliceLength > 30) return 1;
     const size_t W = (size_t(lshCount) - 1) / 64 + 1;
     std::vector<double> table;
     similarityTable(lshCount, table);
     const size_t sliceCount = size_t(lshCount) / lshSliceLength;
-    std::vector< std::vector< std::vector<CellId> > > tables(sliceCount);
+    const size_t valueCount = size_t(1) << lshSliceLength;
+    // counting sort per slice: stable, so the cells of a bucket ascend like the reference's push_back order
+    std::vector<std::vector<uint32_t>> start(sliceCount), members(sliceCount);
+    std::vector<uint32_t> value(cellCount);
     for (size_t s = 0; s < sliceCount; s++) {
-        tables[s].resize(1ULL << lshSliceLength);
+        start[s].assign(valueCount + 1, 0u);
         for (CellId c = 0; c < cellCount; c++) {
-            tables[s][getBitsRange(signatures + size_t(c) * W, s * lshSliceLength, lshSliceLength)].push_back(c);
+            value[c] = uint32_t(getBitsRange(signatures + size_t(c) * W, s * lshSliceLength, lshSliceLength));
+            ++start[s][value[c] + 1];
         }
+        for (size_t v = 0; v < valueCount; v++) start[s][v + 1] += start[s][v];
+        members[s].resize(cellCount);
+        std::vector<uint32_t> at(start[s].begin(), start[s].end() - 1);
+        for (CellId c = 0; c < cellCount; c++) members[s][at[value[c]]++] = c;
     }
-    std::vector< std::vector<Pair> > tmp(rowEnd - rowBegin);
+    std::vector< std::vector<Pair> > tmp(listed);
     std::vector<CellId> candidates;
     std::vector<Pair> cellNeighbors;
-    for (CellId c0 = rowBegin; c0 < rowEnd; c0++) {
+    for (uint32_t i = 0; i < listed; i++) {
+        const CellId c0 = cells[i];
         candidates.clear();
         for (size_t s = 0; s < sliceCount; s++) {
-            const std::vector<CellId>& bucket =
-                tables[s][getBitsRange(signatures + size_t(c0) * W, s * lshSliceLength, lshSliceLength)];
-            if (bucketOverflow == 0 || bucket.size() <= bucketOverflow) {
-                candidates.insert(candidates.end(), bucket.begin(), bucket.end());
+            const uint64_t v = getBitsRange(signatures + size_t(c0) * W, s * lshSliceLength, lshSliceLength);
+            const size_t size = start[s][v + 1] - start[s][v];
+            if (bucketOverflow == 0 || size <= bucketOverflow) {
+                candidates.insert(candidates.end(), members[s].begin() + start[s][v], members[s].begin() + start[s][v + 1]);
             }
         }
         std::sort(candidates.begin(), candidates.end());
@@ -419,10 +433,22 @@ int em2o_find_similar_pairs5_rows(
             if (similarity > similarityThreshold) cellNeighbors.push_back(std::make_pair(c1, float(similarity)));
         }
         keepBest(cellNeighbors, k);
-        tmp[c0 - rowBegin] = cellNeighbors;
+        tmp[i] = cellNeighbors;
     }
     storeAndSort(tmp, k, outCell, outSim, outUsed);
     return 0;
+}
+
+// The cells [rowBegin, rowEnd).
+int em2o_find_similar_pairs5_rows(
+    const uint64_t* signatures, uint32_t cellCount, uint32_t lshCount,
+    uint32_t k, double similarityThreshold, uint32_t lshSliceLength, uint64_t bucketOverflow,
+    uint32_t rowBegin, uint32_t rowEnd, uint32_t* outCell, float* outSim, uint32_t* outUsed)
+{
+    std::vector<uint32_t> cells;
+    for (uint32_t c = rowBegin; c < rowEnd; c++) cells.push_back(c);
+    return em2o_find_similar_pairs5_cells(signatures, cellCount, lshCount, k, similarityThreshold, lshSliceLength, bucketOverflow,
+                                          cells.data(), uint32_t(cells.size()), outCell, outSim, outUsed);
 }
 
 
@@ -625,6 +651,55 @@ uint64_t em2o_cell_graph_edges(const void* pairsRaw, const uint32_t* usedCount, 
     return edgeCount;
 }
 
+
+// The same edge list for problems of a million cells, where the literal form above (a std::map of the vertices, a std::set of
+// 15 million edges) takes minutes: the two containers become hash tables, nothing else changes -- same loop, same order of
+// the add_edge calls, same first-entry-wins vertex table.  tests/test_cell_graph_cpu.py holds the two equal on every case
+// of the literal form, which stays the definition.
+uint64_t em2o_cell_graph_edges_hashed(const void* pairsRaw, const uint32_t* usedCount, uint32_t similarPairsCellCount, uint32_t k,
+                                      const uint32_t* similarPairsCellSet, const uint32_t* graphCellSet, uint32_t graphCellCount,
+                                      double similarityThreshold, uint64_t maxConnectivity, uint32_t* edgeVertex0,
+                                      uint32_t* edgeVertex1, float* edgeSimilarity)
+{
+    struct StoredPair { uint32_t cell; float similarity; };
+    const StoredPair* pairs = static_cast<const StoredPair*>(pairsRaw);
+    std::unordered_map<uint32_t, uint32_t> vertexTable;
+    vertexTable.reserve(size_t(graphCellCount) * 2u);
+    for (uint32_t v = 0; v < graphCellCount; v++) vertexTable.insert(std::make_pair(graphCellSet[v], v));     // keeps the first
+    std::unordered_set<uint64_t> existing;
+    existing.reserve(size_t(graphCellCount) * size_t(maxConnectivity ? std::min<uint64_t>(maxConnectivity, k) : k));
+    uint64_t edgeCount = 0;
+    std::vector<std::pair<uint32_t, float>> selected;
+    for (uint32_t i = 0; i < graphCellCount; i++) {
+        const uint32_t cellId0 = graphCellSet[i];
+        const uint32_t* it = std::lower_bound(similarPairsCellSet, similarPairsCellSet + similarPairsCellCount, cellId0);
+        if (it == similarPairsCellSet + similarPairsCellCount || *it != cellId0) continue;
+        const uint32_t local0 = uint32_t(it - similarPairsCellSet);
+        const uint32_t v0 = vertexTable[cellId0];
+        selected.clear();
+        const StoredPair* begin = pairs + size_t(local0) * k;
+        const StoredPair* end = begin + usedCount[local0];
+        for (const StoredPair* p = begin; p != end; ++p) {
+            const float similarity = p->similarity;
+            if (similarity < similarityThreshold) break;
+            const uint32_t cellId1 = similarPairsCellSet[p->cell];
+            const auto it1 = vertexTable.find(cellId1);
+            if (it1 == vertexTable.end()) continue;
+            selected.push_back(std::make_pair(it1->second, similarity));
+            if (selected.size() == maxConnectivity) break;
+        }
+        for (const auto& s : selected) {
+            const uint32_t v1 = s.first;
+            const uint64_t key = (uint64_t(std::min(v0, v1)) << 32) | std::max(v0, v1);
+            if (!existing.insert(key).second) continue;
+            edgeVertex0[edgeCount] = v0;
+            edgeVertex1[edgeCount] = v1;
+            edgeSimilarity[edgeCount] = s.second;
+            ++edgeCount;
+        }
+    }
+    return edgeCount;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // CellGraph::labelPropagationClustering (src/CellGraph.cpp:443-612) with ClusterTable (src/CellGraph.hpp:50-121),

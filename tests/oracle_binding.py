@@ -44,6 +44,9 @@ class Oracle:
         lib.em2o_find_similar_pairs5_rows.argtypes = [P, c.c_uint32, c.c_uint32, c.c_uint32, c.c_double, c.c_uint32,
                                                       c.c_uint64, c.c_uint32, c.c_uint32, P, P, P]
         lib.em2o_find_similar_pairs5_rows.restype = c.c_int
+        lib.em2o_find_similar_pairs5_cells.argtypes = [P, c.c_uint32, c.c_uint32, c.c_uint32, c.c_double, c.c_uint32,
+                                                       c.c_uint64, P, c.c_uint32, P, P, P]
+        lib.em2o_find_similar_pairs5_cells.restype = c.c_int
         lib.em2o_keep_best.argtypes = [P, P, c.c_uint32, c.c_uint32]
         lib.em2o_keep_best.restype = c.c_uint32
         lib.em2o_multiple_set_union.argtypes = [P, P, c.c_uint32, P]
@@ -54,6 +57,8 @@ class Oracle:
         lib.em2o_cell_graph_edges.argtypes = [P, P, c.c_uint32, c.c_uint32, P, P, c.c_uint32, c.c_double, c.c_uint64,
                                               P, P, P]
         lib.em2o_cell_graph_edges.restype = c.c_uint64
+        lib.em2o_cell_graph_edges_hashed.argtypes = lib.em2o_cell_graph_edges.argtypes
+        lib.em2o_cell_graph_edges_hashed.restype = c.c_uint64
         lib.em2o_label_propagation.argtypes = [P, c.c_uint32, P, P, P, c.c_uint64, c.c_uint64, c.c_uint64, c.c_uint64, P]
         lib.em2o_label_propagation.restype = c.c_uint64
         lib.em2o_murmur_hash_64a.argtypes = [P, c.c_int, c.c_uint64]
@@ -187,6 +192,19 @@ class Oracle:
             raise ValueError("oracle fsp5 rejected the arguments")
         return cell, sim, used
 
+    def find_similar_pairs5_cells(self, sig, lsh_count, k, thr, slice_length, bucket_overflow, cells):
+        """findSimilarPairs5 for the listed cells only (the tables, over all cells, are built once)."""
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        cells = np.ascontiguousarray(cells, dtype=np.uint32)
+        cell = np.zeros((len(cells), k), dtype=np.uint32)
+        sim = np.zeros((len(cells), k), dtype=np.float32)
+        used = np.zeros(len(cells), dtype=np.uint32)
+        rc = self.lib.em2o_find_similar_pairs5_cells(_ptr(sig), sig.shape[0], lsh_count, k, thr, slice_length,
+                                                     bucket_overflow, _ptr(cells), len(cells), _ptr(cell), _ptr(sim), _ptr(used))
+        if rc != 0:
+            raise ValueError("oracle fsp5 rejected the arguments")
+        return cell, sim, used
+
     def find_similar_pairs7(self, sig, lsh_count, k, thr, slice_lengths, max_check, log2_bucket_count):
         sig = np.ascontiguousarray(sig, dtype=np.uint64)
         n = sig.shape[0]
@@ -200,7 +218,8 @@ class Oracle:
             raise ValueError("oracle fsp7 rejected the arguments (%d)" % rc)
         return cell, sim, used
 
-    def cell_graph_edges(self, cell, sim, used, sp_cells, graph_cells, thr, max_connectivity):
+    def cell_graph_edges(self, cell, sim, used, sp_cells, graph_cells, thr, max_connectivity, hashed=False):
+        """hashed=True: the same loop with hash tables in place of the std::map / std::set (million-cell problems)."""
         n, k = cell.shape
         pairs = np.zeros((n, k), dtype=np.dtype([("cell", np.uint32), ("similarity", np.float32)]))
         pairs["cell"] = cell
@@ -212,8 +231,9 @@ class Oracle:
         v0 = np.zeros(cap, dtype=np.uint32)
         v1 = np.zeros(cap, dtype=np.uint32)
         es = np.zeros(cap, dtype=np.float32)
-        m = self.lib.em2o_cell_graph_edges(_ptr(pairs), _ptr(used), n, k, _ptr(sp_cells), _ptr(graph_cells),
-                                           len(graph_cells), thr, max_connectivity, _ptr(v0), _ptr(v1), _ptr(es))
+        function = self.lib.em2o_cell_graph_edges_hashed if hashed else self.lib.em2o_cell_graph_edges
+        m = function(_ptr(pairs), _ptr(used), n, k, _ptr(sp_cells), _ptr(graph_cells),
+                     len(graph_cells), thr, max_connectivity, _ptr(v0), _ptr(v1), _ptr(es))
         return v0[:m], v1[:m], es[:m]
 
     def label_propagation(self, vertex_cells, v0, v1, sim, seed=231, stable=3, max_iterations=100):

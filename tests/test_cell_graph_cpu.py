@@ -22,6 +22,9 @@ def pairs_from_lists(lists, k):
 def edges(oracle, lists, k, sp_cells, graph_cells, thr, max_conn):
     cell, sim, used = pairs_from_lists(lists, k)
     v0, v1, s = oracle.cell_graph_edges(cell, sim, used, sp_cells, graph_cells, thr, max_conn)
+    # the hash-table form used at a million cells is the same function
+    h0, h1, hs = oracle.cell_graph_edges(cell, sim, used, sp_cells, graph_cells, thr, max_conn, hashed=True)
+    assert np.array_equal(v0, h0) and np.array_equal(v1, h1) and np.array_equal(s.view(np.uint32), hs.view(np.uint32))
     return list(zip(v0.tolist(), v1.tolist())), s
 
 
@@ -93,3 +96,33 @@ def test_knn_property_on_fsp4_output(oracle):
     for a, b, w in zip(v0.tolist(), v1.tolist(), s.tolist()):
         best = [(c, x) for c, x in zip(cell[a, :used[a]].tolist(), sim[a, :used[a]].tolist()) if x >= 0.5][:5]
         assert (b, np.float32(w)) in [(c, np.float32(x)) for c, x in best]
+
+
+def test_hashed_form_equals_the_literal_form_on_random_inputs(oracle):
+    """em2o_cell_graph_edges_hashed (what the 1M-cell GPU test checks against) against the literal std::map / std::set
+    restatement: random SimilarPairs incl. duplicate and self pairs, graph cell sets that are unsorted, overlap the
+    SimilarPairs cell set partially and name a cell twice (the vertex table keeps the first), several caps."""
+    rng = np.random.default_rng(12)
+    for trial in range(30):
+        n, k = int(rng.integers(1, 300)), int(rng.integers(1, 9))
+        sp_cells = np.sort(rng.choice(1000, size=n, replace=False)).astype(np.uint32)
+        cell = rng.integers(0, n, size=(n, k)).astype(np.uint32)
+        sim = -np.sort(-rng.random((n, k)).astype(np.float32), axis=1)
+        used = rng.integers(0, k + 1, size=n).astype(np.uint32)
+        graph_cells = rng.choice(1000, size=int(rng.integers(1, 400)), replace=True).astype(np.uint32)
+        for max_conn in (0, 1, 3, 20):
+            a = oracle.cell_graph_edges(cell, sim, used, sp_cells, graph_cells, 0.3, max_conn)
+            b = oracle.cell_graph_edges(cell, sim, used, sp_cells, graph_cells, 0.3, max_conn, hashed=True)
+            assert all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(a, b))
+
+
+def test_fsp5_listed_cells_equal_the_full_run(oracle):
+    """em2o_find_similar_pairs5_cells (flat bucket tables, listed cells) against em2o_find_similar_pairs5 (the reference's
+    vector-of-vectors tables, every cell)."""
+    for L, q, overflow in ((256, 6, 0), (256, 7, 30), (200, 9, 1000)):
+        sig = synth.clustered_signatures(700, L, cluster_count=5, flip=0.12, seed=L + q)
+        cell, sim, used = oracle.find_similar_pairs5(sig, L, 7, 0.1, q, overflow)
+        listed = np.array([699, 0, 5, 5, 340], dtype=np.uint32)
+        c, s, u = oracle.find_similar_pairs5_cells(sig, L, 7, 0.1, q, overflow, listed)
+        assert np.array_equal(c, cell[listed]) and np.array_equal(s.view(np.uint32), sim[listed].view(np.uint32))
+        assert np.array_equal(u, used[listed])
