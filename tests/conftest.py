@@ -48,3 +48,12 @@ def reflib():
     if lib is None:
         pytest.skip("oracle/_ref/libem2ref.so not built (needs /root/reference)")
     return lib
+
+
+@pytest.fixture(scope="session")
+def reflayout():
+    import oracle_binding
+    lib = oracle_binding.load_ref_layout()
+    if lib is None:
+        pytest.skip("oracle/_ref/libem2ref_layout.so not built (needs /root/reference)")
+    return lib

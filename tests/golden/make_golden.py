@@ -72,6 +72,15 @@ def bucketed_digests(oracle):
     return out
 
 
+def info_cases():
+    """(k, geneSetName, geneSetHash, cellSetName, cellSetHash) of the recorded SimilarPairs::Info objects."""
+    return [(100, "AllGenes", 0x0123456789abcdef, "AllCells", 0xfedcba9876543210),
+            (1, "", 0, "", 0),
+            (3, "HighInformationGenes", 2**64 - 1, "c", 1),
+            (2**40 + 7, "g" * 230, 5, "x" * 240, 6),          # (file names end at 255 bytes: GeneSet-<name>-GlobalIds)
+            (9, "g" * 255, 7, "x" * 254, 8)]
+
+
 def make_signatures(case):
     if case["kind"] == "clustered":
         return synth.clustered_signatures(case["n"], case["L"], cluster_count=8, flip=0.15, seed=4242)
@@ -94,6 +103,16 @@ def main():
     for n in [0, 1, 5, 8, 13, 64, 257]:
         data = (synth.hash_u64(5, np.arange(n, dtype=np.uint64)) & np.uint64(0xFF)).astype(np.uint8)
         known["murmur64a_seed231"].append({"bytes": data.tolist(), "hash": str(ref.murmur(data))})
+    # SimilarPairs::Info (src/SimilarPairs.hpp:190-203) as the reference's own StaticString255 lays it out
+    # (src/ShortStaticString.hpp compiled in place, oracle/ref_layout.cpp): size, member offsets, and the bytes of a few
+    # filled-in objects, hex
+    layout = oracle_binding.load_ref_layout()
+    assert layout is not None, "needs /root/reference to build oracle/_ref"
+    known["similarPairsInfo"] = {"size": layout.info_size(), "offsets": layout.info_offsets(), "objects": []}
+    for k, gene_set, gene_hash, cell_set, cell_hash in info_cases():
+        known["similarPairsInfo"]["objects"].append({
+            "k": k, "geneSetName": gene_set, "geneSetHash": str(gene_hash), "cellSetName": cell_set, "cellSetHash": str(cell_hash),
+            "bytes": layout.make_info(k, gene_set, gene_hash, cell_set, cell_hash).hex()})
     with open(os.path.join(HERE, "reference_known_answers.json"), "w") as f:
         json.dump(known, f, indent=1)
 

@@ -371,6 +371,42 @@ def load_ref():
     return Ref(ctypes.CDLL(path))
 
 
+class RefLayout:
+    """oracle/_ref/libem2ref_layout.so: SimilarPairs::Info built from the reference's own StaticString255 (oracle/ref_layout.cpp)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        lib.em2ref_info_size.restype = c.c_uint64
+        lib.em2ref_info_offsets.argtypes = [P]
+        lib.em2ref_make_info.argtypes = [c.c_uint64, c.c_char_p, c.c_uint64, c.c_char_p, c.c_uint64, P]
+        lib.em2ref_make_info.restype = c.c_int
+
+    def info_size(self):
+        return int(self.lib.em2ref_info_size())
+
+    def info_offsets(self):
+        out = np.zeros(8, dtype=np.uint64)
+        self.lib.em2ref_info_offsets(_ptr(out))
+        return [int(x) for x in out]
+
+    def make_info(self, k, gene_set_name, gene_set_hash, cell_set_name, cell_set_hash):
+        out = np.zeros(self.info_size(), dtype=np.uint8)
+        rc = self.lib.em2ref_make_info(k, gene_set_name.encode(), gene_set_hash, cell_set_name.encode(), cell_set_hash, _ptr(out))
+        if rc != 0:
+            raise ValueError("ShortStaticString capacity exceeded.")
+        return out.tobytes()
+
+
+def load_ref_layout():
+    path = os.path.join(ORACLE_DIR, "_ref", "libem2ref_layout.so")
+    if not os.path.exists(path):
+        if os.path.isdir("/root/reference/src"):
+            _make("ref")
+        else:
+            return None
+    return RefLayout(ctypes.CDLL(path))
+
+
 def load_host_checks():
     build = os.path.join(NATIVE_DIR, "build")
     os.makedirs(build, exist_ok=True)

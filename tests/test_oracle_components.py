@@ -5,7 +5,9 @@ Pinned here:
     the reference header compiled in place (oracle/_ref), on tie-heavy inputs;
   * the reference's print-only self-test inputs (src/heap.cpp:32-38, src/multipleSetUnion.cpp:9-23);
   * MurmurHash64A against src/MurmurHash2.cpp;
-  * SimilarPairs::sort's comparator (src/orderPairs.hpp:44-52).
+  * SimilarPairs::sort's comparator (src/orderPairs.hpp:44-52);
+  * the bytes of SimilarPairs-<name>-Info (src/SimilarPairs.hpp:190-203) against the reference's own StaticString255
+    (src/ShortStaticString.hpp compiled in place: oracle/ref_layout.cpp) and the bytes recorded from it.
 """
 import json
 import os
@@ -94,3 +96,63 @@ def test_keep_best_golden_from_reference_header(oracle):
         oc, osim = oracle.keep_best(cell, sim, k)
         assert np.array_equal(oc, data["out_cell_%d" % i])
         assert np.array_equal(osim.view(np.uint32), data["out_sim_%d" % i].view(np.uint32))
+
+
+def write_info_and_read_payload(tmp_path, k, gene_set, cell_set, genes=5, cells=4):
+    """SimilarPairs-P-Info as the product writes it (csrc/em2_host.cpp through the C ABI): the 536 bytes behind the
+    256-byte header of MemoryMapped::Object (src/MemoryMappedObject.hpp:88-135)."""
+    from expressionmatrix2_amd import capi, files
+    d = str(tmp_path / ("data_%d_%d" % (len(gene_set), len(cell_set))))
+    toc = np.zeros(cells + 1, dtype=np.uint64)
+    files.create_directory(d, genes, toc, capi.make_counts(np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.float32)))
+    if gene_set != "AllGenes":
+        files.add_gene_set(d, gene_set, np.arange(genes, dtype=np.uint32))
+    if cell_set != "AllCells":
+        files.add_cell_set(d, cell_set, np.arange(cells, dtype=np.uint32))
+    files.write_similar_pairs(d, "P", gene_set, cell_set, k, np.zeros((cells, k), dtype=capi.PAIR_DTYPE), np.zeros(cells, dtype=np.uint32))
+    raw = open(os.path.join(d, "SimilarPairs-P-Info"), "rb").read()
+    return raw[256:256 + 536], capi.murmur_hash_64a(np.arange(genes, dtype=np.uint32)), capi.murmur_hash_64a(np.arange(cells, dtype=np.uint32))
+
+
+INFO_NAMES = [("AllGenes", "AllCells"), ("HighInformationGenes", "c"), ("g" * 230, "x" * 240)]
+
+
+@pytest.mark.parametrize("gene_set,cell_set", INFO_NAMES)
+def test_similar_pairs_info_bytes_match_reference_static_string(reflayout, tmp_path, gene_set, cell_set):
+    """Every byte of the Info object the product writes equals what the reference's class leaves in memory after
+    `new(data) Info()` and the five assignments of src/SimilarPairs.cpp:24-29."""
+    assert reflayout.info_size() == 536
+    assert reflayout.info_offsets() == [0, 8, 264, 272, 528, 0, 1, 256]
+    payload, gene_hash, cell_hash = write_info_and_read_payload(tmp_path, 3, gene_set, cell_set)
+    assert payload == reflayout.make_info(3, gene_set, gene_hash, cell_set, cell_hash)
+
+
+def test_similar_pairs_info_golden(tmp_path):
+    """The same against the bytes recorded from the reference's class by tests/golden/make_golden.py (runs everywhere)."""
+    with open(os.path.join(GOLDEN, "reference_known_answers.json")) as f:
+        golden = json.load(f)["similarPairsInfo"]
+    assert golden["size"] == 536 and golden["offsets"] == [0, 8, 264, 272, 528, 0, 1, 256]
+    recorded = {(o["geneSetName"], o["cellSetName"]): o for o in golden["objects"]}
+    for gene_set, cell_set in INFO_NAMES:
+        payload, gene_hash, cell_hash = write_info_and_read_payload(tmp_path, 3, gene_set, cell_set)
+        o = recorded[(gene_set, cell_set)]
+        expect = bytearray(bytes.fromhex(o["bytes"]))
+        # the recorded object holds another k and other hashes: those three fields are plain integers at the recorded offsets
+        import struct
+        expect[0:8] = struct.pack("<Q", 3)
+        expect[264:272] = struct.pack("<Q", gene_hash)
+        expect[528:536] = struct.pack("<Q", cell_hash)
+        assert payload == bytes(expect)
+        assert int.from_bytes(bytes.fromhex(o["bytes"])[0:8], "little") == o["k"]
+        assert int.from_bytes(bytes.fromhex(o["bytes"])[264:272], "little") == int(o["geneSetHash"])
+        assert int.from_bytes(bytes.fromhex(o["bytes"])[528:536], "little") == int(o["cellSetHash"])
+
+
+def test_reference_static_string_capacity(reflayout):
+    """ShortStaticString::setSize throws 'ShortStaticString capacity exceeded.' beyond 255 characters
+    (src/ShortStaticString.hpp:122-128); 255 fit.  (A set name that long cannot reach the product: GeneSet-<name>-GlobalIds
+    would be a file name of more than 255 bytes.)"""
+    with pytest.raises(ValueError):
+        reflayout.make_info(1, "g" * 256, 0, "c", 0)
+    full = reflayout.make_info(9, "g" * 255, 7, "x" * 254, 8)
+    assert full[8] == 255 and full[9:264] == b"g" * 255 and full[272] == 254 and full[273:527] == b"x" * 254 and full[527] == 0
