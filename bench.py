@@ -75,6 +75,71 @@ def parse_args():
     return p.parse_args()
 
 
+class Watchdog:
+    """Bounded time for every stage of a multi-rank run: a collective that one rank never enters (or a kernel that never
+    ends) would otherwise hold the whole job until the driver's own limit.  arm(name, seconds) starts the clock of a stage,
+    disarm() stops it; a stage that overruns ends THIS process (os._exit: the GPU and the communicator may be wedged, nothing
+    of this process can be trusted to unwind).  Every rank runs the same watchdog with the same limits, so on a hung
+    collective all ranks leave within a second of each other.  on_expiry, when set (rank 0 with a finished first leg),
+    prints the line of what was measured before and turns the exit code into 0."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank = rank
+        self.deadline = None
+        self.stage = ""
+        self.on_expiry = None
+        self.exit_code = 1
+        self.lock = threading.Lock()
+        thread = threading.Thread(target=self._run, daemon=True)
+        thread.start()
+
+    def arm(self, stage, seconds):
+        seconds = float(os.environ.get("EM2_BENCH_STAGE_LIMIT", seconds))          # (tests shorten the limits)
+        with self.lock:
+            self.stage, self.deadline = stage, time.monotonic() + seconds
+
+    def disarm(self):
+        with self.lock:
+            self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                expired = self.deadline is not None and time.monotonic() > self.deadline
+                stage, handler, code = self.stage, self.on_expiry, self.exit_code
+            if expired:
+                print("[bench] rank %d: stage '%s' exceeded its time limit; leaving" % (self.rank, stage), file=sys.stderr, flush=True)
+                if handler is not None:
+                    try:
+                        handler(stage)
+                    except Exception as error:            # noqa: BLE001 -- nothing may stop the exit
+                        print("[bench] rank %d: %s" % (self.rank, error), file=sys.stderr, flush=True)
+                        code = 1
+                sys.stdout.flush()
+                os._exit(code)
+
+
+def device_state(device_index):
+    """Clock / power / temperature as rocm-smi reports them for this GPU, or None: recorded next to the measurement so that a
+    reader can tell a throttled box from a regression (the scan kernel's own in-kernel clock is in roofline.clock_ghz)."""
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--json"],
+                             capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(out.stdout).values()))
+        keep = {}
+        for key, value in card.items():
+            low = key.lower()
+            if any(word in low for word in ("sclk", "mclk", "fclk", "power", "temperature (sensor junction)", "temperature (sensor edge)",
+                                            "performance level")):
+                keep[key] = value
+        return keep or None
+    except Exception:                                     # noqa: BLE001 -- a diagnostic, never a reason to fail
+        return None
+
+
 def parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host, check_rows):
     """The result of the pipeline's LAST step against the CPU oracle, bit for bit: the signatures of a few of this
     rank's cells and sampled SimilarPairs rows this rank owns against all columns.  Exits on a difference.
@@ -176,18 +241,19 @@ def bench_fsp5(args, capi, oracle, device, torch, check_ranges=3):
     torch.cuda.synchronize()
     check = {"skipped": "--no-check"}
     if not args.no_check:
+        # sampled cells in six places of the id range against the oracle (one build of its tables over all cells)
         sig_host = sig.cpu().numpy().view(np.uint64)
-        rows = 0
-        for begin in (0, C // 2, max(0, C - 8))[:check_ranges]:
-            end = min(C, begin + 8)
-            cell, sim, oused = oracle.find_similar_pairs5_rows(sig_host, L, k, thr, q, args.bucket_overflow, begin, end)
-            got = pairs[begin:end].cpu().numpy().view(np.uint32)
-            ok = (np.array_equal(used[begin:end].cpu().numpy().view(np.uint32), oused) and np.array_equal(got[:, :, 0], cell) and
-                  np.array_equal(got[:, :, 1], sim.view(np.uint32)))
-            if not ok:
-                raise SystemExit("PARITY FAILURE: findSimilarPairs5 rows %d..%d differ from the oracle" % (begin, end))
-            rows += end - begin
-        check = {"fsp5_rows": rows}
+        span = min(12, C)
+        listed = np.unique(np.concatenate([np.arange(b, b + span) for b in
+                                           (0, C // 5, (2 * C) // 5 + 3, (3 * C) // 5 + 11, (4 * C) // 5 + 17, C - span)]).clip(0, C - 1)).astype(np.uint32)
+        cell, sim, oused = oracle.find_similar_pairs5_cells(sig_host, L, k, thr, q, args.bucket_overflow, listed)
+        index = torch.from_numpy(listed.astype(np.int64)).to(device)
+        got = pairs[index].cpu().numpy().view(np.uint32)
+        ok = (np.array_equal(used[index].cpu().numpy().view(np.uint32), oused) and np.array_equal(got[:, :, 0], cell) and
+              np.array_equal(got[:, :, 1], sim.view(np.uint32)))
+        if not ok:
+            raise SystemExit("PARITY FAILURE: findSimilarPairs5 differs from the oracle on the sampled cells")
+        check = {"fsp5_cells": int(len(listed)), "places": 6}
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -203,8 +269,23 @@ def bench_fsp5(args, capi, oracle, device, torch, check_ranges=3):
     info = capi.dev_find_similar_pairs5_last_launch()
     filter_ms /= args.steps
     select_ms /= args.steps
-    algorithmic = info["gathered_candidates"] * 8.0 * W + 4.0 * C * info["slice_count"]
+    # candidates x 8*W bytes of signature gathers + 4*N*sliceCount bytes of tables.  Candidates = what the
+    # filter reads: the DISTINCT ids of every cell's union of buckets, counted by the library (the ids gathered with duplicates
+    # are reported beside it).
+    distinct = info["distinct_candidates"] if info["distinct_candidates"] >= 0 else info["gathered_candidates"]
+    algorithmic = distinct * 8.0 * W + 4.0 * C * info["slice_count"]
     achieved = algorithmic / (filter_ms * 1e-3) / 1e9 if filter_ms > 0 else 0.0
+    traffic = None
+    traffic_source = None
+    traffic_file = os.path.join(ROOT, "profiles", "r03_pmc_fsp5_1Mcells_2048bit.json")
+    if os.path.exists(traffic_file):
+        with open(traffic_file) as f:
+            prof = json.load(f)
+        cfg = prof.get("config", {})
+        if (cfg.get("cells"), cfg.get("lsh_count"), cfg.get("k"), cfg.get("slice_length")) == (C, L, k, q):
+            t = prof["per_call_bytes"]["filterCooperativeKernel"]
+            traffic = t["fetch"] + t["write"]
+            traffic_source = "profiles/r03_pmc_fsp5_1Mcells_2048bit.json (FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE, all batches of one call)"
     return {
         "metric": "cells/sec through findSimilarPairs5 (bucketed LSH, tables + candidate filter + selection)",
         "value": C * args.steps / elapsed, "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -214,13 +295,13 @@ def bench_fsp5(args, capi, oracle, device, torch, check_ranges=3):
                                "bucketOverflow=%d k=%d threshold=%g, 1 GPU" % (C, L, q, args.bucket_overflow, k, thr),
                    "cells": C, "lsh_count": L, "k": k, "slices": info["slice_count"], "batches": info["batches"]},
         "phases_ms": {"candidate_filter": filter_ms, "selection": select_ms,
-                      "tables_and_candidate_lists": elapsed / args.steps * 1e3 - filter_ms - select_ms},
+                      "tables_and_candidate_unions": elapsed / args.steps * 1e3 - filter_ms - select_ms},
         "roofline": {"kernel": "filterCooperativeKernel (all batches)", "kernel_ms": filter_ms, "bound": "hbm", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes": algorithmic, "gathered_candidates": info["gathered_candidates"],
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "algorithmic_bytes": algorithmic, "distinct_candidates": distinct, "gathered_candidates": info["gathered_candidates"],
                      "note": "SURVEY.md 8(d): candidates x 8*W bytes of signature gathers + 4*N*sliceCount bytes of tables; candidates "
-                             "= ids gathered from the buckets (duplicates included: an upper bound of the distinct ones the filter "
-                             "reads); kernel_ms = HIP events around the filter kernels on the launch stream"},
+                             "= the distinct ids of every cell's union of buckets, which is what the filter gathers (counted by the "
+                             "library); kernel_ms = HIP events around the filter kernels on the launch stream"},
         "parity_check": check,
     }
 
@@ -265,20 +346,17 @@ def bench_chain(args, capi, sharded, synthetic, oracle, device, torch):
     v0, v1, sim, clusters, iterations, edge_count = step(False, fetch=True)
     check = {"skipped": "--no-check"}
     if not args.no_check:
+        # the WHOLE edge list and EVERY label against the oracle (above 250000 cells its hash-table form: the same loop as the
+        # literal std::map / std::set restatement, tests/test_cell_graph_cpu.py holds the two equal)
         p, u = pipe.results_for(0, C)
-        sample = min(C, 200000)
-        if C <= 250000:
-            ev0, ev1, es = oracle.cell_graph_edges(p["cell"], p["similarity"], u, cells, cells, thr, args.graph_k)
-            if not (np.array_equal(ev0, v0) and np.array_equal(ev1, v1) and np.array_equal(es.view(np.uint32), sim.view(np.uint32))):
-                raise SystemExit("PARITY FAILURE: cell graph edges differ from the oracle")
-            oc, oit = oracle.label_propagation(cells, v0, v1, sim)
-            if not (np.array_equal(oc, clusters) and oit == iterations):
-                raise SystemExit("PARITY FAILURE: clusters differ from the oracle")
-            check = {"edges": int(len(v0)), "labels": int(C), "iterations": int(iterations)}
-        else:
-            check = {"edges": "not checked above 250000 cells (the oracle's map/set restatement takes minutes); "
-                              "tests/test_gpu_cell_graph.py and tests/test_gpu_label_propagation.py cover them",
-                     "sample": sample}
+        ev0, ev1, es = oracle.cell_graph_edges(p["cell"], p["similarity"], u, cells, cells, thr, args.graph_k, hashed=C > 250000)
+        if not (np.array_equal(ev0, v0) and np.array_equal(ev1, v1) and np.array_equal(es.view(np.uint32), sim.view(np.uint32))):
+            raise SystemExit("PARITY FAILURE: cell graph edges differ from the oracle")
+        oc, oit = oracle.label_propagation(cells, v0, v1, sim)
+        if not (np.array_equal(oc, clusters) and oit == iterations):
+            raise SystemExit("PARITY FAILURE: clusters differ from the oracle")
+        check = {"edges": int(len(v0)), "labels": int(C), "iterations": int(iterations)}
+        del p, u, ev0, ev1, es, oc
     for _ in range(args.warmup):
         step(False)
     t0 = time.perf_counter()
@@ -324,13 +402,28 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     capi.load()
+    watchdog = Watchdog(rank)
+    collective_check = None
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("EM2_BENCH_BACKEND", "nccl")
+        watchdog.arm("process group + first collective", 300)
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=300))
+        # what the communicator itself says: every rank adds a one, and the ranks' ids are gathered
+        ones = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(ones)
+        ids = torch.empty(world, dtype=torch.int64, device=torch.device("cuda", local_rank))
+        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int64, device=torch.device("cuda", local_rank)))
+        torch.cuda.synchronize()
+        collective_check = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_counted_by_all_reduce": int(ones.item()),
+                            "rank_ids_gathered": [int(x) for x in ids.cpu()], "devices_visible_to_rank0": torch.cuda.device_count()}
+        if collective_check["ranks_counted_by_all_reduce"] != world or collective_check["rank_ids_gathered"] != list(range(world)):
+            raise SystemExit("bench.py: the communicator counts %s ranks, %d expected" % (collective_check, world))
+        watchdog.disarm()
 
     C, G, L, k, thr = args.cells, args.genes, args.lsh_count, args.k, args.threshold
     W = capi.word_count(L)
@@ -347,254 +440,361 @@ def main():
         return
 
     # ---- synthetic inputs, resident in HBM ----
-    pipe = sharded.DevicePipeline(C, G, L, k, thr, world_size=world, rank=rank, dist=dist if world > 1 else None,
-                                  device=device)
-    toc, data = synthetic.expression_shard(pipe.row_begin, pipe.row_end, G, density=args.density, device=device)
     vectors_host = capi.lsh_generate_vectors(G, L, args.seed)            # Lsh::generateLshVectors (host, once)
     vectors = torch.from_numpy(vectors_host).to(device)
-    pipe.set_inputs(toc, data, vectors)
-    nnz_local = int(data.numel())
-    torch.cuda.synchronize()
-
-    # ---- correctness gate: one untimed pass, sampled rows/cells against the CPU oracle ----
     import oracle_binding
     oracle = oracle_binding.load_oracle()
-    check = {"golden_cases": 0, "signature_cells": 0, "fsp4_rows": 0}
-    if rank == 0 and not args.no_check:
-        # the committed golden digests (tests/golden/, produced by the oracle) against this build's GPU path
-        from golden.make_golden import digest, make_signatures, regression_cases
-        with open(os.path.join(ROOT, "tests", "golden", "oracle_regression.json")) as f:
-            golden = json.load(f)
-        for case in regression_cases():
-            g_pairs, g_used = capi.find_similar_pairs4(make_signatures(case), case["L"], case["k"], case["thr"])
-            if digest(np.ascontiguousarray(g_pairs["cell"]), np.ascontiguousarray(g_pairs["similarity"]), g_used) != golden[case["name"]]["fsp4"]:
-                raise SystemExit("PARITY FAILURE: golden case %s" % case["name"])
-            check["golden_cases"] += 1
-    pipe.step()
-    torch.cuda.synchronize()
-    sig_host = pipe.full_sig[:C].cpu().numpy().view(np.uint64)
-    if not args.no_check:
-        check["signature_cells"], check["fsp4_rows"] = parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host,
-                                                                   args.check_rows)
+    inputs = {}
 
-    # ---- warmup + timed steps ----
-    for _ in range(args.warmup):
+    def make_pipe(sharded_scan):
+        saved = os.environ.get("EM2_SHARDED_SCAN")
+        if not sharded_scan:
+            os.environ["EM2_SHARDED_SCAN"] = "0"
+        try:
+            pipe = sharded.DevicePipeline(C, G, L, k, thr, world_size=world, rank=rank, dist=dist if world > 1 else None, device=device)
+        finally:
+            if saved is None:
+                os.environ.pop("EM2_SHARDED_SCAN", None)
+            else:
+                os.environ["EM2_SHARDED_SCAN"] = saved
+        if not inputs:
+            inputs["toc"], inputs["data"] = synthetic.expression_shard(pipe.row_begin, pipe.row_end, G, density=args.density, device=device)
+        pipe.set_inputs(inputs["toc"], inputs["data"], vectors)
+        torch.cuda.synchronize()
+        return pipe
+
+    def run_leg(pipe, label, golden_cases):
+        """One measurement by the contract: correctness gate (an untimed pass against the CPU oracle), W warmup steps, exactly K
+        timed steps between barrier + synchronize on both sides, MAX over the ranks, the gate again on the LAST timed step's
+        result.  Every stage runs under the watchdog."""
+        toc, data = inputs["toc"], inputs["data"]
+        check = {"golden_cases": 0, "signature_cells": 0, "fsp4_rows": 0}
+        watchdog.arm(label + ": first pass and parity gate", 900)
+        if rank == 0 and not args.no_check and golden_cases:
+            # the committed golden digests (tests/golden/, produced by the oracle) against this build's GPU path
+            from golden.make_golden import digest, make_signatures, regression_cases
+            with open(os.path.join(ROOT, "tests", "golden", "oracle_regression.json")) as f:
+                golden = json.load(f)
+            for case in regression_cases():
+                g_pairs, g_used = capi.find_similar_pairs4(make_signatures(case), case["L"], case["k"], case["thr"])
+                if digest(np.ascontiguousarray(g_pairs["cell"]), np.ascontiguousarray(g_pairs["similarity"]), g_used) != golden[case["name"]]["fsp4"]:
+                    raise SystemExit("PARITY FAILURE: golden case %s" % case["name"])
+                check["golden_cases"] += 1
         pipe.step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    pipe.scan_events = []
-    proj_events = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        pipe.project()
-        e1.record()
-        proj_events.append((e0, e1))
-        pipe.exchange()
-        pipe.scan(record_events=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    pipe.check()                 # the scan's inter-wave hand-offs all completed (raises otherwise)
-    # The hand-off, speculation and inbox paths of the scan depend on timing, so the result of the LAST timed step is
-    # put through the same gate again: same signatures as before, sampled rows bit-identical to the oracle.
-    if args.no_check:
-        check["skipped"] = "--no-check: diagnostic run, NOT a measurement"
-    else:
-        sig_after = pipe.full_sig[:C].cpu().numpy().view(np.uint64)
-        if not np.array_equal(sig_after, sig_host):
-            raise SystemExit("PARITY FAILURE: the signatures of the last timed step differ from the first pass")
-        check["after_timing_signature_cells"], check["after_timing_rows"] = parity_gate(
-            pipe, oracle, synthetic, sig_after, toc, data, vectors_host, args.check_rows)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        torch.cuda.synchronize()
+        sig_host = pipe.full_sig[:C].cpu().numpy().view(np.uint64)
+        if not args.no_check:
+            check["signature_cells"], check["fsp4_rows"] = parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host,
+                                                                       args.check_rows)
+        # ---- warmup + timed steps ----
+        watchdog.arm(label + ": warmup and timed steps", 180 + 20 * (args.warmup + args.steps))
+        if label == "sharded symmetric" and os.environ.get("EM2_BENCH_TEST_FAIL_RANK") == str(rank):
+            raise RuntimeError("injected failure (EM2_BENCH_TEST_FAIL_RANK: tests/test_gpu_sharded.py)")
+        for _ in range(args.warmup):
+            pipe.step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        pipe.scan_events = []
+        proj_events = []
+        state_before = device_state(local_rank) if rank == 0 else None
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            pipe.project()
+            e1.record()
+            proj_events.append((e0, e1))
+            pipe.exchange()
+            pipe.scan(record_events=True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        state_after = device_state(local_rank) if rank == 0 else None
+        pipe.check()                 # the scan's inter-wave hand-offs all completed (raises otherwise)
+        # The hand-off, speculation and inbox paths of the scan depend on timing, so the result of the LAST timed step is
+        # put through the same gate again: same signatures as before, sampled rows bit-identical to the oracle.
+        watchdog.arm(label + ": parity gate after the timed steps", 900)
+        if args.no_check:
+            check["skipped"] = "--no-check: diagnostic run, NOT a measurement"
+        else:
+            sig_after = pipe.full_sig[:C].cpu().numpy().view(np.uint64)
+            if not np.array_equal(sig_after, sig_host):
+                raise SystemExit("PARITY FAILURE: the signatures of the last timed step differ from the first pass")
+            check["after_timing_signature_cells"], check["after_timing_rows"] = parity_gate(
+                pipe, oracle, synthetic, sig_after, toc, data, vectors_host, args.check_rows)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        watchdog.disarm()
+        return {"pipe": pipe, "elapsed": elapsed, "check": check, "sig_host": sig_host,
+                "scan_ms": float(np.mean([a.elapsed_time(b) for a, b in pipe.scan_events])) if pipe.scan_events else 0.0,
+                "proj_ms": float(np.mean([a.elapsed_time(b) for a, b in proj_events])) if proj_events else 0.0,
+                "launch": capi.dev_find_similar_pairs4_last_launch(),
+                "device_state": {"before_timed_steps": state_before, "after_timed_steps": state_after}}
 
-    scan_ms = float(np.mean([a.elapsed_time(b) for a, b in pipe.scan_events])) if pipe.scan_events else 0.0
-    proj_ms = float(np.mean([a.elapsed_time(b) for a, b in proj_events])) if proj_events else 0.0
+    def stage_times(pipe, label):
+        """Diagnostics outside the timed region: wall ms per stage and per collective with a device synchronisation after each
+        (so the stages do not overlap as they do in the measurement), MAX over the ranks."""
+        watchdog.arm(label + ": per-stage diagnostic pass", 300)
+        pipe.start_timing()
+        for _ in range(2):
+            pipe.step()
+        stages = pipe.stop_timing()
+        names = sorted(stages)
+        t = torch.tensor([stages[n] for n in names], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        watchdog.disarm()
+        return {n: float(v) for n, v in zip(names, t.tolist())}
 
     total_pairs = C * (C - 1) / 2.0
-    value = total_pairs * args.steps / elapsed
-    # The scan of THIS rank handles rows*(C-1)/2 unordered pairs' worth of the job (its share of N(N-1)/2).  In the
-    # ordered form that is rows*C comparisons by the kernel; in the symmetric form (1 GPU, all rows in one launch)
-    # every unordered pair is evaluated once.  The library reports what it ran.
-    launch = capi.dev_find_similar_pairs4_last_launch()
-    matrix = launch["form"] == 3                  # the symmetric form with its triangle part on the matrix cores
-    symmetric = launch["form"] in (1, 3)
-    sharded_symmetric = launch["form"] == 2
-    kernel_ms = launch["scan_kernel_ms"] if symmetric and launch["scan_kernel_ms"] > 0 else scan_ms
-    launch_pairs = total_pairs / world if sharded_symmetric else pipe.rows * (C - 1) / 2.0
-    algorithmic_bytes = launch_pairs * 16.0 * W
-    achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
-    lane_ops = launch["wave_column_steps"] * 64.0 * 4.0 * W      # (v_xor + v_bcnt) per 32 bits per (lane, column)
-    valu_frac = lane_ops / (kernel_ms * 1e-3) / VALU_LANE_OPS_PER_S if kernel_ms else 0.0
 
-    # HBM-side traffic of one scan launch from the PMC counters, when a profile of THIS configuration has been
-    # collected (rocprofv3 --pmc runs are separate from timing runs; see the file for the command and caveats).
-    traffic = None
-    traffic_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_1Mcells.json")
-    if os.path.exists(traffic_file):
-        with open(traffic_file) as f:
-            prof = json.load(f)
-        cfg = prof.get("config", {})
-        if (cfg.get("cells"), cfg.get("genes"), cfg.get("lsh_count"), cfg.get("k"), cfg.get("n_gpus")) == (C, G, L, k, world):
-            t = prof["per_launch_bytes"]["fsp4ScanKernel"]
-            if prof.get("form", "ordered") == ("symmetric" if symmetric else "ordered"):
-                traffic = t["fetch"] + t["write"]
+    def assemble(leg):
+        """The JSON line of one leg."""
+        pipe, elapsed, check, scan_ms, proj_ms, launch = (leg[key] for key in ("pipe", "elapsed", "check", "scan_ms", "proj_ms", "launch"))
+        nnz_local = int(inputs["data"].numel())
+        value = total_pairs * args.steps / elapsed
+        # The scan of THIS rank handles rows*(C-1)/2 unordered pairs' worth of the job (its share of N(N-1)/2).  In the
+        # ordered form that is rows*C comparisons by the kernel; in the symmetric form (1 GPU, all rows in one launch)
+        # every unordered pair is evaluated once.  The library reports what it ran.
+        matrix = launch["form"] == 3                  # the symmetric form with its triangle part on the matrix cores
+        symmetric = launch["form"] in (1, 3)
+        sharded_symmetric = launch["form"] == 2
+        kernel_ms = launch["scan_kernel_ms"] if symmetric and launch["scan_kernel_ms"] > 0 else scan_ms
+        launch_pairs = total_pairs / world if sharded_symmetric else pipe.rows * (C - 1) / 2.0
+        algorithmic_bytes = launch_pairs * 16.0 * W
+        achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
+        lane_ops = launch["wave_column_steps"] * 64.0 * 4.0 * W      # (v_xor + v_bcnt) per 32 bits per (lane, column)
+        valu_frac = lane_ops / (kernel_ms * 1e-3) / VALU_LANE_OPS_PER_S if kernel_ms else 0.0
 
-    result = {
-        "metric": "cell-pair Hamming comparisons/sec (whole node), findSimilarPairs4 incl. signature projection",
-        "value": value,
-        "unit": "pairs/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "u64 popcount (scan) / f64 (projection)",
-        "data": "synthetic",
-        "config": {
-            "workload": "BASELINE configs[2]: %d synthetic cells x %d genes (%.3g nnz/cell), %d-bit signatures, "
-                        "findSimilarPairs4 k=%d threshold=%g, rows sharded over %d GPU(s)"
-                        % (C, G, args.density * G, L, k, thr, world),
-            "cells": C, "genes": G, "lsh_count": L, "k": k, "similarity_threshold": thr,
-            "rows_per_gpu": pipe.shard, "nnz_rank0": nnz_local,
-            "scan": "sharded-symmetric" if sharded_symmetric else "symmetric-matrix" if matrix else "symmetric" if symmetric else "row-shards",
-        },
-        "phases_ms_rank0": {"projection": proj_ms, "scan": scan_ms},
-        "roofline": None,
-    }
-    hbm_roofline = {
-            "kernel": ("fsp4ScanKernel<%d,...>" if os.environ.get("EM2_SCAN_MODE") == "simple"
-                       else "fsp4ScanSymmetricKernel<%d,true>" if symmetric
-                       else "fsp4ScanSymmetricKernel<%d,true> + fsp4TileKernel" if sharded_symmetric
-                       else "fsp4ScanPersistentKernel<%d,true>") % (2 * W),
-            "kernel_ms": kernel_ms,
-            "form": "symmetric: every unordered pair evaluated once; inbox sort + replay follow the kernel"
-                    if symmetric else
-                    "sharded symmetric: every unordered pair evaluated once across the ranks (blocks dealt round-robin; "
-                    "2 all_reduce + 1 all_gather inside the scan time)" if sharded_symmetric
-                    else "ordered: every row of the shard against every column",
-            "inbox_entries": launch["inbox_entries"] if (symmetric or sharded_symmetric) else None,
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "traffic_source": "profiles/r01_pmc_hbm_traffic_1Mcells.json (FETCH_SIZE+WRITE_SIZE, bytes per launch)"
-                              if traffic is not None else None,
-            "algorithmic_bytes": algorithmic_bytes,
-            "comparisons_executed_per_s": launch["wave_column_steps"] * 64.0 / (kernel_ms * 1e-3) if kernel_ms else 0.0,
-            "valu_frac": valu_frac,
-            "note": "algorithmic bytes = 16*W per unordered pair; comparisons_executed_per_s = (row, column) mismatch counts the kernel "
-                    "actually evaluated per second (about one per unordered pair in the symmetric forms, two in the ordered one); "
-                    "operands are cache/SGPR resident so frac is not "
-                    "bounded by 1; valu_frac = (v_xor+v_bcnt lane-ops actually executed)/(256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz), "
-                    "the measured issue rate of these ops; kernel_ms = HIP events on the launch stream around the scan kernel "
-                    "(recorded inside the library for the symmetric form, around the call otherwise)",
-    }
-    if matrix:
-        result["dtype"] = "fp4 e2m1 +-1 products, f32 accumulate, exact (scan on the matrix cores) / u32 popcount (band, full rows) / f64 (projection)"
-    matrix_traffic = None
-    matrix_traffic_source = None
-    pinned_walk = os.environ.get("EM2_MATRIX_WALK", "3") not in ("0",)
-    for name in (("r02_pmc_matrix_scan_1Mcells.json",) if pinned_walk else ()) + ("r01_pmc_matrix_scan_1Mcells.json",):
-        matrix_traffic_file = os.path.join(ROOT, "profiles", name)
-        if not (matrix and os.path.exists(matrix_traffic_file)):
-            continue
-        with open(matrix_traffic_file) as f:
-            prof = json.load(f)
-        cfg = prof.get("config", {})
-        if (cfg.get("cells"), cfg.get("genes"), cfg.get("lsh_count"), cfg.get("k"), cfg.get("n_gpus")) == (C, G, L, k, world):
-            t = prof["per_launch_bytes"]["fsp4ScanKernel"]
-            matrix_traffic = t["fetch"] + t["write"]
-            matrix_traffic_source = "profiles/%s (FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE, bytes per launch)" % name
-            break
-    if matrix and launch["matrix_kernel_ms"] > 0:
-        # Dominant kernel: fsp4ScanMatrixKernel, bound by the matrix cores.  One (row, column) pair = a 1024-long dot
-        # product of FP4 +-1 values = 2 * 1024 flop on v_mfma_scale_f32_32x32x64_f8f6f4; peak = the dense FP4 MFMA
-        # figure of MI355X_MICROARCH.md (10 PFLOP/s).  The HBM / instruction view of the same launch rides along.
-        # (signatures of 1025..2048 bits: fsp4ScanMatrixWideKernel, a 2048-long contraction per pair)
-        contraction = 2048.0 if L > 1024 else 1024.0
-        flops = launch["matrix_pairs"] * 2.0 * contraction
-        tflops = flops / (launch["matrix_kernel_ms"] * 1e-3) / 1e12
-        result["roofline"] = {
-            "kernel": "fsp4ScanMatrixWideKernel<true>" if L > 1024 else
-                      ("fsp4ScanMatrixPinnedKernel<true>" if pinned_walk else "fsp4ScanMatrixKernel<true>"),
-            "kernel_ms": launch["matrix_kernel_ms"],
-            "form": "symmetric, triangle part on the matrix cores: every unordered pair evaluated once as an FP4 +-1 dot "
-                    "product (%d - 2 * mismatches, exact in f32); the first cells' full rows and each quad's own 256 columns "
-                    "stay on v_xor/v_bcnt; inbox sort + replay follow" % int(contraction),
-            "bound": "mfma",
-            "achieved": tflops,
-            "peak": MFMA_FP4_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": tflops / MFMA_FP4_PEAK_TFLOPS,
-            "traffic": matrix_traffic,
-            "traffic_source": matrix_traffic_source,
-            "flop_per_launch": flops,
-            "pairs_on_matrix_cores": launch["matrix_pairs"],
-            "pairs_per_s_on_matrix_cores": launch["matrix_pairs"] / (launch["matrix_kernel_ms"] * 1e-3),
-            "inbox_entries": launch["inbox_entries"],
-            "scan_launches_ms": kernel_ms,
-            "hbm_view": {key: hbm_roofline[key] for key in ("achieved", "peak", "unit", "frac", "algorithmic_bytes")},
-            "note": "flop = 2 * %d per (row, column) pair contracted by fsp4ScanMatrixKernel (pairs counted by the launcher: "
-                    "64 rows x the columns below each quad); kernel_ms = HIP events on the launch stream around that kernel "
-                    "alone, scan_launches_ms = around all launches of the scan (full-row blocks on v_xor/v_bcnt, fragment "
-                    "expansion, the matrix kernel); hbm_view = the algorithmic 16*W bytes per unordered pair over "
-                    "scan_launches_ms, kept for comparison with earlier rounds (operands are cache resident, so it is not "
-                    "bounded by 1)" % int(contraction),
+        # HBM-side traffic of one scan launch from the PMC counters, when a profile of THIS configuration has been
+        # collected (rocprofv3 --pmc runs are separate from timing runs; see the file for the command and caveats).
+        traffic = None
+        traffic_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_1Mcells.json")
+        if os.path.exists(traffic_file):
+            with open(traffic_file) as f:
+                prof = json.load(f)
+            cfg = prof.get("config", {})
+            if (cfg.get("cells"), cfg.get("genes"), cfg.get("lsh_count"), cfg.get("k"), cfg.get("n_gpus")) == (C, G, L, k, world):
+                t = prof["per_launch_bytes"]["fsp4ScanKernel"]
+                if prof.get("form", "ordered") == ("symmetric" if symmetric else "ordered"):
+                    traffic = t["fetch"] + t["write"]
+
+        result = {
+            "metric": "cell-pair Hamming comparisons/sec (whole node), findSimilarPairs4 incl. signature projection",
+            "value": value,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u64 popcount (scan) / f64 (projection)",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: %d synthetic cells x %d genes (%.3g nnz/cell), %d-bit signatures, "
+                            "findSimilarPairs4 k=%d threshold=%g, rows sharded over %d GPU(s)"
+                            % (C, G, args.density * G, L, k, thr, world),
+                "cells": C, "genes": G, "lsh_count": L, "k": k, "similarity_threshold": thr,
+                "rows_per_gpu": pipe.shard, "nnz_rank0": nnz_local,
+                "scan": "sharded-symmetric" if sharded_symmetric else "symmetric-matrix" if matrix else "symmetric" if symmetric else "row-shards",
+            },
+            "phases_ms_rank0": {"projection": proj_ms, "scan": scan_ms},
+            "roofline": None,
         }
-    elif sharded_symmetric and launch["matrix_pairs"] > 0 and scan_ms > 0:
-        # Sharded scan with phases 1 and 2 on the matrix cores: this rank's share of the FP4 contraction over the whole
-        # scan time of the rank (phases 0..3 and the collectives between them; no per-kernel events here).
-        flops = launch["matrix_pairs"] * 2.0 * 1024.0
-        tflops = flops / (scan_ms * 1e-3) / 1e12
-        result["dtype"] = "fp4 e2m1 +-1 products, f32 accumulate, exact (phases 1-2 on the matrix cores) / u32 popcount (phase 0, bands) / f64 (projection)"
-        result["roofline"] = {
-            "kernel": "fsp4ScanMatrixKernel<true> + fsp4TileMatrixKernel (rank 0)",
-            "kernel_ms": scan_ms,
-            "form": "sharded symmetric, phases 1 and 2 on the matrix cores: every unordered pair evaluated once across the ranks; "
-                    "2 all_reduce + the entry exchange are inside kernel_ms",
-            "bound": "mfma",
-            "achieved": tflops,
-            "peak": MFMA_FP4_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": tflops / MFMA_FP4_PEAK_TFLOPS,
-            "traffic": None,
-            "flop_per_launch": flops,
-            "pairs_on_matrix_cores": launch["matrix_pairs"],
-            "inbox_entries": launch["inbox_entries"],
-            "hbm_view": {key: hbm_roofline[key] for key in ("achieved", "peak", "unit", "frac", "algorithmic_bytes")},
-            "note": "per rank: flop = 2 * 1024 per (row, column) pair of this rank's share of phases 1 and 2; kernel_ms is the whole "
-                    "scan of the rank including the collectives, so frac understates the kernels",
+        hbm_roofline = {
+                "kernel": ("fsp4ScanKernel<%d,...>" if os.environ.get("EM2_SCAN_MODE") == "simple"
+                           else "fsp4ScanSymmetricKernel<%d,true>" if symmetric
+                           else "fsp4ScanSymmetricKernel<%d,true> + fsp4TileKernel" if sharded_symmetric
+                           else "fsp4ScanPersistentKernel<%d,true>") % (2 * W),
+                "kernel_ms": kernel_ms,
+                "form": "symmetric: every unordered pair evaluated once; inbox sort + replay follow the kernel"
+                        if symmetric else
+                        "sharded symmetric: every unordered pair evaluated once across the ranks (blocks dealt round-robin; "
+                        "2 all_reduce + 1 all_gather inside the scan time)" if sharded_symmetric
+                        else "ordered: every row of the shard against every column",
+                "inbox_entries": launch["inbox_entries"] if (symmetric or sharded_symmetric) else None,
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_hbm_traffic_1Mcells.json (FETCH_SIZE+WRITE_SIZE, bytes per launch)"
+                                  if traffic is not None else None,
+                "algorithmic_bytes": algorithmic_bytes,
+                "comparisons_executed_per_s": launch["wave_column_steps"] * 64.0 / (kernel_ms * 1e-3) if kernel_ms else 0.0,
+                "valu_frac": valu_frac,
+                "note": "algorithmic bytes = 16*W per unordered pair; comparisons_executed_per_s = (row, column) mismatch counts the kernel "
+                        "actually evaluated per second (about one per unordered pair in the symmetric forms, two in the ordered one); "
+                        "operands are cache/SGPR resident so frac is not "
+                        "bounded by 1; valu_frac = (v_xor+v_bcnt lane-ops actually executed)/(256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz), "
+                        "the measured issue rate of these ops; kernel_ms = HIP events on the launch stream around the scan kernel "
+                        "(recorded inside the library for the symmetric form, around the call otherwise)",
         }
+        if matrix:
+            result["dtype"] = "fp4 e2m1 +-1 products, f32 accumulate, exact (scan on the matrix cores) / u32 popcount (band, full rows) / f64 (projection)"
+        matrix_traffic = None
+        matrix_traffic_source = None
+        pinned_walk = os.environ.get("EM2_MATRIX_WALK", "3") not in ("0",)
+        for name in (("r02_pmc_matrix_scan_1Mcells.json",) if pinned_walk else ()) + ("r01_pmc_matrix_scan_1Mcells.json",):
+            matrix_traffic_file = os.path.join(ROOT, "profiles", name)
+            if not (matrix and os.path.exists(matrix_traffic_file)):
+                continue
+            with open(matrix_traffic_file) as f:
+                prof = json.load(f)
+            cfg = prof.get("config", {})
+            if (cfg.get("cells"), cfg.get("genes"), cfg.get("lsh_count"), cfg.get("k"), cfg.get("n_gpus")) == (C, G, L, k, world):
+                t = prof["per_launch_bytes"]["fsp4ScanKernel"]
+                matrix_traffic = t["fetch"] + t["write"]
+                matrix_traffic_source = "profiles/%s (FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE, bytes per launch)" % name
+                break
+        if matrix and launch["matrix_kernel_ms"] > 0:
+            # Dominant kernel: fsp4ScanMatrixKernel, bound by the matrix cores.  One (row, column) pair = a 1024-long dot
+            # product of FP4 +-1 values = 2 * 1024 flop on v_mfma_scale_f32_32x32x64_f8f6f4; peak = the dense FP4 MFMA
+            # figure of MI355X_MICROARCH.md (10 PFLOP/s).  The HBM / instruction view of the same launch rides along.
+            # (signatures of 1025..2048 bits: fsp4ScanMatrixWideKernel, a 2048-long contraction per pair)
+            contraction = 2048.0 if L > 1024 else 1024.0
+            flops = launch["matrix_pairs"] * 2.0 * contraction
+            tflops = flops / (launch["matrix_kernel_ms"] * 1e-3) / 1e12
+            result["roofline"] = {
+                "kernel": "fsp4ScanMatrixWideKernel<true>" if L > 1024 else
+                          ("fsp4ScanMatrixPinnedKernel<true>" if pinned_walk else "fsp4ScanMatrixKernel<true>"),
+                "kernel_ms": launch["matrix_kernel_ms"],
+                "form": "symmetric, triangle part on the matrix cores: every unordered pair evaluated once as an FP4 +-1 dot "
+                        "product (%d - 2 * mismatches, exact in f32); the first cells' full rows and each quad's own 256 columns "
+                        "stay on v_xor/v_bcnt; inbox sort + replay follow" % int(contraction),
+                "bound": "mfma",
+                "achieved": tflops,
+                "peak": MFMA_FP4_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": tflops / MFMA_FP4_PEAK_TFLOPS,
+                "clock_ghz": launch["matrix_clock_ghz"] or None,
+                "frac_of_peak_at_that_clock": (tflops / (MFMA_FP4_PEAK_TFLOPS * launch["matrix_clock_ghz"] / 2.4)
+                                               if launch["matrix_clock_ghz"] else None),
+                "traffic": matrix_traffic,
+                "traffic_source": matrix_traffic_source,
+                "flop_per_launch": flops,
+                "pairs_on_matrix_cores": launch["matrix_pairs"],
+                "pairs_per_s_on_matrix_cores": launch["matrix_pairs"] / (launch["matrix_kernel_ms"] * 1e-3),
+                "inbox_entries": launch["inbox_entries"],
+                "scan_launches_ms": kernel_ms,
+                "hbm_view": {key: hbm_roofline[key] for key in ("achieved", "peak", "unit", "frac", "algorithmic_bytes")},
+                "note": "flop = 2 * %d per (row, column) pair contracted by fsp4ScanMatrixKernel (pairs counted by the launcher: "
+                        "64 rows x the columns below each quad); kernel_ms = HIP events on the launch stream around that kernel "
+                        "alone, scan_launches_ms = around all launches of the scan (full-row blocks on v_xor/v_bcnt, fragment "
+                        "expansion, the matrix kernel); hbm_view = the algorithmic 16*W bytes per unordered pair over "
+                        "scan_launches_ms, kept for comparison with earlier rounds (operands are cache resident, so it is not "
+                        "bounded by 1)" % int(contraction),
+            }
+        elif sharded_symmetric and launch["matrix_pairs"] > 0 and scan_ms > 0:
+            # Sharded scan with phases 1 and 2 on the matrix cores: this rank's share of the FP4 contraction over the whole
+            # scan time of the rank (phases 0..3 and the collectives between them; no per-kernel events here).
+            flops = launch["matrix_pairs"] * 2.0 * 1024.0
+            tflops = flops / (scan_ms * 1e-3) / 1e12
+            result["dtype"] = "fp4 e2m1 +-1 products, f32 accumulate, exact (phases 1-2 on the matrix cores) / u32 popcount (phase 0, bands) / f64 (projection)"
+            result["roofline"] = {
+                "kernel": "fsp4ScanMatrixKernel<true> + fsp4TileMatrixKernel (rank 0)",
+                "kernel_ms": scan_ms,
+                "form": "sharded symmetric, phases 1 and 2 on the matrix cores: every unordered pair evaluated once across the ranks; "
+                        "2 all_reduce + the entry exchange are inside kernel_ms",
+                "bound": "mfma",
+                "achieved": tflops,
+                "peak": MFMA_FP4_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": tflops / MFMA_FP4_PEAK_TFLOPS,
+                "traffic": None,
+                "flop_per_launch": flops,
+                "pairs_on_matrix_cores": launch["matrix_pairs"],
+                "inbox_entries": launch["inbox_entries"],
+                "hbm_view": {key: hbm_roofline[key] for key in ("achieved", "peak", "unit", "frac", "algorithmic_bytes")},
+                "note": "per rank: flop = 2 * 1024 per (row, column) pair of this rank's share of phases 1 and 2; kernel_ms is the whole "
+                        "scan of the rank including the collectives, so frac understates the kernels",
+            }
+        else:
+            result["roofline"] = hbm_roofline
+        result["parity_check"] = check
+        # The other kernel of the step: the signature projection.  Algorithmic bytes per SURVEY.md 8(d): the CSR once
+        # (8 B per expression count), the hyperplanes once (8 B x genes x bits), the signatures out; flop = 2 x counts x
+        # bits (the reference's own formula, src/Lsh.cpp:222).  Bound: HBM.
+        if proj_ms > 0 and pipe.rows:
+            proj_bytes = 8.0 * nnz_local + 8.0 * G * L + pipe.rows * L / 8.0
+            result["roofline_projection"] = {
+                "kernel": "projectionScreenQuantizedKernel + projectionScreenItemsKernel + projectionExactItemsKernel (rank 0)",
+                "kernel_ms": proj_ms, "bound": "hbm", "achieved": proj_bytes / (proj_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": proj_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": proj_bytes,
+                "flop_per_launch": 2.0 * nnz_local * L, "tflops": 2.0 * nnz_local * L / (proj_ms * 1e-3) / 1e12,
+                "note": "kernel_ms = HIP events around em2_dev_compute_signatures on the launch stream (16-bit fixed-point screening "
+                        "tier, float tier on the words it left, exact recomputation of the rest); its measured fabric traffic is in "
+                        "profiles/ and DESIGN.md",
+            }
+        result["device_state_rank0"] = leg["device_state"]
+        if collective_check is not None:
+            result["collective_check"] = collective_check
+        return result
+
+    # ---- the measurement(s) ----
+    # One GPU: one leg.  Several GPUs: north_star's own partitioning FIRST (contiguous row shards, one all_gather of the
+    # signatures, every rank scans its rows against all columns: the simplest collectives), measured and parity-gated by the
+    # same contract, and only then the sharded symmetric form (every unordered pair once across the ranks: two all_reduce and
+    # an all_to_all inside the scan).  If the second form fails or stops in a collective, the first leg's line is what this
+    # run reports -- with the failure on it -- instead of nothing.
+    result = None
+    if world == 1:
+        leg = run_leg(make_pipe(True), "single GPU", True)
+        result = assemble(leg)
     else:
-        result["roofline"] = hbm_roofline
-    result["parity_check"] = check
-    # The other kernel of the step: the signature projection.  Algorithmic bytes per SURVEY.md 8(d): the CSR once
-    # (8 B per expression count), the hyperplanes once (8 B x genes x bits), the signatures out; flop = 2 x counts x
-    # bits (the reference's own formula, src/Lsh.cpp:222).  Bound: HBM.
-    if proj_ms > 0 and pipe.rows:
-        proj_bytes = 8.0 * nnz_local + 8.0 * G * L + pipe.rows * L / 8.0
-        result["roofline_projection"] = {
-            "kernel": "projectionScreenQuantizedKernel + projectionScreenItemsKernel + projectionExactItemsKernel (rank 0)",
-            "kernel_ms": proj_ms, "bound": "hbm", "achieved": proj_bytes / (proj_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": proj_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": proj_bytes,
-            "flop_per_launch": 2.0 * nnz_local * L, "tflops": 2.0 * nnz_local * L / (proj_ms * 1e-3) / 1e12,
-            "note": "kernel_ms = HIP events around em2_dev_compute_signatures on the launch stream (16-bit fixed-point screening "
-                    "tier, float tier on the words it left, exact recomputation of the rest); its measured fabric traffic is in "
-                    "profiles/ and DESIGN.md",
-        }
+        rows_leg = run_leg(make_pipe(False), "row shards", True)
+        rows_result = assemble(rows_leg)
+        rows_result["stages_ms_max_over_ranks"] = {"form": "row-shards", "backend": dist.get_backend(),
+                                                   "note": "diagnostic pass with a synchronisation after every stage; not the measurement",
+                                                   **stage_times(rows_leg["pipe"], "row shards")}
+        result = rows_result
+        symmetric_pipe = make_pipe(True)
+        if symmetric_pipe.sharded:
+            def report_first_leg(stage):
+                rows_result["sharded_symmetric_leg"] = {"status": "did not complete", "stage": stage,
+                                                        "note": "the sharded symmetric form stopped in this stage; the line is the row-shard leg, measured before it"}
+                if rank == 0:
+                    print(json.dumps(rows_result), flush=True)
+            watchdog.on_expiry = report_first_leg
+            watchdog.exit_code = 0
+            try:
+                sym_leg = run_leg(symmetric_pipe, "sharded symmetric", False)
+                if sym_leg["pipe"].sharded is None:
+                    # (a pool overflow or a failed phase on some rank: all ranks agreed to fall back to row shards)
+                    rows_result["sharded_symmetric_leg"] = {"status": "fell back to row shards by agreement of the ranks"}
+                else:
+                    result = assemble(sym_leg)
+                    result["stages_ms_max_over_ranks"] = {"form": result["config"]["scan"], "backend": dist.get_backend(),
+                                                          "note": "diagnostic pass with a synchronisation after every stage; not the measurement",
+                                                          **stage_times(sym_leg["pipe"], "sharded symmetric")}
+                    result["row_shard_leg"] = {key: rows_result[key] for key in ("value", "unit", "ms_per_step", "steps", "warmup", "parity_check",
+                                                                                   "phases_ms_rank0", "stages_ms_max_over_ranks")}
+                    result["row_shard_leg"]["scan"] = "row-shards"
+                    result["row_shard_leg"]["note"] = ("the same job with north_star's partitioning, measured first by the same contract: every "
+                                                       "rank scans its contiguous rows against all columns (each unordered pair evaluated twice "
+                                                       "across the node)")
+            except BaseException as error:                # noqa: BLE001 -- this rank must not leave the others in a collective alone
+                if isinstance(error, SystemExit) and str(error).startswith("PARITY FAILURE"):
+                    # wrong results are never papered over: the whole run fails
+                    print("[bench] rank %d: %s" % (rank, error), file=sys.stderr, flush=True)
+                    os._exit(1)
+                print("[bench] rank %d: sharded symmetric leg failed: %r" % (rank, error), file=sys.stderr, flush=True)
+                # the other ranks are (or will be) waiting in a collective this rank has left: all of them leave through their
+                # watchdogs, rank 0 printing the first leg; so does this one
+                watchdog.arm("sharded symmetric leg failed on rank %d (%s)" % (rank, type(error).__name__), 5)
+                time.sleep(3600)
+            watchdog.on_expiry = None
+            watchdog.exit_code = 1
+        leg = rows_leg if result is rows_result else sym_leg
+    pipe, sig_host = leg["pipe"], leg["sig_host"]
 
     if rank == 0 and not args.no_cpu_baseline:
         m = min(args.cpu_baseline_cells, C)
@@ -632,7 +832,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra and (C, G) == (1000000, 30000):
         # BASELINE configs[1] (100k cells x 20k genes, 1% nnz, 1024 bit, 1 GPU): a second, small measurement on the same
         # line -- never the headline.  Same pipeline, same gates (sampled rows against the oracle before and after).
-        del pipe, toc, data, vectors
+        leg.clear()
+        inputs.clear()
+        del pipe, vectors
         torch.cuda.empty_cache()
         result["extra"] = {"configs[1]": small_config(args, capi, sharded, synthetic, oracle, device, torch)}
         # BASELINE configs[3] (bucketed findSimilarPairs5, 2048 bit) and configs[4] (findSimilarPairs4 -> createCellGraph ->
@@ -648,64 +850,13 @@ def main():
         line = bench_chain(small, capi, sharded, synthetic, oracle, device, torch)
         result["extra"]["configs[4]"] = {key: line[key] for key in ("metric", "value", "unit", "ms_per_step", "steps", "config",
                                                                      "phases_ms", "parity_check", "note")}
-    if world > 1:
-        # ---- diagnostics of the multi-GPU step, outside the timed region: wall ms per stage and per collective with a device
-        # synchronisation after each (so the stages do not overlap as they do in the measurement), MAX over the ranks ----
-        pipe.start_timing()
-        for _ in range(2):
-            pipe.step()
-        stages = pipe.stop_timing()
-        names = sorted(stages)
-        t = torch.tensor([stages[n] for n in names], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        result["stages_ms_max_over_ranks"] = {"form": result["config"]["scan"], "backend": dist.get_backend(),
-                                              "note": "diagnostic pass with a synchronisation after every stage; not the measurement",
-                                              **{n: float(v) for n, v in zip(names, t.tolist())}}
-        if pipe.sharded:
-            # ---- second leg: north_star's own partitioning (contiguous row shards, one all_gather, every rank scans its
-            # rows against all columns), timed like the first, so the scaling curve exists for both forms ----
-            saved = os.environ.get("EM2_SHARDED_SCAN")
-            os.environ["EM2_SHARDED_SCAN"] = "0"
-            rows_pipe = sharded.DevicePipeline(C, G, L, k, thr, world_size=world, rank=rank, dist=dist, device=device)
-            if saved is None:
-                os.environ.pop("EM2_SHARDED_SCAN", None)
-            else:
-                os.environ["EM2_SHARDED_SCAN"] = saved
-            rows_pipe.set_inputs(toc, data, vectors)
-            rows_pipe.step()
-            leg_steps = max(1, min(args.steps, 5))
-            dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(leg_steps):
-                rows_pipe.step()
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-            leg = time.perf_counter() - t0
-            rows_pipe.check()
-            leg_check = {"skipped": "--no-check"}
-            if not args.no_check:
-                cells_checked, rows_checked = parity_gate(rows_pipe, oracle, synthetic, sig_host, toc, data, vectors_host, args.check_rows)
-                leg_check = {"signature_cells": cells_checked, "fsp4_rows": rows_checked}
-            t = torch.tensor([leg], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            leg = float(t.item())
-            rows_pipe.start_timing()
-            rows_pipe.step()
-            leg_stages = rows_pipe.stop_timing()
-            names = sorted(leg_stages)
-            t = torch.tensor([leg_stages[n] for n in names], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            result["row_shard_leg"] = {"value": total_pairs * leg_steps / leg, "unit": "pairs/s", "ms_per_step": leg / leg_steps * 1e3,
-                                       "steps": leg_steps, "scan": "row-shards", "parity_check": leg_check,
-                                       "stages_ms_max_over_ranks": {n: float(v) for n, v in zip(names, t.tolist())},
-                                       "note": "the same job with north_star's partitioning: every rank scans its contiguous rows "
-                                               "against all columns (each unordered pair evaluated twice across the node)"}
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
+        watchdog.arm("destroy_process_group", 60)
+        watchdog.exit_code = 0                 # (the line is out; a shutdown that hangs is not a failed measurement)
         dist.destroy_process_group()
+        watchdog.disarm()
 
 
 if __name__ == "__main__":

@@ -399,11 +399,11 @@ def dev_find_similar_pairs4_form(cell_count, row_count):
 def dev_find_similar_pairs4_last_launch():
     """dict(form, scan_kernel_ms, wave_column_steps, inbox_entries, segments, full_row_cells, matrix_pairs,
     matrix_kernel_ms) of the last launch; form 0 ordered, 1 symmetric, 2 sharded symmetric, 3 symmetric on the matrix cores."""
-    v = np.zeros(8, dtype=np.float64)
-    check(load().em2_dev_find_similar_pairs4_last_launch(_ptr(v), 8))
+    v = np.zeros(9, dtype=np.float64)
+    check(load().em2_dev_find_similar_pairs4_last_launch(_ptr(v), 9))
     return {"form": int(v[0]), "scan_kernel_ms": float(v[1]), "wave_column_steps": float(v[2]),
             "inbox_entries": float(v[3]), "segments": int(v[4]), "full_row_cells": int(v[5]),
-            "matrix_pairs": float(v[6]), "matrix_kernel_ms": float(v[7])}
+            "matrix_pairs": float(v[6]), "matrix_kernel_ms": float(v[7]), "matrix_clock_ghz": float(v[8])}
 
 
 # ---- em2_collectives (include/em2_lsh.h): the transport table of em2_dist_find_similar_pairs4_with ----
@@ -447,10 +447,10 @@ def dist_find_similar_pairs4(comm_or_table, local_sig_ptr, cell_count, lsh_count
 
 def dev_find_similar_pairs5_last_launch():
     """dict(gathered_candidates, cells, slice_count, batches, filter_ms, select_ms) of the last findSimilarPairs5 launch."""
-    v = np.zeros(6, dtype=np.float64)
-    check(load().em2_dev_find_similar_pairs5_last_launch(_ptr(v), 6))
+    v = np.zeros(7, dtype=np.float64)
+    check(load().em2_dev_find_similar_pairs5_last_launch(_ptr(v), 7))
     return {"gathered_candidates": float(v[0]), "cells": int(v[1]), "slice_count": int(v[2]), "batches": int(v[3]),
-            "filter_ms": float(v[4]), "select_ms": float(v[5])}
+            "filter_ms": float(v[4]), "select_ms": float(v[5]), "distinct_candidates": float(v[6])}
 
 
 def dev_find_similar_pairs4(sig_ptr, cell_count, row_begin, row_end, lsh_count, k, similarity_threshold,

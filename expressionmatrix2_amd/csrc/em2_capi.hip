@@ -363,9 +363,9 @@ int em2_dev_find_similar_pairs4_last_launch(double* values, uint32_t valueCount)
 {
     if (!values && valueCount) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs4_last_launch: null pointer");
     const em2::Fsp4LaunchInfo info = em2::fsp4LastLaunchInfo();
-    const double all[8] = {double(info.form), info.scanKernelMs, info.waveColumnSteps, info.inboxEntries, info.segments, info.fullRowCells,
-                           info.matrixPairs, info.matrixKernelMs};
-    for (uint32_t i = 0; i < valueCount; i++) values[i] = i < 8 ? all[i] : 0.0;
+    const double all[9] = {double(info.form), info.scanKernelMs, info.waveColumnSteps, info.inboxEntries, info.segments, info.fullRowCells,
+                           info.matrixPairs, info.matrixKernelMs, info.matrixClockGHz};
+    for (uint32_t i = 0; i < valueCount; i++) values[i] = i < 9 ? all[i] : 0.0;
     return EM2_OK;
 }
 
@@ -374,8 +374,9 @@ int em2_dev_find_similar_pairs5_last_launch(double* values, uint32_t valueCount)
 {
     if (!values && valueCount) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs5_last_launch: null pointer");
     const em2::Fsp5LaunchInfo info = em2::fsp5LastLaunchInfo();
-    const double all[6] = {info.gatheredCandidates, info.cells, info.sliceCount, info.batches, info.filterMs, info.selectMs};
-    for (uint32_t i = 0; i < valueCount; i++) values[i] = i < 6 ? all[i] : 0.0;
+    const double all[7] = {info.gatheredCandidates, info.cells, info.sliceCount, info.batches, info.filterMs, info.selectMs,
+                           info.distinctCandidates};
+    for (uint32_t i = 0; i < valueCount; i++) values[i] = i < 7 ? all[i] : 0.0;
     return EM2_OK;
 }
 

@@ -67,6 +67,7 @@ struct Fsp4LaunchInfo {
     double fullRowCells;
     double matrixPairs;       // form 3: (row, column) pairs contracted on the matrix cores
     double matrixKernelMs;    // form 3: duration of fsp4ScanMatrixKernel alone
+    double matrixClockGHz;    // form 3: the shader clock that kernel ran at (block-lifetime s_memtime / s_memrealtime sums), 0 if unknown
 };
 Fsp4LaunchInfo fsp4LastLaunchInfo();      // of the calling thread's last launchFsp4Scan
 hipError_t readFsp4Error(const void* control, uint32_t rowCount, hipStream_t stream, uint32_t* error);
@@ -119,6 +120,7 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
 // gather of candidate signatures + popcounts) and of the selection over all batches.
 struct Fsp5LaunchInfo {
     double gatheredCandidates, cells, sliceCount, batches, filterMs, selectMs;
+    double distinctCandidates;      // what the filter read: the sizes of the cells' duplicate-free unions (the cell itself included); -1 in the sort form
 };
 Fsp5LaunchInfo fsp5LastLaunchInfo();
 

@@ -243,12 +243,46 @@ int em2_dist_find_similar_pairs4_with(const em2_collectives* c, const uint64_t* 
     if (!l.symmetric) return rowsForm(c, d_allSignatures, cellCount, lshCount, k, similarityThreshold, d_pairs, d_usedCount, ws, l, stream, timer);
 
     // ---- symmetric form ----
+    // A failure on ONE rank must not leave the others blocked in a collective that rank never enters.  Up to the agreement
+    // point a local failure (a phase's status, a HIP error, a hand-off time-out) is therefore only recorded: the rank goes
+    // on issuing every collective of the choreography -- the phases it can no longer run are skipped -- and reports
+    // overflow = 1, so that ALL ranks take the rows form together, after which this rank returns the recorded error.
+    // What is checked after the agreement (capacities of the exchange areas) is evaluated by every rank for every rank
+    // from the gathered count matrix, i.e. identically everywhere.  A failure behind the exchange (phase 3, the copies
+    // of the redistribution) is recorded as well and returned after the last collective.  Only a collective that itself
+    // reports failure ends the call at once: the transport is gone, there is nothing left to keep in step with.
+    // (As in expressionmatrix2_amd/sharded.py: guarded() / the agreed overflow flag.)
+    if (world > 255u) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dist_find_similar_pairs4: the symmetric form supports up to 255 ranks");
     em2_pair* globalPairs = reinterpret_cast<em2_pair*>(ws + l.globalPairs);
     uint32_t* globalUsed = reinterpret_cast<uint32_t*>(ws + l.globalUsed);
     char* shardWs = ws + l.sharded;
+    int localError = EM2_OK;
+    std::string localMessage;
+    auto record = [&](int rc) {
+        if (rc != EM2_OK && localError == EM2_OK) {
+            localError = rc;
+            localMessage = em2_last_error();
+        }
+        return rc == EM2_OK;
+    };
+    auto recordHip = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && localError == EM2_OK) {
+            localError = EM2_ERROR_HIP;
+            localMessage = std::string(what) + ": " + hipGetErrorString(e);
+        }
+        return e == hipSuccess;
+    };
     auto phase = [&](int number, uint64_t gatheredCount) {
-        return em2_dev_fsp4_sharded_phase(number, d_allSignatures, cellCount, lshCount, k, similarityThreshold, rank, world, globalPairs,
-                                          globalUsed, shardWs, size_t(l.plan[1]), gatheredCount, stream);
+        if (localError != EM2_OK) return false;
+#ifdef EM2_DIAG
+        // fault injection (diagnostic build only, tests/test_gpu_dist_entry.py): phase EM2_DIST_FAIL_PHASE fails on rank EM2_DIST_FAIL_RANK
+        if (getenv("EM2_DIST_FAIL_PHASE") && getenv("EM2_DIST_FAIL_RANK") && atoi(getenv("EM2_DIST_FAIL_PHASE")) == number &&
+            uint32_t(atoi(getenv("EM2_DIST_FAIL_RANK"))) == rank) {
+            return record(fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: injected failure of phase " + std::to_string(number)));
+        }
+#endif
+        return record(em2_dev_fsp4_sharded_phase(number, d_allSignatures, cellCount, lshCount, k, similarityThreshold, rank, world, globalPairs,
+                                                 globalUsed, shardWs, size_t(l.plan[1]), gatheredCount, stream));
     };
     int32_t* snap = reinterpret_cast<int32_t*>(shardWs + l.plan[2]);
     uint64_t* pool = reinterpret_cast<uint64_t*>(shardWs + l.plan[3]);
@@ -257,54 +291,71 @@ int em2_dist_find_similar_pairs4_with(const em2_collectives* c, const uint64_t* 
     uint64_t* counts = reinterpret_cast<uint64_t*>(ws + l.counts);            // [world][world + 2] gathered, then bounds[world + 1]
     const uint32_t stride = world + 2u;
 
-    EM2_DIST_OK(phase(0, 0));
+    phase(0, 0);
     timer.stage(EM2_DIST_MS_SCAN);
     if (c->all_reduce_max_i32(c->context, snap, cellCount, stream) != 0) return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: all_reduce failed");
     timer.stage(EM2_DIST_MS_ALL_REDUCE);
-    EM2_DIST_OK(phase(1, 0));
+    phase(1, 0);
     timer.stage(EM2_DIST_MS_SCAN);
     if (c->all_reduce_max_i32(c->context, snap, cellCount, stream) != 0) return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: all_reduce failed");
     timer.stage(EM2_DIST_MS_ALL_REDUCE);
-    EM2_DIST_OK(phase(2, 0));
+    phase(2, 0);
     uint64_t used = 0;
     uint32_t overflow = 0;
-    std::string handOffError;
-    if (em2_dev_fsp4_sharded_status(cellCount, k, rank, world, shardWs, stream, &used, &overflow) != EM2_OK) {
-        handOffError = em2_last_error();          // keep the collectives in step; every rank falls back, this one reports
-        used = 0;
-        overflow = 1;
-    }
+    if (localError == EM2_OK) record(em2_dev_fsp4_sharded_status(cellCount, k, rank, world, shardWs, stream, &used, &overflow));
     timer.stage(EM2_DIST_MS_SCAN);
 
-    // ---- what every rank sends to every rank, and whether anybody overflowed: one small all_gather, one read-back ----
+    // ---- what every rank sends to every rank, and whether anybody overflowed or failed: one small all_gather, one read-back ----
     const bool routed = (world & (world - 1u)) == 0u && !(getenv("EM2_SHARDED_EXCHANGE") && getenv("EM2_SHARDED_EXCHANGE")[0] == 'g');
     std::vector<uint64_t> mine(stride, 0), all(size_t(world) * stride, 0);
+    if (routed && !overflow && localError == EM2_OK) {
+        if (used) phase(4, used);
+        uint64_t* bounds = counts + size_t(world) * stride;
+        std::vector<uint64_t> hostBounds(world + 1u, 0);
+        if (localError == EM2_OK) {
+            ownerBoundsKernel<<<dim3(1), dim3(256), 0, stream>>>(sorted, used, uint32_t(l.plan[11]), world, bounds);
+            recordHip(hipGetLastError(), "ownerBoundsKernel") &&
+                recordHip(hipMemcpyAsync(hostBounds.data(), bounds, (world + 1u) * 8u, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(bounds)") &&
+                recordHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        }
+        if (localError == EM2_OK) {
+            for (uint32_t r = 0; r < world; r++) mine[r] = hostBounds[r + 1u] - hostBounds[r];
+        }
+    }
+    if (localError != EM2_OK) {
+        used = 0;
+        overflow = 1;
+        for (uint32_t r = 0; r < world; r++) mine[r] = 0;
+    }
     mine[world] = used;
     mine[world + 1u] = overflow;
-    if (routed && !overflow) {
-        if (used) EM2_DIST_OK(phase(4, used));
-        uint64_t* bounds = counts + size_t(world) * stride;
-        ownerBoundsKernel<<<dim3(1), dim3(256), 0, stream>>>(sorted, used, uint32_t(l.plan[11]), world, bounds);
-        EM2_DIST_HIP(hipGetLastError());
-        std::vector<uint64_t> hostBounds(world + 1u);
-        EM2_DIST_HIP(hipMemcpyAsync(hostBounds.data(), bounds, (world + 1u) * 8u, hipMemcpyDeviceToHost, stream));
-        EM2_DIST_HIP(hipStreamSynchronize(stream));
-        for (uint32_t r = 0; r < world; r++) mine[r] = hostBounds[r + 1u] - hostBounds[r];
-    }
+    // (a failed copy of this rank's own row would send stale counts: the row is staged through a pinned-size host vector and
+    // the flag travels in it, so a HIP error here is the one place where this rank cannot tell the others -- the transport
+    // call below then fails or the others time out; such an error means the device is lost)
     EM2_DIST_HIP(hipMemcpyAsync(counts + size_t(rank) * stride, mine.data(), stride * 8u, hipMemcpyHostToDevice, stream));
     if (c->all_gather(c->context, counts + size_t(rank) * stride, counts, stride * 8u, stream) != 0) return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: all_gather of the counts failed");
     EM2_DIST_HIP(hipMemcpyAsync(all.data(), counts, all.size() * 8u, hipMemcpyDeviceToHost, stream));
     EM2_DIST_HIP(hipStreamSynchronize(stream));
-    bool anyOverflow = false;
+    // ---- the agreement: every rank evaluates the same matrix the same way ----
+    bool fallBack = false;
     uint64_t maxUsed = 0;
     for (uint32_t r = 0; r < world; r++) {
-        anyOverflow = anyOverflow || all[size_t(r) * stride + world + 1u] != 0;
+        fallBack = fallBack || all[size_t(r) * stride + world + 1u] != 0;
         if (all[size_t(r) * stride + world] > maxUsed) maxUsed = all[size_t(r) * stride + world];
     }
+    if (routed) {
+        for (uint32_t receiver = 0; receiver < world; receiver++) {        // what each rank would receive must fit its exchange area
+            uint64_t entries = 0;
+            for (uint32_t sender = 0; sender < world; sender++) entries += all[size_t(sender) * stride + receiver];
+            fallBack = fallBack || entries > l.plan[6];
+        }
+    } else {
+        fallBack = fallBack || uint64_t(world) * maxUsed > l.plan[6];
+    }
     timer.stage(EM2_DIST_MS_EXCHANGE);
-    if (anyOverflow) {
+    if (fallBack) {
         const int rc = rowsForm(c, d_allSignatures, cellCount, lshCount, k, similarityThreshold, d_pairs, d_usedCount, ws, l, stream, timer);
-        if (rc == EM2_OK && !handOffError.empty()) return fail(EM2_ERROR_RUNTIME, handOffError);
+        if (localError != EM2_OK) return fail(localError, localMessage);
         return rc;
     }
 
@@ -322,18 +373,16 @@ int em2_dist_find_similar_pairs4_with(const em2_collectives* c, const uint64_t* 
             ro += recvBytes[r];
         }
         receivedEntries = ro / 8u;
-        if (receivedEntries > l.plan[6]) return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: received more entries than the exchange area holds");
         if (c->all_to_all_v(c->context, sorted, sendBytes.data(), sendOffsets.data(), gathered, recvBytes.data(), recvOffsets.data(), stream) != 0) {
             return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: all_to_all of the deferred candidates failed");
         }
     } else if (maxUsed) {
-        if (uint64_t(world) * maxUsed > l.plan[6]) return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: gathered more entries than the exchange area holds");
-        if (used < maxUsed) EM2_DIST_HIP(hipMemsetAsync(pool + used, 0xff, (maxUsed - used) * 8u, stream));      // ~0 sorts behind every entry
+        if (used < maxUsed) recordHip(hipMemsetAsync(pool + used, 0xff, (maxUsed - used) * 8u, stream), "hipMemsetAsync(pool tail)");      // ~0 sorts behind every entry
         if (c->all_gather(c->context, pool, gathered, maxUsed * 8u, stream) != 0) return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: all_gather of the deferred candidates failed");
         receivedEntries = uint64_t(world) * maxUsed;
     }
     timer.stage(EM2_DIST_MS_EXCHANGE);
-    EM2_DIST_OK(phase(3, receivedEntries));
+    phase(3, receivedEntries);          // (a failure from here on is returned after the last collective)
     timer.stage(EM2_DIST_MS_SCAN);
 
     // ---- finished rows go from the ranks that own their blocks to the ranks of their contiguous ranges ----
@@ -365,11 +414,12 @@ int em2_dist_find_similar_pairs4_with(const em2_collectives* c, const uint64_t* 
     uint32_t* stagingUsed = reinterpret_cast<uint32_t*>(ws + l.stagingUsed);
     em2_pair* received = reinterpret_cast<em2_pair*>(ws + l.received);
     uint32_t* receivedUsed = reinterpret_cast<uint32_t*>(ws + l.receivedUsed);
-    if (!ownedRows.empty()) {
-        EM2_DIST_HIP(hipMemcpyAsync(dOwnedRows, ownedRows.data(), ownedRows.size() * 4u, hipMemcpyHostToDevice, stream));
-        moveRowsKernel<<<dim3(uint32_t(ownedRows.size())), dim3(64), 0, stream>>>(globalPairs, globalUsed, dOwnedRows, nullptr,
-                                                                                 uint32_t(ownedRows.size()), k, staging, stagingUsed);
-        EM2_DIST_HIP(hipGetLastError());
+    if (!ownedRows.empty() && localError == EM2_OK) {
+        if (recordHip(hipMemcpyAsync(dOwnedRows, ownedRows.data(), ownedRows.size() * 4u, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(owned rows)")) {
+            moveRowsKernel<<<dim3(uint32_t(ownedRows.size())), dim3(64), 0, stream>>>(globalPairs, globalUsed, dOwnedRows, nullptr,
+                                                                                     uint32_t(ownedRows.size()), k, staging, stagingUsed);
+            recordHip(hipGetLastError(), "moveRowsKernel");
+        }
     }
     for (int pass = 0; pass < 2; pass++) {          // the pairs, then the used counts
         const size_t unit = pass == 0 ? rowBytes : 4u;
@@ -390,13 +440,15 @@ int em2_dist_find_similar_pairs4_with(const em2_collectives* c, const uint64_t* 
             return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: all_to_all of the finished rows failed");
         }
     }
-    if (rows) {
-        EM2_DIST_HIP(hipMemcpyAsync(dShardRows, shardRows.data(), shardRows.size() * 4u, hipMemcpyHostToDevice, stream));
-        moveRowsKernel<<<dim3(rows), dim3(64), 0, stream>>>(received, receivedUsed, nullptr, dShardRows, rows, k, d_pairs, d_usedCount);
-        EM2_DIST_HIP(hipGetLastError());
+    if (rows && localError == EM2_OK) {
+        if (recordHip(hipMemcpyAsync(dShardRows, shardRows.data(), shardRows.size() * 4u, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(shard rows)")) {
+            moveRowsKernel<<<dim3(rows), dim3(64), 0, stream>>>(received, receivedUsed, nullptr, dShardRows, rows, k, d_pairs, d_usedCount);
+            recordHip(hipGetLastError(), "moveRowsKernel");
+        }
     }
-    EM2_DIST_HIP(hipStreamSynchronize(stream));          // the host lists above must outlive the copies
+    recordHip(hipStreamSynchronize(stream), "hipStreamSynchronize");          // the host lists above must outlive the copies
     timer.stage(EM2_DIST_MS_REDISTRIBUTE);
+    if (localError != EM2_OK) return fail(localError, localMessage);
     return EM2_OK;
 }
 

@@ -72,13 +72,13 @@ runFlagsKernel(const uint64_t* __restrict__ sortedKeys, uint64_t total, uint32_t
 __global__ void __launch_bounds__(256)
 runTablesKernel(const uint64_t* __restrict__ sortedKeys, const uint32_t* __restrict__ sortedCells,
                 const uint32_t* __restrict__ flags, const uint32_t* __restrict__ scan, uint64_t total,
-                uint32_t cellCount, uint32_t* __restrict__ runStart, uint32_t* __restrict__ runOfSliceCell)
+                uint32_t cellCount, uint32_t sliceCount, uint32_t* __restrict__ runStart, uint32_t* __restrict__ runOfSliceCell)
 {
     for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += uint64_t(gridDim.x) * blockDim.x) {
         const uint32_t run = scan[i] - 1u;
         if (flags[i]) runStart[run] = uint32_t(i);
         const uint32_t s = uint32_t(sortedKeys[i] >> 32);
-        runOfSliceCell[size_t(s) * cellCount + sortedCells[i]] = run;
+        runOfSliceCell[size_t(sortedCells[i]) * sliceCount + s] = run;        // [cell][slice]: a cell's descriptors are one contiguous read
         if (i == total - 1) runStart[run + 1u] = uint32_t(total);
     }
 }
@@ -92,7 +92,7 @@ candidateCountKernel(const uint32_t* __restrict__ runOfSliceCell, const uint32_t
     if (c >= cellCount) return;
     uint64_t n = 0;
     for (uint32_t s = 0; s < sliceCount; ++s) {
-        const uint32_t run = runOfSliceCell[size_t(s) * cellCount + c];
+        const uint32_t run = runOfSliceCell[size_t(c) * sliceCount + s];
         const uint64_t size = runStart[run + 1u] - runStart[run];
         if (bucketOverflow == 0 || size <= bucketOverflow) n += size;       // ExpressionMatrixLsh.cpp:419
     }
@@ -118,7 +118,7 @@ gatherKernel(const uint32_t* __restrict__ runOfSliceCell, const uint32_t* __rest
         const uint32_t s = first + lane;
         uint32_t begin = 0, size = 0;
         if (s < sliceCount) {
-            const uint32_t run = runOfSliceCell[size_t(s) * cellCount + c];
+            const uint32_t run = runOfSliceCell[size_t(c) * sliceCount + s];
             begin = runStart[run];
             size = runStart[run + 1u] - begin;
             if (bucketOverflow != 0 && uint64_t(size) > bucketOverflow) size = 0u;
@@ -153,6 +153,120 @@ gatherKernel(const uint32_t* __restrict__ runOfSliceCell, const uint32_t* __rest
     }
 }
 
+
+// The union of a cell's buckets without a sort (multipleSetUnion.hpp:44-76 asks for the ascending, duplicate-free union): a
+// bitmap over the cell ids in LDS.  One block of 1024 threads per cell, two blocks per CU; the id space is covered in passes of
+// kUnionWords * 32 ids (two passes at a million cells), so any cell count works.  Per pass: every bucket member inside the
+// pass's id range sets its bit (ds_or_b32); thread t then owns the words [17 t, 17 t + 17) -- an odd stride, so the 64 lanes of
+// a wave read 64 different banks -- takes them into registers, zeroes them, and counts its bits; one block-wide prefix sum
+// gives every thread the position of its first id; the ids go into the (now free) bitmap area in ascending order and from
+// there to the cell's segment of `candidates` with coalesced stores.  The cell itself stays in the list (the reference takes
+// the union first and drops the cell afterwards, :417-439: the filter does).
+// Replaces gatherKernel + rocPRIM's segmented radix sort (14 + 77 ms of the 390 at 1M cells x 2048 bits, q = 20).
+constexpr uint32_t kUnionThreads = 1024;
+constexpr uint32_t kUnionWordsPerThread = 17;
+constexpr uint32_t kUnionWords = kUnionThreads * kUnionWordsPerThread;      // 17408 words = 557,056 ids per pass, 68 KB
+constexpr uint32_t kUnionSliceChunk = 256;
+constexpr size_t kUnionLdsBytes = size_t(kUnionWords) * 4u + 2u * kUnionSliceChunk * 4u + 32u * 4u;
+
+__global__ void __launch_bounds__(kUnionThreads)
+unionKernel(const uint32_t* __restrict__ runOfCellSlice, const uint32_t* __restrict__ runStart,
+            const uint32_t* __restrict__ sortedCells, uint32_t cellCount, uint32_t sliceCount, uint64_t bucketOverflow,
+            uint32_t batchBegin, uint32_t batchCells, const uint32_t* __restrict__ segmentBegin,
+            uint32_t* __restrict__ candidates, uint32_t* __restrict__ distinctCounts)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t unionLds[];
+    uint32_t* bitmap = unionLds;                                    // kUnionWords, all zero between two uses
+    uint32_t* bucketBegin = unionLds + kUnionWords;                 // kUnionSliceChunk
+    uint32_t* bucketSize = bucketBegin + kUnionSliceChunk;          // kUnionSliceChunk
+    uint32_t* waveTotals = bucketSize + kUnionSliceChunk;           // 16 (+ the block total)
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    for (uint32_t w = t; w < kUnionWords; w += kUnionThreads) bitmap[w] = 0u;
+    __syncthreads();
+    const uint32_t passes = (cellCount + kUnionWords * 32u - 1u) / (kUnionWords * 32u);
+    for (uint32_t local = blockIdx.x; local < batchCells; local += gridDim.x) {
+        const uint32_t c = batchBegin + local;
+        uint32_t* out = candidates + segmentBegin[local];
+        uint32_t written = 0;
+        for (uint32_t pass = 0; pass < passes; ++pass) {
+            const uint32_t lo = pass * kUnionWords * 32u;
+            // ---- the members of the cell's buckets that fall into [lo, lo + kUnionWords * 32) set their bits ----
+            for (uint32_t base = 0; base < sliceCount; base += kUnionSliceChunk) {
+                if (t < kUnionSliceChunk) {
+                    uint32_t begin = 0, size = 0;
+                    if (base + t < sliceCount) {
+                        const uint32_t run = runOfCellSlice[size_t(c) * sliceCount + base + t];
+                        begin = runStart[run];
+                        size = runStart[run + 1u] - begin;
+                        if (bucketOverflow != 0 && uint64_t(size) > bucketOverflow) size = 0u;         // ExpressionMatrixLsh.cpp:419
+                    }
+                    bucketBegin[t] = begin;
+                    bucketSize[t] = size;
+                }
+                __syncthreads();
+                const uint32_t buckets = sliceCount - base < kUnionSliceChunk ? sliceCount - base : kUnionSliceChunk;
+                for (uint32_t b = wave; b < buckets; b += kUnionThreads / 64u) {
+                    const uint32_t begin = bucketBegin[b], size = bucketSize[b];
+                    for (uint32_t i = lane; i < size; i += 64u) {
+                        const uint32_t id = sortedCells[begin + i] - lo;           // (ids below lo wrap to huge values)
+                        if (id < kUnionWords * 32u) atomicOr(&bitmap[id >> 5], 1u << (id & 31u));
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- every thread takes its 17 words, leaves zeroes, counts ----
+            uint32_t words[kUnionWordsPerThread];
+            uint32_t count = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kUnionWordsPerThread; ++j) {
+                words[j] = bitmap[t * kUnionWordsPerThread + j];
+                count += uint32_t(__builtin_popcount(words[j]));
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kUnionWordsPerThread; ++j) bitmap[t * kUnionWordsPerThread + j] = 0u;
+            // block-wide exclusive prefix sum of the counts
+            uint32_t inclusive = count;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t below = uint32_t(__shfl_up(int(inclusive), d, 64));
+                if (lane >= uint32_t(d)) inclusive += below;
+            }
+            if (lane == 63u) waveTotals[wave] = inclusive;
+            __syncthreads();                    // (also: every thread has read and zeroed its words)
+            uint32_t before = 0, total = 0;
+            for (uint32_t w = 0; w < kUnionThreads / 64u; ++w) {
+                const uint32_t x = waveTotals[w];
+                before += w < wave ? x : 0u;
+                total += x;
+            }
+            uint32_t position = before + inclusive - count;
+            // ---- ids in ascending order: through the bitmap area when they fit (coalesced stores), else straight from the registers ----
+            const bool staged = total <= kUnionWords;
+            uint32_t* target = staged ? bitmap : out + written;
+#pragma unroll
+            for (uint32_t j = 0; j < kUnionWordsPerThread; ++j) {
+                uint32_t bits = words[j];
+                const uint32_t first = lo + (t * kUnionWordsPerThread + j) * 32u;
+                while (bits) {
+                    const uint32_t bit = uint32_t(__builtin_ctz(bits));
+                    bits &= bits - 1u;
+                    target[position++] = first + bit;
+                }
+            }
+            __syncthreads();
+            if (staged) {
+                for (uint32_t i = t; i < total; i += kUnionThreads) {
+                    out[written + i] = bitmap[i];
+                    bitmap[i] = 0u;
+                }
+            }
+            written += total;
+            __syncthreads();
+        }
+        if (t == 0u) distinctCounts[local] = written;
+    }
+}
+
 __device__ __forceinline__ void waveFence()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -167,14 +281,14 @@ __global__ void __launch_bounds__(256)
 filterKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batchBegin, uint32_t batchCells,
              const uint32_t* __restrict__ segmentBegin, const uint32_t* __restrict__ sortedCandidates,
              Entry* __restrict__ lists, int32_t mGlobal, const uint32_t* __restrict__ keyOfMismatch,
-             uint32_t* __restrict__ listCounts)
+             uint32_t* __restrict__ listCounts, const uint32_t* __restrict__ distinctCounts)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t local = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (local >= batchCells) return;
     const uint32_t c = batchBegin + local;
     const uint32_t begin = segmentBegin[local];
-    const uint32_t end = segmentBegin[local + 1u];
+    const uint32_t end = distinctCounts ? begin + distinctCounts[local] : segmentBegin[local + 1u];
     const uint64_t* mine = sig + size_t(c) * words;
     Entry* list = lists + begin;                    // at most (end-begin) entries survive
     uint32_t n = 0;
@@ -213,7 +327,7 @@ __global__ void __launch_bounds__(256)
 filterCooperativeKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batchBegin, uint32_t batchCells,
                         const uint32_t* __restrict__ segmentBegin, const uint32_t* __restrict__ sortedCandidates,
                         Entry* __restrict__ lists, int32_t mGlobal, const uint32_t* __restrict__ keyOfMismatch,
-                        uint32_t* __restrict__ listCounts)
+                        uint32_t* __restrict__ listCounts, const uint32_t* __restrict__ distinctCounts)
 {
     __shared__ uint32_t candOfRankAll[4][64];
     const uint32_t lane = threadIdx.x & 63u;
@@ -222,7 +336,8 @@ filterCooperativeKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32
     if (local >= batchCells) return;
     const uint32_t c = batchBegin + local;
     const uint32_t begin = segmentBegin[local];
-    const uint32_t end = segmentBegin[local + 1u];
+    // (after unionKernel the segment holds the distinct candidates only, distinctCounts of them)
+    const uint32_t end = distinctCounts ? begin + distinctCounts[local] : segmentBegin[local + 1u];
     Entry* list = lists + begin;
     uint32_t lpc = 16u;
     while (lpc > words) lpc >>= 1;
@@ -518,7 +633,7 @@ uint32_t bitsFor(uint64_t maxValue)
 // cellCount cells; candidates are generated and selected for the cells [rowBegin,rowEnd) only (the shard one
 // rank owns).  d_pairs / d_used are device arrays of (rowEnd-rowBegin)*k and (rowEnd-rowBegin) elements.
 namespace {
-thread_local Fsp5LaunchInfo lastFsp5Info = {0., 0., 0., 0., -1., -1.};
+thread_local Fsp5LaunchInfo lastFsp5Info = {0., 0., 0., 0., -1., -1., -1.};
 }
 
 Fsp5LaunchInfo fsp5LastLaunchInfo() { return lastFsp5Info; }
@@ -570,7 +685,7 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
     EM2_TRY(scanTemp.allocate(scanBytes));
     EM2_TRY(rocprim::inclusive_scan(scanTemp.p, scanBytes, flags.as<uint32_t>(), scan.as<uint32_t>(), size_t(total), rocprim::plus<uint32_t>(), stream));
     runTablesKernel<<<gridFor(total), 256, 0, stream>>>(sortedKeys, sortedCells, flags.as<uint32_t>(), scan.as<uint32_t>(), total,
-                                                        cellCount, runStart.as<uint32_t>(), runOf.as<uint32_t>());
+                                                        cellCount, sliceCount, runStart.as<uint32_t>(), runOf.as<uint32_t>());
     EM2_TRY(hipGetLastError());
     candidateCountKernel<<<(cellCount + 255u) / 256u, 256, 0, stream>>>(runOf.as<uint32_t>(), runStart.as<uint32_t>(), cellCount,
                                                                          sliceCount, bucketOverflow, counts.as<uint64_t>());
@@ -618,18 +733,35 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
         lastFsp5Info.sliceCount = double(sliceCount);
         lastFsp5Info.batches = double(batches.size());
         lastFsp5Info.filterMs = lastFsp5Info.selectMs = 0.;
+        lastFsp5Info.distinctCandidates = -1.;
     }
     static thread_local hipEvent_t timing[3] = {nullptr, nullptr, nullptr};
     if (!timing[0]) {
         if (hipEventCreate(&timing[0]) != hipSuccess || hipEventCreate(&timing[1]) != hipSuccess ||
             hipEventCreate(&timing[2]) != hipSuccess) timing[0] = timing[1] = timing[2] = nullptr;
     }
-    Buffer segBegin, candA, candB, lists, sortTemp, listCounts;
+    Buffer segBegin, candA, candB, lists, sortTemp, listCounts, distinctCounts;
+    // EM2_FSP5_UNION=sort keeps gatherKernel + the segmented sort (A/B measurements)
+    const char* unionMode = getenv("EM2_FSP5_UNION");
+    const bool useUnion = !(unionMode && unionMode[0] == 's');
+    uint32_t unionBlocks = 1;
+    if (useUnion) {
+        int device = 0, cuCount = 0, perCu = 0;
+        EM2_TRY(hipGetDevice(&device));
+        EM2_TRY(hipDeviceGetAttribute(&cuCount, hipDeviceAttributeMultiprocessorCount, device));
+        EM2_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&unionKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(kUnionLdsBytes)));
+        EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, reinterpret_cast<const void*>(&unionKernel), int(kUnionThreads), kUnionLdsBytes));
+        unionBlocks = uint32_t(cuCount > 0 ? cuCount : 1) * uint32_t(perCu > 0 ? perCu : 1);
+    }
+    std::vector<uint32_t> hostDistinct;
+    double distinctTotal = 0.;
     EM2_TRY(segBegin.allocate((size_t(maxCells) + 1u) * sizeof(uint32_t)));
     EM2_TRY(candA.allocate(size_t(maxTotal) * sizeof(uint32_t)));
     EM2_TRY(candB.allocate(size_t(maxTotal) * sizeof(uint32_t)));
     EM2_TRY(lists.allocate(size_t(maxTotal) * sizeof(Entry)));
     EM2_TRY(listCounts.allocate(size_t(maxCells) * sizeof(uint32_t)));
+    EM2_TRY(distinctCounts.allocate(size_t(maxCells) * sizeof(uint32_t)));
+    if (useUnion) hostDistinct.resize(maxCells);
     size_t sortTempBytes = 0;
     const uint32_t idBits = bitsFor(cellCount - 1u);
     // EM2_FSP5_FILTER=lane selects the one-lane-per-candidate filter (A/B measurements)
@@ -641,7 +773,17 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
         const uint32_t batchTotal = batch.seg.back();
         EM2_TRY(hipMemcpyAsync(segBegin.p, batch.seg.data(), batch.seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         const uint32_t* sorted = candA.as<uint32_t>();
-        if (batchTotal) {
+        const uint32_t* distinct = nullptr;
+        if (batchTotal && useUnion) {
+            // the ascending, duplicate-free union of every cell's buckets through a bitmap in LDS (unionKernel)
+            unionKernel<<<unionBlocks, kUnionThreads, kUnionLdsBytes, stream>>>(runOf.as<uint32_t>(), runStart.as<uint32_t>(), sortedCells, cellCount,
+                                                                                sliceCount, bucketOverflow, batchBegin, batchCells,
+                                                                                segBegin.as<uint32_t>(), candA.as<uint32_t>(),
+                                                                                distinctCounts.as<uint32_t>());
+            EM2_TRY(hipGetLastError());
+            distinct = distinctCounts.as<uint32_t>();
+        } else if (batchTotal) {
+            // EM2_FSP5_UNION=sort (A/B measurements): gather the buckets' members and sort each cell's segment
             gatherKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(runOf.as<uint32_t>(), runStart.as<uint32_t>(), sortedCells, cellCount,
                                                                      sliceCount, bucketOverflow, batchBegin, batchCells,
                                                                      segBegin.as<uint32_t>(), candA.as<uint32_t>());
@@ -662,11 +804,11 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
         if (cooperative) {
             filterCooperativeKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(),
                                                                                 sorted, lists.as<Entry>(), tables.mGlobal,
-                                                                                tables.keyOfMismatch, listCounts.as<uint32_t>());
+                                                                                tables.keyOfMismatch, listCounts.as<uint32_t>(), distinct);
         } else {
             filterKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
                                                                      lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,
-                                                                     listCounts.as<uint32_t>());
+                                                                     listCounts.as<uint32_t>(), distinct);
         }
         EM2_TRY(hipGetLastError());
         if (timing[0]) (void)hipEventRecord(timing[1], stream);
@@ -719,7 +861,9 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
             EM2_TRY(hipGetLastError());
         }
         if (timing[0]) (void)hipEventRecord(timing[2], stream);
+        if (distinct) EM2_TRY(hipMemcpyAsync(hostDistinct.data(), distinct, size_t(batchCells) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         EM2_TRY(hipStreamSynchronize(stream));       // the batch's offsets (pageable host memory) and scratch are reused
+        if (distinct) for (uint32_t i = 0; i < batchCells; i++) distinctTotal += double(hostDistinct[i]);
         if (timing[0]) {
             float a = 0.f, b = 0.f;
             if (hipEventElapsedTime(&a, timing[0], timing[1]) == hipSuccess && hipEventElapsedTime(&b, timing[1], timing[2]) == hipSuccess) {
@@ -728,6 +872,7 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
             }
         }
     }
+    lastFsp5Info.distinctCandidates = useUnion ? distinctTotal : -1.;
     return hipSuccess;
 }
 

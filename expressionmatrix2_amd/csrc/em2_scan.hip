@@ -386,7 +386,7 @@ static bool scanModeIsSimple()
 }
 
 // What the last launch on this thread did (benchmarks and logs): see em2_dev_find_similar_pairs4_last_launch.
-thread_local Fsp4LaunchInfo lastLaunchInfo = {0, -1.0, 0.0, 0.0, 0.0, 0.0, 0.0, -1.0};
+thread_local Fsp4LaunchInfo lastLaunchInfo = {0, -1.0, 0.0, 0.0, 0.0, 0.0, 0.0, -1.0, 0.0};
 
 Fsp4LaunchInfo fsp4LastLaunchInfo() { return lastLaunchInfo; }
 
@@ -478,6 +478,7 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     lastLaunchInfo.fullRowCells = double(rows);
     lastLaunchInfo.matrixPairs = 0.0;
     lastLaunchInfo.matrixKernelMs = -1.0;
+    lastLaunchInfo.matrixClockGHz = 0.0;
 
     if (scanModeIsSimple() || !control) {
         uint32_t rowsPerLane = forcedRowsPerLane();

@@ -757,6 +757,9 @@ typedef const __attribute__((address_space(1))) int32_t* GlobalIntPtr;
 typedef __attribute__((address_space(1))) uint64_t* GlobalWord64Ptr;
 
 constexpr uint32_t kMatrixLogMargin = 96u;
+// inboxControl (256 bytes): words 0..3 inbox position / overflow, byte 32 the longest inbox, 40..63 and 64..127 the cycle
+// counters of the diagnostic build, 128..143 the sums of shader-clock and 100 MHz wall-clock ticks of the matrix kernel's blocks
+constexpr uint32_t kClockWordsOffset = 32u;     // in 32-bit words
 
 typedef const __attribute__((address_space(3))) int32_t* LdsIntPtr;
 
@@ -1290,6 +1293,10 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
     if (threadIdx.x < 4u) shared[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t emitPos = 0, emitEnd = 0;
+    // The clock this launch ran at: every block's first lane stamps the shader clock counter and the 100 MHz wall counter when
+    // it starts and when it leaves; the launcher divides the sums (MI355X_MICROARCH.md, 'DVFS give-back' item 6).  Two scalar
+    // reads per block and launch; the values go to two words of the control block that nothing else reads.
+    const uint64_t clockStart = __builtin_amdgcn_s_memtime(), wallStart = __builtin_amdgcn_s_memrealtime();
 
     for (;;) {
         if (threadIdx.x == 0u) {
@@ -1530,6 +1537,11 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
     if (TIMED && lane == 0u) {
         unsigned long long* counters = reinterpret_cast<unsigned long long*>(kernelArgs()->inboxControl + 16);
         for (int i = 0; i < 8; i++) atomicAdd(counters + i, (unsigned long long)phaseCycles[i]);
+    }
+    if (threadIdx.x == 0u) {
+        unsigned long long* clockWords = reinterpret_cast<unsigned long long*>(kernelArgs()->inboxControl + kClockWordsOffset);
+        atomicAdd(clockWords, (unsigned long long)(__builtin_amdgcn_s_memtime() - clockStart));
+        atomicAdd(clockWords + 1, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - wallStart));
     }
 }
 #undef EM2_PHASE
@@ -2409,6 +2421,13 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     }
     const uint64_t used = uint64_t(inboxWords[0]) | (uint64_t(inboxWords[1]) << 32);
     if (inboxWords[2] != 0u || used > layout.capacity) return hipSuccess;      // overflow: *done stays false
+    double matrixClockGHz = 0.0;
+    if (matrix) {
+        unsigned long long ticks[2] = {0, 0};
+        if (hipMemcpy(ticks, ws + layout.control + 4u * kClockWordsOffset, sizeof(ticks), hipMemcpyDeviceToHost) == hipSuccess && ticks[1]) {
+            matrixClockGHz = double(ticks[0]) / double(ticks[1]) * 0.1;          // s_memrealtime counts at 100 MHz
+        }
+    }
     if (matrix && (diagNumber("EM2_MATRIX_DIAG") & 2048u)) {
         unsigned long long cycles[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpy(cycles, ws + layout.control + 64u, sizeof(cycles), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -2436,6 +2455,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         if (matrix && (!timing[0] || hipEventElapsedTime(&matrixMs, timing[2], timing[1]) != hipSuccess)) matrixMs = -1.0f;
         lastLaunchInfo.matrixPairs = matrixPairs;
         lastLaunchInfo.matrixKernelMs = double(matrixMs);
+        lastLaunchInfo.matrixClockGHz = matrixClockGHz;
         lastLaunchInfo.form = matrix ? 3 : 1;
         lastLaunchInfo.scanKernelMs = double(ms);
         lastLaunchInfo.waveColumnSteps = steps;

@@ -178,7 +178,8 @@ int em2_dev_find_similar_pairs4_form_for(uint32_t cellCount, uint32_t rowCount, 
  * (symmetric form, which synchronises anyway), else -1, [2] (64-row wave, column) steps executed, [3] symmetric
  * form: inbox entries sorted and replayed, [4] column segments, [5] cells whose rows scanned all columns, [6] pairs
  * contracted on the matrix cores and [7] the duration in ms of that kernel alone (form 3, the matrix-core form of the
- * symmetric scan: FP4 +-1 contraction, signatures zero-extended to 1024 or 2048 bits). */
+ * symmetric scan: FP4 +-1 contraction, signatures zero-extended to 1024 or 2048 bits), [8] the shader clock in GHz that
+ * kernel ran at (sums over its blocks of s_memtime and s_memrealtime ticks; 0 when unknown). */
 int em2_dev_find_similar_pairs4_last_launch(double* values, uint32_t valueCount);
 
 /* findSimilarPairs4 for the rows [rowBegin,rowEnd) of the cell set against all cellCount cells: the shard
@@ -300,7 +301,8 @@ int em2_dev_find_similar_pairs5(const uint64_t* d_signatures, uint32_t cellCount
  * values[0] candidate ids gathered from the buckets (duplicates and the cell itself included: each costs the filter
  * one look at the sorted list, each distinct one a gather of 8*W signature bytes), [1] cells queried, [2] slices
  * (lshCount / lshSliceLength, src/ExpressionMatrixLsh.cpp:355), [3] batches, [4] / [5] ms of the candidate filter and
- * of the selection, summed over the batches (HIP events on the launch stream). */
+ * of the selection, summed over the batches (HIP events on the launch stream), [6] the DISTINCT candidates of all cells
+ * (the sizes of the duplicate-free unions, the cell itself included): the signatures the filter actually gathers. */
 int em2_dev_find_similar_pairs5_last_launch(double* values, uint32_t valueCount);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -92,11 +92,25 @@ def main():
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
     form = capi.dist_find_similar_pairs4_form(cells, L, k, world)
     stages = None
+    # EM2_TEST_EXPECT_FAILURE_ON_RANK (with the diagnostic library's fault injection): that rank's call must raise, every
+    # rank must come back (nobody may be left waiting in a collective), and -- unless EM2_TEST_OTHERS_MAY_DIFFER, i.e. when the
+    # failure comes after the ranks' agreement -- the other ranks must still hold the right rows
+    failing = int(os.environ.get("EM2_TEST_EXPECT_FAILURE_ON_RANK", "-1"))
     for timed in (False, True):
-        stages = capi.dist_find_similar_pairs4(table, local.data_ptr(), cells, L, k, thr, everything.data_ptr(), pairs.data_ptr(),
-                                               used.data_ptr(), ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream,
-                                               timed=timed)
+        try:
+            stages = capi.dist_find_similar_pairs4(table, local.data_ptr(), cells, L, k, thr, everything.data_ptr(), pairs.data_ptr(),
+                                                   used.data_ptr(), ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream,
+                                                   timed=timed)
+            if rank == failing:
+                print("rank %d: the injected failure was not reported" % rank, file=sys.stderr)
+                sys.exit(4)
+        except RuntimeError as error:
+            if rank != failing or "injected failure" not in str(error):
+                raise
+            stages = {}
         torch.cuda.synchronize()
+        if rank == failing or (failing >= 0 and os.environ.get("EM2_TEST_OTHERS_MAY_DIFFER") == "1"):
+            continue
         oracle = oracle_binding.load_oracle()
         cell, sim, oused = oracle.find_similar_pairs4_rows(sig, L, k, thr, begin, end)
         got = pairs[:end - begin].cpu().numpy().view(np.uint32)

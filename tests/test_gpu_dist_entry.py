@@ -55,6 +55,26 @@ def test_overflow_sends_all_ranks_to_the_rows_form():
     assert result["form"] == 2 and result["calls"]["all_to_all"] == 0
 
 
+@pytest.mark.parametrize("phase,ranks", [(0, 2), (1, 3), (2, 2), (4, 2), (3, 2)])
+def test_failure_on_one_rank_leaves_nobody_waiting(phase, ranks):
+    """a rank whose phase fails keeps issuing the collectives, all ranks take the rows form together, the failing
+    rank returns its error and the others their (right) rows.  The failure is injected by the diagnostic build of the
+    library (make diag: -DEM2_DIAG, EM2_DIST_FAIL_PHASE / EM2_DIST_FAIL_RANK); the product has no such knob.  Phase 3 lies
+    behind the agreement: there the requirement is that every rank returns and the failing one reports."""
+    diag = os.path.join(ROOT, "expressionmatrix2_amd", "libem2lsh_diag.so")
+    if not os.path.exists(diag):
+        build = subprocess.run(["make", "-C", os.path.join(ROOT, "expressionmatrix2_amd", "csrc"), "diag"], capture_output=True, text=True)
+        assert build.returncode == 0, build.stderr[-3000:]
+    env = {"EM2_SHARDED_MIN_CELLS": "1000", "EM2_LIBRARY": diag, "EM2_DIST_FAIL_PHASE": str(phase), "EM2_DIST_FAIL_RANK": str(ranks - 1),
+           "EM2_TEST_EXPECT_FAILURE_ON_RANK": str(ranks - 1)}
+    if phase == 3:
+        env["EM2_TEST_OTHERS_MAY_DIFFER"] = "1"
+    result = run_ranks(ranks, 20000, 1024, 10, 0.2, 29670 + phase, env)
+    assert result["form"] == 2
+    if phase != 3:
+        assert result["calls"]["all_to_all"] == 0          # nobody entered the exchange
+
+
 def test_rccl_transport_world_one(tmp_path):
     source = os.path.join(ROOT, "tests", "native", "em2_dist_rccl.cpp")
     binary = str(tmp_path / "em2_dist_rccl")

@@ -127,12 +127,28 @@ def test_fsp5_last_launch_reports_what_the_filter_read(oracle):
     assert info["filter_ms"] > 0 and info["select_ms"] > 0
     bits = np.unpackbits(sig.view(np.uint8).reshape(n, -1, 8)[:, :, ::-1].reshape(n, -1), axis=1)[:, :L]
     expected = 0
+    member = np.zeros((n, n), dtype=bool)            # member[c, o]: o is in one of the buckets c gathers
     for s in range(slices):
         keys = bits[:, s * q:(s + 1) * q].astype(np.uint64) @ (1 << np.arange(q - 1, -1, -1, dtype=np.uint64))
         _, inverse, counts = np.unique(keys, return_inverse=True, return_counts=True)
         size = counts[inverse]
         expected += int(size[size <= ovf].sum())
+        member |= (keys[:, None] == keys[None, :]) & (size <= ovf)[:, None]
     assert info["gathered_candidates"] == expected
+    # the distinct candidates, i.e. the signatures the filter gathers (unionKernel counts them): the union's size per cell
+    assert info["distinct_candidates"] == int(member.sum())
+
+
+@pytest.mark.parametrize("mode", ["union", "sort"])
+def test_fsp5_union_forms_agree(oracle, monkeypatch, mode):
+    """The duplicate-free ascending union of a cell's buckets (src/multipleSetUnion.hpp:44-76) through the LDS bitmap
+    (unionKernel, default) and through gather + segmented sort (EM2_FSP5_UNION=sort): both against the oracle, on shapes
+    that need several passes of the bitmap's id range would be too large for a unit test -- the pass logic is exercised by
+    ids on both sides of a word and of a thread's 17-word share, overflowing buckets, and cells whose union is everything."""
+    monkeypatch.setenv("EM2_FSP5_UNION", mode)
+    for n, L, k, thr, q, ovf in ((5000, 192, 12, 0.1, 6, 0), (3333, 256, 7, 0.2, 11, 25), (70, 64, 3, -1.0, 1, 0)):
+        sig = synth.clustered_signatures(n, L, cluster_count=5, flip=0.2, seed=n)
+        check(oracle, sig, L, k, thr, q, ovf)
 
 
 @pytest.mark.parametrize("mode", ["tiers", "unpacked", "global", "lds"])

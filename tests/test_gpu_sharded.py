@@ -38,6 +38,10 @@ def test_sharded_symmetric_scan_two_ranks(exchange):
     assert result["config"]["scan"] == "sharded-symmetric"
     assert result["n_gpus"] == 2 and result["parity_check"]["fsp4_rows"] > 0
     assert result["roofline"]["inbox_entries"] > 0
+    # north_star's own partitioning was measured first, by the same contract, and rides along
+    leg = result["row_shard_leg"]
+    assert leg["scan"] == "row-shards" and leg["value"] > 0 and leg["steps"] == 1 and leg["parity_check"]["fsp4_rows"] > 0
+    assert result["collective_check"]["ranks_counted_by_all_reduce"] == 2 and result["collective_check"]["rank_ids_gathered"] == [0, 1]
 
 
 def test_sharded_symmetric_scan_four_ranks_ragged_size():
@@ -57,3 +61,13 @@ def test_sharded_scan_overflow_falls_back_to_row_shards():
     result = run_two_ranks({"EM2_SHARDED_MIN_CELLS": "1000", "EM2_INBOX_CAPACITY": "2048"}, cells=30000, port=29633)
     assert result["config"]["scan"] == "row-shards"
     assert result["parity_check"]["fsp4_rows"] > 0
+
+
+def test_a_rank_that_leaves_the_symmetric_leg_does_not_void_the_run():
+    """one broken exchange must not cost the whole record.  Rank 1 fails at the start of the sharded
+    symmetric leg's timed steps; rank 0 is left in a collective; every rank leaves through its watchdog within the stage limit
+    (shortened here), exit code 0, and the line is the row-shard leg measured before -- with the failure on it."""
+    result = run_two_ranks({"EM2_SHARDED_MIN_CELLS": "1000", "EM2_BENCH_TEST_FAIL_RANK": "1", "EM2_BENCH_STAGE_LIMIT": "25"}, cells=30000,
+                           port=29636)
+    assert result["config"]["scan"] == "row-shards" and result["value"] > 0 and result["parity_check"]["after_timing_rows"] > 0
+    assert result["sharded_symmetric_leg"]["status"] == "did not complete"
