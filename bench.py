@@ -283,7 +283,7 @@ def bench_fsp5(args, capi, oracle, device, torch, check_ranges=3):
             prof = json.load(f)
         cfg = prof.get("config", {})
         if (cfg.get("cells"), cfg.get("lsh_count"), cfg.get("k"), cfg.get("slice_length")) == (C, L, k, q):
-            t = prof["per_call_bytes"]["filterCooperativeKernel"]
+            t = prof["per_call_bytes"]["filterKernel"]
             traffic = t["fetch"] + t["write"]
             traffic_source = "profiles/r03_pmc_fsp5_1Mcells_2048bit.json (FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE, all batches of one call)"
     return {
@@ -296,7 +296,8 @@ def bench_fsp5(args, capi, oracle, device, torch, check_ranges=3):
                    "cells": C, "lsh_count": L, "k": k, "slices": info["slice_count"], "batches": info["batches"]},
         "phases_ms": {"candidate_filter": filter_ms, "selection": select_ms,
                       "tables_and_candidate_unions": elapsed / args.steps * 1e3 - filter_ms - select_ms},
-        "roofline": {"kernel": "filterCooperativeKernel (all batches)", "kernel_ms": filter_ms, "bound": "hbm", "achieved": achieved,
+        "roofline": {"kernel": ("filterWideKernel<%d> (all batches)" % (1 if W <= 32 else 2)) if W % 2 == 0 and W <= 64 and
+                               os.environ.get("EM2_FSP5_FILTER", "w")[0] == "w" else "filterCooperativeKernel (all batches)", "kernel_ms": filter_ms, "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes": algorithmic, "distinct_candidates": distinct, "gathered_candidates": info["gathered_candidates"],
                      "note": "SURVEY.md 8(d): candidates x 8*W bytes of signature gathers + 4*N*sliceCount bytes of tables; candidates "

@@ -156,20 +156,28 @@ gatherKernel(const uint32_t* __restrict__ runOfSliceCell, const uint32_t* __rest
 
 // The union of a cell's buckets without a sort (multipleSetUnion.hpp:44-76 asks for the ascending, duplicate-free union): a
 // bitmap over the cell ids in LDS.  One block of 1024 threads per cell, two blocks per CU; the id space is covered in passes of
-// kUnionWords * 32 ids (two passes at a million cells), so any cell count works.  Per pass: every bucket member inside the
-// pass's id range sets its bit (ds_or_b32); thread t then owns the words [17 t, 17 t + 17) -- an odd stride, so the 64 lanes of
-// a wave read 64 different banks -- takes them into registers, zeroes them, and counts its bits; one block-wide prefix sum
-// gives every thread the position of its first id; the ids go into the (now free) bitmap area in ascending order and from
-// there to the cell's segment of `candidates` with coalesced stores.  The cell itself stays in the list (the reference takes
-// the union first and drops the cell afterwards, :417-439: the filter does).
-// Replaces gatherKernel + rocPRIM's segmented radix sort (14 + 77 ms of the 390 at 1M cells x 2048 bits, q = 20).
+// kUnionWords * 32 ids (two passes at a million cells), so any cell count works.
+//   * descriptors: thread s < sliceCount holds (begin, size) of the cell's bucket in slice s -- loaded one cell ahead, so the
+//     two dependent loads behind them are not waited for -- and a prefix sum of the sizes numbers the bucket members 0 .. M-1;
+//   * members: thread t takes members t, t + 1024, ... (binary search of the prefix sums for the bucket), the first
+//     kUnionHeld of them with all loads in flight at once and kept in registers for both passes;
+//   * per pass every member inside the pass's id range sets its bit (ds_or_b32); thread t then owns the words
+//     [17 t, 17 t + 17) -- an odd stride, so the 64 lanes of a wave read 64 different banks -- takes them into registers,
+//     zeroes them and counts its bits; one block-wide prefix sum gives every thread the position of its first id; the ids go
+//     into the (now free) bitmap area in ascending order and from there to the cell's segment of `candidates` with
+//     coalesced stores.
+// The cell itself stays in the list (the reference takes the union first and drops the cell afterwards, :417-439: the filter
+// does).  Replaces gatherKernel + rocPRIM's segmented radix sort (14 + 77 ms of the 390 at 1M cells x 2048 bits, q = 20);
+// more than kUnionSlices slices keep that form.
 constexpr uint32_t kUnionThreads = 1024;
 constexpr uint32_t kUnionWordsPerThread = 17;
 constexpr uint32_t kUnionWords = kUnionThreads * kUnionWordsPerThread;      // 17408 words = 557,056 ids per pass, 68 KB
-constexpr uint32_t kUnionSliceChunk = 256;
-constexpr size_t kUnionLdsBytes = size_t(kUnionWords) * 4u + 2u * kUnionSliceChunk * 4u + 32u * 4u;
+constexpr uint32_t kUnionSlices = 256;
+constexpr uint32_t kUnionHeld = 6;
+constexpr uint32_t kUnionStaged = 2304;         // ids of a pass staged for coalesced stores (a pass of a million-cell problem has about 2000)
+constexpr size_t kUnionLdsBytes = size_t(kUnionWords) * 4u + (2u * kUnionSlices + 1u) * 4u + 32u * 4u + kUnionStaged * 4u;
 
-__global__ void __launch_bounds__(kUnionThreads)
+__global__ void __launch_bounds__(kUnionThreads, 8)          // two blocks per CU: at most 64 vector registers
 unionKernel(const uint32_t* __restrict__ runOfCellSlice, const uint32_t* __restrict__ runStart,
             const uint32_t* __restrict__ sortedCells, uint32_t cellCount, uint32_t sliceCount, uint64_t bucketOverflow,
             uint32_t batchBegin, uint32_t batchCells, const uint32_t* __restrict__ segmentBegin,
@@ -177,53 +185,89 @@ unionKernel(const uint32_t* __restrict__ runOfCellSlice, const uint32_t* __restr
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t unionLds[];
     uint32_t* bitmap = unionLds;                                    // kUnionWords, all zero between two uses
-    uint32_t* bucketBegin = unionLds + kUnionWords;                 // kUnionSliceChunk
-    uint32_t* bucketSize = bucketBegin + kUnionSliceChunk;          // kUnionSliceChunk
-    uint32_t* waveTotals = bucketSize + kUnionSliceChunk;           // 16 (+ the block total)
+    uint32_t* bucketBegin = unionLds + kUnionWords;                 // kUnionSlices
+    uint32_t* memberPrefix = bucketBegin + kUnionSlices;            // kUnionSlices + 1: members in the buckets before slice s
+    uint32_t* waveTotals = memberPrefix + kUnionSlices + 1u;        // 16 (of 32)
+    uint32_t* staging = waveTotals + 32u;                           // kUnionStaged
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     for (uint32_t w = t; w < kUnionWords; w += kUnionThreads) bitmap[w] = 0u;
-    __syncthreads();
     const uint32_t passes = (cellCount + kUnionWords * 32u - 1u) / (kUnionWords * 32u);
+    // the descriptor this thread holds for the cell about to be processed
+    uint32_t nextBegin = 0, nextSize = 0;
+    auto loadDescriptor = [&](uint32_t local) {
+        nextBegin = nextSize = 0u;
+        if (local < batchCells && t < sliceCount) {
+            const uint32_t run = runOfCellSlice[size_t(batchBegin + local) * sliceCount + t];
+            nextBegin = runStart[run];
+            nextSize = runStart[run + 1u] - nextBegin;
+            if (bucketOverflow != 0 && uint64_t(nextSize) > bucketOverflow) nextSize = 0u;             // ExpressionMatrixLsh.cpp:419
+        }
+    };
+    loadDescriptor(blockIdx.x);
+    __syncthreads();
     for (uint32_t local = blockIdx.x; local < batchCells; local += gridDim.x) {
-        const uint32_t c = batchBegin + local;
         uint32_t* out = candidates + segmentBegin[local];
+        // ---- the buckets' begins and the prefix sums of their sizes (threads 0 .. 255 = waves 0 .. 3) ----
+        uint32_t inclusiveSize = nextSize;
+        if (t < kUnionSlices) {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t below = uint32_t(__shfl_up(int(inclusiveSize), d, 64));
+                if (lane >= uint32_t(d)) inclusiveSize += below;
+            }
+            if (lane == 63u) waveTotals[wave] = inclusiveSize;
+            bucketBegin[t] = nextBegin;
+        }
+        __syncthreads();
+        if (t < kUnionSlices) {
+            uint32_t before = 0;
+            for (uint32_t w = 0; w < wave; ++w) before += waveTotals[w];
+            memberPrefix[t + 1u] = before + inclusiveSize;
+            if (t == 0u) memberPrefix[0] = 0u;
+        }
+        __syncthreads();
+        loadDescriptor(local + gridDim.x);              // (in flight until the next cell)
+        const uint32_t members = memberPrefix[sliceCount];
+        // ---- member f -> its id: bucket by binary search of the prefix sums ----
+        auto memberAddress = [&](uint32_t f) {
+            // (eight fixed steps, no branches: the searches of a thread's members are straight-line code whose LDS reads overlap)
+            uint32_t lo = 0;                            // the last slice with memberPrefix[slice] <= f
+#pragma unroll
+            for (int step = 7; step >= 0; --step) {
+                const uint32_t mid = lo + (1u << step);
+                const uint32_t bound = memberPrefix[mid < sliceCount ? mid : sliceCount];
+                lo = (mid < sliceCount && bound <= f) ? mid : lo;
+            }
+            return bucketBegin[lo] + (f - memberPrefix[lo]);
+        };
+        uint32_t held[kUnionHeld];
+#pragma unroll
+        for (uint32_t r = 0; r < kUnionHeld; ++r) {
+            const uint32_t f = t + r * kUnionThreads;
+            held[r] = f < members ? sortedCells[memberAddress(f)] : 0xffffffffu;
+        }
         uint32_t written = 0;
         for (uint32_t pass = 0; pass < passes; ++pass) {
             const uint32_t lo = pass * kUnionWords * 32u;
-            // ---- the members of the cell's buckets that fall into [lo, lo + kUnionWords * 32) set their bits ----
-            for (uint32_t base = 0; base < sliceCount; base += kUnionSliceChunk) {
-                if (t < kUnionSliceChunk) {
-                    uint32_t begin = 0, size = 0;
-                    if (base + t < sliceCount) {
-                        const uint32_t run = runOfCellSlice[size_t(c) * sliceCount + base + t];
-                        begin = runStart[run];
-                        size = runStart[run + 1u] - begin;
-                        if (bucketOverflow != 0 && uint64_t(size) > bucketOverflow) size = 0u;         // ExpressionMatrixLsh.cpp:419
-                    }
-                    bucketBegin[t] = begin;
-                    bucketSize[t] = size;
-                }
-                __syncthreads();
-                const uint32_t buckets = sliceCount - base < kUnionSliceChunk ? sliceCount - base : kUnionSliceChunk;
-                for (uint32_t b = wave; b < buckets; b += kUnionThreads / 64u) {
-                    const uint32_t begin = bucketBegin[b], size = bucketSize[b];
-                    for (uint32_t i = lane; i < size; i += 64u) {
-                        const uint32_t id = sortedCells[begin + i] - lo;           // (ids below lo wrap to huge values)
-                        if (id < kUnionWords * 32u) atomicOr(&bitmap[id >> 5], 1u << (id & 31u));
-                    }
-                }
-                __syncthreads();
+            // ---- the members inside [lo, lo + kUnionWords * 32) set their bits ----
+#pragma unroll
+            for (uint32_t r = 0; r < kUnionHeld; ++r) {
+                const uint32_t id = held[r] - lo;                   // (ids below lo, and the "no member" value, wrap out of range)
+                if (held[r] != 0xffffffffu && id < kUnionWords * 32u) atomicOr(&bitmap[id >> 5], 1u << (id & 31u));
             }
-            // ---- every thread takes its 17 words, leaves zeroes, counts ----
-            uint32_t words[kUnionWordsPerThread];
-            uint32_t count = 0;
+            for (uint32_t f = t + kUnionHeld * kUnionThreads; f < members; f += kUnionThreads) {        // (long lists: reloaded per pass)
+                const uint32_t id = sortedCells[memberAddress(f)] - lo;
+                if (id < kUnionWords * 32u) atomicOr(&bitmap[id >> 5], 1u << (id & 31u));
+            }
+            __syncthreads();
+            // ---- every thread counts the bits of its 17 words and notes which of them hold any (about two do) ----
+            uint32_t count = 0, occupied = 0;
 #pragma unroll
             for (uint32_t j = 0; j < kUnionWordsPerThread; ++j) {
-                words[j] = bitmap[t * kUnionWordsPerThread + j];
-                count += uint32_t(__builtin_popcount(words[j]));
+                const uint32_t word = bitmap[t * kUnionWordsPerThread + j];
+                count += uint32_t(__builtin_popcount(word));
+                occupied |= (word != 0u ? 1u : 0u) << j;
             }
-#pragma unroll
-            for (uint32_t j = 0; j < kUnionWordsPerThread; ++j) bitmap[t * kUnionWordsPerThread + j] = 0u;
             // block-wide exclusive prefix sum of the counts
             uint32_t inclusive = count;
 #pragma unroll
@@ -232,7 +276,7 @@ unionKernel(const uint32_t* __restrict__ runOfCellSlice, const uint32_t* __restr
                 if (lane >= uint32_t(d)) inclusive += below;
             }
             if (lane == 63u) waveTotals[wave] = inclusive;
-            __syncthreads();                    // (also: every thread has read and zeroed its words)
+            __syncthreads();
             uint32_t before = 0, total = 0;
             for (uint32_t w = 0; w < kUnionThreads / 64u; ++w) {
                 const uint32_t x = waveTotals[w];
@@ -240,25 +284,40 @@ unionKernel(const uint32_t* __restrict__ runOfCellSlice, const uint32_t* __restr
                 total += x;
             }
             uint32_t position = before + inclusive - count;
-            // ---- ids in ascending order: through the bitmap area when they fit (coalesced stores), else straight from the registers ----
-            const bool staged = total <= kUnionWords;
-            uint32_t* target = staged ? bitmap : out + written;
-#pragma unroll
-            for (uint32_t j = 0; j < kUnionWordsPerThread; ++j) {
-                uint32_t bits = words[j];
-                const uint32_t first = lo + (t * kUnionWordsPerThread + j) * 32u;
-                while (bits) {
-                    const uint32_t bit = uint32_t(__builtin_ctz(bits));
-                    bits &= bits - 1u;
-                    target[position++] = first + bit;
+            // ---- ids in ascending order, the words left zero: through the staging area when they fit (coalesced stores), else
+            // straight to the cell's segment ----
+            const bool staged = total <= kUnionStaged;
+            // (two loops, not one pointer chosen at run time: an LDS-or-global pointer becomes a flat access)
+            if (staged) {
+                while (occupied) {
+                    const uint32_t j = uint32_t(__builtin_ctz(occupied));
+                    occupied &= occupied - 1u;
+                    uint32_t bits = bitmap[t * kUnionWordsPerThread + j];
+                    bitmap[t * kUnionWordsPerThread + j] = 0u;
+                    const uint32_t first = lo + (t * kUnionWordsPerThread + j) * 32u;
+                    while (bits) {
+                        const uint32_t bit = uint32_t(__builtin_ctz(bits));
+                        bits &= bits - 1u;
+                        staging[position++] = first + bit;
+                    }
+                }
+            } else {
+                while (occupied) {
+                    const uint32_t j = uint32_t(__builtin_ctz(occupied));
+                    occupied &= occupied - 1u;
+                    uint32_t bits = bitmap[t * kUnionWordsPerThread + j];
+                    bitmap[t * kUnionWordsPerThread + j] = 0u;
+                    const uint32_t first = lo + (t * kUnionWordsPerThread + j) * 32u;
+                    while (bits) {
+                        const uint32_t bit = uint32_t(__builtin_ctz(bits));
+                        bits &= bits - 1u;
+                        out[written + position++] = first + bit;
+                    }
                 }
             }
             __syncthreads();
             if (staged) {
-                for (uint32_t i = t; i < total; i += kUnionThreads) {
-                    out[written + i] = bitmap[i];
-                    bitmap[i] = 0u;
-                }
+                for (uint32_t i = t; i < total; i += kUnionThreads) out[written + i] = staging[i];
             }
             written += total;
             __syncthreads();
@@ -383,6 +442,99 @@ filterCooperativeKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32
         }
         waveFence();
         const bool keep = need && int32_t(m) <= mGlobal;
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) {
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+            Entry e;
+            e.cell = cand;
+            e.key = keyOfMismatch[m];
+            list[n + before] = e;
+        }
+        n += uint32_t(__builtin_popcountll(mask));
+    }
+    if (lane == 0u) listCounts[local] = n;
+}
+
+// The cooperative filter with 16-byte loads and four groups of candidates in flight (default for an even number of words up
+// to 64, i.e. every multiple of 128 bits up to 4096): a group of lpc lanes reads ONE candidate's signature as consecutive
+// 16-byte units -- at 2048 bits one 256-byte request per candidate, where filterCooperativeKernel issues two 128-byte requests
+// of 8-byte lane loads (8-byte accesses reach 0.54-0.70 of the 16-byte rate: MI355X_MICROARCH.md, visibility table) -- and a
+// lane has UNROLL such loads outstanding before the first popcount.  Everything else is filterCooperativeKernel.
+template <int T>            // 16-byte units per lane: 1 (up to 2048 bits with 16 lanes per candidate), 2 (up to 4096 bits)
+__global__ void __launch_bounds__(256)
+filterWideKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batchBegin, uint32_t batchCells,
+                 const uint32_t* __restrict__ segmentBegin, const uint32_t* __restrict__ sortedCandidates,
+                 Entry* __restrict__ lists, int32_t mGlobal, const uint32_t* __restrict__ keyOfMismatch,
+                 uint32_t* __restrict__ listCounts, const uint32_t* __restrict__ distinctCounts)
+{
+    constexpr int UNROLL = 4;
+    __shared__ uint32_t candOfRankAll[4][64];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* candOfRank = candOfRankAll[threadIdx.x >> 6];
+    const uint32_t local = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (local >= batchCells) return;
+    const uint32_t c = batchBegin + local;
+    const uint32_t begin = segmentBegin[local];
+    const uint32_t end = distinctCounts ? begin + distinctCounts[local] : segmentBegin[local + 1u];
+    Entry* list = lists + begin;
+    const uint32_t units = words / 2u;                      // 16-byte units of a signature
+    uint32_t lpc = 1u;
+    while (lpc < 16u && lpc * uint32_t(T) < units) lpc <<= 1;
+    const uint32_t perStep = 64u / lpc;
+    const uint32_t sub = lane % lpc;
+    const uint32_t slot = lane / lpc;
+    const ulonglong2* sig16 = reinterpret_cast<const ulonglong2*>(sig);
+    ulonglong2 mine[T];
+    bool active[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        active[t] = sub + uint32_t(t) * lpc < units;
+        mine[t] = active[t] ? sig16[size_t(c) * units + sub + uint32_t(t) * lpc] : ulonglong2{0ull, 0ull};
+    }
+    uint32_t n = 0;
+    for (uint32_t base = begin; base < end; base += 64u) {
+        const uint32_t i = base + lane;
+        bool need = false;
+        uint32_t cand = 0;
+        if (i < end) {
+            cand = sortedCandidates[i];
+            const bool duplicate = i > begin && sortedCandidates[i - 1u] == cand;
+            need = !duplicate && cand != c;                                  // ExpressionMatrixLsh.cpp:437-439
+        }
+        const uint64_t needMask = __builtin_amdgcn_ballot_w64(need);
+        const uint32_t needCount = uint32_t(__builtin_popcountll(needMask));
+        const uint32_t myRank = __builtin_amdgcn_mbcnt_hi(uint32_t(needMask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(needMask), 0u));
+        if (need) candOfRank[myRank] = cand;
+        waveFence();
+        uint32_t m = 0;
+        for (uint32_t first = 0; first < needCount; first += perStep * uint32_t(UNROLL)) {
+            ulonglong2 theirs[UNROLL][T];
+            bool have[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const uint32_t rank = first + uint32_t(u) * perStep + slot;
+                have[u] = rank < needCount;
+                const size_t row = have[u] ? size_t(candOfRank[rank]) * units : 0;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    theirs[u][t] = (have[u] && active[t]) ? sig16[row + sub + uint32_t(t) * lpc] : mine[t];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                uint32_t part = 0;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    part += uint32_t(__builtin_popcountll(mine[t].x ^ theirs[u][t].x)) + uint32_t(__builtin_popcountll(mine[t].y ^ theirs[u][t].y));
+                }
+                for (uint32_t d = 1; d < lpc; d <<= 1) part += uint32_t(__shfl_xor(int(part), int(d), 64));
+                const uint32_t offset = myRank - first - uint32_t(u) * perStep;          // (wraps for ranks below this group)
+                const uint32_t got = uint32_t(__shfl(int(part), int((offset % perStep) * lpc), 64));
+                if (need && offset < perStep) m = got;
+            }
+        }
+        waveFence();
+        const bool keep = need && int32_t(m) <= mGlobal;                     // similarity > similarityThreshold (:441)
         const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
         if (keep) {
             const uint32_t before = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
@@ -743,7 +895,7 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
     Buffer segBegin, candA, candB, lists, sortTemp, listCounts, distinctCounts;
     // EM2_FSP5_UNION=sort keeps gatherKernel + the segmented sort (A/B measurements)
     const char* unionMode = getenv("EM2_FSP5_UNION");
-    const bool useUnion = !(unionMode && unionMode[0] == 's');
+    const bool useUnion = !(unionMode && unionMode[0] == 's') && sliceCount <= kUnionSlices;
     uint32_t unionBlocks = 1;
     if (useUnion) {
         int device = 0, cuCount = 0, perCu = 0;
@@ -767,6 +919,9 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
     // EM2_FSP5_FILTER=lane selects the one-lane-per-candidate filter (A/B measurements)
     const char* filterMode = getenv("EM2_FSP5_FILTER");
     const bool cooperative = words <= 8u * 16u && !(filterMode && filterMode[0] == 'l');
+    // EM2_FSP5_FILTER=cooperative keeps the 8-byte-load form (A/B measurements)
+    const bool wide = cooperative && words % 2u == 0u && words <= 64u && reinterpret_cast<uintptr_t>(d_sig) % 16u == 0u &&
+                      !(filterMode && filterMode[0] == 'c');
     for (const Batch& batch : batches) {
         const uint32_t batchBegin = batch.begin;
         const uint32_t batchCells = batch.end - batch.begin;
@@ -801,7 +956,19 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
             sorted = candB.as<uint32_t>();
         }
         if (timing[0]) (void)hipEventRecord(timing[0], stream);
-        if (cooperative) {
+        if (wide) {
+            // (signature rows are 16-byte aligned: an even number of words, and the array itself as hipMalloc / the caller's
+            // uint64 array provides it -- checked below)
+            if (words <= 32u) {
+                filterWideKernel<1><<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
+                                                                              lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,
+                                                                              listCounts.as<uint32_t>(), distinct);
+            } else {
+                filterWideKernel<2><<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
+                                                                              lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,
+                                                                              listCounts.as<uint32_t>(), distinct);
+            }
+        } else if (cooperative) {
             filterCooperativeKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(),
                                                                                 sorted, lists.as<Entry>(), tables.mGlobal,
                                                                                 tables.keyOfMismatch, listCounts.as<uint32_t>(), distinct);
