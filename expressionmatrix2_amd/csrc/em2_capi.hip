@@ -61,6 +61,8 @@ struct CachedTables {
 std::mutex cacheMutex;
 std::vector<CachedTables> tableCache;
 constexpr size_t kTableCacheEntries = 16;
+std::vector<void*> retiredBlocks;               // evicted from the cache, freed kRetiredBlocks evictions later (see getDeviceTables)
+constexpr size_t kRetiredBlocks = 64;
 
 int getDeviceTables(uint32_t lshCount, double similarityThreshold, em2::DeviceTables& out)
 {
@@ -107,17 +109,25 @@ int getDeviceTables(uint32_t lshCount, double similarityThreshold, em2::DeviceTa
     c.tables.mGlobal = host.mGlobal;
     c.tables.mMaxInitial = host.mMaxInitial;
     c.tables.identityKeys = host.keySimilarity.size() == host.keyOfMismatch.size();
-    // At most kTableCacheEntries sets of tables per device stay allocated (a caller that sweeps thresholds would otherwise
-    // grow the cache without bound): the least recently used one goes.  Its kernels have long been enqueued -- hipFree
-    // waits for the device -- and tables are copied by value into every launch's arguments.
+    // At most kTableCacheEntries sets of tables per device stay in the cache (a caller that sweeps thresholds would otherwise
+    // grow it without bound): the least recently used one leaves it.  Its block is NOT freed at that moment: a caller on
+    // another thread may have fetched these pointers a moment ago and not yet enqueued its kernel (DeviceTables holds device
+    // pointers, not the arrays), and hipFree would also synchronise the device inside calls documented as asynchronous.
+    // Evicted blocks wait in a retired list; only when kRetiredBlocks more evictions have followed is the oldest one freed
+    // (a few KB each: the wait costs nothing, and by then every launch that could hold the pointers has long been enqueued
+    // -- hipFree itself waits for the device before it releases memory that enqueued kernels still read).
     size_t onThisDevice = 0;
     for (const CachedTables& other : tableCache) onThisDevice += other.device == device ? 1u : 0u;
     if (onThisDevice >= kTableCacheEntries) {
         for (size_t i = 0; i < tableCache.size(); i++) {
             if (tableCache[i].device != device) continue;
-            (void)hipFree(const_cast<uint32_t*>(tableCache[i].tables.keyOfMismatch));       // the block's base pointer
+            retiredBlocks.push_back(const_cast<uint32_t*>(tableCache[i].tables.keyOfMismatch));       // the block's base pointer
             tableCache.erase(tableCache.begin() + long(i));
             break;
+        }
+        if (retiredBlocks.size() > kRetiredBlocks) {
+            (void)hipFree(retiredBlocks.front());
+            retiredBlocks.erase(retiredBlocks.begin());
         }
     }
     tableCache.push_back(c);

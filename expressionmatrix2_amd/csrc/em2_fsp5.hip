@@ -994,7 +994,8 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
                                                                     outUsed, UP_TO);                                             \
         EM2_TRY(hipGetLastError())
         uint32_t globalAbove = kSelectLdsEntriesBig;
-        const bool packed = mode != 'l' && mode != 'g' && mode != 'u' && k <= kSelectPackedMaxK;
+        // (the packed tiers keep a key in 16 bits: lshCount + 1 key classes must fit)
+        const bool packed = mode != 'l' && mode != 'g' && mode != 'u' && k <= kSelectPackedMaxK && lshCount < 65535u;
         if (packed) {
 #define EM2_SELECT_PACKED(CAPACITY, ABOVE)                                                                                        \
             selectPackedKernel<CAPACITY, ABOVE><<<batchCells, 64, 0, stream>>>(batchCells, segBegin.as<uint32_t>(), lists.as<Entry>(), \

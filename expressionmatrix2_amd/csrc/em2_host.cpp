@@ -543,12 +543,21 @@ void SimilarPairsWriter::finish(const uint32_t* usedCount)
         ci[c].lowestSimilarityIndex = 0xffffffffu;           // constructor values, never updated by copy (:36-40)
         ci[c].lowestSimilarity = FLT_MAX;
     }
-    // Info last: a reader opens it first (SimilarPairs.cpp:49-52)
+    // The three files replace an existing object in this order: the old -Info is removed first (a reader opens -Info
+    // first, SimilarPairs.cpp:49-52: while the swap is in progress it finds no object instead of a -Pairs file under an -Info
+    // that describes another k), then -Pairs and -CellInfo move into place, -Info last.  A rename that fails leaves the
+    // object absent rather than mixed: what has been moved already is removed again.  What remains is the window between
+    // the unlink and the last rename, during which the name does not exist; a failure BEFORE this point (the computation)
+    // still leaves an existing object untouched.
+    (void)::unlink((base_ + "-Info").c_str());
+    std::vector<std::string> moved;
     for (const char* part : {"-Pairs", "-CellInfo", "-Info"}) {
         const std::string final = base_ + part;
         if (::rename((final + kTemporarySuffix).c_str(), final.c_str()) != 0) {
+            for (const std::string& name : moved) (void)::unlink(name.c_str());
             fail(EM2_ERROR_RUNTIME, "Error renaming " + final + kTemporarySuffix + " to " + final);
         }
+        moved.push_back(final);
     }
     finished_ = true;
 }
