@@ -244,7 +244,7 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
                                 const double* __restrict__ vectorSums, const double* __restrict__ vectorMaxAbs,
                                 const double* __restrict__ means, const double* __restrict__ sumAbs, uint32_t lshCount,
                                 uint32_t wordCount, uint64_t* __restrict__ signatures, uint64_t* __restrict__ workList,
-                                uint32_t* __restrict__ workCount)
+                                uint32_t* __restrict__ workCount, uint64_t* __restrict__ bitList, uint32_t* __restrict__ bitCount)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -370,7 +370,7 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
         const double absMean = fabs(mean);
         const double absX = sumAbs[c];
         uint32_t byte = 0;
-        bool ambiguous = false;
+        uint32_t ambiguousBits = 0;             // bit t: the lane's t-th bit is undecided
         uint32_t firstConstant = sub * 8u;
         asm volatile("" : "+v"(firstConstant));          // (not loop-invariant as far as the compiler knows)
         const double* constantsOfLane = allConstants + firstConstant;
@@ -383,7 +383,7 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
             const double bound = factor * (absMean * fabs(sT) + absX * mxT) + 0.501 * scaleT * absX + 9.6e-7 * absX * mxT +
                                  n * 1.5e-45 * scaleT + 1e-300;
             // (a single-precision chunk that overflowed makes the total infinite: undecided as well)
-            ambiguous |= !(fabs(total) > bound) || !(fabs(total) <= 1.7976931348623157e308);
+            ambiguousBits |= (!(fabs(total) > bound) || !(fabs(total) <= 1.7976931348623157e308)) ? (1u << t) : 0u;
             byte |= (total > 0.) ? (0x80u >> t) : 0u;                  // first bit most significant
         }
         // 8 lanes x 8 bits -> one MSB-first 64-bit word
@@ -394,12 +394,21 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
             const uint32_t hi = uint32_t(__shfl_xor(int(uint32_t(w >> 32)), d, 8));
             w |= uint64_t(lo) | (uint64_t(hi) << 32);
         }
-        const uint64_t ambMask = __builtin_amdgcn_ballot_w64(ambiguous);
+        // A word with undecided bits goes to a later tier.  Almost always it is ONE bit (a cell has 1.1 undecided bits in 1.07
+        // words on the benchmark data): such a word is listed by that bit, for the per-bit form of the float tier (one float
+        // per count instead of the 64 of the whole word); anything else is listed as a word.
+        const uint32_t ambLanes = uint32_t(__builtin_amdgcn_ballot_w64(ambiguousBits != 0u)) & 0xffu;
+        const uint32_t firstAmbLane = ambLanes ? uint32_t(__builtin_ctz(ambLanes)) : 0u;
+        const uint32_t bitsOfThatLane = uint32_t(__builtin_amdgcn_readlane(int(ambiguousBits), int(firstAmbLane)));
         if (lane == 0u) {
             signatures[size_t(c) * wordCount + word] = w;
-            if ((ambMask & 0xffull) != 0ull && DIAG == 0) {
-                const uint32_t slot = atomicAdd(workCount, 1u);
-                workList[slot] = (uint64_t(c) << 32) | word;
+            if (ambLanes != 0u && DIAG == 0) {
+                if ((ambLanes & (ambLanes - 1u)) == 0u && (bitsOfThatLane & (bitsOfThatLane - 1u)) == 0u && bitList) {
+                    const uint32_t bit = word * 64u + firstAmbLane * 8u + uint32_t(__builtin_ctz(bitsOfThatLane));
+                    bitList[atomicAdd(bitCount, 1u)] = (uint64_t(c) << 32) | bit;
+                } else {
+                    workList[atomicAdd(workCount, 1u)] = (uint64_t(c) << 32) | word;
+                }
             }
         }
     }
@@ -672,6 +681,61 @@ projectionScreenItemsKernel(const uint64_t* __restrict__ toc, const CountIn* __r
     }
 }
 
+// The same tier for the words in which ONE bit is undecided, listed by that bit: lane = item, each lane walks its own cell
+// with eight gathers of a single float in flight -- 4 bytes per count where the word form above reads two 128-byte lines.
+// Same arithmetic, same bound; a bit that stays undecided sends its word to the exact tier's list, any other goes into the
+// signature (nobody else writes that word: a word is on exactly one of the two lists).
+__global__ void __launch_bounds__(256)
+projectionScreenBitsKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t geneCount,
+                           const float* __restrict__ vectors32, const double* __restrict__ vectorSums,
+                           const double* __restrict__ vectorMaxAbs, const double* __restrict__ means,
+                           const double* __restrict__ sumAbs, uint32_t wordCount, uint64_t* __restrict__ signatures,
+                           const uint64_t* __restrict__ bitList, const uint32_t* __restrict__ bitCount,
+                           uint64_t* __restrict__ nextList, uint32_t* __restrict__ nextCount)
+{
+    const uint32_t count = *bitCount;
+    const uint64_t* entries = reinterpret_cast<const uint64_t*>(data);
+    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
+        const uint64_t it = bitList[item];
+        const uint32_t c = uint32_t(it >> 32);
+        const uint32_t bit = uint32_t(it);
+        const float* column = vectors32 + size_t(bit >> 5) * geneCount * 32u + (bit & 31u);
+        const double s = vectorSums[bit];
+        const uint64_t jBegin = toc[c];
+        const uint64_t jEnd = toc[c + 1];
+        const double mean = means[c];
+        double a = __dmul_rn(-mean, s);
+        uint64_t j = jBegin;
+        for (; j + 8u <= jEnd; j += 8u) {            // eight loads in flight, the additions in stored order
+            double u[8], x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint64_t e = entries[j + q];
+                u[q] = double(column[size_t(uint32_t(e)) * 32u]);
+                x[q] = double(__uint_as_float(uint32_t(e >> 32)));
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a = __fma_rn(x[q], u[q], a);
+        }
+        for (; j < jEnd; ++j) {
+            const uint64_t e = entries[j];
+            a = __fma_rn(double(__uint_as_float(uint32_t(e >> 32))), double(column[size_t(uint32_t(e)) * 32u]), a);
+        }
+        const double n = double(jEnd - jBegin);
+        const double factor = (1.01 * 5.9604644775390625e-08 + (n + 2.) * 2.220446049250313e-16) * 1.000001;
+        const double absX = sumAbs[c];
+        const double bound = factor * (fabs(mean) * fabs(s) + absX * vectorMaxAbs[bit]) + absX * 1.5e-45 + 1e-300;
+        const uint32_t word = bit >> 6;
+        if (!(fabs(a) > bound)) {
+            nextList[atomicAdd(nextCount, 1u)] = (uint64_t(c) << 32) | word;
+        } else {
+            const uint64_t mask = 1ull << (63u - (bit & 63u));          // first bit most significant (src/BitSet.hpp:48-62)
+            uint64_t* target = signatures + size_t(c) * wordCount + word;
+            *target = a > 0. ? (*target | mask) : (*target & ~mask);
+        }
+    }
+}
+
 // Exact recomputation of the listed (cell, word) items: the arithmetic of projectionKernel, one wave per item.
 __global__ void __launch_bounds__(256)
 projectionExactItemsKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data,
@@ -818,8 +882,13 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
 #else
         auto kernel = &projectionScreenQuantizedKernel<0>;
 #endif
+        // (the work area holds 4 slots per word: [0, CW) the words for the float tier, [CW, 2 CW) the single bits for its per-bit
+        // form, [2 CW, 4 CW) what the two leave to the exact tier; EM2_PROJECTION_BITS=0 lists everything by words: A/B runs)
+        const char* bitsMode = getenv("EM2_PROJECTION_BITS");
+        const bool perBit = !(bitsMode && bitsMode[0] == '0');
         kernel<<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, quantized, scales, sums, maxAbs, means,
-                                                                        sumAbs, lshCount, wordCount, signatures, workList, workCount);
+                                                                        sumAbs, lshCount, wordCount, signatures, workList, workCount,
+                                                                        perBit ? workList + size_t(cellCount) * wordCount : nullptr, workCount + 32);
     } else if (sliced) {
         e = hipMemsetAsync(signatures, 0, size_t(cellCount) * wordCount * sizeof(uint64_t), stream);    // halves nobody owns
         if (e != hipSuccess) return e;
@@ -844,10 +913,15 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
     if (quantizedTier) {
         // second tier on the float copy for what the 16-bit tier left; its own leftovers form a second list (the work
         // area holds 4 slots per word: the second list starts at slot cellCount * wordCount)
-        uint64_t* nextList = workList + size_t(cellCount) * wordCount;
+        uint64_t* nextList = workList + 2u * size_t(cellCount) * wordCount;
         uint32_t* nextCount = workCount + 16;
         projectionScreenItemsKernel<<<dim3(2048), dim3(256), 0, stream>>>(toc, data, geneCount, vectors32, sums, maxAbs, means, sumAbs, lshCount,
                                                                           wordCount, signatures, workList, workCount, nextList, nextCount);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        projectionScreenBitsKernel<<<dim3(2048), dim3(256), 0, stream>>>(toc, data, geneCount, vectors32, sums, maxAbs, means, sumAbs, wordCount,
+                                                                         signatures, workList + size_t(cellCount) * wordCount, workCount + 32,
+                                                                         nextList, nextCount);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         workList = nextList;
