@@ -140,6 +140,27 @@ def device_state(device_index):
         return None
 
 
+def profiled_traffic(file_name, config, kernel_prefixes):
+    """Fabric bytes per launch (FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE, as tools/profile_digest.py corrects them) of the
+    kernels whose names start with one of kernel_prefixes, from a committed digest of tools/profile_bench.sh -- when that
+    digest is of THIS configuration (its `config` holds every (key, value) of `config`).  (bytes per launch summed over the
+    kernels, {kernel: launches per pass}) or (None, None).  PMC passes are separate runs: the figure is per launch of the
+    profiled run, not of this one."""
+    path = os.path.join(ROOT, "profiles", file_name)
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        digest = json.load(f)
+    if any(digest.get("config", {}).get(key) != value for key, value in config.items()):
+        return None, None
+    total, launches = 0.0, {}
+    for name, entry in digest.get("kernels", {}).items():
+        if any(name.startswith(prefix) for prefix in kernel_prefixes) and "fabric_fetch_bytes_per_launch" in entry:
+            total += entry["fabric_fetch_bytes_per_launch"] + entry.get("fabric_write_bytes_per_launch", 0.0)
+            launches[name] = entry["launches_per_pass"]
+    return (total, launches) if launches else (None, None)
+
+
 def parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host, check_rows):
     """The result of the pipeline's LAST step against the CPU oracle, bit for bit: the signatures of a few of this
     rank's cells and sampled SimilarPairs rows this rank owns against all columns.  Exits on a difference.
@@ -275,17 +296,12 @@ def bench_fsp5(args, capi, oracle, device, torch, check_ranges=3):
     distinct = info["distinct_candidates"] if info["distinct_candidates"] >= 0 else info["gathered_candidates"]
     algorithmic = distinct * 8.0 * W + 4.0 * C * info["slice_count"]
     achieved = algorithmic / (filter_ms * 1e-3) / 1e9 if filter_ms > 0 else 0.0
-    traffic = None
-    traffic_source = None
-    traffic_file = os.path.join(ROOT, "profiles", "r03_pmc_fsp5_1Mcells_2048bit.json")
-    if os.path.exists(traffic_file):
-        with open(traffic_file) as f:
-            prof = json.load(f)
-        cfg = prof.get("config", {})
-        if (cfg.get("cells"), cfg.get("lsh_count"), cfg.get("k"), cfg.get("slice_length")) == (C, L, k, q):
-            t = prof["per_call_bytes"]["filterKernel"]
-            traffic = t["fetch"] + t["write"]
-            traffic_source = "profiles/r03_pmc_fsp5_1Mcells_2048bit.json (FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE, all batches of one call)"
+    per_launch, launches = profiled_traffic("r03_pmc_bench_fsp5_1Mcells_2048bit.json",
+                                            {"cells": C, "lsh_count": L, "k": k, "slice_length": q, "bucket_overflow": args.bucket_overflow},
+                                            ("filterWideKernel", "filterCooperativeKernel"))
+    traffic = per_launch * info["batches"] if per_launch is not None else None
+    traffic_source = ("profiles/r03_pmc_bench_fsp5_1Mcells_2048bit.json (FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE per launch of the "
+                      "filter, x the batches of one call)") if traffic is not None else None
     return {
         "metric": "cells/sec through findSimilarPairs5 (bucketed LSH, tables + candidate filter + selection)",
         "value": C * args.steps / elapsed, "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -644,9 +660,15 @@ def main():
         matrix_traffic = None
         matrix_traffic_source = None
         pinned_walk = os.environ.get("EM2_MATRIX_WALK", "3") not in ("0",)
+        profile_config = {"cells": C, "genes": G, "lsh_count": L, "k": k, "n_gpus": world}
+        if matrix and pinned_walk and L <= 1024:
+            matrix_traffic, _ = profiled_traffic("r03_pmc_bench_1Mcells_1gpu.json", profile_config, ("fsp4ScanMatrixPinnedKernel",))
+            if matrix_traffic is not None:
+                matrix_traffic_source = ("profiles/r03_pmc_bench_1Mcells_1gpu.json (tools/profile_bench.sh: FETCH_SIZE x 2 for 16-byte "
+                                         "loads + WRITE_SIZE, bytes per launch of the profiled run)")
         for name in (("r02_pmc_matrix_scan_1Mcells.json",) if pinned_walk else ()) + ("r01_pmc_matrix_scan_1Mcells.json",):
             matrix_traffic_file = os.path.join(ROOT, "profiles", name)
-            if not (matrix and os.path.exists(matrix_traffic_file)):
+            if matrix_traffic is not None or not (matrix and os.path.exists(matrix_traffic_file)):
                 continue
             with open(matrix_traffic_file) as f:
                 prof = json.load(f)
@@ -732,9 +754,15 @@ def main():
                 "unit": "GB/s", "frac": proj_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": proj_bytes,
                 "flop_per_launch": 2.0 * nnz_local * L, "tflops": 2.0 * nnz_local * L / (proj_ms * 1e-3) / 1e12,
                 "note": "kernel_ms = HIP events around em2_dev_compute_signatures on the launch stream (16-bit fixed-point screening "
-                        "tier, float tier on the words it left, exact recomputation of the rest); its measured fabric traffic is in "
-                        "profiles/ and DESIGN.md",
+                        "tier, float tier on the words and single bits it left, exact recomputation of the rest); traffic = fabric bytes "
+                        "of all its kernels per launch from the committed PMC digest of this configuration: the tiers gather one "
+                        "hyperplane line per (count, 64-bit word) from a copy that fills the L2s, so they move far more than the "
+                        "algorithmic bytes (wasted_traffic_ratio)",
             }
+            projection_traffic, _ = profiled_traffic("r03_pmc_bench_1Mcells_1gpu.json", {"cells": C, "genes": G, "lsh_count": L, "k": k, "n_gpus": world},
+                                                     ("projectionScreen", "projectionExact", "cellStatsKernel"))
+            result["roofline_projection"]["traffic"] = projection_traffic
+            result["roofline_projection"]["wasted_traffic_ratio"] = projection_traffic / proj_bytes if projection_traffic else None
         result["device_state_rank0"] = leg["device_state"]
         if collective_check is not None:
             result["collective_check"] = collective_check
