@@ -92,9 +92,33 @@ struct ClusterArgs {
     uint32_t ticketBatch;       // 0: wave w of W takes positions w, w+W, ..; else positions drawn from the ticket, this many at a time
     Candidate* scratchA;
     Candidate* scratchB;
+#ifdef EM2_DIAG
+    unsigned long long* diag;   // kDiagWords sums over the waves of one launch (EM2_TIMING=1 prints them)
+#endif
     uint64_t* sortKeys;         // 4 x adjacency slots: (event time << 32 | list index) of either list, padded to a power of two
     uint64_t slots;
 };
+
+// Diagnostic build: where a wave's cycles go.  Slots: 0 draw + header loads, 1 gather (degree <= 64), 2 phase A events,
+// 3 phase B events, 4 waits for a neighbour's turn, 5 hub gather, 6 hub sort, 7 hub events, 8 the turn's stores, 9 whole wave;
+// counts: 10 events A, 11 events B, 12 waits, 13 hub turns, 14 findBest rescans, 15 table relocations.
+constexpr uint32_t kDiagWords = 16;
+#ifdef EM2_DIAG
+#define LP_CLOCK(slot)                                          \
+    do {                                                        \
+        const uint64_t lpNow = __builtin_amdgcn_s_memtime();    \
+        diagAcc[slot] += lpNow - diagLast;                      \
+        diagLast = lpNow;                                       \
+    } while (0)
+#define LP_COUNT(slot) (++diagAcc[slot])
+#define LP_DIAG_PARAM , uint64_t* diagAcc, uint64_t& diagLast
+#define LP_DIAG_PASS , diagAcc, diagLast
+#else
+#define LP_CLOCK(slot) ((void)0)
+#define LP_COUNT(slot) ((void)0)
+#define LP_DIAG_PARAM
+#define LP_DIAG_PASS
+#endif
 
 __device__ __forceinline__ uint32_t uniform(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
 __device__ __forceinline__ float uniform(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
@@ -107,7 +131,7 @@ __device__ __forceinline__ uint32_t waveMin(uint32_t x)
 }
 
 // ClusterTable::findBestCluster (CellGraph.hpp:104-114): the first entry holding the largest weight, if above -1.
-__device__ void findBest(TableMeta& t, const TableEntry* arena, uint32_t lane)
+__device__ __forceinline__ void findBest(TableMeta& t, const TableEntry* arena, uint32_t lane)
 {
     float bestWeight = -1.f;
     uint32_t bestIndex = kNone;
@@ -140,7 +164,7 @@ __device__ void findBest(TableMeta& t, const TableEntry* arena, uint32_t lane)
 }
 
 // ClusterTable::addWeight (CellGraph.hpp:70-99).  Returns false when the arena is exhausted.
-__device__ bool addWeight(TableMeta& t, const ClusterArgs& args, uint32_t cluster, float weight, uint32_t lane)
+__device__ __forceinline__ bool addWeight(TableMeta& t, const ClusterArgs& args, uint32_t cluster, float weight, uint32_t lane LP_DIAG_PARAM)
 {
     TableEntry* arena = args.arena;
     for (uint32_t base = 0; base < t.size; base += 64u) {
@@ -163,7 +187,10 @@ __device__ bool addWeight(TableMeta& t, const ClusterArgs& args, uint32_t cluste
         }
         const float updated = __shfl(w, owner);
         if (cluster == t.best) {
-            if (weight < 0.f) findBest(t, arena, lane);
+            if (weight < 0.f) {
+                LP_COUNT(14);
+                findBest(t, arena, lane);
+            }
             else t.bestWeight = updated;
         } else if (updated > t.bestWeight) {
             t.best = cluster;
@@ -177,6 +204,7 @@ __device__ bool addWeight(TableMeta& t, const ClusterArgs& args, uint32_t cluste
         if (lane == 0u) at = atomicAdd(args.arenaTop, (unsigned long long)capacity);
         at = uniform(uint64_t(at));
         if (at + capacity > args.arenaCapacity) return false;
+        LP_COUNT(15);
         for (uint32_t i = lane; i < t.size; i += 64u) arena[at + i] = arena[t.begin + i];
         t.begin = at;
         t.capacity = capacity;
@@ -192,18 +220,22 @@ __device__ bool addWeight(TableMeta& t, const ClusterArgs& args, uint32_t cluste
 
 // One label change of a neighbour as the table of the current vertex sees it (CellGraph.cpp:529-530).
 __device__ __forceinline__ bool applyEvent(TableMeta& t, const ClusterArgs& args, uint32_t oldLabel, uint32_t newLabel,
-                                           float weight, uint32_t lane)
+                                           float weight, uint32_t lane LP_DIAG_PARAM)
 {
-    return addWeight(t, args, newLabel, weight, lane) && addWeight(t, args, oldLabel, -weight, lane);
+    return addWeight(t, args, newLabel, weight, lane LP_DIAG_PASS) && addWeight(t, args, oldLabel, -weight, lane LP_DIAG_PASS);
 }
 
 // Waits until the vertex has had its turn in this iteration; returns its label, or sets failed.
-__device__ uint32_t labelAfterTurn(const ClusterArgs& args, uint32_t vertex, bool& failed)
+__device__ __forceinline__ uint32_t labelAfterTurn(const ClusterArgs& args, uint32_t vertex, bool& failed LP_DIAG_PARAM)
 {
     const uint64_t* word = args.state + vertex;
     const uint32_t want = args.iteration + 1u;
     uint64_t s = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (uint32_t(s >> 32) != want) {
+#ifdef EM2_DIAG
+        const uint64_t lpEntered = __builtin_amdgcn_s_memtime();
+        LP_COUNT(12);
+#endif
         const uint64_t start = __builtin_amdgcn_s_memrealtime();             // 100 MHz
         for (;;) {
             __builtin_amdgcn_s_sleep(2);
@@ -215,6 +247,11 @@ __device__ uint32_t labelAfterTurn(const ClusterArgs& args, uint32_t vertex, boo
                 break;
             }
         }
+#ifdef EM2_DIAG
+        const uint64_t lpLeft = __builtin_amdgcn_s_memtime();      // the wait leaves the surrounding phase's account
+        diagAcc[4] += lpLeft - lpEntered;
+        diagLast += lpLeft - lpEntered;
+#endif
     }
     return uniform(uint32_t(s));
 }
@@ -247,6 +284,11 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
     const uint32_t want = args.iteration + 1u;
     const uint32_t waves = gridDim.x * (blockDim.x / 64u);
     uint32_t next = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u, end = 0, changes = 0;
+#ifdef EM2_DIAG
+    uint64_t diagAcc[kDiagWords] = {};
+    const uint64_t diagStart = __builtin_amdgcn_s_memtime();
+    uint64_t diagLast = diagStart;
+#endif
     for (;;) {
         // Every wave takes its positions in ascending order, so the smallest unfinished position is always the one
         // its wave is working on and the waits below cannot deadlock -- with the strided assignment provided the
@@ -284,6 +326,7 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
         const bool later = args.iteration > 0u;
         const uint32_t posPrevV = later ? uniform(args.posPrev[v]) : 0u;
         uint32_t error = 0;
+        LP_CLOCK(0);
 
         if (degree <= 64u) {
             // ---- one neighbour per lane; both candidate lists stay in registers ----
@@ -311,6 +354,7 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
                 if (known && afterU == labelU) keyB = kNone;
             }
             const uint64_t knownMask = __builtin_amdgcn_ballot_w64(known);
+            LP_CLOCK(1);
             while (!error) {
                 const uint32_t m = waveMin(keyA);
                 if (m == kNone) break;
@@ -319,8 +363,10 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
                 const uint32_t newLabel = uint32_t(__shfl(int(labelU), owner));
                 const float weight = __shfl(w, owner);
                 if (int(lane) == owner) keyA = kNone;
-                if (!applyEvent(t, args, oldLabel, newLabel, weight, lane)) error = 2;
+                LP_COUNT(10);
+                if (!applyEvent(t, args, oldLabel, newLabel, weight, lane LP_DIAG_PASS)) error = 2;
             }
+            LP_CLOCK(2);
             while (!error) {
                 const uint32_t m = waveMin(keyB);
                 if (m == kNone) break;
@@ -331,11 +377,14 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
                 if (int(lane) == owner) keyB = kNone;
                 bool failed = false;
                 const uint32_t newLabel = ((knownMask >> owner) & 1ull) ? uint32_t(__shfl(int(afterU), owner))
-                                                                        : labelAfterTurn(args, other, failed);
+                                                                        : labelAfterTurn(args, other, failed LP_DIAG_PASS);
+                LP_COUNT(11);
                 if (failed) error = 1;
-                else if (newLabel != oldLabel && !applyEvent(t, args, oldLabel, newLabel, weight, lane)) error = 2;
+                else if (newLabel != oldLabel && !applyEvent(t, args, oldLabel, newLabel, weight, lane LP_DIAG_PASS)) error = 2;
             }
+            LP_CLOCK(3);
         } else {
+            LP_COUNT(13);
             // ---- the candidate lists go through scratch memory (slots base .. base+degree of each list) ----
             Candidate* listA = args.scratchA + base;
             Candidate* listB = args.scratchB + base;
@@ -371,6 +420,7 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
                 countA += uint32_t(__builtin_popcountll(maskA));
                 countB += uint32_t(__builtin_popcountll(maskB));
             }
+            LP_CLOCK(5);
             for (int phase = 0; phase < 2 && !error; ++phase) {
                 Candidate* list = phase ? listB : listA;
                 const uint32_t count = phase ? countB : countA;
@@ -381,20 +431,24 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
                 while (padded < count) padded <<= 1;
                 for (uint32_t i = lane; i < padded; i += 64u) keys[i] = i < count ? (uint64_t(list[i].key) << 32) | i : ~0ull;
                 sortKeysByWave(keys, padded, lane);
+                LP_CLOCK(6);
                 for (uint32_t n = 0; n < count && !error; ++n) {
                     const uint32_t index = uniform(uint32_t(keys[n]));
                     const Candidate candidate = list[index];
                     const uint32_t a = uniform(candidate.a), b = uniform(candidate.b);
                     const float weight = uniform(candidate.weight);
                     if (phase == 0) {
-                        if (!applyEvent(t, args, a, b, weight, lane)) error = 2;
+                        LP_COUNT(10);
+                        if (!applyEvent(t, args, a, b, weight, lane LP_DIAG_PASS)) error = 2;
                     } else {
                         bool failed = false;
-                        const uint32_t newLabel = uniform(candidate.known) ? uniform(candidate.c) : labelAfterTurn(args, a, failed);
+                        const uint32_t newLabel = uniform(candidate.known) ? uniform(candidate.c) : labelAfterTurn(args, a, failed LP_DIAG_PASS);
+                        LP_COUNT(11);
                         if (failed) error = 1;
-                        else if (newLabel != b && !applyEvent(t, args, b, newLabel, weight, lane)) error = 2;
+                        else if (newLabel != b && !applyEvent(t, args, b, newLabel, weight, lane LP_DIAG_PASS)) error = 2;
                     }
                 }
+                LP_CLOCK(7);
             }
         }
 
@@ -419,7 +473,477 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
             args.meta[v] = t;
             __hip_atomic_store(args.state + v, (uint64_t(want) << 32) | label, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        LP_CLOCK(8);
     }
+#ifdef EM2_DIAG
+    diagAcc[9] = __builtin_amdgcn_s_memtime() - diagStart;
+    if (lane == 0u && args.diag) {
+        for (uint32_t i = 0; i < kDiagWords; ++i) atomicAdd(args.diag + i, (unsigned long long)diagAcc[i]);
+    }
+#endif
+    if (lane == 0u && changes) __hip_atomic_fetch_add(args.control + 1, changes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3 form of the turn: the table of the vertex whose turn it is lives in LDS for the turn.
+//
+// Measured with the diagnostic build (LP_CLOCK) at 1M vertices / 15M edges: in the iterations with many label changes a wave
+// spent 36 % of its cycles applying events -- two addWeight calls each, every one a dependent global load of the table, a
+// ballot and a store: 3000 cycles -- 8 % in the 4 % of turns whose vertex has more than 64 neighbours (tables of hundreds of
+// entries scanned from global memory 64 at a time, candidates staged and sorted in global memory), and 40-65 % WAITING for
+// such slow turns of earlier neighbours.  Here a table is read once per turn, on the first event (two entries per lane, 16
+// bytes), searched and updated in LDS (one ds_read per 128 entries), and written back once; a table that outgrows its
+// allocation only changes its address (no copy: the content is in LDS); the candidate events of a vertex of large degree are
+// sorted as (time, adjacency index) keys in LDS and their data gathered again 64 at a time; the earliest event of a small
+// neighbourhood comes out of a DPP reduction instead of six ds_bpermute.  Tables above kCacheEntries and candidate lists above
+// kHubKeys take the global-memory forms above.  EM2_LABEL_FORM=global runs the older kernel (A/B; both are tested).
+constexpr uint32_t kCacheEntries = 640;
+constexpr uint32_t kHubKeys = 512;
+
+struct alignas(16) WaveArea {
+    uint2 table[kCacheEntries];         // (cluster, weight bits)
+    uint64_t keys[kHubKeys];
+};
+
+template <uint32_t CTRL, uint32_t ROWS, uint32_t BANKS>
+__device__ __forceinline__ uint32_t dppMin(uint32_t x)
+{
+    return min(x, uint32_t(__builtin_amdgcn_update_dpp(-1, int(x), CTRL, ROWS, BANKS, false)));
+}
+
+// Smallest value of the wave (kNone where a lane has none), in every lane.
+__device__ __forceinline__ uint32_t waveMinDpp(uint32_t x)
+{
+    x = dppMin<0x111, 0xf, 0xf>(x);      // row_shr:1
+    x = dppMin<0x112, 0xf, 0xf>(x);      // row_shr:2
+    x = dppMin<0x114, 0xf, 0xf>(x);      // row_shr:4
+    x = dppMin<0x118, 0xf, 0xf>(x);      // row_shr:8: lane 15 of every row holds the row's minimum
+    x = dppMin<0x142, 0xa, 0xf>(x);      // row_bcast15 into rows 1 and 3
+    x = dppMin<0x143, 0xc, 0xf>(x);      // row_bcast31 into rows 2 and 3: lane 63 holds the minimum
+    return uint32_t(__builtin_amdgcn_readlane(int(x), 63));
+}
+
+__device__ __forceinline__ uint32_t laneValue(uint32_t x, int owner) { return uint32_t(__builtin_amdgcn_readlane(int(x), owner)); }
+__device__ __forceinline__ float laneValue(float x, int owner) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), owner)); }
+
+struct CachedTable {
+    TableMeta t;
+    uint32_t mode;          // 0 untouched in global memory, 1 in LDS, 2 worked on in global memory (too large for the LDS area)
+    bool dirty;
+};
+
+__device__ __forceinline__ void cachedFindBest(CachedTable& c, const uint2* table, uint32_t lane)
+{
+    float bestWeight = -1.f;
+    uint32_t bestIndex = kNone;
+    for (uint32_t i = lane; i < c.t.size; i += 64u) {
+        const float w = __uint_as_float(table[i].y);
+        if (w > bestWeight) {
+            bestWeight = w;
+            bestIndex = i;
+        }
+    }
+    for (int offset = 32; offset; offset >>= 1) {
+        const float otherWeight = __shfl_xor(bestWeight, offset);
+        const uint32_t otherIndex = uint32_t(__shfl_xor(int(bestIndex), offset));
+        if (otherWeight > bestWeight || (otherWeight == bestWeight && otherIndex < bestIndex)) {
+            bestWeight = otherWeight;
+            bestIndex = otherIndex;
+        }
+    }
+    bestIndex = uniform(bestIndex);
+    if (bestIndex == kNone) {
+        c.t.best = kNone;
+        c.t.bestWeight = -1.f;
+    } else {
+        c.t.best = uniform(table[bestIndex].x);
+        c.t.bestWeight = uniform(bestWeight);
+    }
+}
+
+// Writes the LDS copy back (the whole table: its entries are contiguous, a turn with events touches most of them).
+__device__ __forceinline__ void cachedFlush(const CachedTable& c, const ClusterArgs& args, const uint2* table, uint32_t lane)
+{
+    uint2* out = reinterpret_cast<uint2*>(args.arena + c.t.begin);
+    for (uint32_t i = lane; i < c.t.size; i += 64u) out[i] = table[i];
+}
+
+// ClusterTable::addWeight (CellGraph.hpp:70-99) on the table of the current turn.  Returns false when the arena is exhausted.
+__device__ __forceinline__ bool cachedAddWeight(CachedTable& c, const ClusterArgs& args, uint2* table, uint32_t cluster, float weight,
+                                                uint32_t lane LP_DIAG_PARAM)
+{
+    if (c.mode == 0u) {
+        if (c.t.size <= kCacheEntries) {
+            // begin and capacity are even (2 * degree + 8, 2 * capacity + 8), the arena 16-byte aligned: two entries per lane
+            const uint4* in = reinterpret_cast<const uint4*>(args.arena + c.t.begin);
+            uint4* out = reinterpret_cast<uint4*>(table);
+            for (uint32_t j = lane; 2u * j < c.t.size; j += 64u) out[j] = in[j];
+            c.mode = 1u;
+            waveSync();
+        } else {
+            c.mode = 2u;
+        }
+    }
+    if (c.mode == 1u) {
+        c.dirty = true;
+        const uint32_t pairs = (c.t.size + 1u) >> 1;
+        for (uint32_t first = 0; first < pairs; first += 64u) {
+            const uint32_t j = first + lane;
+            bool hit0 = false, hit1 = false;
+            uint2 e0 = make_uint2(0u, 0u), e1 = make_uint2(0u, 0u);
+            if (j < pairs) {
+                e0 = table[2u * j];
+                e1 = table[2u * j + 1u];
+                hit0 = e0.x == cluster;
+                hit1 = 2u * j + 1u < c.t.size && e1.x == cluster;
+            }
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(hit0 || hit1);
+            if (mask == 0ull) continue;
+            // the first entry of that cluster, like the reference's linear search
+            const int owner = __ffsll((unsigned long long)mask) - 1;
+            float w = __uint_as_float(hit0 ? e0.y : e1.y);
+            if (int(lane) == owner) {
+                w += weight;
+                table[2u * j + (hit0 ? 0u : 1u)].y = __float_as_uint(w);
+            }
+            const float updated = laneValue(w, owner);
+            if (cluster == c.t.best) {
+                if (weight < 0.f) {
+                    LP_COUNT(14);
+                    waveSync();
+                    cachedFindBest(c, table, lane);
+                } else {
+                    c.t.bestWeight = updated;
+                }
+            } else if (updated > c.t.bestWeight) {
+                c.t.best = cluster;
+                c.t.bestWeight = updated;
+            }
+            return true;
+        }
+        if (c.t.size < kCacheEntries) {
+            if (c.t.size == c.t.capacity) {
+                // the content is in LDS: a table that outgrows its allocation only changes the address it is written back to
+                const uint32_t capacity = c.t.capacity * 2u + 8u;
+                unsigned long long at = 0;
+                if (lane == 0u) at = atomicAdd(args.arenaTop, (unsigned long long)capacity);
+                at = uniform(uint64_t(at));
+                if (at + capacity > args.arenaCapacity) return false;
+                LP_COUNT(15);
+                c.t.begin = at;
+                c.t.capacity = capacity;
+            }
+            if (lane == 0u) table[c.t.size] = make_uint2(cluster, __float_as_uint(weight));
+            ++c.t.size;
+            waveSync();
+            if (weight > c.t.bestWeight) {
+                c.t.best = cluster;
+                c.t.bestWeight = weight;
+            }
+            return true;
+        }
+        // no room in LDS for another entry: back to global memory for the rest of the turn
+        waveSync();
+        cachedFlush(c, args, table, lane);
+        waveSyncGlobal();
+        c.mode = 2u;
+    }
+    return addWeight(c.t, args, cluster, weight, lane LP_DIAG_PASS);
+}
+
+// One label change of a neighbour as the table of the current vertex sees it (CellGraph.cpp:529-530): +weight on the new
+// label, then -weight on the old one.
+__device__ __forceinline__ bool cachedApplyEvent(CachedTable& c, const ClusterArgs& args, uint2* table, uint32_t oldLabel, uint32_t newLabel,
+                                                 float weight, uint32_t lane LP_DIAG_PARAM)
+{
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        if (!cachedAddWeight(c, args, table, half ? oldLabel : newLabel, half ? -weight : weight, lane LP_DIAG_PASS)) return false;
+    }
+    return true;
+}
+
+// Bitonic sort of n (a power of two) keys by one wave; KEYS is a pointer into LDS or into global memory (two instantiations).
+template <bool GLOBAL>
+__device__ __forceinline__ void sortKeysOfTurn(uint64_t* keys, uint32_t n, uint32_t lane)
+{
+    for (uint32_t k = 2u; k <= n; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+            for (uint32_t i = lane; i < n; i += 64u) {
+                const uint32_t partner = i ^ j;
+                if (partner > i) {
+                    const uint64_t x = keys[i], y = keys[partner];
+                    const bool ascending = (i & k) == 0u;
+                    if ((x > y) == ascending) {
+                        keys[i] = y;
+                        keys[partner] = x;
+                    }
+                }
+            }
+            waveSyncFor<GLOBAL>();
+        }
+    }
+}
+
+// The candidates' keys of one phase of a vertex with more than 64 neighbours, padded and sorted.
+template <bool GLOBAL>
+__device__ __forceinline__ void sortHubKeys(uint64_t* keys, uint32_t count, uint32_t lane)
+{
+    uint32_t padded = 1u;
+    while (padded < count) padded <<= 1;
+    for (uint32_t i = count + lane; i < padded; i += 64u) keys[i] = ~0ull;
+    waveSyncFor<GLOBAL>();
+    sortKeysOfTurn<GLOBAL>(keys, padded, lane);
+}
+
+__global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs args)
+{
+    __shared__ WaveArea areas[4];
+    WaveArea& area = areas[threadIdx.x / 64u];
+    uint2* table = area.table;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t want = args.iteration + 1u;
+    const uint32_t waves = gridDim.x * (blockDim.x / 64u);
+    uint32_t next = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u, end = 0, changes = 0;
+#ifdef EM2_DIAG
+    uint64_t diagAcc[kDiagWords] = {};
+    const uint64_t diagStart = __builtin_amdgcn_s_memtime();
+    uint64_t diagLast = diagStart;
+#endif
+    for (;;) {
+        uint32_t p;                                   // (the schedule: see labelPropagationKernel)
+        if (args.ticketBatch == 0u) {
+            if (next >= args.vertexCount) break;
+            p = next;
+            next += waves;
+        } else {
+            if (next >= end) {
+                uint32_t first = kNone;
+                if (lane == 0u && __hip_atomic_load(args.control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    first = __hip_atomic_fetch_add(args.control, args.ticketBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                first = uniform(first);
+                if (first >= args.vertexCount) break;
+                next = first;
+                end = min(first + args.ticketBatch, args.vertexCount);
+            }
+            p = next++;
+        }
+        const uint32_t v = uniform(args.order[p]);
+        const uint64_t base = uniform(args.offsets[v]);
+        const uint32_t degree = uniform(uint32_t(args.offsets[v + 1] - base));
+        CachedTable c;
+        c.t = args.meta[v];
+        c.t.begin = uniform(c.t.begin);
+        c.t.size = uniform(c.t.size);
+        c.t.capacity = uniform(c.t.capacity);
+        c.t.best = uniform(c.t.best);
+        c.t.bestWeight = uniform(c.t.bestWeight);
+        c.mode = 0u;
+        c.dirty = false;
+        uint32_t label = uniform(args.labelPrev[v]);
+        const bool later = args.iteration > 0u;
+        const uint32_t posPrevV = later ? uniform(args.posPrev[v]) : 0u;
+        uint32_t error = 0;
+        LP_CLOCK(0);
+
+        if (degree <= 64u) {
+            // ---- one neighbour per lane; both candidate lists stay in registers ----
+            uint32_t u = 0, labelU = 0, beforeU = 0, keyA = kNone, keyB = kNone;
+            float w = 0.f;
+            if (lane < degree) {
+                u = args.neighbour[base + lane];
+                w = args.weight[base + lane];
+                labelU = args.labelPrev[u];
+                if (later) {
+                    beforeU = args.labelPrev2[u];
+                    const uint32_t pp = args.posPrev[u];
+                    if (labelU != beforeU && pp > posPrevV) keyA = pp;
+                }
+                const uint32_t pc = args.posCur[u];
+                if (pc < p) keyB = pc;
+            }
+            // First look at the earlier neighbours, all at once: most have had their turn and kept their label.
+            uint32_t afterU = 0;
+            bool known = false;
+            if (keyB != kNone) {
+                const uint64_t s = __hip_atomic_load(args.state + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                known = uint32_t(s >> 32) == want;
+                afterU = uint32_t(s);
+                if (known && afterU == labelU) keyB = kNone;
+            }
+            const uint64_t knownMask = __builtin_amdgcn_ballot_w64(known);
+            LP_CLOCK(1);
+            // phase 0: the events of the previous iteration that came after this vertex; phase 1: those of this iteration
+            // before it -- each in the order of their times
+#pragma unroll 1
+            for (int phase = 0; phase < 2 && !error; ++phase) {
+                uint32_t key = phase ? keyB : keyA;
+                const uint32_t before = phase ? labelU : beforeU;
+                const uint32_t after = phase ? afterU : labelU;
+                const uint64_t certain = phase ? knownMask : ~0ull;
+                for (;;) {
+                    const uint32_t m = waveMinDpp(key);
+                    if (m == kNone) break;
+                    const int owner = __ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(key == m)) - 1;
+                    if (int(lane) == owner) key = kNone;
+                    const uint32_t oldLabel = laneValue(before, owner);
+                    const float weight = laneValue(w, owner);
+                    uint32_t newLabel;
+                    if ((certain >> owner) & 1ull) {
+                        newLabel = laneValue(after, owner);
+                    } else {
+                        bool failed = false;
+                        newLabel = labelAfterTurn(args, laneValue(u, owner), failed LP_DIAG_PASS);
+                        if (failed) {
+                            error = 1;
+                            break;
+                        }
+                    }
+                    if (phase) LP_COUNT(11);
+                    else LP_COUNT(10);
+                    if (newLabel != oldLabel && !cachedApplyEvent(c, args, table, oldLabel, newLabel, weight, lane LP_DIAG_PASS)) {
+                        error = 2;
+                        break;
+                    }
+                }
+                LP_CLOCK(2 + phase);
+            }
+        } else {
+            LP_COUNT(13);
+#pragma unroll 1
+            for (int phase = later ? 0 : 1; phase < 2 && !error; ++phase) {
+                // the candidates of this phase: (event time << 32 | adjacency index); equal times (parallel edges) keep the
+                // order of the adjacency.  In LDS while they fit, else in the vertex's slots of the global key area.
+                uint64_t* global = args.sortKeys + (phase ? 2u * args.slots : 0u) + 2u * base;
+                uint32_t count = 0;
+                bool inLds = true;
+                for (uint32_t first = 0; first < degree; first += 64u) {
+                    const uint32_t i = first + lane;
+                    bool candidate = false;
+                    uint32_t key = 0;
+                    if (i < degree) {
+                        const uint32_t u = args.neighbour[base + i];
+                        if (phase == 0) {
+                            key = args.posPrev[u];
+                            candidate = key > posPrevV && args.labelPrev[u] != args.labelPrev2[u];
+                        } else {
+                            key = args.posCur[u];
+                            candidate = key < p;
+                            if (candidate) {
+                                const uint64_t s = __hip_atomic_load(args.state + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (uint32_t(s >> 32) == want && uint32_t(s) == args.labelPrev[u]) candidate = false;
+                            }
+                        }
+                    }
+                    const uint64_t mask = __builtin_amdgcn_ballot_w64(candidate);
+                    const uint32_t more = uint32_t(__builtin_popcountll(mask));
+                    if (inLds && count + more > kHubKeys) {
+                        // the list leaves LDS: what was collected so far moves to the global area
+                        waveSync();
+                        for (uint32_t k = lane; k < count; k += 64u) global[k] = area.keys[k];
+                        inLds = false;
+                    }
+                    if (candidate) {
+                        const uint64_t entry = (uint64_t(key) << 32) | i;
+                        if (inLds) area.keys[count + lanesBelow(mask)] = entry;
+                        else global[count + lanesBelow(mask)] = entry;
+                    }
+                    count += more;
+                }
+                LP_CLOCK(5);
+                if (count == 0u) continue;
+                if (inLds) {
+                    waveSync();
+                    sortHubKeys<false>(area.keys, count, lane);
+                } else {
+                    waveSyncGlobal();
+                    sortHubKeys<true>(global, count, lane);
+                }
+                LP_CLOCK(6);
+                // applied 64 at a time: the lane that holds a key gathers the neighbour's data again (the lines are still in L2)
+                for (uint32_t first = 0; first < count && !error; first += 64u) {
+                    const uint32_t n = min(64u, count - first);
+                    uint32_t u = 0, before = 0, after = 0;
+                    float w = 0.f;
+                    bool known = true;
+                    if (lane < n) {
+                        uint64_t entry;
+                        if (inLds) entry = area.keys[first + lane];
+                        else entry = global[first + lane];
+                        const uint32_t index = uint32_t(entry);
+                        u = args.neighbour[base + index];
+                        w = args.weight[base + index];
+                        if (phase == 0) {
+                            before = args.labelPrev2[u];
+                            after = args.labelPrev[u];
+                        } else {
+                            before = args.labelPrev[u];
+                            const uint64_t s = __hip_atomic_load(args.state + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            known = uint32_t(s >> 32) == want;
+                            after = uint32_t(s);
+                        }
+                    }
+                    const uint64_t knownMask = __builtin_amdgcn_ballot_w64(known);
+                    for (uint32_t j = 0; j < n; ++j) {
+                        const uint32_t oldLabel = laneValue(before, int(j));
+                        const float weight = laneValue(w, int(j));
+                        uint32_t newLabel;
+                        if ((knownMask >> j) & 1ull) {
+                            newLabel = laneValue(after, int(j));
+                        } else {
+                            bool failed = false;
+                            newLabel = labelAfterTurn(args, laneValue(u, int(j)), failed LP_DIAG_PASS);
+                            if (failed) {
+                                error = 1;
+                                break;
+                            }
+                        }
+                        if (phase) LP_COUNT(11);
+                        else LP_COUNT(10);
+                        if (newLabel != oldLabel && !cachedApplyEvent(c, args, table, oldLabel, newLabel, weight, lane LP_DIAG_PASS)) {
+                            error = 2;
+                            break;
+                        }
+                    }
+                }
+                LP_CLOCK(7);
+            }
+        }
+
+        if (error) {
+            if (lane == 0u) {
+                // Keep the first cause: a timeout that follows an exhausted arena is only its consequence.
+                uint32_t expected = 0;
+                __hip_atomic_compare_exchange_strong(args.control + 2, &expected, error, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+
+        // ---- the turn proper (CellGraph.cpp:507-524) ----
+        const bool change = c.t.size != 0u && label != c.t.best;
+        if (change) {
+            label = c.t.best;
+            ++changes;
+        }
+        if (lane == 0u) {
+            args.labelCur[v] = label;
+            args.meta[v] = c.t;
+            __hip_atomic_store(args.state + v, (uint64_t(want) << 32) | label, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (c.mode == 1u && c.dirty) {
+            waveSync();
+            cachedFlush(c, args, table, lane);
+        }
+        LP_CLOCK(8);
+    }
+#ifdef EM2_DIAG
+    diagAcc[9] = __builtin_amdgcn_s_memtime() - diagStart;
+    if (lane == 0u && args.diag) {
+        for (uint32_t i = 0; i < kDiagWords; ++i) atomicAdd(args.diag + i, (unsigned long long)diagAcc[i]);
+    }
+#endif
     if (lane == 0u && changes) __hip_atomic_fetch_add(args.control + 1, changes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -587,6 +1111,8 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
     }
     clock.stage("adjacency");
 
+    const char* formText = getenv("EM2_LABEL_FORM");
+    const bool cachedForm = !(formText && strcmp(formText, "global") == 0);
     const uint64_t initialEntries = 2 * slots + 8ull * vertexCount;
     // Tables only grow (the reference never removes an entry either) and a table that fills up moves to the tail, so
     // the tail is sized generously and, should a graph whose labels keep churning outgrow it anyway, the whole run is
@@ -604,9 +1130,13 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
     EM2_TRY(dMeta.allocate(size_t(vertexCount) * sizeof(TableMeta)));
     EM2_TRY(dArena.allocate(arenaCapacity * sizeof(TableEntry)));
     EM2_TRY(dControl.allocate(4 * sizeof(uint32_t) + sizeof(unsigned long long)));
+#ifdef EM2_DIAG
+    Buffer dDiag;
+    EM2_TRY(dDiag.allocate(kDiagWords * sizeof(unsigned long long)));
+#endif
     Buffer dSortKeys;
     if (maxDegree > 64u) {
-        EM2_TRY(dScratch.allocate(2 * slots * sizeof(Candidate)));
+        if (!cachedForm) EM2_TRY(dScratch.allocate(2 * slots * sizeof(Candidate)));
         EM2_TRY(dSortKeys.allocate(4 * slots * sizeof(uint64_t)));
     }
 
@@ -619,7 +1149,8 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
     const char* batchText = getenv("EM2_LABEL_TICKET_BATCH");
     uint32_t ticketBatch = batchText && atoi(batchText) > 0 ? uint32_t(atoi(batchText)) : 0u;
     int blocksPerUnit = 0;
-    EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerUnit, labelPropagationKernel, 256, 0));
+    if (cachedForm) EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerUnit, labelPropagationCachedKernel, 256, 0));
+    else EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerUnit, labelPropagationKernel, 256, 0));
     blocksPerUnit = std::max(1, std::min(blocksPerUnit, 4));
     const uint32_t waveBlocks = (vertexCount + 3u) / 4u;
     const dim3 grid(std::min<uint32_t>(waveBlocks, uint32_t(computeUnits) * uint32_t(blocksPerUnit)));
@@ -683,7 +1214,12 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
             args.scratchB = dScratch.as<Candidate>() + slots;
             args.sortKeys = dSortKeys.as<uint64_t>();
             args.slots = slots;
-            labelPropagationKernel<<<grid, block, 0, stream>>>(args);
+#ifdef EM2_DIAG
+            args.diag = clock.on ? dDiag.as<unsigned long long>() : nullptr;
+            EM2_TRY(hipMemsetAsync(dDiag.p, 0, kDiagWords * sizeof(unsigned long long), stream));
+#endif
+            if (cachedForm) labelPropagationCachedKernel<<<grid, block, 0, stream>>>(args);
+            else labelPropagationKernel<<<grid, block, 0, stream>>>(args);
             EM2_TRY(hipGetLastError());
             ++iterations;
             if (iterations < maxIterationCount) {
@@ -694,6 +1230,19 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
             EM2_TRY(hipMemcpyAsync(result, control, sizeof(result), hipMemcpyDeviceToHost, stream));
             EM2_TRY(hipStreamSynchronize(stream));
             if (clock.on) fprintf(stderr, "[em2 timing]   label propagation: iteration %u, %u changes, %.1f ms\n", t, result[1], clock.lap());
+#ifdef EM2_DIAG
+            if (clock.on) {
+                unsigned long long d[kDiagWords];
+                EM2_TRY(hipMemcpy(d, dDiag.p, sizeof(d), hipMemcpyDeviceToHost));
+                const double whole = double(d[9]) > 0 ? double(d[9]) : 1.0;
+                fprintf(stderr, "[em2 timing]     wave cycles %%: header %.1f gather %.1f A %.1f B %.1f wait %.1f hub gather %.1f hub sort %.1f hub events %.1f "
+                        "store %.1f | events A %llu B %llu, waits %llu, hub turns %llu, rescans %llu, relocations %llu, mean wave %.2f Mticks\n",
+                        100 * d[0] / whole, 100 * d[1] / whole, 100 * d[2] / whole, 100 * d[3] / whole, 100 * d[4] / whole, 100 * d[5] / whole,
+                        100 * d[6] / whole, 100 * d[7] / whole, 100 * d[8] / whole, d[10], d[11], d[12], d[13], d[14], d[15],
+                        whole / (double(grid.x) * 4.0) / 1e6);
+                clock.lap();
+            }
+#endif
             if (result[2] != 0) {
                 failure = result[2];
                 break;
