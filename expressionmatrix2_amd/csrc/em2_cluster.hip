@@ -32,7 +32,12 @@
 #include "em2_select_wave.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -230,7 +235,9 @@ __device__ __forceinline__ uint32_t labelAfterTurn(const ClusterArgs& args, uint
 {
     const uint64_t* word = args.state + vertex;
     const uint32_t want = args.iteration + 1u;
-    uint64_t s = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (every value that steers the loop goes through readfirstlane: the compiler must see the polling as uniform control flow,
+    // or everything live across it -- the table's size, its mode, the error -- ends up in vector registers behind exec masks)
+    uint64_t s = uniform(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (uint32_t(s >> 32) != want) {
 #ifdef EM2_DIAG
         const uint64_t lpEntered = __builtin_amdgcn_s_memtime();
@@ -239,9 +246,9 @@ __device__ __forceinline__ uint32_t labelAfterTurn(const ClusterArgs& args, uint
         const uint64_t start = __builtin_amdgcn_s_memrealtime();             // 100 MHz
         for (;;) {
             __builtin_amdgcn_s_sleep(2);
-            s = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s = uniform(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (uint32_t(s >> 32) == want) break;
-            if (__hip_atomic_load(args.control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+            if (uniform(__hip_atomic_load(args.control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u ||
                 __builtin_amdgcn_s_memrealtime() - start > 400000000ull) {
                 failed = true;
                 break;
@@ -572,6 +579,15 @@ __device__ __forceinline__ void cachedFlush(const CachedTable& c, const ClusterA
 __device__ __forceinline__ bool cachedAddWeight(CachedTable& c, const ClusterArgs& args, uint2* table, uint32_t cluster, float weight,
                                                 uint32_t lane LP_DIAG_PARAM)
 {
+    // (wave-uniform by construction; said again so that the branches below are scalar ones)
+    c.mode = uniform(c.mode);
+    c.t.size = uniform(c.t.size);
+    c.t.capacity = uniform(c.t.capacity);
+    c.t.begin = uniform(c.t.begin);
+    c.t.best = uniform(c.t.best);
+    c.t.bestWeight = uniform(c.t.bestWeight);
+    cluster = uniform(cluster);
+    weight = uniform(weight);
     if (c.mode == 0u) {
         if (c.t.size <= kCacheEntries) {
             // begin and capacity are even (2 * degree + 8, 2 * capacity + 8), the arena 16-byte aligned: two entries per lane
@@ -696,6 +712,7 @@ __device__ __forceinline__ void sortHubKeys(uint64_t* keys, uint32_t count, uint
     sortKeysOfTurn<GLOBAL>(keys, padded, lane);
 }
 
+template <bool STRIDED>
 __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs args)
 {
     __shared__ WaveArea areas[4];
@@ -710,12 +727,85 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
     const uint64_t diagStart = __builtin_amdgcn_s_memtime();
     uint64_t diagLast = diagStart;
 #endif
+    // What a turn reads before it can look at its neighbours -- its vertex, the vertex's header (adjacency range, table, label,
+    // previous position), the neighbour list -- is a chain of three dependent loads that depends on nothing the launch writes
+    // (a vertex's table header is only written by its own turn).  With the strided schedule (STRIDED) a wave knows its positions
+    // in advance, so the chain is loaded ahead: at the start of turn k the neighbours of turn k+1, the header of turn k+2 and
+    // the vertex of turn k+3 are requested -- unconditionally, with clamped indices and per-lane addresses, so that no branch
+    // and no readfirstlane, hence no wait, lies between the requests -- and the stages move up by one at the END of the turn,
+    // before its stores are issued (the moves wait for loads that arrived long ago; a wait at the start of the next turn
+    // would also wait for those stores).  With the ticket schedule the chain is loaded at the start of the turn.
+    struct Header {         // wave-uniform
+        uint64_t base;
+        uint32_t degree;
+        TableMeta t;
+        uint32_t label, posPrev;
+    };
+    struct RawHeader {      // as loaded: the same value in every lane
+        uint64_t base, end;
+        TableMeta t;
+        uint32_t label, posPrev;
+    };
+    const bool later = args.iteration > 0u;
+    const uint32_t lastPosition = args.vertexCount - 1u;
+    const uint64_t lastSlot = args.slots ? args.slots - 1u : 0u;
+    auto loadVertex = [&](uint32_t position) -> uint32_t { return args.order[min(position, lastPosition)]; };
+    auto loadHeader = [&](uint32_t vertex) -> RawHeader {
+        RawHeader h;
+        h.base = args.offsets[vertex];
+        h.end = args.offsets[vertex + 1];
+        h.t = args.meta[vertex];
+        h.label = args.labelPrev[vertex];
+        h.posPrev = args.posPrev[vertex];               // (of iteration 0: not used)
+        return h;
+    };
+    auto pickUp = [&](const RawHeader& raw) -> Header {
+        Header h;
+        h.base = uniform(raw.base);
+        h.degree = uniform(uint32_t(raw.end - raw.base));
+        h.t.begin = uniform(raw.t.begin);
+        h.t.size = uniform(raw.t.size);
+        h.t.capacity = uniform(raw.t.capacity);
+        h.t.best = uniform(raw.t.best);
+        h.t.bestWeight = uniform(raw.t.bestWeight);
+        h.label = uniform(raw.label);
+        h.posPrev = uniform(raw.posPrev);
+        return h;
+    };
+    // (lanes beyond the degree read some valid slot and never use it)
+    auto loadNeighbour = [&](uint64_t base, uint32_t& u, float& w) {
+        const uint64_t slot = min(base + lane, lastSlot);
+        u = args.neighbour[slot];
+        w = args.weight[slot];
+    };
+    uint32_t rawVertexA = 0, rawVertexB = 0, rawVertexC = 0, uA = 0;
+    float wA = 0.f;
+    RawHeader rawHeaderA = {}, rawHeaderB = {};
+    if (STRIDED && next < args.vertexCount) {
+        rawVertexA = loadVertex(next);
+        rawVertexB = loadVertex(next + waves);
+        rawVertexC = loadVertex(next + 2u * waves);
+        rawHeaderA = loadHeader(rawVertexA);
+        rawHeaderB = loadHeader(rawVertexB);
+        loadNeighbour(rawHeaderA.base, uA, wA);
+    }
     for (;;) {
         uint32_t p;                                   // (the schedule: see labelPropagationKernel)
-        if (args.ticketBatch == 0u) {
+        uint32_t v, u = 0, rawVertexD = 0, uB = 0;
+        float w = 0.f, wB = 0.f;
+        Header header;
+        RawHeader rawHeaderC = {};
+        if (STRIDED) {
             if (next >= args.vertexCount) break;
             p = next;
             next += waves;
+            v = uniform(rawVertexA);
+            header = pickUp(rawHeaderA);
+            u = uA;
+            w = wA;
+            loadNeighbour(rawHeaderB.base, uB, wB);
+            rawHeaderC = loadHeader(rawVertexC);
+            rawVertexD = loadVertex(next + 2u * waves);
         } else {
             if (next >= end) {
                 uint32_t first = kNone;
@@ -728,32 +818,25 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
                 end = min(first + args.ticketBatch, args.vertexCount);
             }
             p = next++;
+            v = uniform(args.order[p]);
+            header = pickUp(loadHeader(v));
+            loadNeighbour(header.base, u, w);
         }
-        const uint32_t v = uniform(args.order[p]);
-        const uint64_t base = uniform(args.offsets[v]);
-        const uint32_t degree = uniform(uint32_t(args.offsets[v + 1] - base));
+        const uint64_t base = header.base;
+        const uint32_t degree = header.degree;
         CachedTable c;
-        c.t = args.meta[v];
-        c.t.begin = uniform(c.t.begin);
-        c.t.size = uniform(c.t.size);
-        c.t.capacity = uniform(c.t.capacity);
-        c.t.best = uniform(c.t.best);
-        c.t.bestWeight = uniform(c.t.bestWeight);
+        c.t = header.t;
         c.mode = 0u;
         c.dirty = false;
-        uint32_t label = uniform(args.labelPrev[v]);
-        const bool later = args.iteration > 0u;
-        const uint32_t posPrevV = later ? uniform(args.posPrev[v]) : 0u;
+        uint32_t label = header.label;
+        const uint32_t posPrevV = later ? header.posPrev : 0u;
         uint32_t error = 0;
         LP_CLOCK(0);
 
         if (degree <= 64u) {
             // ---- one neighbour per lane; both candidate lists stay in registers ----
-            uint32_t u = 0, labelU = 0, beforeU = 0, keyA = kNone, keyB = kNone;
-            float w = 0.f;
+            uint32_t labelU = 0, beforeU = 0, keyA = kNone, keyB = kNone;
             if (lane < degree) {
-                u = args.neighbour[base + lane];
-                w = args.weight[base + lane];
                 labelU = args.labelPrev[u];
                 if (later) {
                     beforeU = args.labelPrev2[u];
@@ -927,6 +1010,16 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
             label = c.t.best;
             ++changes;
         }
+        if (STRIDED) {
+            // the turns ahead move up by one (their loads were requested at the start of this turn)
+            rawVertexA = rawVertexB;
+            rawHeaderA = rawHeaderB;
+            uA = uB;
+            wA = wB;
+            rawVertexB = rawVertexC;
+            rawHeaderB = rawHeaderC;
+            rawVertexC = rawVertexD;
+        }
         if (lane == 0u) {
             args.labelCur[v] = label;
             args.meta[v] = c.t;
@@ -1010,7 +1103,7 @@ adjacencyKernel(const uint32_t* __restrict__ endsSorted, uint32_t slots, const u
 struct Buffer {
     void* p = nullptr;
     ~Buffer() { if (p) (void)hipFree(p); }
-    hipError_t allocate(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    hipError_t allocate(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -1028,6 +1121,131 @@ struct StageClock {
     void stage(const char* name)
     {
         if (on) fprintf(stderr, "[em2 timing]   label propagation: %s %.1f ms\n", name, lap());
+    }
+};
+
+// The visiting orders of the iterations (CellGraph.cpp:480-489: one std::mt19937 seeded once, one std::shuffle of the vertices
+// in ascending cell id per iteration -- libstdc++'s, which is what the reference links), drawn by a thread of its own ahead of
+// the GPU: an order costs 3.4 ms of host time at a million vertices, more than an iteration without label changes costs the
+// GPU, and depends on nothing but the generator.  The orders land in pinned memory so that their upload overlaps the kernels.
+class OrderProducer {
+public:
+    OrderProducer(const uint32_t* input, uint32_t count, uint64_t seed, uint64_t iterations)
+        : input_(input), count_(count), iterations_(iterations), generator_(seed)
+    {
+        for (uint32_t*& slot : slots_) {
+            void* p = nullptr;
+            if (hipHostMalloc(&p, std::max<size_t>(size_t(count) * sizeof(uint32_t), 4), hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                p = nullptr;
+            }
+            slot = static_cast<uint32_t*>(p);
+            pinned_ = pinned_ && p != nullptr;
+        }
+        if (!pinned_) {
+            for (uint32_t*& slot : slots_) {
+                if (slot) (void)hipHostFree(slot);
+                slot = nullptr;
+            }
+            pageable_.resize(size_t(kSlots) * count);
+            for (uint32_t i = 0; i < kSlots; ++i) slots_[i] = pageable_.data() + size_t(i) * count;
+        }
+        thread_ = std::thread([this] { run(); });
+    }
+    ~OrderProducer()
+    {
+        {
+            std::lock_guard<std::mutex> guard(mutex_);
+            stop_ = true;
+        }
+        stopRequested_.store(true, std::memory_order_relaxed);
+        changed_.notify_all();
+        thread_.join();
+        if (pinned_) {
+            for (uint32_t* slot : slots_) (void)hipHostFree(slot);
+        }
+    }
+    OrderProducer(const OrderProducer&) = delete;
+    OrderProducer& operator=(const OrderProducer&) = delete;
+
+    // The order of that iteration; waits for it to be drawn.
+    const uint32_t* order(uint64_t iteration)
+    {
+        std::unique_lock<std::mutex> lock(mutex_);
+        changed_.wait(lock, [&] { return produced_ > iteration; });
+        return slots_[iteration % kSlots];
+    }
+    // The orders of the iterations below this one are no longer read (their uploads have completed).
+    void release(uint64_t iteration)
+    {
+        {
+            std::lock_guard<std::mutex> guard(mutex_);
+            released_ = std::max(released_, iteration);
+        }
+        changed_.notify_all();
+    }
+
+private:
+    static constexpr uint32_t kSlots = 4;
+    void run()
+    {
+        for (uint64_t i = 0; i < iterations_; ++i) {
+            {
+                std::unique_lock<std::mutex> lock(mutex_);
+                changed_.wait(lock, [&] { return stop_ || i < released_ + kSlots; });
+                if (stop_) return;
+            }
+            uint32_t* slot = slots_[i % kSlots];
+            std::copy(input_, input_ + count_, slot);
+            if (count_ < 65536u) {
+                std::shuffle(slot, slot + count_, generator_);
+            } else {
+                // std::shuffle itself, spelled out so that a call that has ended does not wait milliseconds for an order nobody
+                // will read: with a 32-bit generator and 65536 elements or more (range of the generator / count < count)
+                // libstdc++'s shuffle is exactly this loop over its own uniform_int_distribution<unsigned long> (bits/stl_algo.h;
+                // the paired draws only exist below that size).  The GPU tests on both sides of the limit hold it to the oracle,
+                // which calls std::shuffle.
+                typedef std::uniform_int_distribution<unsigned long> Distribution;
+                Distribution distribution;
+                for (unsigned long i = 1; i < count_; ++i) {
+                    std::swap(slot[i], slot[distribution(generator_, Distribution::param_type(0, i))]);
+                    if ((i & 0x3fffu) == 0u && stopRequested_.load(std::memory_order_relaxed)) return;
+                }
+            }
+            {
+                std::lock_guard<std::mutex> guard(mutex_);
+                produced_ = i + 1;
+            }
+            changed_.notify_all();
+        }
+    }
+    const uint32_t* input_;
+    uint32_t count_;
+    uint64_t iterations_;
+    std::mt19937 generator_;
+    uint32_t* slots_[kSlots] = {};
+    bool pinned_ = true;
+    std::vector<uint32_t> pageable_;
+    std::mutex mutex_;
+    std::condition_variable changed_;
+    uint64_t produced_ = 0, released_ = 0;
+    bool stop_ = false;
+    std::atomic<bool> stopRequested_{false};
+    std::thread thread_;
+};
+
+struct StreamHolder {
+    hipStream_t stream = nullptr;
+    hipEvent_t ready[2] = {nullptr, nullptr};
+    ~StreamHolder()
+    {
+        for (hipEvent_t e : ready) {
+            if (e) (void)hipEventDestroy(e);
+        }
+        if (stream) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
     }
 };
 
@@ -1054,6 +1272,13 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
     if (vertexCount == 0) return hipSuccess;
     StageClock clock;
     const dim3 block(256);
+    // (declared before every device buffer: the thread is joined, the copy stream drained, after the buffers are released --
+    // both only touch memory of their own by then)
+    std::unique_ptr<OrderProducer> orders(new OrderProducer(shuffleInput, vertexCount, seed, maxIterationCount));
+    StreamHolder copies;
+    EM2_TRY(hipStreamCreateWithFlags(&copies.stream, hipStreamNonBlocking));
+    for (hipEvent_t& e : copies.ready) EM2_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    clock.stage("pinned order buffers, copy stream");
 
     // ---- out_edges() of every vertex in add_edge order: a stable sort of the 2E edge ends by vertex ----
     const uint64_t slots = 2 * edgeCount;
@@ -1125,8 +1350,8 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
     Buffer dLabels, dState, dPositions, dOrder, dMeta, dArena, dControl, dScratch;
     EM2_TRY(dLabels.allocate(4 * size_t(vertexCount) * sizeof(uint32_t)));
     EM2_TRY(dState.allocate(size_t(vertexCount) * sizeof(uint64_t)));
-    EM2_TRY(dPositions.allocate(2 * size_t(vertexCount) * sizeof(uint32_t)));
-    EM2_TRY(dOrder.allocate(size_t(vertexCount) * sizeof(uint32_t)));
+    EM2_TRY(dPositions.allocate(3 * size_t(vertexCount) * sizeof(uint32_t)));
+    EM2_TRY(dOrder.allocate(2 * size_t(vertexCount) * sizeof(uint32_t)));
     EM2_TRY(dMeta.allocate(size_t(vertexCount) * sizeof(TableMeta)));
     EM2_TRY(dArena.allocate(arenaCapacity * sizeof(TableEntry)));
     EM2_TRY(dControl.allocate(4 * sizeof(uint32_t) + sizeof(unsigned long long)));
@@ -1149,19 +1374,29 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
     const char* batchText = getenv("EM2_LABEL_TICKET_BATCH");
     uint32_t ticketBatch = batchText && atoi(batchText) > 0 ? uint32_t(atoi(batchText)) : 0u;
     int blocksPerUnit = 0;
-    if (cachedForm) EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerUnit, labelPropagationCachedKernel, 256, 0));
+    if (cachedForm) EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerUnit, labelPropagationCachedKernel<true>, 256, 0));
     else EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerUnit, labelPropagationKernel, 256, 0));
     blocksPerUnit = std::max(1, std::min(blocksPerUnit, 4));
     const uint32_t waveBlocks = (vertexCount + 3u) / 4u;
     const dim3 grid(std::min<uint32_t>(waveBlocks, uint32_t(computeUnits) * uint32_t(blocksPerUnit)));
     uint32_t* label[4];
     for (int i = 0; i < 4; i++) label[i] = dLabels.as<uint32_t>() + size_t(i) * vertexCount;
-    uint32_t* position[2] = {dPositions.as<uint32_t>(), dPositions.as<uint32_t>() + vertexCount};
+    // three position arrays and two order arrays: those of iteration t + 1 are filled on the copy stream while the kernel of
+    // iteration t still reads those of t and t - 1
+    uint32_t* position[3] = {dPositions.as<uint32_t>(), dPositions.as<uint32_t>() + vertexCount, dPositions.as<uint32_t>() + 2 * size_t(vertexCount)};
+    uint32_t* orderOf[2] = {dOrder.as<uint32_t>(), dOrder.as<uint32_t>() + vertexCount};
     uint32_t* control = dControl.as<uint32_t>();
     unsigned long long* arenaTop = reinterpret_cast<unsigned long long*>(control + 4);
-    const std::vector<uint32_t> allVertices(shuffleInput, shuffleInput + vertexCount);
-    std::vector<uint32_t> shuffled[2];
     clock.stage("allocate");
+    // Order and positions of an iteration, on the copy stream, from the producer's pinned memory.
+    auto upload = [&](uint64_t iteration) -> hipError_t {
+        const uint32_t* order = orders->order(iteration);
+        EM2_TRY(hipMemcpyAsync(orderOf[iteration & 1u], order, size_t(vertexCount) * sizeof(uint32_t), hipMemcpyHostToDevice, copies.stream));
+        positionsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, copies.stream>>>(orderOf[iteration & 1u], vertexCount,
+                                                                                       position[iteration % 3u]);
+        EM2_TRY(hipGetLastError());
+        return hipEventRecord(copies.ready[iteration & 1u], copies.stream);
+    };
 
     int arenaGrowths = 0;
     for (int attempt = 0;; ++attempt) {
@@ -1174,22 +1409,20 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
         const unsigned long long top = initialEntries;
         EM2_TRY(hipMemcpyAsync(arenaTop, &top, sizeof(top), hipMemcpyHostToDevice, stream));
 
-        // :480-549.  std::mt19937 / std::shuffle are libstdc++'s, which is what the reference links; the order of
-        // one iteration is drawn while the GPU works on the previous one.
-        std::mt19937 randomGenerator(seed);
+        // :480-549.  The orders come from the producer thread; order and positions of iteration t + 1 are uploaded while the
+        // kernel of iteration t runs.
+        if (attempt > 0) {
+            EM2_TRY(hipStreamSynchronize(copies.stream));
+            orders.reset();
+            orders.reset(new OrderProducer(shuffleInput, vertexCount, seed, maxIterationCount));
+        }
         uint64_t stable = 0, iterations = 0;
         uint32_t failure = 0;
-        if (maxIterationCount > 0) {
-            shuffled[0] = allVertices;
-            std::shuffle(shuffled[0].begin(), shuffled[0].end(), randomGenerator);
-        }
-        clock.stage("first tables, first shuffle");
+        if (maxIterationCount > 0) EM2_TRY(upload(0));
+        clock.stage("first tables, first order");
         while (iterations < maxIterationCount) {
             const uint32_t t = uint32_t(iterations);
-            const std::vector<uint32_t>& order = shuffled[t & 1u];
-            EM2_TRY(hipMemcpyAsync(dOrder.p, order.data(), size_t(vertexCount) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            positionsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, stream>>>(dOrder.as<uint32_t>(), vertexCount, position[t & 1u]);
-            EM2_TRY(hipGetLastError());
+            EM2_TRY(hipStreamWaitEvent(stream, copies.ready[t & 1u], 0));
             EM2_TRY(hipMemsetAsync(control, 0, 2 * sizeof(uint32_t), stream));
             ClusterArgs args;
             args.vertexCount = vertexCount;
@@ -1197,9 +1430,9 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
             args.offsets = dOffsets.as<uint64_t>();
             args.neighbour = dNeighbour.as<uint32_t>();
             args.weight = dWeight.as<float>();
-            args.order = dOrder.as<uint32_t>();
-            args.posCur = position[t & 1u];
-            args.posPrev = position[(t + 1u) & 1u];
+            args.order = orderOf[t & 1u];
+            args.posCur = position[t % 3u];
+            args.posPrev = position[(t + 2u) % 3u];
             args.labelPrev = label[t & 3u];
             args.labelPrev2 = label[(t + 3u) & 3u];
             args.labelCur = label[(t + 1u) & 3u];
@@ -1218,17 +1451,16 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
             args.diag = clock.on ? dDiag.as<unsigned long long>() : nullptr;
             EM2_TRY(hipMemsetAsync(dDiag.p, 0, kDiagWords * sizeof(unsigned long long), stream));
 #endif
-            if (cachedForm) labelPropagationCachedKernel<<<grid, block, 0, stream>>>(args);
+            if (cachedForm && ticketBatch == 0u) labelPropagationCachedKernel<true><<<grid, block, 0, stream>>>(args);
+            else if (cachedForm) labelPropagationCachedKernel<false><<<grid, block, 0, stream>>>(args);
             else labelPropagationKernel<<<grid, block, 0, stream>>>(args);
             EM2_TRY(hipGetLastError());
             ++iterations;
-            if (iterations < maxIterationCount) {
-                shuffled[iterations & 1u] = allVertices;
-                std::shuffle(shuffled[iterations & 1u].begin(), shuffled[iterations & 1u].end(), randomGenerator);
-            }
+            if (iterations < maxIterationCount) EM2_TRY(upload(iterations));
             uint32_t result[3] = {0, 0, 0};
             EM2_TRY(hipMemcpyAsync(result, control, sizeof(result), hipMemcpyDeviceToHost, stream));
             EM2_TRY(hipStreamSynchronize(stream));
+            orders->release(iterations);          // the kernel that waited for this order's upload has completed
             if (clock.on) fprintf(stderr, "[em2 timing]   label propagation: iteration %u, %u changes, %.1f ms\n", t, result[1], clock.lap());
 #ifdef EM2_DIAG
             if (clock.on) {

@@ -85,6 +85,9 @@ def test_matches_oracle(lib, oracle, vertex_count, degree, clusters, tie_levels,
     (6000, 6, 8, 3, 2500, 0, 4, 231),         # ... and tables longer than one 64-entry chunk, relocated when they grow
     (3000, 8, 6, 2, 200, 400, 0, 231),        # parallel edges: equal event times, duplicate clusters in a first table
     (60000, 20, 64, 0, 0, 0, 0, 231),
+    (65535, 6, 30, 2, 700, 0, 0, 3),          # std::shuffle draws in pairs below 65536 elements ...
+    (65536, 6, 30, 0, 0, 0, 0, 3),            # ... and one at a time from there on (the order producer spells that loop out)
+    (70001, 8, 50, 3, 900, 50, 2, 17),        # hub tables beyond the LDS area of a turn (640 entries)
 ])
 def test_large_graphs_match_oracle(lib, oracle, vertex_count, degree, clusters, hubs, hub_degree, parallel_edges, tie_levels, seed):
     rng = np.random.default_rng(vertex_count + degree + hubs)
@@ -110,6 +113,18 @@ def test_ticket_schedule_matches_too(lib, oracle, monkeypatch, batch):
     monkeypatch.setenv("EM2_LABEL_TICKET_BATCH", batch)
     rng = np.random.default_rng(11)
     cells, v0, v1, sim = fast_graph(rng, 20000, 10, 16, 2, 200)
+    got, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim)
+    expected, expected_iterations = oracle.label_propagation(cells, v0, v1, sim)
+    assert iterations == expected_iterations and np.array_equal(got, expected)
+
+
+@pytest.mark.parametrize("hub_degree,parallel_edges", [(300, 0), (2500, 100)])
+def test_global_memory_form_matches_too(lib, oracle, monkeypatch, hub_degree, parallel_edges):
+    # EM2_LABEL_FORM=global: round 2's kernel (tables searched in global memory; candidates of hubs staged there), kept for A/B
+    # runs and as the form the LDS kernel falls back on for tables and candidate lists beyond its areas.
+    monkeypatch.setenv("EM2_LABEL_FORM", "global")
+    rng = np.random.default_rng(12)
+    cells, v0, v1, sim = fast_graph(rng, 20000, 10, 16, 3, hub_degree, parallel_edges)
     got, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim)
     expected, expected_iterations = oracle.label_propagation(cells, v0, v1, sim)
     assert iterations == expected_iterations and np.array_equal(got, expected)
