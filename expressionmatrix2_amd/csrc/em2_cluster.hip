@@ -76,6 +76,20 @@ struct Candidate {
     uint32_t known;
 };
 
+// The LDS form of the kernel reads what it needs of a neighbour with ONE 16-byte gather (+ its turn word from the same 64 bytes)
+// instead of five 4-byte gathers from five arrays: a turn without events is bound by exactly that traffic.  Two arrays of records
+// alternate: the turns of iteration t read records[t & 1] and write the label fields and their own position into
+// records[(t + 1) & 1], whose posCur the positions kernel of iteration t + 1 fills (other bytes of the same record).  A stale
+// turn word is that of iteration t - 2 and never equals (t + 1).
+struct alignas(32) VertexRecord {
+    uint32_t labelPrev;     // the label after the previous iteration
+    uint32_t labelPrev2;    // ... and after the one before
+    uint32_t posPrev;       // position in the previous iteration's order
+    uint32_t posCur;        // position in this iteration's order
+    uint64_t turn;          // (iteration + 1) << 32 | label once the vertex has had its turn in this iteration
+    uint64_t unused;
+};
+
 struct ClusterArgs {
     uint32_t vertexCount;
     uint32_t iteration;
@@ -89,6 +103,8 @@ struct ClusterArgs {
     const uint32_t* labelPrev2;
     uint32_t* labelCur;
     uint64_t* state;
+    const VertexRecord* records;    // LDS form only: this iteration's records ...
+    VertexRecord* recordsNext;      // ... and the next one's
     TableMeta* meta;
     TableEntry* arena;
     unsigned long long* arenaTop;
@@ -231,9 +247,8 @@ __device__ __forceinline__ bool applyEvent(TableMeta& t, const ClusterArgs& args
 }
 
 // Waits until the vertex has had its turn in this iteration; returns its label, or sets failed.
-__device__ __forceinline__ uint32_t labelAfterTurn(const ClusterArgs& args, uint32_t vertex, bool& failed LP_DIAG_PARAM)
+__device__ __forceinline__ uint32_t labelAfterTurnAt(const ClusterArgs& args, const uint64_t* word, bool& failed LP_DIAG_PARAM)
 {
-    const uint64_t* word = args.state + vertex;
     const uint32_t want = args.iteration + 1u;
     // (every value that steers the loop goes through readfirstlane: the compiler must see the polling as uniform control flow,
     // or everything live across it -- the table's size, its mode, the error -- ends up in vector registers behind exec masks)
@@ -261,6 +276,11 @@ __device__ __forceinline__ uint32_t labelAfterTurn(const ClusterArgs& args, uint
 #endif
     }
     return uniform(uint32_t(s));
+}
+
+__device__ __forceinline__ uint32_t labelAfterTurn(const ClusterArgs& args, uint32_t vertex, bool& failed LP_DIAG_PARAM)
+{
+    return labelAfterTurnAt(args, args.state + vertex, failed LP_DIAG_PASS);
 }
 
 // Bitonic sort of n (a power of two) 64-bit keys in global memory by one wave: the candidate events of a vertex of
@@ -755,8 +775,9 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
         h.base = args.offsets[vertex];
         h.end = args.offsets[vertex + 1];
         h.t = args.meta[vertex];
-        h.label = args.labelPrev[vertex];
-        h.posPrev = args.posPrev[vertex];               // (of iteration 0: not used)
+        const uint4 own = *reinterpret_cast<const uint4*>(args.records + vertex);
+        h.label = own.x;
+        h.posPrev = own.z;                              // (of iteration 0: not used)
         return h;
     };
     auto pickUp = [&](const RawHeader& raw) -> Header {
@@ -837,20 +858,17 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
             // ---- one neighbour per lane; both candidate lists stay in registers ----
             uint32_t labelU = 0, beforeU = 0, keyA = kNone, keyB = kNone;
             if (lane < degree) {
-                labelU = args.labelPrev[u];
-                if (later) {
-                    beforeU = args.labelPrev2[u];
-                    const uint32_t pp = args.posPrev[u];
-                    if (labelU != beforeU && pp > posPrevV) keyA = pp;
-                }
-                const uint32_t pc = args.posCur[u];
-                if (pc < p) keyB = pc;
+                const uint4 r = *reinterpret_cast<const uint4*>(args.records + u);
+                labelU = r.x;
+                beforeU = r.y;
+                if (later && labelU != beforeU && r.z > posPrevV) keyA = r.z;
+                if (r.w < p) keyB = r.w;
             }
             // First look at the earlier neighbours, all at once: most have had their turn and kept their label.
             uint32_t afterU = 0;
             bool known = false;
             if (keyB != kNone) {
-                const uint64_t s = __hip_atomic_load(args.state + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t s = __hip_atomic_load(&args.records[u].turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 known = uint32_t(s >> 32) == want;
                 afterU = uint32_t(s);
                 if (known && afterU == labelU) keyB = kNone;
@@ -877,7 +895,7 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
                         newLabel = laneValue(after, owner);
                     } else {
                         bool failed = false;
-                        newLabel = labelAfterTurn(args, laneValue(u, owner), failed LP_DIAG_PASS);
+                        newLabel = labelAfterTurnAt(args, &args.records[laneValue(u, owner)].turn, failed LP_DIAG_PASS);
                         if (failed) {
                             error = 1;
                             break;
@@ -907,15 +925,16 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
                     uint32_t key = 0;
                     if (i < degree) {
                         const uint32_t u = args.neighbour[base + i];
+                        const uint4 r = *reinterpret_cast<const uint4*>(args.records + u);
                         if (phase == 0) {
-                            key = args.posPrev[u];
-                            candidate = key > posPrevV && args.labelPrev[u] != args.labelPrev2[u];
+                            key = r.z;
+                            candidate = key > posPrevV && r.x != r.y;
                         } else {
-                            key = args.posCur[u];
+                            key = r.w;
                             candidate = key < p;
                             if (candidate) {
-                                const uint64_t s = __hip_atomic_load(args.state + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (uint32_t(s >> 32) == want && uint32_t(s) == args.labelPrev[u]) candidate = false;
+                                const uint64_t s = __hip_atomic_load(&args.records[u].turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (uint32_t(s >> 32) == want && uint32_t(s) == r.x) candidate = false;
                             }
                         }
                     }
@@ -957,12 +976,13 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
                         const uint32_t index = uint32_t(entry);
                         u = args.neighbour[base + index];
                         w = args.weight[base + index];
+                        const uint4 r = *reinterpret_cast<const uint4*>(args.records + u);
                         if (phase == 0) {
-                            before = args.labelPrev2[u];
-                            after = args.labelPrev[u];
+                            before = r.y;
+                            after = r.x;
                         } else {
-                            before = args.labelPrev[u];
-                            const uint64_t s = __hip_atomic_load(args.state + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            before = r.x;
+                            const uint64_t s = __hip_atomic_load(&args.records[u].turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             known = uint32_t(s >> 32) == want;
                             after = uint32_t(s);
                         }
@@ -976,7 +996,7 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
                             newLabel = laneValue(after, int(j));
                         } else {
                             bool failed = false;
-                            newLabel = labelAfterTurn(args, laneValue(u, int(j)), failed LP_DIAG_PASS);
+                            newLabel = labelAfterTurnAt(args, &args.records[laneValue(u, int(j))].turn, failed LP_DIAG_PASS);
                             if (failed) {
                                 error = 1;
                                 break;
@@ -1005,6 +1025,7 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
         }
 
         // ---- the turn proper (CellGraph.cpp:507-524) ----
+        const uint32_t labelBefore = label;
         const bool change = c.t.size != 0u && label != c.t.best;
         if (change) {
             label = c.t.best;
@@ -1021,9 +1042,14 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
             rawVertexC = rawVertexD;
         }
         if (lane == 0u) {
-            args.labelCur[v] = label;
+            // the next iteration's record of this vertex: its labels and this position (posCur is the positions kernel's)
+            uint32_t* nextRecord = reinterpret_cast<uint32_t*>(args.recordsNext + v);
+            nextRecord[0] = label;
+            nextRecord[1] = labelBefore;
+            nextRecord[2] = p;
             args.meta[v] = c.t;
-            __hip_atomic_store(args.state + v, (uint64_t(want) << 32) | label, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(const_cast<uint64_t*>(&args.records[v].turn), (uint64_t(want) << 32) | label, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
         if (c.mode == 1u && c.dirty) {
             waveSync();
@@ -1075,6 +1101,42 @@ positionsKernel(const uint32_t* __restrict__ order, uint32_t count, uint32_t* __
     if (p < count) position[order[p]] = p;
 }
 
+__global__ void __launch_bounds__(256)
+recordPositionsKernel(const uint32_t* __restrict__ order, uint32_t count, VertexRecord* __restrict__ records)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < count) records[order[p]].posCur = p;
+}
+
+__global__ void __launch_bounds__(256)
+initialRecordsKernel(const uint32_t* __restrict__ vertexCellIds, uint32_t count, VertexRecord* __restrict__ first, VertexRecord* __restrict__ second)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= count) return;
+    // posCur is the positions kernels' field, written on another stream (that of the second iteration possibly before this
+    // kernel has run): leave it alone in both records
+    const uint32_t cell = vertexCellIds[v];
+    uint32_t* a = reinterpret_cast<uint32_t*>(first + v);
+    uint32_t* b = reinterpret_cast<uint32_t*>(second + v);
+    a[0] = cell;
+    a[1] = cell;
+    a[2] = 0u;
+    a[4] = 0u;
+    a[5] = 0u;
+    b[0] = 0u;
+    b[1] = 0u;
+    b[2] = 0u;
+    b[4] = 0u;
+    b[5] = 0u;
+}
+
+__global__ void __launch_bounds__(256)
+recordLabelsKernel(const VertexRecord* __restrict__ records, uint32_t count, uint32_t* __restrict__ labels)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < count) labels[v] = records[v].labelPrev;
+}
+
 // The two ends of edge e are records 2e and 2e+1: key = the vertex whose list the record joins.
 __global__ void __launch_bounds__(256)
 edgeEndsKernel(const uint32_t* __restrict__ edge0, const uint32_t* __restrict__ edge1, uint32_t slots,
@@ -1100,10 +1162,46 @@ adjacencyKernel(const uint32_t* __restrict__ endsSorted, uint32_t slots, const u
     weight[j] = similarity[r >> 1];
 }
 
+// A buffer of its own, or a 256-byte aligned piece of a Pool: releasing device memory is what costs (a dozen hipFree calls on
+// 1.5 GB took 3 ms of a 58 ms call), so the buffers of one phase share one allocation.
+struct Pool {
+    char* base = nullptr;
+    size_t size = 0, used = 0;
+    ~Pool() { if (base) (void)hipFree(base); }
+    hipError_t reserve(size_t bytes)
+    {
+        size = bytes;
+        return hipMalloc(reinterpret_cast<void**>(&base), bytes ? bytes : 16);
+    }
+    static size_t rounded(size_t bytes) { return (std::max<size_t>(bytes, 16) + 255u) & ~size_t(255); }
+};
+
 struct Buffer {
     void* p = nullptr;
-    ~Buffer() { if (p) (void)hipFree(p); }
-    hipError_t allocate(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    bool owned = false;
+    ~Buffer() { release(); }
+    void release()
+    {
+        if (p && owned) (void)hipFree(p);
+        p = nullptr;
+        owned = false;
+    }
+    hipError_t allocate(size_t bytes)
+    {
+        owned = true;
+        return hipMalloc(&p, bytes ? bytes : 16);
+    }
+    hipError_t allocate(Pool& pool, size_t bytes)
+    {
+        const size_t need = Pool::rounded(bytes);
+        if (pool.base && pool.used + need <= pool.size) {
+            p = pool.base + pool.used;
+            pool.used += need;
+            owned = false;
+            return hipSuccess;
+        }
+        return allocate(bytes);
+    }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -1133,20 +1231,12 @@ public:
     OrderProducer(const uint32_t* input, uint32_t count, uint64_t seed, uint64_t iterations)
         : input_(input), count_(count), iterations_(iterations), generator_(seed)
     {
-        for (uint32_t*& slot : slots_) {
-            void* p = nullptr;
-            if (hipHostMalloc(&p, std::max<size_t>(size_t(count) * sizeof(uint32_t), 4), hipHostMallocDefault) != hipSuccess) {
-                (void)hipGetLastError();
-                p = nullptr;
-            }
-            slot = static_cast<uint32_t*>(p);
-            pinned_ = pinned_ && p != nullptr;
-        }
-        if (!pinned_) {
-            for (uint32_t*& slot : slots_) {
-                if (slot) (void)hipHostFree(slot);
-                slot = nullptr;
-            }
+        // one pinned block for all slots, kept by the process between calls (pinning and unpinning 32 MB costs milliseconds)
+        const size_t bytes = std::max<size_t>(size_t(kSlots) * count * sizeof(uint32_t), 64);
+        block_ = pinnedPool().take(bytes);
+        if (block_) {
+            for (uint32_t i = 0; i < kSlots; ++i) slots_[i] = static_cast<uint32_t*>(block_) + size_t(i) * count;
+        } else {
             pageable_.resize(size_t(kSlots) * count);
             for (uint32_t i = 0; i < kSlots; ++i) slots_[i] = pageable_.data() + size_t(i) * count;
         }
@@ -1161,9 +1251,7 @@ public:
         stopRequested_.store(true, std::memory_order_relaxed);
         changed_.notify_all();
         thread_.join();
-        if (pinned_) {
-            for (uint32_t* slot : slots_) (void)hipHostFree(slot);
-        }
+        if (block_) pinnedPool().give(block_, blockBytes());
     }
     OrderProducer(const OrderProducer&) = delete;
     OrderProducer& operator=(const OrderProducer&) = delete;
@@ -1186,7 +1274,49 @@ public:
     }
 
 private:
-    static constexpr uint32_t kSlots = 4;
+    static constexpr uint32_t kSlots = 8;
+    size_t blockBytes() const { return std::max<size_t>(size_t(kSlots) * count_ * sizeof(uint32_t), 64); }
+    // At most one pinned block is kept; a call that finds it taken (another thread) or too small pins its own.
+    struct PinnedPool {
+        std::mutex mutex;
+        void* kept = nullptr;
+        size_t keptBytes = 0;
+        void* take(size_t bytes)
+        {
+            {
+                std::lock_guard<std::mutex> guard(mutex);
+                if (kept && keptBytes >= bytes) {
+                    void* p = kept;
+                    kept = nullptr;
+                    return p;
+                }
+            }
+            void* p = nullptr;
+            if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            return p;
+        }
+        void give(void* p, size_t bytes)
+        {
+            void* release = p;
+            {
+                std::lock_guard<std::mutex> guard(mutex);
+                if (!kept || keptBytes < bytes) {
+                    release = kept;
+                    kept = p;
+                    keptBytes = bytes;
+                }
+            }
+            if (release) (void)hipHostFree(release);
+        }
+    };
+    static PinnedPool& pinnedPool()
+    {
+        static PinnedPool pool;
+        return pool;
+    }
     void run()
     {
         for (uint64_t i = 0; i < iterations_; ++i) {
@@ -1224,7 +1354,7 @@ private:
     uint64_t iterations_;
     std::mt19937 generator_;
     uint32_t* slots_[kSlots] = {};
-    bool pinned_ = true;
+    void* block_ = nullptr;
     std::vector<uint32_t> pageable_;
     std::mutex mutex_;
     std::condition_variable changed_;
@@ -1261,11 +1391,11 @@ struct StreamHolder {
 // vector the reference shuffles every iteration: the vertices in ascending cell id (CellGraph.cpp:484-489).  Edges
 // must not be self loops (a vertex never pulls from itself).  *error: 0 ok, 1 a wait timed out, 2 table arena
 // exhausted.  Synchronises the stream.
-hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
-                               const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount,
-                               const uint32_t* shuffleInput, uint64_t seed, uint64_t stableIterationCountThreshold,
-                               uint64_t maxIterationCount, uint32_t* labels, uint64_t* iterationCount, uint32_t* error,
-                               hipStream_t stream)
+static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
+                                          const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount,
+                                          const uint32_t* shuffleInput, uint64_t seed, uint64_t stableIterationCountThreshold,
+                                          uint64_t maxIterationCount, uint32_t* labels, uint64_t* iterationCount, uint32_t* error,
+                                          hipStream_t stream)
 {
     *iterationCount = 0;
     *error = 0;
@@ -1284,24 +1414,43 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
     const uint64_t slots = 2 * edgeCount;
     if (slots >= (1ull << 32)) return hipErrorInvalidValue;
     Buffer dOffsets, dNeighbour, dWeight, dCells, dDegree;
-    EM2_TRY(dOffsets.allocate((size_t(vertexCount) + 1) * sizeof(uint64_t)));
-    EM2_TRY(dNeighbour.allocate(slots * sizeof(uint32_t)));
-    EM2_TRY(dWeight.allocate(slots * sizeof(float)));
-    EM2_TRY(dCells.allocate(size_t(vertexCount) * sizeof(uint32_t)));
-    EM2_TRY(dDegree.allocate((size_t(vertexCount) + 1) * sizeof(uint32_t)));
+    Pool graphPool;
+    EM2_TRY(graphPool.reserve(Pool::rounded((size_t(vertexCount) + 1) * sizeof(uint64_t)) + 2 * Pool::rounded(slots * sizeof(uint32_t)) +
+                              Pool::rounded(size_t(vertexCount) * sizeof(uint32_t)) + Pool::rounded((size_t(vertexCount) + 1) * sizeof(uint32_t))));
+    EM2_TRY(dOffsets.allocate(graphPool, (size_t(vertexCount) + 1) * sizeof(uint64_t)));
+    EM2_TRY(dNeighbour.allocate(graphPool, slots * sizeof(uint32_t)));
+    EM2_TRY(dWeight.allocate(graphPool, slots * sizeof(float)));
+    EM2_TRY(dCells.allocate(graphPool, size_t(vertexCount) * sizeof(uint32_t)));
+    EM2_TRY(dDegree.allocate(graphPool, (size_t(vertexCount) + 1) * sizeof(uint32_t)));
     EM2_TRY(hipMemcpyAsync(dCells.p, vertexCellIds, size_t(vertexCount) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     EM2_TRY(hipMemsetAsync(dDegree.p, 0, (size_t(vertexCount) + 1) * sizeof(uint32_t), stream));
     uint32_t maxDegree = 0;
     if (slots) {
         Buffer dEdge0, dEdge1, dSimilarity, dKeys, dKeysSorted, dEnds, dEndsSorted, dTemp, dMax;
-        EM2_TRY(dEdge0.allocate(edgeCount * sizeof(uint32_t)));
-        EM2_TRY(dEdge1.allocate(edgeCount * sizeof(uint32_t)));
-        EM2_TRY(dSimilarity.allocate(edgeCount * sizeof(float)));
-        EM2_TRY(dKeys.allocate(slots * sizeof(uint32_t)));
-        EM2_TRY(dKeysSorted.allocate(slots * sizeof(uint32_t)));
-        EM2_TRY(dEnds.allocate(slots * sizeof(uint32_t)));
-        EM2_TRY(dEndsSorted.allocate(slots * sizeof(uint32_t)));
-        EM2_TRY(dMax.allocate(sizeof(uint32_t)));
+        uint32_t keyBits = 1;
+        while (keyBits < 32u && (1ull << keyBits) < vertexCount) ++keyBits;
+        size_t sortBytes = 0, scanBytes = 0, maxBytes = 0;
+        {
+            uint32_t* const noWords = nullptr;          // (the queries only look at types and sizes)
+            uint64_t* const noOffsets = nullptr;
+            EM2_TRY(rocprim::radix_sort_pairs(nullptr, sortBytes, noWords, noWords, noWords, noWords, size_t(slots), 0u, keyBits, stream));
+            EM2_TRY(rocprim::exclusive_scan(nullptr, scanBytes, noWords, noOffsets, uint64_t(0), size_t(vertexCount) + 1,
+                                            rocprim::plus<uint64_t>(), stream));
+            EM2_TRY(rocprim::reduce(nullptr, maxBytes, noWords, noWords, 0u, size_t(vertexCount), rocprim::maximum<uint32_t>(), stream));
+        }
+        const size_t tempBytes = std::max(sortBytes, std::max(scanBytes, maxBytes));
+        Pool edgePool;
+        EM2_TRY(edgePool.reserve(3 * Pool::rounded(edgeCount * sizeof(uint32_t)) + 4 * Pool::rounded(slots * sizeof(uint32_t)) +
+                                 Pool::rounded(sizeof(uint32_t)) + Pool::rounded(tempBytes)));
+        EM2_TRY(dEdge0.allocate(edgePool, edgeCount * sizeof(uint32_t)));
+        EM2_TRY(dEdge1.allocate(edgePool, edgeCount * sizeof(uint32_t)));
+        EM2_TRY(dSimilarity.allocate(edgePool, edgeCount * sizeof(float)));
+        EM2_TRY(dKeys.allocate(edgePool, slots * sizeof(uint32_t)));
+        EM2_TRY(dKeysSorted.allocate(edgePool, slots * sizeof(uint32_t)));
+        EM2_TRY(dEnds.allocate(edgePool, slots * sizeof(uint32_t)));
+        EM2_TRY(dEndsSorted.allocate(edgePool, slots * sizeof(uint32_t)));
+        EM2_TRY(dMax.allocate(edgePool, sizeof(uint32_t)));
+        EM2_TRY(dTemp.allocate(edgePool, tempBytes));
         EM2_TRY(hipMemcpyAsync(dEdge0.p, edgeVertex0, edgeCount * sizeof(uint32_t), hipMemcpyDefault, stream));       // (host or device arrays)
         EM2_TRY(hipMemcpyAsync(dEdge1.p, edgeVertex1, edgeCount * sizeof(uint32_t), hipMemcpyDefault, stream));       // (host or device arrays)
         EM2_TRY(hipMemcpyAsync(dSimilarity.p, edgeSimilarity, edgeCount * sizeof(float), hipMemcpyDefault, stream));       // (host or device arrays)
@@ -1309,16 +1458,6 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
         edgeEndsKernel<<<endGrid, block, 0, stream>>>(dEdge0.as<uint32_t>(), dEdge1.as<uint32_t>(), uint32_t(slots),
                                                       dKeys.as<uint32_t>(), dEnds.as<uint32_t>(), dDegree.as<uint32_t>());
         EM2_TRY(hipGetLastError());
-        uint32_t keyBits = 1;
-        while (keyBits < 32u && (1ull << keyBits) < vertexCount) ++keyBits;
-        size_t sortBytes = 0, scanBytes = 0, maxBytes = 0;
-        EM2_TRY(rocprim::radix_sort_pairs(nullptr, sortBytes, dKeys.as<uint32_t>(), dKeysSorted.as<uint32_t>(), dEnds.as<uint32_t>(),
-                                          dEndsSorted.as<uint32_t>(), size_t(slots), 0u, keyBits, stream));
-        EM2_TRY(rocprim::exclusive_scan(nullptr, scanBytes, dDegree.as<uint32_t>(), dOffsets.as<uint64_t>(), uint64_t(0),
-                                        size_t(vertexCount) + 1, rocprim::plus<uint64_t>(), stream));
-        EM2_TRY(rocprim::reduce(nullptr, maxBytes, dDegree.as<uint32_t>(), dMax.as<uint32_t>(), 0u, size_t(vertexCount),
-                                rocprim::maximum<uint32_t>(), stream));
-        EM2_TRY(dTemp.allocate(std::max(sortBytes, std::max(scanBytes, maxBytes))));
         EM2_TRY(rocprim::radix_sort_pairs(dTemp.p, sortBytes, dKeys.as<uint32_t>(), dKeysSorted.as<uint32_t>(), dEnds.as<uint32_t>(),
                                           dEndsSorted.as<uint32_t>(), size_t(slots), 0u, keyBits, stream));
         EM2_TRY(rocprim::exclusive_scan(dTemp.p, scanBytes, dDegree.as<uint32_t>(), dOffsets.as<uint64_t>(), uint64_t(0),
@@ -1347,23 +1486,34 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
         if (atoll(v) >= 0) arenaTail = uint64_t(atoll(v));
     }
     uint64_t arenaCapacity = initialEntries + arenaTail;
-    Buffer dLabels, dState, dPositions, dOrder, dMeta, dArena, dControl, dScratch;
-    EM2_TRY(dLabels.allocate(4 * size_t(vertexCount) * sizeof(uint32_t)));
-    EM2_TRY(dState.allocate(size_t(vertexCount) * sizeof(uint64_t)));
-    EM2_TRY(dPositions.allocate(3 * size_t(vertexCount) * sizeof(uint32_t)));
-    EM2_TRY(dOrder.allocate(2 * size_t(vertexCount) * sizeof(uint32_t)));
-    EM2_TRY(dMeta.allocate(size_t(vertexCount) * sizeof(TableMeta)));
-    EM2_TRY(dArena.allocate(arenaCapacity * sizeof(TableEntry)));
-    EM2_TRY(dControl.allocate(4 * sizeof(uint32_t) + sizeof(unsigned long long)));
+    Buffer dLabels, dState, dPositions, dOrder, dMeta, dArena, dControl, dScratch, dRecords, dSortKeys;
 #ifdef EM2_DIAG
     Buffer dDiag;
-    EM2_TRY(dDiag.allocate(kDiagWords * sizeof(unsigned long long)));
 #endif
-    Buffer dSortKeys;
-    if (maxDegree > 64u) {
-        if (!cachedForm) EM2_TRY(dScratch.allocate(2 * slots * sizeof(Candidate)));
-        EM2_TRY(dSortKeys.allocate(4 * slots * sizeof(uint64_t)));
+    const bool hubs = maxDegree > 64u;
+    Pool statePool;
+    EM2_TRY(statePool.reserve(Pool::rounded(4 * size_t(vertexCount) * sizeof(uint32_t)) + Pool::rounded(size_t(vertexCount) * sizeof(uint64_t)) +
+                              Pool::rounded(cachedForm ? 2 * size_t(vertexCount) * sizeof(VertexRecord) : 0) +
+                              Pool::rounded(3 * size_t(vertexCount) * sizeof(uint32_t)) + Pool::rounded(2 * size_t(vertexCount) * sizeof(uint32_t)) +
+                              Pool::rounded(size_t(vertexCount) * sizeof(TableMeta)) + Pool::rounded(64) + Pool::rounded(kDiagWords * 8) +
+                              Pool::rounded(hubs && !cachedForm ? 2 * slots * sizeof(Candidate) : 0) +
+                              Pool::rounded(hubs ? 4 * slots * sizeof(uint64_t) : 0)));
+    EM2_TRY(dLabels.allocate(statePool, 4 * size_t(vertexCount) * sizeof(uint32_t)));
+    EM2_TRY(dState.allocate(statePool, size_t(vertexCount) * sizeof(uint64_t)));
+    if (cachedForm) EM2_TRY(dRecords.allocate(statePool, 2 * size_t(vertexCount) * sizeof(VertexRecord)));
+    EM2_TRY(dPositions.allocate(statePool, 3 * size_t(vertexCount) * sizeof(uint32_t)));
+    EM2_TRY(dOrder.allocate(statePool, 2 * size_t(vertexCount) * sizeof(uint32_t)));
+    EM2_TRY(dMeta.allocate(statePool, size_t(vertexCount) * sizeof(TableMeta)));
+    EM2_TRY(dControl.allocate(statePool, 4 * sizeof(uint32_t) + sizeof(unsigned long long)));
+#ifdef EM2_DIAG
+    EM2_TRY(dDiag.allocate(statePool, kDiagWords * sizeof(unsigned long long)));
+#endif
+    if (hubs) {
+        if (!cachedForm) EM2_TRY(dScratch.allocate(statePool, 2 * slots * sizeof(Candidate)));
+        EM2_TRY(dSortKeys.allocate(statePool, 4 * slots * sizeof(uint64_t)));
     }
+    // (the tables' arena stays an allocation of its own: a run whose tables outgrow it replaces it)
+    EM2_TRY(dArena.allocate(arenaCapacity * sizeof(TableEntry)));
 
     int device = 0, computeUnits = 0;
     EM2_TRY(hipGetDevice(&device));
@@ -1385,6 +1535,7 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
     // iteration t still reads those of t and t - 1
     uint32_t* position[3] = {dPositions.as<uint32_t>(), dPositions.as<uint32_t>() + vertexCount, dPositions.as<uint32_t>() + 2 * size_t(vertexCount)};
     uint32_t* orderOf[2] = {dOrder.as<uint32_t>(), dOrder.as<uint32_t>() + vertexCount};
+    VertexRecord* recordsOf[2] = {dRecords.as<VertexRecord>(), dRecords.as<VertexRecord>() + (cachedForm ? vertexCount : 0u)};
     uint32_t* control = dControl.as<uint32_t>();
     unsigned long long* arenaTop = reinterpret_cast<unsigned long long*>(control + 4);
     clock.stage("allocate");
@@ -1392,8 +1543,13 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
     auto upload = [&](uint64_t iteration) -> hipError_t {
         const uint32_t* order = orders->order(iteration);
         EM2_TRY(hipMemcpyAsync(orderOf[iteration & 1u], order, size_t(vertexCount) * sizeof(uint32_t), hipMemcpyHostToDevice, copies.stream));
-        positionsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, copies.stream>>>(orderOf[iteration & 1u], vertexCount,
-                                                                                       position[iteration % 3u]);
+        if (cachedForm) {
+            recordPositionsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, copies.stream>>>(orderOf[iteration & 1u], vertexCount,
+                                                                                                 recordsOf[iteration & 1u]);
+        } else {
+            positionsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, copies.stream>>>(orderOf[iteration & 1u], vertexCount,
+                                                                                           position[iteration % 3u]);
+        }
         EM2_TRY(hipGetLastError());
         return hipEventRecord(copies.ready[iteration & 1u], copies.stream);
     };
@@ -1404,6 +1560,11 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
                                                         dWeight.as<float>(), dCells.as<uint32_t>(), dMeta.as<TableMeta>(),
                                                         dArena.as<TableEntry>(), label[0], dState.as<uint64_t>());
         EM2_TRY(hipGetLastError());
+        if (cachedForm) {
+            initialRecordsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, stream>>>(dCells.as<uint32_t>(), vertexCount, recordsOf[0],
+                                                                                         recordsOf[1]);
+            EM2_TRY(hipGetLastError());
+        }
         const uint32_t zero[4] = {0, 0, 0, 0};
         EM2_TRY(hipMemcpyAsync(control, zero, sizeof(zero), hipMemcpyHostToDevice, stream));
         const unsigned long long top = initialEntries;
@@ -1437,6 +1598,8 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
             args.labelPrev2 = label[(t + 3u) & 3u];
             args.labelCur = label[(t + 1u) & 3u];
             args.state = dState.as<uint64_t>();
+            args.records = recordsOf[t & 1u];
+            args.recordsNext = recordsOf[(t + 1u) & 1u];
             args.meta = dMeta.as<TableMeta>();
             args.arena = dArena.as<TableEntry>();
             args.arenaTop = arenaTop;
@@ -1493,8 +1656,7 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
             arenaCapacity = initialEntries + arenaTail;
             if (clock.on) fprintf(stderr, "[em2 timing]   label propagation: tables outgrew the arena, repeating with %llu entries\n",
                                   (unsigned long long)arenaCapacity);
-            (void)hipFree(dArena.p);
-            dArena.p = nullptr;
+            dArena.release();
             const hipError_t grown = dArena.allocate(arenaCapacity * sizeof(TableEntry));
             if (grown != hipSuccess) {
                 *iterationCount = iterations;
@@ -1509,11 +1671,31 @@ hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCou
             *error = failure;
             return hipSuccess;
         }
-        EM2_TRY(hipMemcpyAsync(labels, label[iterations & 3u], size_t(vertexCount) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (cachedForm) {
+            recordLabelsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, stream>>>(recordsOf[iterations & 1u], vertexCount, label[0]);
+            EM2_TRY(hipGetLastError());
+            EM2_TRY(hipMemcpyAsync(labels, label[0], size_t(vertexCount) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        } else {
+            EM2_TRY(hipMemcpyAsync(labels, label[iterations & 3u], size_t(vertexCount) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        }
         EM2_TRY(hipStreamSynchronize(stream));
         clock.stage("labels to the host");
         return hipSuccess;
     }
+}
+
+hipError_t runLabelPropagation(const uint32_t* vertexCellIds, uint32_t vertexCount, const uint32_t* edgeVertex0,
+                               const uint32_t* edgeVertex1, const float* edgeSimilarity, uint64_t edgeCount,
+                               const uint32_t* shuffleInput, uint64_t seed, uint64_t stableIterationCountThreshold,
+                               uint64_t maxIterationCount, uint32_t* labels, uint64_t* iterationCount, uint32_t* error,
+                               hipStream_t stream)
+{
+    StageClock whole;
+    const hipError_t status = runLabelPropagationBody(vertexCellIds, vertexCount, edgeVertex0, edgeVertex1, edgeSimilarity, edgeCount,
+                                                      shuffleInput, seed, stableIterationCountThreshold, maxIterationCount, labels,
+                                                      iterationCount, error, stream);
+    whole.stage("the whole call, buffers released");
+    return status;
 }
 
 }  // namespace em2
