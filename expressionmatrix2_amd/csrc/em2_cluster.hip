@@ -123,7 +123,7 @@ struct ClusterArgs {
 // Diagnostic build: where a wave's cycles go.  Slots: 0 draw + header loads, 1 gather (degree <= 64), 2 phase A events,
 // 3 phase B events, 4 waits for a neighbour's turn, 5 hub gather, 6 hub sort, 7 hub events, 8 the turn's stores, 9 whole wave;
 // counts: 10 events A, 11 events B, 12 waits, 13 hub turns, 14 findBest rescans, 15 table relocations.
-constexpr uint32_t kDiagWords = 16;
+constexpr uint32_t kDiagWords = 32;       // (16: ordering a turn's events, 17: applying them)
 #ifdef EM2_DIAG
 #define LP_CLOCK(slot)                                          \
     do {                                                        \
@@ -258,13 +258,18 @@ __device__ __forceinline__ uint32_t labelAfterTurnAt(const ClusterArgs& args, co
         const uint64_t lpEntered = __builtin_amdgcn_s_memtime();
         LP_COUNT(12);
 #endif
+        // A waiting wave must cost the working waves of its CU next to nothing: every instruction of the poll, and above all
+        // its branches, competes with theirs (measured: with a poll every ~130 cycles + load, 70 % of a launch's branch
+        // instructions were polls, and the working waves ran at a third of their speed).  So the polls are spaced by ~2000
+        // cycles -- a wait lasts 10^5 .. 10^6 -- and the error word and the clock are looked at every 64th poll only.
         const uint64_t start = __builtin_amdgcn_s_memrealtime();             // 100 MHz
-        for (;;) {
-            __builtin_amdgcn_s_sleep(2);
+        for (uint32_t polls = 1;; ++polls) {
+            __builtin_amdgcn_s_sleep(31);
             s = uniform(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (uint32_t(s >> 32) == want) break;
-            if (uniform(__hip_atomic_load(args.control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u ||
-                __builtin_amdgcn_s_memrealtime() - start > 400000000ull) {
+            if ((polls & 63u) == 0u &&
+                (uniform(__hip_atomic_load(args.control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u ||
+                 __builtin_amdgcn_s_memrealtime() - start > 400000000ull)) {
                 failed = true;
                 break;
             }
@@ -553,11 +558,65 @@ __device__ __forceinline__ uint32_t waveMinDpp(uint32_t x)
 __device__ __forceinline__ uint32_t laneValue(uint32_t x, int owner) { return uint32_t(__builtin_amdgcn_readlane(int(x), owner)); }
 __device__ __forceinline__ float laneValue(float x, int owner) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), owner)); }
 
+// Most tables have a few dozen entries: up to kRegisterSlots * 64 of them are held in REGISTERS for the turn (entry i in lane
+// i & 63, slot i >> 6), where an addWeight is a compare, a ballot and a predicated add -- no LDS round trip; a table that is or
+// grows larger goes through the LDS area, and beyond that through global memory.  (The slots are named members and the code
+// per slot is spelled out by EM2_TABLE_SLOTS: an array member sent the whole structure to scratch memory.)
+constexpr uint32_t kRegisterSlots = 4;
+#define EM2_TABLE_SLOTS(F) F(0, cluster0, weight0) F(1, cluster1, weight1) F(2, cluster2, weight2) F(3, cluster3, weight3)
+
 struct CachedTable {
     TableMeta t;
-    uint32_t mode;          // 0 untouched in global memory, 1 in LDS, 2 worked on in global memory (too large for the LDS area)
+    uint32_t mode;          // 0 untouched in global memory, 3 in registers, 1 in LDS, 2 worked on in global memory
     bool dirty;
+    uint32_t cluster0, cluster1, cluster2, cluster3;        // mode 3: kNone where the table has no entry
+    float weight0, weight1, weight2, weight3;
 };
+
+// findBestCluster over the registers: the first entry holding the largest weight, if above -1.
+__device__ __forceinline__ void registerFindBest(CachedTable& c, uint32_t lane)
+{
+    float bestWeight = -1.f;
+    uint32_t bestIndex = kNone;
+#define EM2_SLOT(SLOT, CLUSTER, WEIGHT)                                   \
+    if (SLOT * 64u + lane < c.t.size && c.WEIGHT > bestWeight) {          \
+        bestWeight = c.WEIGHT;                                            \
+        bestIndex = SLOT * 64u + lane;                                    \
+    }
+    EM2_TABLE_SLOTS(EM2_SLOT)
+#undef EM2_SLOT
+    for (int offset = 32; offset; offset >>= 1) {
+        const float otherWeight = __shfl_xor(bestWeight, offset);
+        const uint32_t otherIndex = uint32_t(__shfl_xor(int(bestIndex), offset));
+        if (otherWeight > bestWeight || (otherWeight == bestWeight && otherIndex < bestIndex)) {
+            bestWeight = otherWeight;
+            bestIndex = otherIndex;
+        }
+    }
+    bestIndex = uniform(bestIndex);
+    if (bestIndex == kNone) {
+        c.t.best = kNone;
+        c.t.bestWeight = -1.f;
+        return;
+    }
+    uint32_t best = 0;
+#define EM2_SLOT(SLOT, CLUSTER, WEIGHT) \
+    if ((bestIndex >> 6) == SLOT) best = laneValue(c.CLUSTER, int(bestIndex & 63u));
+    EM2_TABLE_SLOTS(EM2_SLOT)
+#undef EM2_SLOT
+    c.t.best = best;
+    c.t.bestWeight = uniform(bestWeight);
+}
+
+__device__ __forceinline__ void registerFlush(const CachedTable& c, const ClusterArgs& args, uint32_t lane)
+{
+    uint2* out = reinterpret_cast<uint2*>(args.arena + c.t.begin);
+#define EM2_SLOT(SLOT, CLUSTER, WEIGHT) \
+    if (SLOT * 64u + lane < c.t.size) out[SLOT * 64u + lane] = make_uint2(c.CLUSTER, __float_as_uint(c.WEIGHT));
+    EM2_TABLE_SLOTS(EM2_SLOT)
+#undef EM2_SLOT
+}
+
 
 __device__ __forceinline__ void cachedFindBest(CachedTable& c, const uint2* table, uint32_t lane)
 {
@@ -595,6 +654,34 @@ __device__ __forceinline__ void cachedFlush(const CachedTable& c, const ClusterA
     for (uint32_t i = lane; i < c.t.size; i += 64u) out[i] = table[i];
 }
 
+// The table of the current turn leaves global memory: into registers, the LDS area, or (too large) stays where it is.
+__device__ __forceinline__ void openTable(CachedTable& c, const ClusterArgs& args, uint2* table, uint32_t lane)
+{
+    if (c.mode != 0u) return;
+    if (c.t.size <= kRegisterSlots * 64u) {
+        const uint2* in = reinterpret_cast<const uint2*>(args.arena + c.t.begin);
+#define EM2_SLOT(SLOT, CLUSTER, WEIGHT)                                                   \
+    {                                                                                     \
+        uint2 e = make_uint2(kNone, 0u);                                                  \
+        if (SLOT * 64u < c.t.size && SLOT * 64u + lane < c.t.size) e = in[SLOT * 64u + lane]; \
+        c.CLUSTER = e.x;                                                                  \
+        c.WEIGHT = __uint_as_float(e.y);                                                  \
+    }
+        EM2_TABLE_SLOTS(EM2_SLOT)
+#undef EM2_SLOT
+        c.mode = 3u;
+    } else if (c.t.size <= kCacheEntries) {
+        // begin and capacity are even (2 * degree + 8, 2 * capacity + 8), the arena 16-byte aligned: two entries per lane
+        const uint4* in = reinterpret_cast<const uint4*>(args.arena + c.t.begin);
+        uint4* out = reinterpret_cast<uint4*>(table);
+        for (uint32_t j = lane; 2u * j < c.t.size; j += 64u) out[j] = in[j];
+        c.mode = 1u;
+        waveSync();
+    } else {
+        c.mode = 2u;
+    }
+}
+
 // ClusterTable::addWeight (CellGraph.hpp:70-99) on the table of the current turn.  Returns false when the arena is exhausted.
 __device__ __forceinline__ bool cachedAddWeight(CachedTable& c, const ClusterArgs& args, uint2* table, uint32_t cluster, float weight,
                                                 uint32_t lane LP_DIAG_PARAM)
@@ -608,17 +695,65 @@ __device__ __forceinline__ bool cachedAddWeight(CachedTable& c, const ClusterArg
     c.t.bestWeight = uniform(c.t.bestWeight);
     cluster = uniform(cluster);
     weight = uniform(weight);
-    if (c.mode == 0u) {
-        if (c.t.size <= kCacheEntries) {
-            // begin and capacity are even (2 * degree + 8, 2 * capacity + 8), the arena 16-byte aligned: two entries per lane
-            const uint4* in = reinterpret_cast<const uint4*>(args.arena + c.t.begin);
-            uint4* out = reinterpret_cast<uint4*>(table);
-            for (uint32_t j = lane; 2u * j < c.t.size; j += 64u) out[j] = in[j];
-            c.mode = 1u;
-            waveSync();
-        } else {
-            c.mode = 2u;
+    openTable(c, args, table, lane);
+    if (c.mode == 3u) {
+        c.dirty = true;
+        // the first entry of that cluster, like the reference's linear search
+#define EM2_SLOT(SLOT, CLUSTER, WEIGHT)                                                   \
+    if (SLOT * 64u < c.t.size) {                                                          \
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(c.CLUSTER == cluster);          \
+        if (mask != 0ull) {                                                               \
+            const int owner = __ffsll((unsigned long long)mask) - 1;                      \
+            if (int(lane) == owner) c.WEIGHT += weight;                                   \
+            const float updated = laneValue(c.WEIGHT, owner);                             \
+            if (cluster == c.t.best) {                                                    \
+                if (weight < 0.f) {                                                       \
+                    LP_COUNT(14);                                                         \
+                    registerFindBest(c, lane);                                            \
+                } else {                                                                  \
+                    c.t.bestWeight = updated;                                             \
+                }                                                                         \
+            } else if (updated > c.t.bestWeight) {                                        \
+                c.t.best = cluster;                                                       \
+                c.t.bestWeight = updated;                                                 \
+            }                                                                             \
+            return true;                                                                  \
+        }                                                                                 \
+    }
+        EM2_TABLE_SLOTS(EM2_SLOT)
+#undef EM2_SLOT
+        if (c.t.size < kRegisterSlots * 64u) {
+            if (c.t.size == c.t.capacity) {
+                // the content is in registers: a table that outgrows its allocation only changes the address it is written back to
+                const uint32_t capacity = c.t.capacity * 2u + 8u;
+                unsigned long long at = 0;
+                if (lane == 0u) at = atomicAdd(args.arenaTop, (unsigned long long)capacity);
+                at = uniform(uint64_t(at));
+                if (at + capacity > args.arenaCapacity) return false;
+                LP_COUNT(15);
+                c.t.begin = at;
+                c.t.capacity = capacity;
+            }
+#define EM2_SLOT(SLOT, CLUSTER, WEIGHT)                                \
+    if ((c.t.size >> 6) == SLOT && lane == (c.t.size & 63u)) {        \
+        c.CLUSTER = cluster;                                           \
+        c.WEIGHT = weight;                                             \
+    }
+            EM2_TABLE_SLOTS(EM2_SLOT)
+#undef EM2_SLOT
+            ++c.t.size;
+            if (weight > c.t.bestWeight) {
+                c.t.best = cluster;
+                c.t.bestWeight = weight;
+            }
+            return true;
         }
+        // the registers are full: the table moves to the LDS area for the rest of the turn
+#define EM2_SLOT(SLOT, CLUSTER, WEIGHT) table[SLOT * 64u + lane] = make_uint2(c.CLUSTER, __float_as_uint(c.WEIGHT));
+        EM2_TABLE_SLOTS(EM2_SLOT)
+#undef EM2_SLOT
+        c.mode = 1u;
+        waveSync();
     }
     if (c.mode == 1u) {
         c.dirty = true;
@@ -699,6 +834,79 @@ __device__ __forceinline__ bool cachedApplyEvent(CachedTable& c, const ClusterAr
     return true;
 }
 
+// n label changes of neighbours (CellGraph.cpp:529-530: +weight on the new label, then -weight on the old one), held by the
+// lanes 0 .. n-1 in the order of their times, applied to the table of the current turn.  0, or the error (2: arena exhausted).
+//
+// The loop is what a turn with events spends its time in, and it is a chain of dependent scalar and vector instructions
+// executed by one wave: what counts is the NUMBER of instructions and branches per addWeight (measured: 2200 cycles per event
+// in the form that picked every event with a wave-wide minimum and went through the general addWeight).  So for a table in
+// registers the common case -- the cluster is there, in one of the first 64 entries -- is spelled out here: a compare, the
+// first set bit, a predicated add, one readlane, and the update of (best, bestWeight).
+__device__ __forceinline__ uint32_t applyBatch(CachedTable& c, const ClusterArgs& args, uint2* table, uint32_t n, uint32_t oldLabels,
+                                               uint32_t newLabels, float weights, uint32_t lane LP_DIAG_PARAM)
+{
+    openTable(c, args, table, lane);
+#ifdef EM2_DIAG
+    if (c.mode == 3u) {
+        // (what the table's load costs: wait for it here instead of at the first compare)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t lpNow = __builtin_amdgcn_s_memtime();
+        diagAcc[18] += lpNow - diagLast;
+    }
+#endif
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t oldLabel = laneValue(oldLabels, int(j)), newLabel = laneValue(newLabels, int(j));
+        const float weight = laneValue(weights, int(j));
+        if (newLabel == oldLabel) continue;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const uint32_t cluster = half ? oldLabel : newLabel;
+            const float delta = half ? -weight : weight;
+            if (c.mode == 3u) {
+#ifdef EM2_DIAG
+                const uint64_t lpOp = __builtin_amdgcn_s_memtime();
+#endif
+                const uint64_t mask = __builtin_amdgcn_ballot_w64(c.cluster0 == cluster);
+                if (mask != 0ull) {
+                    const int owner = __ffsll((unsigned long long)mask) - 1;
+                    const float sum = c.weight0 + delta;
+                    c.weight0 = int(lane) == owner ? sum : c.weight0;
+                    const float updated = laneValue(sum, owner);
+                    c.dirty = true;
+                    const bool isBest = cluster == c.t.best;
+                    if (isBest && delta < 0.f) {
+                        LP_COUNT(14);
+                        registerFindBest(c, lane);
+                    } else if (isBest || updated > c.t.bestWeight) {
+                        c.t.best = cluster;
+                        c.t.bestWeight = updated;
+                    }
+#ifdef EM2_DIAG
+                    diagAcc[20] += __builtin_amdgcn_s_memtime() - lpOp;
+                    ++diagAcc[21];
+#endif
+                    continue;
+                }
+            }
+            LP_COUNT(19);
+#ifdef EM2_DIAG
+            const uint64_t lpSlow = __builtin_amdgcn_s_memtime();
+            const uint32_t lpMode = c.mode;
+#endif
+            if (!cachedAddWeight(c, args, table, cluster, delta, lane LP_DIAG_PASS)) return 2u;
+#ifdef EM2_DIAG
+            {
+                const uint64_t spent = __builtin_amdgcn_s_memtime() - lpSlow;
+                if (lpMode == 3u) { diagAcc[24] += spent; ++diagAcc[25]; }
+                else if (lpMode == 1u) { diagAcc[26] += spent; ++diagAcc[27]; }
+                else { diagAcc[28] += spent; ++diagAcc[29]; }
+            }
+#endif
+        }
+    }
+    return 0u;
+}
+
 // Bitonic sort of n (a power of two) keys by one wave; KEYS is a pointer into LDS or into global memory (two instantiations).
 template <bool GLOBAL>
 __device__ __forceinline__ void sortKeysOfTurn(uint64_t* keys, uint32_t n, uint32_t lane)
@@ -732,10 +940,30 @@ __device__ __forceinline__ void sortHubKeys(uint64_t* keys, uint32_t count, uint
     sortKeysOfTurn<GLOBAL>(keys, padded, lane);
 }
 
-template <bool STRIDED>
-__global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs args)
+// SCHEDULE: how the positions of an iteration's order reach the waves.
+//   kScheduleTicket   positions drawn from one global ticket, ticketBatch at a time (no residency requirement; 45 ns per draw)
+//   kScheduleStrided  wave w of W takes positions w, w + W, ... and, knowing them in advance, keeps the loads of three turns in
+//                     flight.  Free, and the fastest form of an iteration WITHOUT label changes -- but every position a wave
+//                     holds ahead of time is a hostage of its current turn: while that turn waits for a neighbour (or is a
+//                     hub's), nobody can take those positions over, their dependents wait in turn, and the waits feed each
+//                     other: 40-60 % of all wave cycles in the iterations with many changes, whatever the turns themselves
+//                     cost (three rewrites of the event arithmetic changed nothing).
+//   kScheduleUnit     one block of 16 waves per compute unit; unit u of U owns positions u, u + U, ... and a wave draws ONE
+//                     position from the unit's ticket in LDS when it is free to work on it, loading nothing ahead: a turn that
+//                     waits holds up nothing but itself (clustering of 1M cells: 53.6 -> 36.6 ms on the same box).
+constexpr int kScheduleTicket = 0, kScheduleStrided = 1, kScheduleUnit = 2;
+
+template <int SCHEDULE>
+__global__ void __launch_bounds__(SCHEDULE == kScheduleUnit ? 1024 : 256) labelPropagationCachedKernel(ClusterArgs args)
 {
-    __shared__ WaveArea areas[4];
+    constexpr bool STRIDED = SCHEDULE == kScheduleStrided;          // (the loads of three turns in flight)
+    extern __shared__ __attribute__((aligned(16))) unsigned char labelLds[];
+    WaveArea* areas = reinterpret_cast<WaveArea*>(labelLds);
+    uint32_t* unitTicket = reinterpret_cast<uint32_t*>(labelLds + (blockDim.x / 64u) * sizeof(WaveArea));
+    if (SCHEDULE == kScheduleUnit) {
+        if (threadIdx.x == 0u) *unitTicket = 0u;
+        __syncthreads();
+    }
     WaveArea& area = areas[threadIdx.x / 64u];
     uint2* table = area.table;
     const uint32_t lane = threadIdx.x & 63u;
@@ -799,34 +1027,53 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
         u = args.neighbour[slot];
         w = args.weight[slot];
     };
-    uint32_t rawVertexA = 0, rawVertexB = 0, rawVertexC = 0, uA = 0;
+    // the next position of this wave under the strided schedule (beyond the order's end: clamped by the loads, ends the loop)
+    auto drawPosition = [&]() -> uint32_t {
+        const uint32_t position = next;
+        next = next < args.vertexCount ? next + waves : next;
+        return min(position, args.vertexCount);
+    };
+    uint32_t rawVertexA = 0, rawVertexB = 0, rawVertexC = 0, uA = 0, positionA = 0, positionB = 0, positionC = 0;
     float wA = 0.f;
     RawHeader rawHeaderA = {}, rawHeaderB = {};
-    if (STRIDED && next < args.vertexCount) {
-        rawVertexA = loadVertex(next);
-        rawVertexB = loadVertex(next + waves);
-        rawVertexC = loadVertex(next + 2u * waves);
+    if (STRIDED) {
+        positionA = drawPosition();
+        positionB = drawPosition();
+        positionC = drawPosition();
+        rawVertexA = loadVertex(positionA);
+        rawVertexB = loadVertex(positionB);
+        rawVertexC = loadVertex(positionC);
         rawHeaderA = loadHeader(rawVertexA);
         rawHeaderB = loadHeader(rawVertexB);
         loadNeighbour(rawHeaderA.base, uA, wA);
     }
     for (;;) {
         uint32_t p;                                   // (the schedule: see labelPropagationKernel)
-        uint32_t v, u = 0, rawVertexD = 0, uB = 0;
+        uint32_t v, u = 0, rawVertexD = 0, uB = 0, positionD = 0;
         float w = 0.f, wB = 0.f;
         Header header;
         RawHeader rawHeaderC = {};
         if (STRIDED) {
-            if (next >= args.vertexCount) break;
-            p = next;
-            next += waves;
+            if (positionA >= args.vertexCount) break;
+            p = positionA;
+            positionD = drawPosition();
             v = uniform(rawVertexA);
             header = pickUp(rawHeaderA);
             u = uA;
             w = wA;
             loadNeighbour(rawHeaderB.base, uB, wB);
             rawHeaderC = loadHeader(rawVertexC);
-            rawVertexD = loadVertex(next + 2u * waves);
+            rawVertexD = loadVertex(positionD);
+        } else if (SCHEDULE == kScheduleUnit) {
+            uint32_t t = 0;
+            if (lane == 0u) t = atomicAdd(unitTicket, 1u);
+            t = uniform(t);
+            const uint64_t position = uint64_t(blockIdx.x) + uint64_t(t) * gridDim.x;
+            if (position >= args.vertexCount) break;
+            p = uint32_t(position);
+            v = uniform(args.order[p]);
+            header = pickUp(loadHeader(v));
+            loadNeighbour(header.base, u, w);
         } else {
             if (next >= end) {
                 uint32_t first = kNone;
@@ -849,6 +1096,8 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
         c.t = header.t;
         c.mode = 0u;
         c.dirty = false;
+        c.cluster0 = c.cluster1 = c.cluster2 = c.cluster3 = kNone;
+        c.weight0 = c.weight1 = c.weight2 = c.weight3 = 0.f;
         uint32_t label = header.label;
         const uint32_t posPrevV = later ? header.posPrev : 0u;
         uint32_t error = 0;
@@ -873,42 +1122,51 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
                 afterU = uint32_t(s);
                 if (known && afterU == labelU) keyB = kNone;
             }
-            const uint64_t knownMask = __builtin_amdgcn_ballot_w64(known);
             LP_CLOCK(1);
+            // The earlier neighbours that have not had their turn yet: wait for them now, one after the other (in any order:
+            // they all hold smaller positions), so that every event of the turn is known before the first is applied.
+            uint64_t unknown = __builtin_amdgcn_ballot_w64(keyB != kNone && !known);
+            while (unknown != 0ull) {
+                const int owner = __ffsll((unsigned long long)unknown) - 1;
+                unknown &= unknown - 1ull;
+                bool failed = false;
+                const uint32_t newLabel = labelAfterTurnAt(args, &args.records[laneValue(u, owner)].turn, failed LP_DIAG_PASS);
+                if (failed) {
+                    error = 1;
+                    break;
+                }
+                if (int(lane) == owner) afterU = newLabel;
+            }
+            if (afterU == labelU) keyB = kNone;
+            LP_CLOCK(3);
             // phase 0: the events of the previous iteration that came after this vertex; phase 1: those of this iteration
-            // before it -- each in the order of their times
+            // before it -- each in the order of their times (equal times, i.e. parallel edges, in the order of the adjacency):
+            // every candidate counts the candidates before it, and the events move to the lanes of those ranks
 #pragma unroll 1
             for (int phase = 0; phase < 2 && !error; ++phase) {
-                uint32_t key = phase ? keyB : keyA;
-                const uint32_t before = phase ? labelU : beforeU;
-                const uint32_t after = phase ? afterU : labelU;
-                const uint64_t certain = phase ? knownMask : ~0ull;
-                for (;;) {
-                    const uint32_t m = waveMinDpp(key);
-                    if (m == kNone) break;
-                    const int owner = __ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(key == m)) - 1;
-                    if (int(lane) == owner) key = kNone;
-                    const uint32_t oldLabel = laneValue(before, owner);
-                    const float weight = laneValue(w, owner);
-                    uint32_t newLabel;
-                    if ((certain >> owner) & 1ull) {
-                        newLabel = laneValue(after, owner);
-                    } else {
-                        bool failed = false;
-                        newLabel = labelAfterTurnAt(args, &args.records[laneValue(u, owner)].turn, failed LP_DIAG_PASS);
-                        if (failed) {
-                            error = 1;
-                            break;
-                        }
-                    }
-                    if (phase) LP_COUNT(11);
-                    else LP_COUNT(10);
-                    if (newLabel != oldLabel && !cachedApplyEvent(c, args, table, oldLabel, newLabel, weight, lane LP_DIAG_PASS)) {
-                        error = 2;
-                        break;
-                    }
+                const uint32_t key = phase ? keyB : keyA;
+                const uint64_t candidates = __builtin_amdgcn_ballot_w64(key != kNone);
+                if (candidates == 0ull) continue;
+                const uint32_t n = uint32_t(__builtin_popcountll(candidates));
+                const uint64_t mine = (uint64_t(key) << 6) | lane;
+                uint32_t rank = 0;
+                for (uint64_t rest = candidates; rest != 0ull; rest &= rest - 1ull) {
+                    const int other = __ffsll((unsigned long long)rest) - 1;
+                    const uint64_t theirs = (uint64_t(laneValue(key, other)) << 6) | uint32_t(other);
+                    rank += theirs < mine ? 1u : 0u;
                 }
-                LP_CLOCK(2 + phase);
+                // (ds_permute: a lane that pushes names the lane that receives, and only lanes that take part receive; so the lanes
+                // without a candidate take part too and push to the lanes behind the events)
+                const int to = int((key != kNone ? rank : n + lanesBelow(~candidates)) << 2);
+                const uint32_t oldLabels = uint32_t(__builtin_amdgcn_ds_permute(to, int(phase ? labelU : beforeU)));
+                const uint32_t newLabels = uint32_t(__builtin_amdgcn_ds_permute(to, int(phase ? afterU : labelU)));
+                const float weights = __int_as_float(__builtin_amdgcn_ds_permute(to, __float_as_int(w)));
+#ifdef EM2_DIAG
+                diagAcc[phase ? 11 : 10] += n;
+#endif
+                LP_CLOCK(16);
+                error = applyBatch(c, args, table, n, oldLabels, newLabels, weights, lane LP_DIAG_PASS);
+                LP_CLOCK(17);
             }
         } else {
             LP_COUNT(13);
@@ -987,28 +1245,24 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
                             after = uint32_t(s);
                         }
                     }
-                    const uint64_t knownMask = __builtin_amdgcn_ballot_w64(known);
-                    for (uint32_t j = 0; j < n; ++j) {
-                        const uint32_t oldLabel = laneValue(before, int(j));
-                        const float weight = laneValue(w, int(j));
-                        uint32_t newLabel;
-                        if ((knownMask >> j) & 1ull) {
-                            newLabel = laneValue(after, int(j));
-                        } else {
-                            bool failed = false;
-                            newLabel = labelAfterTurnAt(args, &args.records[laneValue(u, int(j))].turn, failed LP_DIAG_PASS);
-                            if (failed) {
-                                error = 1;
-                                break;
-                            }
-                        }
-                        if (phase) LP_COUNT(11);
-                        else LP_COUNT(10);
-                        if (newLabel != oldLabel && !cachedApplyEvent(c, args, table, oldLabel, newLabel, weight, lane LP_DIAG_PASS)) {
-                            error = 2;
+                    // the neighbours that have not had their turn yet: wait for them (any order), then all events are known
+                    uint64_t unknown = __builtin_amdgcn_ballot_w64(!known);
+                    while (unknown != 0ull) {
+                        const int owner = __ffsll((unsigned long long)unknown) - 1;
+                        unknown &= unknown - 1ull;
+                        bool failed = false;
+                        const uint32_t newLabel = labelAfterTurnAt(args, &args.records[laneValue(u, owner)].turn, failed LP_DIAG_PASS);
+                        if (failed) {
+                            error = 1;
                             break;
                         }
+                        if (int(lane) == owner) after = newLabel;
                     }
+                    if (error) break;
+#ifdef EM2_DIAG
+                    diagAcc[phase ? 11 : 10] += n;
+#endif
+                    error = applyBatch(c, args, table, n, before, after, w, lane LP_DIAG_PASS);
                 }
                 LP_CLOCK(7);
             }
@@ -1040,6 +1294,9 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
             rawVertexB = rawVertexC;
             rawHeaderB = rawHeaderC;
             rawVertexC = rawVertexD;
+            positionA = positionB;
+            positionB = positionC;
+            positionC = positionD;
         }
         if (lane == 0u) {
             // the next iteration's record of this vertex: its labels and this position (posCur is the positions kernel's)
@@ -1051,7 +1308,9 @@ __global__ void __launch_bounds__(256) labelPropagationCachedKernel(ClusterArgs 
             __hip_atomic_store(const_cast<uint64_t*>(&args.records[v].turn), (uint64_t(want) << 32) | label, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (c.mode == 1u && c.dirty) {
+        if (c.mode == 3u && c.dirty) {
+            registerFlush(c, args, lane);
+        } else if (c.mode == 1u && c.dirty) {
             waveSync();
             cachedFlush(c, args, table, lane);
         }
@@ -1262,6 +1521,11 @@ public:
         std::unique_lock<std::mutex> lock(mutex_);
         changed_.wait(lock, [&] { return produced_ > iteration; });
         return slots_[iteration % kSlots];
+    }
+    bool ready(uint64_t iteration)
+    {
+        std::lock_guard<std::mutex> guard(mutex_);
+        return produced_ > iteration;
     }
     // The orders of the iterations below this one are no longer read (their uploads have completed).
     void release(uint64_t iteration)
@@ -1524,11 +1788,23 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
     const char* batchText = getenv("EM2_LABEL_TICKET_BATCH");
     uint32_t ticketBatch = batchText && atoi(batchText) > 0 ? uint32_t(atoi(batchText)) : 0u;
     int blocksPerUnit = 0;
-    if (cachedForm) EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerUnit, labelPropagationCachedKernel<true>, 256, 0));
-    else EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerUnit, labelPropagationKernel, 256, 0));
-    blocksPerUnit = std::max(1, std::min(blocksPerUnit, 4));
-    const uint32_t waveBlocks = (vertexCount + 3u) / 4u;
-    const dim3 grid(std::min<uint32_t>(waveBlocks, uint32_t(computeUnits) * uint32_t(blocksPerUnit)));
+    // EM2_LABEL_SCHEDULE = unit (default) / strided; EM2_LABEL_TICKET_BATCH selects the global ticket (see the kernel)
+    const char* scheduleText = getenv("EM2_LABEL_SCHEDULE");
+    bool unitSchedule = cachedForm && ticketBatch == 0u && !(scheduleText && strcmp(scheduleText, "strided") == 0);
+    const size_t areaBytes4 = 4 * sizeof(WaveArea) + 64, areaBytes16 = 16 * sizeof(WaveArea) + 64;
+    if (unitSchedule) {
+        EM2_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(labelPropagationCachedKernel<kScheduleUnit>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(areaBytes16)));
+        EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerUnit, labelPropagationCachedKernel<kScheduleUnit>, 1024, areaBytes16));
+        if (blocksPerUnit < 1) unitSchedule = false;
+    }
+    int smallBlocksPerUnit = 0;
+    if (cachedForm) EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&smallBlocksPerUnit, labelPropagationCachedKernel<kScheduleStrided>, 256, areaBytes4));
+    else EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&smallBlocksPerUnit, labelPropagationKernel, 256, 0));
+    smallBlocksPerUnit = std::max(1, std::min(smallBlocksPerUnit, 4));
+    // 256-thread blocks (strided or ticket schedule, the older kernel, the first tables) and one 1024-thread block per unit
+    const dim3 grid(std::min<uint32_t>((vertexCount + 3u) / 4u, uint32_t(computeUnits) * uint32_t(smallBlocksPerUnit)));
+    const dim3 unitGrid(std::min<uint32_t>((vertexCount + 15u) / 16u, uint32_t(computeUnits)));
     uint32_t* label[4];
     for (int i = 0; i < 4; i++) label[i] = dLabels.as<uint32_t>() + size_t(i) * vertexCount;
     // three position arrays and two order arrays: those of iteration t + 1 are filled on the copy stream while the kernel of
@@ -1614,12 +1890,19 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
             args.diag = clock.on ? dDiag.as<unsigned long long>() : nullptr;
             EM2_TRY(hipMemsetAsync(dDiag.p, 0, kDiagWords * sizeof(unsigned long long), stream));
 #endif
-            if (cachedForm && ticketBatch == 0u) labelPropagationCachedKernel<true><<<grid, block, 0, stream>>>(args);
-            else if (cachedForm) labelPropagationCachedKernel<false><<<grid, block, 0, stream>>>(args);
+            if (unitSchedule) labelPropagationCachedKernel<kScheduleUnit><<<unitGrid, dim3(1024), areaBytes16, stream>>>(args);
+            else if (cachedForm && ticketBatch == 0u) labelPropagationCachedKernel<kScheduleStrided><<<grid, block, areaBytes4, stream>>>(args);
+            else if (cachedForm) labelPropagationCachedKernel<kScheduleTicket><<<grid, block, areaBytes4, stream>>>(args);
             else labelPropagationKernel<<<grid, block, 0, stream>>>(args);
             EM2_TRY(hipGetLastError());
             ++iterations;
-            if (iterations < maxIterationCount) EM2_TRY(upload(iterations));
+            // the next order goes up while this kernel runs -- if it has been drawn already: this iteration may be the last, and
+            // then nobody should wait milliseconds for an order that is not needed
+            bool uploaded = false;
+            if (iterations < maxIterationCount && orders->ready(iterations)) {
+                EM2_TRY(upload(iterations));
+                uploaded = true;
+            }
             uint32_t result[3] = {0, 0, 0};
             EM2_TRY(hipMemcpyAsync(result, control, sizeof(result), hipMemcpyDeviceToHost, stream));
             EM2_TRY(hipStreamSynchronize(stream));
@@ -1634,7 +1917,15 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
                         "store %.1f | events A %llu B %llu, waits %llu, hub turns %llu, rescans %llu, relocations %llu, mean wave %.2f Mticks\n",
                         100 * d[0] / whole, 100 * d[1] / whole, 100 * d[2] / whole, 100 * d[3] / whole, 100 * d[4] / whole, 100 * d[5] / whole,
                         100 * d[6] / whole, 100 * d[7] / whole, 100 * d[8] / whole, d[10], d[11], d[12], d[13], d[14], d[15],
-                        whole / (double(grid.x) * 4.0) / 1e6);
+                        whole / (unitSchedule ? double(unitGrid.x) * 16.0 : double(grid.x) * 4.0) / 1e6);
+                fprintf(stderr, "[em2 timing]     LDS form, degree <= 64: ordering the events %.1f %%, applying them %.1f %% of the wave cycles (B = the first polls)\n",
+                        100 * d[16] / whole, 100 * d[17] / whole);
+                fprintf(stderr, "[em2 timing]     ... of which waiting for the table's load %.1f %%; addWeight calls that left the short path %llu\n",
+                        100 * d[18] / whole, d[19]);
+                fprintf(stderr, "[em2 timing]     general addWeight from the batch: registers %llu x %.0f cycles, LDS %llu x %.0f, global %llu x %.0f\n", d[25],
+                        d[25] ? double(d[24]) / double(d[25]) : 0.0, d[27], d[27] ? double(d[26]) / double(d[27]) : 0.0, d[29],
+                        d[29] ? double(d[28]) / double(d[29]) : 0.0);
+                fprintf(stderr, "[em2 timing]     short-path addWeight: %llu calls, %.0f cycles each between two s_memtime\n", d[21], d[21] ? double(d[20]) / double(d[21]) : 0.0);
                 clock.lap();
             }
 #endif
@@ -1644,10 +1935,12 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
             }
             stable = result[1] ? 0 : stable + 1;
             if (stable == stableIterationCountThreshold) break;
+            if (!uploaded && iterations < maxIterationCount) EM2_TRY(upload(iterations));
         }
         if (failure == 1 && ticketBatch == 0 && attempt == 0) {
             if (clock.on) fprintf(stderr, "[em2 timing]   label propagation: the strided schedule timed out, repeating with the ticket\n");
             ticketBatch = 4;
+            unitSchedule = false;
             continue;
         }
         if (failure == 2 && arenaGrowths < 6) {
