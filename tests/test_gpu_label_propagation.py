@@ -130,6 +130,18 @@ def test_global_memory_form_matches_too(lib, oracle, monkeypatch, hub_degree, pa
     assert iterations == expected_iterations and np.array_equal(got, expected)
 
 
+@pytest.mark.parametrize("hub_degree,parallel_edges", [(300, 0), (700, 100)])
+def test_strided_schedule_matches_too(lib, oracle, monkeypatch, hub_degree, parallel_edges):
+    # EM2_LABEL_SCHEDULE=strided: wave w of W takes positions w, w + W, ... and loads three turns ahead (the fastest form of an
+    # iteration without changes, the slower one overall: DESIGN.md 3.6); the default draws positions from a ticket per unit.
+    monkeypatch.setenv("EM2_LABEL_SCHEDULE", "strided")
+    rng = np.random.default_rng(13)
+    cells, v0, v1, sim = fast_graph(rng, 30000, 10, 16, 3, hub_degree, parallel_edges)
+    got, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim)
+    expected, expected_iterations = oracle.label_propagation(cells, v0, v1, sim)
+    assert iterations == expected_iterations and np.array_equal(got, expected)
+
+
 def test_tables_that_outgrow_the_arena_restart_with_a_larger_one(lib, oracle, monkeypatch):
     # EM2_LABEL_ARENA_TAIL=0: no room at all for a table to move to; the run notices, takes a larger arena and starts
     # again (twice here), with the same labels at the end.

@@ -29,22 +29,25 @@ def main():
     while time.time() < deadline:
         for key in KNOBS:
             os.environ.pop(key, None)
-        if rng.random() < 0.15 and not os.environ.get("FUZZ_ONLY"):
+        if os.environ.get("FUZZ_ONLY") == "labels" or (rng.random() < 0.15 and not os.environ.get("FUZZ_ONLY")):
             # label propagation over a random k-NN-like graph: every schedule against the serial oracle
-            vertices = int(rng.choice([2, 3, 50, 64, 65, 1000, 5000, 30000]))
-            degree = int(rng.choice([1, 2, 5, 12, 30]))
-            hubs = int(rng.choice([0, 0, 1, 4]))
+            vertices = int(rng.choice([2, 3, 50, 64, 65, 1000, 5000, 30000, 70000]))
+            degree = int(rng.choice([1, 2, 5, 12, 30, 50]))
+            hubs = int(rng.choice([0, 0, 1, 4, 30]))
             case = dict(vertices=vertices, degree=degree, clusters=int(rng.choice([1, 3, 10, 40])), hubs=min(hubs, vertices),
-                        hub_degree=int(rng.choice([70, 300, 3000])), parallel=int(rng.choice([0, 0, 5, 200])),
+                        hub_degree=int(rng.choice([70, 150, 300, 500, 700, 3000])), parallel=int(rng.choice([0, 0, 5, 200])),
                         ties=int(rng.choice([0, 0, 2, 16])), graph_seed=int(rng.integers(1 << 30)),
                         seed=int(rng.choice([231, 1, 2 ** 33 + 7])), stable=int(rng.choice([0, 1, 3])),
-                        max_iterations=int(rng.choice([0, 1, 3, 100])), ticket=str(rng.choice(["", "1", "3", "8"])))
+                        max_iterations=int(rng.choice([0, 1, 3, 100])), ticket=str(rng.choice(["", "", "1", "3", "8"])),
+                        form=str(rng.choice(["", "", "", "global"])), schedule=str(rng.choice(["", "", "strided"])))
             cells, v0, v1, s = fast_graph(np.random.default_rng(case["graph_seed"]), vertices, degree, case["clusters"],
                                           case["hubs"], case["hub_degree"], case["parallel"] if vertices > 3 else 0, case["ties"])
-            if case["ticket"]:
-                os.environ["EM2_LABEL_TICKET_BATCH"] = case["ticket"]
+            for name, key in (("EM2_LABEL_TICKET_BATCH", "ticket"), ("EM2_LABEL_FORM", "form"), ("EM2_LABEL_SCHEDULE", "schedule")):
+                if case[key]:
+                    os.environ[name] = case[key]
             got = capi.cell_graph_label_propagation(cells, v0, v1, s, case["seed"], case["stable"], case["max_iterations"])
-            os.environ.pop("EM2_LABEL_TICKET_BATCH", None)
+            for name in ("EM2_LABEL_TICKET_BATCH", "EM2_LABEL_FORM", "EM2_LABEL_SCHEDULE"):
+                os.environ.pop(name, None)
             expect = oracle.label_propagation(cells, v0, v1, s, case["seed"], case["stable"], case["max_iterations"])
             if got[1] != expect[1] or not np.array_equal(got[0], expect[0]):
                 raise SystemExit("PARITY FAILURE labels %r" % case)
