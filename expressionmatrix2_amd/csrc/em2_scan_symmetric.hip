@@ -2938,6 +2938,22 @@ hipError_t readFsp4ShardStatus(const Fsp4ShardPlan& plan, const void* rankWs, hi
     return hipSuccess;
 }
 
+// sorted[0, n) is grouped by owner = (key >> shift) & (world - 1), ascending; bounds[r] = first index whose owner >= r,
+// bounds[world] = n (the emulation's copy of the kernel of csrc/em2_dist.hip).
+__global__ void emulationOwnerBoundsKernel(const uint64_t* __restrict__ sorted, uint64_t n, uint32_t shift, uint32_t world,
+                                           uint64_t* __restrict__ bounds)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > world) return;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo) / 2u;
+        if (uint32_t((sorted[mid] >> shift) & uint64_t(world - 1u)) < r) lo = mid + 1u;
+        else hi = mid;
+    }
+    bounds[r] = lo;
+}
+
 // All ranks of the sharded scan played one after the other on this GPU (tests; EM2_SCAN_MODE=virtual with
 // EM2_VIRTUAL_WORLD=P).  *done = false: not eligible or an entry pool overflowed; the caller runs the ordered scan.
 hipError_t runFsp4ShardedEmulation(const uint32_t* sig32, uint32_t paddedDw, uint32_t cellCount, uint32_t k,
@@ -3000,19 +3016,99 @@ hipError_t runFsp4ShardedEmulation(const uint32_t* sig32, uint32_t paddedDw, uin
         if (used[r] > maxUsed) maxUsed = used[r];
     }
     uint64_t* gathered = reinterpret_cast<uint64_t*>(exchange + p0.offGathered - p0.rankBytes);
-    e = hipMemsetAsync(gathered, 0xff, size_t(maxUsed) * world * 8u, stream);
-    if (e != hipSuccess) return e;
-    for (uint32_t r = 0; r < world; ++r) {
-        if (!used[r]) continue;
-        e = hipMemcpyAsync(gathered + size_t(r) * maxUsed, base + p0.rankBytes * r + p0.offPool, size_t(used[r]) * 8u,
-                           hipMemcpyDeviceToDevice, stream);
+    // The exchange of the deferred candidates, as the product does it (csrc/em2_dist.hip, expressionmatrix2_amd/sharded.py): with a
+    // power-of-two world every rank groups its pool by the owner of the target cell (phase 4) and the groups travel by
+    // all_to_all -- a rank receives, sorts and replays only the candidates of its own cells; otherwise (or with
+    // EM2_SHARDED_EXCHANGE=gather) every rank gathers every pool.  The routed form is played with device-to-device copies
+    // through one staging area per receiver; its grouping sort is timed as phase 4.
+    const bool routed = (world & (world - 1u)) == 0u && world > 1u &&
+                        !(getenv("EM2_SHARDED_EXCHANGE") && getenv("EM2_SHARDED_EXCHANGE")[0] == 'g');
+    std::vector<uint64_t> receivedEntries(world, 0);
+    std::vector<size_t> phase4Events;
+    char* staging = nullptr;
+    struct FreeStaging { char*& p; ~FreeStaging() { if (p) (void)hipFree(p); } } stagingGuard{staging};
+    if (routed) {
+        uint64_t total = 0;
+        for (uint32_t r = 0; r < world; ++r) total += used[r];
+        e = hipMalloc(reinterpret_cast<void**>(&staging), std::max<size_t>(size_t(total) * 8u + (world + 1u) * 8u, 64));
         if (e != hipSuccess) return e;
-    }
-    for (uint32_t r = 0; r < world; ++r) {
-        mark();
-        e = launchFsp4ShardPhase(plans[r], 3, sig32, paddedDw, t, base + p0.rankBytes * r, exchange, outPairs, outUsed,
-                                 maxUsed * world, stream);
+        uint64_t* bounds = reinterpret_cast<uint64_t*>(staging + size_t(total) * 8u);
+        uint32_t rowBits = 1, ownerBits = 0;
+        while ((1ull << rowBits) < uint64_t(cellCount)) ++rowBits;
+        while ((1u << ownerBits) < world) ++ownerBits;
+        const uint32_t ownerShift = 13u + rowBits + 6u;
+        const uint64_t* sortedPool = reinterpret_cast<const uint64_t*>(exchange + p0.offSorted - p0.rankBytes);
+        // first pass: the counts matrix (what the ranks learn from the small all_gather); second pass: the copies
+        std::vector<std::vector<uint64_t>> counts(world, std::vector<uint64_t>(world, 0));
+        std::vector<std::vector<uint64_t>> starts(world, std::vector<uint64_t>(world + 1u, 0));
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<uint64_t> receiverBase(world, 0), receiverFill(world, 0);
+            if (pass == 1) {
+                uint64_t at = 0;
+                for (uint32_t q = 0; q < world; ++q) {
+                    receiverBase[q] = at;
+                    for (uint32_t r = 0; r < world; ++r) receivedEntries[q] += counts[r][q];
+                    at += receivedEntries[q];
+                }
+            }
+            for (uint32_t r = 0; r < world; ++r) {
+                if (pass == 0) {
+                    phase4Events.push_back(events.size());
+                    mark();
+                }
+                e = launchFsp4ShardPhase(plans[r], 4, sig32, paddedDw, t, base + p0.rankBytes * r, exchange, outPairs, outUsed, used[r], stream);
+                if (e != hipSuccess) return e;
+                if (pass == 0) {
+                    mark();
+                    emulationOwnerBoundsKernel<<<dim3(1), dim3(256), 0, stream>>>(sortedPool, used[r], ownerShift, world, bounds);
+                    e = hipMemcpyAsync(starts[r].data(), bounds, (world + 1u) * 8u, hipMemcpyDeviceToHost, stream);
+                    if (e != hipSuccess) return e;
+                    e = hipStreamSynchronize(stream);
+                    if (e != hipSuccess) return e;
+                    for (uint32_t q = 0; q < world; ++q) counts[r][q] = starts[r][q + 1u] - starts[r][q];
+                } else {
+                    for (uint32_t q = 0; q < world; ++q) {
+                        if (!counts[r][q]) continue;
+                        e = hipMemcpyAsync(reinterpret_cast<uint64_t*>(staging) + receiverBase[q] + receiverFill[q], sortedPool + starts[r][q],
+                                           size_t(counts[r][q]) * 8u, hipMemcpyDeviceToDevice, stream);
+                        if (e != hipSuccess) return e;
+                        receiverFill[q] += counts[r][q];
+                    }
+                }
+            }
+            if (pass == 1) {
+                for (uint32_t q = 0; q < world; ++q) {
+                    if (receivedEntries[q] > plans[q].capGathered) return hipSuccess;          // *done stays false: the callers fall back
+                }
+                for (uint32_t q = 0; q < world; ++q) {
+                    if (receivedEntries[q]) {
+                        e = hipMemcpyAsync(gathered, reinterpret_cast<uint64_t*>(staging) + receiverBase[q], size_t(receivedEntries[q]) * 8u,
+                                           hipMemcpyDeviceToDevice, stream);
+                        if (e != hipSuccess) return e;
+                    }
+                    mark();
+                    e = launchFsp4ShardPhase(plans[q], 3, sig32, paddedDw, t, base + p0.rankBytes * q, exchange, outPairs, outUsed,
+                                             receivedEntries[q], stream);
+                    if (e != hipSuccess) return e;
+                }
+            }
+        }
+    } else {
+        e = hipMemsetAsync(gathered, 0xff, size_t(maxUsed) * world * 8u, stream);
         if (e != hipSuccess) return e;
+        for (uint32_t r = 0; r < world; ++r) {
+            if (!used[r]) continue;
+            e = hipMemcpyAsync(gathered + size_t(r) * maxUsed, base + p0.rankBytes * r + p0.offPool, size_t(used[r]) * 8u,
+                               hipMemcpyDeviceToDevice, stream);
+            if (e != hipSuccess) return e;
+        }
+        for (uint32_t r = 0; r < world; ++r) {
+            mark();
+            e = launchFsp4ShardPhase(plans[r], 3, sig32, paddedDw, t, base + p0.rankBytes * r, exchange, outPairs, outUsed,
+                                     maxUsed * world, stream);
+            if (e != hipSuccess) return e;
+            receivedEntries[r] = maxUsed * world;
+        }
     }
     mark();
     e = hipStreamSynchronize(stream);
@@ -3020,8 +3116,10 @@ hipError_t runFsp4ShardedEmulation(const uint32_t* sig32, uint32_t paddedDw, uin
     if (verbose) {
         fprintf(stderr, "[em2] sharded emulation: world %u, prefix %u cells, entries per rank (max) %llu;", world, p0.prefixCells,
                 (unsigned long long)maxUsed);
+        // events: phases 0..2 are (world starts + one end) each; then, routed, a (start, end) pair per rank for the grouping
+        // sort; then the world starts + one end of phase 3
         size_t at = 0;
-        for (int phase = 0; phase < 4; ++phase) {
+        for (int phase = 0; phase < 3; ++phase) {
             fprintf(stderr, " phase %d ms:", phase);
             for (uint32_t r = 0; r < world; ++r) {
                 float ms = 0;
@@ -3029,6 +3127,24 @@ hipError_t runFsp4ShardedEmulation(const uint32_t* sig32, uint32_t paddedDw, uin
                 fprintf(stderr, " %.2f", ms);
                 ++at;
             }
+            ++at;
+        }
+        if (routed) {
+            fprintf(stderr, " grouping by owner ms:");
+            for (size_t first : phase4Events) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, events[first], events[first + 1]);
+                fprintf(stderr, " %.2f", ms);
+            }
+            at += 2u * phase4Events.size();
+        }
+        fprintf(stderr, " phase 3 (%s, entries received", routed ? "all_to_all" : "all_gather");
+        for (uint32_t r = 0; r < world; ++r) fprintf(stderr, " %llu", (unsigned long long)receivedEntries[r]);
+        fprintf(stderr, ") ms:");
+        for (uint32_t r = 0; r < world; ++r) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, events[at], events[at + 1]);
+            fprintf(stderr, " %.2f", ms);
             ++at;
         }
         fprintf(stderr, "\n");
