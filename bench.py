@@ -125,6 +125,11 @@ def device_state(device_index):
     """Clock / power / temperature as rocm-smi reports them for this GPU, or None: recorded next to the measurement so that a
     reader can tell a throttled box from a regression (the scan kernel's own in-kernel clock is in roofline.clock_ghz)."""
     import subprocess
+    # (under a profiler whose preloaded library initialises the GPU in every child, rocm-smi -- an `env python3` script -- would
+    # be an exec from a GPU-initialised process, which the GPU pool refuses: the profile has its own clock counters)
+    if any("rocprof" in os.environ.get(name, "").lower() for name in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) \
+            or any(name.startswith("ROCPROF") for name in os.environ):
+        return None
     try:
         out = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--json"],
                              capture_output=True, text=True, timeout=20)
