@@ -16,17 +16,24 @@
 // float sums, the tie decisions and the labels.  What is gained is parallelism: v only has to wait for the
 // neighbours that precede it in this iteration's order.
 //
-// Schedule: one launch per iteration; waves draw positions from one atomic ticket in shuffle order and handle one
-// vertex each.  A wave only ever waits (phase B) for vertices with smaller tickets, which running waves hold, so the
-// waits cannot deadlock whatever the grid size.  The only data shared inside a launch is state[v] = (iteration+1)<<32
-// | label, one 64-bit agent-scope atomic word, so no fences are needed; everything else a wave touches is private
-// to its vertex until the next launch.
+// Two kernels.  labelPropagationKernel is the form of rounds 1-2 (EM2_LABEL_FORM=global: tables searched in global memory,
+// five arrays gathered per neighbour, candidates of large neighbourhoods staged in global memory); labelPropagationCachedKernel
+// is the product's: the table of the vertex whose turn it is lives in registers (up to 256 entries) or LDS (up to 640) for the
+// turn, a neighbour is ONE 32-byte record, the events of a turn are ranked and applied in batches.  Both reproduce the
+// reference's addWeight sequences exactly and are held to the oracle by the same tests.
+//
+// Schedule: one launch per iteration; a wave handles one vertex at a time and only ever waits (phase B) for vertices at
+// smaller positions, which running waves hold or will draw before anything larger, so the waits cannot deadlock.  How the
+// positions reach the waves is the SCHEDULE parameter of the cached kernel (a ticket per compute unit by default; see
+// there).  The only data shared inside a launch is the turn word of a vertex, (iteration + 1) << 32 | label, one 64-bit
+// agent-scope atomic word, so no fences are needed; everything else a wave touches is private to its vertex until the next
+// launch.  The host draws the orders (std::shuffle) in a thread of its own and uploads them on a second stream.
 //
 // Layout: adjacency CSR in add_edge order (what out_edges() of adjacency_list<listS,listS,undirectedS> walks);
 // tables in one arena of (cluster, weight), 2*degree+8 entries per vertex to start with, relocated to the bump-
-// allocated tail when full (entries are never removed, as in the reference); labels of the last four iterations;
-// for vertices of degree > 64 the candidate events are staged in a scratch area addressed like the adjacency and
-// ordered by a wave-level bitonic sort.
+// allocated tail when full (entries are never removed, as in the reference); two arrays of per-vertex records alternating
+// between iterations; for vertices of degree > 64 the candidate events are sorted as (time, adjacency index) keys in LDS
+// (beyond 512 of them: in global memory).
 
 #include "em2_device.h"
 #include "em2_select_wave.h"
@@ -517,18 +524,17 @@ __global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Round 3 form of the turn: the table of the vertex whose turn it is lives in LDS for the turn.
+// The product's form of the turn (round 3).
 //
-// Measured with the diagnostic build (LP_CLOCK) at 1M vertices / 15M edges: in the iterations with many label changes a wave
-// spent 36 % of its cycles applying events -- two addWeight calls each, every one a dependent global load of the table, a
-// ballot and a store: 3000 cycles -- 8 % in the 4 % of turns whose vertex has more than 64 neighbours (tables of hundreds of
-// entries scanned from global memory 64 at a time, candidates staged and sorted in global memory), and 40-65 % WAITING for
-// such slow turns of earlier neighbours.  Here a table is read once per turn, on the first event (two entries per lane, 16
-// bytes), searched and updated in LDS (one ds_read per 128 entries), and written back once; a table that outgrows its
-// allocation only changes its address (no copy: the content is in LDS); the candidate events of a vertex of large degree are
-// sorted as (time, adjacency index) keys in LDS and their data gathered again 64 at a time; the earliest event of a small
-// neighbourhood comes out of a DPP reduction instead of six ds_bpermute.  Tables above kCacheEntries and candidate lists above
-// kHubKeys take the global-memory forms above.  EM2_LABEL_FORM=global runs the older kernel (A/B; both are tested).
+// Measured with the diagnostic build (LP_CLOCK) at 1M vertices / 15M edges, on the older kernel: in the iterations with many
+// label changes a wave spent 36 % of its cycles applying events -- two addWeight calls each, every one a dependent global
+// load of the table, a ballot and a store: 3000 cycles -- 8 % in the 4 % of turns whose vertex has more than 64 neighbours
+// (tables of hundreds of entries scanned from global memory 64 at a time, candidates staged and sorted in global memory), and
+// 40-65 % WAITING.  Here a table is read once per turn, on the first event, into registers or (two entries per lane, 16
+// bytes) into LDS, searched and updated there, and written back once; a table that outgrows its allocation only changes its
+// address (no copy: the content is on chip); the candidate events of a vertex of large degree are sorted as (time, adjacency
+// index) keys in LDS and their data gathered again 64 at a time.  Tables above kCacheEntries and candidate lists above
+// kHubKeys take the global-memory forms above.  The waits were the schedule's (see SCHEDULE below).
 constexpr uint32_t kCacheEntries = 640;
 constexpr uint32_t kHubKeys = 512;
 
@@ -536,24 +542,6 @@ struct alignas(16) WaveArea {
     uint2 table[kCacheEntries];         // (cluster, weight bits)
     uint64_t keys[kHubKeys];
 };
-
-template <uint32_t CTRL, uint32_t ROWS, uint32_t BANKS>
-__device__ __forceinline__ uint32_t dppMin(uint32_t x)
-{
-    return min(x, uint32_t(__builtin_amdgcn_update_dpp(-1, int(x), CTRL, ROWS, BANKS, false)));
-}
-
-// Smallest value of the wave (kNone where a lane has none), in every lane.
-__device__ __forceinline__ uint32_t waveMinDpp(uint32_t x)
-{
-    x = dppMin<0x111, 0xf, 0xf>(x);      // row_shr:1
-    x = dppMin<0x112, 0xf, 0xf>(x);      // row_shr:2
-    x = dppMin<0x114, 0xf, 0xf>(x);      // row_shr:4
-    x = dppMin<0x118, 0xf, 0xf>(x);      // row_shr:8: lane 15 of every row holds the row's minimum
-    x = dppMin<0x142, 0xa, 0xf>(x);      // row_bcast15 into rows 1 and 3
-    x = dppMin<0x143, 0xc, 0xf>(x);      // row_bcast31 into rows 2 and 3: lane 63 holds the minimum
-    return uint32_t(__builtin_amdgcn_readlane(int(x), 63));
-}
 
 __device__ __forceinline__ uint32_t laneValue(uint32_t x, int owner) { return uint32_t(__builtin_amdgcn_readlane(int(x), owner)); }
 __device__ __forceinline__ float laneValue(float x, int owner) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), owner)); }
@@ -820,18 +808,6 @@ __device__ __forceinline__ bool cachedAddWeight(CachedTable& c, const ClusterArg
         c.mode = 2u;
     }
     return addWeight(c.t, args, cluster, weight, lane LP_DIAG_PASS);
-}
-
-// One label change of a neighbour as the table of the current vertex sees it (CellGraph.cpp:529-530): +weight on the new
-// label, then -weight on the old one.
-__device__ __forceinline__ bool cachedApplyEvent(CachedTable& c, const ClusterArgs& args, uint2* table, uint32_t oldLabel, uint32_t newLabel,
-                                                 float weight, uint32_t lane LP_DIAG_PARAM)
-{
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        if (!cachedAddWeight(c, args, table, half ? oldLabel : newLabel, half ? -weight : weight, lane LP_DIAG_PASS)) return false;
-    }
-    return true;
 }
 
 // n label changes of neighbours (CellGraph.cpp:529-530: +weight on the new label, then -weight on the old one), held by the
