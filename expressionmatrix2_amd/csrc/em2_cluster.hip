@@ -1475,7 +1475,14 @@ public:
             pageable_.resize(size_t(kSlots) * count);
             for (uint32_t i = 0; i < kSlots; ++i) slots_[i] = pageable_.data() + size_t(i) * count;
         }
-        thread_ = std::thread([this] { run(); });
+        try {
+            const char* wanted = getenv("EM2_LABEL_ORDER_THREAD");          // (0: the fallback below, for its test)
+            if (wanted && wanted[0] == '0') throw 0;
+            thread_ = std::thread([this] { run(); });
+            threaded_ = true;
+        } catch (...) {
+            threaded_ = false;          // no thread to be had: the orders are drawn by the caller, when it asks for them
+        }
     }
     ~OrderProducer()
     {
@@ -1485,7 +1492,7 @@ public:
         }
         stopRequested_.store(true, std::memory_order_relaxed);
         changed_.notify_all();
-        thread_.join();
+        if (threaded_) thread_.join();
         if (block_) pinnedPool().give(block_, blockBytes());
     }
     OrderProducer(const OrderProducer&) = delete;
@@ -1494,12 +1501,17 @@ public:
     // The order of that iteration; waits for it to be drawn.
     const uint32_t* order(uint64_t iteration)
     {
+        if (!threaded_) {
+            while (produced_ <= iteration) draw(produced_++);
+            return slots_[iteration % kSlots];
+        }
         std::unique_lock<std::mutex> lock(mutex_);
         changed_.wait(lock, [&] { return produced_ > iteration; });
         return slots_[iteration % kSlots];
     }
     bool ready(uint64_t iteration)
     {
+        if (!threaded_) return false;
         std::lock_guard<std::mutex> guard(mutex_);
         return produced_ > iteration;
     }
@@ -1557,6 +1569,28 @@ private:
         static PinnedPool pool;
         return pool;
     }
+    // The order of iteration i into its slot; false when the call ended meanwhile.
+    bool draw(uint64_t i)
+    {
+        uint32_t* slot = slots_[i % kSlots];
+        std::copy(input_, input_ + count_, slot);
+        if (count_ < 65536u) {
+            std::shuffle(slot, slot + count_, generator_);
+        } else {
+            // std::shuffle itself, spelled out so that a call that has ended does not wait milliseconds for an order nobody
+            // will read: with a 32-bit generator and 65536 elements or more (range of the generator / count < count)
+            // libstdc++'s shuffle is exactly this loop over its own uniform_int_distribution<unsigned long> (bits/stl_algo.h;
+            // the paired draws only exist below that size).  The GPU tests on both sides of the limit hold it to the oracle,
+            // which calls std::shuffle.
+            typedef std::uniform_int_distribution<unsigned long> Distribution;
+            Distribution distribution;
+            for (unsigned long at = 1; at < count_; ++at) {
+                std::swap(slot[at], slot[distribution(generator_, Distribution::param_type(0, at))]);
+                if ((at & 0x3fffu) == 0u && stopRequested_.load(std::memory_order_relaxed)) return false;
+            }
+        }
+        return true;
+    }
     void run()
     {
         for (uint64_t i = 0; i < iterations_; ++i) {
@@ -1565,23 +1599,7 @@ private:
                 changed_.wait(lock, [&] { return stop_ || i < released_ + kSlots; });
                 if (stop_) return;
             }
-            uint32_t* slot = slots_[i % kSlots];
-            std::copy(input_, input_ + count_, slot);
-            if (count_ < 65536u) {
-                std::shuffle(slot, slot + count_, generator_);
-            } else {
-                // std::shuffle itself, spelled out so that a call that has ended does not wait milliseconds for an order nobody
-                // will read: with a 32-bit generator and 65536 elements or more (range of the generator / count < count)
-                // libstdc++'s shuffle is exactly this loop over its own uniform_int_distribution<unsigned long> (bits/stl_algo.h;
-                // the paired draws only exist below that size).  The GPU tests on both sides of the limit hold it to the oracle,
-                // which calls std::shuffle.
-                typedef std::uniform_int_distribution<unsigned long> Distribution;
-                Distribution distribution;
-                for (unsigned long i = 1; i < count_; ++i) {
-                    std::swap(slot[i], slot[distribution(generator_, Distribution::param_type(0, i))]);
-                    if ((i & 0x3fffu) == 0u && stopRequested_.load(std::memory_order_relaxed)) return;
-                }
-            }
+            if (!draw(i)) return;
             {
                 std::lock_guard<std::mutex> guard(mutex_);
                 produced_ = i + 1;
@@ -1601,6 +1619,7 @@ private:
     uint64_t produced_ = 0, released_ = 0;
     bool stop_ = false;
     std::atomic<bool> stopRequested_{false};
+    bool threaded_ = false;
     std::thread thread_;
 };
 

@@ -142,6 +142,16 @@ def test_strided_schedule_matches_too(lib, oracle, monkeypatch, hub_degree, para
     assert iterations == expected_iterations and np.array_equal(got, expected)
 
 
+def test_orders_drawn_by_the_caller_when_no_thread_can_be_had(lib, oracle, monkeypatch):
+    # EM2_LABEL_ORDER_THREAD=0 takes the path of a failed std::thread: the orders are drawn when they are asked for.
+    monkeypatch.setenv("EM2_LABEL_ORDER_THREAD", "0")
+    rng = np.random.default_rng(14)
+    cells, v0, v1, sim = fast_graph(rng, 70000, 8, 20, 2, 300)
+    got, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim)
+    expected, expected_iterations = oracle.label_propagation(cells, v0, v1, sim)
+    assert iterations == expected_iterations and np.array_equal(got, expected)
+
+
 def test_tables_that_outgrow_the_arena_restart_with_a_larger_one(lib, oracle, monkeypatch):
     # EM2_LABEL_ARENA_TAIL=0: no room at all for a table to move to; the run notices, takes a larger arena and starts
     # again (twice here), with the same labels at the end.
