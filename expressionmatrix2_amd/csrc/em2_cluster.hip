@@ -1788,10 +1788,14 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
     bool unitSchedule = cachedForm && ticketBatch == 0u && !(scheduleText && strcmp(scheduleText, "strided") == 0);
     const size_t areaBytes4 = 4 * sizeof(WaveArea) + 64, areaBytes16 = 16 * sizeof(WaveArea) + 64;
     if (unitSchedule) {
-        EM2_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(labelPropagationCachedKernel<kScheduleUnit>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(areaBytes16)));
-        EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerUnit, labelPropagationCachedKernel<kScheduleUnit>, 1024, areaBytes16));
-        if (blocksPerUnit < 1) unitSchedule = false;
+        // (a device that cannot hold a 16-wave block with its LDS areas takes the strided schedule)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(labelPropagationCachedKernel<kScheduleUnit>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(areaBytes16)) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerUnit, labelPropagationCachedKernel<kScheduleUnit>, 1024, areaBytes16) != hipSuccess ||
+            blocksPerUnit < 1) {
+            (void)hipGetLastError();
+            unitSchedule = false;
+        }
     }
     int smallBlocksPerUnit = 0;
     if (cachedForm) EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&smallBlocksPerUnit, labelPropagationCachedKernel<kScheduleStrided>, 256, areaBytes4));
