@@ -118,6 +118,7 @@ struct ClusterArgs {
     uint64_t arenaCapacity;
     uint32_t* control;          // [0] ticket, [1] label changes, [2] error (1 wait timed out, 2 arena exhausted)
     uint32_t ticketBatch;       // 0: wave w of W takes positions w, w+W, ..; else positions drawn from the ticket, this many at a time
+    uint32_t poolAreas;         // LDS form: areas in the block's pool (one per wave, or fewer: see the unit schedule)
     Candidate* scratchA;
     Candidate* scratchB;
 #ifdef EM2_DIAG
@@ -658,7 +659,7 @@ __device__ __forceinline__ void openTable(CachedTable& c, const ClusterArgs& arg
         EM2_TABLE_SLOTS(EM2_SLOT)
 #undef EM2_SLOT
         c.mode = 3u;
-    } else if (c.t.size <= kCacheEntries) {
+    } else if (c.t.size <= kCacheEntries && table != nullptr) {
         // begin and capacity are even (2 * degree + 8, 2 * capacity + 8), the arena 16-byte aligned: two entries per lane
         const uint4* in = reinterpret_cast<const uint4*>(args.arena + c.t.begin);
         uint4* out = reinterpret_cast<uint4*>(table);
@@ -736,12 +737,19 @@ __device__ __forceinline__ bool cachedAddWeight(CachedTable& c, const ClusterArg
             }
             return true;
         }
-        // the registers are full: the table moves to the LDS area for the rest of the turn
+        // the registers are full: the table moves to the LDS area for the rest of the turn -- or, for a turn that holds no
+        // area, back to global memory
+        if (table != nullptr) {
 #define EM2_SLOT(SLOT, CLUSTER, WEIGHT) table[SLOT * 64u + lane] = make_uint2(c.CLUSTER, __float_as_uint(c.WEIGHT));
-        EM2_TABLE_SLOTS(EM2_SLOT)
+            EM2_TABLE_SLOTS(EM2_SLOT)
 #undef EM2_SLOT
-        c.mode = 1u;
-        waveSync();
+            c.mode = 1u;
+            waveSync();
+        } else {
+            registerFlush(c, args, lane);
+            waveSyncGlobal();
+            c.mode = 2u;
+        }
     }
     if (c.mode == 1u) {
         c.dirty = true;
@@ -930,18 +938,22 @@ __device__ __forceinline__ void sortHubKeys(uint64_t* keys, uint32_t count, uint
 constexpr int kScheduleTicket = 0, kScheduleStrided = 1, kScheduleUnit = 2;
 
 template <int SCHEDULE>
-__global__ void __launch_bounds__(SCHEDULE == kScheduleUnit ? 1024 : 256) labelPropagationCachedKernel(ClusterArgs args)
+__global__ void __launch_bounds__(SCHEDULE == kScheduleUnit ? 1024 : 256, SCHEDULE == kScheduleUnit ? 8 : 1)  // (HIP: maximum threads per block, minimum WAVES per SIMD)
+labelPropagationCachedKernel(ClusterArgs args)
 {
     constexpr bool STRIDED = SCHEDULE == kScheduleStrided;          // (the loads of three turns in flight)
+    // LDS: the pool of areas (tables beyond the registers, keys of large neighbourhoods: 4 % of the turns need one), then the
+    // unit's ticket and the mask of free areas.  With one area per wave (256-thread blocks) a turn always gets one; a unit of
+    // 16 waves shares fewer, so that two units fit a compute unit: a turn that finds none takes the global-memory forms.
     extern __shared__ __attribute__((aligned(16))) unsigned char labelLds[];
     WaveArea* areas = reinterpret_cast<WaveArea*>(labelLds);
-    uint32_t* unitTicket = reinterpret_cast<uint32_t*>(labelLds + (blockDim.x / 64u) * sizeof(WaveArea));
-    if (SCHEDULE == kScheduleUnit) {
-        if (threadIdx.x == 0u) *unitTicket = 0u;
-        __syncthreads();
+    uint32_t* unitTicket = reinterpret_cast<uint32_t*>(labelLds + args.poolAreas * sizeof(WaveArea));
+    uint32_t* freeAreas = unitTicket + 1;
+    if (threadIdx.x == 0u) {
+        *unitTicket = 0u;
+        *freeAreas = args.poolAreas >= 32u ? 0xffffffffu : (1u << args.poolAreas) - 1u;
     }
-    WaveArea& area = areas[threadIdx.x / 64u];
-    uint2* table = area.table;
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t want = args.iteration + 1u;
     const uint32_t waves = gridDim.x * (blockDim.x / 64u);
@@ -1074,6 +1086,25 @@ __global__ void __launch_bounds__(SCHEDULE == kScheduleUnit ? 1024 : 256) labelP
         c.dirty = false;
         c.cluster0 = c.cluster1 = c.cluster2 = c.cluster3 = kNone;
         c.weight0 = c.weight1 = c.weight2 = c.weight3 = 0.f;
+        // an area of the pool for the turns that need one: a large neighbourhood, or a table beyond the registers (a table that
+        // grows beyond them during a turn without an area goes back to global memory)
+        uint32_t areaIndex = kNone;
+        if (degree > 64u || c.t.size > kRegisterSlots * 64u) {
+            if (lane == 0u) {
+                uint32_t seen = __hip_atomic_load(freeAreas, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (seen != 0u) {
+                    const uint32_t bit = seen & (0u - seen);
+                    if (__hip_atomic_compare_exchange_strong(freeAreas, &seen, seen & ~bit, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        areaIndex = uint32_t(__ffs(int(bit)) - 1);
+                        break;
+                    }
+                }
+            }
+            areaIndex = uniform(areaIndex);
+        }
+        WaveArea* const area = areaIndex != kNone ? areas + areaIndex : nullptr;
+        uint2* const table = area ? area->table : nullptr;
         uint32_t label = header.label;
         const uint32_t posPrevV = later ? header.posPrev : 0u;
         uint32_t error = 0;
@@ -1152,7 +1183,7 @@ __global__ void __launch_bounds__(SCHEDULE == kScheduleUnit ? 1024 : 256) labelP
                 // order of the adjacency.  In LDS while they fit, else in the vertex's slots of the global key area.
                 uint64_t* global = args.sortKeys + (phase ? 2u * args.slots : 0u) + 2u * base;
                 uint32_t count = 0;
-                bool inLds = true;
+                bool inLds = area != nullptr;
                 for (uint32_t first = 0; first < degree; first += 64u) {
                     const uint32_t i = first + lane;
                     bool candidate = false;
@@ -1177,12 +1208,12 @@ __global__ void __launch_bounds__(SCHEDULE == kScheduleUnit ? 1024 : 256) labelP
                     if (inLds && count + more > kHubKeys) {
                         // the list leaves LDS: what was collected so far moves to the global area
                         waveSync();
-                        for (uint32_t k = lane; k < count; k += 64u) global[k] = area.keys[k];
+                        for (uint32_t k = lane; k < count; k += 64u) global[k] = area->keys[k];
                         inLds = false;
                     }
                     if (candidate) {
                         const uint64_t entry = (uint64_t(key) << 32) | i;
-                        if (inLds) area.keys[count + lanesBelow(mask)] = entry;
+                        if (inLds) area->keys[count + lanesBelow(mask)] = entry;
                         else global[count + lanesBelow(mask)] = entry;
                     }
                     count += more;
@@ -1191,7 +1222,7 @@ __global__ void __launch_bounds__(SCHEDULE == kScheduleUnit ? 1024 : 256) labelP
                 if (count == 0u) continue;
                 if (inLds) {
                     waveSync();
-                    sortHubKeys<false>(area.keys, count, lane);
+                    sortHubKeys<false>(area->keys, count, lane);
                 } else {
                     waveSyncGlobal();
                     sortHubKeys<true>(global, count, lane);
@@ -1205,7 +1236,7 @@ __global__ void __launch_bounds__(SCHEDULE == kScheduleUnit ? 1024 : 256) labelP
                     bool known = true;
                     if (lane < n) {
                         uint64_t entry;
-                        if (inLds) entry = area.keys[first + lane];
+                        if (inLds) entry = area->keys[first + lane];
                         else entry = global[first + lane];
                         const uint32_t index = uint32_t(entry);
                         u = args.neighbour[base + index];
@@ -1289,6 +1320,10 @@ __global__ void __launch_bounds__(SCHEDULE == kScheduleUnit ? 1024 : 256) labelP
         } else if (c.mode == 1u && c.dirty) {
             waveSync();
             cachedFlush(c, args, table, lane);
+        }
+        if (areaIndex != kNone) {
+            waveSync();                                       // (the flush has read the area)
+            if (lane == 0u) __hip_atomic_fetch_or(freeAreas, 1u << areaIndex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         LP_CLOCK(8);
     }
@@ -1786,16 +1821,21 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
     // EM2_LABEL_SCHEDULE = unit (default) / strided; EM2_LABEL_TICKET_BATCH selects the global ticket (see the kernel)
     const char* scheduleText = getenv("EM2_LABEL_SCHEDULE");
     bool unitSchedule = cachedForm && ticketBatch == 0u && !(scheduleText && strcmp(scheduleText, "strided") == 0);
-    const size_t areaBytes4 = 4 * sizeof(WaveArea) + 64, areaBytes16 = 16 * sizeof(WaveArea) + 64;
+    // 256-thread blocks: an area per wave.  Units of 16 waves: a pool of kUnitAreas, so that two units fit a compute unit.
+    constexpr uint32_t kUnitAreas = 8;
+    const size_t areaBytes4 = 4 * sizeof(WaveArea) + 64, areaBytes16 = kUnitAreas * sizeof(WaveArea) + 64;
+    int unitsPerCu = 0;
     if (unitSchedule) {
         // (a device that cannot hold a 16-wave block with its LDS areas takes the strided schedule)
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(labelPropagationCachedKernel<kScheduleUnit>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(areaBytes16)) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerUnit, labelPropagationCachedKernel<kScheduleUnit>, 1024, areaBytes16) != hipSuccess ||
-            blocksPerUnit < 1) {
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&unitsPerCu, labelPropagationCachedKernel<kScheduleUnit>, 1024, areaBytes16) != hipSuccess ||
+            unitsPerCu < 1) {
             (void)hipGetLastError();
             unitSchedule = false;
         }
+        unitsPerCu = std::min(unitsPerCu, 2);
+        if (const char* text = getenv("EM2_LABEL_UNITS")) unitsPerCu = std::max(1, std::min(unitsPerCu, atoi(text)));        // (A/B)
     }
     int smallBlocksPerUnit = 0;
     if (cachedForm) EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&smallBlocksPerUnit, labelPropagationCachedKernel<kScheduleStrided>, 256, areaBytes4));
@@ -1803,7 +1843,8 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
     smallBlocksPerUnit = std::max(1, std::min(smallBlocksPerUnit, 4));
     // 256-thread blocks (strided or ticket schedule, the older kernel, the first tables) and one 1024-thread block per unit
     const dim3 grid(std::min<uint32_t>((vertexCount + 3u) / 4u, uint32_t(computeUnits) * uint32_t(smallBlocksPerUnit)));
-    const dim3 unitGrid(std::min<uint32_t>((vertexCount + 15u) / 16u, uint32_t(computeUnits)));
+    if (clock.on && unitSchedule) fprintf(stderr, "[em2 timing]   label propagation: %d unit(s) of 16 waves per compute unit\n", unitsPerCu);
+    const dim3 unitGrid(std::min<uint32_t>((vertexCount + 15u) / 16u, uint32_t(computeUnits) * uint32_t(std::max(1, unitsPerCu))));
     uint32_t* label[4];
     for (int i = 0; i < 4; i++) label[i] = dLabels.as<uint32_t>() + size_t(i) * vertexCount;
     // three position arrays and two order arrays: those of iteration t + 1 are filled on the copy stream while the kernel of
@@ -1881,6 +1922,10 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
             args.arenaCapacity = arenaCapacity;
             args.control = control;
             args.ticketBatch = ticketBatch;
+            args.poolAreas = unitSchedule ? kUnitAreas : 4u;
+            if (const char* text = getenv("EM2_LABEL_POOL_AREAS")) {          // (tests: a smaller pool, turns that find no area)
+                if (atoi(text) >= 0 && uint32_t(atoi(text)) < args.poolAreas) args.poolAreas = uint32_t(atoi(text));
+            }
             args.scratchA = dScratch.as<Candidate>();
             args.scratchB = dScratch.as<Candidate>() + slots;
             args.sortKeys = dSortKeys.as<uint64_t>();
@@ -1889,7 +1934,11 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
             args.diag = clock.on ? dDiag.as<unsigned long long>() : nullptr;
             EM2_TRY(hipMemsetAsync(dDiag.p, 0, kDiagWords * sizeof(unsigned long long), stream));
 #endif
-            if (unitSchedule) labelPropagationCachedKernel<kScheduleUnit><<<unitGrid, dim3(1024), areaBytes16, stream>>>(args);
+            if (unitSchedule) {
+                const char* wavesText = getenv("EM2_LABEL_UNIT_WAVES");          // (measurement: fewer waves per unit)
+                const uint32_t unitWaves = wavesText && atoi(wavesText) >= 1 && atoi(wavesText) <= 16 ? uint32_t(atoi(wavesText)) : 16u;
+                labelPropagationCachedKernel<kScheduleUnit><<<unitGrid, dim3(64u * unitWaves), areaBytes16, stream>>>(args);
+            }
             else if (cachedForm && ticketBatch == 0u) labelPropagationCachedKernel<kScheduleStrided><<<grid, block, areaBytes4, stream>>>(args);
             else if (cachedForm) labelPropagationCachedKernel<kScheduleTicket><<<grid, block, areaBytes4, stream>>>(args);
             else labelPropagationKernel<<<grid, block, 0, stream>>>(args);

@@ -142,6 +142,20 @@ def test_strided_schedule_matches_too(lib, oracle, monkeypatch, hub_degree, para
     assert iterations == expected_iterations and np.array_equal(got, expected)
 
 
+@pytest.mark.parametrize("areas,schedule", [("0", ""), ("1", ""), ("1", "strided")])
+def test_turns_that_find_no_lds_area_take_the_global_memory_forms(lib, oracle, monkeypatch, areas, schedule):
+    # The 16 waves of a unit share a pool of LDS areas (tables beyond the registers, keys of large neighbourhoods); a turn that
+    # finds none sorts its keys and keeps its table in global memory.  EM2_LABEL_POOL_AREAS shrinks the pool so that it happens.
+    monkeypatch.setenv("EM2_LABEL_POOL_AREAS", areas)
+    if schedule:
+        monkeypatch.setenv("EM2_LABEL_SCHEDULE", schedule)
+    rng = np.random.default_rng(15)
+    cells, v0, v1, sim = fast_graph(rng, 30000, 10, 16, 40, 400, 50)
+    got, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim)
+    expected, expected_iterations = oracle.label_propagation(cells, v0, v1, sim)
+    assert iterations == expected_iterations and np.array_equal(got, expected)
+
+
 def test_orders_drawn_by_the_caller_when_no_thread_can_be_had(lib, oracle, monkeypatch):
     # EM2_LABEL_ORDER_THREAD=0 takes the path of a failed std::thread: the orders are drawn when they are asked for.
     monkeypatch.setenv("EM2_LABEL_ORDER_THREAD", "0")

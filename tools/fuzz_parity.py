@@ -39,14 +39,16 @@ def main():
                         ties=int(rng.choice([0, 0, 2, 16])), graph_seed=int(rng.integers(1 << 30)),
                         seed=int(rng.choice([231, 1, 2 ** 33 + 7])), stable=int(rng.choice([0, 1, 3])),
                         max_iterations=int(rng.choice([0, 1, 3, 100])), ticket=str(rng.choice(["", "", "1", "3", "8"])),
-                        form=str(rng.choice(["", "", "", "global"])), schedule=str(rng.choice(["", "", "strided"])))
+                        form=str(rng.choice(["", "", "", "global"])), schedule=str(rng.choice(["", "", "strided"])),
+                        pool=str(rng.choice(["", "", "0", "1", "3"])))
             cells, v0, v1, s = fast_graph(np.random.default_rng(case["graph_seed"]), vertices, degree, case["clusters"],
                                           case["hubs"], case["hub_degree"], case["parallel"] if vertices > 3 else 0, case["ties"])
-            for name, key in (("EM2_LABEL_TICKET_BATCH", "ticket"), ("EM2_LABEL_FORM", "form"), ("EM2_LABEL_SCHEDULE", "schedule")):
+            for name, key in (("EM2_LABEL_TICKET_BATCH", "ticket"), ("EM2_LABEL_FORM", "form"), ("EM2_LABEL_SCHEDULE", "schedule"),
+                              ("EM2_LABEL_POOL_AREAS", "pool")):
                 if case[key]:
                     os.environ[name] = case[key]
             got = capi.cell_graph_label_propagation(cells, v0, v1, s, case["seed"], case["stable"], case["max_iterations"])
-            for name in ("EM2_LABEL_TICKET_BATCH", "EM2_LABEL_FORM", "EM2_LABEL_SCHEDULE"):
+            for name in ("EM2_LABEL_TICKET_BATCH", "EM2_LABEL_FORM", "EM2_LABEL_SCHEDULE", "EM2_LABEL_POOL_AREAS"):
                 os.environ.pop(name, None)
             expect = oracle.label_propagation(cells, v0, v1, s, case["seed"], case["stable"], case["max_iterations"])
             if got[1] != expect[1] or not np.array_equal(got[0], expect[0]):
