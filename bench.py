@@ -405,6 +405,8 @@ def bench_chain(args, capi, sharded, synthetic, oracle, device, torch):
 
 def main():
     args = parse_args()
+    # (the pool's driver only supports dmabuf IPC: without this RCCL fails with hipIpcGetMemHandle: invalid argument)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     from expressionmatrix2_amd import capi, sharded, synthetic
