@@ -150,7 +150,8 @@ hipError_t runCellGraphEdges(const PairOut* pairs, const uint32_t* usedCount, ui
                              const uint32_t* spCellSet, const uint32_t* graphCellSet, const uint32_t* graphSortedIds,
                              const uint32_t* graphVertexOfSorted, uint32_t graphCellCount, double similarityThreshold,
                              uint32_t maxConnectivity, uint32_t* edge0, uint32_t* edge1, float* edgeSimilarity,
-                             uint64_t* edgeCountHost, hipStream_t stream);
+                             uint64_t* edgeCountHost, hipStream_t stream, bool spConsecutive, uint32_t spFirst, bool graphConsecutive,
+                             uint32_t graphFirst);
 
 // CellGraph::labelPropagationClustering (src/CellGraph.cpp:443-612) on the device (em2_cluster.hip).  Host buffers;
 // labels[v] = the raw label (a cell id) of vertex v after the last iteration.

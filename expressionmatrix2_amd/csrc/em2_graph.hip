@@ -22,8 +22,12 @@ namespace {
 
 constexpr uint32_t kInvalid = 0xffffffffu;
 
-__device__ __forceinline__ uint32_t findSorted(const uint32_t* __restrict__ ids, uint32_t n, uint32_t id)
+// Position of id in the ascending ids[0, n), or kInvalid.  A set of consecutive ids (AllCells; any stored set without gaps:
+// ids[n - 1] - ids[0] == n - 1, which the caller passes as `consecutive`) needs no search: twenty dependent loads per look-up,
+// a hundred look-ups per vertex, were most of selectNeighboursKernel.
+__device__ __forceinline__ uint32_t findSorted(const uint32_t* __restrict__ ids, uint32_t n, uint32_t id, bool consecutive, uint32_t first)
 {
+    if (consecutive) return id - first < n ? id - first : kInvalid;
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
         const uint32_t mid = lo + (hi - lo) / 2u;
@@ -39,21 +43,25 @@ selectNeighboursKernel(const PairOut* __restrict__ pairs, const uint32_t* __rest
                        uint32_t k, const uint32_t* __restrict__ spCellSet, const uint32_t* __restrict__ graphSortedIds,
                        const uint32_t* __restrict__ graphVertexOfSorted, const uint32_t* __restrict__ graphCellSet,
                        uint32_t graphCellCount, double similarityThreshold, uint32_t maxConnectivity,
-                       uint32_t* __restrict__ selVertex, float* __restrict__ selSimilarity, uint32_t* __restrict__ selCount)
+                       uint32_t* __restrict__ selVertex, float* __restrict__ selSimilarity, uint32_t* __restrict__ selCount,
+                       bool spConsecutive, uint32_t spFirst, bool graphConsecutive, uint32_t graphFirst)
 {
     const uint32_t v0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (v0 >= graphCellCount) return;
     uint32_t n = 0;
-    const uint32_t local0 = findSorted(spCellSet, spCellCount, graphCellSet[v0]);      // getLocalCellId (:70)
+    // (a set of consecutive ids in ascending order is arithmetic: the caller passes no array for it)
+    const uint32_t id0 = graphCellSet ? graphCellSet[v0] : graphFirst + v0;
+    const uint32_t local0 = findSorted(spCellSet, spCellCount, id0, spConsecutive, spFirst);      // getLocalCellId (:70)
     if (local0 != kInvalid) {
         const PairOut* p = pairs + size_t(local0) * k;
         const uint32_t used = usedCount[local0];
         for (uint32_t j = 0; j < used; ++j) {
             const float similarity = p[j].similarity;
             if (double(similarity) < similarityThreshold) break;                        // :92
-            const uint32_t sorted1 = findSorted(graphSortedIds, graphCellCount, spCellSet[p[j].cell]);
+            const uint32_t id1 = spConsecutive ? spFirst + p[j].cell : spCellSet[p[j].cell];
+            const uint32_t sorted1 = findSorted(graphSortedIds, graphCellCount, id1, graphConsecutive, graphFirst);
             if (sorted1 == kInvalid) continue;                                          // :96-99
-            selVertex[size_t(v0) * maxConnectivity + n] = graphVertexOfSorted[sorted1];
+            selVertex[size_t(v0) * maxConnectivity + n] = graphVertexOfSorted ? graphVertexOfSorted[sorted1] : sorted1;
             selSimilarity[size_t(v0) * maxConnectivity + n] = similarity;
             if (++n == maxConnectivity) break;                                          // :101-103
         }
@@ -117,7 +125,8 @@ hipError_t runCellGraphEdges(const PairOut* pairs, const uint32_t* usedCount, ui
                              const uint32_t* spCellSet, const uint32_t* graphCellSet, const uint32_t* graphSortedIds,
                              const uint32_t* graphVertexOfSorted, uint32_t graphCellCount, double similarityThreshold,
                              uint32_t maxConnectivity, uint32_t* edge0, uint32_t* edge1, float* edgeSimilarity,
-                             uint64_t* edgeCountHost, hipStream_t stream)
+                             uint64_t* edgeCountHost, hipStream_t stream, bool spConsecutive, uint32_t spFirst, bool graphConsecutive,
+                             uint32_t graphFirst)
 {
     *edgeCountHost = 0;
     if (graphCellCount == 0 || maxConnectivity == 0) return hipSuccess;
@@ -132,7 +141,7 @@ hipError_t runCellGraphEdges(const PairOut* pairs, const uint32_t* usedCount, ui
     selectNeighboursKernel<<<grid, block, 0, stream>>>(pairs, usedCount, spCellCount, k, spCellSet, graphSortedIds,
                                                        graphVertexOfSorted, graphCellSet, graphCellCount, similarityThreshold,
                                                        maxConnectivity, selVertex.as<uint32_t>(), selSim.as<float>(),
-                                                       selCount.as<uint32_t>());
+                                                       selCount.as<uint32_t>(), spConsecutive, spFirst, graphConsecutive, graphFirst);
     EM2_TRY(hipGetLastError());
     filterEdgesKernel<false><<<grid, block, 0, stream>>>(selVertex.as<uint32_t>(), selSim.as<float>(), selCount.as<uint32_t>(),
                                                          graphCellCount, maxConnectivity, kept.as<uint32_t>(), nullptr, nullptr,
