@@ -15,17 +15,26 @@ One step = one pass of the hot path over the synthetic matrix resident in HBM:
 value = unordered cell pairs of the whole problem, N(N-1)/2 (the reference's own accounting,
 src/ExpressionMatrixLsh.cpp:220,274), per second of wall time, whole job.
 
+`python bench.py --gpus N` with N > 1 and no launcher environment starts `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>` as a CHILD process -- before this process has
+imported torch or touched a GPU -- relays its output (rank 0's one JSON line) and exits with its code.
+
 Also on the JSON line:
-    roofline      the scan kernel (dominant): algorithmic bytes = 2*8*W per unordered pair,
-                  i.e. 256 B at 1024 bits, x the unordered pairs one launch covers (rows*(N-1)/2 per rank; a rank
-                  evaluates rows*(N-1) ordered comparisons), / its duration measured with HIP events on the
-                  launch stream, against the 8 TB/s HBM peak.  The signature array (128 MB) is cache resident
-                  and each loaded column is reused by 64 rows from SGPRs, so this fraction is NOT bounded by 1;
-                  `valu_frac` next to it is the fraction of the XOR+popcount instruction roofline.
+    roofline      the dominant kernel.  1 GPU, 129..2048-bit signatures: fsp4ScanMatrixPinnedKernel / fsp4ScanMatrixWideKernel,
+                  the triangle part of the scan as FP4 +-1 dot products on the matrix cores -- bound "mfma": 2 x 1024 (2048)
+                  flop per (row, column) pair the launcher counted / the kernel's duration (HIP events on the launch stream,
+                  recorded inside the library) against the dense FP4 MFMA peak (10 PFLOP/s), with the in-kernel clock and the
+                  fraction at that clock beside it; `hbm_view` keeps SURVEY.md 8(d)'s byte model (2*8*W bytes per unordered
+                  pair against 8 TB/s; operands are cache / register resident, so that one is NOT bounded by 1).  Other
+                  forms (row shards, other widths): the byte model with `valu_frac`, the fraction of the v_xor/v_bcnt
+                  instruction roofline.  `traffic` = fabric bytes per launch from the committed PMC digest of THIS
+                  configuration (PROFILE_DIGESTS; a digest of another configuration is refused, there is no fallback).
+    roofline_projection   the signature projection against its 8(d) HBM bytes, with the digest's traffic and the ratio.
     cpu_baseline  the CPU oracle's literal findSimilarPairs4 (oracle/, kind "port": the reference itself cannot
                   be built in this image) on the first cells of the same signatures, one thread, ~15-20 s.
-Before timing, the GPU result is checked against the oracle on sampled rows (bit-exact) -- a run whose
-check fails prints no number.
+Before timing AND after the last timed step, the GPU result is checked against the oracle bit for bit: the signatures of
+64 cells and >= 10^4 SimilarPairs rows x all columns at 1M cells (the whole result for configs[1]), the
+oracle's rows spread over the host's threads -- a run whose check fails prints no number.
 """
 import argparse
 import json
@@ -46,6 +55,42 @@ MFMA_FP4_PEAK_TFLOPS = 10000.0   # MI355X_MICROARCH.md: FP4/FP6 block-scaled MFM
 VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9     # 256 CUs x 4 SIMD x 16 lanes/clk x 2.4 GHz
 
 
+# The PMC digests `traffic` may come from (tools/profile_bench.sh -> tools/profile_digest.py), one per workload; each names
+# the configuration it was taken on and is used for that configuration only (tests/test_bench_plumbing_cpu.py).
+PROFILE_DIGESTS = {
+    "fsp4": "r03_pmc_bench_1Mcells_1gpu.json",
+    "fsp5": "r03_pmc_bench_fsp5_1Mcells_2048bit.json",
+    "chain": "r03_pmc_bench_chain_1Mcells.json",
+}
+TRAFFIC_NOTE = "FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE, bytes per launch of the profiled run"
+
+
+def profile_query(workload, cells, lsh_count, k, n_gpus=1, genes=None, slices=None):
+    """The (key, value) pairs a digest's `config` must hold to stand for this run."""
+    query = {"cells": cells, "lsh_count": lsh_count, "k": k, "n_gpus": n_gpus}
+    if workload == "fsp4":
+        query["genes"] = genes
+    if workload == "fsp5":
+        query["slices"] = slices
+    return query
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a plain command line: the N ranks are started by torch.distributed.run as a child of this
+    process, which has not imported torch and never touches a GPU (a GPU-initialised process must not exec, and does not need
+    to: it waits).  The child's stdout/stderr are this process's own, its exit code is returned."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(command, env=env).returncode
+
+
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -60,7 +105,11 @@ def parse_args():
     p.add_argument("--seed", type=int, default=231)
     p.add_argument("--cpu-baseline-cells", type=int, default=50000)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--check-rows", type=int, default=384)
+    p.add_argument("--check-rows", type=int, default=10240,
+                   help="SimilarPairs rows (x all columns) compared with the oracle before and after the timed steps "
+                        "(SURVEY.md 8(d): >= 10^4 at 1M cells); 0 = every row this rank owns")
+    p.add_argument("--check-threads", type=int, default=0, help="host threads of the oracle in the parity gates (0: all, at most 64)")
+    p.add_argument("--fsp5-check-cells", type=int, default=2048)
     p.add_argument("--no-extra", action="store_true", help="skip the configs[1] block")
     p.add_argument("--workload", choices=["fsp4", "fsp5", "chain"], default="fsp4",
                    help="fsp4 (default): the headline, BASELINE configs[2]; fsp5: configs[3], bucketed findSimilarPairs5 at 2048 "
@@ -166,10 +215,45 @@ def profiled_traffic(file_name, config, kernel_prefixes):
     return (total, launches) if launches else (None, None)
 
 
-def parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host, check_rows):
+def sample_ranges(owned, rows_wanted, places=16):
+    """Row ranges totalling about rows_wanted rows out of the owned [begin, end) ranges: one contiguous owned range is sampled in
+    `places` evenly spread spans (the first and the last rows included), a list of 64-row blocks by evenly spread whole blocks.
+    rows_wanted <= 0 or >= what is owned: everything."""
+    total = sum(e - b for b, e in owned)
+    if rows_wanted <= 0 or rows_wanted >= total:
+        return list(owned)
+    if len(owned) == 1:
+        begin, end = owned[0]
+        span = max(1, rows_wanted // places)
+        starts = sorted(set(begin + (end - begin - span) * i // (places - 1) for i in range(places)))
+        out = []
+        for s0 in starts:                                    # (merge overlapping spans)
+            if out and s0 < out[-1][1]:
+                out[-1] = (out[-1][0], max(out[-1][1], s0 + span))
+            else:
+                out.append((s0, s0 + span))
+        return out
+    count = max(1, min(len(owned), -(-rows_wanted // max(1, owned[0][1] - owned[0][0]))))
+    return [owned[i] for i in sorted(set((len(owned) - 1) * i // max(1, count - 1) for i in range(count)))]
+
+
+def oracle_rows_parallel(oracle, sig_host, L, k, thr, ranges, threads=0):
+    """The oracle's per-cell findSimilarPairs4 contract (rows against all columns) for the row ranges, spread over host threads
+    (the ctypes call releases the GIL; rows are independent).  Returns [(begin, end, cell, sim, used)] in pieces."""
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or max(1, min(64, os.cpu_count() or 1))
+    total = sum(e - b for b, e in ranges)
+    per = max(1, -(-total // (4 * threads)))
+    pieces = [(s0, min(e, s0 + per)) for b, e in ranges for s0 in range(b, e, per)]
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        results = list(pool.map(lambda piece: oracle.find_similar_pairs4_rows(sig_host, L, k, thr, piece[0], piece[1]), pieces))
+    return [(b, e) + tuple(r) for (b, e), r in zip(pieces, results)]
+
+
+def parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host, check_rows, threads=0):
     """The result of the pipeline's LAST step against the CPU oracle, bit for bit: the signatures of a few of this
-    rank's cells and sampled SimilarPairs rows this rank owns against all columns.  Exits on a difference.
-    Returns (signature cells checked, rows checked)."""
+    rank's cells and sampled SimilarPairs rows this rank owns against all columns (check_rows of them; 0 = all).
+    Exits on a difference.  Returns (signature cells checked, rows checked)."""
     C, G, L, k, thr = pipe.cell_count, pipe.gene_count, pipe.lsh_count, pipe.k, pipe.thr
     if not pipe.rows:
         return 0, 0
@@ -179,24 +263,17 @@ def parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host, chec
     got = sig_host[pipe.row_begin:pipe.row_begin + sample]
     if not np.array_equal(expect, got):
         raise SystemExit("PARITY FAILURE: signatures differ from the oracle")
+    ranges = sample_ranges(pipe.owned_ranges(), check_rows)
+    fetched = {(b, e): pipe.results_for(b, e) for b, e in ranges}
     rows_checked = 0
-    ranges = pipe.owned_ranges()
-    span = max(1, check_rows // 3)
-    picks = [ranges[i] for i in sorted(set([0, len(ranges) // 2, len(ranges) - 1]))] if ranges else []
-    for r_begin, r_end in picks:
-        for begin in sorted(set([r_begin, max(r_begin, (r_begin + r_end) // 2 - span // 2), max(r_begin, r_end - span)])):
-            end = min(r_end, begin + span)
-            if end <= begin:
-                continue
-            pairs, used = pipe.results_for(begin, end)
-            cell, sim, oused = oracle.find_similar_pairs4_rows(sig_host, L, k, thr, begin, end)
-            ok = (np.array_equal(used, oused) and np.array_equal(pairs["cell"], cell) and
-                  np.array_equal(pairs["similarity"].view(np.uint32), sim.view(np.uint32)))
-            if not ok:
-                raise SystemExit("PARITY FAILURE: SimilarPairs rows %d..%d differ from the oracle" % (begin, end))
-            rows_checked += end - begin
-            if len(picks) > 1:
-                break           # block-sized ranges: one sample each
+    for begin, end, cell, sim, oused in oracle_rows_parallel(oracle, sig_host, L, k, thr, ranges, threads):
+        r_begin, (pairs, used) = next((b, fetched[(b, e)]) for b, e in ranges if b <= begin and end <= e)
+        lo, hi = begin - r_begin, end - r_begin
+        ok = (np.array_equal(used[lo:hi], oused) and np.array_equal(pairs["cell"][lo:hi], cell) and
+              np.array_equal(pairs["similarity"][lo:hi].view(np.uint32), sim.view(np.uint32)))
+        if not ok:
+            raise SystemExit("PARITY FAILURE: SimilarPairs rows %d..%d differ from the oracle" % (begin, end))
+        rows_checked += end - begin
     return sample, rows_checked
 
 
@@ -210,7 +287,8 @@ def small_config(args, capi, sharded, synthetic, oracle, device, torch, cells=10
     pipe.step()
     torch.cuda.synchronize()
     sig_host = pipe.full_sig[:cells].cpu().numpy().view(np.uint64)
-    before = parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host, args.check_rows)
+    # "the full CPU result for config B" -- every row against every column, before and after the timed steps
+    before = parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host, 0, args.check_threads)
     for _ in range(warmup):
         pipe.step()
     torch.cuda.synchronize()
@@ -221,7 +299,7 @@ def small_config(args, capi, sharded, synthetic, oracle, device, torch, cells=10
     elapsed = time.perf_counter() - t0
     pipe.check()
     after = parity_gate(pipe, oracle, synthetic, pipe.full_sig[:cells].cpu().numpy().view(np.uint64), toc, data, vectors_host,
-                        args.check_rows)
+                        0, args.check_threads)
     launch = capi.dev_find_similar_pairs4_last_launch()
     return {"workload": "%d cells x %d genes (%.3g nnz/cell), %d-bit signatures, findSimilarPairs4 k=%d threshold=%g, 1 GPU"
                         % (cells, genes, args.density * genes, L, k, thr),
@@ -250,7 +328,7 @@ def synthetic_signatures(torch, cells, lsh_count, device, cluster_count=64, flip
     return out
 
 
-def bench_fsp5(args, capi, oracle, device, torch, check_ranges=3):
+def bench_fsp5(args, capi, oracle, device, torch):
     """BASELINE configs[3] on one GPU: bucketed findSimilarPairs5, 2048-bit signatures, lshSliceLength 20, bucketOverflow
     1000, k=100.  One step = em2_dev_find_similar_pairs5 over all cells (tables + candidate filter + selection)."""
     C, L, k, thr, q = args.cells, 2048 if args.lsh_count == 1024 else args.lsh_count, args.k, args.threshold, args.slice_length
@@ -267,11 +345,12 @@ def bench_fsp5(args, capi, oracle, device, torch, check_ranges=3):
     torch.cuda.synchronize()
     check = {"skipped": "--no-check"}
     if not args.no_check:
-        # sampled cells in six places of the id range against the oracle (one build of its tables over all cells)
+        # sampled cells in sixteen places of the id range against the oracle (one build of its tables over all cells)
         sig_host = sig.cpu().numpy().view(np.uint64)
-        span = min(12, C)
+        places = 16
+        span = max(1, min(C, args.fsp5_check_cells) // places)
         listed = np.unique(np.concatenate([np.arange(b, b + span) for b in
-                                           (0, C // 5, (2 * C) // 5 + 3, (3 * C) // 5 + 11, (4 * C) // 5 + 17, C - span)]).clip(0, C - 1)).astype(np.uint32)
+                                           [(C - span) * i // (places - 1) for i in range(places)]]).clip(0, C - 1)).astype(np.uint32)
         cell, sim, oused = oracle.find_similar_pairs5_cells(sig_host, L, k, thr, q, args.bucket_overflow, listed)
         index = torch.from_numpy(listed.astype(np.int64)).to(device)
         got = pairs[index].cpu().numpy().view(np.uint32)
@@ -279,7 +358,7 @@ def bench_fsp5(args, capi, oracle, device, torch, check_ranges=3):
               np.array_equal(got[:, :, 1], sim.view(np.uint32)))
         if not ok:
             raise SystemExit("PARITY FAILURE: findSimilarPairs5 differs from the oracle on the sampled cells")
-        check = {"fsp5_cells": int(len(listed)), "places": 6}
+        check = {"fsp5_cells": int(len(listed)), "places": places}
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -301,12 +380,10 @@ def bench_fsp5(args, capi, oracle, device, torch, check_ranges=3):
     distinct = info["distinct_candidates"] if info["distinct_candidates"] >= 0 else info["gathered_candidates"]
     algorithmic = distinct * 8.0 * W + 4.0 * C * info["slice_count"]
     achieved = algorithmic / (filter_ms * 1e-3) / 1e9 if filter_ms > 0 else 0.0
-    per_launch, launches = profiled_traffic("r03_pmc_bench_fsp5_1Mcells_2048bit.json",
-                                            {"cells": C, "lsh_count": L, "k": k, "slice_length": q, "bucket_overflow": args.bucket_overflow},
+    per_launch, launches = profiled_traffic(PROFILE_DIGESTS["fsp5"], profile_query("fsp5", C, L, k, slices=info["slice_count"]),
                                             ("filterWideKernel", "filterCooperativeKernel"))
     traffic = per_launch * info["batches"] if per_launch is not None else None
-    traffic_source = ("profiles/r03_pmc_bench_fsp5_1Mcells_2048bit.json (FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE per launch of the "
-                      "filter, x the batches of one call)") if traffic is not None else None
+    traffic_source = ("profiles/%s (%s of the filter, x the batches of one call)" % (PROFILE_DIGESTS["fsp5"], TRAFFIC_NOTE)) if traffic is not None else None
     return {
         "metric": "cells/sec through findSimilarPairs5 (bucketed LSH, tables + candidate filter + selection)",
         "value": C * args.steps / elapsed, "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -314,7 +391,8 @@ def bench_fsp5(args, capi, oracle, device, torch, check_ranges=3):
         "dtype": "u64 popcount", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: %d synthetic cells, %d-bit signatures, findSimilarPairs5 lshSliceLength=%d "
                                "bucketOverflow=%d k=%d threshold=%g, 1 GPU" % (C, L, q, args.bucket_overflow, k, thr),
-                   "cells": C, "lsh_count": L, "k": k, "slices": info["slice_count"], "batches": info["batches"]},
+                   "cells": C, "lsh_count": L, "k": k, "slice_length": q, "bucket_overflow": args.bucket_overflow,
+                   "slices": info["slice_count"], "batches": info["batches"]},
         "phases_ms": {"candidate_filter": filter_ms, "selection": select_ms,
                       "tables_and_candidate_unions": elapsed / args.steps * 1e3 - filter_ms - select_ms},
         "roofline": {"kernel": ("filterWideKernel<%d> (all batches)" % (1 if W <= 32 else 2)) if W % 2 == 0 and W <= 64 and
@@ -407,6 +485,8 @@ def main():
     args = parse_args()
     # (the pool's driver only supports dmabuf IPC: without this RCCL fails with hipIpcGetMemHandle: invalid argument)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))           # (nothing GPU-related has been imported yet; the ranks are children)
     import torch
     import torch.distributed as dist
     from expressionmatrix2_amd import capi, sharded, synthetic
@@ -415,8 +495,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
         raise SystemExit("bench.py --gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path to benchmark)")
@@ -509,7 +587,7 @@ def main():
         sig_host = pipe.full_sig[:C].cpu().numpy().view(np.uint64)
         if not args.no_check:
             check["signature_cells"], check["fsp4_rows"] = parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host,
-                                                                       args.check_rows)
+                                                                       args.check_rows, args.check_threads)
         # ---- warmup + timed steps ----
         watchdog.arm(label + ": warmup and timed steps", 180 + 20 * (args.warmup + args.steps))
         if label == "sharded symmetric" and os.environ.get("EM2_BENCH_TEST_FAIL_RANK") == str(rank):
@@ -549,7 +627,7 @@ def main():
             if not np.array_equal(sig_after, sig_host):
                 raise SystemExit("PARITY FAILURE: the signatures of the last timed step differ from the first pass")
             check["after_timing_signature_cells"], check["after_timing_rows"] = parity_gate(
-                pipe, oracle, synthetic, sig_after, toc, data, vectors_host, args.check_rows)
+                pipe, oracle, synthetic, sig_after, toc, data, vectors_host, args.check_rows, args.check_threads)
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -595,19 +673,6 @@ def main():
         lane_ops = launch["wave_column_steps"] * 64.0 * 4.0 * W      # (v_xor + v_bcnt) per 32 bits per (lane, column)
         valu_frac = lane_ops / (kernel_ms * 1e-3) / VALU_LANE_OPS_PER_S if kernel_ms else 0.0
 
-        # HBM-side traffic of one scan launch from the PMC counters, when a profile of THIS configuration has been
-        # collected (rocprofv3 --pmc runs are separate from timing runs; see the file for the command and caveats).
-        traffic = None
-        traffic_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_1Mcells.json")
-        if os.path.exists(traffic_file):
-            with open(traffic_file) as f:
-                prof = json.load(f)
-            cfg = prof.get("config", {})
-            if (cfg.get("cells"), cfg.get("genes"), cfg.get("lsh_count"), cfg.get("k"), cfg.get("n_gpus")) == (C, G, L, k, world):
-                t = prof["per_launch_bytes"]["fsp4ScanKernel"]
-                if prof.get("form", "ordered") == ("symmetric" if symmetric else "ordered"):
-                    traffic = t["fetch"] + t["write"]
-
         result = {
             "metric": "cell-pair Hamming comparisons/sec (whole node), findSimilarPairs4 incl. signature projection",
             "value": value,
@@ -649,9 +714,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_hbm_traffic_1Mcells.json (FETCH_SIZE+WRITE_SIZE, bytes per launch)"
-                                  if traffic is not None else None,
+                "traffic": None,            # (no PMC digest of the v_xor/v_bcnt forms at this build: the matrix form is the product)
+                "traffic_source": None,
                 "algorithmic_bytes": algorithmic_bytes,
                 "comparisons_executed_per_s": launch["wave_column_steps"] * 64.0 / (kernel_ms * 1e-3) if kernel_ms else 0.0,
                 "valu_frac": valu_frac,
@@ -667,24 +731,12 @@ def main():
         matrix_traffic = None
         matrix_traffic_source = None
         pinned_walk = os.environ.get("EM2_MATRIX_WALK", "3") not in ("0",)
-        profile_config = {"cells": C, "genes": G, "lsh_count": L, "k": k, "n_gpus": world}
-        if matrix and pinned_walk and L <= 1024:
-            matrix_traffic, _ = profiled_traffic("r03_pmc_bench_1Mcells_1gpu.json", profile_config, ("fsp4ScanMatrixPinnedKernel",))
+        profile_config = profile_query("fsp4", C, L, k, world, genes=G)
+        if matrix and pinned_walk:
+            matrix_traffic, _ = profiled_traffic(PROFILE_DIGESTS["fsp4"], profile_config,
+                                                 ("fsp4ScanMatrixPinnedKernel", "fsp4ScanMatrixWideKernel"))
             if matrix_traffic is not None:
-                matrix_traffic_source = ("profiles/r03_pmc_bench_1Mcells_1gpu.json (tools/profile_bench.sh: FETCH_SIZE x 2 for 16-byte "
-                                         "loads + WRITE_SIZE, bytes per launch of the profiled run)")
-        for name in (("r02_pmc_matrix_scan_1Mcells.json",) if pinned_walk else ()) + ("r01_pmc_matrix_scan_1Mcells.json",):
-            matrix_traffic_file = os.path.join(ROOT, "profiles", name)
-            if matrix_traffic is not None or not (matrix and os.path.exists(matrix_traffic_file)):
-                continue
-            with open(matrix_traffic_file) as f:
-                prof = json.load(f)
-            cfg = prof.get("config", {})
-            if (cfg.get("cells"), cfg.get("genes"), cfg.get("lsh_count"), cfg.get("k"), cfg.get("n_gpus")) == (C, G, L, k, world):
-                t = prof["per_launch_bytes"]["fsp4ScanKernel"]
-                matrix_traffic = t["fetch"] + t["write"]
-                matrix_traffic_source = "profiles/%s (FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE, bytes per launch)" % name
-                break
+                matrix_traffic_source = "profiles/%s (tools/profile_bench.sh: %s)" % (PROFILE_DIGESTS["fsp4"], TRAFFIC_NOTE)
         if matrix and launch["matrix_kernel_ms"] > 0:
             # Dominant kernel: fsp4ScanMatrixKernel, bound by the matrix cores.  One (row, column) pair = a 1024-long dot
             # product of FP4 +-1 values = 2 * 1024 flop on v_mfma_scale_f32_32x32x64_f8f6f4; peak = the dense FP4 MFMA
@@ -766,9 +818,11 @@ def main():
                         "hyperplane line per (count, 64-bit word) from a copy that fills the L2s, so they move far more than the "
                         "algorithmic bytes (wasted_traffic_ratio)",
             }
-            projection_traffic, _ = profiled_traffic("r03_pmc_bench_1Mcells_1gpu.json", {"cells": C, "genes": G, "lsh_count": L, "k": k, "n_gpus": world},
+            projection_traffic, _ = profiled_traffic(PROFILE_DIGESTS["fsp4"], profile_query("fsp4", C, L, k, world, genes=G),
                                                      ("projectionScreen", "projectionExact", "cellStatsKernel"))
             result["roofline_projection"]["traffic"] = projection_traffic
+            result["roofline_projection"]["traffic_source"] = ("profiles/%s (%s, all projection kernels)" % (PROFILE_DIGESTS["fsp4"], TRAFFIC_NOTE)
+                                                               if projection_traffic else None)
             result["roofline_projection"]["wasted_traffic_ratio"] = projection_traffic / proj_bytes if projection_traffic else None
         result["device_state_rank0"] = leg["device_state"]
         if collective_check is not None:
@@ -879,7 +933,7 @@ def main():
         import copy
         small = copy.copy(args)
         small.steps, small.warmup = 2, 1
-        line = bench_fsp5(small, capi, oracle, device, torch, check_ranges=1)
+        line = bench_fsp5(small, capi, oracle, device, torch)
         result["extra"]["configs[3]"] = {key: line[key] for key in ("metric", "value", "unit", "ms_per_step", "steps", "config",
                                                                      "phases_ms", "roofline", "parity_check")}
         torch.cuda.empty_cache()

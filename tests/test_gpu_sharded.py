@@ -71,3 +71,20 @@ def test_a_rank_that_leaves_the_symmetric_leg_does_not_void_the_run():
                            port=29636)
     assert result["config"]["scan"] == "row-shards" and result["value"] > 0 and result["parity_check"]["after_timing_rows"] > 0
     assert result["sharded_symmetric_leg"]["status"] == "did not complete"
+
+
+def test_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher (the shape of the driver's 1-GPU command): the parent starts
+    torch.distributed.run as a child before touching the GPU, relays rank 0's one line and returns the child's exit code."""
+    env = {key: value for key, value in os.environ.items() if key not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update({"EM2_BENCH_SHARE_DEVICE": "1", "EM2_BENCH_BACKEND": "gloo", "EM2_BLOCKS_PER_CU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                "EM2_SHARDED_MIN_CELLS": "1000"})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cells", "30000", "--genes", "3000",
+           "--no-cpu-baseline", "--check-rows", "96"]
+    done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
+    lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1
+    result = json.loads(lines[0])
+    assert result["n_gpus"] == 2 and result["collective_check"]["ranks_counted_by_all_reduce"] == 2
+    assert result["row_shard_leg"]["value"] > 0 and result["row_shard_leg"]["parity_check"]["fsp4_rows"] > 0

@@ -2,7 +2,12 @@
 the launches, average duration (kernel trace), fabric bytes per launch (FETCH_SIZE x 2 for the 16-byte-per-lane loads these
 kernels issue -- MI355X_MICROARCH.md, HBM section -- plus WRITE_SIZE) and the figures derived from the SQ / GRBM counters.
 
-    python3 tools/profile_digest.py gpurun_out/<dir> '{"cells": 1000000, ...}' > profiles/r03_pmc_<what>.json
+    python3 tools/profile_digest.py gpurun_out/<dir> > profiles/rNN_pmc_bench_<what>.json
+
+`config` of the digest is what bench.py itself printed under the trace (the scalar entries of the line's `config` plus
+`n_gpus`): bench.profiled_traffic() accepts a digest only for the configuration it is running, so the digest must say which
+one it is of -- never an argument somebody may forget.  `--rewrite-config FILE...` re-derives `config` of committed digests
+from their embedded line in place (no GPU needed).
 """
 import csv
 import json
@@ -17,9 +22,36 @@ def short(name):
     return name.split("(")[0]
 
 
+def config_of_line(bench_line):
+    """The configuration a bench.py line was measured on: the scalar entries of its `config` (cells, genes, lsh_count, k, ...;
+    not the prose `workload`) and `n_gpus`."""
+    if not isinstance(bench_line, dict):
+        return {}
+    config = {key: value for key, value in bench_line.get("config", {}).items()
+              if key != "workload" and isinstance(value, (int, float, str, bool))}
+    if "n_gpus" in bench_line:
+        config["n_gpus"] = bench_line["n_gpus"]
+    return config
+
+
+def rewrite_config(paths):
+    for path in paths:
+        with open(path) as f:
+            digest = json.load(f)
+        config = config_of_line(digest.get("bench_line_under_trace"))
+        if not config:
+            raise SystemExit("%s: no bench line under trace to take the configuration from" % path)
+        digest["config"] = config
+        with open(path, "w") as f:
+            json.dump(digest, f, indent=1)
+            f.write("\n")
+        print(path, config)
+
+
 def main():
+    if sys.argv[1] == "--rewrite-config":
+        return rewrite_config(sys.argv[2:])
     directory = sys.argv[1]
-    config = json.loads(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].strip() else {}
     pmc = json.load(open(os.path.join(directory, "pmc_summary.json")))
     durations = {}
     for row in csv.DictReader(open(os.path.join(directory, "kernel_stats.csv"))):
@@ -62,6 +94,9 @@ def main():
         bench_line = json.loads(text)
     except Exception:           # noqa: BLE001
         pass
+    config = config_of_line(bench_line)
+    if not config:
+        raise SystemExit("profile_digest: %s holds no bench line under trace: a digest without its configuration is unusable" % directory)
     out = {
         "_what": "tools/profile_bench.sh: rocprofv3 --kernel-trace --stats of bench.py, then one --pmc pass per counter group "
                  "(FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_ANY "
