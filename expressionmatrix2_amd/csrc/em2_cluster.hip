@@ -1870,7 +1870,16 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
         return hipEventRecord(copies.ready[iteration & 1u], copies.stream);
     };
 
+    // (test / A-B knobs of the schedule, read once: a smaller pool -- turns that find no area --, fewer waves per unit)
+    uint32_t poolAreas = unitSchedule ? kUnitAreas : 4u;
+    if (const char* text = getenv("EM2_LABEL_POOL_AREAS")) {
+        if (atoi(text) >= 0 && uint32_t(atoi(text)) < poolAreas) poolAreas = uint32_t(atoi(text));
+    }
+    const char* wavesText = getenv("EM2_LABEL_UNIT_WAVES");
+    const uint32_t unitWaves = wavesText && atoi(wavesText) >= 1 && atoi(wavesText) <= 16 ? uint32_t(atoi(wavesText)) : 16u;
+
     int arenaGrowths = 0;
+    bool triedTicket = false;           // (its own flag: an arena growth before the time-out must not forfeit the ticket repeat)
     for (int attempt = 0;; ++attempt) {
         initialTablesKernel<<<grid, block, 0, stream>>>(vertexCount, dOffsets.as<uint64_t>(), dNeighbour.as<uint32_t>(),
                                                         dWeight.as<float>(), dCells.as<uint32_t>(), dMeta.as<TableMeta>(),
@@ -1922,10 +1931,7 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
             args.arenaCapacity = arenaCapacity;
             args.control = control;
             args.ticketBatch = ticketBatch;
-            args.poolAreas = unitSchedule ? kUnitAreas : 4u;
-            if (const char* text = getenv("EM2_LABEL_POOL_AREAS")) {          // (tests: a smaller pool, turns that find no area)
-                if (atoi(text) >= 0 && uint32_t(atoi(text)) < args.poolAreas) args.poolAreas = uint32_t(atoi(text));
-            }
+            args.poolAreas = unitSchedule ? std::min(poolAreas, kUnitAreas) : std::min(poolAreas, 4u);
             args.scratchA = dScratch.as<Candidate>();
             args.scratchB = dScratch.as<Candidate>() + slots;
             args.sortKeys = dSortKeys.as<uint64_t>();
@@ -1935,8 +1941,6 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
             EM2_TRY(hipMemsetAsync(dDiag.p, 0, kDiagWords * sizeof(unsigned long long), stream));
 #endif
             if (unitSchedule) {
-                const char* wavesText = getenv("EM2_LABEL_UNIT_WAVES");          // (measurement: fewer waves per unit)
-                const uint32_t unitWaves = wavesText && atoi(wavesText) >= 1 && atoi(wavesText) <= 16 ? uint32_t(atoi(wavesText)) : 16u;
                 labelPropagationCachedKernel<kScheduleUnit><<<unitGrid, dim3(64u * unitWaves), areaBytes16, stream>>>(args);
             }
             else if (cachedForm && ticketBatch == 0u) labelPropagationCachedKernel<kScheduleStrided><<<grid, block, areaBytes4, stream>>>(args);
@@ -1985,7 +1989,8 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
             if (stable == stableIterationCountThreshold) break;
             if (!uploaded && iterations < maxIterationCount) EM2_TRY(upload(iterations));
         }
-        if (failure == 1 && ticketBatch == 0 && attempt == 0) {
+        if (failure == 1 && ticketBatch == 0 && !triedTicket) {
+            triedTicket = true;
             if (clock.on) fprintf(stderr, "[em2 timing]   label propagation: the strided schedule timed out, repeating with the ticket\n");
             ticketBatch = 4;
             unitSchedule = false;

@@ -143,7 +143,9 @@ Layout layoutOf(uint32_t cellCount, uint32_t lshCount, uint32_t k, uint32_t rank
     l.rowScan = at;
     l.rowScanBytes = em2_dev_find_similar_pairs4_workspace(cellCount, rows, lshCount, k);
     at += alignUp(l.rowScanBytes);
-    if (symmetricWanted(cellCount, world, k)) {
+    // (the owner of a deferred candidate's target travels in eight bits of the entry: beyond 255 ranks every rank takes the
+    // always-valid rows form, by this same arithmetic)
+    if (world <= 255u && symmetricWanted(cellCount, world, k)) {
         em2_dev_fsp4_sharded_plan(cellCount, lshCount, k, rank, world, l.plan, 12);
         l.symmetric = l.plan[0] != 0;
     }
@@ -249,10 +251,12 @@ int em2_dist_find_similar_pairs4_with(const em2_collectives* c, const uint64_t* 
     // overflow = 1, so that ALL ranks take the rows form together, after which this rank returns the recorded error.
     // What is checked after the agreement (capacities of the exchange areas) is evaluated by every rank for every rank
     // from the gathered count matrix, i.e. identically everywhere.  A failure behind the exchange (phase 3, the copies
-    // of the redistribution) is recorded as well and returned after the last collective.  Only a collective that itself
-    // reports failure ends the call at once: the transport is gone, there is nothing left to keep in step with.
+    // of the redistribution) is recorded as well; the rank keeps entering the collectives of the redistribution -- so its
+    // peers receive rows that mean nothing -- and the call therefore ends with ONE more reduction, of the ranks' failure
+    // flags: if any rank failed behind the agreement, EVERY rank returns an error (its own, or "another rank failed"),
+    // nobody hands back rows that look valid and are not.  Only a collective that itself reports failure ends the call at
+    // once: the transport is gone, there is nothing left to keep in step with.
     // (As in expressionmatrix2_amd/sharded.py: guarded() / the agreed overflow flag.)
-    if (world > 255u) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dist_find_similar_pairs4: the symmetric form supports up to 255 ranks");
     em2_pair* globalPairs = reinterpret_cast<em2_pair*>(ws + l.globalPairs);
     uint32_t* globalUsed = reinterpret_cast<uint32_t*>(ws + l.globalUsed);
     char* shardWs = ws + l.sharded;
@@ -447,8 +451,17 @@ int em2_dist_find_similar_pairs4_with(const em2_collectives* c, const uint64_t* 
         }
     }
     recordHip(hipStreamSynchronize(stream), "hipStreamSynchronize");          // the host lists above must outlive the copies
+    // ---- the outcome is collective: a rank that failed behind the agreement has sent rows that mean nothing ----
+    int32_t* dFailed = reinterpret_cast<int32_t*>(counts);                    // (the count matrix has served)
+    int32_t failed = localError != EM2_OK ? 1 : 0;
+    EM2_DIST_HIP(hipMemcpyAsync(dFailed, &failed, 4u, hipMemcpyHostToDevice, stream));
+    if (c->all_reduce_max_i32(c->context, dFailed, 1, stream) != 0) return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: all_reduce of the outcome failed");
+    EM2_DIST_HIP(hipMemcpyAsync(&failed, dFailed, 4u, hipMemcpyDeviceToHost, stream));
+    EM2_DIST_HIP(hipStreamSynchronize(stream));
     timer.stage(EM2_DIST_MS_REDISTRIBUTE);
     if (localError != EM2_OK) return fail(localError, localMessage);
+    if (failed) return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: another rank failed behind the ranks' agreement (phase 3 or the "
+                                               "redistribution of the finished rows); the rows received from it are not valid");
     return EM2_OK;
 }
 

@@ -417,7 +417,8 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     args.k = k;
     args.rowBegin = rowBegin;
     args.rowEnd = rowEnd;
-    args.pad = 0;
+    args.departTicks = 0;
+    args.departWindow = 0;
     args.rowState = nullptr;
     args.segmentsDone = nullptr;
     args.control = nullptr;

@@ -31,7 +31,7 @@ struct Fsp4Args {
     uint32_t k;
     uint32_t rowBegin;
     uint32_t rowEnd;
-    uint32_t pad;
+    uint32_t departTicks;       // matrix form: an item's walk starts within departWindow of a multiple of this (100 MHz ticks); 0 = at once
     // persistent (segment-chained) variant only
     uint32_t* rowState;         // [rowBlocks*64][2] = {count, mMax} handed from one column segment to the next
     uint32_t* segmentsDone;     // [rowBlocks] number of finished column segments of the row block
@@ -61,6 +61,7 @@ struct Fsp4Args {
     // matrix-core form of the symmetric scan only (em2_scan_symmetric.hip)
     const void* fragments;      // the signatures as FP4 +-1 in MFMA fragment order, 512 B per cell
     uint32_t matrixLdsOffset;   // where the column tiles start in the block's dynamic LDS
+    uint32_t departWindow;      // (see departTicks)
     uint32_t pad2;              // diagnostic build only (EM2_DIAG_WORD below): the EM2_MATRIX_DIAG bits; 0 in the product
 };
 

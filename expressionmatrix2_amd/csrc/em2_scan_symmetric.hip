@@ -1374,7 +1374,23 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
             }
         }
 
-        // ---- the columns below the quad, in lock step ----
+        // ---- departures ----
+        // The blocks take their items whenever they finish the previous one, so the 64 blocks of an XCD walk the same
+        // segment's tiles at 64 different offsets, which its 4 MB L2 cannot hold together (47 % hits, 570 GB of fabric reads
+        // per launch at 1M cells).  With departTicks set, a walk starts only within departWindow ticks of a multiple of
+        // departTicks on the 100 MHz wall counter all blocks share: blocks that finish at about the same time leave together
+        // and follow each other through the tiles closely enough for the L2 to serve all but the first.  A block waits
+        // (asleep) for at most one period; order and content of everything it does are unchanged.
+        if (PINNED && aux->departTicks != 0u && colBegin < commonEnd) {
+            if (threadIdx.x == 0u) {
+                const uint32_t period = aux->departTicks, window = aux->departWindow;
+                for (uint32_t spins = 0; spins < (1u << 16); ++spins) {
+                    if (uint32_t(__builtin_amdgcn_s_memrealtime() % period) < window) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            __syncthreads();
+        }
         bool failed = false;
         uint32_t at = colBegin;
         uint32_t rowHalf = 0;           // (2048 bits: the columns are walked once per half of the wave's rows)
@@ -2376,6 +2392,9 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         matrixArgs.totalTickets = uint32_t(ticketsMatrix);
         matrixArgs.fragments = ws + layout.fragments;
         matrixArgs.matrixLdsOffset = uint32_t((lds + 15u) & ~size_t(15));
+        // (EM2_MATRIX_DEPART_US / EM2_MATRIX_DEPART_WINDOW_US: period and window of the walks' departures, microseconds)
+        matrixArgs.departTicks = uint32_t(envNumber("EM2_MATRIX_DEPART_US", 0) * 100u);
+        matrixArgs.departWindow = uint32_t(envNumber("EM2_MATRIX_DEPART_WINDOW_US", envNumber("EM2_MATRIX_DEPART_US", 0) / 4u) * 100u);
         const size_t matrixLds = size_t(matrixArgs.matrixLdsOffset) + scanMatrixLdsBytes(args.k);
         const void* matrixKernel = scanMatrixKernelFor(identity, wide);
         int device = 0, cuCount = 0, blocksPerCu = 0;
@@ -2407,7 +2426,8 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     const uint64_t ticketsMatrixCount = matrix ? ticketsMatrix : 0u;
 
     // the number of inbox entries (incl. chunk tails), the overflow flag and the hand-off error word
-    uint32_t inboxWords[4] = {0, 0, 0, 0};
+    // (and, in the same copy, the two clock words the matrix kernel leaves kClockWordsOffset words further on)
+    uint32_t inboxWords[kClockWordsOffset + 4u] = {0};
     uint32_t controlWords[2] = {0, 0};
     e = hipMemcpyAsync(inboxWords, ws + layout.control, sizeof(inboxWords), hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return e;
@@ -2424,9 +2444,8 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     double matrixClockGHz = 0.0;
     if (matrix) {
         unsigned long long ticks[2] = {0, 0};
-        if (hipMemcpy(ticks, ws + layout.control + 4u * kClockWordsOffset, sizeof(ticks), hipMemcpyDeviceToHost) == hipSuccess && ticks[1]) {
-            matrixClockGHz = double(ticks[0]) / double(ticks[1]) * 0.1;          // s_memrealtime counts at 100 MHz
-        }
+        std::memcpy(ticks, inboxWords + kClockWordsOffset, sizeof(ticks));
+        if (ticks[1]) matrixClockGHz = double(ticks[0]) / double(ticks[1]) * 0.1;          // s_memrealtime counts at 100 MHz
     }
     if (matrix && (diagNumber("EM2_MATRIX_DIAG") & 2048u)) {
         unsigned long long cycles[8] = {0, 0, 0, 0, 0, 0, 0, 0};

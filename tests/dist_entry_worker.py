@@ -93,23 +93,28 @@ def main():
     form = capi.dist_find_similar_pairs4_form(cells, L, k, world)
     stages = None
     # EM2_TEST_EXPECT_FAILURE_ON_RANK (with the diagnostic library's fault injection): that rank's call must raise, every
-    # rank must come back (nobody may be left waiting in a collective), and -- unless EM2_TEST_OTHERS_MAY_DIFFER, i.e. when the
-    # failure comes after the ranks' agreement -- the other ranks must still hold the right rows
+    # rank must come back (nobody may be left waiting in a collective), and the other ranks must still hold the right rows --
+    # unless EM2_TEST_ALL_RANKS_FAIL, i.e. when the failure comes after the ranks' agreement: then the failing rank's rows
+    # have travelled, and EVERY rank must report an error (the outcome is collective) instead of returning them
     failing = int(os.environ.get("EM2_TEST_EXPECT_FAILURE_ON_RANK", "-1"))
+    all_fail = os.environ.get("EM2_TEST_ALL_RANKS_FAIL") == "1"
     for timed in (False, True):
         try:
             stages = capi.dist_find_similar_pairs4(table, local.data_ptr(), cells, L, k, thr, everything.data_ptr(), pairs.data_ptr(),
                                                    used.data_ptr(), ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream,
                                                    timed=timed)
-            if rank == failing:
+            if rank == failing or (failing >= 0 and all_fail):
                 print("rank %d: the injected failure was not reported" % rank, file=sys.stderr)
                 sys.exit(4)
         except RuntimeError as error:
-            if rank != failing or "injected failure" not in str(error):
+            if rank == failing and "injected failure" in str(error):
+                stages = {}
+            elif failing >= 0 and all_fail and "another rank failed" in str(error):
+                stages = {}
+            else:
                 raise
-            stages = {}
         torch.cuda.synchronize()
-        if rank == failing or (failing >= 0 and os.environ.get("EM2_TEST_OTHERS_MAY_DIFFER") == "1"):
+        if rank == failing or (failing >= 0 and all_fail):
             continue
         oracle = oracle_binding.load_oracle()
         cell, sim, oused = oracle.find_similar_pairs4_rows(sig, L, k, thr, begin, end)
