@@ -1835,7 +1835,6 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
             unitSchedule = false;
         }
         unitsPerCu = std::min(unitsPerCu, 2);
-        if (const char* text = getenv("EM2_LABEL_UNITS")) unitsPerCu = std::max(1, std::min(unitsPerCu, atoi(text)));        // (A/B)
     }
     int smallBlocksPerUnit = 0;
     if (cachedForm) EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&smallBlocksPerUnit, labelPropagationCachedKernel<kScheduleStrided>, 256, areaBytes4));
@@ -1870,13 +1869,12 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
         return hipEventRecord(copies.ready[iteration & 1u], copies.stream);
     };
 
-    // (test / A-B knobs of the schedule, read once: a smaller pool -- turns that find no area --, fewer waves per unit)
+    // (test knob of the schedule, read once: a smaller pool of LDS areas -- turns that find none)
     uint32_t poolAreas = unitSchedule ? kUnitAreas : 4u;
     if (const char* text = getenv("EM2_LABEL_POOL_AREAS")) {
         if (atoi(text) >= 0 && uint32_t(atoi(text)) < poolAreas) poolAreas = uint32_t(atoi(text));
     }
-    const char* wavesText = getenv("EM2_LABEL_UNIT_WAVES");
-    const uint32_t unitWaves = wavesText && atoi(wavesText) >= 1 && atoi(wavesText) <= 16 ? uint32_t(atoi(wavesText)) : 16u;
+    constexpr uint32_t unitWaves = 16u;
 
     int arenaGrowths = 0;
     bool triedTicket = false;           // (its own flag: an arena growth before the time-out must not forfeit the ticket repeat)

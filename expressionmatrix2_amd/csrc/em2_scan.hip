@@ -40,8 +40,8 @@ namespace {
 //     instruction roofline of this formulation is 256 CU x 4 SIMD x 16 lanes x 2.4 GHz / (4*W lane-ops per
 //     comparison) = 6.1e11 ordered comparisons/s at 1024 bits; this kernel keeps the VALUs 89% busy at 1M cells.
 //   * the scalar path is NOT the limiter: R = 1, 2, 4 (2x / 4x fewer scalar loads per comparison) run within
-//     3% of each other, R = 1 fastest (most waves).  R stays a template parameter for experiments
-//     (EM2_ROWS_PER_LANE); the product path uses R = 1.
+//     3% of each other, R = 1 fastest (most waves).  R stays a template parameter (narrow signatures use R > 1); for
+//     1024 bits and more the product path uses R = 1.
 //   * the other operand path that keeps the per-pair instruction count at the floor -- column in VGPRs,
 //     broadcast with DPP row_newbcast -- was built and measured as well: v_xor_b32_dpp is slower than the
 //     SGPR-operand form on gfx950 and the kernel came out 5% slower; removed.
@@ -345,12 +345,8 @@ uint32_t paddedDwords(uint32_t lshCount)
     return p <= 128u ? p : 0u;
 }
 
-// EM2_ROWS_PER_LANE=2 selects two rows per lane for 1024/2048-bit signatures (A/B measurements only).
-static uint32_t forcedRowsPerLane()
-{
-    const char* v = getenv("EM2_ROWS_PER_LANE");
-    return (v && atoi(v) == 2) ? 2u : 0u;
-}
+// (two rows per lane for 1024/2048-bit signatures was an A/B knob of round 1: within 3 % of one row per lane, never faster)
+static uint32_t forcedRowsPerLane() { return 0u; }
 
 uint32_t fsp4MaxK()
 {

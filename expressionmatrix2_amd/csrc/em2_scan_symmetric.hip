@@ -2117,7 +2117,7 @@ static uint64_t inboxCapacity(uint32_t cellCount)
     // EM2_INBOX_CAPACITY (entries) is a test knob: tiny pools force the overflow -> ordered-scan fallback.
     const uint64_t forced = envNumber("EM2_INBOX_CAPACITY", 0);
     if (forced >= kInboxChunk) return forced < 0xfff00000ull ? forced : 0xfff00000ull;
-    uint64_t cap = uint64_t(cellCount) * envNumber("EM2_INBOX_PER_CELL", 1024);
+    uint64_t cap = uint64_t(cellCount) * 1024u;
     const uint64_t floor = uint64_t(maxResidentWaves()) * kInboxChunk * 2u;      // every wave can hold a chunk
     if (cap < floor) cap = floor;
     if (cap > 0xfff00000ull) cap = 0xfff00000ull;
@@ -2543,7 +2543,7 @@ static uint64_t shardCapLocal(uint32_t cellCount, uint32_t world)
 {
     const uint64_t forced = envNumber("EM2_INBOX_CAPACITY", 0);
     if (forced >= kInboxChunk) return forced;
-    uint64_t cap = uint64_t(cellCount) * envNumber("EM2_INBOX_PER_CELL", 1024) / world;
+    uint64_t cap = uint64_t(cellCount) * 1024u / world;
     cap += cap / 4u;
     const uint64_t floor = uint64_t(maxResidentWaves()) * kInboxChunk * 2u;
     if (cap < floor) cap = floor;
@@ -2870,7 +2870,7 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             args.fragments = ws + plan.offFragments;
-            args.matrixLdsOffset = uint32_t(envNumber("EM2_TILE_LDS_PAD", 0));          // debugging aid
+            args.matrixLdsOffset = 0u;
             const size_t matrixLds = args.matrixLdsOffset + kMatrixLdsBytes;
             uint64_t blocksWanted = uint64_t(cuCount) * 2u;
             if (blocksWanted > own) blocksWanted = own;

@@ -109,7 +109,7 @@ def scan_knobs():
                                              "EM2_BLOCKS_PER_CU", "EM2_FULL_ROW_CELLS", "EM2_SEGMENTS",
                                              "EM2_INBOX_CAPACITY", "EM2_SYMMETRIC_MIN_CELLS", "EM2_VIRTUAL_WORLD",
                                              "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_SCAN_MATRIX", "EM2_MATRIX_WALK",
-                                             "EM2_SCAN_MATRIX_WIDE")}
+                                             "EM2_SCAN_MATRIX_WIDE", "EM2_MATRIX_DEPART_US", "EM2_MATRIX_DEPART_WINDOW_US")}
 
     def set_knobs(**kw):
         for key, value in kw.items():
@@ -343,6 +343,8 @@ def test_matrix_form_is_the_one_that_runs(oracle, scan_knobs):
     (1700, 1024, 300, -0.5, "clustered", dict(EM2_FULL_ROW_CELLS=256, EM2_MIN_SEGMENT_COLUMNS=256, EM2_LOG_CAPACITY=1)),
     (4000, 1024, 25, 0.5, "clustered", dict(EM2_FULL_ROW_CELLS=512, EM2_SEGMENTS=3, EM2_BLOCKS_PER_CU=1)),
     (1300, 1024, 100, 0.2, "equal", dict(EM2_FULL_ROW_CELLS=256)),                                     # all cells identical: dot = 1024 everywhere
+    # walks leave on a common clock (the departure schedule, an A/B form): waiting changes nothing but the timing
+    (4000, 1024, 25, 0.2, "clustered", dict(EM2_FULL_ROW_CELLS=512, EM2_SEGMENTS=3, EM2_MATRIX_DEPART_US=50, EM2_MATRIX_DEPART_WINDOW_US=5)),
 ])
 def test_matrix_form_matches_oracle(oracle, scan_knobs, n, L, k, thr, kind, knobs):
     sig = np.tile(make(1, L, "random"), (n, 1)) if kind == "equal" else make(n, L, kind)

@@ -151,6 +151,17 @@ def test_fsp5_union_forms_agree(oracle, monkeypatch, mode):
         check(oracle, sig, L, k, thr, q, ovf)
 
 
+@pytest.mark.parametrize("mode", ["wide", "cooperative", "lane"])
+def test_fsp5_filter_forms_agree(oracle, monkeypatch, mode):
+    """The candidate filter (src/ExpressionMatrixLsh.cpp:436-457) as 16-byte loads with several candidates in flight
+    (filterWideKernel, default), as round 2's cooperative 8-byte form and as one lane per candidate (EM2_FSP5_FILTER): all
+    against the oracle, on even and odd word counts (odd ones keep the 8-byte form in every mode)."""
+    monkeypatch.setenv("EM2_FSP5_FILTER", mode)
+    for n, L, k, thr, q, ovf in ((4000, 256, 12, 0.1, 8, 0), (3000, 2048, 9, 0.2, 11, 25), (2500, 192, 5, 0.0, 6, 0), (900, 4096, 4, 0.2, 12, 0)):
+        sig = synth.clustered_signatures(n, L, cluster_count=5, flip=0.2, seed=n + 1)
+        check(oracle, sig, L, k, thr, q, ovf)
+
+
 @pytest.mark.parametrize("mode", ["tiers", "unpacked", "global", "lds"])
 def test_fsp5_long_lists_all_selection_tiers(oracle, mode, monkeypatch):
     """Lists of 4097.., 12289.. candidates with few distinct keys (ties decide who survives keepBest) and with many: the

@@ -84,15 +84,18 @@ def test_screening_pass_defers_to_exact_arithmetic_when_it_cannot_decide(oracle)
     assert 0.3 * cells * L < ones < 0.7 * cells * L            # the signs are genuinely mixed
 
 
-@pytest.mark.parametrize("mode", ["exact", "default", "sliced", "sliced16", "screen"])
+@pytest.mark.parametrize("mode", ["exact", "default", "words", "sliced", "sliced16", "screen"])
 def test_exact_only_and_screened_paths_agree_with_oracle(oracle, mode, monkeypatch):
-    """default = 16-bit fixed-point first tier -> float tier on the undecided words -> exact arithmetic; sliced / sliced16 /
-    screen = the float forms as first tier; exact = no screening at all."""
+    """default = 16-bit fixed-point first tier -> float tier on the undecided single bits and words -> exact arithmetic; words =
+    the same with everything undecided listed by words (EM2_PROJECTION_BITS=0, round 2's form); sliced / sliced16 / screen = the
+    float forms as first tier; exact = no screening at all."""
     cells, genes, L = 800, 3000, 1024
     toc, g, c = synth.expression_matrix(cells, genes, density=0.02, cluster_count=6, seed=9)
     vectors = oracle.generate_lsh_vectors(genes, L, 231)
     expect = oracle.compute_signatures(toc, g, c, genes, vectors, L)
-    if mode != "default":
+    if mode == "words":
+        monkeypatch.setenv("EM2_PROJECTION_BITS", "0")
+    elif mode != "default":
         monkeypatch.setenv("EM2_PROJECTION", mode)
     got = capi.compute_signatures(toc, capi.make_counts(g, c), genes, vectors, L)
     assert np.array_equal(got, expect)

@@ -109,17 +109,23 @@ static void run(const char* name, int blocksPerCu, int rounds, int mode, float b
     hipFree(out);
 }
 
+// ubench_matrix_step [codeA0 codeA1 codeB0 codeB1]: the FP4 (E2M1) codes that stand for a signature bit 0 / 1 in the column tiles
+// (A) and in the rows (B); default 2 10 2 10 = +1 / -1 on both sides, the product's encoding.  (Round 4: does another pair of
+// values -- 0 / 1, +-0.5, +-2 ... -- cost the matrix pipe less power, i.e. hold a higher clock?  Only "plain" is meaningful then.)
 int main(int argc, char** argv)
 {
+    const unsigned codeA0 = argc > 4 ? unsigned(atoi(argv[1])) : 0x2u, codeA1 = argc > 4 ? unsigned(atoi(argv[2])) : 0xAu;
+    const unsigned codeB0 = argc > 4 ? unsigned(atoi(argv[3])) : 0x2u, codeB1 = argc > 4 ? unsigned(atoi(argv[4])) : 0xAu;
+    printf("codes: columns %x / %x, rows %x / %x\n", codeA0, codeA1, codeB0, codeB1);
     int cus = 0;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     const size_t waves = size_t(cus) * 2 * 4;
     std::vector<unsigned> tiles(65536 / 4), rows(waves * 32768 / 4);
     unsigned long long state = 88172645463325252ull;
     auto next = [&]() { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return state; };
-    auto nibbles = [&]() { unsigned w = 0; const unsigned long long r = next(); for (int n = 0; n < 8; n++) w |= (((r >> n) & 1u) ? 0xAu : 0x2u) << (4 * n); return w; };
-    for (auto& w : tiles) w = nibbles();
-    for (auto& w : rows) w = nibbles();
+    auto nibbles = [&](unsigned c0, unsigned c1) { unsigned w = 0; const unsigned long long r = next(); for (int n = 0; n < 8; n++) w |= (((r >> n) & 1u) ? c1 : c0) << (4 * n); return w; };
+    for (auto& w : tiles) w = nibbles(codeA0, codeA1);
+    for (auto& w : rows) w = nibbles(codeB0, codeB1);
     unsigned *dTiles, *dRows, *dCounts;
     unsigned long long* dLogs;
     hipMalloc(&dTiles, 65536);
@@ -131,15 +137,18 @@ int main(int argc, char** argv)
     const int rounds = 20000;
     run("plain", 1, rounds, 0, 0.f, dTiles, dRows, dLogs, dCounts);
     run("plain", 2, rounds, 0, 0.f, dTiles, dRows, dLogs, dCounts);
+    if (argc == 6) return 0;          // (a fifth argument alone: the plain runs only)
+    // (argv[5], argv[6]: mean and standard deviation of the dot product under these codes, for the bounds of the event runs)
+    const float mean = argc > 6 ? float(atof(argv[5])) : 0.f, sigma = argc > 6 ? float(atof(argv[6])) : 32.f;
     run("tests, nothing passes", 2, rounds, 1, 1e9f, dTiles, dRows, dLogs, dCounts);
     run("pair: tests, nothing passes", 2, rounds, 2, 1e9f, dTiles, dRows, dLogs, dCounts);
     const float sigmas[] = {3.5f, 3.0f, 2.5f};
     for (float s : sigmas) {
         char name[64];
         snprintf(name, sizeof(name), "events, bound %.1f sigma", s);
-        run(name, 2, rounds, 1, 32.f * s, dTiles, dRows, dLogs, dCounts);
+        run(name, 2, rounds, 1, mean + sigma * s, dTiles, dRows, dLogs, dCounts);
         snprintf(name, sizeof(name), "pair: events, %.1f sigma", s);
-        run(name, 2, rounds, 2, 32.f * s, dTiles, dRows, dLogs, dCounts);
+        run(name, 2, rounds, 2, mean + sigma * s, dTiles, dRows, dLogs, dCounts);
     }
     return 0;
 }
