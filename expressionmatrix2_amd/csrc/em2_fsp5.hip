@@ -573,12 +573,25 @@ selectKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegin, Ent
     Entry* work = list;
     const bool inLds = n <= CAPACITY;
     if (inLds) {
-        for (uint32_t i = lane; i < n; i += 64u) lds[i] = list[i];
+        // (eight loads in flight before the first LDS store: see selectPackedKernel)
+        for (uint32_t base = 0; base < n; base += 64u * 8u) {
+            Entry staged[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) {
+                const uint32_t i = base + j * 64u + lane;
+                staged[j] = i < n ? list[i] : Entry();
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) {
+                const uint32_t i = base + j * 64u + lane;
+                if (i < n) lds[i] = staged[j];
+            }
+        }
         work = lds;
         waveFence();
     }
     if (n > k) {
-        if (inLds) nthElementWave(work, ldsL, ldsR, int(k), int(n), lane);
+        if (inLds) nthElementWaveT<uint16_t, false, Entry, 4>(work, ldsL, ldsR, int(k), int(n), lane);
         else if (lane == 0u) nthElement(work, int(k), int(n));
         n = k;
         waveFence();
@@ -630,6 +643,18 @@ struct PackedEntry {
     uint16_t key;
     uint16_t index;
 };
+#ifdef EM2_DIAG
+// (diagnostic build, EM2_TIMING=1: wave cycles of selectPackedKernel by phase -- staging, selection, survivors + sort, output)
+__device__ unsigned long long selectPhaseCycles[8];
+#define EM2_SELECT_PHASE(i)                                                                       \
+    do {                                                                                          \
+        const unsigned long long now_ = __builtin_readcyclecounter();                             \
+        if (lane == 0u) atomicAdd(&selectPhaseCycles[i], now_ - phaseStart_);                     \
+        phaseStart_ = now_;                                                                       \
+    } while (0)
+#else
+#define EM2_SELECT_PHASE(i) do { } while (0)
+#endif
 constexpr uint32_t kSelectPackedMaxK = 2048;        // the survivors are gathered into the smallest tier's position arrays
 
 template <uint32_t CAPACITY, uint32_t ABOVE>
@@ -647,19 +672,39 @@ selectPackedKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegi
     if (local >= batchCells) return;
     uint32_t n = listCounts[local];
     if (n <= ABOVE || n > CAPACITY) return;             // another tier's cells
+#ifdef EM2_DIAG
+    unsigned long long phaseStart_ = __builtin_readcyclecounter();
+#endif
     const Entry* list = lists + segmentBegin[local];
-    for (uint32_t i = lane; i < n; i += 64u) {
-        PackedEntry e;
-        e.key = uint16_t(list[i].key);
-        e.index = uint16_t(i);
-        lds[i] = e;
+    // Staging: the list was written by the filter of this batch (gigabytes per batch: it comes from HBM), and a loop of one
+    // load and one LDS store per 64 entries paid a memory latency per turn -- 67 turns for the 4300 entries of config D's
+    // lists, most of the kernel's time.  Sixteen loads are in flight before the first store.
+    for (uint32_t base = 0; base < n; base += 64u * 16u) {
+        uint32_t keys[16];
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; ++j) {
+            const uint32_t i = base + j * 64u + lane;
+            keys[j] = i < n ? list[i].key : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; ++j) {
+            const uint32_t i = base + j * 64u + lane;
+            if (i < n) {
+                PackedEntry e;
+                e.key = uint16_t(keys[j]);
+                e.index = uint16_t(i);
+                lds[i] = e;
+            }
+        }
     }
     waveFence();
+    EM2_SELECT_PHASE(0);
     if (n > k) {
-        nthElementWaveT<uint16_t, false, PackedEntry>(lds, ldsL, ldsR, int(k), int(n), lane);
+        nthElementWaveT<uint16_t, false, PackedEntry, 4>(lds, ldsL, ldsR, int(k), int(n), lane);
         n = k;
         waveFence();
     }
+    EM2_SELECT_PHASE(1);
     // the survivors' cells, then the rank sort of SimilarPairs::copy + sort (:489-496) on (key, cell)
     Entry* kept = reinterpret_cast<Entry*>(positions);     // (the position arrays are free now; k <= kSelectPackedMaxK entries of 8 bytes)
     static_assert(CAPACITY * 4u >= kSelectPackedMaxK * 8u, "the position arrays must hold k entries");
@@ -670,12 +715,14 @@ selectPackedKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegi
         kept[i] = e;
     }
     waveFence();
+    EM2_SELECT_PHASE(2);
     PairOut* out = outPairs + size_t(local) * k;
     uint32_t padded = 1;
     while (padded < n) padded <<= 1;
     if (padded * 8u <= CAPACITY * 4u) {
         // (the bitonic network of em2_select_wave.h whenever the position arrays hold the padded list: k <= 1024 at every tier)
         sortListWave(kept, n, lane);
+        EM2_SELECT_PHASE(3);
         for (uint32_t i = lane; i < n; i += 64u) {
             const Entry e = kept[i];
             PairOut po;
@@ -704,6 +751,7 @@ selectPackedKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegi
         out[i] = zero;
     }
     if (lane == 0u) outUsed[local] = n;
+    EM2_SELECT_PHASE(4);
 }
 
 // The same for lists of any length, left where the filter wrote them: one wave per cell runs the wave-parallel selection
@@ -979,8 +1027,8 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
         }
         EM2_TRY(hipGetLastError());
         if (timing[0]) (void)hipEventRecord(timing[1], stream);
-        // keepBest + sort + store, by list length: LDS tiers of 4096 / 6144 / 8192 / 16384 entries with {key, position} in
-        // 4 bytes + two position arrays (8 bytes per entry: 5, 3, 2 and 1 wave per CU), beyond that the same wave-parallel
+        // keepBest + sort + store, by list length: LDS tiers of 4096 / 5120 / 6144 / 8192 / 16384 entries with {key, position} in
+        // 4 bytes + two position arrays (8 bytes per entry: 5, 4, 3, 2 and 1 wave per CU), beyond that the same wave-parallel
         // selection on global memory.  EM2_FSP5_SELECT (A/B measurements): "unpacked" = tiers of 4096 / 5120 / 6656 / 12288
         // whole entries (12 bytes each), "lds" = round 1's form (4096 and 12288, longer lists by a single lane in HBM),
         // "global" = everything above 4096 in global memory (3.8x slower than the LDS tiers on config D: agent-scope fences).
@@ -1003,7 +1051,8 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
                                                                               outPairs, outUsed);                                 \
             EM2_TRY(hipGetLastError())
             EM2_SELECT_PACKED(4096u, 0u);
-            EM2_SELECT_PACKED(6144u, 4096u);
+            EM2_SELECT_PACKED(5120u, 4096u);          // (40 KB: four waves per CU where 6144 entries allow three; config D's lists are 3600..4700 long)
+            EM2_SELECT_PACKED(6144u, 5120u);
             EM2_SELECT_PACKED(8192u, 6144u);
             EM2_SELECT_PACKED(16384u, 8192u);
 #undef EM2_SELECT_PACKED
@@ -1041,6 +1090,17 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
         }
     }
     lastFsp5Info.distinctCandidates = useUnion ? distinctTotal : -1.;
+#ifdef EM2_DIAG
+    if (getenv("EM2_TIMING") && getenv("EM2_TIMING")[0] == '1') {
+        unsigned long long cycles[8] = {0};
+        if (hipMemcpyFromSymbol(cycles, HIP_SYMBOL(selectPhaseCycles), sizeof(cycles)) == hipSuccess) {
+            double total = 0;
+            for (int i = 0; i < 5; i++) total += double(cycles[i]);
+            fprintf(stderr, "[em2 timing] selectPackedKernel wave cycles (cumulative): staging %.1f%% selection %.1f%% survivors %.1f%% sort %.1f%% output %.1f%% (%.3g cycles)\n",
+                    100 * cycles[0] / total, 100 * cycles[1] / total, 100 * cycles[2] / total, 100 * cycles[3] / total, 100 * cycles[4] / total, total);
+        }
+    }
+#endif
     return hipSuccess;
 }
 

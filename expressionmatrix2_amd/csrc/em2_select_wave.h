@@ -73,6 +73,27 @@ __device__ __forceinline__ void waveSyncFor()
     else waveSync();
 }
 
+// __move_median_to_first for the wave forms (one lane calls it): the four elements are loaded at once -- one LDS round trip
+// instead of a chain of dependent ones (a 200-entry selection of the scan spends most of its time between partitions) --, the
+// decision tree is medianToFirst's, and swapping a[result] with the median is two stores.  result, ia, ib, ic are distinct
+// (introselect calls it on ranges of more than three elements).
+template <class E> __device__ __forceinline__ void medianToFirstLoaded(E* a, int result, int ia, int ib, int ic)
+{
+    const E er = a[result], ea = a[ia], eb = a[ib], ec = a[ic];
+    int m;
+    if (ea.key < eb.key) {
+        if (eb.key < ec.key) m = ib;
+        else if (ea.key < ec.key) m = ic;
+        else m = ia;
+    }
+    else if (ea.key < ec.key) m = ia;
+    else if (eb.key < ec.key) m = ic;
+    else m = ib;
+    const E em = m == ia ? ea : (m == ib ? eb : ec);
+    a[result] = em;
+    a[m] = er;
+}
+
 __device__ __forceinline__ uint32_t lanesBelow(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
@@ -80,49 +101,106 @@ __device__ __forceinline__ uint32_t lanesBelow(uint64_t mask)
 
 // __unguarded_partition(a+lo, a+hi, pivot = a[lo-1]); returns the cut (wave-uniform).  Index: uint16_t positions for lists
 // staged in LDS, uint32_t with GLOBAL for lists of any length left in global memory.
-template <class Index, bool GLOBAL, class E = Entry>
+// CHUNKS > 1 (LDS form only): the pipelined form for long lists -- findSimilarPairs5's, thousands of entries, one wave per SIMD.
+// The scan's 2k-entry selections keep CHUNKS = 1: their ranges fit one or two chunks, and the unrolled bodies cost the
+// scan kernels more than they saved (same box, alternating: +0.3 ms kernel, +0.7 ms scan at 1M cells).
+template <class Index, bool GLOBAL, class E = Entry, int CHUNKS = 1>
 __device__ inline int partitionWaveT(E* a, int lo, int hi, Index* Lpos, Index* Rpos, uint32_t lane)
 {
     const uint32_t pk = a[lo - 1].key;
     int nL = 0, nR = 0;
-    for (int base = lo; base < hi; base += 64) {
-        const int x = base + int(lane);
-        const bool valid = x < hi;
-        const uint32_t key = valid ? a[x].key : 0u;
-        const bool isL = valid && key >= pk;
-        const bool isR = valid && key <= pk;
-        const uint64_t mL = __builtin_amdgcn_ballot_w64(isL);
-        const uint64_t mR = __builtin_amdgcn_ballot_w64(isR);
-        if (isL) Lpos[nL + int(lanesBelow(mL))] = Index(x);
-        if (isR) Rpos[nR + int(lanesBelow(mR))] = Index(x);
-        nL += __builtin_popcountll(mL);
-        nR += __builtin_popcountll(mR);
+    // (LDS form: the keys of four chunks are loaded before the first of them is used -- the scan writes only the position
+    // arrays, and a wave that waited for every chunk's load spent its time in LDS latency, one wave per SIMD being the rule)
+    constexpr int kChunks = GLOBAL ? 1 : CHUNKS;
+    for (int base = lo; base < hi; base += 64 * kChunks) {
+        uint32_t key[kChunks];
+        bool valid[kChunks];
+#pragma unroll
+        for (int j = 0; j < kChunks; ++j) {
+            const int x = base + 64 * j + int(lane);
+            valid[j] = x < hi;
+            key[j] = valid[j] ? a[x].key : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < kChunks; ++j) {
+            if (j > 0 && base + 64 * j >= hi) break;          // (uniform: the short ranges of a 2k-entry list end in the first chunk)
+            const int x = base + 64 * j + int(lane);
+            const bool isL = valid[j] && key[j] >= pk;
+            const bool isR = valid[j] && key[j] <= pk;
+            const uint64_t mL = __builtin_amdgcn_ballot_w64(isL);
+            const uint64_t mR = __builtin_amdgcn_ballot_w64(isR);
+            if (isL) Lpos[nL + int(lanesBelow(mL))] = Index(x);
+            if (isR) Rpos[nR + int(lanesBelow(mR))] = Index(x);
+            nL += __builtin_popcountll(mL);
+            nR += __builtin_popcountll(mR);
+        }
     }
     waveSyncFor<GLOBAL>();
     int T = 0;
-    for (int base = 0; base < nL; base += 64) {
-        const int t = base + int(lane);
-        const bool valid = t < nL;
-        int x = 0, y = 0;
-        bool c = false;
-        if (valid) {
-            x = int(Lpos[t]);
-            y = t < nR ? int(Rpos[nR - 1 - t]) : lo - 1;
-            c = x < y;
+    if (!GLOBAL && CHUNKS > 1) {
+        // The pairs (L[t], R[t]) are disjoint for all t below T (header), so a lane's loads and stores of its own pairs need no
+        // order against any other lane's: two chunks of pairs per turn, all four loads before the stores.
+        for (int base = 0; base < nL; base += 128) {
+            int x[2] = {0, 0}, y[2] = {0, 0};
+            bool c[2] = {false, false}, valid[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int t = base + 64 * j + int(lane);
+                valid[j] = t < nL;
+                if (valid[j]) {
+                    x[j] = int(Lpos[t]);
+                    y[j] = t < nR ? int(Rpos[nR - 1 - t]) : lo - 1;
+                    c[j] = x[j] < y[j];
+                }
+            }
+            E ex[2] = {E(), E()}, ey[2] = {E(), E()};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (c[j]) {
+                    ex[j] = a[x[j]];
+                    ey[j] = a[y[j]];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (c[j]) {
+                    a[x[j]] = ey[j];
+                    a[y[j]] = ex[j];
+                }
+            }
+            const uint64_t m0 = __builtin_amdgcn_ballot_w64(c[0]);
+            T += __builtin_popcountll(m0);
+            if (m0 != __builtin_amdgcn_ballot_w64(valid[0])) break;
+            if (base + 64 >= nL) break;
+            const uint64_t m1 = __builtin_amdgcn_ballot_w64(c[1]);
+            T += __builtin_popcountll(m1);
+            if (m1 != __builtin_amdgcn_ballot_w64(valid[1])) break;
         }
-        E ex = E(), ey = E();
-        if (c) {
-            ex = a[x];
-            ey = a[y];
+    } else {
+        for (int base = 0; base < nL; base += 64) {
+            const int t = base + int(lane);
+            const bool valid = t < nL;
+            int x = 0, y = 0;
+            bool c = false;
+            if (valid) {
+                x = int(Lpos[t]);
+                y = t < nR ? int(Rpos[nR - 1 - t]) : lo - 1;
+                c = x < y;
+            }
+            E ex = E(), ey = E();
+            if (c) {
+                ex = a[x];
+                ey = a[y];
+            }
+            waveSyncFor<GLOBAL>();
+            if (c) {
+                a[x] = ey;
+                a[y] = ex;
+            }
+            const uint64_t mc = __builtin_amdgcn_ballot_w64(c);
+            T += __builtin_popcountll(mc);
+            if (mc != __builtin_amdgcn_ballot_w64(valid)) break;
         }
-        waveSyncFor<GLOBAL>();
-        if (c) {
-            a[x] = ey;
-            a[y] = ex;
-        }
-        const uint64_t mc = __builtin_amdgcn_ballot_w64(c);
-        T += __builtin_popcountll(mc);
-        if (mc != __builtin_amdgcn_ballot_w64(valid)) break;
     }
     waveSyncFor<GLOBAL>();
     int cut;
@@ -133,12 +211,12 @@ __device__ inline int partitionWaveT(E* a, int lo, int hi, Index* Lpos, Index* R
 
 __device__ inline int partitionWave(Entry* a, int lo, int hi, uint16_t* Lpos, uint16_t* Rpos, uint32_t lane)
 {
-    return partitionWaveT<uint16_t, false>(a, lo, hi, Lpos, Rpos, lane);
+    return partitionWaveT<uint16_t, false, Entry, 1>(a, lo, hi, Lpos, Rpos, lane);
 }
 
 // std::nth_element(a, a+nth, a+n, cmp) by one wave; a, Lpos, Rpos in LDS (Lpos/Rpos: n uint16 each, n <= 65535), or all
 // three in global memory (GLOBAL, Index = uint32_t).
-template <class Index, bool GLOBAL, class E = Entry>
+template <class Index, bool GLOBAL, class E = Entry, int CHUNKS = 1>
 __device__ inline void nthElementWaveT(E* a, Index* Lpos, Index* Rpos, int nth, int n, uint32_t lane)
 {
     if (n == 0 || nth == n) return;
@@ -154,9 +232,12 @@ __device__ inline void nthElementWaveT(E* a, Index* Lpos, Index* Rpos, int nth, 
             return;
         }
         --depthLimit;
-        if (lane == 0u) medianToFirst(a, first, first + 1, first + (last - first) / 2, last - 1);
+        if (lane == 0u) {
+            if (CHUNKS > 1) medianToFirstLoaded(a, first, first + 1, first + (last - first) / 2, last - 1);
+            else medianToFirst(a, first, first + 1, first + (last - first) / 2, last - 1);
+        }
         waveSyncFor<GLOBAL>();
-        const int cut = partitionWaveT<Index, GLOBAL, E>(a, first + 1, last, Lpos, Rpos, lane);
+        const int cut = partitionWaveT<Index, GLOBAL, E, CHUNKS>(a, first + 1, last, Lpos, Rpos, lane);
         if (cut <= nth) first = cut;
         else last = cut;
     }

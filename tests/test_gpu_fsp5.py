@@ -169,7 +169,7 @@ def test_fsp5_long_lists_all_selection_tiers(oracle, mode, monkeypatch):
     lane in HBM must all reproduce libstdc++'s nth_element."""
     monkeypatch.setenv("EM2_FSP5_SELECT", mode)
     rng = np.random.default_rng(17)
-    for cells, L, k, flips in ((5000, 64, 7, 3), (13000, 128, 25, 10), (7000, 256, 100, 40), (17000, 64, 3, 6), (5000, 128, 2500, 30)):
+    for cells, L, k, flips in ((5000, 64, 7, 3), (5600, 128, 50, 12), (13000, 128, 25, 10), (7000, 256, 100, 40), (17000, 64, 3, 6), (5000, 128, 2500, 30)):
         base = synth.random_signatures(1, L, seed=cells)
         sig = np.tile(base, (cells, 1))
         # flip up to `flips` random bits per cell outside the first slice: one bucket holds everybody, keys vary
