@@ -565,6 +565,11 @@ def main():
         torch.cuda.synchronize()
         return pipe
 
+    # With several ranks on one host the gates share its cores: every rank checks its share of the rows with its share of the
+    # threads (the job as a whole still compares >= --check-rows rows per gate).
+    rows_per_gate = args.check_rows if world == 1 or args.check_rows <= 0 else max(min(1024, args.check_rows), -(-args.check_rows // world))
+    gate_threads = args.check_threads or max(1, min(64, (os.cpu_count() or 1) // world))
+
     def run_leg(pipe, label, golden_cases):
         """One measurement by the contract: correctness gate (an untimed pass against the CPU oracle), W warmup steps, exactly K
         timed steps between barrier + synchronize on both sides, MAX over the ranks, the gate again on the LAST timed step's
@@ -587,7 +592,7 @@ def main():
         sig_host = pipe.full_sig[:C].cpu().numpy().view(np.uint64)
         if not args.no_check:
             check["signature_cells"], check["fsp4_rows"] = parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host,
-                                                                       args.check_rows, args.check_threads)
+                                                                       rows_per_gate, gate_threads)
         # ---- warmup + timed steps ----
         watchdog.arm(label + ": warmup and timed steps", 180 + 20 * (args.warmup + args.steps))
         if label == "sharded symmetric" and os.environ.get("EM2_BENCH_TEST_FAIL_RANK") == str(rank):
@@ -627,7 +632,7 @@ def main():
             if not np.array_equal(sig_after, sig_host):
                 raise SystemExit("PARITY FAILURE: the signatures of the last timed step differ from the first pass")
             check["after_timing_signature_cells"], check["after_timing_rows"] = parity_gate(
-                pipe, oracle, synthetic, sig_after, toc, data, vectors_host, args.check_rows, args.check_threads)
+                pipe, oracle, synthetic, sig_after, toc, data, vectors_host, rows_per_gate, gate_threads)
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
