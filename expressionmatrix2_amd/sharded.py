@@ -7,7 +7,7 @@ rank scans its own ROWS against all columns, which is exactly the per-cell contr
 no collective on the result, no cross-rank merge of top-k state.
 
 DevicePipeline (device-resident, used by bench.py) goes one step further when the problem is large enough: the
-SHARDED SYMMETRIC scan (csrc/em2_scan_symmetric.hip, include/em2_lsh.h: em2_dev_fsp4_sharded_*) evaluates every unordered
+SHARDED SYMMETRIC scan (csrc/em2_scan_sharded.hip, include/em2_lsh.h: em2_dev_fsp4_sharded_*) evaluates every unordered
 pair once across all ranks instead of once per rank and side.  64-cell blocks are dealt round-robin to the ranks;
 four kernel phases are separated by two all_reduce(MAX) of a 4-byte-per-cell snapshot array and one all_gather of
 the ranks' deferred-candidate pools.  EM2_SHARDED_SCAN=0 keeps the row-shard scan.

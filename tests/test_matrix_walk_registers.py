@@ -1,8 +1,9 @@
 """The hand-scheduled matrix-core walk keeps the wave's rows and accumulators in v64..v255 without the compiler knowing
 (tools/gen_matrix_step_asm.py): the compiler's own code inside scanTilesMatrixPinned must never touch those registers,
 must not spill between the steps, and must not use flat_ instructions there.  Nothing but the compiled code can show
-that, so this test compiles em2_scan_symmetric.hip for gfx950 (no GPU needed) and checks the assembly; it also checks
-that the committed asm header is what the generator writes."""
+that, so this test compiles the two units that contain the walk -- em2_scan_symmetric.hip (the scan kernels) and
+em2_scan_sharded.hip (the tile kernels of the sharded scan) -- for gfx950 (no GPU needed) and checks the assembly; it also
+checks that the committed asm header is what the generator writes."""
 import os
 import subprocess
 import sys
@@ -17,10 +18,14 @@ def test_generated_header_is_current():
     assert text == open(os.path.join(CSRC, "em2_matrix_step_asm.h")).read()
 
 
-def test_compiled_walk_leaves_the_steps_registers_alone(tmp_path):
-    out = str(tmp_path / "sym.s")
+import pytest
+
+
+@pytest.mark.parametrize("unit", ["em2_scan_symmetric.hip", "em2_scan_sharded.hip"])
+def test_compiled_walk_leaves_the_steps_registers_alone(tmp_path, unit):
+    out = str(tmp_path / "unit.s")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-inline-asm",
-           "--cuda-device-only", "-S", "-o", out, os.path.join(CSRC, "em2_scan_symmetric.hip")]
+           "--cuda-device-only", "-S", "-o", out, os.path.join(CSRC, unit)]
     done = subprocess.run(cmd, capture_output=True, text=True)
     assert done.returncode == 0, done.stderr[-3000:]
     check = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_matrix_walk_registers.py"), out], capture_output=True,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Checks the compiled kernels of the hand-scheduled matrix-core walk (fsp4ScanMatrixPinnedKernel,
-fsp4TileMatrixPinnedKernel, csrc/em2_scan_symmetric.hip): the steps keep the wave's rows and accumulators in v64..v255
+fsp4TileMatrixPinnedKernel; csrc/em2_scan_symmetric.hip and csrc/em2_scan_sharded.hip): the steps keep the wave's rows and accumulators in v64..v255
 without the compiler knowing (tools/gen_matrix_step_asm.py), so the compiler's own code in those kernels must never
 touch those registers -- nor v28 / v29, which hold the lane's record offsets from step to step --, should not spill between
 the steps, and must not use flat_ instructions there (their out-of-order completion would break the counted LDS waits).

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes expressionmatrix2_amd/csrc/em2_matrix_step_asm.h: the inline-assembly body of one tile step of the
-matrix-core walk (fsp4ScanMatrixKernel / fsp4TileMatrixKernel, csrc/em2_scan_symmetric.hip).
+matrix-core walk (fsp4ScanMatrixKernel in csrc/em2_scan_symmetric.hip, fsp4TileMatrixKernel in csrc/em2_scan_sharded.hip; the walk itself: csrc/em2_scan_symmetric_device.h).
 
     python3 tools/gen_matrix_step_asm.py > expressionmatrix2_amd/csrc/em2_matrix_step_asm.h
 
@@ -42,7 +42,7 @@ A register that passes in some lane branches to its stub behind the body: the pa
 so that a log holds the records of one row only (v28 / v29 = the lane's byte offsets into the wave's log area, which the
 step returns; they persist from step to step).  That is all a step does about an event:
 which side of the pair the record is for (row, column, both), the exact state machine and the inbox are the business
-of the replay that follows the walk (csrc/em2_scan_symmetric.hip), which reads the logs lane-parallel, many records per
+of the replay that follows the walk (csrc/em2_scan_symmetric_device.h), which reads the logs lane-parallel, many records per
 lane, instead of a few per step.
 The column bounds come from the wave's bound scratch in LDS (32 floats per tile), 16 bytes per group and lane half;
 the row bounds from the wave's state block (float rowDot[64], lane l reads [l & 31] and [32 + (l & 31)]).
@@ -365,7 +365,7 @@ def main():
     out = sys.stdout
     out.write("// em2_matrix_step_asm.h -- GENERATED by tools/gen_matrix_step_asm.py (see there for the register map); do not edit.\n")
     out.write("#ifndef EM2_MATRIX_STEP_ASM_H\n#define EM2_MATRIX_STEP_ASM_H\n\n")
-    # Operand order of the asm statements in em2_scan_symmetric.hip:
+    # Operand order of the asm statements in em2_scan_symmetric_device.h:
     #   step with tests:    %0 / %1 the lanes' record offsets for accumulator 0 / 1 ("=v"), %2..%6 five scratch pairs ("=&s",
     #                       64 bits: the pass masks in flight, the saved exec), then "s": %7 tileBase, %8 boundBase,
     #                       %9 stateBase (LDS byte addresses), %10 logBase (64 bits: the wave's log area), %11 tileCode (first
