@@ -22,6 +22,8 @@
 #include "em2_device.h"
 #include "em2_select_wave.h"
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>      // rocprim/iterator/texture_cache_iterator.hpp calls memset without including it
 
@@ -97,6 +99,58 @@ candidateCountKernel(const uint32_t* __restrict__ runOfSliceCell, const uint32_t
         if (bucketOverflow == 0 || size <= bucketOverflow) n += size;       // ExpressionMatrixLsh.cpp:419
     }
     counts[c] = n;
+}
+
+// ---- the order in which the filter visits the cells of a batch (a schedule: it changes no result) ----
+// The filter gathers the signatures of a cell's candidates, and the candidates of a cell are mostly the cells that are similar
+// to it -- which are also the candidates of every other cell similar to it.  Visited in id order, the waves in flight at any
+// time gather from all over the signature array (256 MB at a million cells x 2048 bits: the Infinity Cache's size); visited
+// group by group, with every XCD working through groups of its own, the waves of an XCD gather from the few megabytes of
+// signatures their group shares, which its L2 holds.  A group label needs no clustering: label(c) = the smallest cell id in
+// any of c's buckets (bucket members ascend: the first member of each), followed through two rounds of pointer jumping
+// (label(label(c)) twice), pulls the cells that are connected through shared buckets to the smallest ids of their
+// neighbourhood -- a handful of values per cluster.  Any labels would give the same SimilarPairs.
+__global__ void __launch_bounds__(256)
+neighbourhoodLabelKernel(const uint32_t* __restrict__ runOfSliceCell, const uint32_t* __restrict__ runStart,
+                         const uint32_t* __restrict__ sortedCells, uint32_t cellCount, uint32_t sliceCount, uint64_t bucketOverflow,
+                         uint32_t* __restrict__ labels)
+{
+    // one wave per cell, lane = slice (the three dependent loads of a bucket's first member, 64 slices at a time)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= cellCount) return;
+    uint32_t best = c;
+    for (uint32_t s = lane; s < sliceCount; s += 64u) {
+        const uint32_t run = runOfSliceCell[size_t(c) * sliceCount + s];
+        const uint32_t begin = runStart[run];
+        const uint64_t size = runStart[run + 1u] - begin;
+        if (bucketOverflow != 0 && size > bucketOverflow) continue;
+        const uint32_t first = sortedCells[begin];
+        best = first < best ? first : best;
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t other = uint32_t(__shfl_xor(int(best), d, 64));
+        best = other < best ? other : best;
+    }
+    if (lane == 0u) labels[c] = best;
+}
+
+__global__ void __launch_bounds__(256)
+jumpLabelsKernel(const uint32_t* __restrict__ in, uint32_t cellCount, uint32_t* __restrict__ out)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < cellCount) out[c] = in[in[c]];
+}
+
+__global__ void __launch_bounds__(256)
+batchOrderKeysKernel(const uint32_t* __restrict__ labels, uint32_t batchBegin, uint32_t batchCells, uint32_t* __restrict__ keys,
+                     uint32_t* __restrict__ locals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batchCells) return;
+    keys[i] = labels[batchBegin + i];
+    locals[i] = i;
 }
 
 // One wave per cell of the batch: copy the members of its buckets into its segment.  The three dependent loads that
@@ -465,13 +519,23 @@ __global__ void __launch_bounds__(256)
 filterWideKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batchBegin, uint32_t batchCells,
                  const uint32_t* __restrict__ segmentBegin, const uint32_t* __restrict__ sortedCandidates,
                  Entry* __restrict__ lists, int32_t mGlobal, const uint32_t* __restrict__ keyOfMismatch,
-                 uint32_t* __restrict__ listCounts, const uint32_t* __restrict__ distinctCounts)
+                 uint32_t* __restrict__ listCounts, const uint32_t* __restrict__ distinctCounts,
+                 const uint32_t* __restrict__ order, uint32_t chunk)
 {
     constexpr int UNROLL = 4;
     __shared__ uint32_t candOfRankAll[4][64];
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* candOfRank = candOfRankAll[threadIdx.x >> 6];
-    const uint32_t local = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t local = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (order) {
+        // (see neighbourhoodLabelKernel) workgroups are dealt to the 8 XCDs round-robin: XCD x walks positions
+        // [x * chunk, (x + 1) * chunk) of the batch's cells in the order of their labels
+        const uint32_t xcd = blockIdx.x & 7u;
+        const uint32_t position = xcd * chunk + (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const uint32_t chunkEnd = (xcd + 1u) * chunk < batchCells ? (xcd + 1u) * chunk : batchCells;
+        if (position >= chunkEnd) return;
+        local = order[position];
+    }
     if (local >= batchCells) return;
     const uint32_t c = batchBegin + local;
     const uint32_t begin = segmentBegin[local];
@@ -813,6 +877,13 @@ uint32_t gridFor(uint64_t n)
     return uint32_t(blocks > 16384 ? 16384 : (blocks ? blocks : 1));
 }
 
+uint64_t envBatchLog2()
+{
+    const char* v = getenv("EM2_FSP5_BATCH_LOG2");
+    const int x = v ? atoi(v) : 29;
+    return uint64_t(x < 20 ? 20 : (x > 31 ? 31 : x));
+}
+
 uint32_t bitsFor(uint64_t maxValue)
 {
     uint32_t b = 1;
@@ -846,6 +917,17 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
     const uint32_t words = (lshCount - 1u) / 64u + 1u;
     const uint32_t sliceCount = lshCount / q;                       // ExpressionMatrixLsh.cpp:355
     if (rowCount == 0) return hipSuccess;
+    // EM2_TIMING=1: wall time of the stages of one call on stderr (each mark synchronises the stream)
+    const bool stageTiming = getenv("EM2_TIMING") && (getenv("EM2_TIMING")[0] == '1' || getenv("EM2_TIMING")[0] == '2');
+    const bool stageSync = stageTiming && getenv("EM2_TIMING")[0] == '1';          // (2: host time only, nothing synchronised)
+    auto stageClock = std::chrono::steady_clock::now();
+    auto stage = [&](const char* name) {
+        if (!stageTiming) return;
+        if (stageSync) (void)hipStreamSynchronize(stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[em2 timing]   findSimilarPairs5: %s %.2f ms\n", name, std::chrono::duration<double, std::milli>(now - stageClock).count());
+        stageClock = now;
+    };
     EM2_TRY(hipMemsetAsync(d_used, 0, size_t(rowCount) * sizeof(uint32_t), stream));
     if (k) EM2_TRY(hipMemsetAsync(d_pairs, 0, size_t(rowCount) * k * sizeof(PairOut), stream));
     if (sliceCount == 0 || cellCount == 0) return hipStreamSynchronize(stream);
@@ -870,6 +952,7 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
     const uint64_t* sortedKeys = keysB.as<uint64_t>();
     const uint32_t* sortedCells = cellsB.as<uint32_t>();
 
+    stage("slice keys + stable sort");
     // 2. runs (= buckets)
     Buffer flags, scan, runStart, runOf, counts;
     EM2_TRY(flags.allocate(total * sizeof(uint32_t)));
@@ -890,15 +973,36 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
     candidateCountKernel<<<(cellCount + 255u) / 256u, 256, 0, stream>>>(runOf.as<uint32_t>(), runStart.as<uint32_t>(), cellCount,
                                                                          sliceCount, bucketOverflow, counts.as<uint64_t>());
     EM2_TRY(hipGetLastError());
+    stage("run tables + candidate counts");
+    // the labels that order the filter's visits (EM2_FSP5_ORDER=id keeps the id order: A/B measurements, tests)
+    const char* orderMode = getenv("EM2_FSP5_ORDER");
+    const bool grouped = !(orderMode && orderMode[0] == 'i');
+    Buffer labelsA, labelsB;
+    if (grouped) {
+        EM2_TRY(labelsA.allocate(size_t(cellCount) * sizeof(uint32_t)));
+        EM2_TRY(labelsB.allocate(size_t(cellCount) * sizeof(uint32_t)));
+        const dim3 labelGrid((cellCount + 255u) / 256u);
+        neighbourhoodLabelKernel<<<dim3((cellCount + 3u) / 4u), 256, 0, stream>>>(runOf.as<uint32_t>(), runStart.as<uint32_t>(), sortedCells, cellCount, sliceCount,
+                                                               bucketOverflow, labelsA.as<uint32_t>());
+        EM2_TRY(hipGetLastError());
+        jumpLabelsKernel<<<labelGrid, 256, 0, stream>>>(labelsA.as<uint32_t>(), cellCount, labelsB.as<uint32_t>());
+        EM2_TRY(hipGetLastError());
+        jumpLabelsKernel<<<labelGrid, 256, 0, stream>>>(labelsB.as<uint32_t>(), cellCount, labelsA.as<uint32_t>());
+        EM2_TRY(hipGetLastError());
+    }
     std::vector<uint64_t> hostCounts(cellCount);
     EM2_TRY(hipMemcpyAsync(hostCounts.data(), counts.p, size_t(cellCount) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     EM2_TRY(hipStreamSynchronize(stream));
+    stage("labels + counts to the host");
     // keys / flags / scan are no longer needed
     keysA.release(); flags.release(); scan.release(); scanTemp.release(); temp.release(); cellsA.release();
 
     // 3. batches of cells whose gathered candidates fit the budget.  The batches are planned first so that the scratch
     // is allocated once, at the size of the largest batch (allocating per batch cost more than the kernels).
-    const uint64_t budget = 1ull << 28;              // 2^28 candidate ids (1 GiB) per batch
+    // (EM2_FSP5_BATCH_LOG2: A/B measurements -- the larger the batch, the longer the filter's grouped order stays on one
+    // neighbourhood's signatures, and the more scratch: 16 bytes per candidate id)
+    const uint64_t budgetLog2 = envBatchLog2();
+    const uint64_t budget = 1ull << budgetLog2;      // 2^29 candidate ids per batch by default (8 GiB of scratch: ids twice, lists)
     struct Batch { uint32_t begin, end; std::vector<uint32_t> seg; };
     std::vector<Batch> batches;
     uint64_t maxTotal = 0;
@@ -962,7 +1066,19 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
     EM2_TRY(listCounts.allocate(size_t(maxCells) * sizeof(uint32_t)));
     EM2_TRY(distinctCounts.allocate(size_t(maxCells) * sizeof(uint32_t)));
     if (useUnion) hostDistinct.resize(maxCells);
+    Buffer orderKeysA, orderKeysB, orderLocalsA, orderLocalsB, orderTemp;
+    size_t orderTempBytes = 0;
+    if (grouped) {
+        EM2_TRY(orderKeysA.allocate(size_t(maxCells) * sizeof(uint32_t)));
+        EM2_TRY(orderKeysB.allocate(size_t(maxCells) * sizeof(uint32_t)));
+        EM2_TRY(orderLocalsA.allocate(size_t(maxCells) * sizeof(uint32_t)));
+        EM2_TRY(orderLocalsB.allocate(size_t(maxCells) * sizeof(uint32_t)));
+        EM2_TRY(rocprim::radix_sort_pairs(nullptr, orderTempBytes, orderKeysA.as<uint32_t>(), orderKeysB.as<uint32_t>(), orderLocalsA.as<uint32_t>(),
+                                          orderLocalsB.as<uint32_t>(), size_t(maxCells), 0u, 32u, stream));
+        EM2_TRY(orderTemp.allocate(orderTempBytes));
+    }
     size_t sortTempBytes = 0;
+    stage("batch plan + scratch allocation");
     const uint32_t idBits = bitsFor(cellCount - 1u);
     // EM2_FSP5_FILTER=lane selects the one-lane-per-candidate filter (A/B measurements)
     const char* filterMode = getenv("EM2_FSP5_FILTER");
@@ -1003,18 +1119,34 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
                                                        segBegin.as<uint32_t>(), segBegin.as<uint32_t>() + 1, 0u, idBits, stream));
             sorted = candB.as<uint32_t>();
         }
+        stage("  batch: union");
+        // the filter's visiting order of this batch: its cells by label (stable: equal labels keep the id order)
+        const uint32_t* order = nullptr;
+        uint32_t orderChunk = 0;
+        if (grouped && wide && batchCells > 64u) {
+            batchOrderKeysKernel<<<(batchCells + 255u) / 256u, 256, 0, stream>>>(labelsA.as<uint32_t>(), batchBegin, batchCells,
+                                                                                 orderKeysA.as<uint32_t>(), orderLocalsA.as<uint32_t>());
+            EM2_TRY(hipGetLastError());
+            size_t bytes = orderTempBytes;
+            EM2_TRY(rocprim::radix_sort_pairs(orderTemp.p, bytes, orderKeysA.as<uint32_t>(), orderKeysB.as<uint32_t>(), orderLocalsA.as<uint32_t>(),
+                                              orderLocalsB.as<uint32_t>(), size_t(batchCells), 0u, idBits, stream));
+            order = orderLocalsB.as<uint32_t>();
+            orderChunk = ((batchCells + 7u) / 8u + 3u) & ~3u;
+        }
+        const uint32_t filterBlocks = order ? 8u * (orderChunk / 4u) : (batchCells + 3u) / 4u;
+        stage("  batch: order");
         if (timing[0]) (void)hipEventRecord(timing[0], stream);
         if (wide) {
             // (signature rows are 16-byte aligned: an even number of words, and the array itself as hipMalloc / the caller's
             // uint64 array provides it -- checked below)
             if (words <= 32u) {
-                filterWideKernel<1><<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
-                                                                              lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,
-                                                                              listCounts.as<uint32_t>(), distinct);
+                filterWideKernel<1><<<filterBlocks, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
+                                                                    lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,
+                                                                    listCounts.as<uint32_t>(), distinct, order, orderChunk);
             } else {
-                filterWideKernel<2><<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
-                                                                              lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,
-                                                                              listCounts.as<uint32_t>(), distinct);
+                filterWideKernel<2><<<filterBlocks, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
+                                                                    lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,
+                                                                    listCounts.as<uint32_t>(), distinct, order, orderChunk);
             }
         } else if (cooperative) {
             filterCooperativeKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(),
@@ -1081,6 +1213,7 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
         if (distinct) EM2_TRY(hipMemcpyAsync(hostDistinct.data(), distinct, size_t(batchCells) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         EM2_TRY(hipStreamSynchronize(stream));       // the batch's offsets (pageable host memory) and scratch are reused
         if (distinct) for (uint32_t i = 0; i < batchCells; i++) distinctTotal += double(hostDistinct[i]);
+        stage("  batch: filter + selection");
         if (timing[0]) {
             float a = 0.f, b = 0.f;
             if (hipEventElapsedTime(&a, timing[0], timing[1]) == hipSuccess && hipEventElapsedTime(&b, timing[1], timing[2]) == hipSuccess) {
@@ -1090,6 +1223,14 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
         }
     }
     lastFsp5Info.distinctCandidates = useUnion ? distinctTotal : -1.;
+    if (stageTiming) {
+        candA.release(); candB.release(); lists.release();
+        stage("release of the candidate scratch");
+        labelsA.release(); labelsB.release(); orderKeysA.release(); orderKeysB.release(); orderLocalsA.release(); orderLocalsB.release(); orderTemp.release();
+        stage("release of the order scratch");
+        keysB.release(); cellsB.release(); runStart.release(); runOf.release(); counts.release();
+        stage("release of the tables");
+    }
 #ifdef EM2_DIAG
     if (getenv("EM2_TIMING") && getenv("EM2_TIMING")[0] == '1') {
         unsigned long long cycles[8] = {0};

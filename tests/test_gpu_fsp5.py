@@ -151,6 +151,19 @@ def test_fsp5_union_forms_agree(oracle, monkeypatch, mode):
         check(oracle, sig, L, k, thr, q, ovf)
 
 
+@pytest.mark.parametrize("order,batch_log2", [("id", "29"), ("group", "29"), ("group", "20"), ("id", "20")])
+def test_fsp5_filter_visiting_orders_agree(oracle, monkeypatch, order, batch_log2):
+    """The filter visits the cells of a batch grouped by a neighbourhood label (smallest id in any of the cell's buckets, two
+    rounds of pointer jumping), every XCD working through its own eighth of that order, instead of in id order
+    (EM2_FSP5_ORDER=id): a schedule, the SimilarPairs are the same.  EM2_FSP5_BATCH_LOG2=20 cuts the cells into many
+    batches (a million candidate ids each), whose orders are computed one by one."""
+    monkeypatch.setenv("EM2_FSP5_ORDER", order)
+    monkeypatch.setenv("EM2_FSP5_BATCH_LOG2", batch_log2)
+    for n, L, k, thr, q, ovf in ((6000, 256, 12, 0.1, 8, 0), (9000, 2048, 9, 0.2, 12, 300), (70, 64, 3, -1.0, 1, 0), (3001, 128, 5, 0.0, 7, 0)):
+        sig = synth.clustered_signatures(n, L, cluster_count=7, flip=0.2, seed=n + 3)
+        check(oracle, sig, L, k, thr, q, ovf)
+
+
 @pytest.mark.parametrize("mode", ["wide", "cooperative", "lane"])
 def test_fsp5_filter_forms_agree(oracle, monkeypatch, mode):
     """The candidate filter (src/ExpressionMatrixLsh.cpp:436-457) as 16-byte loads with several candidates in flight
