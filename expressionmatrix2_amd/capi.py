@@ -89,6 +89,7 @@ SYMBOLS = {
     "em2_dev_find_similar_pairs4_form_for": (_c.c_int, [_c.c_uint32, _c.c_uint32, _c.c_uint32]),
     "em2_dev_find_similar_pairs4_last_launch": (_c.c_int, [_c.c_void_p, _c.c_uint32]),
     "em2_dev_find_similar_pairs5_last_launch": (_c.c_int, [_c.c_void_p, _c.c_uint32]),
+    "em2_dev_release_scratch": (None, []),
     "em2_dev_fsp4_sharded_plan": (_c.c_int, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                              _c.c_void_p, _c.c_uint32]),
     "em2_dev_fsp4_sharded_phase": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_double,
@@ -451,6 +452,11 @@ def dev_find_similar_pairs5_last_launch():
     check(load().em2_dev_find_similar_pairs5_last_launch(_ptr(v), 7))
     return {"gathered_candidates": float(v[0]), "cells": int(v[1]), "slice_count": int(v[2]), "batches": int(v[3]),
             "filter_ms": float(v[4]), "select_ms": float(v[5]), "distinct_candidates": float(v[6])}
+
+
+def dev_release_scratch():
+    """Frees the device scratch findSimilarPairs5 keeps between the calls of this process (include/em2_lsh.h)."""
+    load().em2_dev_release_scratch()
 
 
 def dev_find_similar_pairs4(sig_ptr, cell_count, row_begin, row_end, lsh_count, k, similarity_threshold,

@@ -380,6 +380,8 @@ int em2_dev_find_similar_pairs4_last_launch(double* values, uint32_t valueCount)
 }
 
 
+void em2_dev_release_scratch(void) { em2::fsp5ReleaseScratch(); }
+
 int em2_dev_find_similar_pairs5_last_launch(double* values, uint32_t valueCount)
 {
     if (!values && valueCount) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_find_similar_pairs5_last_launch: null pointer");

@@ -123,6 +123,8 @@ struct Fsp5LaunchInfo {
     double distinctCandidates;      // what the filter read: the sizes of the cells' duplicate-free unions (the cell itself included); -1 in the sort form
 };
 Fsp5LaunchInfo fsp5LastLaunchInfo();
+// Frees the device scratch runFsp5 keeps between calls (em2_fsp5.hip: ScratchCache).
+void fsp5ReleaseScratch();
 
 hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin, uint32_t rowEnd, uint32_t lshCount,
                    uint32_t k, uint32_t q, uint64_t bucketOverflow, const DeviceTables& tables, PairOut* d_pairs,

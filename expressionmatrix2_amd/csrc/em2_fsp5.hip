@@ -30,6 +30,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 namespace em2 {
@@ -538,9 +539,10 @@ filterWideKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batc
     }
     if (local >= batchCells) return;
     const uint32_t c = batchBegin + local;
-    const uint32_t begin = segmentBegin[local];
-    const uint32_t end = distinctCounts ? begin + distinctCounts[local] : segmentBegin[local + 1u];
-    Entry* list = lists + begin;
+    const uint32_t listBegin = segmentBegin[local];
+    const uint32_t listEnd = distinctCounts ? listBegin + distinctCounts[local] : segmentBegin[local + 1u];
+    Entry* list = lists + listBegin;
+    const uint32_t begin = listBegin, end = listEnd;
     const uint32_t units = words / 2u;                      // 16-byte units of a signature
     uint32_t lpc = 1u;
     while (lpc < 16u && lpc * uint32_t(T) < units) lpc <<= 1;
@@ -561,8 +563,10 @@ filterWideKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batc
         bool need = false;
         uint32_t cand = 0;
         if (i < end) {
-            cand = sortedCandidates[i];
-            const bool duplicate = i > begin && sortedCandidates[i - 1u] == cand;
+            // (the candidate ids and the list entries are streams: non-temporal, so that they do not push the signatures the
+            // XCD's cells share out of its L2)
+            cand = __builtin_nontemporal_load(sortedCandidates + i);
+            const bool duplicate = i > listBegin && __builtin_nontemporal_load(sortedCandidates + i - 1u) == cand;
             need = !duplicate && cand != c;                                  // ExpressionMatrixLsh.cpp:437-439
         }
         const uint64_t needMask = __builtin_amdgcn_ballot_w64(need);
@@ -602,10 +606,8 @@ filterWideKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batc
         const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
         if (keep) {
             const uint32_t before = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
-            Entry e;
-            e.cell = cand;
-            e.key = keyOfMismatch[m];
-            list[n + before] = e;
+            const uint64_t entry = uint64_t(cand) | (uint64_t(keyOfMismatch[m]) << 32);          // Entry {cell, key}
+            __builtin_nontemporal_store(entry, reinterpret_cast<uint64_t*>(list + n + before));
         }
         n += uint32_t(__builtin_popcountll(mask));
     }
@@ -863,11 +865,103 @@ selectGlobalKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegi
     if (lane == 0u) outUsed[local] = n;
 }
 
+// The scratch of a call (tables, candidate ids, lists: 10 GB at a million cells x 2048 bits) comes from a cache of device blocks
+// the process keeps between calls: hipMalloc of gigabytes costs anything between 4 and 200 ms per call depending on the state of
+// the box (measured: the same command, two leases), more than the tables' kernels.  A block goes back to the cache only when
+// the call completed (its stream synchronised); a call that returns early with an error frees its blocks (hipFree waits for the
+// device).  EM2_SCRATCH_CACHE_MB caps what is kept (default 32768; 0 = nothing is kept); em2_dev_release_scratch() frees it.
+class ScratchCache {
+public:
+    void* take(size_t bytes, int device, size_t* got)
+    {
+        std::lock_guard<std::mutex> guard(mutex_);
+        size_t best = blocks_.size();
+        for (size_t i = 0; i < blocks_.size(); ++i) {
+            const Block& b = blocks_[i];
+            if (b.device != device || b.bytes < bytes || b.bytes > bytes + bytes / 2u + (size_t(1) << 20)) continue;
+            if (best == blocks_.size() || b.bytes < blocks_[best].bytes) best = i;
+        }
+        if (best == blocks_.size()) return nullptr;
+        void* p = blocks_[best].p;
+        *got = blocks_[best].bytes;
+        total_ -= blocks_[best].bytes;
+        blocks_.erase(blocks_.begin() + long(best));
+        return p;
+    }
+    void give(void* p, size_t bytes, int device)
+    {
+        {
+            std::lock_guard<std::mutex> guard(mutex_);
+            if (total_ + bytes <= capBytes() && blocks_.size() < 256u) {
+                blocks_.push_back(Block{p, bytes, device});
+                total_ += bytes;
+                return;
+            }
+        }
+        (void)hipFree(p);
+    }
+    void clear()
+    {
+        std::vector<Block> freed;
+        {
+            std::lock_guard<std::mutex> guard(mutex_);
+            freed.swap(blocks_);
+            total_ = 0;
+        }
+        for (const Block& b : freed) (void)hipFree(b.p);
+    }
+    static ScratchCache& instance()
+    {
+        static ScratchCache* cache = new ScratchCache();          // (never destroyed: the HIP runtime may be gone at exit)
+        return *cache;
+    }
+
+private:
+    struct Block { void* p; size_t bytes; int device; };
+    static size_t capBytes()
+    {
+        const char* v = getenv("EM2_SCRATCH_CACHE_MB");
+        const unsigned long long mb = v ? strtoull(v, nullptr, 10) : 32768ull;
+        return size_t(mb) << 20;
+    }
+    std::mutex mutex_;
+    std::vector<Block> blocks_;
+    size_t total_ = 0;
+};
+
+thread_local bool scratchCallCompleted = false;          // set right before a call's normal return: its buffers may be cached
+
 struct Buffer {
     void* p = nullptr;
-    ~Buffer() { if (p) (void)hipFree(p); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; } }
-    hipError_t allocate(size_t bytes) { release(); return hipMalloc(&p, bytes ? bytes : 1); }
+    size_t bytes = 0;
+    int device = 0;
+    ~Buffer() { drop(scratchCallCompleted); }
+    // (explicit releases happen behind a synchronisation of the stream: the block is idle)
+    void release() { drop(true); }
+    void drop(bool idle)
+    {
+        if (!p) return;
+        if (idle) ScratchCache::instance().give(p, bytes, device);
+        else (void)hipFree(p);
+        p = nullptr;
+    }
+    hipError_t allocate(size_t wanted)
+    {
+        drop(false);
+        wanted = wanted ? wanted : 1;
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+        p = ScratchCache::instance().take(wanted, device, &bytes);
+        if (p) return hipSuccess;
+        bytes = wanted;
+        const hipError_t e = hipMalloc(&p, wanted);
+        if (e != hipSuccess) {
+            // (memory held by the cache may be what is missing)
+            (void)hipGetLastError();
+            ScratchCache::instance().clear();
+            return hipMalloc(&p, wanted);
+        }
+        return e;
+    }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -909,6 +1003,8 @@ thread_local Fsp5LaunchInfo lastFsp5Info = {0., 0., 0., 0., -1., -1., -1.};
 
 Fsp5LaunchInfo fsp5LastLaunchInfo() { return lastFsp5Info; }
 
+void fsp5ReleaseScratch() { ScratchCache::instance().clear(); }
+
 hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin, uint32_t rowEnd, uint32_t lshCount,
                    uint32_t k, uint32_t q, uint64_t bucketOverflow, const DeviceTables& tables, PairOut* d_pairs,
                    uint32_t* d_used, hipStream_t stream)
@@ -917,6 +1013,7 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
     const uint32_t words = (lshCount - 1u) / 64u + 1u;
     const uint32_t sliceCount = lshCount / q;                       // ExpressionMatrixLsh.cpp:355
     if (rowCount == 0) return hipSuccess;
+    scratchCallCompleted = false;
     // EM2_TIMING=1: wall time of the stages of one call on stderr (each mark synchronises the stream)
     const bool stageTiming = getenv("EM2_TIMING") && (getenv("EM2_TIMING")[0] == '1' || getenv("EM2_TIMING")[0] == '2');
     const bool stageSync = stageTiming && getenv("EM2_TIMING")[0] == '1';          // (2: host time only, nothing synchronised)
@@ -1242,6 +1339,7 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
         }
     }
 #endif
+    scratchCallCompleted = true;          // (every batch ended with a synchronisation of the stream: the scratch is idle)
     return hipSuccess;
 }
 

@@ -305,6 +305,12 @@ int em2_dev_find_similar_pairs5(const uint64_t* d_signatures, uint32_t cellCount
  * (the sizes of the duplicate-free unions, the cell itself included): the signatures the filter actually gathers. */
 int em2_dev_find_similar_pairs5_last_launch(double* values, uint32_t valueCount);
 
+/* findSimilarPairs5 keeps its device scratch (bucket tables, candidate ids, candidate lists: about 10 GB at a million cells x
+ * 2048 bits) between calls of the process, because allocating gigabytes costs up to 200 ms per call on some hosts; at most
+ * EM2_SCRATCH_CACHE_MB megabytes are kept (default 32768, 0 = none).  This call frees what is kept.  The reference has no
+ * counterpart (its tables are std::vectors of the call, src/ExpressionMatrixLsh.cpp:377-389). */
+void em2_dev_release_scratch(void);
+
 /* ------------------------------------------------------------------------------------------------------
  * SURVEY.md 8(f), first "next" row: the consumer of SimilarPairs.
  * ------------------------------------------------------------------------------------------------------ */

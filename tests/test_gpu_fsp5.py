@@ -196,3 +196,18 @@ def test_fsp5_long_lists_all_selection_tiers(oracle, mode, monkeypatch):
         assert np.array_equal(pairs["similarity"][:40].view(np.uint32), sim.view(np.uint32))
         cell, sim, oused = oracle.find_similar_pairs5_rows(sig, L, k, 0.2, 16, 0, cells - 30, cells)
         assert np.array_equal(gused[-30:], oused) and np.array_equal(pairs["cell"][-30:], cell)
+
+
+@pytest.mark.parametrize("cache_mb", [None, "0", "1"])
+def test_fsp5_scratch_cache_is_only_a_cache(oracle, monkeypatch, cache_mb):
+    """The call's device scratch comes from blocks the process keeps between calls (hipMalloc of gigabytes costs up to 200 ms on
+    some hosts): repeated calls of different sizes, with the cache off (EM2_SCRATCH_CACHE_MB=0), too small to keep anything
+    useful (1 MB) and at its default, and after em2_dev_release_scratch(), all give the oracle's SimilarPairs."""
+    if cache_mb is not None:
+        monkeypatch.setenv("EM2_SCRATCH_CACHE_MB", cache_mb)
+    for n, L, k, q in ((4000, 256, 9, 8), (2500, 256, 9, 8), (4000, 256, 9, 8), (6000, 128, 5, 7)):
+        sig = synth.clustered_signatures(n, L, cluster_count=5, flip=0.2, seed=n)
+        check(oracle, sig, L, k, 0.2, q, 0)
+        if n == 2500:
+            capi.dev_release_scratch()
+    capi.dev_release_scratch()
