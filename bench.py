@@ -395,7 +395,7 @@ def bench_fsp5(args, capi, oracle, device, torch):
                    "slices": info["slice_count"], "batches": info["batches"]},
         "phases_ms": {"candidate_filter": filter_ms, "selection": select_ms,
                       "tables_and_candidate_unions": elapsed / args.steps * 1e3 - filter_ms - select_ms},
-        "roofline": {"kernel": ("filterWideKernel<%d> (all batches)" % (1 if W <= 32 else 2)) if W % 2 == 0 and W <= 64 and
+        "roofline": {"kernel": ("filterWideKernel<%s> (all batches)" % ("1, 16" if W == 32 else "2, 16" if W == 64 else "T, LPC")) if W % 2 == 0 and W <= 64 and
                                os.environ.get("EM2_FSP5_FILTER", "w")[0] == "w" else "filterCooperativeKernel (all batches)", "kernel_ms": filter_ms, "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes": algorithmic, "distinct_candidates": distinct, "gathered_candidates": info["gathered_candidates"],

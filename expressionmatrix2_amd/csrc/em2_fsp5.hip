@@ -515,7 +515,13 @@ filterCooperativeKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32
 // 16-byte units -- at 2048 bits one 256-byte request per candidate, where filterCooperativeKernel issues two 128-byte requests
 // of 8-byte lane loads (8-byte accesses reach 0.54-0.70 of the 16-byte rate: MI355X_MICROARCH.md, visibility table) -- and a
 // lane has UNROLL such loads outstanding before the first popcount.  Everything else is filterCooperativeKernel.
-template <int T>            // 16-byte units per lane: 1 (up to 2048 bits with 16 lanes per candidate), 2 (up to 4096 bits)
+// T: 16-byte units per lane -- 1 (up to 2048 bits with 16 lanes per candidate), 2 (up to 4096 bits).  LPC: lanes per candidate
+// as a compile-time constant (16, 8), or 0 = decided at run time (narrow signatures).  Since the grouped visiting order the kernel
+// is bound by its vector ALUs (VALU busy 85 %), so the inner loop is straight-line code: the loads are unconditional (a slot
+// without a candidate reads the cell's own row and counts 0), one 16-byte load per unit, the 16-lane sums are four
+// data-parallel-primitive adds, and a candidate's count goes to its rank's slot in LDS, from where the lane that holds the
+// candidate picks it up once per 64 candidates (it was a shuffle per group of candidates).
+template <int T, int LPC>
 __global__ void __launch_bounds__(256)
 filterWideKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batchBegin, uint32_t batchCells,
                  const uint32_t* __restrict__ segmentBegin, const uint32_t* __restrict__ sortedCandidates,
@@ -525,8 +531,10 @@ filterWideKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batc
 {
     constexpr int UNROLL = 4;
     __shared__ uint32_t candOfRankAll[4][64];
+    __shared__ uint32_t countOfRankAll[4][64];
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* candOfRank = candOfRankAll[threadIdx.x >> 6];
+    uint32_t* countOfRank = countOfRankAll[threadIdx.x >> 6];
     uint32_t local = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (order) {
         // (see neighbourhoodLabelKernel) workgroups are dealt to the 8 XCDs round-robin: XCD x walks positions
@@ -544,18 +552,22 @@ filterWideKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batc
     Entry* list = lists + listBegin;
     const uint32_t begin = listBegin, end = listEnd;
     const uint32_t units = words / 2u;                      // 16-byte units of a signature
-    uint32_t lpc = 1u;
-    while (lpc < 16u && lpc * uint32_t(T) < units) lpc <<= 1;
+    uint32_t lpc = LPC ? uint32_t(LPC) : 1u;
+    if (!LPC) {
+        while (lpc < 16u && lpc * uint32_t(T) < units) lpc <<= 1;
+    }
     const uint32_t perStep = 64u / lpc;
     const uint32_t sub = lane % lpc;
     const uint32_t slot = lane / lpc;
-    const ulonglong2* sig16 = reinterpret_cast<const ulonglong2*>(sig);
-    ulonglong2 mine[T];
+    const uint4* sig16 = reinterpret_cast<const uint4*>(sig);
+    uint4 mine[T];
+    uint32_t unit[T];          // the lane's 16-byte units of a row (a lane beyond the row re-reads unit 0 and counts nothing)
     bool active[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         active[t] = sub + uint32_t(t) * lpc < units;
-        mine[t] = active[t] ? sig16[size_t(c) * units + sub + uint32_t(t) * lpc] : ulonglong2{0ull, 0ull};
+        unit[t] = active[t] ? sub + uint32_t(t) * lpc : 0u;
+        mine[t] = sig16[size_t(c) * units + unit[t]];
     }
     uint32_t n = 0;
     for (uint32_t base = begin; base < end; base += 64u) {
@@ -574,34 +586,36 @@ filterWideKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batc
         const uint32_t myRank = __builtin_amdgcn_mbcnt_hi(uint32_t(needMask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(needMask), 0u));
         if (need) candOfRank[myRank] = cand;
         waveFence();
-        uint32_t m = 0;
         for (uint32_t first = 0; first < needCount; first += perStep * uint32_t(UNROLL)) {
-            ulonglong2 theirs[UNROLL][T];
-            bool have[UNROLL];
+            uint4 theirs[UNROLL][T];
+            uint32_t rank[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-                const uint32_t rank = first + uint32_t(u) * perStep + slot;
-                have[u] = rank < needCount;
-                const size_t row = have[u] ? size_t(candOfRank[rank]) * units : 0;
+                rank[u] = first + uint32_t(u) * perStep + slot;
+                const uint32_t rowCell = rank[u] < needCount ? candOfRank[rank[u]] : c;
+                const uint4* row = sig16 + size_t(rowCell) * units;
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    theirs[u][t] = (have[u] && active[t]) ? sig16[row + sub + uint32_t(t) * lpc] : mine[t];
-                }
+                for (int t = 0; t < T; ++t) theirs[u][t] = row[unit[t]];
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 uint32_t part = 0;
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    part += uint32_t(__builtin_popcountll(mine[t].x ^ theirs[u][t].x)) + uint32_t(__builtin_popcountll(mine[t].y ^ theirs[u][t].y));
+                    const uint32_t bits = uint32_t(__builtin_popcount(mine[t].x ^ theirs[u][t].x)) + uint32_t(__builtin_popcount(mine[t].y ^ theirs[u][t].y)) +
+                                          uint32_t(__builtin_popcount(mine[t].z ^ theirs[u][t].z)) + uint32_t(__builtin_popcount(mine[t].w ^ theirs[u][t].w));
+                    part += active[t] ? bits : 0u;
                 }
-                for (uint32_t d = 1; d < lpc; d <<= 1) part += uint32_t(__shfl_xor(int(part), int(d), 64));
-                const uint32_t offset = myRank - first - uint32_t(u) * perStep;          // (wraps for ranks below this group)
-                const uint32_t got = uint32_t(__shfl(int(part), int((offset % perStep) * lpc), 64));
-                if (need && offset < perStep) m = got;
+                // sum over the lpc (<= 16) lanes of the candidate: data-parallel-primitive adds inside a row of 16 lanes
+                if (lpc >= 2u) part += uint32_t(__builtin_amdgcn_update_dpp(0, int(part), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+                if (lpc >= 4u) part += uint32_t(__builtin_amdgcn_update_dpp(0, int(part), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+                if (lpc >= 8u) part += uint32_t(__builtin_amdgcn_update_dpp(0, int(part), 0x141, 0xF, 0xF, false));     // row_half_mirror
+                if (lpc >= 16u) part += uint32_t(__builtin_amdgcn_update_dpp(0, int(part), 0x140, 0xF, 0xF, false));    // row_mirror
+                if (sub == 0u && rank[u] < needCount) countOfRank[rank[u]] = part;
             }
         }
         waveFence();
+        const uint32_t m = need ? countOfRank[myRank] : 0u;
         const bool keep = need && int32_t(m) <= mGlobal;                     // similarity > similarityThreshold (:441)
         const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
         if (keep) {
@@ -610,6 +624,7 @@ filterWideKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batc
             __builtin_nontemporal_store(entry, reinterpret_cast<uint64_t*>(list + n + before));
         }
         n += uint32_t(__builtin_popcountll(mask));
+        waveFence();          // (the next 64 candidates overwrite the two rank arrays)
     }
     if (lane == 0u) listCounts[local] = n;
 }
@@ -1236,15 +1251,20 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
         if (wide) {
             // (signature rows are 16-byte aligned: an even number of words, and the array itself as hipMalloc / the caller's
             // uint64 array provides it -- checked below)
-            if (words <= 32u) {
-                filterWideKernel<1><<<filterBlocks, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
-                                                                    lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,
-                                                                    listCounts.as<uint32_t>(), distinct, order, orderChunk);
-            } else {
-                filterWideKernel<2><<<filterBlocks, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,
-                                                                    lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,
-                                                                    listCounts.as<uint32_t>(), distinct, order, orderChunk);
-            }
+            const uint32_t units = words / 2u;
+            const uint32_t unitsPerLane = words <= 32u ? 1u : 2u;
+            uint32_t lanesPerCandidate = 1u;
+            while (lanesPerCandidate < 16u && lanesPerCandidate * unitsPerLane < units) lanesPerCandidate <<= 1;
+#define EM2_FILTER_WIDE(TT, LL)                                                                                                     \
+            filterWideKernel<TT, LL><<<filterBlocks, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,  \
+                                                                     lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,         \
+                                                                     listCounts.as<uint32_t>(), distinct, order, orderChunk)
+            if (unitsPerLane == 1u && lanesPerCandidate == 16u) EM2_FILTER_WIDE(1, 16);
+            else if (unitsPerLane == 1u && lanesPerCandidate == 8u) EM2_FILTER_WIDE(1, 8);
+            else if (unitsPerLane == 1u) EM2_FILTER_WIDE(1, 0);
+            else if (lanesPerCandidate == 16u) EM2_FILTER_WIDE(2, 16);
+            else EM2_FILTER_WIDE(2, 0);
+#undef EM2_FILTER_WIDE
         } else if (cooperative) {
             filterCooperativeKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(),
                                                                                 sorted, lists.as<Entry>(), tables.mGlobal,

@@ -84,9 +84,15 @@ def main():
         elif what == "fsp5":
             q = int(rng.choice([1, 3, 8, 13, 20]))
             overflow = int(rng.choice([0, 5, 1000]))
-            label.update(q=q, overflow=overflow)
+            knobs = {"EM2_FSP5_ORDER": str(rng.choice(["group", "group", "id"])), "EM2_FSP5_BATCH_LOG2": str(int(rng.choice([20, 22, 29]))),
+                     "EM2_SCRATCH_CACHE_MB": str(int(rng.choice([0, 1, 32768]))), "EM2_FSP5_FILTER": str(rng.choice(["wide", "wide", "cooperative", "lane"])),
+                     "EM2_FSP5_UNION": str(rng.choice(["bitmap", "bitmap", "sort"]))}
+            os.environ.update(knobs)
+            label.update(q=q, overflow=overflow, **knobs)
             cell, sim, used = oracle.find_similar_pairs5(sig, L, k, thr, q, overflow)
             pairs, gused = capi.find_similar_pairs5(sig, L, k, thr, q, overflow)
+            for key in knobs:
+                os.environ.pop(key, None)
         elif what == "fsp7":
             lengths = sorted(set(int(x) for x in rng.choice([1, 2, 5, 8, 13, 16, 24, 33, 64], size=int(rng.integers(1, 4)))), reverse=True)
             max_check = int(rng.choice([0, 1, 7, 100, 100000]))
