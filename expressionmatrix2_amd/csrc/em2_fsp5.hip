@@ -114,27 +114,36 @@ candidateCountKernel(const uint32_t* __restrict__ runOfSliceCell, const uint32_t
 __global__ void __launch_bounds__(256)
 neighbourhoodLabelKernel(const uint32_t* __restrict__ runOfSliceCell, const uint32_t* __restrict__ runStart,
                          const uint32_t* __restrict__ sortedCells, uint32_t cellCount, uint32_t sliceCount, uint64_t bucketOverflow,
-                         uint32_t* __restrict__ labels)
+                         uint32_t* __restrict__ labels, uint64_t* __restrict__ counts)
 {
-    // one wave per cell, lane = slice (the three dependent loads of a bucket's first member, 64 slices at a time)
+    // one wave per cell, lane = slice (the dependent loads of a bucket's size and first member, 64 slices at a time); the same
+    // walk gives the number of bucket members the cell will gather (candidateCountKernel's result; labels may be null)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= cellCount) return;
     uint32_t best = c;
+    uint64_t members = 0;
     for (uint32_t s = lane; s < sliceCount; s += 64u) {
         const uint32_t run = runOfSliceCell[size_t(c) * sliceCount + s];
         const uint32_t begin = runStart[run];
         const uint64_t size = runStart[run + 1u] - begin;
-        if (bucketOverflow != 0 && size > bucketOverflow) continue;
-        const uint32_t first = sortedCells[begin];
-        best = first < best ? first : best;
+        if (bucketOverflow != 0 && size > bucketOverflow) continue;                // ExpressionMatrixLsh.cpp:419
+        members += size;
+        if (labels) {
+            const uint32_t first = sortedCells[begin];
+            best = first < best ? first : best;
+        }
     }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t other = uint32_t(__shfl_xor(int(best), d, 64));
         best = other < best ? other : best;
+        members += uint64_t(__shfl_xor((long long)members, d, 64));
     }
-    if (lane == 0u) labels[c] = best;
+    if (lane == 0u) {
+        if (labels) labels[c] = best;
+        counts[c] = members;
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -516,12 +525,13 @@ filterCooperativeKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32
 // of 8-byte lane loads (8-byte accesses reach 0.54-0.70 of the 16-byte rate: MI355X_MICROARCH.md, visibility table) -- and a
 // lane has UNROLL such loads outstanding before the first popcount.  Everything else is filterCooperativeKernel.
 // T: 16-byte units per lane -- 1 (up to 2048 bits with 16 lanes per candidate), 2 (up to 4096 bits).  LPC: lanes per candidate
-// as a compile-time constant (16, 8), or 0 = decided at run time (narrow signatures).  Since the grouped visiting order the kernel
+// as a compile-time constant (16, 8), or 0 = decided at run time (narrow signatures); FULL: every lane holds a unit of the row
+// (units == T * LPC: 2048 and 4096 bits).  Since the grouped visiting order the kernel
 // is bound by its vector ALUs (VALU busy 85 %), so the inner loop is straight-line code: the loads are unconditional (a slot
 // without a candidate reads the cell's own row and counts 0), one 16-byte load per unit, the 16-lane sums are four
 // data-parallel-primitive adds, and a candidate's count goes to its rank's slot in LDS, from where the lane that holds the
 // candidate picks it up once per 64 candidates (it was a shuffle per group of candidates).
-template <int T, int LPC>
+template <int T, int LPC, bool FULL>
 __global__ void __launch_bounds__(256)
 filterWideKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batchBegin, uint32_t batchCells,
                  const uint32_t* __restrict__ segmentBegin, const uint32_t* __restrict__ sortedCandidates,
@@ -597,21 +607,38 @@ filterWideKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batc
 #pragma unroll
                 for (int t = 0; t < T; ++t) theirs[u][t] = row[unit[t]];
             }
+            uint32_t part[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-                uint32_t part = 0;
+                part[u] = 0;
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     const uint32_t bits = uint32_t(__builtin_popcount(mine[t].x ^ theirs[u][t].x)) + uint32_t(__builtin_popcount(mine[t].y ^ theirs[u][t].y)) +
                                           uint32_t(__builtin_popcount(mine[t].z ^ theirs[u][t].z)) + uint32_t(__builtin_popcount(mine[t].w ^ theirs[u][t].w));
-                    part += active[t] ? bits : 0u;
+                    part[u] += (FULL || active[t]) ? bits : 0u;
                 }
-                // sum over the lpc (<= 16) lanes of the candidate: data-parallel-primitive adds inside a row of 16 lanes
-                if (lpc >= 2u) part += uint32_t(__builtin_amdgcn_update_dpp(0, int(part), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
-                if (lpc >= 4u) part += uint32_t(__builtin_amdgcn_update_dpp(0, int(part), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
-                if (lpc >= 8u) part += uint32_t(__builtin_amdgcn_update_dpp(0, int(part), 0x141, 0xF, 0xF, false));     // row_half_mirror
-                if (lpc >= 16u) part += uint32_t(__builtin_amdgcn_update_dpp(0, int(part), 0x140, 0xF, 0xF, false));    // row_mirror
-                if (sub == 0u && rank[u] < needCount) countOfRank[rank[u]] = part;
+            }
+            // sums over the lpc (<= 16) lanes of a candidate: data-parallel-primitive adds inside a row of 16 lanes, the four
+            // candidates of a turn step by step (an add's result may not feed the next DPP read for two cycles)
+            if (lpc >= 2u) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) part[u] += uint32_t(__builtin_amdgcn_update_dpp(0, int(part[u]), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+            }
+            if (lpc >= 4u) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) part[u] += uint32_t(__builtin_amdgcn_update_dpp(0, int(part[u]), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+            }
+            if (lpc >= 8u) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) part[u] += uint32_t(__builtin_amdgcn_update_dpp(0, int(part[u]), 0x141, 0xF, 0xF, false));     // row_half_mirror
+            }
+            if (lpc >= 16u) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) part[u] += uint32_t(__builtin_amdgcn_update_dpp(0, int(part[u]), 0x140, 0xF, 0xF, false));     // row_mirror
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                if (sub == 0u && rank[u] < needCount) countOfRank[rank[u]] = part[u];
             }
         }
         waveFence();
@@ -1082,21 +1109,21 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
     runTablesKernel<<<gridFor(total), 256, 0, stream>>>(sortedKeys, sortedCells, flags.as<uint32_t>(), scan.as<uint32_t>(), total,
                                                         cellCount, sliceCount, runStart.as<uint32_t>(), runOf.as<uint32_t>());
     EM2_TRY(hipGetLastError());
-    candidateCountKernel<<<(cellCount + 255u) / 256u, 256, 0, stream>>>(runOf.as<uint32_t>(), runStart.as<uint32_t>(), cellCount,
-                                                                         sliceCount, bucketOverflow, counts.as<uint64_t>());
-    EM2_TRY(hipGetLastError());
-    stage("run tables + candidate counts");
-    // the labels that order the filter's visits (EM2_FSP5_ORDER=id keeps the id order: A/B measurements, tests)
+    stage("run tables");
+    // the labels that order the filter's visits (EM2_FSP5_ORDER=id keeps the id order: A/B measurements, tests), and in the same
+    // walk over the cells' bucket descriptors the number of members every cell will gather
     const char* orderMode = getenv("EM2_FSP5_ORDER");
     const bool grouped = !(orderMode && orderMode[0] == 'i');
     Buffer labelsA, labelsB;
     if (grouped) {
         EM2_TRY(labelsA.allocate(size_t(cellCount) * sizeof(uint32_t)));
         EM2_TRY(labelsB.allocate(size_t(cellCount) * sizeof(uint32_t)));
+    }
+    neighbourhoodLabelKernel<<<dim3((cellCount + 3u) / 4u), 256, 0, stream>>>(runOf.as<uint32_t>(), runStart.as<uint32_t>(), sortedCells, cellCount, sliceCount,
+                                                                             bucketOverflow, grouped ? labelsA.as<uint32_t>() : nullptr, counts.as<uint64_t>());
+    EM2_TRY(hipGetLastError());
+    if (grouped) {
         const dim3 labelGrid((cellCount + 255u) / 256u);
-        neighbourhoodLabelKernel<<<dim3((cellCount + 3u) / 4u), 256, 0, stream>>>(runOf.as<uint32_t>(), runStart.as<uint32_t>(), sortedCells, cellCount, sliceCount,
-                                                               bucketOverflow, labelsA.as<uint32_t>());
-        EM2_TRY(hipGetLastError());
         jumpLabelsKernel<<<labelGrid, 256, 0, stream>>>(labelsA.as<uint32_t>(), cellCount, labelsB.as<uint32_t>());
         EM2_TRY(hipGetLastError());
         jumpLabelsKernel<<<labelGrid, 256, 0, stream>>>(labelsB.as<uint32_t>(), cellCount, labelsA.as<uint32_t>());
@@ -1255,15 +1282,17 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
             const uint32_t unitsPerLane = words <= 32u ? 1u : 2u;
             uint32_t lanesPerCandidate = 1u;
             while (lanesPerCandidate < 16u && lanesPerCandidate * unitsPerLane < units) lanesPerCandidate <<= 1;
-#define EM2_FILTER_WIDE(TT, LL)                                                                                                     \
-            filterWideKernel<TT, LL><<<filterBlocks, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,  \
+#define EM2_FILTER_WIDE(TT, LL, FF)                                                                                                     \
+            filterWideKernel<TT, LL, FF><<<filterBlocks, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,  \
                                                                      lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,         \
                                                                      listCounts.as<uint32_t>(), distinct, order, orderChunk)
-            if (unitsPerLane == 1u && lanesPerCandidate == 16u) EM2_FILTER_WIDE(1, 16);
-            else if (unitsPerLane == 1u && lanesPerCandidate == 8u) EM2_FILTER_WIDE(1, 8);
-            else if (unitsPerLane == 1u) EM2_FILTER_WIDE(1, 0);
-            else if (lanesPerCandidate == 16u) EM2_FILTER_WIDE(2, 16);
-            else EM2_FILTER_WIDE(2, 0);
+            if (unitsPerLane == 1u && units == 16u) EM2_FILTER_WIDE(1, 16, true);
+            else if (unitsPerLane == 1u && lanesPerCandidate == 16u) EM2_FILTER_WIDE(1, 16, false);
+            else if (unitsPerLane == 1u && lanesPerCandidate == 8u) EM2_FILTER_WIDE(1, 8, false);
+            else if (unitsPerLane == 1u) EM2_FILTER_WIDE(1, 0, false);
+            else if (units == 32u) EM2_FILTER_WIDE(2, 16, true);
+            else if (lanesPerCandidate == 16u) EM2_FILTER_WIDE(2, 16, false);
+            else EM2_FILTER_WIDE(2, 0, false);
 #undef EM2_FILTER_WIDE
         } else if (cooperative) {
             filterCooperativeKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(),
