@@ -58,20 +58,21 @@ VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9     # 256 CUs x 4 SIMD x 16 lanes/clk
 # The PMC digests `traffic` may come from (tools/profile_bench.sh -> tools/profile_digest.py), one per workload; each names
 # the configuration it was taken on and is used for that configuration only (tests/test_bench_plumbing_cpu.py).
 PROFILE_DIGESTS = {
-    "fsp4": "r03_pmc_bench_1Mcells_1gpu.json",
-    "fsp5": "r03_pmc_bench_fsp5_1Mcells_2048bit.json",
-    "chain": "r03_pmc_bench_chain_1Mcells.json",
+    "fsp4": "r04_pmc_bench_1Mcells_1gpu.json",
+    "fsp5": "r04_pmc_bench_fsp5_1Mcells_2048bit.json",
+    "chain": "r04_pmc_bench_chain_1Mcells.json",
 }
 TRAFFIC_NOTE = "FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE, bytes per launch of the profiled run"
 
 
-def profile_query(workload, cells, lsh_count, k, n_gpus=1, genes=None, slices=None):
+def profile_query(workload, cells, lsh_count, k, n_gpus=1, genes=None, slice_length=None, bucket_overflow=None):
     """The (key, value) pairs a digest's `config` must hold to stand for this run."""
     query = {"cells": cells, "lsh_count": lsh_count, "k": k, "n_gpus": n_gpus}
     if workload == "fsp4":
         query["genes"] = genes
     if workload == "fsp5":
-        query["slices"] = slices
+        query["slice_length"] = slice_length
+        query["bucket_overflow"] = bucket_overflow
     return query
 
 
@@ -380,7 +381,7 @@ def bench_fsp5(args, capi, oracle, device, torch):
     distinct = info["distinct_candidates"] if info["distinct_candidates"] >= 0 else info["gathered_candidates"]
     algorithmic = distinct * 8.0 * W + 4.0 * C * info["slice_count"]
     achieved = algorithmic / (filter_ms * 1e-3) / 1e9 if filter_ms > 0 else 0.0
-    per_launch, launches = profiled_traffic(PROFILE_DIGESTS["fsp5"], profile_query("fsp5", C, L, k, slices=info["slice_count"]),
+    per_launch, launches = profiled_traffic(PROFILE_DIGESTS["fsp5"], profile_query("fsp5", C, L, k, slice_length=q, bucket_overflow=args.bucket_overflow),
                                             ("filterWideKernel", "filterCooperativeKernel"))
     traffic = per_launch * info["batches"] if per_launch is not None else None
     traffic_source = ("profiles/%s (%s of the filter, x the batches of one call)" % (PROFILE_DIGESTS["fsp5"], TRAFFIC_NOTE)) if traffic is not None else None
@@ -401,7 +402,10 @@ def bench_fsp5(args, capi, oracle, device, torch):
                      "algorithmic_bytes": algorithmic, "distinct_candidates": distinct, "gathered_candidates": info["gathered_candidates"],
                      "note": "SURVEY.md 8(d): candidates x 8*W bytes of signature gathers + 4*N*sliceCount bytes of tables; candidates "
                              "= the distinct ids of every cell's union of buckets, which is what the filter gathers (counted by the "
-                             "library); kernel_ms = HIP events around the filter kernels on the launch stream"},
+                             "library); kernel_ms = HIP events around the filter kernels on the launch stream.  Since round 4 the filter "
+                             "visits cells grouped by neighbourhood, so most of these bytes come from the L2s and not over the fabric "
+                             "(`traffic`, from the PMC digest, is what crosses the fabric): frac may exceed 1 -- the byte model against "
+                             "the HBM peak no longer bounds the kernel, its vector ALUs do (VALU busy 66-85 % in the digest)"},
         "parity_check": check,
     }
 

@@ -37,8 +37,68 @@ __device__ __forceinline__ void waveSyncGlobal()
 // (src/ExpressionMatrixLsh.cpp:330-340 via keepBest) -- with a bitonic network over the next power of two (< 2n <= 2k
 // slots, which the wave's area has), sentinels behind the entries.  (It was a rank count, n^2 comparisons: 2.8 of the
 // 9.5 ms of the inbox replay kernel at 1M cells, k = 100.)
+// Up to 128 entries (the k = 100 lists of the benchmark configurations): the same bitonic network in registers, two entries per
+// lane (slots lane and lane + 64) as 64-bit (key, cell) values, partners fetched across lanes with shuffles -- no LDS round trips
+// and no synchronisation between the 28 stages (the LDS form spends ~13k cycles on 128 slots, a seventh of findSimilarPairs5's
+// selection kernel and a third of the inbox replay's finish).
+__device__ __attribute__((noinline)) void sortListWaveRegisters(Entry* lds, uint32_t n, uint32_t lane)
+{
+    uint64_t v0 = ~0ull, v1 = ~0ull;          // sentinels sort behind every entry
+    if (lane < n) {
+        const Entry e = lds[lane];
+        v0 = (uint64_t(e.key) << 32) | e.cell;
+    }
+    if (lane + 64u < n) {
+        const Entry e = lds[lane + 64u];
+        v1 = (uint64_t(e.key) << 32) | e.cell;
+    }
+    auto exchange = [&](uint64_t x, uint32_t stride, bool keepMin) {
+        const uint32_t lo = uint32_t(__shfl_xor(int(uint32_t(x)), int(stride), 64));
+        const uint32_t hi = uint32_t(__shfl_xor(int(uint32_t(x >> 32)), int(stride), 64));
+        const uint64_t y = (uint64_t(hi) << 32) | lo;
+        const bool takeOther = keepMin ? y < x : y > x;
+        return takeOther ? y : x;
+    };
+#pragma unroll
+    for (uint32_t size = 2; size <= 128u; size <<= 1) {
+#pragma unroll
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride == 64u) {
+                // (size 128: every pair (i, i + 64) ascends)
+                const uint64_t a = v0 < v1 ? v0 : v1, b = v0 < v1 ? v1 : v0;
+                v0 = a;
+                v1 = b;
+            } else {
+                const bool lower = (lane & stride) == 0u;
+                const bool ascending0 = (lane & size) == 0u;                  // slot `lane`
+                const bool ascending1 = ((lane + 64u) & size) == 0u;          // slot `lane + 64`
+                v0 = exchange(v0, stride, lower == ascending0);
+                v1 = exchange(v1, stride, lower == ascending1);
+            }
+        }
+    }
+    waveSync();          // every lane has read its entries
+    if (lane < n) {
+        Entry e;
+        e.cell = uint32_t(v0);
+        e.key = uint32_t(v0 >> 32);
+        lds[lane] = e;
+    }
+    if (lane + 64u < n) {
+        Entry e;
+        e.cell = uint32_t(v1);
+        e.key = uint32_t(v1 >> 32);
+        lds[lane + 64u] = e;
+    }
+    waveSync();
+}
+
 __device__ __forceinline__ void sortListWave(Entry* lds, uint32_t n, uint32_t lane)
 {
+    if (n <= 128u) {
+        sortListWaveRegisters(lds, n, lane);
+        return;
+    }
     uint32_t padded = 1;
     while (padded < n) padded <<= 1;
     for (uint32_t i = n + lane; i < padded; i += 64u) {

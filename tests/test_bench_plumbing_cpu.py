@@ -16,7 +16,7 @@ def test_every_named_digest_answers_for_its_configuration():
     queries = {
         "fsp4": (bench.profile_query("fsp4", 1000000, 1024, 100, 1, genes=30000),
                  [("fsp4ScanMatrixPinnedKernel", "fsp4ScanMatrixWideKernel"), ("projectionScreen", "projectionExact", "cellStatsKernel")]),
-        "fsp5": (bench.profile_query("fsp5", 1000000, 2048, 100, slices=102), [("filterWideKernel", "filterCooperativeKernel")]),
+        "fsp5": (bench.profile_query("fsp5", 1000000, 2048, 100, slice_length=20, bucket_overflow=1000), [("filterWideKernel", "filterCooperativeKernel")]),
     }
     for workload, (query, prefix_sets) in queries.items():
         for prefixes in prefix_sets:
@@ -27,6 +27,8 @@ def test_every_named_digest_answers_for_its_configuration():
                                   ("fsp4ScanMatrixPinnedKernel",)) == (None, None)
     assert bench.profiled_traffic(bench.PROFILE_DIGESTS["fsp4"], bench.profile_query("fsp4", 1000000, 1024, 100, 2, genes=30000),
                                   ("fsp4ScanMatrixPinnedKernel",)) == (None, None)
+    assert bench.profiled_traffic(bench.PROFILE_DIGESTS["fsp5"], bench.profile_query("fsp5", 1000000, 2048, 100, slice_length=16, bucket_overflow=1000),
+                                  ("filterWideKernel",)) == (None, None)
 
 
 def test_every_committed_bench_digest_names_its_configuration():
