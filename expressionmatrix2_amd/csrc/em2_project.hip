@@ -116,7 +116,7 @@ projectionKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ d
 // not is summed again by one lane in stored order.
 __global__ void __launch_bounds__(256)
 cellStatsKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t cellCount,
-                uint32_t geneCount, double* __restrict__ means, double* __restrict__ sumAbs)
+                uint32_t geneCount, double* __restrict__ means, double* __restrict__ sumAbs, uint32_t* __restrict__ notAllInteger)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -124,11 +124,13 @@ cellStatsKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ da
     const uint64_t begin = toc[c], end = toc[c + 1];
     double sum1 = 0., abs1 = 0.;
     int lowest = 1000;                              // exponent of the last mantissa bit of the smallest count seen
+    bool integers = true;                           // every count an integer of at most 15 bits (the integer first tier)
     for (uint64_t j = begin + lane; j < end; j += 64u) {
         const float value = data[j].count;
         const double x = double(value);
         sum1 += x;
         abs1 += fabs(x);
+        integers = integers && value == truncf(value) && fabsf(value) <= 32767.f;
         const int exponentField = int((__float_as_uint(value) >> 23) & 0xffu);
         if (value != 0.f) lowest = min(lowest, (exponentField ? exponentField : 1) - 150);
     }
@@ -149,9 +151,12 @@ cellStatsKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ da
             abs1 += fabs(x);
         }
     }
+    // (the integer tier accumulates count * q, |q| <= 32767, in 32 bits: sum|count| <= 65535 keeps every partial sum in range)
+    const bool integerCell = __builtin_amdgcn_ballot_w64(!integers) == 0ull && abs1 <= 65535.;
     if (lane == 0u) {
         means[c] = sum1 / double(geneCount);
         sumAbs[c] = abs1 * (1. + 1e-12);             // upper bound of the exact sum of magnitudes
+        if (!integerCell && notAllInteger) atomicOr(notAllInteger, 1u);
     }
 }
 
@@ -237,19 +242,26 @@ vectorsToQuantizedKernel(const double* __restrict__ vectors, uint32_t geneCount,
 // list like the float tier's, for the exact arithmetic.
 // DIAG (EM2_PROJECTION_DIAG, measurements only, wrong results, nothing listed for the later tiers): 1 = the gathers
 // without the arithmetic, 2 = the arithmetic without the row gathers.
-template <int DIAG = 0>
+// INTEGER: the tier for matrices whose counts are all small integers (what expression COUNTS are, and the benchmark's): the
+// products count * q are formed and summed exactly in 32-bit integers, one v_mad_i32_i16 per product (the high half of a
+// register through op_sel) where the float form needs 1.5 instructions (two conversions and a packed fma per two products);
+// the chunking, its single-precision term of the bound and the overflow case go away.  Both instantiations are launched;
+// the statistics kernel has set a device flag when some cell does not qualify, and the one whose turn it is not leaves at once.
+template <int DIAG = 0, bool INTEGER = false>
 __global__ void __launch_bounds__(256, 4)
 projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t cellCount,
                                 uint32_t geneCount, const int16_t* __restrict__ quantized, const double* __restrict__ scales,
                                 const double* __restrict__ vectorSums, const double* __restrict__ vectorMaxAbs,
                                 const double* __restrict__ means, const double* __restrict__ sumAbs, uint32_t lshCount,
                                 uint32_t wordCount, uint64_t* __restrict__ signatures, uint64_t* __restrict__ workList,
-                                uint32_t* __restrict__ workCount, uint64_t* __restrict__ bitList, uint32_t* __restrict__ bitCount)
+                                uint32_t* __restrict__ workCount, uint64_t* __restrict__ bitList, uint32_t* __restrict__ bitCount,
+                                const uint32_t* __restrict__ notAllInteger)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t word = blockIdx.y * 8u + (blockIdx.x & 7u);
     if (word >= wordCount) return;
+    if (notAllInteger && (*notAllInteger != 0u) == INTEGER) return;          // (uniform: the other instantiation's launch)
     const uint32_t sub = lane & 7u;
     const uint32_t group = lane >> 3;
     // the word's slice of the 16-bit copy (wave-uniform: a scalar base) and the lane's 16 bytes of a gene's 128-byte line
@@ -302,6 +314,7 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
         }
         if (entryCount) EM2_LOAD_ENTRIES(0u)
         Float2 chunk[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        int exact[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // INTEGER: the eight sums of count * q, exact
         uint32_t partsInChunk = 0;
         for (uint32_t first = 0; first < entryCount; first += 2u * kPart) {
             const int entryGene = int(uint32_t(nextEntry)), entryCountBits = int(uint32_t(nextEntry >> 32));
@@ -337,6 +350,19 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
                     }
                     continue;
                 }
+                if (INTEGER) {
+#pragma unroll
+                    for (uint32_t q = 0; q < kQuantizedInFlight; ++q) {
+                        const uint32_t w[4] = {u[q].x, u[q].y, u[q].z, u[q].w};
+                        const int count = int(x[q]);          // (an integer of at most 15 bits: the statistics kernel checked)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            asm("v_mad_i32_i16 %0, %1, %2, %0" : "+v"(exact[2 * m]) : "v"(w[m]), "v"(count));
+                            asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(exact[2 * m + 1]) : "v"(w[m]), "v"(count));
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (uint32_t q = 0; q < kQuantizedInFlight; ++q) {
                     const uint32_t w[4] = {u[q].x, u[q].y, u[q].z, u[q].w};
@@ -359,10 +385,21 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
             }
         }
 #undef EM2_LOAD_ENTRIES
+        if (INTEGER) {
+            // (the eight entry groups' sums: still exact in 32 bits, sum|count| <= 65535 bounds the cell's whole sum)
 #pragma unroll
-        for (int d = 8; d < 64; d <<= 1) {
+            for (int d = 8; d < 64; d <<= 1) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) a[t] += __shfl_xor(a[t], d, 64);
+                for (int t = 0; t < 8; ++t) exact[t] += __shfl_xor(exact[t], d, 64);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a[t] = double(exact[t]);
+        } else {
+#pragma unroll
+            for (int d = 8; d < 64; d <<= 1) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) a[t] += __shfl_xor(a[t], d, 64);
+            }
         }
         const double mean = means[c];
         const double n = double(jEnd - jBegin);
@@ -380,8 +417,9 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
             const double total = __fma_rn(a[t], scaleT, __dmul_rn(-mean, sT));
             // (+ the single-precision chunks: 16 * 2^-24 * sum|count * q| * scale <= 9.6e-7 * sum|x| * max|U_i|, and a
             // subnormal slack for them)
-            const double bound = factor * (absMean * fabs(sT) + absX * mxT) + 0.501 * scaleT * absX + 9.6e-7 * absX * mxT +
-                                 n * 1.5e-45 * scaleT + 1e-300;
+            // (INTEGER: the sum of count * q is exact, that term and the subnormal slack are not needed)
+            const double bound = factor * (absMean * fabs(sT) + absX * mxT) + 0.501 * scaleT * absX +
+                                 (INTEGER ? 0. : 9.6e-7 * absX * mxT + n * 1.5e-45 * scaleT) + 1e-300;
             // (a single-precision chunk that overflowed makes the total infinite: undecided as well)
             ambiguousBits |= (!(fabs(total) > bound) || !(fabs(total) <= 1.7976931348623157e308)) ? (1u << t) : 0u;
             byte |= (total > 0.) ? (0x80u >> t) : 0u;                  // first bit most significant
@@ -859,7 +897,8 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
     uint64_t* workList = reinterpret_cast<uint64_t*>(ws + 2u * a + 256u);
     hipError_t e = hipMemsetAsync(workCount, 0, 256, stream);
     if (e != hipSuccess) return e;
-    cellStatsKernel<<<dim3((cellCount + 3u) / 4u), dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, means, sumAbs);
+    // workCount[48]: set by the statistics when some cell's counts are no small integers (then the float first tier runs)
+    cellStatsKernel<<<dim3((cellCount + 3u) / 4u), dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, means, sumAbs, workCount + 48);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // EM2_PROJECTION=screen keeps the one-block-per-1024-bits form (A/B measurements); default is the XCD-sliced form
@@ -879,16 +918,29 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
         const char* diagText = getenv("EM2_PROJECTION_DIAG");
         const int diag = diagText ? atoi(diagText) : 0;
         auto kernel = diag == 1 ? &projectionScreenQuantizedKernel<1> : (diag == 2 ? &projectionScreenQuantizedKernel<2> : &projectionScreenQuantizedKernel<0>);
+        const bool diagOff = diag == 0;
 #else
         auto kernel = &projectionScreenQuantizedKernel<0>;
+        const bool diagOff = true;
 #endif
         // (the work area holds 4 slots per word: [0, CW) the words for the float tier, [CW, 2 CW) the single bits for its per-bit
         // form, [2 CW, 4 CW) what the two leave to the exact tier; EM2_PROJECTION_BITS=0 lists everything by words: A/B runs)
         const char* bitsMode = getenv("EM2_PROJECTION_BITS");
         const bool perBit = !(bitsMode && bitsMode[0] == '0');
+        // (EM2_PROJECTION_INTEGER=0: the float form for every matrix -- A/B measurements, tests)
+        const char* integerMode = getenv("EM2_PROJECTION_INTEGER");
+        const bool integerTier = diagOff && !(integerMode && integerMode[0] == '0');
         kernel<<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, quantized, scales, sums, maxAbs, means,
                                                                         sumAbs, lshCount, wordCount, signatures, workList, workCount,
-                                                                        perBit ? workList + size_t(cellCount) * wordCount : nullptr, workCount + 32);
+                                                                        perBit ? workList + size_t(cellCount) * wordCount : nullptr, workCount + 32,
+                                                                        integerTier ? workCount + 48 : nullptr);
+        if (integerTier) {
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            projectionScreenQuantizedKernel<0, true><<<grid, dim3(256), 0, stream>>>(
+                toc, data, cellCount, geneCount, quantized, scales, sums, maxAbs, means, sumAbs, lshCount, wordCount, signatures, workList,
+                workCount, perBit ? workList + size_t(cellCount) * wordCount : nullptr, workCount + 32, workCount + 48);
+        }
     } else if (sliced) {
         e = hipMemsetAsync(signatures, 0, size_t(cellCount) * wordCount * sizeof(uint64_t), stream);    // halves nobody owns
         if (e != hipSuccess) return e;

@@ -153,3 +153,35 @@ def test_fractional_counts_and_the_cell_mean(oracle, spread):
     expect = oracle.compute_signatures(toc, g, c, genes, vectors, L)
     got = capi.compute_signatures(toc, capi.make_counts(g, c), genes, vectors, L)
     assert np.array_equal(got, expect)
+
+
+@pytest.mark.parametrize("case", ["integers", "float-tier-forced", "one-fraction", "count-32768", "sum-above-65535", "negative", "at-the-limits"])
+def test_integer_first_tier_and_when_it_steps_aside(oracle, monkeypatch, case):
+    """The first tier has an exact integer form (v_mad_i32_i16, 32-bit sums) for matrices whose counts are all integers of at
+    most 15 bits with sum|count| <= 65535 per cell; the statistics kernel sets a device flag otherwise and the float form runs.
+    Same signatures either way, against the oracle: integer counts (integer form), the float form forced by
+    EM2_PROJECTION_INTEGER=0, and matrices that must step aside -- one fractional count in one cell, a count of 32768, a cell
+    whose counts sum above 65535 -- plus negative integers and a cell exactly at both limits (integer form)."""
+    cells, genes, L = 700, 1500, 1024
+    toc, g, c = synth.expression_matrix(cells, genes, density=0.06, cluster_count=5, seed=21)
+    c = c.copy()
+    if case == "float-tier-forced":
+        monkeypatch.setenv("EM2_PROJECTION_INTEGER", "0")
+    elif case == "one-fraction":
+        c[len(c) // 2] = np.float32(2.5)
+    elif case == "count-32768":
+        c[7] = np.float32(32768.0)
+    elif case == "sum-above-65535":
+        lo, hi = int(toc[3]), int(toc[4])
+        c[lo:hi] = np.float32(np.ceil(65536.0 / max(1, hi - lo)) + 1)
+    elif case == "negative":
+        c[::3] = -c[::3]
+    elif case == "at-the-limits":
+        lo, hi = int(toc[5]), int(toc[6])
+        assert hi - lo >= 3
+        c[lo:hi] = np.float32(0.0)
+        c[lo], c[lo + 1], c[lo + 2] = np.float32(32767.0), np.float32(-32767.0), np.float32(1.0)       # sum|count| = 65535
+    vectors = oracle.generate_lsh_vectors(genes, L, 231)
+    expect = oracle.compute_signatures(toc, g, c, genes, vectors, L)
+    got = capi.compute_signatures(toc, capi.make_counts(g, c), genes, vectors, L)
+    assert np.array_equal(got, expect)
