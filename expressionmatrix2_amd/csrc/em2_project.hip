@@ -301,8 +301,12 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
         // are used), handed to the groups through the LDS crossbar (ds_bpermute: group g, slot q of half h reads lane
         // 32 h + 8 q + g) -- eight lanes loading the same 8 bytes cost the vector memory path as much as 64 different ones,
         // a third of what the rows cost it, and that path is what bounds this kernel (the gathers alone: 34 of 38 ms).
-        constexpr uint32_t kPart = kQuantizedInFlight * 8u;              // entries of the wave per part
-        static_assert(kQuantizedInFlight == 4u, "two parts per 64 entries");
+        // (the integer form needs 76 registers where the float form needs 94: eight entries per lane in flight still leave five
+        // waves per SIMD -- 40 row loads in flight per SIMD instead of 24)
+        constexpr uint32_t kInFlight = INTEGER ? 2u * kQuantizedInFlight : kQuantizedInFlight;
+        constexpr uint32_t kPart = kInFlight * 8u;                       // entries of the wave per part
+        constexpr uint32_t kHalves = 64u / kPart;                        // parts per 64 loaded entries
+        static_assert(kQuantizedInFlight == 4u && kHalves * kPart == 64u, "one or two parts per 64 entries");
         const uint32_t sourceLane = group << 2;                          // (byte address of a lane for ds_bpermute)
         uint64_t nextEntry = 0;
 #define EM2_LOAD_ENTRIES(first_)                                                                                              \
@@ -316,30 +320,30 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
         Float2 chunk[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         int exact[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // INTEGER: the eight sums of count * q, exact
         uint32_t partsInChunk = 0;
-        for (uint32_t first = 0; first < entryCount; first += 2u * kPart) {
+        for (uint32_t first = 0; first < entryCount; first += 64u) {
             const int entryGene = int(uint32_t(nextEntry)), entryCountBits = int(uint32_t(nextEntry >> 32));
-            if (first + 2u * kPart < entryCount) EM2_LOAD_ENTRIES(first + 2u * kPart)
+            if (first + 64u < entryCount) EM2_LOAD_ENTRIES(first + 64u)
 #pragma unroll
-            for (uint32_t half = 0; half < 2u; ++half) {
+            for (uint32_t half = 0; half < kHalves; ++half) {
                 if (half && first + kPart >= entryCount) break;          // (uniform)
-                uint4 u[kQuantizedInFlight];
-                float x[kQuantizedInFlight];
-                uint32_t gene[kQuantizedInFlight];
+                uint4 u[kInFlight];
+                float x[kInFlight];
+                uint32_t gene[kInFlight];
 #pragma unroll
-                for (uint32_t q = 0; q < kQuantizedInFlight; ++q) {
-                    const int from = int(sourceLane + 4u * (32u * half + 8u * q));
+                for (uint32_t q = 0; q < kInFlight; ++q) {
+                    const int from = int(sourceLane + 4u * (kPart * half + 8u * q));
                     gene[q] = uint32_t(__builtin_amdgcn_ds_bpermute(from, entryGene));
                     x[q] = __int_as_float(__builtin_amdgcn_ds_bpermute(from, entryCountBits));
                 }
 #pragma unroll
-                for (uint32_t q = 0; q < kQuantizedInFlight; ++q) {
+                for (uint32_t q = 0; q < kInFlight; ++q) {
                     if (DIAG == 2) u[q] = uint4{gene[q], gene[q] + 1u, gene[q] + 2u, gene[q] + 3u};
                     else u[q] = *reinterpret_cast<const uint4*>(slice + ((gene[q] << 7) | laneBytes));
                 }
                 const bool lastPart = first + (half + 1u) * kPart >= entryCount;
                 if (DIAG == 1) {
 #pragma unroll
-                    for (uint32_t q = 0; q < kQuantizedInFlight; ++q) {
+                    for (uint32_t q = 0; q < kInFlight; ++q) {
                         chunk[q & 3u].x += __uint_as_float((u[q].x ^ u[q].y ^ u[q].z ^ u[q].w) & 0x3fffffffu);
                         chunk[q & 3u].y += x[q];
                     }
@@ -352,7 +356,7 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
                 }
                 if (INTEGER) {
 #pragma unroll
-                    for (uint32_t q = 0; q < kQuantizedInFlight; ++q) {
+                    for (uint32_t q = 0; q < kInFlight; ++q) {
                         const uint32_t w[4] = {u[q].x, u[q].y, u[q].z, u[q].w};
                         const int count = int(x[q]);          // (an integer of at most 15 bits: the statistics kernel checked)
 #pragma unroll
@@ -364,7 +368,7 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
                     continue;
                 }
 #pragma unroll
-                for (uint32_t q = 0; q < kQuantizedInFlight; ++q) {
+                for (uint32_t q = 0; q < kInFlight; ++q) {
                     const uint32_t w[4] = {u[q].x, u[q].y, u[q].z, u[q].w};
                     const Float2 xx = {x[q], x[q]};
 #pragma unroll
