@@ -723,10 +723,12 @@ projectionScreenItemsKernel(const uint64_t* __restrict__ toc, const CountIn* __r
     }
 }
 
-// The same tier for the words in which ONE bit is undecided, listed by that bit: lane = item, each lane walks its own cell
-// with eight gathers of a single float in flight -- 4 bytes per count where the word form above reads two 128-byte lines.
-// Same arithmetic, same bound; a bit that stays undecided sends its word to the exact tier's list, any other goes into the
-// signature (nobody else writes that word: a word is on exactly one of the two lists).
+// The same tier for the words in which ONE bit is undecided, listed by that bit: eight lanes per item, each taking every eighth
+// count of the item's cell with eight gathers of a single float in flight -- 4 bytes per count where the word form above reads
+// two 128-byte lines; the eight partial sums are added by a butterfly (the bound's (n + 10) half-ulps cover the order of the
+// additions, as in the sliced kernel's).  (One lane per item walked its cell alone: 33 dependent rounds of gathers per item,
+// 3.3 ms at a million cells; now four.)  A bit that stays undecided sends its word to the exact tier's list, any other goes into
+// the signature (nobody else writes that word: a word is on exactly one of the two lists).
 __global__ void __launch_bounds__(256)
 projectionScreenBitsKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t geneCount,
                            const float* __restrict__ vectors32, const double* __restrict__ vectorSums,
@@ -737,34 +739,44 @@ projectionScreenBitsKernel(const uint64_t* __restrict__ toc, const CountIn* __re
 {
     const uint32_t count = *bitCount;
     const uint64_t* entries = reinterpret_cast<const uint64_t*>(data);
-    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
-        const uint64_t it = bitList[item];
+    const uint32_t sub = threadIdx.x & 7u;
+    const uint32_t groups = gridDim.x * (blockDim.x >> 3);
+    // (every lane of a wave makes the same number of turns: the butterfly below involves the whole wave)
+    const uint32_t turns = (count + groups - 1u) / groups;
+    for (uint32_t turn = 0; turn < turns; ++turn) {
+        const uint32_t item = turn * groups + blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);
+        const bool live = item < count;
+        const uint64_t it = live ? bitList[item] : 0ull;
         const uint32_t c = uint32_t(it >> 32);
         const uint32_t bit = uint32_t(it);
         const float* column = vectors32 + size_t(bit >> 5) * geneCount * 32u + (bit & 31u);
-        const double s = vectorSums[bit];
-        const uint64_t jBegin = toc[c];
-        const uint64_t jEnd = toc[c + 1];
-        const double mean = means[c];
-        double a = __dmul_rn(-mean, s);
-        uint64_t j = jBegin;
-        for (; j + 8u <= jEnd; j += 8u) {            // eight loads in flight, the additions in stored order
+        const uint64_t jBegin = live ? toc[c] : 0ull;
+        const uint64_t jEnd = live ? toc[c + 1] : 0ull;
+        double a = 0.;
+        uint64_t j = jBegin + sub;
+        for (; j + 56u < jEnd; j += 64u) {            // eight loads in flight per lane, 64 counts of the cell per round
             double u[8], x[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const uint64_t e = entries[j + q];
+                const uint64_t e = entries[j + 8u * uint32_t(q)];
                 u[q] = double(column[size_t(uint32_t(e)) * 32u]);
                 x[q] = double(__uint_as_float(uint32_t(e >> 32)));
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) a = __fma_rn(x[q], u[q], a);
         }
-        for (; j < jEnd; ++j) {
+        for (; j < jEnd; j += 8u) {
             const uint64_t e = entries[j];
             a = __fma_rn(double(__uint_as_float(uint32_t(e >> 32))), double(column[size_t(uint32_t(e)) * 32u]), a);
         }
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) a += __shfl_xor(a, d, 64);
+        if (!live || sub != 0u) continue;
+        const double s = vectorSums[bit];
+        const double mean = means[c];
+        a += __dmul_rn(-mean, s);
         const double n = double(jEnd - jBegin);
-        const double factor = (1.01 * 5.9604644775390625e-08 + (n + 2.) * 2.220446049250313e-16) * 1.000001;
+        const double factor = (1.01 * 5.9604644775390625e-08 + (n + 10.) * 2.220446049250313e-16) * 1.000001;
         const double absX = sumAbs[c];
         const double bound = factor * (fabs(mean) * fabs(s) + absX * vectorMaxAbs[bit]) + absX * 1.5e-45 + 1e-300;
         const uint32_t word = bit >> 6;
