@@ -415,6 +415,8 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     args.rowEnd = rowEnd;
     args.departTicks = 0;
     args.departWindow = 0;
+    args.convoy = 0;
+    args.convoyPad = 0;
     args.rowState = nullptr;
     args.segmentsDone = nullptr;
     args.control = nullptr;

@@ -62,6 +62,9 @@ struct Fsp4Args {
     const void* fragments;      // the signatures as FP4 +-1 in MFMA fragment order, 512 B per cell
     uint32_t matrixLdsOffset;   // where the column tiles start in the block's dynamic LDS
     uint32_t departWindow;      // (see departTicks)
+    uint32_t convoy;            // matrix form: 0 = every walk starts at its segment's first column; 1 = a walk joins the walks of its XCD
+                                // where they are and wraps around (scanMatrixBody); n >= 2 (tests): every walk starts 64 (n - 1) columns in
+    uint32_t convoyPad;
     uint32_t pad2;              // diagnostic build only (EM2_DIAG_WORD below): the EM2_MATRIX_DIAG bits; 0 in the product
 };
 

@@ -211,7 +211,7 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
     FragmentWord4* tiles = reinterpret_cast<FragmentWord4*>(ldsRaw + kernelArgs()->matrixLdsOffset);
     volatile uint32_t* shared = reinterpret_cast<volatile uint32_t*>(ldsRaw + kernelArgs()->matrixLdsOffset + 4u * kMatrixTileWords * 16u);
     unsigned char* walkBlock = ldsRaw + kernelArgs()->matrixLdsOffset + 4u * kMatrixTileWords * 16u + 64u + wave * kMatrixWalkLdsBytes;
-    if (threadIdx.x < 4u) shared[threadIdx.x] = 0u;
+    if (threadIdx.x < 12u) shared[threadIdx.x] = 0u;         // (words 4..8: no convoy here, see scanMatrixBody)
     __syncthreads();
     uint32_t emitPos = 0, emitEnd = 0;
     for (;;) {
@@ -572,6 +572,11 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             if (e != hipSuccess) return e;
             args.fragments = ws + plan.offFragments;
             args.matrixLdsOffset = uint32_t(matrixLdsOffset);
+            // the walks of an XCD go around their segment together (scanMatrixBody, "convoy"); the position words start at zero
+            args.convoy = uint32_t(envNumber("EM2_MATRIX_CONVOY", 1));
+            if (cps / 64u > kConvoyMaxPairs && args.convoy == 1u) args.convoy = 0u;
+            e = hipMemsetAsync(args.inboxControl + kConvoyWordsOffset, 0, 64u, stream);
+            if (e != hipSuccess) return e;
             lastLaunchInfo.matrixPairs += double(slotCount) * 64.0 * double(M);
             const void* matrixKernel = scanMatrixKernelFor(t.identityKeys, wide);
             int device = 0, cuCount = 0;

@@ -328,8 +328,8 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
     unsigned char* walkBlock = (selectionStride >= kMatrixWalkLdsBytes && selectionStride % 16u == 0u)
                                    ? ldsRaw + wave * selectionStride
                                    : ldsRaw + kernelArgs()->matrixLdsOffset + 4u * kMatrixTileWords * 16u + 64u + wave * kMatrixWalkLdsBytes;
-    // shared[0..2] stop words of the walk, shared[3] the block's ticket
-    if (threadIdx.x < 4u) shared[threadIdx.x] = 0u;
+    // shared[0..2] stop words of the walk, shared[3] the block's ticket, shared[4..8] the convoy (kConvoyStartWord ...)
+    if (threadIdx.x < 12u) shared[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t emitPos = 0, emitEnd = 0;
     // The clock this launch ran at: every block's first lane stamps the shader clock counter and the 100 MHz wall counter when
@@ -420,46 +420,118 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         // departTicks on the 100 MHz wall counter all blocks share: blocks that finish at about the same time leave together
         // and follow each other through the tiles closely enough for the L2 to serve all but the first.  A block waits
         // (asleep) for at most one period; order and content of everything it does are unchanged.
-        if (PINNED && aux->departTicks != 0u && colBegin < commonEnd) {
+        auto depart = [&]() {
             if (threadIdx.x == 0u) {
-                const uint32_t period = aux->departTicks, window = aux->departWindow;
+                const uint32_t period = aux->departTicks, window = aux->departWindow & 0x7fffffffu;
                 for (uint32_t spins = 0; spins < (1u << 16); ++spins) {
                     if (uint32_t(__builtin_amdgcn_s_memrealtime() % period) < window) break;
                     __builtin_amdgcn_s_sleep(8);
                 }
             }
             __syncthreads();
-        }
+        };
+        if (PINNED && aux->departTicks != 0u && colBegin < commonEnd) depart();
+
+        // ---- the convoy ----
+        // The departures showed what the L2s can do when the walks of an XCD stay together, and what waiting for that costs.
+        // Nobody waits here: a walk STARTS WHERE THE OTHERS ARE and goes around -- from its starting column to the segment's
+        // end, then from the segment's begin to its starting column.  Every walk publishes its position now and then in a
+        // word of its XCD group (blockIdx & 7: the blocks of a launch are dealt to the XCDs in turn) and of its segment's
+        // parity; a block that takes an item of the same segment reads it.  All walks move at the same pace, so the group
+        // circles through the segment as one stream of tiles that the first to ask fetches over the fabric and the others find
+        // in the L2.  The logs of such a walk hold the higher columns in front of the lower ones: the replay takes them in
+        // the order of the columns (WalkLogReader), so the lists see the candidates exactly as before.  A walk whose logs fill
+        // up before it has reached the segment's end cannot replay them yet (the lower columns come first): it drops them
+        // and starts again at the segment's begin, as a walk without convoy (in the lower columns a stop is harmless: those
+        // records are in order, they are replayed and removed).  Never at the bench's sizes (0 of 120 337 items stop at all).
+        auto convoyStart = [&]() -> uint32_t {
+            const uint32_t mode = aux->convoy;
+            if (!PINNED || mode == 0u || colBegin + 128u >= commonEnd) return colBegin;
+            if (threadIdx.x == 0u) {
+                uint32_t* word = aux->inboxControl + kConvoyWordsOffset + 2u * (blockIdx.x & 7u) + (seg & 1u);
+                const uint32_t code = (seg + 1u) << 20;
+                uint32_t from = colBegin, lap = 0u;
+                bool publish = mode == 1u;
+                if (mode == 1u) {
+                    const uint32_t seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((seen & 0xfff00000u) == code) {
+                        lap = (seen >> 12) & 0xffu;
+                        from = colBegin + ((seen & 0xfffu) << 6);
+                        publish = false;            // (unless it joins: a walk on its own is no head to follow)
+                    }
+                } else {
+                    from = colBegin + 64u * (mode - 1u);
+                }
+                // (whole pairs of tiles from the segment's begin, and something left to walk on either side)
+                if (from <= colBegin || from + 64u >= commonEnd) from = colBegin;
+                else publish = mode == 1u;
+                shared[kConvoyStartWord] = from;
+                shared[kConvoyCodeWord] = publish ? code | (lap << 12) : 0u;
+                shared[kConvoyAddressWord] = uint32_t(reinterpret_cast<uintptr_t>(word));
+                shared[kConvoyAddressWord + 1u] = uint32_t(uint64_t(reinterpret_cast<uintptr_t>(word)) >> 32);
+                shared[kConvoyPairBaseWord] = colBegin >> 6;
+                // (one call walks both parts: scanTilesMatrixPinned, scanTilesMatrixWide)
+                shared[kWrapBeginWord] = from != colBegin ? colBegin : 0u;
+                shared[kWrapEndWord] = from != colBegin ? from : 0u;
+            }
+            __syncthreads();
+            const uint32_t from = uint32_t(__builtin_amdgcn_readfirstlane(int(shared[kConvoyStartWord])));
+            __syncthreads();
+            return from;
+        };
         bool failed = false;
-        uint32_t at = colBegin;
+        uint32_t start = convoyStart();         // (start == colBegin: a walk as ever)
+        uint32_t at = start, rangeEnd = commonEnd;
+        bool lower = false;                     // the walk has gone around: [colBegin, start) now
+        uint32_t firstRecord[2] = {0u, 0u};     // the lane's records when it did
         uint32_t rowHalf = 0;           // (2048 bits: the columns are walked once per half of the wave's rows)
         EM2_PHASE(1);
         for (;;) {
-            if (at < commonEnd) {
+            if (at < rangeEnd) {
                 if (WIDE) {
-                    at = scanTilesMatrixWide<IDENTITY>(aux->fragments, aux->snap, at, commonEnd, rowFragmentBlock + rowHalf,
+                    at = scanTilesMatrixWide<IDENTITY>(aux->fragments, aux->snap, at, rangeEnd, rowFragmentBlock + rowHalf,
                                                        bits - 2.f * float(mMax), rowHalf, myLog - size_t(lane) * logCapacity, logCapacity,
                                                        recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                        ldsAddress(walkBlock));
                 } else if (PINNED) {
                     if (EM2_DIAG_WORD(aux)) {
-                        at = scanTilesMatrixPinned<IDENTITY, false, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
+                        at = scanTilesMatrixPinned<IDENTITY, false, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, rangeEnd,
                                                          rowFragmentBlock, kMatrixBits - 2.f * float(mMax), myLog - size_t(lane) * logCapacity,
                                                          logCapacity, recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                          ldsAddress(walkBlock));
                     } else {
-                        at = scanTilesMatrixPinned<IDENTITY, false, false>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
+                        at = scanTilesMatrixPinned<IDENTITY, false, false>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, rangeEnd,
                                                          rowFragmentBlock, kMatrixBits - 2.f * float(mMax), myLog - size_t(lane) * logCapacity,
                                                          logCapacity, recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                          ldsAddress(walkBlock));
                     }
                 } else {
-                    at = scanTilesMatrix<IDENTITY>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, at, commonEnd,
+                    at = scanTilesMatrix<IDENTITY>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, at, rangeEnd,
                                                    rowFragmentBlock, kMatrixBits - 2.f * float(mMax), row, rowValid && !fullRows, lane, myLog,
                                                    logCapacity, logCount, emitPos, emitEnd, tiles, shared);
                 }
             }
             EM2_PHASE(2);
+            if (TIMED && start != colBegin && !lower) phaseCycles[7] += 1u << 20;           // (walks that joined a convoy)
+            if (start != colBegin && !lower && (at & kWalkInLowerColumns) != 0u) {
+                // the walk went around within the call: it is in its lower columns (or through with them)
+                at &= ~kWalkInLowerColumns;
+                lower = true;
+                rangeEnd = start;
+                const volatile uint32_t* counts = reinterpret_cast<const volatile uint32_t*>(walkBlock + kWalkWrapCounts);
+                firstRecord[0] = WIDE && rowHalf != 0u ? 0u : counts[lane];
+                firstRecord[1] = WIDE && rowHalf == 0u ? 0u : counts[64u + lane];
+            }
+            const bool stopped = at < rangeEnd;                           // (for its logs; the same in all waves of the block)
+            if (TIMED && stopped) phaseCycles[7] += 1u;
+            if (start != colBegin && !lower) {
+                // the logs filled up in the higher columns (see above): once more, from the segment's begin, publishing nothing
+                recordCount[0] = recordCount[1] = 0u;
+                start = at = colBegin;
+                if (threadIdx.x == 0u) shared[kConvoyCodeWord] = 0u;
+                __syncthreads();
+                continue;
+            }
             if (!haveState && !idle && !failed) {
                 const uint32_t* flag = aux->segmentsDone + block;
                 const uint64_t start = __builtin_amdgcn_s_memrealtime();         // 100 MHz
@@ -485,11 +557,14 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
             EM2_PHASE(3);
             // replay the log through the exact state machine (ascending column order per row)
             if (PINNED) {
+                // (a walk that went around and stopped in its lower columns: those records only, the others stay)
+                const bool all = !(lower && stopped);
                 if (!idle && !failed) {
-                    replayWalkLogs<IDENTITY, WIDE>(myLog - size_t(lane) * logCapacity, logCapacity, recordCount, lane, row, rowValid, !fullRows,
-                                                   listBlock, myList, twoK, count, mMax, emitPos, emitEnd, ldsRaw);
+                    replayWalkLogs<IDENTITY, WIDE>(myLog - size_t(lane) * logCapacity, logCapacity, recordCount, firstRecord, all, lane, row,
+                                                   rowValid, !fullRows, listBlock, myList, twoK, count, mMax, emitPos, emitEnd, ldsRaw);
                 }
-                recordCount[0] = recordCount[1] = 0u;
+                recordCount[0] = all ? 0u : firstRecord[0];
+                recordCount[1] = all ? 0u : firstRecord[1];
             } else if (!idle && !failed) {
                 for (uint32_t i = 0;; ++i) {
                     const bool active = i < logCount;
@@ -508,10 +583,15 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
             }
             logCount = 0;
             EM2_PHASE(4);
-            if (at >= commonEnd) {
+            if (at >= rangeEnd) {
                 if (!WIDE || rowHalf == 1u || colBegin >= commonEnd) break;
                 rowHalf = 1u;
-                at = colBegin;
+                if (aux->departTicks != 0u && (aux->departWindow >> 31) != 0u) depart();
+                start = convoyStart();
+                at = start;
+                rangeEnd = commonEnd;
+                lower = false;
+                firstRecord[0] = firstRecord[1] = 0u;
             }
         }
         // (a wave whose hand-off failed keeps walking with its block -- the barriers need it -- and the launch ends at
@@ -1037,6 +1117,11 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         // (EM2_MATRIX_DEPART_US / EM2_MATRIX_DEPART_WINDOW_US: period and window of the walks' departures, microseconds)
         matrixArgs.departTicks = uint32_t(envNumber("EM2_MATRIX_DEPART_US", 0) * 100u);
         matrixArgs.departWindow = uint32_t(envNumber("EM2_MATRIX_DEPART_WINDOW_US", envNumber("EM2_MATRIX_DEPART_US", 0) / 4u) * 100u);
+        if (envNumber("EM2_MATRIX_DEPART_HALVES", 0) != 0) matrixArgs.departWindow |= 0x80000000u;
+        // (EM2_MATRIX_CONVOY: 0 = every walk from its segment's first column, 1 = the walks of an XCD go around together,
+        // n >= 2: every walk starts 64 (n - 1) columns into its segment -- the tests' way to the same code)
+        matrixArgs.convoy = uint32_t(envNumber("EM2_MATRIX_CONVOY", 1));
+        if (cpsMatrix / 64u > kConvoyMaxPairs && matrixArgs.convoy == 1u) matrixArgs.convoy = 0u;       // (positions have 12 bits)
         const size_t matrixLds = size_t(matrixArgs.matrixLdsOffset) + scanMatrixLdsBytes(args.k);
         const void* matrixKernel = scanMatrixKernelFor(identity, wide);
         int device = 0, cuCount = 0, blocksPerCu = 0;
@@ -1097,8 +1182,9 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
             const char* names[7] = {"ticket", "set-up", "walk", "hand-off wait", "replay", "own columns", "publication"};
             fprintf(stderr, "[em2] matrix kernel, wave cycles by phase (%llu items):", (unsigned long long)ticketsMatrixCount);
             for (int i = 0; i < 7; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * double(cycles[i]) / (total > 0 ? total : 1));
-            fprintf(stderr, "; %.0f cycles per item and wave outside the walk\n",
-                    (total - double(cycles[2])) / (4.0 * double(ticketsMatrixCount ? ticketsMatrixCount : 1)));
+            fprintf(stderr, "; %.0f cycles per item and wave outside the walk; %.0f walks stopped for their logs\n",
+                    (total - double(cycles[2])) / (4.0 * double(ticketsMatrixCount ? ticketsMatrixCount : 1)), double(cycles[7] & 0xfffffu) / 4.0);
+            fprintf(stderr, "[em2] matrix kernel: %.0f walks started inside their segment\n", double(cycles[7] >> 20) / 4.0);
         }
     }
     {

@@ -488,7 +488,8 @@ __device__ __forceinline__ P ldsPointer(uint32_t address)
 constexpr uint32_t kWalkRowDot = 0u;            // float[64]: bound of row r as a dot product (1024 - 2 mMax), read by the steps
 constexpr uint32_t kWalkBounds = 256u;          // float[4][32]: column bounds of the four tile buffers (as dot products)
 constexpr uint32_t kWalkSnapStage = 768u;       // int32[2][64]: the published cut-offs of a pair of tiles, as loaded
-constexpr uint32_t kMatrixWalkLdsBytes = 1280u;
+constexpr uint32_t kWalkWrapCounts = 1280u;     // uint32[2][64]: a walk that went around -- the lanes' records per accumulator when it did
+constexpr uint32_t kMatrixWalkLdsBytes = 1792u;
 
 __device__ __forceinline__ uint32_t uniform(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
 
@@ -527,6 +528,25 @@ __device__ __forceinline__ WalkRecord loadWalkRecord(const Entry* log, uint32_t 
     return r;
 }
 
+// The convoy (scanMatrixBody): words 4..8 of the block's stop-word area.  [4] = where this item's walk starts (written by the
+// block's first thread, read by all); [5] = 0 or what the walk publishes its position under: (segment + 1) << 20 | lap << 12,
+// lap = how often the convoy has been around the segment when this part of the walk began; [6..7] = the address of the word
+// it publishes to; [8] = the segment's first column >> 6.  A position is [5] + (column >> 6) - [8]: positions of one segment
+// grow as the convoy moves on, later segments (of the same parity: they share the word) are larger still, so the word --
+// an atomic maximum -- is where the convoy's HEAD is, and who starts there starts where the tiles are in the L2.
+// [9], [10] = the columns [begin, end) that scanTilesMatrixPinned walks BEHIND the ones it is called for (the walk that goes around
+// in one call; the walk clears the two words, so only the call that follows their writing sees them).
+constexpr uint32_t kConvoyStartWord = 4u, kConvoyCodeWord = 5u, kConvoyAddressWord = 6u, kConvoyPairBaseWord = 8u;
+constexpr uint32_t kWrapBeginWord = 9u, kWrapEndWord = 10u;
+constexpr uint32_t kWalkInLowerColumns = 0x80000000u;        // flag in scanTilesMatrixPinned's result
+constexpr uint32_t kConvoyWordsOffset = 40u;    // in 32-bit words from inboxControl: 8 groups x 2 segment parities
+constexpr uint32_t kConvoyMaxPairs = 4096u;     // pairs of tiles per segment that a position can tell apart
+__device__ __forceinline__ void publishWalkPosition(uint64_t address, uint32_t value)
+{
+    // (a global_ instruction from inline asm: a flat_ one would count against lgkmcnt, which the steps wait for by number)
+    asm volatile("global_atomic_umax %0, %1, off sc1" : : "v"(address), "v"(value) : "memory");
+}
+
 // The lock-step walk over the tiles [colBegin, colEnd) with the hand-scheduled steps.  Out of line: the steps own
 // v28..v255, and inlined into the kernels the values that live across the walk compete with them; as a function of its
 // own the walk keeps next to nothing in vector registers across a step, and nothing of the compiler's may ever sit at
@@ -539,6 +559,10 @@ __device__ __forceinline__ WalkRecord loadWalkRecord(const Entry* log, uint32_t 
 // records in its log of accumulator a.  It returns the first column not scanned, the same in all waves of the block: it
 // ends early, at a pair boundary, when some log could overflow within the next three tiles (48 records: a tile has 16
 // registers per accumulator).  The caller replays the logs (replayWalkLogs / drainWalkLogs) and calls again.
+// With the stop words kWrapBeginWord / kWrapEndWord set (scanMatrixBody: a walk that goes around its segment) the walk
+// continues with those columns, whole pairs of tiles, when it has reached colEnd -- same pipeline, no new start -- and leaves
+// each lane's record counts of that moment at kWalkWrapCounts; the result then is a column of THAT range (or its end), marked
+// with kWalkInLowerColumns.
 template <bool IDENTITY, bool BOTH = false, bool DIAG = false>
 __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* auxArg, const void* fragmentsArg, const void* snapArg,
                                                                     uint32_t colBeginArg, uint32_t colEndArg,
@@ -556,6 +580,10 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     const LdsFloatPtr boundScratch = ldsPointer<LdsFloatPtr>(walkLds + kWalkBounds);
     const LdsIntPtr snapStage = ldsPointer<LdsIntPtr>(walkLds + kWalkSnapStage);
     const uint64_t logBase = uniform64(reinterpret_cast<uint64_t>(waveLogArg));
+    uint32_t convoyCode = uniform(stopWords[kConvoyCodeWord]);
+    const uint32_t convoyPairBase = uniform(stopWords[kConvoyPairBaseWord]);
+    const uint64_t convoyAddress = uint64_t(uniform(stopWords[kConvoyAddressWord])) | (uint64_t(uniform(stopWords[kConvoyAddressWord + 1u])) << 32);
+    const uint32_t wrapBegin = uniform(stopWords[kWrapBeginWord]), wrapEnd = uniform(stopWords[kWrapEndWord]);
     // (EM2_MATRIX_DIAG, measurements only: the walk that looks at the bits is an instantiation of its own, so that the
     // one that runs in production has none of their branches between its steps)
     const uint32_t diag = DIAG ? EM2_DIAG_WORD((ArgsPtr)uniform64(reinterpret_cast<uint64_t>(auxArg))) : 0u;
@@ -602,10 +630,10 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     // The published cut-offs of the 64 columns of a pair of tiles (lane = column) travel the same way one pair ahead
     // (columns past the end repeat the last one: never tested).  Any value a cell published earlier is valid: bounds
     // only tighten.
-#define EM2_STAGE_SNAP(firstColumn, buffer)                                                                                   \
+#define EM2_STAGE_SNAP(firstColumn, lastColumn, buffer)                                                                       \
     do {                                                                                                                      \
         uint32_t column_ = (firstColumn) + laneId();                                                                          \
-        column_ = column_ < colEnd ? column_ : colEnd - 1u;                                                                   \
+        column_ = column_ < (lastColumn) ? column_ : (lastColumn) - 1u;                                                       \
         const uint64_t address_ = reinterpret_cast<uint64_t>(snap) + uint64_t(column_) * 4u;                                 \
         const uint32_t dst_ = walkLds + kWalkSnapStage + (buffer) * 256u;                                                     \
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"                                           \
@@ -614,28 +642,45 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
                      : "memory", "m0");                                                                                       \
     } while (0)
 #define EM2_WAIT_STAGED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define EM2_KEEP_WRAP_COUNTS()                                                                                                \
+    do {                                                                                                                      \
+        ldsPointer<LdsWordPtr>(walkLds + kWalkWrapCounts)[laneId()] = (recordOffset - firstOffset0) / uint32_t(sizeof(Entry)); \
+        ldsPointer<LdsWordPtr>(walkLds + kWalkWrapCounts)[64u + laneId()] = (recordOffset1 - firstOffset1) / uint32_t(sizeof(Entry)); \
+    } while (0)
     EM2_STAGE_TILE(colBegin / 32u, 0u);
     if (colBegin + 32u < colEnd) EM2_STAGE_TILE(colBegin / 32u + 1u, 1u);
-    EM2_STAGE_SNAP(colBegin, 0u);
+    EM2_STAGE_SNAP(colBegin, colEnd, 0u);
     EM2_WAIT_STAGED();
     __syncthreads();
+    if (wrapBegin < wrapEnd && waveSlot == 0u && laneId() == 0u) stopWords[kWrapBeginWord] = stopWords[kWrapEndWord] = 0u;
     bool tested = false;
     uint64_t passScratch[5];        // scalar pairs for the steps: pass masks in flight, saved exec
     bool pending = false, pendingInY = false;
     uint32_t pendingBase = 0, pendingSlot = 0;
     uint32_t iteration = 0, stopSlot = 0;
+    uint32_t rangeEnd = colEnd;     // of the columns being walked: colEnd, then wrapEnd
+    bool lowerColumns = false;      // the walk has gone around: [wrapBegin, wrapEnd) now
+    bool keepCounts = false;        // ... and the last tile of the higher columns is tested by the step that comes next
     uint32_t result = colEnd;
     // the staged cut-offs of the pair about to be walked (lane = column); those of the next pair are read right behind
     // the barrier that ends a pair, together with the stop word: one LDS round trip there instead of two
     int32_t stagedSnap = snapStage[laneId()];
-    for (uint32_t colBase = colBegin; colBase < colEnd; colBase += 64u, ++iteration) {
+    for (uint32_t colBase = colBegin;; ++iteration) {
         const uint32_t pair = iteration & 1u;
         boundScratch[pair * 64u + laneId()] = kMatrixBits - 2.f * float(stagedSnap);
-        if (colBase + 64u < colEnd) {
-            EM2_STAGE_TILE(colBase / 32u + 2u, 2u * (pair ^ 1u));
-            EM2_STAGE_SNAP(colBase + 64u, pair ^ 1u);
+        // the pair behind this one: the next of these columns, or -- at their end -- the first of the lower ones
+        uint32_t nextBase = colBase + 64u, nextEnd = rangeEnd;
+        const bool around = nextBase >= rangeEnd && !lowerColumns && wrapBegin < wrapEnd;
+        if (around) {
+            nextBase = wrapBegin;
+            nextEnd = wrapEnd;
         }
-        if (colBase + 96u < colEnd) EM2_STAGE_TILE(colBase / 32u + 3u, 2u * (pair ^ 1u) + 1u);
+        const bool more = nextBase < nextEnd;
+        if (more) {
+            EM2_STAGE_TILE(nextBase / 32u, 2u * (pair ^ 1u));
+            EM2_STAGE_SNAP(nextBase, nextEnd, pair ^ 1u);
+            if (nextBase + 32u < nextEnd) EM2_STAGE_TILE(nextBase / 32u + 1u, 2u * (pair ^ 1u) + 1u);
+        }
         // ---- first tile of the pair -> X, under it the test of the pending tile (always in Y here) ----
         {
             const uint32_t tileBase = tilesLds + 2u * pair * (kMatrixTileWords * 16u);
@@ -654,12 +699,16 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
             pendingBase = colBase;
             pendingSlot = 2u * pair;
         }
+        if (keepCounts) {           // (all tiles of the higher columns have been tested now)
+            EM2_KEEP_WRAP_COUNTS();
+            keepCounts = false;
+        }
         // ---- second tile -> Y, under it the test of the first ----
-        if (colBase + 32u < colEnd && (diag & 32u)) {
+        if (colBase + 32u < rangeEnd && (diag & 32u)) {
             const uint32_t tileBase = tilesLds + (2u * pair + 1u) * (kMatrixTileWords * 16u);
             asm volatile(EM2_MATRIX_STEP_Y : : "s"(tileBase) : EM2_MATRIX_STEP_CLOBBERS);
             pendingInY = true;
-        } else if (colBase + 32u < colEnd) {
+        } else if (colBase + 32u < rangeEnd) {
             const uint32_t tileBase = tilesLds + (2u * pair + 1u) * (kMatrixTileWords * 16u);
             const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
             asm volatile(EM2_MATRIX_STEP_Y_TESTING_X
@@ -676,6 +725,23 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
             recordOffset = firstOffset0;
             recordOffset1 = firstOffset1;
         }
+        if (around) {
+            // The higher columns end here.  Their last tile is tested by the next step if that can do it (a pending tile in Y),
+            // and right here otherwise (an odd number of tiles: the pending one sits in X, which the next step fills).
+            if (!pendingInY && !(diag & 32u)) {
+                const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
+                asm volatile(EM2_MATRIX_TEST_X
+                             : "=v"(recordOffset), "=v"(recordOffset1), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
+                             : "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(logBase), "s"(pendingBase) : EM2_MATRIX_STEP_CLOBBERS);
+                tested = true;
+                pending = false;
+                EM2_KEEP_WRAP_COUNTS();
+            } else {
+                keepCounts = true;
+            }
+            lowerColumns = true;
+            rangeEnd = nextEnd;
+        }
         // the untested tile and the next pair add at most 48 records to a log before the next chance to stop
         const bool full = __builtin_amdgcn_ballot_w64(recordOffset > stopOffset0 || recordOffset1 > stopOffset1) != 0ull;
         const uint32_t slot = stopSlot;
@@ -686,13 +752,29 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         if (!(diag & 64u)) __syncthreads();
         const uint32_t stop = stopWords[slot];
         stagedSnap = snapStage[(pair ^ 1u) * 64u + laneId()];
+        if (convoyCode != 0u && (iteration & 3u) == 0u && waveSlot == 0u && laneId() == 0u) {
+            publishWalkPosition(convoyAddress, convoyCode + ((colBase >> 6) - convoyPairBase));
+        }
         if (stop != 0u) {
             __syncthreads();
             if (waveSlot == 0u && laneId() == 0u) stopWords[slot] = 0u;
             __syncthreads();
-            result = colBase + 64u < colEnd ? colBase + 64u : colEnd;
+            result = more ? nextBase : rangeEnd;
+            if (around) {
+                // Logs this full at the end of the higher columns leave the lower ones no room (a call must be able to add
+                // the records of three tiles to what it finds): for the caller the walk stopped in its higher columns.
+                result = colBegin;
+                lowerColumns = false;
+                keepCounts = false;
+            }
             break;
         }
+        if (!more) {
+            result = rangeEnd;
+            break;
+        }
+        if (around && convoyCode != 0u && ((convoyCode >> 12) & 0xffu) < 255u) convoyCode += 1u << 12;       // the convoy's next lap
+        colBase = nextBase;
     }
 #undef EM2_STAGE_TILE
 #undef EM2_STAGE_SNAP
@@ -711,6 +793,8 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         }
         tested = true;
     }
+    if (keepCounts) EM2_KEEP_WRAP_COUNTS();         // (a walk that stopped at the very end of its higher columns)
+#undef EM2_KEEP_WRAP_COUNTS
     // the records were stored by one lane and are read back by others: the stores must have left the wave before the
     // caller replays the logs (it reads past the L1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -718,7 +802,7 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         recordCount[0] = (recordOffset - firstOffset0) / uint32_t(sizeof(Entry));
         recordCount[1] = (recordOffset1 - firstOffset1) / uint32_t(sizeof(Entry));
     }
-    return result;
+    return lowerColumns ? result | kWalkInLowerColumns : result;
 }
 
 // The same walk for 2048-bit signatures (EM2_MATRIX_WIDE_*: the registers hold 32 rows x 32 k-steps, a tile is 32 columns x
@@ -744,6 +828,10 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixWide(const void* fr
     const LdsFloatPtr boundScratch = ldsPointer<LdsFloatPtr>(walkLds + kWalkBounds);
     const LdsIntPtr snapStage = ldsPointer<LdsIntPtr>(walkLds + kWalkSnapStage);
     const uint64_t logBase = uniform64(reinterpret_cast<uint64_t>(waveLogArg));
+    uint32_t convoyCode = uniform(stopWords[kConvoyCodeWord]);
+    const uint32_t convoyPairBase = uniform(stopWords[kConvoyPairBaseWord]);
+    const uint64_t convoyAddress = uint64_t(uniform(stopWords[kConvoyAddressWord])) | (uint64_t(uniform(stopWords[kConvoyAddressWord + 1u])) << 32);
+    const uint32_t wrapBegin = uniform(stopWords[kWrapBeginWord]), wrapEnd = uniform(stopWords[kWrapEndWord]);
     const uint32_t halfCapacity = logCapacity / 2u;
     const uint32_t firstOffset = (laneId() * logCapacity + rowHalf * halfCapacity) * uint32_t(sizeof(Entry));
     const uint32_t stopRecords = halfCapacity > kMatrixLogMargin / 2u ? halfCapacity - kMatrixLogMargin / 2u : 0u;
@@ -772,12 +860,12 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixWide(const void* fr
                      : "v"(src_), "v"(src_ + 0x1000u), "v"(src_ + 0x2000u), "v"(src_ + 0x3000u), "s"(dst_)                   \
                      : "memory", "m0", "scc");                                                                                \
     } while (0)
-#define EM2_STAGE_WIDE_TILE(firstColumn, parity)                                                                              \
+#define EM2_STAGE_WIDE_TILE(firstColumn, lastColumn, parity)                                                                  \
     do {                                                                                                                      \
         EM2_STAGE_UNIT((firstColumn) / 16u, 2u * (parity));                                                                   \
         EM2_STAGE_UNIT((firstColumn) / 16u + 1u, 2u * (parity) + 1u);                                                         \
         uint32_t column_ = (firstColumn) + (laneId() & 31u);                                                                  \
-        column_ = column_ < colEnd ? column_ : colEnd - 1u;                                                                   \
+        column_ = column_ < (lastColumn) ? column_ : (lastColumn) - 1u;                                                       \
         const uint64_t address_ = reinterpret_cast<uint64_t>(snap) + uint64_t(column_) * 4u;                                 \
         const uint32_t dstSnap_ = walkLds + kWalkSnapStage + (parity) * 256u;                                                 \
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"                                           \
@@ -785,20 +873,32 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixWide(const void* fr
                      : "v"(address_), "s"(dstSnap_)                                                                           \
                      : "memory", "m0");                                                                                       \
     } while (0)
-    EM2_STAGE_WIDE_TILE(colBegin, 0u);
+    EM2_STAGE_WIDE_TILE(colBegin, colEnd, 0u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (wrapBegin < wrapEnd && waveSlot == 0u && laneId() == 0u) stopWords[kWrapBeginWord] = stopWords[kWrapEndWord] = 0u;
+#define EM2_KEEP_WRAP_COUNTS()                                                                                                \
+    ldsPointer<LdsWordPtr>(walkLds + kWalkWrapCounts)[rowHalf * 64u + laneId()] = (recordOffset - firstOffset) / uint32_t(sizeof(Entry))
     bool tested = false;
     uint64_t passScratch[5];
     bool pending = false;
     uint32_t pendingBase = 0, pendingParity = 0;
     uint32_t iteration = 0, stopSlot = 0;
+    uint32_t rangeEnd = colEnd;     // (the walk that goes around: as in scanTilesMatrixPinned)
+    bool lowerColumns = false, keepCounts = false;
     uint32_t result = colEnd;
     int32_t stagedSnap = snapStage[laneId()];
-    for (uint32_t colBase = colBegin; colBase < colEnd; colBase += 32u, ++iteration) {
+    for (uint32_t colBase = colBegin;; ++iteration) {
         const uint32_t parity = iteration & 1u;
         boundScratch[parity * 32u + (laneId() & 31u)] = 2.f * kMatrixBits - 2.f * float(stagedSnap);
-        if (colBase + 32u < colEnd) EM2_STAGE_WIDE_TILE(colBase + 32u, parity ^ 1u);
+        uint32_t nextBase = colBase + 32u, nextEnd = rangeEnd;
+        const bool around = nextBase >= rangeEnd && !lowerColumns && wrapBegin < wrapEnd;
+        if (around) {
+            nextBase = wrapBegin;
+            nextEnd = wrapEnd;
+        }
+        const bool more = nextBase < nextEnd;
+        if (more) EM2_STAGE_WIDE_TILE(nextBase, nextEnd, parity ^ 1u);
         const uint32_t tileBase = tilesLds + 2u * parity * (kMatrixTileWords * 16u);
         const uint32_t boundBase = walkLds + kWalkBounds + pendingParity * 128u;
         const uint32_t tileCode = pendingBase | rowHalf;
@@ -817,9 +917,18 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixWide(const void* fr
                          : EM2_MATRIX_STEP_CLOBBERS);
             tested = true;
         }
+        if (keepCounts) {           // (all tiles of the higher columns have been tested now)
+            EM2_KEEP_WRAP_COUNTS();
+            keepCounts = false;
+        }
         pending = true;
         pendingBase = colBase;
         pendingParity = parity;
+        if (around) {
+            keepCounts = true;
+            lowerColumns = true;
+            rangeEnd = nextEnd;
+        }
         // the untested tile and the next one add at most 32 records to a log before the next chance to stop
         const bool full = __builtin_amdgcn_ballot_w64(recordOffset > stopOffset) != 0ull;
         const uint32_t slot = stopSlot;
@@ -830,13 +939,29 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixWide(const void* fr
         __syncthreads();
         const uint32_t stop = stopWords[slot];
         stagedSnap = snapStage[(parity ^ 1u) * 64u + laneId()];
+        if (convoyCode != 0u && (iteration & 3u) == 0u && waveSlot == 0u && laneId() == 0u) {
+            publishWalkPosition(convoyAddress, convoyCode + ((colBase >> 6) - convoyPairBase));
+        }
         if (stop != 0u) {
             __syncthreads();
             if (waveSlot == 0u && laneId() == 0u) stopWords[slot] = 0u;
             __syncthreads();
-            result = colBase + 32u;
+            result = more ? nextBase : rangeEnd;
+            if (around) {
+                // Logs this full at the end of the higher columns leave the lower ones no room (a call must be able to add
+                // the records of three tiles to what it finds): for the caller the walk stopped in its higher columns.
+                result = colBegin;
+                lowerColumns = false;
+                keepCounts = false;
+            }
             break;
         }
+        if (!more) {
+            result = rangeEnd;
+            break;
+        }
+        if (around && convoyCode != 0u && ((convoyCode >> 12) & 0xffu) < 255u) convoyCode += 1u << 12;       // the convoy's next lap
+        colBase = nextBase;
     }
 #undef EM2_STAGE_WIDE_TILE
 #undef EM2_STAGE_UNIT
@@ -854,9 +979,11 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixWide(const void* fr
         }
         tested = true;
     }
+    if (keepCounts) EM2_KEEP_WRAP_COUNTS();         // (a walk that stopped at the very end of its higher columns)
+#undef EM2_KEEP_WRAP_COUNTS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tested) recordCount[rowHalf] = (recordOffset - firstOffset) / uint32_t(sizeof(Entry));
-    return result;
+    return lowerColumns ? result | kWalkInLowerColumns : result;
 }
 
 // The log of `lane` for accumulator a in the wave's log area.
@@ -868,20 +995,27 @@ __device__ __forceinline__ const Entry* walkLogOf(const Entry* waveLog, uint32_t
 // A log read a few records ahead of its use (the records were written by another lane: every load goes past the L1, and
 // a replay that waited for each one -- the next record is needed to decide which stream to take from -- spent most of its
 // time in that latency).
+// The records are taken in the order first, first + 1, ..., stored - 1 and then -- a walk that went around its segment
+// (scanMatrixBody, "convoy") -- 0 .. first - 1: the log of such a walk holds the columns from its starting point to the
+// segment's end in front of the columns from the segment's begin to its starting point.
 struct WalkLogReader {
     const Entry* log;
-    uint32_t count, fetched, taken;
+    uint32_t count, fetched, taken, first, stored;
     WalkRecord ahead[4];
-    __device__ __forceinline__ void start(const Entry* l, uint32_t n)
+    __device__ __forceinline__ uint32_t physical(uint32_t i) const { return first + i < stored ? first + i : first + i - stored; }
+    // n records of a log that holds `stored`, from record `from` on
+    __device__ __forceinline__ void start(const Entry* l, uint32_t n, uint32_t from = 0u, uint32_t storedRecords = 0u)
     {
         log = l;
         count = n;
+        first = from;
+        stored = from ? storedRecords : n;
         fetched = taken = 0u;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             ahead[i].code = 0u;
             ahead[i].dot = 0.f;
-            if (uint32_t(i) < count) ahead[i] = loadWalkRecord(log, uint32_t(i));
+            if (uint32_t(i) < count) ahead[i] = loadWalkRecord(log, physical(uint32_t(i)));
         }
         fetched = count < 4u ? count : 4u;
     }
@@ -892,7 +1026,7 @@ struct WalkLogReader {
         ahead[0] = ahead[1];
         ahead[1] = ahead[2];
         ahead[2] = ahead[3];
-        if (fetched < count) ahead[3] = loadWalkRecord(log, fetched);
+        if (fetched < count) ahead[3] = loadWalkRecord(log, physical(fetched));
         fetched += fetched < count ? 1u : 0u;
         ++taken;
     }
@@ -904,9 +1038,13 @@ struct WalkLogReader {
 // lane its own, all lanes in step.  Per record: the row side through the exact state machine (acceptColumn), the column
 // side -- unless the rows scan all columns themselves (full rows) -- to the inbox if it passes the column's published
 // cut-off, read now (fresher than the one the walk tested against: fewer entries).
-// recordCount[a] = the calling lane's number of records in its log of accumulator a.
+// recordCount[a] = the calling lane's number of records in its log of accumulator a.  A walk that went around its segment:
+// firstRecord[a] = the lane's number of records when the walk reached the segment's end (their columns are the higher ones and
+// come last); all = false replays only the records from firstRecord on (the walk stopped for its logs in the lower columns:
+// those are in order and go first, the others stay).
 template <bool IDENTITY, bool WIDE = false>
-__device__ __forceinline__ void replayWalkLogs(const Entry* waveLog, uint32_t logCapacity, const uint32_t (&recordCount)[2], uint32_t lane,
+__device__ __forceinline__ void replayWalkLogs(const Entry* waveLog, uint32_t logCapacity, const uint32_t (&recordCount)[2],
+                                               const uint32_t (&firstRecord)[2], bool all, uint32_t lane,
                                                uint32_t row, bool rowValid, bool emitColumns, uint32_t listBlock, Entry* myList,
                                                uint32_t twoK, uint32_t& count, int32_t& mMax, uint32_t& emitPos, uint32_t& emitEnd,
                                                unsigned char* ldsRaw)
@@ -915,9 +1053,17 @@ __device__ __forceinline__ void replayWalkLogs(const Entry* waveLog, uint32_t lo
     // the counts of the two source logs: accumulator a of lanes t and 32 + t
     const uint32_t mine0 = uint32_t(__shfl(int(recordCount[0]), int(t), 64)), mine1 = uint32_t(__shfl(int(recordCount[1]), int(t), 64));
     const uint32_t theirs0 = uint32_t(__shfl(int(recordCount[0]), int(t + 32u), 64)), theirs1 = uint32_t(__shfl(int(recordCount[1]), int(t + 32u), 64));
+    const uint32_t mineFirst0 = uint32_t(__shfl(int(firstRecord[0]), int(t), 64)), mineFirst1 = uint32_t(__shfl(int(firstRecord[1]), int(t), 64));
+    const uint32_t theirsFirst0 = uint32_t(__shfl(int(firstRecord[0]), int(t + 32u), 64)), theirsFirst1 = uint32_t(__shfl(int(firstRecord[1]), int(t + 32u), 64));
     WalkLogReader lower, upper;
-    lower.start(walkLogOf(waveLog, logCapacity, t, a), a ? mine1 : mine0);
-    upper.start(walkLogOf(waveLog, logCapacity, t + 32u, a), a ? theirs1 : theirs0);
+    {
+        const uint32_t stored = a ? mine1 : mine0, first = a ? mineFirst1 : mineFirst0;
+        lower.start(walkLogOf(waveLog, logCapacity, t, a), all ? stored : stored - first, first, stored);
+    }
+    {
+        const uint32_t stored = a ? theirs1 : theirs0, first = a ? theirsFirst1 : theirsFirst0;
+        upper.start(walkLogOf(waveLog, logCapacity, t + 32u, a), all ? stored : stored - first, first, stored);
+    }
     const int32_t* snap = kernelArgs()->snap;
     for (;;) {
         const bool have0 = lower.have(), have1 = upper.have();

@@ -109,7 +109,7 @@ def scan_knobs():
                                              "EM2_BLOCKS_PER_CU", "EM2_FULL_ROW_CELLS", "EM2_SEGMENTS",
                                              "EM2_INBOX_CAPACITY", "EM2_SYMMETRIC_MIN_CELLS", "EM2_VIRTUAL_WORLD",
                                              "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_SCAN_MATRIX", "EM2_MATRIX_WALK",
-                                             "EM2_SCAN_MATRIX_WIDE", "EM2_MATRIX_DEPART_US", "EM2_MATRIX_DEPART_WINDOW_US")}
+                                             "EM2_SCAN_MATRIX_WIDE", "EM2_MATRIX_DEPART_US", "EM2_MATRIX_DEPART_WINDOW_US", "EM2_MATRIX_CONVOY")}
 
     def set_knobs(**kw):
         for key, value in kw.items():
@@ -351,6 +351,46 @@ def test_matrix_form_matches_oracle(oracle, scan_knobs, n, L, k, thr, kind, knob
     cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
     scan_knobs(EM2_SCAN_MODE="triangle", **knobs)
     pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    assert capi.dev_find_similar_pairs4_last_launch()["form"] == 3
+    assert_same(pairs, gused, cell, sim, used)
+
+
+@pytest.mark.parametrize("convoy", [0, 2, 3, 6])
+@pytest.mark.parametrize("n,L,k,thr,kind,knobs", [
+    (2500, 1024, 10, 0.2, "clustered", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=512)),
+    (4000, 1024, 25, 0.2, "clustered", dict(EM2_FULL_ROW_CELLS=512, EM2_SEGMENTS=3)),                  # full rows go around as well
+    (2309, 600, 7, 0.0, "clustered", dict(EM2_FULL_ROW_CELLS=300, EM2_MIN_SEGMENT_COLUMNS=700)),       # an idle wave
+    (1700, 1024, 5, -1.0, "random", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=512)),          # logs fill on either side of the wrap
+    (1700, 1024, 300, -0.5, "clustered", dict(EM2_FULL_ROW_CELLS=256, EM2_MIN_SEGMENT_COLUMNS=512, EM2_LOG_CAPACITY=1)),
+    (2500, 2048, 10, 0.2, "clustered", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=512)),       # the 2048-bit walk: each pass goes around
+    (1700, 2048, 5, -1.0, "random", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=512)),
+    (3100, 1500, 40, 0.1, "clustered", dict(EM2_FULL_ROW_CELLS=256, EM2_SEGMENTS=2, EM2_LOG_CAPACITY=1)),
+])
+def test_matrix_form_walks_that_go_around(oracle, scan_knobs, n, L, k, thr, kind, knobs, convoy):
+    """The convoy: a walk starts where the other walks of its XCD are and goes around its segment; the replay
+    takes the logs in the order of the columns.  EM2_MATRIX_CONVOY=n >= 2 starts EVERY walk 64 (n - 1) columns into its
+    segment (the product's setting, 1, follows the other blocks: not reproducible); 0 = no walk goes around.  Logs that fill
+    before the wrap send the walk back to the segment's begin, logs that fill behind it are replayed in part."""
+    sig = make(n, L, kind)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_MATRIX_CONVOY=convoy, **knobs)
+    pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    info = capi.dev_find_similar_pairs4_last_launch()
+    assert info["form"] == 3 and info["matrix_pairs"] > 0
+    assert_same(pairs, gused, cell, sim, used)
+
+
+@pytest.mark.parametrize("convoy", [4, 5, 6])
+@pytest.mark.parametrize("L", [1024, 2048])
+def test_walk_that_goes_around_with_nearly_full_logs(oracle, scan_knobs, L, convoy):
+    """Found by tools/fuzz_parity.py (seed 41): one cluster, k = 5, threshold 0.5 -- nearly every pair is logged.  A walk whose
+    logs are nearly full when it has reached its segment's end must not go on into the lower columns (a call of the walk has to
+    find room for three tiles' records: the logs of the neighbouring lanes were overwritten, rows got neighbours with the
+    similarity of another pair); it starts again at the segment's begin instead."""
+    sig = synth.clustered_signatures(1500, L, cluster_count=1, flip=0.1, seed=285543329)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, 5, 0.5)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_MIN_SEGMENT_COLUMNS=257, EM2_FULL_ROW_CELLS=64, EM2_MATRIX_CONVOY=convoy)
+    pairs, gused = capi.find_similar_pairs4(sig, L, 5, 0.5)
     assert capi.dev_find_similar_pairs4_last_launch()["form"] == 3
     assert_same(pairs, gused, cell, sim, used)
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on a GPU box (not part of pytest): random shapes, thresholds, k and scan-form knobs, every
 result compared bit for bit with the CPU oracle.  SECONDS=300 python3 tools/fuzz_parity.py [seed]
-FUZZ_ONLY=fsp4 restricts the sweep to one path, FUZZ_WIDTHS=1100,1500,2048 to those signature widths."""
+FUZZ_ONLY=fsp4 restricts the sweep to one path, FUZZ_WIDTHS=1100,1500,2048 to those signature widths, FUZZ_MODE=triangle
+to one scan form with the matrix cores on."""
 import os
 import sys
 import time
@@ -17,7 +18,7 @@ from label_graphs import fast_graph  # noqa: E402
 from expressionmatrix2_amd import capi  # noqa: E402
 
 KNOBS = ("EM2_SCAN_MODE", "EM2_MIN_SEGMENT_COLUMNS", "EM2_LOG_CAPACITY", "EM2_FULL_ROW_CELLS", "EM2_VIRTUAL_WORLD",
-         "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_BLOCKS_PER_CU", "EM2_SEGMENTS", "EM2_SCAN_MATRIX")
+         "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_BLOCKS_PER_CU", "EM2_SEGMENTS", "EM2_SCAN_MATRIX", "EM2_MATRIX_CONVOY")
 
 
 def main():
@@ -63,10 +64,11 @@ def main():
         thr = float(rng.choice([-1.0, -0.5, 0.0, 0.1, 0.2, 0.5, 0.9]))
         clusters = int(rng.choice([1, 2, 5, 20]))
         flip = float(rng.choice([0.0, 0.02, 0.1, 0.3, 0.5]))
-        sig = synth.clustered_signatures(n, L, cluster_count=clusters, flip=flip, seed=int(rng.integers(1 << 30)))
+        sig_seed = int(rng.integers(1 << 30))
+        sig = synth.clustered_signatures(n, L, cluster_count=clusters, flip=flip, seed=sig_seed)
         what = rng.choice(["fsp4", "fsp4", "fsp4", "fsp5", "fsp7", "signatures", "graph"])
         what = os.environ.get("FUZZ_ONLY", what)
-        label = dict(n=n, L=L, k=k, thr=thr, clusters=clusters, flip=flip)
+        label = dict(n=n, L=L, k=k, thr=thr, clusters=clusters, flip=flip, sig_seed=sig_seed)
         if what == "fsp4":
             knobs = {"EM2_SCAN_MODE": str(rng.choice(["persistent", "triangle", "virtual", "simple"])),
                      "EM2_MIN_SEGMENT_COLUMNS": str(int(rng.choice([64, 100, 257, 1000, 4096]))),
@@ -76,7 +78,12 @@ def main():
                      "EM2_PREFIX_PERMILLE": str(int(rng.choice([50, 200, 500, 900]))),
                      "EM2_TILE_SEGMENTS": str(int(rng.choice([1, 3, 17, 256]))),
                      "EM2_BLOCKS_PER_CU": str(int(rng.choice([1, 2, 4]))),
-                     "EM2_SCAN_MATRIX": str(int(rng.choice([0, 1, 1])))}
+                     "EM2_SCAN_MATRIX": str(int(rng.choice([0, 1, 1]))),
+                     # (the convoy of the matrix walks: off, following the other blocks, or every walk n - 1 pairs of tiles in)
+                     "EM2_MATRIX_CONVOY": str(int(rng.choice([0, 1, 1, 2, 3, 5, 9, 30])))}
+            if os.environ.get("FUZZ_MODE"):
+                knobs["EM2_SCAN_MODE"] = os.environ["FUZZ_MODE"]
+                knobs["EM2_SCAN_MATRIX"] = "1"
             os.environ.update(knobs)
             label.update(knobs)
             cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
@@ -134,6 +141,13 @@ def main():
         ok = (np.array_equal(gused, used) and np.array_equal(pairs["cell"], cell) and
               np.array_equal(pairs["similarity"].view(np.uint32), sim.view(np.uint32)))
         if not ok:
+            # which rows, and where in them (the first few)
+            rows = np.nonzero((gused != used) | (pairs["cell"] != cell).any(axis=1) |
+                              (pairs["similarity"].view(np.uint32) != sim.view(np.uint32)).any(axis=1))[0]
+            print("differing rows: %d of %d, first %s" % (len(rows), len(used), rows[:12].tolist()))
+            for r in rows[:4]:
+                print(" row %d: used %d / expected %d; cells %s / expected %s" % (r, gused[r], used[r], pairs["cell"][r][:12].tolist(),
+                                                                                 cell[r][:12].tolist()))
             raise SystemExit("PARITY FAILURE %s %r" % (what, label))
         runs[what] += 1
     print("fuzz ok", runs)

@@ -98,7 +98,11 @@ def prologue(s, o, tile, tests):
         s.emit("v_lshl_add_u32 %s, %s, 4, %s" % (vreg(BOUND_ADDR), vreg(BOUND_ADDR), o["boundBase"]))     # + 16 * (lane >> 5)
         s.lds("rowBound0", "ds_read_b32 %s, %s" % (vreg(ROW_BOUND0), vreg(STATE_ADDR)))
         s.lds("rowBound1", "ds_read_b32 %s, %s offset:128" % (vreg(ROW_BOUND1), vreg(STATE_ADDR)))
-        s.lds("bounds0", "ds_read_b128 %s, %s" % (vreg(BOUNDS, 4), vreg(BOUND_ADDR)))
+        if TILE_BOUND:
+            s.emit("v_mov_b32 %s, %s" % (vreg(BOUND_ADDR), o["boundBase"]))
+            s.lds("bounds0", "ds_read_b32 %s, %s" % (vreg(BOUNDS), vreg(BOUND_ADDR)))
+        else:
+            s.lds("bounds0", "ds_read_b128 %s, %s" % (vreg(BOUNDS, 4), vreg(BOUND_ADDR)))
 
 
 def tests_of(s, o, q, j, k, prev0, prev1):
@@ -106,9 +110,10 @@ def tests_of(s, o, q, j, k, prev0, prev1):
     pass0 / pass1 of parity k & 1; their scalar half (shift_in) follows one k-step later, when the masks have long
     arrived -- a scalar instruction that reads a mask a vector compare has just written stalls the wave for the length
     of the vector pipeline, twice per k-step."""
-    bound = BOUNDS + 4 * (q & 1) + j
-    s.emit("v_min_f32 %s, %s, %s" % (vreg(THR0), vreg(ROW_BOUND0), vreg(bound)))
-    s.emit("v_min_f32 %s, %s, %s" % (vreg(THR1), vreg(ROW_BOUND1), vreg(bound)))
+    bound = BOUNDS if TILE_BOUND else BOUNDS + 4 * (q & 1) + j
+    if not TILE_BOUND or k == 0:
+        s.emit("v_min_f32 %s, %s, %s" % (vreg(THR0), vreg(ROW_BOUND0), vreg(bound)))
+        s.emit("v_min_f32 %s, %s, %s" % (vreg(THR1), vreg(ROW_BOUND1), vreg(bound)))
     s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass0_%d" % (k & 1)], vreg(THR0), vreg(prev0 + k)))
     s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass1_%d" % (k & 1)], vreg(THR1), vreg(prev1 + k)))
 
@@ -164,18 +169,18 @@ def fragment_read(s, k, slot, carry):
 
 def place(s, o, k, what, prev0, prev1, slot, carry=False):
     q, j = k >> 2, k & 3
-    bound = BOUNDS + 4 * (q & 1) + j
+    bound = BOUNDS if TILE_BOUND else BOUNDS + 4 * (q & 1) + j
     for letter in what:
         if letter == "S" and k:
             shift_in(s, o, k - 1)
-        if letter == "M":
+        if letter == "M" and (not TILE_BOUND or k == 0):
             if j == 0:
                 s.wait_for("bounds%d" % q)
             s.emit("v_min_f32 %s, %s, %s" % (vreg(THR0), vreg(ROW_BOUND0), vreg(bound)))
             s.emit("v_min_f32 %s, %s, %s" % (vreg(THR1), vreg(ROW_BOUND1), vreg(bound)))
         if letter == "D":
             fragment_read(s, k, slot, carry)
-            if j == 1 and q < 3:
+            if j == 1 and q < 3 and not TILE_BOUND:
                 s.lds("bounds%d" % (q + 1), "ds_read_b128 %s, %s offset:%d"
                       % (vreg(BOUNDS + 4 * ((q + 1) & 1), 4), vreg(BOUND_ADDR), 32 * (q + 1)))
         if letter == "C":
@@ -188,6 +193,9 @@ def place(s, o, k, what, prev0, prev1, slot, carry=False):
 # barrier), and the step of the second tile (Y) starts with them in flight -- no LDS round trip in front of its first MFMA.
 # EM2_GEN_CARRY=0 generates the steps without it (every step fills the ring itself).
 CARRY = os.environ.get("EM2_GEN_CARRY", "1") != "0"
+# EM2_GEN_TILE_BOUND=1: ONE column bound per tile (the loosest of its 32 columns, a float at boundBase): the two v_min of a
+# step's first k-step serve all 32 results, the per-result work is the v_cmp alone.
+TILE_BOUND = os.environ.get("EM2_GEN_TILE_BOUND", "0") == "1"
 
 
 def step(cur, prev, tests, operands):
@@ -240,7 +248,7 @@ def test_only(prev, operands):
     s.emit("s_nop 15")
     prologue(s, o, False, True)
     for q in range(4):
-        if q:
+        if q and not TILE_BOUND:
             s.lds("bounds%d" % q, "ds_read_b128 %s, %s offset:%d" % (vreg(BOUNDS + 4 * (q & 1), 4), vreg(BOUND_ADDR), 32 * q))
         s.wait_for("bounds%d" % q)
         for j in range(4):
@@ -274,7 +282,11 @@ def wide_prologue(s, o, tile, tests):
         s.emit("v_lshrrev_b32 %s, 5, %s" % (vreg(BOUND_ADDR), vreg(LANE)))
         s.emit("v_lshl_add_u32 %s, %s, 4, %s" % (vreg(BOUND_ADDR), vreg(BOUND_ADDR), o["boundBase"]))
         s.lds("rowBound0", "ds_read_b32 %s, %s" % (vreg(ROW_BOUND0), vreg(STATE_ADDR)))
-        s.lds("bounds0", "ds_read_b128 %s, %s" % (vreg(BOUNDS, 4), vreg(BOUND_ADDR)))
+        if TILE_BOUND:
+            s.emit("v_mov_b32 %s, %s" % (vreg(BOUND_ADDR), o["boundBase"]))
+            s.lds("bounds0", "ds_read_b32 %s, %s" % (vreg(BOUNDS), vreg(BOUND_ADDR)))
+        else:
+            s.lds("bounds0", "ds_read_b128 %s, %s" % (vreg(BOUNDS, 4), vreg(BOUND_ADDR)))
 
 
 def wide_shift_in(s, o, i):
@@ -286,6 +298,11 @@ def wide_shift_in(s, o, i):
 
 def wide_min(s, i):
     q, j = i >> 2, i & 3
+    if TILE_BOUND:
+        if i == 0:
+            s.wait_for("bounds0")
+            s.emit("v_min_f32 %s, %s, %s" % (vreg(THR0), vreg(ROW_BOUND0), vreg(BOUNDS)))
+        return
     if j == 0:
         s.wait_for("bounds%d" % q)
     s.emit("v_min_f32 %s, %s, %s" % (vreg(THR0), vreg(ROW_BOUND0), vreg(BOUNDS + 4 * (q & 1) + j)))
@@ -297,7 +314,7 @@ def wide_cmp(s, o, i, prev0):
 
 def wide_bounds_ahead(s, i):
     q, j = i >> 2, i & 3
-    if j == 1 and q < 3:
+    if j == 1 and q < 3 and not TILE_BOUND:
         s.lds("bounds%d" % (q + 1), "ds_read_b128 %s, %s offset:%d"
               % (vreg(BOUNDS + 4 * ((q + 1) & 1), 4), vreg(BOUND_ADDR), 32 * (q + 1)))
 
