@@ -211,7 +211,7 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
     FragmentWord4* tiles = reinterpret_cast<FragmentWord4*>(ldsRaw + kernelArgs()->matrixLdsOffset);
     volatile uint32_t* shared = reinterpret_cast<volatile uint32_t*>(ldsRaw + kernelArgs()->matrixLdsOffset + 4u * kMatrixTileWords * 16u);
     unsigned char* walkBlock = ldsRaw + kernelArgs()->matrixLdsOffset + 4u * kMatrixTileWords * 16u + 64u + wave * kMatrixWalkLdsBytes;
-    if (threadIdx.x < 12u) shared[threadIdx.x] = 0u;         // (words 4..8: no convoy here, see scanMatrixBody)
+    if (threadIdx.x < 12u) shared[threadIdx.x] = 0u;         // (words 4..10: the convoy, see scanMatrixBody)
     __syncthreads();
     uint32_t emitPos = 0, emitEnd = 0;
     for (;;) {
@@ -254,34 +254,49 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
                 // the walk logs what passes either bound; both sides of every record go to the inbox afterwards
                 const uint32_t logCapacity = aux->logCapacity < kMatrixLogMargin ? kMatrixLogMargin : aux->logCapacity;
                 Entry* waveLog = aux->logs + size_t(blockIdx.x * 4u + wave) * 64u * logCapacity;
-                uint32_t at = colBegin;
-                if (WIDE) {
-                    // (2048 bits: the columns once per half of the wave's rows, see scanTilesMatrixWide)
-                    for (uint32_t rowHalf = 0; rowHalf < 2u; ++rowHalf) {
-                        at = colBegin;
-                        while (at < commonEnd) {
-                            uint32_t records[2] = {0u, 0u};
-                            at = scanTilesMatrixWide<true>(aux->fragments, aux->snap, at, commonEnd, 2u * fragmentBlock + rowHalf,
-                                                           2.f * kMatrixBits - 2.f * float(snapRow), rowHalf, waveLog, logCapacity, records,
-                                                           ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)), ldsAddress(walkBlock));
-                            if (!idle) drainWalkLogs<true>(waveLog, logCapacity, records, lane, rowBase, cellCount, emitPos, emitEnd);
+                // The walk may start where the other walks of the XCD are and go around (the convoy, scanMatrixBody); here the
+                // order of the columns means nothing -- both sides of every record go to the inbox, which is sorted -- so the
+                // logs are emptied after every call, wherever it stopped.  range = [at, end), then [colBegin, start).
+                for (uint32_t rowHalf = 0; rowHalf < (WIDE ? 2u : 1u); ++rowHalf) {
+                    const uint32_t start = convoyStartColumn(aux, shared, seg, colBegin, commonEnd);
+                    uint32_t at = start, end = commonEnd;
+                    bool around = start == colBegin;            // (nothing left below the starting column)
+                    for (;;) {
+                        if (at >= end) {
+                            if (around) break;
+                            around = true;                      // (the call stopped before it could go around itself)
+                            at = colBegin;
+                            end = start;
+                            continue;
+                        }
+                        uint32_t records[2] = {0u, 0u};
+                        uint32_t next;
+                        if (WIDE) {
+                            next = scanTilesMatrixWide<true, true>(aux->fragments, aux->snap, at, end, 2u * fragmentBlock + rowHalf,
+                                                                   2.f * kMatrixBits - 2.f * float(snapRow), rowHalf, waveLog, logCapacity, records,
+                                                                   ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)), ldsAddress(walkBlock));
+                        } else if (EM2_DIAG_WORD(aux)) {
+                            next = scanTilesMatrixPinned<true, true, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, end,
+                                                               2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), waveLog, logCapacity,
+                                                               records, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
+                                                               ldsAddress(walkBlock));
+                        } else {
+                            next = scanTilesMatrixPinned<true, true, false>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, end,
+                                                               2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), waveLog, logCapacity,
+                                                               records, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
+                                                               ldsAddress(walkBlock));
+                        }
+                        if ((next & kWalkInLowerColumns) != 0u) {
+                            around = true;
+                            end = start;
+                            next &= ~kWalkInLowerColumns;
+                        }
+                        at = next;
+                        if (!idle) {
+                            if (WIDE) drainWalkLogs<true>(waveLog, logCapacity, records, lane, rowBase, cellCount, emitPos, emitEnd);
+                            else drainWalkLogs(waveLog, logCapacity, records, lane, rowBase, cellCount, emitPos, emitEnd);
                         }
                     }
-                }
-                while (!WIDE && at < commonEnd) {
-                    uint32_t records[2] = {0u, 0u};
-                    if (EM2_DIAG_WORD(aux)) {
-                        at = scanTilesMatrixPinned<true, true, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
-                                                           2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), waveLog, logCapacity,
-                                                           records, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
-                                                           ldsAddress(walkBlock));
-                    } else {
-                        at = scanTilesMatrixPinned<true, true, false>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, commonEnd,
-                                                           2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), waveLog, logCapacity,
-                                                           records, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
-                                                           ldsAddress(walkBlock));
-                    }
-                    if (!idle) drainWalkLogs(waveLog, logCapacity, records, lane, rowBase, cellCount, emitPos, emitEnd);
                 }
             } else {
                 scanTilesMatrix<true, true>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, colBegin, commonEnd,
@@ -572,11 +587,10 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             if (e != hipSuccess) return e;
             args.fragments = ws + plan.offFragments;
             args.matrixLdsOffset = uint32_t(matrixLdsOffset);
-            // the walks of an XCD go around their segment together (scanMatrixBody, "convoy"); the position words start at zero
-            args.convoy = uint32_t(envNumber("EM2_MATRIX_CONVOY", 1));
-            if (cps / 64u > kConvoyMaxPairs && args.convoy == 1u) args.convoy = 0u;
-            e = hipMemsetAsync(args.inboxControl + kConvoyWordsOffset, 0, 64u, stream);
-            if (e != hipSuccess) return e;
+            // No convoy here unless a test forces one (EM2_MATRIX_CONVOY >= 2): these launches are a few items per block, which
+            // start together and stay together (measured at 1M cells, four ranks: 16.2 ms per launch without, 16.8 with it).
+            args.convoy = uint32_t(envNumber("EM2_MATRIX_CONVOY", 0));
+            if (args.convoy == 1u) args.convoy = 0u;
             lastLaunchInfo.matrixPairs += double(slotCount) * 64.0 * double(M);
             const void* matrixKernel = scanMatrixKernelFor(t.identityKeys, wide);
             int device = 0, cuCount = 0;
@@ -694,6 +708,12 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             if (e != hipSuccess) return e;
             args.fragments = ws + plan.offFragments;
             args.matrixLdsOffset = 0u;
+            // the tiles' walks go around their segments in convoys (scanMatrixBody; 30.5 -> 29.8 ms per launch at 1M cells, four
+            // ranks); the position words start at zero
+            args.convoy = uint32_t(envNumber("EM2_MATRIX_CONVOY", 1));
+            if (cps / 64u > kConvoyMaxPairs && args.convoy == 1u) args.convoy = 0u;
+            e = hipMemsetAsync(args.inboxControl + kConvoyWordsOffset, 0, 64u, stream);
+            if (e != hipSuccess) return e;
             const size_t matrixLds = args.matrixLdsOffset + kMatrixLdsBytes;
             uint64_t blocksWanted = uint64_t(cuCount) * 2u;
             if (blocksWanted > own) blocksWanted = own;

@@ -445,39 +445,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         // and starts again at the segment's begin, as a walk without convoy (in the lower columns a stop is harmless: those
         // records are in order, they are replayed and removed).  Never at the bench's sizes (0 of 120 337 items stop at all).
         auto convoyStart = [&]() -> uint32_t {
-            const uint32_t mode = aux->convoy;
-            if (!PINNED || mode == 0u || colBegin + 128u >= commonEnd) return colBegin;
-            if (threadIdx.x == 0u) {
-                uint32_t* word = aux->inboxControl + kConvoyWordsOffset + 2u * (blockIdx.x & 7u) + (seg & 1u);
-                const uint32_t code = (seg + 1u) << 20;
-                uint32_t from = colBegin, lap = 0u;
-                bool publish = mode == 1u;
-                if (mode == 1u) {
-                    const uint32_t seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((seen & 0xfff00000u) == code) {
-                        lap = (seen >> 12) & 0xffu;
-                        from = colBegin + ((seen & 0xfffu) << 6);
-                        publish = false;            // (unless it joins: a walk on its own is no head to follow)
-                    }
-                } else {
-                    from = colBegin + 64u * (mode - 1u);
-                }
-                // (whole pairs of tiles from the segment's begin, and something left to walk on either side)
-                if (from <= colBegin || from + 64u >= commonEnd) from = colBegin;
-                else publish = mode == 1u;
-                shared[kConvoyStartWord] = from;
-                shared[kConvoyCodeWord] = publish ? code | (lap << 12) : 0u;
-                shared[kConvoyAddressWord] = uint32_t(reinterpret_cast<uintptr_t>(word));
-                shared[kConvoyAddressWord + 1u] = uint32_t(uint64_t(reinterpret_cast<uintptr_t>(word)) >> 32);
-                shared[kConvoyPairBaseWord] = colBegin >> 6;
-                // (one call walks both parts: scanTilesMatrixPinned, scanTilesMatrixWide)
-                shared[kWrapBeginWord] = from != colBegin ? colBegin : 0u;
-                shared[kWrapEndWord] = from != colBegin ? from : 0u;
-            }
-            __syncthreads();
-            const uint32_t from = uint32_t(__builtin_amdgcn_readfirstlane(int(shared[kConvoyStartWord])));
-            __syncthreads();
-            return from;
+            return PINNED ? convoyStartColumn(aux, shared, seg, colBegin, commonEnd) : colBegin;
         };
         bool failed = false;
         uint32_t start = convoyStart();         // (start == colBegin: a walk as ever)

@@ -547,6 +547,48 @@ __device__ __forceinline__ void publishWalkPosition(uint64_t address, uint32_t v
     asm volatile("global_atomic_umax %0, %1, off sc1" : : "v"(address), "v"(value) : "memory");
 }
 
+// Where the walk of an item starts (scanMatrixBody, tileMatrixBody): the first column of its segment -- or, with the convoy, the
+// column at which the head of its XCD group's walks through this segment is; the walk then goes around.  Block-uniform; the
+// block's first thread sets the convoy's stop words for the call of the walk that follows.  aux->convoy: 0 = off, 1 = follow
+// the head, n >= 2 = 64 (n - 1) columns into the segment (tests).
+__device__ __forceinline__ uint32_t convoyStartColumn(ArgsPtr aux, volatile uint32_t* shared, uint32_t seg, uint32_t colBegin,
+                                                      uint32_t commonEnd)
+{
+    const uint32_t mode = aux->convoy;
+    if (mode == 0u || colBegin + 128u >= commonEnd) return colBegin;
+    if (threadIdx.x == 0u) {
+        uint32_t* word = aux->inboxControl + kConvoyWordsOffset + 2u * (blockIdx.x & 7u) + (seg & 1u);
+        const uint32_t code = (seg + 1u) << 20;
+        uint32_t from = colBegin, lap = 0u;
+        bool publish = mode == 1u;
+        if (mode == 1u) {
+            const uint32_t seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((seen & 0xfff00000u) == code) {
+                lap = (seen >> 12) & 0xffu;
+                from = colBegin + ((seen & 0xfffu) << 6);
+                publish = false;            // (unless it joins: a walk on its own is no head to follow)
+            }
+        } else {
+            from = colBegin + 64u * (mode - 1u);
+        }
+        // (whole pairs of tiles from the segment's begin, and something left to walk on either side)
+        if (from <= colBegin || from + 64u >= commonEnd) from = colBegin;
+        else publish = mode == 1u;
+        shared[kConvoyStartWord] = from;
+        shared[kConvoyCodeWord] = publish ? code | (lap << 12) : 0u;
+        shared[kConvoyAddressWord] = uint32_t(reinterpret_cast<uintptr_t>(word));
+        shared[kConvoyAddressWord + 1u] = uint32_t(uint64_t(reinterpret_cast<uintptr_t>(word)) >> 32);
+        shared[kConvoyPairBaseWord] = colBegin >> 6;
+        // (one call walks both parts: scanTilesMatrixPinned, scanTilesMatrixWide)
+        shared[kWrapBeginWord] = from != colBegin ? colBegin : 0u;
+        shared[kWrapEndWord] = from != colBegin ? from : 0u;
+    }
+    __syncthreads();
+    const uint32_t from = uint32_t(__builtin_amdgcn_readfirstlane(int(shared[kConvoyStartWord])));
+    __syncthreads();
+    return from;
+}
+
 // The lock-step walk over the tiles [colBegin, colEnd) with the hand-scheduled steps.  Out of line: the steps own
 // v28..v255, and inlined into the kernels the values that live across the walk compete with them; as a function of its
 // own the walk keeps next to nothing in vector registers across a step, and nothing of the compiler's may ever sit at
@@ -760,9 +802,10 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
             if (waveSlot == 0u && laneId() == 0u) stopWords[slot] = 0u;
             __syncthreads();
             result = more ? nextBase : rangeEnd;
-            if (around) {
+            if (around && !BOTH) {
                 // Logs this full at the end of the higher columns leave the lower ones no room (a call must be able to add
                 // the records of three tiles to what it finds): for the caller the walk stopped in its higher columns.
+                // (BOTH, the tile kernels: their caller empties the logs whatever the order of the columns.)
                 result = colBegin;
                 lowerColumns = false;
                 keepCounts = false;
@@ -810,7 +853,7 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
 // rows: rowHalf a = rows 32a .. 32a+31, whose fragments are the 32 KB block rowFragmentBlock (in 32-cell blocks), whose
 // records go to the lanes' logs of accumulator a (recordCount[a]).  The walk may stop at any tile boundary, where one tile
 // is still untested: a log needs room for two tiles (32 records).
-template <bool IDENTITY>
+template <bool IDENTITY, bool BOTH = false>
 __device__ __attribute__((noinline)) uint32_t scanTilesMatrixWide(const void* fragmentsArg, const void* snapArg, uint32_t colBeginArg,
                                                                   uint32_t colEndArg, uint32_t rowFragmentBlockArg, float rowDotArg,
                                                                   uint32_t rowHalfArg, Entry* waveLogArg, uint32_t logCapacityArg,
@@ -947,9 +990,10 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixWide(const void* fr
             if (waveSlot == 0u && laneId() == 0u) stopWords[slot] = 0u;
             __syncthreads();
             result = more ? nextBase : rangeEnd;
-            if (around) {
+            if (around && !BOTH) {
                 // Logs this full at the end of the higher columns leave the lower ones no room (a call must be able to add
                 // the records of three tiles to what it finds): for the caller the walk stopped in its higher columns.
+                // (BOTH, the tile kernels: their caller empties the logs whatever the order of the columns.)
                 result = colBegin;
                 lowerColumns = false;
                 keepCounts = false;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One-box sweep of the departure schedule of the matrix scan (EM2_MATRIX_DEPART_US / _WINDOW_US), baseline interleaved:
-#   tools/sweep_depart.sh "period window" ...      (0 0 = no departures; SWEEP_ARGS="--lsh-count 2048" for other bench arguments)
+#   tools/sweep_depart.sh "period window [halves]" ...      (0 0 = no departures; SWEEP_ARGS="--lsh-count 2048" for other bench arguments)
 cd "$(dirname "$0")/.."
 for setting in "$@"; do
   set -- $setting
