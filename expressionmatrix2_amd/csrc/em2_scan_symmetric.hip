@@ -437,7 +437,8 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         // Nobody waits here: a walk STARTS WHERE THE OTHERS ARE and goes around -- from its starting column to the segment's
         // end, then from the segment's begin to its starting column.  Every walk publishes its position now and then in a
         // word of its XCD group (blockIdx & 7: the blocks of a launch are dealt to the XCDs in turn) and of its segment's
-        // parity; a block that takes an item of the same segment reads it.  All walks move at the same pace, so the group
+        // parity -- an atomic maximum, so the word is where the group's HEAD is (em2_scan_symmetric_device.h) -- and a block
+        // that takes an item of the same segment starts there.  All walks move at the same pace, so the group
         // circles through the segment as one stream of tiles that the first to ask fetches over the fabric and the others find
         // in the L2.  The logs of such a walk hold the higher columns in front of the lower ones: the replay takes them in
         // the order of the columns (WalkLogReader), so the lists see the candidates exactly as before.  A walk whose logs fill
