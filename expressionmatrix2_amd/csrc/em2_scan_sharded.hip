@@ -258,7 +258,7 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
                 // order of the columns means nothing -- both sides of every record go to the inbox, which is sorted -- so the
                 // logs are emptied after every call, wherever it stopped.  range = [at, end), then [colBegin, start).
                 for (uint32_t rowHalf = 0; rowHalf < (WIDE ? 2u : 1u); ++rowHalf) {
-                    const uint32_t start = convoyStartColumn(aux, shared, seg, colBegin, commonEnd);
+                    const uint32_t start = convoyStartColumn(aux, shared, seg, colBegin, commonEnd, ~0u);      // (no stops are counted here)
                     uint32_t at = start, end = commonEnd;
                     bool around = start == colBegin;            // (nothing left below the starting column)
                     for (;;) {

@@ -446,7 +446,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         // and starts again at the segment's begin, as a walk without convoy (in the lower columns a stop is harmless: those
         // records are in order, they are replayed and removed).  Never at the bench's sizes (0 of 120 337 items stop at all).
         auto convoyStart = [&]() -> uint32_t {
-            return PINNED ? convoyStartColumn(aux, shared, seg, colBegin, commonEnd) : colBegin;
+            return PINNED ? convoyStartColumn(aux, shared, seg, colBegin, commonEnd, ticket) : colBegin;
         };
         bool failed = false;
         uint32_t start = convoyStart();         // (start == colBegin: a walk as ever)
@@ -493,6 +493,9 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
             }
             const bool stopped = at < rangeEnd;                           // (for its logs; the same in all waves of the block)
             if (TIMED && stopped) phaseCycles[7] += 1u;
+            if (stopped && PINNED && threadIdx.x == 0u && aux->convoy == 1u) {
+                __hip_atomic_fetch_add(aux->inboxControl + kConvoyStopsWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (start != colBegin && !lower) {
                 // the logs filled up in the higher columns (see above): once more, from the segment's begin, publishing nothing
                 recordCount[0] = recordCount[1] = 0u;
