@@ -380,7 +380,7 @@ def test_matrix_form_walks_that_go_around(oracle, scan_knobs, n, L, k, thr, kind
     assert_same(pairs, gused, cell, sim, used)
 
 
-@pytest.mark.parametrize("convoy", [4, 5, 6])
+@pytest.mark.parametrize("convoy", [1, 4, 5, 6])
 @pytest.mark.parametrize("L", [1024, 2048])
 def test_walk_that_goes_around_with_nearly_full_logs(oracle, scan_knobs, L, convoy):
     """Found by tools/fuzz_parity.py (seed 41): one cluster, k = 5, threshold 0.5 -- nearly every pair is logged.  A walk whose
