@@ -29,7 +29,8 @@ Also on the JSON line:
                   forms (row shards, other widths): the byte model with `valu_frac`, the fraction of the v_xor/v_bcnt
                   instruction roofline.  `traffic` = fabric bytes per launch from the committed PMC digest of THIS
                   configuration (PROFILE_DIGESTS; a digest of another configuration is refused, there is no fallback).
-    roofline_projection   the signature projection against its 8(d) HBM bytes, with the digest's traffic and the ratio.
+    roofline_projection   the signature projection against its 8(d) HBM bytes, with the digest's traffic and the ratio, and
+                          (gather_view) against the L2 -> L1 line rate its first tier is really bound by.
     cpu_baseline  the CPU oracle's literal findSimilarPairs4 (oracle/, kind "port": the reference itself cannot
                   be built in this image) on the first cells of the same signatures, one thread, ~15-20 s.
 Before timing AND after the last timed step, the GPU result is checked against the oracle bit for bit: the signatures of
@@ -833,6 +834,13 @@ def main():
             result["roofline_projection"]["traffic_source"] = ("profiles/%s (%s, all projection kernels)" % (PROFILE_DIGESTS["fsp4"], TRAFFIC_NOTE)
                                                                if projection_traffic else None)
             result["roofline_projection"]["wasted_traffic_ratio"] = projection_traffic / proj_bytes if projection_traffic else None
+            # What the tiers actually wait for: one 128-byte line of the 16-bit copy per (count, 64-bit word)
+            # through the L2 -> L1 path of a CU, 64 bytes per clock.  A floor of the first tier's design, not of the problem.
+            lines = float(nnz_local) * ((L + 63) // 64)
+            floor_ms = lines * 128.0 / (256 * 64.0 * 2.4e9) * 1e3
+            result["roofline_projection"]["gather_view"] = {
+                "lines_per_launch": lines, "bytes_per_launch": lines * 128.0, "floor_ms": floor_ms, "frac": floor_ms / proj_ms,
+                "note": "the first tier's gathers at 64 B/clk per CU x 256 CUs x 2.4 GHz; kernel_ms includes the later tiers"}
         result["device_state_rank0"] = leg["device_state"]
         if collective_check is not None:
             result["collective_check"] = collective_check
