@@ -727,8 +727,13 @@ projectionScreenItemsKernel(const uint64_t* __restrict__ toc, const CountIn* __r
 // count of the item's cell with eight gathers of a single float in flight -- 4 bytes per count where the word form above reads
 // two 128-byte lines; the eight partial sums are added by a butterfly (the bound's (n + 10) half-ulps cover the order of the
 // additions, as in the sliced kernel's).  (One lane per item walked its cell alone: 33 dependent rounds of gathers per item,
-// 3.3 ms at a million cells; now four.)  A bit that stays undecided sends its word to the exact tier's list, any other goes into
-// the signature (nobody else writes that word: a word is on exactly one of the two lists).
+// 3.3 ms at a million cells; eight lanes per item in list order: 3.0 ms, and 22 GB over the fabric -- every gather a 64-byte
+// sector of a 123 MB table.)  The items are taken SLICE BY SLICE, every XCD its own slices: blockIdx & 7 picks the words w with
+// w & 7 == that (as in the first tier, whose blocks listed them), and for each of their 32-bit slices in turn the group's waves
+// go through the list, 64 items at a time, and take those of the slice -- a slice of the float copy is 128 bytes per gene,
+// 3.84 MB at 30 000 genes: it stays in the XCD's L2 while its items are worked on.  The list is read once per slice of a
+// group (9 MB per reading at a million cells).  A bit that stays undecided sends its word to the exact tier's list, any other
+// goes into the signature (nobody else writes that word: a word is on exactly one of the two lists).
 __global__ void __launch_bounds__(256)
 projectionScreenBitsKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t geneCount,
                            const float* __restrict__ vectors32, const double* __restrict__ vectorSums,
@@ -739,54 +744,75 @@ projectionScreenBitsKernel(const uint64_t* __restrict__ toc, const CountIn* __re
 {
     const uint32_t count = *bitCount;
     const uint64_t* entries = reinterpret_cast<const uint64_t*>(data);
-    const uint32_t sub = threadIdx.x & 7u;
-    const uint32_t groups = gridDim.x * (blockDim.x >> 3);
-    // (every lane of a wave makes the same number of turns: the butterfly below involves the whole wave)
-    const uint32_t turns = (count + groups - 1u) / groups;
-    for (uint32_t turn = 0; turn < turns; ++turn) {
-        const uint32_t item = turn * groups + blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);
-        const bool live = item < count;
-        const uint64_t it = live ? bitList[item] : 0ull;
-        const uint32_t c = uint32_t(it >> 32);
-        const uint32_t bit = uint32_t(it);
-        const float* column = vectors32 + size_t(bit >> 5) * geneCount * 32u + (bit & 31u);
-        const uint64_t jBegin = live ? toc[c] : 0ull;
-        const uint64_t jEnd = live ? toc[c + 1] : 0ull;
-        double a = 0.;
-        uint64_t j = jBegin + sub;
-        for (; j + 56u < jEnd; j += 64u) {            // eight loads in flight per lane, 64 counts of the cell per round
-            double u[8], x[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const uint64_t e = entries[j + 8u * uint32_t(q)];
-                u[q] = double(column[size_t(uint32_t(e)) * 32u]);
-                x[q] = double(__uint_as_float(uint32_t(e >> 32)));
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t sub = lane & 7u, slot = lane >> 3;
+    const uint32_t group = blockIdx.x & 7u;
+    const uint32_t wavesInGroup = (gridDim.x >> 3) * (blockDim.x >> 6);          // (the grid is a multiple of 8 blocks)
+    const uint32_t waveInGroup = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t chunks = (count + 63u) / 64u;
+    for (uint32_t slice = 2u * group; slice < 2u * wordCount; slice += (slice & 1u) ? 15u : 1u) {
+      for (uint32_t chunk = waveInGroup; chunk < chunks; chunk += wavesInGroup) {
+        const uint32_t index = chunk * 64u + lane;
+        const uint64_t mine = index < count ? bitList[index] : 0ull;
+        // the chunk's items of this slice, eight at a time: slot k takes the k-th of those still to do.  (Two of a chunk's 64 on
+        // average: most slots idle -- collecting eight in LDS first changes nothing, 1.95 ms either way: the gathers of single
+        // floats, 2.9e8 sectors per launch, run at the rate of the L2s.)
+        uint64_t todo = __builtin_amdgcn_ballot_w64(index < count && (uint32_t(mine) >> 5) == slice);
+        while (todo != 0ull) {
+            uint64_t rest = todo;
+            uint32_t source = 64u;
+            for (uint32_t q = 0; q <= slot && rest != 0ull; ++q) {
+                source = q == slot ? uint32_t(__builtin_ctzll(rest)) : 64u;
+                rest &= rest - 1ull;
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) a = __fma_rn(x[q], u[q], a);
+            for (int q = 0; q < 8; ++q) todo &= todo - (todo != 0ull ? 1ull : 0ull);
+            const bool live = source < 64u;
+            const uint32_t from = live ? source : 0u;
+            const uint64_t it = (uint64_t(uint32_t(__shfl(int(uint32_t(mine >> 32)), int(from), 64))) << 32) |
+                                uint64_t(uint32_t(__shfl(int(uint32_t(mine)), int(from), 64)));
+            const uint32_t c = uint32_t(it >> 32);
+            const uint32_t bit = uint32_t(it);
+            const float* column = vectors32 + size_t(bit >> 5) * geneCount * 32u + (bit & 31u);
+            const uint64_t jBegin = live ? toc[c] : 0ull;
+            const uint64_t jEnd = live ? toc[c + 1] : 0ull;
+            double a = 0.;
+            uint64_t j = jBegin + sub;
+            for (; j + 56u < jEnd; j += 64u) {            // eight loads in flight per lane, 64 counts of the cell per round
+                double u[8], x[8];
+    #pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint64_t e = entries[j + 8u * uint32_t(q)];
+                    u[q] = double(column[size_t(uint32_t(e)) * 32u]);
+                    x[q] = double(__uint_as_float(uint32_t(e >> 32)));
+                }
+    #pragma unroll
+                for (int q = 0; q < 8; ++q) a = __fma_rn(x[q], u[q], a);
+            }
+            for (; j < jEnd; j += 8u) {
+                const uint64_t e = entries[j];
+                a = __fma_rn(double(__uint_as_float(uint32_t(e >> 32))), double(column[size_t(uint32_t(e)) * 32u]), a);
+            }
+    #pragma unroll
+            for (int d = 1; d < 8; d <<= 1) a += __shfl_xor(a, d, 64);
+            if (!live || sub != 0u) continue;
+            const double s = vectorSums[bit];
+            const double mean = means[c];
+            a += __dmul_rn(-mean, s);
+            const double n = double(jEnd - jBegin);
+            const double factor = (1.01 * 5.9604644775390625e-08 + (n + 10.) * 2.220446049250313e-16) * 1.000001;
+            const double absX = sumAbs[c];
+            const double bound = factor * (fabs(mean) * fabs(s) + absX * vectorMaxAbs[bit]) + absX * 1.5e-45 + 1e-300;
+            const uint32_t word = bit >> 6;
+            if (!(fabs(a) > bound)) {
+                nextList[atomicAdd(nextCount, 1u)] = (uint64_t(c) << 32) | word;
+            } else {
+                const uint64_t mask = 1ull << (63u - (bit & 63u));          // first bit most significant (src/BitSet.hpp:48-62)
+                uint64_t* target = signatures + size_t(c) * wordCount + word;
+                *target = a > 0. ? (*target | mask) : (*target & ~mask);
+            }
         }
-        for (; j < jEnd; j += 8u) {
-            const uint64_t e = entries[j];
-            a = __fma_rn(double(__uint_as_float(uint32_t(e >> 32))), double(column[size_t(uint32_t(e)) * 32u]), a);
-        }
-#pragma unroll
-        for (int d = 1; d < 8; d <<= 1) a += __shfl_xor(a, d, 64);
-        if (!live || sub != 0u) continue;
-        const double s = vectorSums[bit];
-        const double mean = means[c];
-        a += __dmul_rn(-mean, s);
-        const double n = double(jEnd - jBegin);
-        const double factor = (1.01 * 5.9604644775390625e-08 + (n + 10.) * 2.220446049250313e-16) * 1.000001;
-        const double absX = sumAbs[c];
-        const double bound = factor * (fabs(mean) * fabs(s) + absX * vectorMaxAbs[bit]) + absX * 1.5e-45 + 1e-300;
-        const uint32_t word = bit >> 6;
-        if (!(fabs(a) > bound)) {
-            nextList[atomicAdd(nextCount, 1u)] = (uint64_t(c) << 32) | word;
-        } else {
-            const uint64_t mask = 1ull << (63u - (bit & 63u));          // first bit most significant (src/BitSet.hpp:48-62)
-            uint64_t* target = signatures + size_t(c) * wordCount + word;
-            *target = a > 0. ? (*target | mask) : (*target & ~mask);
-        }
+      }
     }
 }
 
