@@ -92,6 +92,8 @@ def prologue(s, o, tile, tests):
     if tile:
         s.emit("v_lshl_add_u32 %s, %s, 4, %s" % (vreg(TILE_ADDR), vreg(LANE), o["tileBase"]))          # + 16 * lane
     if tests:
+        if CMPX:
+            s.emit("s_mov_b64 %s, exec" % o["save"])
         s.emit("v_and_b32 %s, 31, %s" % (vreg(STATE_ADDR), vreg(LANE)))
         s.emit("v_lshl_add_u32 %s, %s, 2, %s" % (vreg(STATE_ADDR), vreg(STATE_ADDR), o["stateBase"]))     # + 4 * (lane & 31)
         s.emit("v_lshrrev_b32 %s, 5, %s" % (vreg(BOUND_ADDR), vreg(LANE)))
@@ -114,12 +116,18 @@ def tests_of(s, o, q, j, k, prev0, prev1):
     if not TILE_BOUND or k == 0:
         s.emit("v_min_f32 %s, %s, %s" % (vreg(THR0), vreg(ROW_BOUND0), vreg(bound)))
         s.emit("v_min_f32 %s, %s, %s" % (vreg(THR1), vreg(ROW_BOUND1), vreg(bound)))
+    if CMPX:
+        masked_record(s, o, k, 0, THR0, prev0, True)
+        masked_record(s, o, k, 1, THR1, prev1, False)
+        return
     s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass0_%d" % (k & 1)], vreg(THR0), vreg(prev0 + k)))
     s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass1_%d" % (k & 1)], vreg(THR1), vreg(prev1 + k)))
 
 
 def shift_in(s, o, k):
     """Scalar half: a register whose test passed in some lane goes through its stub (out of line, behind the body)."""
+    if CMPX:
+        return
     for a in range(2):
         s.emit("s_cmp_lg_u64 %s, 0" % o["pass%d_%d" % (a, k & 1)])
         s.emit("s_cbranch_scc1 L_stub_%d_%d_%%=" % (k, a))
@@ -130,6 +138,10 @@ def shift_in(s, o, k):
 def stubs(s, o, prev0, prev1):
     """The lanes in which register k of accumulator a passed append one record to their log in global memory:
     {tile's first column | 2k + a, dot as it stands in the accumulator}."""
+    if CMPX:
+        s.emit("v_mov_b32 %s, %s" % (o["count"], vreg(OFFSET)))
+        s.emit("v_mov_b32 %s, %s" % (o["count1"], vreg(OFFSET + 1)))
+        return
     s.emit("s_branch L_end_%=")
     for k, a in s.stubs:
         acc = (prev0, prev1)[a] + k
@@ -183,7 +195,10 @@ def place(s, o, k, what, prev0, prev1, slot, carry=False):
             if j == 1 and q < 3 and not TILE_BOUND:
                 s.lds("bounds%d" % (q + 1), "ds_read_b128 %s, %s offset:%d"
                       % (vreg(BOUNDS + 4 * ((q + 1) & 1), 4), vreg(BOUND_ADDR), 32 * (q + 1)))
-        if letter == "C":
+        if letter == "C" and CMPX:
+            masked_record(s, o, k, 0, THR0, prev0, True)
+            masked_record(s, o, k, 1, THR1, prev1, False)
+        elif letter == "C":
             s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass0_%d" % (k & 1)], vreg(THR0), vreg(prev0 + k)))
             s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass1_%d" % (k & 1)], vreg(THR1), vreg(prev1 + k)))
 
@@ -196,6 +211,20 @@ CARRY = os.environ.get("EM2_GEN_CARRY", "1") != "0"
 # EM2_GEN_TILE_BOUND=1: ONE column bound per tile (the loosest of its 32 columns, a float at boundBase): the two v_min of a
 # step's first k-step serve all 32 results, the per-result work is the v_cmp alone.
 TILE_BOUND = os.environ.get("EM2_GEN_TILE_BOUND", "0") == "1"
+# EM2_GEN_CMPX=1: no branches -- the compare writes EXEC, the record is formed and stored under that mask (nothing happens where
+# nothing passed), EXEC is restored; five more instructions per result, all of them masked off almost always (DESIGN 3.1.6:
+# 4.9 PFLOP/s at every record rate against 6.6 at the scan's -- instructions under an empty EXEC are not free, the stores least).
+CMPX = os.environ.get("EM2_GEN_CMPX", "0") == "1"
+
+
+def masked_record(s, o, k, a, thr, acc, first):
+    """The branch-free test of register k of accumulator a: EXEC = the lanes that pass, their record stored, EXEC restored."""
+    s.emit("v_cmpx_le_f32_e32 vcc, %s, %s" % (vreg(thr), vreg(acc + k)))
+    s.emit("v_or_b32_e64 %s, %s, %d" % (vreg(RECORD), o["tileCode"], 2 * k + a))
+    s.emit("v_mov_b32 %s, %s" % (vreg(RECORD + 1), vreg(acc + k)))
+    s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET + a), vreg(RECORD, 2), o["logBase"]))
+    s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET + a), vreg(OFFSET + a)))
+    s.emit("s_mov_b64 exec, %s" % o["save"])
 
 
 def step(cur, prev, tests, operands):
