@@ -422,7 +422,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         // (asleep) for at most one period; order and content of everything it does are unchanged.
         auto depart = [&]() {
             if (threadIdx.x == 0u) {
-                const uint32_t period = aux->departTicks, window = aux->departWindow & 0x7fffffffu;
+                const uint32_t period = aux->departTicks, window = aux->departWindow;
                 for (uint32_t spins = 0; spins < (1u << 16); ++spins) {
                     if (uint32_t(__builtin_amdgcn_s_memrealtime() % period) < window) break;
                     __builtin_amdgcn_s_sleep(8);
@@ -558,7 +558,6 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
             if (at >= rangeEnd) {
                 if (!WIDE || rowHalf == 1u || colBegin >= commonEnd) break;
                 rowHalf = 1u;
-                if (aux->departTicks != 0u && (aux->departWindow >> 31) != 0u) depart();
                 start = convoyStart();
                 at = start;
                 rangeEnd = commonEnd;
@@ -1089,7 +1088,6 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         // (EM2_MATRIX_DEPART_US / EM2_MATRIX_DEPART_WINDOW_US: period and window of the walks' departures, microseconds)
         matrixArgs.departTicks = uint32_t(envNumber("EM2_MATRIX_DEPART_US", 0) * 100u);
         matrixArgs.departWindow = uint32_t(envNumber("EM2_MATRIX_DEPART_WINDOW_US", envNumber("EM2_MATRIX_DEPART_US", 0) / 4u) * 100u);
-        if (envNumber("EM2_MATRIX_DEPART_HALVES", 0) != 0) matrixArgs.departWindow |= 0x80000000u;
         // (EM2_MATRIX_CONVOY: 0 = every walk from its segment's first column, 1 = the walks of an XCD go around together,
         // n >= 2: every walk starts 64 (n - 1) columns into its segment -- the tests' way to the same code)
         matrixArgs.convoy = uint32_t(envNumber("EM2_MATRIX_CONVOY", 1));
