@@ -32,3 +32,19 @@ def test_compiled_walk_leaves_the_steps_registers_alone(tmp_path, unit):
                            text=True)
     assert check.returncode == 0, check.stdout[-3000:]
     assert "scanTilesMatrixPinned" in check.stdout
+
+
+@pytest.mark.parametrize("knob", ["EM2_GEN_TILE_BOUND", "EM2_GEN_CMPX"])
+def test_experiment_forms_of_the_step_still_assemble(tmp_path, knob):
+    """The generator's experiment knobs (measured, not used) write steps the assembler accepts: the
+    microbenchmark tools/ubench_matrix_step.hip compiles against each of them."""
+    env = dict(os.environ)
+    env[knob] = "1"
+    text = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_matrix_step_asm.py")], capture_output=True, text=True,
+                          check=True, env=env).stdout
+    assert text != open(os.path.join(CSRC, "em2_matrix_step_asm.h")).read()
+    (tmp_path / "em2_matrix_step_asm.h").write_text(text)
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-w", "--cuda-device-only", "-c", "-I", str(tmp_path), "-o",
+           str(tmp_path / "ubench.o"), os.path.join(ROOT, "tools", "ubench_matrix_step.hip")]
+    done = subprocess.run(cmd, capture_output=True, text=True)
+    assert done.returncode == 0, done.stderr[-3000:]
