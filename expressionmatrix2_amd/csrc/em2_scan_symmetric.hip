@@ -971,13 +971,16 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     table[segments] = uint32_t(tickets);
     // The matrix kernel has segments of its own, and longer ones: every item starts by loading 32 KB of row fragments per
     // wave and priming the tile pipeline, and its columns need not stay in one L2 (kernel ms at 1M cells with 4096 /
-    // 8192 / 16384 / 32768 / 131072 columns per segment: 289 / 278 / 273 / 270 / 274; 2048: 335).  The test knobs apply
-    // to both launches.
+    // 8192 / 16384 / 32768 / 131072 columns per segment: 289 / 278 / 273 / 270 / 274; 2048: 335).  With the convoy, which
+    // keeps the L2s out of the question (1M cells, same box, 16384 / 20480 / 24576 / 28672 / 32768 / 49152 columns: 185.4 /
+    // 184.3 / 184.1 / 183.9 ms, and 178.0 / - / 176.8 / - / 177.5 / 180.3 on another; 2048 bits: 8192 / 16384 / 32768:
+    // 396.1 / 394.2 / 399.2), the 1024-bit form takes 24576.  The test knobs apply to both launches.
     uint64_t segmentsMatrix = segments;
     uint32_t cpsMatrix = cps;
     if (matrix) {
         uint64_t defaultColumns = cellCount / 24u;              // small problems keep enough items to fill the machine
-        defaultColumns = defaultColumns < 4096 ? 4096 : (defaultColumns > 16384 ? 16384 : defaultColumns);
+        const uint64_t longest = wide ? 16384u : 24576u;
+        defaultColumns = defaultColumns < 4096 ? 4096 : (defaultColumns > longest ? longest : defaultColumns);
         uint64_t minColumns = envNumber("EM2_MIN_SEGMENT_COLUMNS", defaultColumns);
         if (minColumns < 1) minColumns = 1;
         segmentsMatrix = cellCount / minColumns;
