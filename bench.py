@@ -279,6 +279,61 @@ def parity_gate(pipe, oracle, synthetic, sig_host, toc, data, vectors_host, chec
     return sample, rows_checked
 
 
+def rows_form_block(args, capi, pipe, oracle, sig_host, torch, threads, shards=((2, 1), (4, 1), (8, 3)), repeats=3, oracle_rows=1024):
+    """North_star's partitioning across GPUs, measured on ONE: this GPU plays rank r of P -- the rank's contiguous rows against
+    all columns (em2_dev_find_similar_pairs4 with a row range: the rows form on the matrix cores) on the signatures of the
+    headline run.  EVERY row of each shard must equal the headline's result (the symmetric form, which the gates held against
+    the oracle), and oracle_rows rows per shard are compared with the oracle directly.  Scan only: a rank's projection is 1/P of
+    the headline's, its all_gather is not played."""
+    C, L, k, thr = pipe.cell_count, pipe.lsh_count, pipe.k, pipe.thr
+    stream = torch.cuda.current_stream().cuda_stream
+    out = []
+    for world, rank in shards:
+        per = -(-C // world)
+        begin, end = min(C, rank * per), min(C, (rank + 1) * per)
+        rows = end - begin
+        ws_bytes = capi.dev_find_similar_pairs4_workspace(C, rows, L, k)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pipe.device)
+        pairs = torch.zeros((rows, k, 2), dtype=torch.int32, device=pipe.device)
+        used = torch.zeros(rows, dtype=torch.int32, device=pipe.device)
+        wall, kernel = [], []
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            capi.dev_find_similar_pairs4(pipe.full_sig.data_ptr(), C, begin, end, L, k, thr, pairs.data_ptr(), used.data_ptr(),
+                                         ws.data_ptr(), ws_bytes, stream)
+            torch.cuda.synchronize()
+            wall.append((time.perf_counter() - t0) * 1e3)
+            kernel.append(capi.dev_find_similar_pairs4_last_launch()["matrix_kernel_ms"])
+        capi.dev_find_similar_pairs4_status(ws.data_ptr(), rows, k, stream)
+        launch = capi.dev_find_similar_pairs4_last_launch()
+        same = bool(torch.equal(pairs, pipe.pairs[begin:end]) and torch.equal(used, pipe.used[begin:end]))
+        if not same:
+            raise SystemExit("PARITY FAILURE: rows form, rank %d of %d: rows differ from the symmetric form's" % (rank, world))
+        ranges = sample_ranges([(begin, end)], oracle_rows)
+        host_pairs = pairs.cpu().numpy().view(np.uint32)
+        host_used = used.cpu().numpy().view(np.uint32)
+        checked = 0
+        for b, e, cell, sim, oused in oracle_rows_parallel(oracle, sig_host, L, k, thr, ranges, threads):
+            lo, hi = b - begin, e - begin
+            if not (np.array_equal(host_used[lo:hi], oused) and np.array_equal(host_pairs[lo:hi, :, 0], cell) and
+                    np.array_equal(host_pairs[lo:hi, :, 1], sim.view(np.uint32))):
+                raise SystemExit("PARITY FAILURE: rows form, rank %d of %d: rows %d..%d differ from the oracle" % (rank, world, b, e))
+            checked += e - b
+        flops = launch["matrix_pairs"] * 2.0 * (2048.0 if L > 1024 else 1024.0)
+        best = min(kernel)
+        out.append({"ranks": world, "rank_played": rank, "rows": [begin, end], "scan_form": launch["form"],
+                    "scan_ms": min(wall), "kernel_ms": best, "clock_ghz": launch["matrix_clock_ghz"] or None,
+                    "ordered_pairs_per_s": rows * float(C) / (min(wall) * 1e-3),
+                    "frac_of_fp4_peak": flops / (best * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS if best > 0 else None,
+                    "rows_equal_to_the_symmetric_result": rows, "rows_against_the_oracle": checked})
+        del ws, pairs, used
+        torch.cuda.empty_cache()
+    return {"what": "one GPU playing rank r of P of the row-shard form (SURVEY 8e: contiguous rows x all columns), scan only; "
+                    "a real node adds the rank's projection (1/P of the headline's) and one all_gather of the signatures",
+            "shards": out}
+
+
 def small_config(args, capi, sharded, synthetic, oracle, device, torch, cells=100000, genes=20000, steps=10, warmup=2):
     """BASELINE configs[1] on one GPU: ms per step and pairs/s, gated like the headline."""
     L, k, thr = args.lsh_count, args.k, args.threshold
@@ -673,10 +728,11 @@ def main():
         # The scan of THIS rank handles rows*(C-1)/2 unordered pairs' worth of the job (its share of N(N-1)/2).  In the
         # ordered form that is rows*C comparisons by the kernel; in the symmetric form (1 GPU, all rows in one launch)
         # every unordered pair is evaluated once.  The library reports what it ran.
-        matrix = launch["form"] == 3                  # the symmetric form with its triangle part on the matrix cores
+        matrix = launch["form"] in (3, 4)             # 3: the symmetric form with its triangle part on the matrix cores
+        rows_matrix = launch["form"] == 4             # 4: the rows of the shard x all columns on the matrix cores
         symmetric = launch["form"] in (1, 3)
         sharded_symmetric = launch["form"] == 2
-        kernel_ms = launch["scan_kernel_ms"] if symmetric and launch["scan_kernel_ms"] > 0 else scan_ms
+        kernel_ms = launch["scan_kernel_ms"] if (symmetric or rows_matrix) and launch["scan_kernel_ms"] > 0 else scan_ms
         launch_pairs = total_pairs / world if sharded_symmetric else pipe.rows * (C - 1) / 2.0
         algorithmic_bytes = launch_pairs * 16.0 * W
         achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
@@ -702,7 +758,8 @@ def main():
                             % (C, G, args.density * G, L, k, thr, world),
                 "cells": C, "genes": G, "lsh_count": L, "k": k, "similarity_threshold": thr,
                 "rows_per_gpu": pipe.shard, "nnz_rank0": nnz_local,
-                "scan": "sharded-symmetric" if sharded_symmetric else "symmetric-matrix" if matrix else "symmetric" if symmetric else "row-shards",
+                "scan": ("sharded-symmetric" if sharded_symmetric else "row-shards-matrix" if rows_matrix else "symmetric-matrix" if matrix
+                         else "symmetric" if symmetric else "row-shards"),
             },
             "phases_ms_rank0": {"projection": proj_ms, "scan": scan_ms},
             "roofline": None,
@@ -759,7 +816,11 @@ def main():
                 "kernel": "fsp4ScanMatrixWideKernel<true>" if L > 1024 else
                           ("fsp4ScanMatrixPinnedKernel<true>" if pinned_walk else "fsp4ScanMatrixKernel<true>"),
                 "kernel_ms": launch["matrix_kernel_ms"],
-                "form": "symmetric, triangle part on the matrix cores: every unordered pair evaluated once as an FP4 +-1 dot "
+                "form": ("row shards on the matrix cores (north_star's partitioning): every row of the rank's contiguous shard walks ALL "
+                         "columns in ascending order as FP4 +-1 dot products (%d - 2 * mismatches, exact in f32), i.e. each unordered "
+                         "pair is evaluated once per side across the node; no inbox, no sort, no second kernel" % int(contraction))
+                        if rows_matrix else
+                        "symmetric, triangle part on the matrix cores: every unordered pair evaluated once as an FP4 +-1 dot "
                         "product (%d - 2 * mismatches, exact in f32); the first cells' full rows and each quad's own 256 columns "
                         "stay on v_xor/v_bcnt; inbox sort + replay follow" % int(contraction),
                 "bound": "mfma",
@@ -939,11 +1000,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra and (C, G) == (1000000, 30000):
         # BASELINE configs[1] (100k cells x 20k genes, 1% nnz, 1024 bit, 1 GPU): a second, small measurement on the same
         # line -- never the headline.  Same pipeline, same gates (sampled rows against the oracle before and after).
+        result["extra"] = {}
+        if not args.no_check:
+            result["extra"]["rows_form_one_gpu_as_rank_r_of_P"] = rows_form_block(args, capi, pipe, oracle, sig_host, torch, gate_threads)
         leg.clear()
         inputs.clear()
         del pipe, vectors
         torch.cuda.empty_cache()
-        result["extra"] = {"configs[1]": small_config(args, capi, sharded, synthetic, oracle, device, torch)}
+        result["extra"]["configs[1]"] = small_config(args, capi, sharded, synthetic, oracle, device, torch)
         # BASELINE configs[3] (bucketed findSimilarPairs5, 2048 bit) and configs[4] (findSimilarPairs4 -> createCellGraph ->
         # label propagation) at their 1-GPU sizes, a few steps each: the secondary lines of --workload fsp5 / chain,
         # abridged, so that they are on the line the driver records (never the headline)

@@ -397,9 +397,16 @@ def dev_find_similar_pairs4_form(cell_count, row_count):
     return int(load().em2_dev_find_similar_pairs4_form(cell_count, row_count))
 
 
+def dev_find_similar_pairs4_form_for(cell_count, row_count, lsh_count):
+    """The form a launch of row_count rows against cell_count columns of lsh_count-bit signatures takes: 0 ordered,
+    1 symmetric, 3 symmetric on the matrix cores, 4 rows x all columns on the matrix cores."""
+    return int(load().em2_dev_find_similar_pairs4_form_for(cell_count, row_count, lsh_count))
+
+
 def dev_find_similar_pairs4_last_launch():
     """dict(form, scan_kernel_ms, wave_column_steps, inbox_entries, segments, full_row_cells, matrix_pairs,
-    matrix_kernel_ms) of the last launch; form 0 ordered, 1 symmetric, 2 sharded symmetric, 3 symmetric on the matrix cores."""
+    matrix_kernel_ms) of the last launch; form 0 ordered, 1 symmetric, 2 sharded symmetric, 3 symmetric on the matrix cores,
+    4 rows x all columns on the matrix cores (a shard of the rows, or the fallback of a symmetric scan)."""
     v = np.zeros(9, dtype=np.float64)
     check(load().em2_dev_find_similar_pairs4_last_launch(_ptr(v), 9))
     return {"form": int(v[0]), "scan_kernel_ms": float(v[1]), "wave_column_steps": float(v[2]),

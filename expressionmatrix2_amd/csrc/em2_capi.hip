@@ -364,7 +364,7 @@ int em2_dev_find_similar_pairs4_form_for(uint32_t cellCount, uint32_t rowCount, 
 {
     if (lshCount == 0) return 0;
     const uint32_t padded = em2::paddedDwords(lshCount);
-    if (!em2::fsp4UsesSymmetricScan(cellCount, rowCount, padded)) return 0;
+    if (!em2::fsp4UsesSymmetricScan(cellCount, rowCount, padded)) return em2::fsp4UsesRowsMatrixScan(cellCount, rowCount, padded) ? 4 : 0;
     return em2::fsp4MatrixFormWanted(padded) ? 3 : 1;
 }
 

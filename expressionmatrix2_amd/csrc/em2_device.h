@@ -56,10 +56,13 @@ size_t fsp4ControlBytes(uint32_t rowCount);
 // rows of the problem are in one launch and this workspace is given; 0 when that form would not be used.
 size_t fsp4SymmetricBytes(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw);
 bool fsp4UsesSymmetricScan(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw);
+// Whether a launch of rowCount rows against cellCount columns that is not symmetric takes the rows form on the matrix
+// cores (form 4: every row walks all columns as FP4 +-1 dot products); fsp4SymmetricBytes then sizes its workspace.
+bool fsp4UsesRowsMatrixScan(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw);
 // Whether signatures of this padded width take the matrix-core form of the symmetric scan (EM2_SCAN_MATRIX included).
 bool fsp4MatrixFormWanted(uint32_t paddedDw);
 struct Fsp4LaunchInfo {
-    int form;                 // 0 ordered rows x columns, 1 symmetric, 2 sharded symmetric, 3 symmetric on the matrix cores
+    int form;                 // 0 ordered rows x columns, 1 symmetric, 2 sharded symmetric, 3 symmetric on the matrix cores, 4 rows x columns on the matrix cores
     double scanKernelMs;      // duration of the scan kernel proper when the launcher measured it (symmetric form), else -1
     double waveColumnSteps;   // (64-row wave, column) steps executed: x 64 lanes x 2*W32 = v_xor/v_bcnt lane-ops
     double inboxEntries;      // symmetric form: entries (incl. chunk padding) sorted and replayed

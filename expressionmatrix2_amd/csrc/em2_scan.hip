@@ -416,7 +416,7 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     args.departTicks = 0;
     args.departWindow = 0;
     args.convoy = 0;
-    args.convoyPad = 0;
+    args.rowFragmentBase = 0;
     args.rowState = nullptr;
     args.segmentsDone = nullptr;
     args.control = nullptr;
@@ -466,7 +466,19 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
                                                       size_t(wavesPerBlock) * bytesPerWave, control, symmetricWs, stream, &done);
         if (es != hipSuccess) return es;
         if (done) return hipSuccess;
-        // inbox overflow: fall through to the ordered scan, which starts from scratch
+        // Inbox overflow: every row scans all columns itself, from scratch -- on the matrix cores where the signatures have
+        // a matrix form (the symmetric workspace holds everything that launch needs), with the ordered scan below otherwise.
+        const hipError_t er = launchFsp4ScanRowsMatrix(args, paddedDw, identity, wavesPerBlock, size_t(wavesPerBlock) * bytesPerWave,
+                                                       control, symmetricWs, true, stream, &done);
+        if (er != hipSuccess) return er;
+        if (done) return hipSuccess;
+    } else if (control && symmetricWs && rowsMatrixEligible(cellCount, rows, paddedDw)) {
+        // a shard of the rows (north_star's partitioning across GPUs) against all columns, on the matrix cores
+        bool done = false;
+        const hipError_t er = launchFsp4ScanRowsMatrix(args, paddedDw, identity, wavesPerBlock, size_t(wavesPerBlock) * bytesPerWave,
+                                                       control, symmetricWs, false, stream, &done);
+        if (er != hipSuccess) return er;
+        if (done) return hipSuccess;
     }
 
     lastLaunchInfo.form = 0;

@@ -64,7 +64,9 @@ struct Fsp4Args {
     uint32_t departWindow;      // (see departTicks)
     uint32_t convoy;            // matrix form: 0 = every walk starts at its segment's first column; 1 = a walk joins the walks of its XCD
                                 // where they are and wraps around (scanMatrixBody); n >= 2 (tests): every walk starts 64 (n - 1) columns in
-    uint32_t convoyPad;
+    uint32_t rowFragmentBase;   // matrix form: the fragments of list / state slot 0's rows start this many 32-cell blocks into `fragments`
+                                // (0 where the rows are cells of the column array itself; the rows form with an unaligned
+                                // rowBegin expands its rows once more behind the columns' fragments)
     uint32_t pad2;              // diagnostic build only (EM2_DIAG_WORD below): the EM2_MATRIX_DIAG bits; 0 in the product
 };
 
@@ -354,6 +356,9 @@ extern thread_local Fsp4LaunchInfo lastLaunchInfo;
 bool symmetricEligible(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw);
 hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identity, uint32_t wavesPerBlock, size_t lds,
                                    void* control, void* symmetricWs, hipStream_t stream, bool* done);
+bool rowsMatrixEligible(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw);
+hipError_t launchFsp4ScanRowsMatrix(Fsp4Args args, uint32_t paddedDw, bool identity, uint32_t wavesPerBlock, size_t lds,
+                                    void* control, void* workspace, bool symmetricWorkspace, hipStream_t stream, bool* done);
 hipError_t runFsp4ShardedEmulation(const uint32_t* sig32, uint32_t paddedDw, uint32_t cellCount, uint32_t k,
                                    const DeviceTables& t, PairOut* outPairs, uint32_t* outUsed, uint32_t world,
                                    hipStream_t stream, bool* done);

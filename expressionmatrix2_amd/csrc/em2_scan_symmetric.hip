@@ -377,11 +377,13 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         const uint32_t block = quadBlock + wave;
         const bool idle = block >= (fullRows ? aux->localBlockBase + aux->fullRowBlocks : aux->rowBlocks);      // a short last quad
         const uint32_t listBlock = idle ? aux->rowBlocks - 1u : block;
-        const uint32_t quadRowBase = (quadBlock * aux->rowBlockStride + aux->rowBlockOffset) * 64u;
-        const uint32_t rowBase = (block * aux->rowBlockStride + aux->rowBlockOffset) * 64u;
-        const uint32_t rowFragmentBlock = 2u * (listBlock * aux->rowBlockStride + aux->rowBlockOffset);
+        // (rowBegin / rowFragmentBase: 0 everywhere but in the rows form -- launchFsp4ScanRowsMatrix -- whose slots are the 64-cell
+        // blocks of [rowBegin, rowEnd) and whose row fragments may be a copy behind the columns' fragments)
+        const uint32_t quadRowBase = aux->rowBegin + (quadBlock * aux->rowBlockStride + aux->rowBlockOffset) * 64u;
+        const uint32_t rowBase = aux->rowBegin + (block * aux->rowBlockStride + aux->rowBlockOffset) * 64u;
+        const uint32_t rowFragmentBlock = aux->rowFragmentBase + 2u * (listBlock * aux->rowBlockStride + aux->rowBlockOffset);
         const uint32_t row = rowBase + lane;
-        const bool rowValid = !idle && row < aux->cellCount;
+        const bool rowValid = !idle && row < aux->rowEnd;
         const uint32_t twoK = 2u * aux->k;
         const uint32_t minLogCapacity = PINNED ? kMatrixLogMargin : 64u;
         uint32_t logCapacity = aux->logCapacity < minLogCapacity ? minLogCapacity : aux->logCapacity;
@@ -805,7 +807,7 @@ bool symmetricEligible(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
     if (rowCount != cellCount || cellCount < 128u || cellCount > (1u << 25)) return false;
     const char* v = getenv("EM2_SCAN_MODE");
     if (v && v[0] == 't') return true;
-    if (v && (v[0] == 's' || v[0] == 'p')) return false;
+    if (v && (v[0] == 's' || v[0] == 'p' || v[0] == 'r')) return false;
     // 1024-bit signatures take the matrix-core form, which wins much earlier (scan ms ordered / symmetric-matrix:
     // 30k cells 2.5 / 2.4, 60k 8.2 / 4.2, 100k 20.1 / 7.5)
     const bool matrix = matrixFormWanted(paddedDw) || matrixWideWanted(paddedDw);
@@ -862,10 +864,56 @@ bool fsp4UsesSymmetricScan(uint32_t cellCount, uint32_t rowCount, uint32_t padde
     return symmetricEligible(cellCount, rowCount, paddedDw);
 }
 
+// ---- the rows form on the matrix cores: rows [rowBegin, rowEnd) x all columns (launchFsp4ScanRowsMatrix) ----
+// The partitioning SURVEY 8(e) prescribes for several GPUs (a rank's contiguous rows against every column, which is
+// exactly the per-cell contract of src/ExpressionMatrixLsh.cpp:200-285) and what a symmetric scan whose inbox
+// overflowed falls back on.  From kRowsMatrixMinPairs (row, column) pairs on; EM2_SCAN_MODE=rows takes it for every
+// launch it can serve (tests), persistent / simple / triangle never.
+constexpr uint64_t kRowsMatrixMinPairs = 1ull << 31;
+
+bool rowsMatrixEligible(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
+{
+    if (!(matrixFormWanted(paddedDw) || matrixWideWanted(paddedDw))) return false;
+    if (cellCount < 64u || rowCount == 0u) return false;
+    const char* v = getenv("EM2_SCAN_MODE");
+    if (v && v[0] == 'r') return true;
+    if (v && (v[0] == 's' || v[0] == 'p' || v[0] == 't' || v[0] == 'v')) return false;
+    return uint64_t(rowCount) * uint64_t(cellCount) >= kRowsMatrixMinPairs;
+}
+
+struct RowsMatrixLayout {
+    size_t snap, table, control, fragments, rowFragments, widened, total;
+};
+
+// (rows that are not all cells get room for a copy of their fragments: a rowBegin that is no multiple of 32 cannot
+// address the columns' array in 32-cell blocks)
+static RowsMatrixLayout rowsMatrixLayout(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
+{
+    RowsMatrixLayout l;
+    const size_t bytesPerCell = matrixWideWanted(paddedDw) ? 1024u : 512u;
+    size_t at = 0;
+    l.snap = at;      at += align256(size_t(cellCount) * 4u);
+    l.table = at;     at += align256(kTableWords * 4u);
+    l.control = at;   at += 256u;
+    l.fragments = at; at += size_t((cellCount + 63u) / 64u) * 64u * bytesPerCell;
+    l.rowFragments = at;
+    if (rowCount < cellCount) at += size_t((rowCount + 63u) / 64u) * 64u * bytesPerCell;
+    l.widened = at;
+    if (paddedDw < 32u && matrixFormWanted(paddedDw)) at += align256(size_t(cellCount) * 128u);
+    l.total = at;
+    return l;
+}
+
+bool fsp4UsesRowsMatrixScan(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
+{
+    return !symmetricEligible(cellCount, rowCount, paddedDw) && rowsMatrixEligible(cellCount, rowCount, paddedDw);
+}
+
 size_t fsp4SymmetricBytes(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
 {
-    if (!symmetricEligible(cellCount, rowCount, paddedDw)) return 0;
-    return symmetricLayout(cellCount, paddedDw).total;
+    if (symmetricEligible(cellCount, rowCount, paddedDw)) return symmetricLayout(cellCount, paddedDw).total;
+    if (rowsMatrixEligible(cellCount, rowCount, paddedDw)) return rowsMatrixLayout(cellCount, rowCount, paddedDw).total;
+    return 0;
 }
 
 // Resident waves of a persistent-style launch of `kernel` (min(occupancy, 4 waves per SIMD) x CUs).
@@ -1217,6 +1265,204 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
                     double(cycles[1]) / waves, double(cycles[2]) / waves);
         }
     }
+    *done = true;
+    return hipSuccess;
+}
+
+
+// The rows form on the matrix cores.  Every 64-row block of [rowBegin, rowEnd) is a full-row block of scanMatrixBody: its
+// quad walks ALL columns of every segment in ascending order (speculatively against the cut-offs its rows published at
+// the previous hand-off, then replayed in column order through the exact state machine -- the same walk, logs and replay
+// as the triangle's), the self pair is dropped at the replay (acceptColumn), nothing is deferred: no inbox, no sort, no
+// second kernel; the rows finish themselves at the last segment.  The column cut-offs the steps test against are all -1
+// ("never"), so only the row side of a pair can pass.  ws: the rows layout, or -- symmetricWorkspace, the fallback of a
+// symmetric scan whose inbox overflowed -- the symmetric layout, whose areas serve as well.
+// *done = false: this launch cannot take the form (k too large for four waves per block, no room in the LDS).
+hipError_t launchFsp4ScanRowsMatrix(Fsp4Args args, uint32_t paddedDw, bool identity, uint32_t wavesPerBlock, size_t lds,
+                                    void* control, void* ws_, bool symmetricWorkspace, hipStream_t stream, bool* done)
+{
+    *done = false;
+    const uint32_t cellCount = args.cellCount;
+    const uint32_t rowBlocks = args.rowBlocks;
+    const uint32_t rows = args.rowEnd - args.rowBegin;
+    const bool wide = matrixWideWanted(paddedDw);
+    if (!(matrixFormWanted(paddedDw) || wide) || wavesPerBlock != 4u ||
+        ((lds + 15u) & ~size_t(15)) + scanMatrixLdsBytes(args.k) > 150u * 1024u) return hipSuccess;
+    char* ws = static_cast<char*>(ws_);
+    char *snapArea, *tableArea, *controlArea, *fragmentArea, *rowFragmentArea, *widenedArea;
+    if (symmetricWorkspace) {
+        const SymmetricLayout l = symmetricLayout(cellCount, paddedDw);
+        snapArea = ws + l.snap; tableArea = ws + l.tableMatrix; controlArea = ws + l.control;
+        fragmentArea = ws + l.fragments; rowFragmentArea = nullptr; widenedArea = ws + l.widened;
+        if (args.rowBegin != 0u) return hipErrorInvalidValue;
+    } else {
+        const RowsMatrixLayout l = rowsMatrixLayout(cellCount, rows, paddedDw);
+        snapArea = ws + l.snap; tableArea = ws + l.table; controlArea = ws + l.control;
+        fragmentArea = ws + l.fragments; rowFragmentArea = rows < cellCount ? ws + l.rowFragments : nullptr; widenedArea = ws + l.widened;
+    }
+    const void* matrixKernel = scanMatrixKernelFor(identity, wide);
+    const size_t matrixLdsOffset = (lds + 15u) & ~size_t(15);
+    const size_t matrixLds = matrixLdsOffset + scanMatrixLdsBytes(args.k);
+    int device = 0, cuCount = 0, blocksPerCu = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cuCount, hipDeviceAttributeMultiprocessorCount, device);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(matrixKernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(matrixLds));
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCu, matrixKernel, 256, matrixLds);
+    if (e != hipSuccess) return e;
+    blocksPerCu = blocksPerCu < 1 ? 1 : (blocksPerCu > 2 ? 2 : blocksPerCu);
+    if (const char* v = getenv("EM2_BLOCKS_PER_CU")) {
+        if (atoi(v) >= 1 && atoi(v) < blocksPerCu) blocksPerCu = atoi(v);
+    }
+    uint64_t blocksWanted = uint64_t(cuCount) * uint64_t(blocksPerCu);
+    if (blocksWanted * 4u > maxResidentWaves()) blocksWanted = maxResidentWaves() / 4u;      // the logs are sized for that
+
+    // Segments as in the symmetric launch (24 576 / 16 384 columns at large sizes); a launch of few rows takes shorter
+    // ones, down to 2048 columns, until there are some four items per resident block.
+    const uint32_t quads = (rowBlocks + 3u) / 4u;
+    uint64_t defaultColumns = cellCount / 24u;
+    const uint64_t longest = wide ? 16384u : 24576u;
+    defaultColumns = defaultColumns < 4096 ? 4096 : (defaultColumns > longest ? longest : defaultColumns);
+    {
+        const uint64_t segmentsForItems = (4u * blocksWanted + quads - 1u) / quads;
+        uint64_t columnsForItems = cellCount / (segmentsForItems ? segmentsForItems : 1u);
+        if (columnsForItems < 2048) columnsForItems = 2048;
+        if (columnsForItems < defaultColumns) defaultColumns = columnsForItems;
+    }
+    uint64_t minColumns = envNumber("EM2_MIN_SEGMENT_COLUMNS", defaultColumns);
+    if (minColumns < 1) minColumns = 1;
+    uint64_t segments = cellCount / minColumns;
+    if (segments > kMatrixMaxSegments) segments = kMatrixMaxSegments;
+    const uint64_t forcedSegments = envNumber("EM2_SEGMENTS", 0);
+    if (forcedSegments >= 1 && forcedSegments <= kMatrixMaxSegments) segments = forcedSegments;
+    if (segments < 1) segments = 1;
+    uint32_t cps = uint32_t((uint64_t(cellCount) + segments - 1u) / segments);
+    cps = (cps + 255u) & ~255u;
+    segments = (uint64_t(cellCount) + cps - 1u) / cps;
+    const uint64_t tickets = segments * quads;
+    if (tickets >= 0xffffffffull) return hipErrorInvalidValue;
+    uint32_t table[kTableWords];
+    for (uint32_t sIdx = 0; sIdx < segments; ++sIdx) {
+        table[sIdx] = sIdx * quads;
+        table[segments + 1u + sIdx] = rowBlocks;        // (no triangle quads)
+    }
+    table[segments] = uint32_t(tickets);
+    if (blocksWanted > tickets) blocksWanted = tickets;
+
+    char* c = static_cast<char*>(control);
+    const size_t stateBytes = align256(size_t(rowBlocks) * 64u * 8u);
+    const size_t doneBytes = align256(size_t(rowBlocks) * 4u);
+    args.rowState = reinterpret_cast<uint32_t*>(c);
+    args.segmentsDone = reinterpret_cast<uint32_t*>(c + stateBytes);
+    args.control = reinterpret_cast<uint32_t*>(c + stateBytes + doneBytes);
+    args.logs = reinterpret_cast<Entry*>(c + stateBytes + doneBytes + 256u);
+    args.logCapacity = kLogCapacity;
+    if (const char* v = getenv("EM2_LOG_CAPACITY")) {
+        if (atoi(v) >= 1 && uint32_t(atoi(v)) < kLogCapacity) args.logCapacity = uint32_t(atoi(v));
+    }
+    args.segments = uint32_t(segments);
+    args.columnsPerSegment = cps;
+    args.snap = reinterpret_cast<int32_t*>(snapArea);
+    args.inbox = nullptr;
+    args.inboxControl = reinterpret_cast<uint32_t*>(controlArea);
+    args.segTable = reinterpret_cast<const uint32_t*>(tableArea);
+    args.inboxCapacity = 0;
+    args.inboxChunk = kInboxChunk;
+    args.fullRowBlocks = rowBlocks;
+    uint32_t rowBits = 1;
+    while ((1ull << rowBits) < uint64_t(cellCount)) ++rowBits;
+    args.rowBits = rowBits;
+    args.totalTickets = uint32_t(tickets);
+    args.rowBlockStride = 1;
+    args.rowBlockOffset = 0;
+    args.localBlockBase = 0;
+    args.columnLimit = cellCount;
+    args.shardFlags = 0;
+    args.fragments = fragmentArea;
+    args.matrixLdsOffset = uint32_t(matrixLdsOffset);
+    args.departTicks = 0;
+    args.departWindow = 0;
+    args.convoy = uint32_t(envNumber("EM2_MATRIX_CONVOY", 1));
+    if (cps / 64u > kConvoyMaxPairs && args.convoy == 1u) args.convoy = 0u;       // (positions have 12 bits)
+
+    e = hipMemsetAsync(c + stateBytes, 0, doneBytes + 256u, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(controlArea, 0, 256u, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(snapArea, 0xff, size_t(cellCount) * 4u, stream);        // -1: no column ever takes a candidate
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(tableArea, table, (2u * segments + 2u) * 4u, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+
+    static thread_local hipEvent_t timing[2] = {nullptr, nullptr};
+    if (!timing[0]) {
+        if (hipEventCreate(&timing[0]) != hipSuccess || hipEventCreate(&timing[1]) != hipSuccess) timing[0] = timing[1] = nullptr;
+    }
+    const uint32_t matrixSteps = wide ? 2u * kMatrixSteps : kMatrixSteps;
+    const size_t bytesPerCell = wide ? 1024u : 512u;
+    const uint32_t signatureDwords = 2u * matrixSteps;          // of a cell as the expansion and the v_xor/v_bcnt parts read it
+    if (paddedDw < 32u) {
+        uint32_t* widened = reinterpret_cast<uint32_t*>(widenedArea);
+        widenSignaturesKernel<<<dim3((cellCount * 32u + 255u) / 256u), dim3(256), 0, stream>>>(args.sig32, paddedDw, cellCount, widened);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        args.sig32 = widened;
+    }
+    {
+        const uint32_t columnBlocks = (cellCount + 63u) / 64u;
+        const uint32_t fragmentCount = columnBlocks * 2u * matrixSteps * 64u;
+        expandFragmentsKernel<<<dim3((fragmentCount + 255u) / 256u), dim3(256), 0, stream>>>(
+            args.sig32, cellCount, fragmentCount, reinterpret_cast<FragmentWord4*>(fragmentArea), matrixSteps);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (args.rowBegin % 32u == 0u) {
+        args.rowFragmentBase = args.rowBegin / 32u;             // the rows are whole blocks of the columns' array
+    } else {
+        if (!rowFragmentArea) return hipErrorInvalidValue;
+        const uint32_t fragmentCount = rowBlocks * 2u * matrixSteps * 64u;
+        expandFragmentsKernel<<<dim3((fragmentCount + 255u) / 256u), dim3(256), 0, stream>>>(
+            args.sig32 + size_t(args.rowBegin) * signatureDwords, rows, fragmentCount, reinterpret_cast<FragmentWord4*>(rowFragmentArea), matrixSteps);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        args.rowFragmentBase = uint32_t(size_t(rowFragmentArea - fragmentArea) / (32u * bytesPerCell));
+    }
+    if (const char* v = getenv("EM2_SCAN_VERBOSE")) {
+        if (v[0] == '1') fprintf(stderr, "[em2] rows form on the matrix cores: rows [%u, %u), %u segments x %u columns, %llu tickets, %llu blocks, "
+                                         "row fragments %s\n", args.rowBegin, args.rowEnd, uint32_t(segments), cps, (unsigned long long)tickets,
+                                 (unsigned long long)blocksWanted, args.rowBegin % 32u == 0u ? "in the columns' array" : "expanded once more");
+    }
+    void* argsArray[] = {&args};
+    if (timing[0]) (void)hipEventRecord(timing[0], stream);
+    e = hipLaunchKernel(matrixKernel, dim3(uint32_t(blocksWanted)), dim3(256), argsArray, matrixLds, stream);
+    if (e != hipSuccess) return e;
+    if (timing[0]) (void)hipEventRecord(timing[1], stream);
+
+    // the clock words of the launch (the hand-off error word stays in the control block for readFsp4Error)
+    uint32_t inboxWords[kClockWordsOffset + 4u] = {0};
+    e = hipMemcpyAsync(inboxWords, controlArea, sizeof(inboxWords), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    double clockGHz = 0.0;
+    {
+        unsigned long long ticks[2] = {0, 0};
+        std::memcpy(ticks, inboxWords + kClockWordsOffset, sizeof(ticks));
+        if (ticks[1]) clockGHz = double(ticks[0]) / double(ticks[1]) * 0.1;
+    }
+    float ms = -1.0f;
+    if (!timing[0] || hipEventElapsedTime(&ms, timing[0], timing[1]) != hipSuccess) ms = -1.0f;
+    lastLaunchInfo.form = 4;
+    lastLaunchInfo.scanKernelMs = double(ms);
+    lastLaunchInfo.waveColumnSteps = double(rowBlocks) * double(cellCount & 31u);
+    lastLaunchInfo.inboxEntries = 0.0;
+    lastLaunchInfo.segments = double(segments);
+    lastLaunchInfo.fullRowCells = double(rows);
+    lastLaunchInfo.matrixPairs = 64.0 * double(rowBlocks) * double(cellCount & ~31u);
+    lastLaunchInfo.matrixKernelMs = double(ms);
+    lastLaunchInfo.matrixClockGHz = clockGHz;
     *done = true;
     return hipSuccess;
 }

@@ -169,7 +169,9 @@ int em2_dev_find_similar_pairs4_form(uint32_t cellCount, uint32_t rowCount);
 
 /* The same question with the signature width: for 129..2048 bits the symmetric form contracts its pairs as FP4 +-1
  * dot products on the matrix cores (3; 1024 - 2 * mismatches up to 1024 bits, 2048 - 2 * mismatches above; exact in f32)
- * and starts at 32768 cells instead of 131072.
+ * and starts at 32768 cells instead of 131072.  A launch that is not symmetric -- a shard of the rows, SURVEY 8(e)'s
+ * partitioning across GPUs -- takes the rows form on the matrix cores (4) from 2^31 (row, column) pairs on: every row walks
+ * all columns in ascending order, which is the per-cell contract of src/ExpressionMatrixLsh.cpp:200-285 as it stands.
  * The last_launch query below reports what actually ran. */
 int em2_dev_find_similar_pairs4_form_for(uint32_t cellCount, uint32_t rowCount, uint32_t lshCount);
 

@@ -5,6 +5,7 @@ import re
 import subprocess
 
 import numpy as np
+import ctypes
 import pytest
 
 from expressionmatrix2_amd import capi
@@ -119,7 +120,19 @@ def test_scan_form_query_knows_about_the_matrix_cores(lib, monkeypatch):
     monkeypatch.delenv("EM2_SCAN_MATRIX_WIDE")
     monkeypatch.setenv("EM2_SCAN_MATRIX", "2")
     assert f(100000, 100000, 64) == 3 and f(200000, 200000, 2048) == 3 and f(200000, 200000, 3000) == 1
-    assert f(200000, 100000, 1024) == 0
+    # a shard of the rows (never symmetric) takes the rows form on the matrix cores (4) from 2^31 (row, column) pairs on
+    assert f(200000, 100000, 1024) == 4 and f(200000, 100000, 2048) == 4 and f(200000, 100000, 3000) == 0
+    assert f(200000, 10000, 1024) == 0 and f(1000000, 125000, 1024) == 4 and f(1000000, 2048, 1024) == 0
     monkeypatch.setenv("EM2_SCAN_MATRIX", "0")
-    assert f(100000, 100000, 1024) == 0 and f(200000, 200000, 1024) == 1
+    assert f(100000, 100000, 1024) == 0 and f(200000, 200000, 1024) == 1 and f(200000, 100000, 1024) == 0
+    monkeypatch.delenv("EM2_SCAN_MATRIX")
+    monkeypatch.setenv("EM2_SCAN_MODE", "rows")               # (tests: the rows form for every launch it can serve)
+    assert f(3000, 3000, 1024) == 4 and f(3000, 1, 1024) == 4 and f(100000, 100000, 1024) == 4 and f(3000, 3000, 64) == 0
+    monkeypatch.setenv("EM2_SCAN_MODE", "persistent")
+    assert f(200000, 100000, 1024) == 0
+    monkeypatch.delenv("EM2_SCAN_MODE")
+    w = lib.em2_dev_find_similar_pairs4_workspace
+    w.restype = ctypes.c_size_t
+    # (the rows form's workspace: fragments of every column, and of the rows once more when they are not all cells)
+    assert w(200000, 100000, 1024, 100) - w(200000, 100000, 128, 100) > 200000 * 512 + 100000 * 512
     assert lib.em2_dev_find_similar_pairs4_form(200000, 200000) == 1

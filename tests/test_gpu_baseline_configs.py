@@ -134,6 +134,43 @@ def test_configs2_1m_cells_30k_genes(million):
     check_similarities_against_signatures(pairs, pipe.used.cpu().numpy().view(np.uint32), sig_host, 1024, THR, rows)
 
 
+@pytest.mark.parametrize("world,rank", [(8, 3), (4, 1), (2, 1), (8, 7)])
+def test_configs2_row_shards_on_the_matrix_cores(oracle, million, world, rank):
+    """BASELINE configs[2] names 8 GPUs with the rows split by contiguous id range: the one GPU of the box plays
+    rank r of P -- em2_dev_find_similar_pairs4 with the rank's row range against all columns, which takes the rows form on the
+    matrix cores (form 4).  EVERY row of the shard equals the one-GPU result, and 10 240 rows of it (16 places) the oracle's
+    (src/ExpressionMatrixLsh.cpp:200-285, per-cell form)."""
+    import bench
+    torch, pipe, sig_host = million
+    cells = pipe.cell_count
+    begin, end = sharded.shard_range(cells, world, rank)
+    rows = end - begin
+    assert capi.dev_find_similar_pairs4_form_for(cells, rows, 1024) == 4
+    ws_bytes = capi.dev_find_similar_pairs4_workspace(cells, rows, 1024, K)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pipe.device)
+    pairs = torch.zeros((rows, K, 2), dtype=torch.int32, device=pipe.device)
+    used = torch.zeros(rows, dtype=torch.int32, device=pipe.device)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        capi.dev_find_similar_pairs4(pipe.full_sig.data_ptr(), cells, begin, end, 1024, K, THR, pairs.data_ptr(), used.data_ptr(),
+                                     ws.data_ptr(), ws_bytes, stream)
+    capi.dev_find_similar_pairs4_status(ws.data_ptr(), rows, K, stream)
+    info = capi.dev_find_similar_pairs4_last_launch()
+    assert info["form"] == 4 and info["matrix_pairs"] >= rows * float(cells & ~31)
+    print("rows form, rank %d of %d: kernel %.1f ms at %.2f GHz" % (rank, world, info["matrix_kernel_ms"], info["matrix_clock_ghz"]))
+    assert torch.equal(used, pipe.used[begin:end]) and torch.equal(pairs, pipe.pairs[begin:end])
+    ranges = bench.sample_ranges([(begin, end)], 10240)
+    host_pairs = pairs.cpu().numpy().view(np.uint32)
+    host_used = used.cpu().numpy().view(np.uint32)
+    checked = 0
+    for b, e, cell, sim, oused in bench.oracle_rows_parallel(oracle, sig_host, 1024, K, THR, ranges):
+        lo, hi = b - begin, e - begin
+        assert np.array_equal(host_used[lo:hi], oused) and np.array_equal(host_pairs[lo:hi, :, 0], cell)
+        assert np.array_equal(host_pairs[lo:hi, :, 1], sim.view(np.uint32))
+        checked += e - b
+    assert checked >= 10240
+
+
 def test_configs4_1m_cells_graph_and_labels(oracle, million):
     """createCellGraph (src/CellGraph.cpp:33-117) and labelPropagationClustering (src/CellGraph.cpp:443-612) on the
     million-cell SimilarPairs: the WHOLE edge list against the oracle's add_edge order (hash-table form of the literal

@@ -445,8 +445,90 @@ def test_matrix_form_inbox_overflow_falls_back(oracle, scan_knobs):
     cell, sim, used = oracle.find_similar_pairs4(sig, 1024, 10, -0.5)
     scan_knobs(EM2_SCAN_MODE="triangle", EM2_FULL_ROW_CELLS=0, EM2_INBOX_CAPACITY=1024)
     pairs, gused = capi.find_similar_pairs4(sig, 1024, 10, -0.5)
-    assert capi.dev_find_similar_pairs4_last_launch()["form"] == 0          # the ordered scan ran instead
+    assert capi.dev_find_similar_pairs4_last_launch()["form"] == 4          # every row walked all columns instead, on the matrix cores
     assert_same(pairs, gused, cell, sim, used)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_FULL_ROW_CELLS=0, EM2_INBOX_CAPACITY=1024, EM2_SCAN_MATRIX_WIDE=0)
+    sig = make(2000, 2048, "clustered")
+    cell, sim, used = oracle.find_similar_pairs4(sig, 2048, 10, -0.5)
+    pairs, gused = capi.find_similar_pairs4(sig, 2048, 10, -0.5)
+    assert capi.dev_find_similar_pairs4_last_launch()["form"] == 0          # no matrix form for this width: the ordered scan
+    assert_same(pairs, gused, cell, sim, used)
+
+
+# ---- the rows form on the matrix cores: rows [rowBegin, rowEnd) x all columns (a rank's shard; the overflow fallback) ----
+
+def run_row_shard(sig, L, k, thr, begin, end):
+    """em2_dev_find_similar_pairs4 for rows [begin, end): (cell, similarity bits, used) as numpy arrays."""
+    import torch
+    n = sig.shape[0]
+    rows = end - begin
+    d_sig = torch.from_numpy(sig.view(np.int64)).cuda()
+    ws_bytes = capi.dev_find_similar_pairs4_workspace(n, rows, L, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    d_pairs = torch.empty((rows, k, 2), dtype=torch.int32, device="cuda")
+    d_used = torch.empty(rows, dtype=torch.int32, device="cuda")
+    capi.dev_find_similar_pairs4(d_sig.data_ptr(), n, begin, end, L, k, thr, d_pairs.data_ptr(), d_used.data_ptr(), ws.data_ptr(),
+                                 ws_bytes, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    capi.dev_find_similar_pairs4_status(ws.data_ptr(), rows, k, torch.cuda.current_stream().cuda_stream)
+    pairs = d_pairs.cpu().numpy().view(np.uint32)
+    return pairs[:, :, 0], pairs[:, :, 1], d_used.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("n,L,k,thr,kind,knobs", [
+    (3000, 1024, 20, 0.2, "clustered", dict()),
+    (3001, 1024, 20, 0.2, "clustered", dict(EM2_MIN_SEGMENT_COLUMNS=256)),                    # a last, partial tile; many hand-offs
+    (2309, 600, 7, 0.0, "clustered", dict(EM2_MIN_SEGMENT_COLUMNS=700)),                       # zero-extended fragments
+    (1700, 1024, 5, -1.0, "random", dict(EM2_MIN_SEGMENT_COLUMNS=512)),                        # everything passes: the walks stop and resume
+    (1700, 1024, 300, -0.5, "clustered", dict(EM2_MIN_SEGMENT_COLUMNS=256, EM2_LOG_CAPACITY=1)),
+    (4000, 1024, 25, 0.5, "clustered", dict(EM2_SEGMENTS=3, EM2_BLOCKS_PER_CU=1)),
+    (2500, 2048, 10, 0.2, "clustered", dict(EM2_MIN_SEGMENT_COLUMNS=512)),                     # the 2048-bit walk
+    (2307, 1500, 12, -0.5, "clustered", dict(EM2_MIN_SEGMENT_COLUMNS=256, EM2_LOG_CAPACITY=1)),
+    (2500, 1024, 10, 0.2, "clustered", dict(EM2_MIN_SEGMENT_COLUMNS=512, EM2_MATRIX_CONVOY=3)),   # every walk goes around its segment
+    (1700, 2048, 5, -1.0, "random", dict(EM2_MIN_SEGMENT_COLUMNS=512, EM2_MATRIX_CONVOY=2)),
+])
+def test_rows_form_on_the_matrix_cores(oracle, scan_knobs, n, L, k, thr, kind, knobs):
+    """A shard of the rows against all columns -- what a rank of the multi-GPU rows form computes -- as FP4 +-1
+    dot products: every row block is a full-row block of the matrix kernel.  Shards that begin at a multiple of 32 take their
+    row fragments out of the columns' array, others get a copy; short last quads, single rows, the whole problem."""
+    sig = make(n, L, kind)
+    scan_knobs(EM2_SCAN_MODE="rows", **knobs)
+    for begin, end in [(0, n), (0, 1000), (1000, 1001), (1001, n), (n - 1, n), (37, n - 100), (1024, 1024 + 256), (960, 960 + 300)]:
+        cell, sim, used = oracle.find_similar_pairs4_rows(sig, L, k, thr, begin, end)
+        gcell, gsim, gused = run_row_shard(sig, L, k, thr, begin, end)
+        info = capi.dev_find_similar_pairs4_last_launch()
+        assert info["form"] == 4 and info["matrix_pairs"] > 0, (begin, end)
+        assert np.array_equal(gused, used), (begin, end)
+        assert np.array_equal(gcell, cell), (begin, end)
+        assert np.array_equal(gsim, sim.view(np.uint32)), (begin, end)
+
+
+@pytest.mark.parametrize("n,L,k,thr,kind", CASES)
+def test_rows_form_whole_problem_matches_oracle(oracle, scan_knobs, n, L, k, thr, kind):
+    """EM2_SCAN_MODE=rows: every launch that has a matrix form takes the rows form (the others run as ever)."""
+    sig = make(n, L, kind)
+    cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
+    scan_knobs(EM2_SCAN_MODE="rows")
+    pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
+    expected = 4 if (128 < L <= 2048 and n >= 64 and k <= 682) else 0
+    assert capi.dev_find_similar_pairs4_last_launch()["form"] == expected
+    assert_same(pairs, gused, cell, sim, used)
+
+
+def test_rows_form_is_the_default_for_a_large_shard(oracle, scan_knobs):
+    """Without any knob: 2^31 (row, column) pairs and more go to the matrix cores, smaller launches keep the ordered scan."""
+    n, L, k, thr = 70000, 1024, 20, 0.2
+    sig = synth.clustered_signatures(n, L, cluster_count=32, flip=0.15, seed=12)
+    assert capi.dev_find_similar_pairs4_form_for(n, 35000, L) == 4
+    assert capi.dev_find_similar_pairs4_form_for(n, 20000, L) == 0
+    begin, end = 30001, 65001
+    gcell, gsim, gused = run_row_shard(sig, L, k, thr, begin, end)
+    assert capi.dev_find_similar_pairs4_last_launch()["form"] == 4
+    for b in (begin, begin + 17003, end - 200):
+        cell, sim, used = oracle.find_similar_pairs4_rows(sig, L, k, thr, b, b + 200)
+        assert np.array_equal(gused[b - begin:b - begin + 200], used)
+        assert np.array_equal(gcell[b - begin:b - begin + 200], cell)
+        assert np.array_equal(gsim[b - begin:b - begin + 200], sim.view(np.uint32))
 
 
 @pytest.mark.parametrize("world,n,permille", [(2, 6000, 200), (4, 9000, 300), (3, 7000, 250), (8, 9000, 100)])

@@ -126,6 +126,57 @@ def main():
         print(json.dumps({"check": "fsp7 parity on the first 20000 cells", "bit_exact": ok}))
         if not ok:
             raise SystemExit("PARITY FAILURE")
+    elif what == "rows":
+        # North_star's partitioning on one GPU: rank r of P scans its contiguous rows against all columns
+        # (em2_dev_find_similar_pairs4 with a row range).  RANKS="8:0,8:3,8:7,4:1,2:1", CHECK_ROWS rows per shard (16 places)
+        # against the oracle on all host threads.  SWEEP as in `sweep` (knob settings separated by ';').
+        from concurrent.futures import ThreadPoolExecutor
+        cells, L, k, thr = int(os.environ.get("CELLS", 1000000)), int(os.environ.get("LSH", 1024)), 100, 0.2
+        check_rows = int(os.environ.get("CHECK_ROWS", 10240))
+        sig = clustered_signatures_gpu(cells, L)
+        host = sig.cpu().numpy().view(np.uint64)
+        threads = max(1, min(64, os.cpu_count() or 1))
+        for config in os.environ.get("SWEEP", "").split(";"):
+            knobs = dict(item.split("=", 1) for item in config.split(",") if "=" in item)
+            os.environ.update(knobs)
+            for item in os.environ.get("RANKS", "8:0,8:3,8:7,4:1,2:1").split(","):
+                world, rank = (int(x) for x in item.split(":"))
+                per = -(-cells // world)
+                begin, end = min(cells, rank * per), min(cells, (rank + 1) * per)
+                rows = end - begin
+                ws_bytes = capi.dev_find_similar_pairs4_workspace(cells, rows, L, k)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+                d_pairs = torch.zeros((rows, k, 2), dtype=torch.int32, device="cuda")
+                d_used = torch.zeros(rows, dtype=torch.int32, device="cuda")
+                times, kernel = [], []
+                for _ in range(int(os.environ.get("REPEATS", 3))):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    capi.dev_find_similar_pairs4(sig.data_ptr(), cells, begin, end, L, k, thr, d_pairs.data_ptr(),
+                                                 d_used.data_ptr(), ws.data_ptr(), ws_bytes, stream)
+                    torch.cuda.synchronize()
+                    times.append(time.perf_counter() - t0)
+                    kernel.append(capi.dev_find_similar_pairs4_last_launch()["matrix_kernel_ms"])
+                capi.dev_find_similar_pairs4_status(ws.data_ptr(), rows, k, stream)
+                span = max(1, check_rows // 16)
+                starts = sorted(set(begin + (rows - span) * i // 15 for i in range(16))) if rows > span else [begin]
+                pieces = [(s0 + j, min(end, s0 + j + 16)) for s0 in starts for j in range(0, span, 16) if s0 + j < end]
+                with ThreadPoolExecutor(max_workers=threads) as pool:
+                    expected = list(pool.map(lambda piece: oracle.find_similar_pairs4_rows(host, L, k, thr, piece[0], piece[1]), pieces))
+                checked, ok = 0, True
+                for (b, e), (c, s_, u) in zip(pieces, expected):
+                    ok = ok and compare(d_pairs, d_used, c, s_, u, slice(b - begin, e - begin))
+                    checked += e - b
+                launch = capi.dev_find_similar_pairs4_last_launch()
+                print(json.dumps({"check": "rows", "cells": cells, "lsh_count": L, "world": world, "rank": rank, "rows": [begin, end],
+                                  "knobs": knobs, "ms": [round(t * 1e3, 2) for t in times], "kernel_ms": [round(t, 2) for t in kernel],
+                                  "ordered_pairs_per_s": rows * cells / min(times), "rows_checked": checked, "rows_bit_exact": ok,
+                                  "form": launch["form"], "clock_ghz": round(launch["matrix_clock_ghz"], 3)}), flush=True)
+                del ws, d_pairs, d_used
+                if not ok and not os.environ.get("IGNORE_PARITY"):
+                    raise SystemExit("PARITY FAILURE")
+            for key in knobs:
+                os.environ.pop(key, None)
     elif what == "sweep":
         cells, L, k, thr = int(os.environ.get("CELLS", 1000000)), int(os.environ.get("LSH", 1024)), 100, 0.2
         sig = clustered_signatures_gpu(cells, L)
