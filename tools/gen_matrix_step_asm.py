@@ -124,15 +124,22 @@ def tests_of(s, o, q, j, k, prev0, prev1):
     s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass1_%d" % (k & 1)], vreg(THR1), vreg(prev1 + k)))
 
 
-def shift_in(s, o, k):
-    """Scalar half: a register whose test passed in some lane goes through its stub (out of line, behind the body)."""
+def shift_in(s, o, k, carried=None):
+    """Scalar half: a register whose test passed in some lane goes through its stub (out of line, behind the body).
+    carried (EM2_GEN_STUB=mfma): the matrix instruction that follows the two checks in the body.  A stub then begins with a
+    copy of it and comes back BEHIND it: the instruction enters the pipe as soon as the stub's first instruction has been
+    fetched, and the record, the stores and the branch back run in its shadow instead of in front of it."""
     if CMPX:
         return
     for a in range(2):
         s.emit("s_cmp_lg_u64 %s, 0" % o["pass%d_%d" % (a, k & 1)])
         s.emit("s_cbranch_scc1 L_stub_%d_%d_%%=" % (k, a))
-        s.emit("L_back_%d_%d_%%=:" % (k, a))
-        s.stubs.append((k, a))
+        if not carried:
+            s.emit("L_back_%d_%d_%%=:" % (k, a))
+        s.stubs.append((k, a, carried))
+    if carried:
+        s.emit(carried)
+        s.emit("L_back_%d_0_%%=:" % k)
 
 
 def stubs(s, o, prev0, prev1):
@@ -143,17 +150,76 @@ def stubs(s, o, prev0, prev1):
         s.emit("v_mov_b32 %s, %s" % (o["count1"], vreg(OFFSET + 1)))
         return
     s.emit("s_branch L_end_%=")
-    for k, a in s.stubs:
+
+    def record(k, a):
         acc = (prev0, prev1)[a] + k
-        s.emit("L_stub_%d_%d_%%=:" % (k, a))
-        s.emit("s_mov_b64 %s, exec" % o["save"])
-        s.emit("s_mov_b64 exec, %s" % o["pass%d_%d" % (a, k & 1)])
+        if STUB == "empty":          # (measurement only: what the two branches of an event cost by themselves)
+            return
+        mask = o["pass%d_%d" % (a, k & 1)]
+        if STUB in ("addfirst", "store4", "dsw", "storeonly"):
+            s.emit("v_or_b32_e64 %s, %s, %d" % (vreg(RECORD), o["tileCode"], 2 * k + a))
+            s.emit("v_mov_b32 %s, %s" % (vreg(RECORD + 1), vreg(acc)))
+            s.emit("s_and_saveexec_b64 %s, %s" % (o["save"], mask))
+            if STUB == "storeonly":        # (measurement: the store without the count)
+                s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET + a), vreg(RECORD, 2), o["logBase"]))
+            else:
+                s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET + a), vreg(OFFSET + a)))
+                if STUB == "addfirst":
+                    s.emit("global_store_dwordx2 %s, %s, %s offset:-8" % (vreg(OFFSET + a), vreg(RECORD, 2), o["logBase"]))
+                elif STUB == "store4":
+                    s.emit("global_store_dword %s, %s, %s offset:-8" % (vreg(OFFSET + a), vreg(RECORD + 1), o["logBase"]))
+                else:                      # (measurement: an LDS write of the same size instead; the address is the tile pointer)
+                    # (the ubench's LDS: 64 KB of tiles, 3 KB of walk blocks, then -- with -DUBENCH_EXTRA_LDS -- a spare 4 KB)
+                    s.emit("v_mbcnt_lo_u32_b32 %s, -1, 0" % vreg(THR0))
+                    s.emit("v_mbcnt_hi_u32_b32 %s, -1, %s" % (vreg(THR0), vreg(THR0)))
+                    s.emit("v_lshlrev_b32 %s, 3, %s" % (vreg(THR0), vreg(THR0)))
+                    s.emit("v_add_u32 %s, 0x%x, %s" % (vreg(THR0), 65536 + 4 * 768, vreg(THR0)))
+                    s.emit("ds_write_b64 %s, %s" % (vreg(THR0), vreg(RECORD, 2)))
+            s.emit("s_mov_b64 exec, %s" % o["save"])
+            return
+        if STUB in ("early", "nostore", "valuonly", "addc"):
+            # the record is formed under the full EXEC (its registers are scratch), only the store and the count are masked
+            s.emit("v_or_b32_e64 %s, %s, %d" % (vreg(RECORD), o["tileCode"], 2 * k + a))
+            s.emit("v_mov_b32 %s, %s" % (vreg(RECORD + 1), vreg(acc)))
+            if STUB == "valuonly":       # (measurement: three vector instructions, no EXEC change, no store)
+                s.emit("v_add_u32 %s, 0, %s" % (vreg(OFFSET + a), vreg(OFFSET + a)))
+                return
+            if STUB == "addc":
+                # the count without EXEC: + 8 where the mask is set (two instructions, no hazard); only the store is masked
+                s.emit("v_cndmask_b32_e64 %s, 0, 8, %s" % (vreg(THR0), mask))
+                s.emit("s_and_saveexec_b64 %s, %s" % (o["save"], mask))
+                s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET + a), vreg(RECORD, 2), o["logBase"]))
+                s.emit("s_mov_b64 exec, %s" % o["save"])
+                s.emit("v_add_u32 %s, %s, %s" % (vreg(OFFSET + a), vreg(THR0), vreg(OFFSET + a)))
+                return
+            s.emit("s_and_saveexec_b64 %s, %s" % (o["save"], mask))
+            if STUB != "nostore":
+                s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET + a), vreg(RECORD, 2), o["logBase"]))
+            s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET + a), vreg(OFFSET + a)))
+            s.emit("s_mov_b64 exec, %s" % o["save"])
+            return
+        if STUB in ("saveexec", "mfma"):
+            s.emit("s_and_saveexec_b64 %s, %s" % (o["save"], mask))
+        else:
+            s.emit("s_mov_b64 %s, exec" % o["save"])
+            s.emit("s_mov_b64 exec, %s" % mask)
         s.emit("v_or_b32_e64 %s, %s, %d" % (vreg(RECORD), o["tileCode"], 2 * k + a))
         s.emit("v_mov_b32 %s, %s" % (vreg(RECORD + 1), vreg(acc)))
         s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET + a), vreg(RECORD, 2), o["logBase"]))
         s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET + a), vreg(OFFSET + a)))
         s.emit("s_mov_b64 exec, %s" % o["save"])
-        s.emit("s_branch L_back_%d_%d_%%=" % (k, a))
+
+    for k, a, carried in s.stubs:
+        s.emit("L_stub_%d_%d_%%=:" % (k, a))
+        if carried:
+            s.emit(carried)
+        record(k, a)
+        if carried and a == 0:
+            # the other accumulator's check, which the body would have made next
+            s.emit("s_cmp_lg_u64 %s, 0" % o["pass1_%d" % (k & 1)])
+            s.emit("s_cbranch_scc0 L_back_%d_0_%%=" % k)
+            record(k, 1)
+        s.emit("s_branch L_back_%d_%d_%%=" % (k, 0 if carried else a))
     s.emit("L_end_%=:")
     s.emit("v_mov_b32 %s, %s" % (o["count"], vreg(OFFSET)))
     s.emit("v_mov_b32 %s, %s" % (o["count1"], vreg(OFFSET + 1)))
@@ -215,6 +281,10 @@ TILE_BOUND = os.environ.get("EM2_GEN_TILE_BOUND", "0") == "1"
 # nothing passed), EXEC is restored; five more instructions per result, all of them masked off almost always (DESIGN 3.1.6:
 # 4.9 PFLOP/s at every record rate against 6.6 at the scan's -- instructions under an empty EXEC are not free, the stores least).
 CMPX = os.environ.get("EM2_GEN_CMPX", "0") == "1"
+# EM2_GEN_STUB: the form of the stubs.  "branches" = round 2's (two s_mov around the record); "saveexec" = s_and_saveexec_b64
+# instead of the first two; "mfma" = that, and the checks of a k-step sit directly in front of its second matrix instruction, of
+# which every stub carries a copy (shift_in); "empty" = no record at all (measurement: the branches alone).
+STUB = os.environ.get("EM2_GEN_STUB", "branches")
 
 
 def masked_record(s, o, k, a, thr, acc, first):
@@ -249,10 +319,14 @@ def step(cur, prev, tests, operands):
         for a, (acc, rows) in enumerate(((cur0, ROWS[0]), (cur1, ROWS[1]))):
             # (the form without block scales: scale 2^0 is what the operands want, and v_mfma_scale_* is two instructions --
             # a v_mfma_ld_scale_b32 in front of this one -- 16 bytes instead of 8 and an issue slot more per MFMA)
-            s.emit("v_mfma_f32_32x32x64_f8f6f4 %s, %s, %s, %s cbsz:4 blgp:4"
-                   % (vreg(acc, 16), vreg(slot, 4), vreg(rows + 4 * k, 4), "0" if k == 0 else vreg(acc, 16)))
+            mfma = ("v_mfma_f32_32x32x64_f8f6f4 %s, %s, %s, %s cbsz:4 blgp:4"
+                    % (vreg(acc, 16), vreg(slot, 4), vreg(rows + 4 * k, 4), "0" if k == 0 else vreg(acc, 16)))
+            if a == 1 and tests and STUB == "mfma" and k:
+                shift_in(s, o, k - 1, carried=mfma)        # (emits the instruction itself behind the two checks)
+            else:
+                s.emit(mfma)
             if a == 0 and tests:
-                place(s, o, k, PLACE[0], prev0, prev1, slot, carry_out)
+                place(s, o, k, PLACE[0].replace("S", "") if STUB == "mfma" else PLACE[0], prev0, prev1, slot, carry_out)
         if tests:
             place(s, o, k, PLACE[1], prev0, prev1, slot, carry_out)
         else:
@@ -322,7 +396,7 @@ def wide_shift_in(s, o, i):
     s.emit("s_cmp_lg_u64 %s, 0" % o["pass0_%d" % (i & 1)])
     s.emit("s_cbranch_scc1 L_stub_%d_0_%%=" % i)
     s.emit("L_back_%d_0_%%=:" % i)
-    s.stubs.append((i, 0))
+    s.stubs.append((i, 0, None))
 
 
 def wide_min(s, i):

@@ -86,7 +86,11 @@ static void run(const char* name, int blocksPerCu, int rounds, int mode, float b
     hipEvent_t a, b;
     hipEventCreate(&a);
     hipEventCreate(&b);
+#ifdef UBENCH_EXTRA_LDS
+    const size_t ldsBytes = 65536 + 4 * 768 + 4096;          // (a spare 4 KB behind the walk blocks: EM2_GEN_STUB=dsw writes there)
+#else
     const size_t ldsBytes = 65536 + 4 * 768;
+#endif
     hipFuncSetAttribute(reinterpret_cast<const void*>(&stepLoop), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
     stepLoop<<<cus * blocksPerCu, 256, ldsBytes>>>(16, mode, bound, tiles, rows, logs, counts, out);
     hipDeviceSynchronize();
