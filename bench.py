@@ -83,14 +83,28 @@ def launch_ranks(args):
     to: it waits).  The child's stdout/stderr are this process's own, its exit code is returned."""
     import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # Under a profiler this hop would be a launcher between the profiler's preloaded library (which may have initialised the
+    # GPU) and the ranks: refuse, the profiled command is `... -- python3 -m torch.distributed.run ... bench.py --gpus N`.
+    preload = " ".join(os.environ.get(name, "") for name in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD"))
+    if "rocprof" in preload.lower():
+        raise SystemExit("bench.py --gpus %d under a profiler: start the ranks with torch.distributed.run yourself "
+                         "(rocprofv3 ... -- python3 -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ...)"
+                         % (args.gpus, args.gpus, args.gpus))
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.run(command, env=env).returncode
+    code = 1
+    for attempt in range(3):                # (the port is free when it is picked, not necessarily when the ranks bind it)
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        done = subprocess.run(command, env=env, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(done.stderr)
+        code = done.returncode
+        if code == 0 or "address already in use" not in done.stderr.lower():
+            break
+    return code
 
 
 def parse_args():
@@ -453,7 +467,7 @@ def bench_fsp5(args, capi, oracle, device, torch):
         "phases_ms": {"candidate_filter": filter_ms, "selection": select_ms,
                       "tables_and_candidate_unions": elapsed / args.steps * 1e3 - filter_ms - select_ms},
         "roofline": {"kernel": ("filterWideKernel<%s> (all batches)" % ("1, 16" if W == 32 else "2, 16" if W == 64 else "T, LPC")) if W % 2 == 0 and W <= 64 and
-                               os.environ.get("EM2_FSP5_FILTER", "w")[0] == "w" else "filterCooperativeKernel (all batches)", "kernel_ms": filter_ms, "bound": "hbm", "achieved": achieved,
+                               True else "filterCooperativeKernel (all batches)", "kernel_ms": filter_ms, "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes": algorithmic, "distinct_candidates": distinct, "gathered_candidates": info["gathered_candidates"],
                      "note": "SURVEY.md 8(d): candidates x 8*W bytes of signature gathers + 4*N*sliceCount bytes of tables; candidates "
@@ -797,7 +811,7 @@ def main():
             result["dtype"] = "fp4 e2m1 +-1 products, f32 accumulate, exact (scan on the matrix cores) / u32 popcount (band, full rows) / f64 (projection)"
         matrix_traffic = None
         matrix_traffic_source = None
-        pinned_walk = os.environ.get("EM2_MATRIX_WALK", "3") not in ("0",)
+        pinned_walk = True
         profile_config = profile_query("fsp4", C, L, k, world, genes=G)
         if matrix and pinned_walk:
             matrix_traffic, _ = profiled_traffic(PROFILE_DIGESTS["fsp4"], profile_config,

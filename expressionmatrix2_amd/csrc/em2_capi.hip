@@ -747,9 +747,8 @@ int em2_subset_find_similar_pairs4(const uint64_t* globalToc, const em2_count* g
     EM2_HIP(dSig.allocate(size_t(cellCount) * words * sizeof(uint64_t)));
     EM2_HIP(dWs.allocate(wsBytes));
     EM2_HIP(hipMemcpy(dVectors.p, vectors, size_t(geneCount) * lshCount * sizeof(double), hipMemcpyHostToDevice));
-    const char* exactOnly = getenv("EM2_PROJECTION");
     void* aux = nullptr;
-    if (!(exactOnly && exactOnly[0] == 'e') && lshCount % 4u == 0u) {
+    if (lshCount % 4u == 0u) {          // (other widths: the exact arithmetic only)
         EM2_HIP(dAux.allocate(em2_dev_vector_aux_bytes(geneCount, lshCount)));
         const int prc = em2_dev_prepare_vectors(dVectors.as<double>(), geneCount, lshCount, dAux.p, nullptr);
         if (prc != EM2_OK) return prc;
@@ -809,9 +808,8 @@ int em2_compute_signatures(const uint64_t* toc, const em2_count* data, uint32_t 
     EM2_HIP(hipMemcpy(dToc.p, toc, (size_t(cellCount) + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     if (nnz) EM2_HIP(hipMemcpy(dData.p, data, nnz * sizeof(em2_count), hipMemcpyHostToDevice));
     EM2_HIP(hipMemcpy(dVectors.p, vectors, size_t(geneCount) * lshCount * sizeof(double), hipMemcpyHostToDevice));
-    const char* exactOnly = getenv("EM2_PROJECTION");             // EM2_PROJECTION=exact: no screening pass (A/B, tests)
     void* aux = nullptr;
-    if (!(exactOnly && exactOnly[0] == 'e') && lshCount % 4u == 0u) {
+    if (lshCount % 4u == 0u) {          // (other widths: the exact arithmetic only)
         EM2_HIP(dAux.allocate(em2_dev_vector_aux_bytes(geneCount, lshCount)));
         const int prc = em2_dev_prepare_vectors(dVectors.as<double>(), geneCount, lshCount, dAux.p, nullptr);
         if (prc != EM2_OK) return prc;

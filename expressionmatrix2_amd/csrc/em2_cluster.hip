@@ -16,11 +16,10 @@
 // float sums, the tie decisions and the labels.  What is gained is parallelism: v only has to wait for the
 // neighbours that precede it in this iteration's order.
 //
-// Two kernels.  labelPropagationKernel is the form of rounds 1-2 (EM2_LABEL_FORM=global: tables searched in global memory,
-// five arrays gathered per neighbour, candidates of large neighbourhoods staged in global memory); labelPropagationCachedKernel
-// is the product's: the table of the vertex whose turn it is lives in registers (up to 256 entries) or LDS (up to 640) for the
-// turn, a neighbour is ONE 32-byte record, the events of a turn are ranked and applied in batches.  Both reproduce the
-// reference's addWeight sequences exactly and are held to the oracle by the same tests.
+// The kernel, labelPropagationCachedKernel: the table of the vertex whose turn it is lives in registers (up to 256 entries) or
+// LDS (up to 640) for the turn, a neighbour is ONE 32-byte record, the events of a turn are ranked and applied in batches.  It
+// reproduces the reference's addWeight sequences exactly.  (Rounds 1-2 searched the tables in global memory and gathered five
+// arrays per neighbour: labelPropagationKernel in the git history, 102 ms where this one takes 34.)
 //
 // Schedule: one launch per iteration; a wave handles one vertex at a time and only ever waits (phase B) for vertices at
 // smaller positions, which running waves hold or will draw before anything larger, so the waits cannot deadlock.  How the
@@ -318,213 +317,6 @@ __device__ void sortKeysByWave(uint64_t* keys, uint32_t n, uint32_t lane)
     }
 }
 
-__global__ void __launch_bounds__(256) labelPropagationKernel(ClusterArgs args)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t want = args.iteration + 1u;
-    const uint32_t waves = gridDim.x * (blockDim.x / 64u);
-    uint32_t next = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u, end = 0, changes = 0;
-#ifdef EM2_DIAG
-    uint64_t diagAcc[kDiagWords] = {};
-    const uint64_t diagStart = __builtin_amdgcn_s_memtime();
-    uint64_t diagLast = diagStart;
-#endif
-    for (;;) {
-        // Every wave takes its positions in ascending order, so the smallest unfinished position is always the one
-        // its wave is working on and the waits below cannot deadlock -- with the strided assignment provided the
-        // whole grid is resident (the launcher sizes it so), with the ticket whatever the grid.  The ticket costs one
-        // same-address agent-scope atomic per draw (about 45 ns each, the floor of an iteration at one position per
-        // draw), and drawing several positions at a time widens the band of positions in flight, hence the waits.
-        uint32_t p;
-        if (args.ticketBatch == 0u) {
-            if (next >= args.vertexCount) break;
-            p = next;
-            next += waves;
-        } else {
-            if (next >= end) {
-                uint32_t first = kNone;
-                if (lane == 0u && __hip_atomic_load(args.control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                    first = __hip_atomic_fetch_add(args.control, args.ticketBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                first = uniform(first);
-                if (first >= args.vertexCount) break;
-                next = first;
-                end = min(first + args.ticketBatch, args.vertexCount);
-            }
-            p = next++;
-        }
-        const uint32_t v = uniform(args.order[p]);
-        const uint64_t base = uniform(args.offsets[v]);
-        const uint32_t degree = uniform(uint32_t(args.offsets[v + 1] - base));
-        TableMeta t = args.meta[v];
-        t.begin = uniform(t.begin);
-        t.size = uniform(t.size);
-        t.capacity = uniform(t.capacity);
-        t.best = uniform(t.best);
-        t.bestWeight = uniform(t.bestWeight);
-        uint32_t label = uniform(args.labelPrev[v]);
-        const bool later = args.iteration > 0u;
-        const uint32_t posPrevV = later ? uniform(args.posPrev[v]) : 0u;
-        uint32_t error = 0;
-        LP_CLOCK(0);
-
-        if (degree <= 64u) {
-            // ---- one neighbour per lane; both candidate lists stay in registers ----
-            uint32_t u = 0, labelU = 0, beforeU = 0, keyA = kNone, keyB = kNone;
-            float w = 0.f;
-            if (lane < degree) {
-                u = args.neighbour[base + lane];
-                w = args.weight[base + lane];
-                labelU = args.labelPrev[u];
-                if (later) {
-                    beforeU = args.labelPrev2[u];
-                    const uint32_t pp = args.posPrev[u];
-                    if (labelU != beforeU && pp > posPrevV) keyA = pp;
-                }
-                const uint32_t pc = args.posCur[u];
-                if (pc < p) keyB = pc;
-            }
-            // First look at the earlier neighbours, all at once: most have had their turn and kept their label.
-            uint32_t afterU = 0;
-            bool known = false;
-            if (keyB != kNone) {
-                const uint64_t s = __hip_atomic_load(args.state + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                known = uint32_t(s >> 32) == want;
-                afterU = uint32_t(s);
-                if (known && afterU == labelU) keyB = kNone;
-            }
-            const uint64_t knownMask = __builtin_amdgcn_ballot_w64(known);
-            LP_CLOCK(1);
-            while (!error) {
-                const uint32_t m = waveMin(keyA);
-                if (m == kNone) break;
-                const int owner = __ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(keyA == m)) - 1;
-                const uint32_t oldLabel = uint32_t(__shfl(int(beforeU), owner));
-                const uint32_t newLabel = uint32_t(__shfl(int(labelU), owner));
-                const float weight = __shfl(w, owner);
-                if (int(lane) == owner) keyA = kNone;
-                LP_COUNT(10);
-                if (!applyEvent(t, args, oldLabel, newLabel, weight, lane LP_DIAG_PASS)) error = 2;
-            }
-            LP_CLOCK(2);
-            while (!error) {
-                const uint32_t m = waveMin(keyB);
-                if (m == kNone) break;
-                const int owner = __ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(keyB == m)) - 1;
-                const uint32_t other = uint32_t(__shfl(int(u), owner));
-                const uint32_t oldLabel = uint32_t(__shfl(int(labelU), owner));
-                const float weight = __shfl(w, owner);
-                if (int(lane) == owner) keyB = kNone;
-                bool failed = false;
-                const uint32_t newLabel = ((knownMask >> owner) & 1ull) ? uint32_t(__shfl(int(afterU), owner))
-                                                                        : labelAfterTurn(args, other, failed LP_DIAG_PASS);
-                LP_COUNT(11);
-                if (failed) error = 1;
-                else if (newLabel != oldLabel && !applyEvent(t, args, oldLabel, newLabel, weight, lane LP_DIAG_PASS)) error = 2;
-            }
-            LP_CLOCK(3);
-        } else {
-            LP_COUNT(13);
-            // ---- the candidate lists go through scratch memory (slots base .. base+degree of each list) ----
-            Candidate* listA = args.scratchA + base;
-            Candidate* listB = args.scratchB + base;
-            uint32_t countA = 0, countB = 0;
-            for (uint32_t c = 0; c < degree; c += 64u) {
-                const uint32_t i = c + lane;
-                bool isA = false, isB = false;
-                uint32_t u = 0, labelU = 0, beforeU = 0, pp = 0, pc = 0;
-                float w = 0.f;
-                if (i < degree) {
-                    u = args.neighbour[base + i];
-                    w = args.weight[base + i];
-                    labelU = args.labelPrev[u];
-                    if (later) {
-                        beforeU = args.labelPrev2[u];
-                        pp = args.posPrev[u];
-                        isA = labelU != beforeU && pp > posPrevV;
-                    }
-                    pc = args.posCur[u];
-                    isB = pc < p;
-                }
-                uint32_t afterU = 0, known = 0;
-                if (isB) {
-                    const uint64_t s = __hip_atomic_load(args.state + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    known = uint32_t(s >> 32) == want ? 1u : 0u;
-                    afterU = uint32_t(s);
-                    if (known && afterU == labelU) isB = false;
-                }
-                const uint64_t maskA = __builtin_amdgcn_ballot_w64(isA);
-                const uint64_t maskB = __builtin_amdgcn_ballot_w64(isB);
-                if (isA) listA[countA + lanesBelow(maskA)] = Candidate{pp, beforeU, labelU, w, 0u, 0u};
-                if (isB) listB[countB + lanesBelow(maskB)] = Candidate{pc, u, labelU, w, afterU, known};
-                countA += uint32_t(__builtin_popcountll(maskA));
-                countB += uint32_t(__builtin_popcountll(maskB));
-            }
-            LP_CLOCK(5);
-            for (int phase = 0; phase < 2 && !error; ++phase) {
-                Candidate* list = phase ? listB : listA;
-                const uint32_t count = phase ? countB : countA;
-                if (count == 0u) continue;
-                // order of application = event time; equal times (parallel edges) keep the order of the adjacency
-                uint64_t* keys = args.sortKeys + (phase ? 2u * args.slots : 0u) + 2u * base;
-                uint32_t padded = 1u;
-                while (padded < count) padded <<= 1;
-                for (uint32_t i = lane; i < padded; i += 64u) keys[i] = i < count ? (uint64_t(list[i].key) << 32) | i : ~0ull;
-                sortKeysByWave(keys, padded, lane);
-                LP_CLOCK(6);
-                for (uint32_t n = 0; n < count && !error; ++n) {
-                    const uint32_t index = uniform(uint32_t(keys[n]));
-                    const Candidate candidate = list[index];
-                    const uint32_t a = uniform(candidate.a), b = uniform(candidate.b);
-                    const float weight = uniform(candidate.weight);
-                    if (phase == 0) {
-                        LP_COUNT(10);
-                        if (!applyEvent(t, args, a, b, weight, lane LP_DIAG_PASS)) error = 2;
-                    } else {
-                        bool failed = false;
-                        const uint32_t newLabel = uniform(candidate.known) ? uniform(candidate.c) : labelAfterTurn(args, a, failed LP_DIAG_PASS);
-                        LP_COUNT(11);
-                        if (failed) error = 1;
-                        else if (newLabel != b && !applyEvent(t, args, b, newLabel, weight, lane LP_DIAG_PASS)) error = 2;
-                    }
-                }
-                LP_CLOCK(7);
-            }
-        }
-
-        if (error) {
-            if (lane == 0u) {
-                // Keep the first cause: a timeout that follows an exhausted arena is only its consequence.
-                uint32_t expected = 0;
-                __hip_atomic_compare_exchange_strong(args.control + 2, &expected, error, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
-        }
-
-        // ---- the turn proper (CellGraph.cpp:507-524) ----
-        const bool change = t.size != 0u && label != t.best;
-        if (change) {
-            label = t.best;
-            ++changes;
-        }
-        if (lane == 0u) {
-            args.labelCur[v] = label;
-            args.meta[v] = t;
-            __hip_atomic_store(args.state + v, (uint64_t(want) << 32) | label, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        LP_CLOCK(8);
-    }
-#ifdef EM2_DIAG
-    diagAcc[9] = __builtin_amdgcn_s_memtime() - diagStart;
-    if (lane == 0u && args.diag) {
-        for (uint32_t i = 0; i < kDiagWords; ++i) atomicAdd(args.diag + i, (unsigned long long)diagAcc[i]);
-    }
-#endif
-    if (lane == 0u && changes) __hip_atomic_fetch_add(args.control + 1, changes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // The product's form of the turn (round 3).
 //
 // Measured with the diagnostic build (LP_CLOCK) at 1M vertices / 15M edges, on the older kernel: in the iterations with many
@@ -1769,8 +1561,6 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
     }
     clock.stage("adjacency");
 
-    const char* formText = getenv("EM2_LABEL_FORM");
-    const bool cachedForm = !(formText && strcmp(formText, "global") == 0);
     const uint64_t initialEntries = 2 * slots + 8ull * vertexCount;
     // Tables only grow (the reference never removes an entry either) and a table that fills up moves to the tail, so
     // the tail is sized generously and, should a graph whose labels keep churning outgrow it anyway, the whole run is
@@ -1787,14 +1577,13 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
     const bool hubs = maxDegree > 64u;
     Pool statePool;
     EM2_TRY(statePool.reserve(Pool::rounded(4 * size_t(vertexCount) * sizeof(uint32_t)) + Pool::rounded(size_t(vertexCount) * sizeof(uint64_t)) +
-                              Pool::rounded(cachedForm ? 2 * size_t(vertexCount) * sizeof(VertexRecord) : 0) +
+                              Pool::rounded(2 * size_t(vertexCount) * sizeof(VertexRecord)) +
                               Pool::rounded(3 * size_t(vertexCount) * sizeof(uint32_t)) + Pool::rounded(2 * size_t(vertexCount) * sizeof(uint32_t)) +
                               Pool::rounded(size_t(vertexCount) * sizeof(TableMeta)) + Pool::rounded(64) + Pool::rounded(kDiagWords * 8) +
-                              Pool::rounded(hubs && !cachedForm ? 2 * slots * sizeof(Candidate) : 0) +
                               Pool::rounded(hubs ? 4 * slots * sizeof(uint64_t) : 0)));
     EM2_TRY(dLabels.allocate(statePool, 4 * size_t(vertexCount) * sizeof(uint32_t)));
     EM2_TRY(dState.allocate(statePool, size_t(vertexCount) * sizeof(uint64_t)));
-    if (cachedForm) EM2_TRY(dRecords.allocate(statePool, 2 * size_t(vertexCount) * sizeof(VertexRecord)));
+    EM2_TRY(dRecords.allocate(statePool, 2 * size_t(vertexCount) * sizeof(VertexRecord)));
     EM2_TRY(dPositions.allocate(statePool, 3 * size_t(vertexCount) * sizeof(uint32_t)));
     EM2_TRY(dOrder.allocate(statePool, 2 * size_t(vertexCount) * sizeof(uint32_t)));
     EM2_TRY(dMeta.allocate(statePool, size_t(vertexCount) * sizeof(TableMeta)));
@@ -1803,7 +1592,6 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
     EM2_TRY(dDiag.allocate(statePool, kDiagWords * sizeof(unsigned long long)));
 #endif
     if (hubs) {
-        if (!cachedForm) EM2_TRY(dScratch.allocate(statePool, 2 * slots * sizeof(Candidate)));
         EM2_TRY(dSortKeys.allocate(statePool, 4 * slots * sizeof(uint64_t)));
     }
     // (the tables' arena stays an allocation of its own: a run whose tables outgrow it replaces it)
@@ -1817,16 +1605,14 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
     // (a GPU shared with another process); a strided run that times out is repeated that way, from the start.
     const char* batchText = getenv("EM2_LABEL_TICKET_BATCH");
     uint32_t ticketBatch = batchText && atoi(batchText) > 0 ? uint32_t(atoi(batchText)) : 0u;
-    int blocksPerUnit = 0;
-    // EM2_LABEL_SCHEDULE = unit (default) / strided; EM2_LABEL_TICKET_BATCH selects the global ticket (see the kernel)
-    const char* scheduleText = getenv("EM2_LABEL_SCHEDULE");
-    bool unitSchedule = cachedForm && ticketBatch == 0u && !(scheduleText && strcmp(scheduleText, "strided") == 0);
+    // a ticket per compute unit (kScheduleUnit) unless the global ticket is asked for or a unit's block does not fit the device
+    bool unitSchedule = ticketBatch == 0u;
     // 256-thread blocks: an area per wave.  Units of 16 waves: a pool of kUnitAreas, so that two units fit a compute unit.
     constexpr uint32_t kUnitAreas = 8;
     const size_t areaBytes4 = 4 * sizeof(WaveArea) + 64, areaBytes16 = kUnitAreas * sizeof(WaveArea) + 64;
     int unitsPerCu = 0;
     if (unitSchedule) {
-        // (a device that cannot hold a 16-wave block with its LDS areas takes the strided schedule)
+        // (a device that cannot hold a 16-wave block with its LDS areas takes the global ticket)
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(labelPropagationCachedKernel<kScheduleUnit>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(areaBytes16)) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&unitsPerCu, labelPropagationCachedKernel<kScheduleUnit>, 1024, areaBytes16) != hipSuccess ||
@@ -1836,9 +1622,9 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
         }
         unitsPerCu = std::min(unitsPerCu, 2);
     }
+    if (!unitSchedule && ticketBatch == 0u) ticketBatch = 4u;          // (no room for a unit's block: the global ticket)
     int smallBlocksPerUnit = 0;
-    if (cachedForm) EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&smallBlocksPerUnit, labelPropagationCachedKernel<kScheduleStrided>, 256, areaBytes4));
-    else EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&smallBlocksPerUnit, labelPropagationKernel, 256, 0));
+    EM2_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&smallBlocksPerUnit, labelPropagationCachedKernel<kScheduleTicket>, 256, areaBytes4));
     smallBlocksPerUnit = std::max(1, std::min(smallBlocksPerUnit, 4));
     // 256-thread blocks (strided or ticket schedule, the older kernel, the first tables) and one 1024-thread block per unit
     const dim3 grid(std::min<uint32_t>((vertexCount + 3u) / 4u, uint32_t(computeUnits) * uint32_t(smallBlocksPerUnit)));
@@ -1850,7 +1636,7 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
     // iteration t still reads those of t and t - 1
     uint32_t* position[3] = {dPositions.as<uint32_t>(), dPositions.as<uint32_t>() + vertexCount, dPositions.as<uint32_t>() + 2 * size_t(vertexCount)};
     uint32_t* orderOf[2] = {dOrder.as<uint32_t>(), dOrder.as<uint32_t>() + vertexCount};
-    VertexRecord* recordsOf[2] = {dRecords.as<VertexRecord>(), dRecords.as<VertexRecord>() + (cachedForm ? vertexCount : 0u)};
+    VertexRecord* recordsOf[2] = {dRecords.as<VertexRecord>(), dRecords.as<VertexRecord>() + vertexCount};
     uint32_t* control = dControl.as<uint32_t>();
     unsigned long long* arenaTop = reinterpret_cast<unsigned long long*>(control + 4);
     clock.stage("allocate");
@@ -1858,13 +1644,8 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
     auto upload = [&](uint64_t iteration) -> hipError_t {
         const uint32_t* order = orders->order(iteration);
         EM2_TRY(hipMemcpyAsync(orderOf[iteration & 1u], order, size_t(vertexCount) * sizeof(uint32_t), hipMemcpyHostToDevice, copies.stream));
-        if (cachedForm) {
-            recordPositionsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, copies.stream>>>(orderOf[iteration & 1u], vertexCount,
-                                                                                                 recordsOf[iteration & 1u]);
-        } else {
-            positionsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, copies.stream>>>(orderOf[iteration & 1u], vertexCount,
-                                                                                           position[iteration % 3u]);
-        }
+        recordPositionsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, copies.stream>>>(orderOf[iteration & 1u], vertexCount,
+                                                                                             recordsOf[iteration & 1u]);
         EM2_TRY(hipGetLastError());
         return hipEventRecord(copies.ready[iteration & 1u], copies.stream);
     };
@@ -1883,11 +1664,9 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
                                                         dWeight.as<float>(), dCells.as<uint32_t>(), dMeta.as<TableMeta>(),
                                                         dArena.as<TableEntry>(), label[0], dState.as<uint64_t>());
         EM2_TRY(hipGetLastError());
-        if (cachedForm) {
-            initialRecordsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, stream>>>(dCells.as<uint32_t>(), vertexCount, recordsOf[0],
-                                                                                         recordsOf[1]);
-            EM2_TRY(hipGetLastError());
-        }
+        initialRecordsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, stream>>>(dCells.as<uint32_t>(), vertexCount, recordsOf[0],
+                                                                                     recordsOf[1]);
+        EM2_TRY(hipGetLastError());
         const uint32_t zero[4] = {0, 0, 0, 0};
         EM2_TRY(hipMemcpyAsync(control, zero, sizeof(zero), hipMemcpyHostToDevice, stream));
         const unsigned long long top = initialEntries;
@@ -1941,9 +1720,7 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
             if (unitSchedule) {
                 labelPropagationCachedKernel<kScheduleUnit><<<unitGrid, dim3(64u * unitWaves), areaBytes16, stream>>>(args);
             }
-            else if (cachedForm && ticketBatch == 0u) labelPropagationCachedKernel<kScheduleStrided><<<grid, block, areaBytes4, stream>>>(args);
-            else if (cachedForm) labelPropagationCachedKernel<kScheduleTicket><<<grid, block, areaBytes4, stream>>>(args);
-            else labelPropagationKernel<<<grid, block, 0, stream>>>(args);
+            else labelPropagationCachedKernel<kScheduleTicket><<<grid, block, areaBytes4, stream>>>(args);
             EM2_TRY(hipGetLastError());
             ++iterations;
             // the next order goes up while this kernel runs -- if it has been drawn already: this iteration may be the last, and
@@ -2015,13 +1792,9 @@ static hipError_t runLabelPropagationBody(const uint32_t* vertexCellIds, uint32_
             *error = failure;
             return hipSuccess;
         }
-        if (cachedForm) {
-            recordLabelsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, stream>>>(recordsOf[iterations & 1u], vertexCount, label[0]);
-            EM2_TRY(hipGetLastError());
-            EM2_TRY(hipMemcpyAsync(labels, label[0], size_t(vertexCount) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        } else {
-            EM2_TRY(hipMemcpyAsync(labels, label[iterations & 3u], size_t(vertexCount) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        }
+        recordLabelsKernel<<<dim3((vertexCount + 255u) / 256u), block, 0, stream>>>(recordsOf[iterations & 1u], vertexCount, label[0]);
+        EM2_TRY(hipGetLastError());
+        EM2_TRY(hipMemcpyAsync(labels, label[0], size_t(vertexCount) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         EM2_TRY(hipStreamSynchronize(stream));
         clock.stage("labels to the host");
         return hipSuccess;

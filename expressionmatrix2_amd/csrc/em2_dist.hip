@@ -310,7 +310,7 @@ int em2_dist_find_similar_pairs4_with(const em2_collectives* c, const uint64_t* 
     timer.stage(EM2_DIST_MS_SCAN);
 
     // ---- what every rank sends to every rank, and whether anybody overflowed or failed: one small all_gather, one read-back ----
-    const bool routed = (world & (world - 1u)) == 0u && !(getenv("EM2_SHARDED_EXCHANGE") && getenv("EM2_SHARDED_EXCHANGE")[0] == 'g');
+    const bool routed = (world & (world - 1u)) == 0u;          // (the owner of a target cell is a bit field of the entry key)
     std::vector<uint64_t> mine(stride, 0), all(size_t(world) * stride, 0);
     if (routed && !overflow && localError == EM2_OK) {
         if (used) phase(4, used);
@@ -454,10 +454,14 @@ int em2_dist_find_similar_pairs4_with(const em2_collectives* c, const uint64_t* 
     // ---- the outcome is collective: a rank that failed behind the agreement has sent rows that mean nothing ----
     int32_t* dFailed = reinterpret_cast<int32_t*>(counts);                    // (the count matrix has served)
     int32_t failed = localError != EM2_OK ? 1 : 0;
-    EM2_DIST_HIP(hipMemcpyAsync(dFailed, &failed, 4u, hipMemcpyHostToDevice, stream));
+    // (nothing returns between the last all_to_all and this reduction: a rank whose device is in a sticky error -- the copy of its
+    // flag fails too -- still enters it, with whatever the word holds; its own error is what it returns)
+    recordHip(hipMemcpyAsync(dFailed, &failed, 4u, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(outcome flag)");
     if (c->all_reduce_max_i32(c->context, dFailed, 1, stream) != 0) return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: all_reduce of the outcome failed");
-    EM2_DIST_HIP(hipMemcpyAsync(&failed, dFailed, 4u, hipMemcpyDeviceToHost, stream));
-    EM2_DIST_HIP(hipStreamSynchronize(stream));
+    if (localError == EM2_OK) {
+        EM2_DIST_HIP(hipMemcpyAsync(&failed, dFailed, 4u, hipMemcpyDeviceToHost, stream));
+        EM2_DIST_HIP(hipStreamSynchronize(stream));
+    }
     timer.stage(EM2_DIST_MS_REDISTRIBUTE);
     if (localError != EM2_OK) return fail(localError, localMessage);
     if (failed) return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: another rank failed behind the ranks' agreement (phase 3 or the "

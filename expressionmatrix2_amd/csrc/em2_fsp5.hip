@@ -657,14 +657,14 @@ filterWideKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batc
 }
 
 // One wave per cell: keepBest(cellNeighbors, k) (:457), then SimilarPairs::copy + sort (:489-496), store.
-// CAPACITY entries are staged in LDS (12 bytes each).  The kernel is launched once per tier and batch and takes the
-// cells with ABOVE < candidates <= min(CAPACITY, upTo): the smaller the tier, the more waves a CU holds (see the launch
-// site).  (Without upTo the largest tier also cuts longer lists, by a single lane in HBM: round 1's form, kept for A/B.)
+// CAPACITY whole entries are staged in LDS (12 bytes each: the form for k beyond the packed tiers' 2048 and for more than
+// 65534 key classes).  The kernel is launched once per tier and batch and takes the cells with ABOVE < candidates <= CAPACITY:
+// the smaller the tier, the more waves a CU holds.
 template <uint32_t CAPACITY, uint32_t ABOVE>
 __global__ void __launch_bounds__(64)
 selectKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegin, Entry* __restrict__ lists,
              const uint32_t* __restrict__ listCounts, const float* __restrict__ keySimilarity, uint32_t k,
-             PairOut* __restrict__ outPairs, uint32_t* __restrict__ outUsed, uint32_t upTo = 0xffffffffu)
+             PairOut* __restrict__ outPairs, uint32_t* __restrict__ outUsed)
 {
     __shared__ Entry lds[CAPACITY];
     __shared__ uint16_t ldsL[CAPACITY];
@@ -674,57 +674,33 @@ selectKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegin, Ent
     if (local >= batchCells) return;
     Entry* list = lists + segmentBegin[local];
     uint32_t n = listCounts[local];
-    if (n <= ABOVE && ABOVE != 0u) return;              // the other launch's cells
-    if (ABOVE == 0u && n > CAPACITY) return;
-    if (n > upTo) return;                               // selectGlobalKernel's cells
-
-    Entry* work = list;
-    const bool inLds = n <= CAPACITY;
-    if (inLds) {
-        // (eight loads in flight before the first LDS store: see selectPackedKernel)
-        for (uint32_t base = 0; base < n; base += 64u * 8u) {
-            Entry staged[8];
+    if (n <= ABOVE || n > CAPACITY) return;             // another tier's cells (beyond the last tier: selectGlobalKernel's)
+    // (eight loads in flight before the first LDS store: see selectPackedKernel)
+    for (uint32_t base = 0; base < n; base += 64u * 8u) {
+        Entry staged[8];
 #pragma unroll
-            for (uint32_t j = 0; j < 8u; ++j) {
-                const uint32_t i = base + j * 64u + lane;
-                staged[j] = i < n ? list[i] : Entry();
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < 8u; ++j) {
-                const uint32_t i = base + j * 64u + lane;
-                if (i < n) lds[i] = staged[j];
-            }
+        for (uint32_t j = 0; j < 8u; ++j) {
+            const uint32_t i = base + j * 64u + lane;
+            staged[j] = i < n ? list[i] : Entry();
         }
-        work = lds;
-        waveFence();
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) {
+            const uint32_t i = base + j * 64u + lane;
+            if (i < n) lds[i] = staged[j];
+        }
     }
+    waveFence();
     if (n > k) {
-        if (inLds) nthElementWaveT<uint16_t, false, Entry, 4>(work, ldsL, ldsR, int(k), int(n), lane);
-        else if (lane == 0u) nthElement(work, int(k), int(n));
+        nthElementWaveT<uint16_t, false, Entry, 4>(lds, ldsL, ldsR, int(k), int(n), lane);
         n = k;
         waveFence();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");      // lane 0's HBM writes (long lists) visible to the wave
     }
     PairOut* out = outPairs + size_t(local) * k;
     for (uint32_t i = lane; i < n; i += 64u) {
-        Entry e;
-        if (inLds) {
-            e = work[i];
-        } else {
-            const uint64_t v = __hip_atomic_load(reinterpret_cast<const uint64_t*>(work + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            e.cell = uint32_t(v);
-            e.key = uint32_t(v >> 32);
-        }
+        const Entry e = lds[i];
         uint32_t rank = 0;
         for (uint32_t j = 0; j < n; ++j) {
-            Entry o;
-            if (inLds) {
-                o = work[j];
-            } else {
-                const uint64_t v = __hip_atomic_load(reinterpret_cast<const uint64_t*>(work + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                o.cell = uint32_t(v);
-                o.key = uint32_t(v >> 32);
-            }
+            const Entry o = lds[j];
             rank += uint32_t((o.key < e.key) || (o.key == e.key && o.cell < e.cell));
         }
         PairOut po;
@@ -911,7 +887,7 @@ selectGlobalKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegi
 // the process keeps between calls: hipMalloc of gigabytes costs anything between 4 and 200 ms per call depending on the state of
 // the box (measured: the same command, two leases), more than the tables' kernels.  A block goes back to the cache only when
 // the call completed (its stream synchronised); a call that returns early with an error frees its blocks (hipFree waits for the
-// device).  EM2_SCRATCH_CACHE_MB caps what is kept (default 32768; 0 = nothing is kept); em2_dev_release_scratch() frees it.
+// device).  EM2_SCRATCH_CACHE_MB caps what is kept (default: a sixteenth of the device's memory; 0 = nothing is kept); em2_dev_release_scratch() frees it.
 class ScratchCache {
 public:
     void* take(size_t bytes, int device, size_t* got)
@@ -962,9 +938,15 @@ private:
     struct Block { void* p; size_t bytes; int device; };
     static size_t capBytes()
     {
-        const char* v = getenv("EM2_SCRATCH_CACHE_MB");
-        const unsigned long long mb = v ? strtoull(v, nullptr, 10) : 32768ull;
-        return size_t(mb) << 20;
+        // what a host process can live with: a sixteenth of the device's memory (18 GB of an MI355X's 288: one call's scratch at
+        // a million cells x 2048 bits is 10 GB) unless EM2_SCRATCH_CACHE_MB says otherwise (0: nothing is kept)
+        if (const char* v = getenv("EM2_SCRATCH_CACHE_MB")) return size_t(strtoull(v, nullptr, 10)) << 20;
+        static size_t sixteenth = 0;
+        if (!sixteenth) {
+            size_t freeBytes = 0, totalBytes = 0;
+            sixteenth = hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && totalBytes ? totalBytes / 16u : size_t(4) << 30;
+        }
+        return sixteenth;
     }
     std::mutex mutex_;
     std::vector<Block> blocks_;
@@ -1110,10 +1092,9 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
                                                         cellCount, sliceCount, runStart.as<uint32_t>(), runOf.as<uint32_t>());
     EM2_TRY(hipGetLastError());
     stage("run tables");
-    // the labels that order the filter's visits (EM2_FSP5_ORDER=id keeps the id order: A/B measurements, tests), and in the same
-    // walk over the cells' bucket descriptors the number of members every cell will gather
-    const char* orderMode = getenv("EM2_FSP5_ORDER");
-    const bool grouped = !(orderMode && orderMode[0] == 'i');
+    // the labels that order the filter's visits, and in the same walk over the cells' bucket descriptors the number of members
+    // every cell will gather
+    const bool grouped = true;
     Buffer labelsA, labelsB;
     if (grouped) {
         EM2_TRY(labelsA.allocate(size_t(cellCount) * sizeof(uint32_t)));
@@ -1184,9 +1165,8 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
             hipEventCreate(&timing[2]) != hipSuccess) timing[0] = timing[1] = timing[2] = nullptr;
     }
     Buffer segBegin, candA, candB, lists, sortTemp, listCounts, distinctCounts;
-    // EM2_FSP5_UNION=sort keeps gatherKernel + the segmented sort (A/B measurements)
-    const char* unionMode = getenv("EM2_FSP5_UNION");
-    const bool useUnion = !(unionMode && unionMode[0] == 's') && sliceCount <= kUnionSlices;
+    // (more than kUnionSlices slices: gatherKernel + a segmented sort, round 2's form)
+    const bool useUnion = sliceCount <= kUnionSlices;
     uint32_t unionBlocks = 1;
     if (useUnion) {
         int device = 0, cuCount = 0, perCu = 0;
@@ -1219,12 +1199,10 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
     size_t sortTempBytes = 0;
     stage("batch plan + scratch allocation");
     const uint32_t idBits = bitsFor(cellCount - 1u);
-    // EM2_FSP5_FILTER=lane selects the one-lane-per-candidate filter (A/B measurements)
-    const char* filterMode = getenv("EM2_FSP5_FILTER");
-    const bool cooperative = words <= 8u * 16u && !(filterMode && filterMode[0] == 'l');
-    // EM2_FSP5_FILTER=cooperative keeps the 8-byte-load form (A/B measurements)
-    const bool wide = cooperative && words % 2u == 0u && words <= 64u && reinterpret_cast<uintptr_t>(d_sig) % 16u == 0u &&
-                      !(filterMode && filterMode[0] == 'c');
+    // the filter by shape: 16-byte loads for an even number of words up to 4096 bits, the 8-byte cooperative form for odd word
+    // counts and up to 8192 bits, one lane per candidate beyond
+    const bool cooperative = words <= 8u * 16u;
+    const bool wide = cooperative && words % 2u == 0u && words <= 64u && reinterpret_cast<uintptr_t>(d_sig) % 16u == 0u;
     for (const Batch& batch : batches) {
         const uint32_t batchBegin = batch.begin;
         const uint32_t batchCells = batch.end - batch.begin;
@@ -1241,7 +1219,7 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
             EM2_TRY(hipGetLastError());
             distinct = distinctCounts.as<uint32_t>();
         } else if (batchTotal) {
-            // EM2_FSP5_UNION=sort (A/B measurements): gather the buckets' members and sort each cell's segment
+            // more slices than unionKernel has descriptors for: gather the buckets' members and sort each cell's segment
             gatherKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(runOf.as<uint32_t>(), runStart.as<uint32_t>(), sortedCells, cellCount,
                                                                      sliceCount, bucketOverflow, batchBegin, batchCells,
                                                                      segBegin.as<uint32_t>(), candA.as<uint32_t>());
@@ -1307,21 +1285,13 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
         if (timing[0]) (void)hipEventRecord(timing[1], stream);
         // keepBest + sort + store, by list length: LDS tiers of 4096 / 5120 / 6144 / 8192 / 16384 entries with {key, position} in
         // 4 bytes + two position arrays (8 bytes per entry: 5, 4, 3, 2 and 1 wave per CU), beyond that the same wave-parallel
-        // selection on global memory.  EM2_FSP5_SELECT (A/B measurements): "unpacked" = tiers of 4096 / 5120 / 6656 / 12288
-        // whole entries (12 bytes each), "lds" = round 1's form (4096 and 12288, longer lists by a single lane in HBM),
-        // "global" = everything above 4096 in global memory (3.8x slower than the LDS tiers on config D: agent-scope fences).
-        const char* selectMode = getenv("EM2_FSP5_SELECT");
-        const char mode = selectMode ? selectMode[0] : 't';
+        // selection on global memory.  k above 2048 or more than 65534 key classes: tiers of 4096 / 5120 / 6656 / 12288 whole
+        // entries (12 bytes each).
         PairOut* outPairs = d_pairs + size_t(batchBegin - rowBegin) * k;
         uint32_t* outUsed = d_used + (batchBegin - rowBegin);
-#define EM2_SELECT_TIER(CAPACITY, ABOVE, UP_TO)                                                                                  \
-        selectKernel<CAPACITY, ABOVE><<<batchCells, 64, 0, stream>>>(batchCells, segBegin.as<uint32_t>(), lists.as<Entry>(),    \
-                                                                    listCounts.as<uint32_t>(), tables.keySimilarity, k, outPairs, \
-                                                                    outUsed, UP_TO);                                             \
-        EM2_TRY(hipGetLastError())
         uint32_t globalAbove = kSelectLdsEntriesBig;
         // (the packed tiers keep a key in 16 bits: lshCount + 1 key classes must fit)
-        const bool packed = mode != 'l' && mode != 'g' && mode != 'u' && k <= kSelectPackedMaxK && lshCount < 65535u;
+        const bool packed = k <= kSelectPackedMaxK && lshCount < 65535u;
         if (packed) {
 #define EM2_SELECT_PACKED(CAPACITY, ABOVE)                                                                                        \
             selectPackedKernel<CAPACITY, ABOVE><<<batchCells, 64, 0, stream>>>(batchCells, segBegin.as<uint32_t>(), lists.as<Entry>(), \
@@ -1336,20 +1306,18 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
 #undef EM2_SELECT_PACKED
             globalAbove = 16384u;
         } else {
-            EM2_SELECT_TIER(kSelectLdsEntries, 0u, 0xffffffffu);
-            if (mode == 'l') {
-                EM2_SELECT_TIER(kSelectLdsEntriesBig, kSelectLdsEntries, 0xffffffffu);
-                globalAbove = 0xffffffffu;
-            } else if (mode == 'g') {
-                globalAbove = kSelectLdsEntries;
-            } else {                                    // "unpacked", or k beyond what the packed tiers gather: whole entries
-                EM2_SELECT_TIER(5120u, kSelectLdsEntries, 5120u);
-                EM2_SELECT_TIER(6656u, 5120u, 6656u);
-                EM2_SELECT_TIER(kSelectLdsEntriesBig, 6656u, kSelectLdsEntriesBig);
-            }
-        }
+#define EM2_SELECT_TIER(CAPACITY, ABOVE)                                                                                         \
+            selectKernel<CAPACITY, ABOVE><<<batchCells, 64, 0, stream>>>(batchCells, segBegin.as<uint32_t>(), lists.as<Entry>(), \
+                                                                        listCounts.as<uint32_t>(), tables.keySimilarity, k, outPairs, \
+                                                                        outUsed);                                                \
+            EM2_TRY(hipGetLastError())
+            EM2_SELECT_TIER(kSelectLdsEntries, 0u);
+            EM2_SELECT_TIER(5120u, kSelectLdsEntries);
+            EM2_SELECT_TIER(6656u, 5120u);
+            EM2_SELECT_TIER(kSelectLdsEntriesBig, 6656u);
 #undef EM2_SELECT_TIER
-        if (globalAbove != 0xffffffffu) {
+        }
+        {
             selectGlobalKernel<<<(batchCells + 3u) / 4u, 256, 0, stream>>>(
                 batchCells, segBegin.as<uint32_t>(), lists.as<Entry>(), listCounts.as<uint32_t>(), tables.keySimilarity, k, globalAbove,
                 candA.as<uint32_t>(), candB.as<uint32_t>(), outPairs, outUsed);

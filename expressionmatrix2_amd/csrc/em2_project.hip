@@ -734,6 +734,7 @@ projectionScreenItemsKernel(const uint64_t* __restrict__ toc, const CountIn* __r
 // 3.84 MB at 30 000 genes: it stays in the XCD's L2 while its items are worked on.  The list is read once per slice of a
 // group (9 MB per reading at a million cells).  A bit that stays undecided sends its word to the exact tier's list, any other
 // goes into the signature (nobody else writes that word: a word is on exactly one of the two lists).
+constexpr uint32_t kProjectionBitsBlocks = 2048;       // the grid of projectionScreenBitsKernel: a multiple of 8 (a group per XCD)
 __global__ void __launch_bounds__(256)
 projectionScreenBitsKernel(const uint64_t* __restrict__ toc, const CountIn* __restrict__ data, uint32_t geneCount,
                            const float* __restrict__ vectors32, const double* __restrict__ vectorSums,
@@ -747,7 +748,9 @@ projectionScreenBitsKernel(const uint64_t* __restrict__ toc, const CountIn* __re
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t sub = lane & 7u, slot = lane >> 3;
     const uint32_t group = blockIdx.x & 7u;
-    const uint32_t wavesInGroup = (gridDim.x >> 3) * (blockDim.x >> 6);          // (the grid is a multiple of 8 blocks)
+    // (kProjectionBitsBlocks: the grid is a multiple of 8 blocks, one group of blocks per XCD; a grid below 8 would leave the
+    // stride at 0)
+    const uint32_t wavesInGroup = max(1u, gridDim.x >> 3) * (blockDim.x >> 6);
     const uint32_t waveInGroup = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t chunks = (count + 63u) / 64u;
     for (uint32_t slice = 2u * group; slice < 2u * wordCount; slice += (slice & 1u) ? 15u : 1u) {
@@ -943,14 +946,11 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
     cellStatsKernel<<<dim3((cellCount + 3u) / 4u), dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, means, sumAbs, workCount + 48);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // EM2_PROJECTION=screen keeps the one-block-per-1024-bits form (A/B measurements); default is the XCD-sliced form
-    // whenever the signature is a whole number of 32-bit slices.
-    const char* mode = getenv("EM2_PROJECTION");
-    const bool sliced = lshCount % 32u == 0u && !(mode && mode[0] == 's' && mode[1] == 'c');
-    // Default whenever the signature is a whole number of 64-bit words: the first tier on the 16-bit fixed-point copy (half
-    // the gathers), what it cannot decide to the float tier on the listed words, the rest of that to the exact arithmetic.
-    // EM2_PROJECTION=sliced / sliced16 / screen keep the float forms as the first tier (A/B measurements).
-    const bool quantizedTier = haveQuantizedCopy(lshCount) && (!mode || mode[0] == 'q');
+    // The first tier by shape: a whole number of 64-bit words -- the 16-bit fixed-point copy (half the gathers), what it cannot
+    // decide to the float tier on the listed words and bits, the rest of that to the exact arithmetic; a whole number of 32-bit
+    // slices -- the XCD-sliced float form; anything else -- one block per 1024 bits on the float copy.
+    const bool sliced = lshCount % 32u == 0u;
+    const bool quantizedTier = haveQuantizedCopy(lshCount);
     if (quantizedTier) {
         const double* scales = reinterpret_cast<const double*>(vectors32 + size_t(geneCount) * lshCount);
         const int16_t* quantized = reinterpret_cast<const int16_t*>(scales + lshCount);
@@ -966,12 +966,9 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
         const bool diagOff = true;
 #endif
         // (the work area holds 4 slots per word: [0, CW) the words for the float tier, [CW, 2 CW) the single bits for its per-bit
-        // form, [2 CW, 4 CW) what the two leave to the exact tier; EM2_PROJECTION_BITS=0 lists everything by words: A/B runs)
-        const char* bitsMode = getenv("EM2_PROJECTION_BITS");
-        const bool perBit = !(bitsMode && bitsMode[0] == '0');
-        // (EM2_PROJECTION_INTEGER=0: the float form for every matrix -- A/B measurements, tests)
-        const char* integerMode = getenv("EM2_PROJECTION_INTEGER");
-        const bool integerTier = diagOff && !(integerMode && integerMode[0] == '0');
+        // form, [2 CW, 4 CW) what the two leave to the exact tier)
+        const bool perBit = true;
+        const bool integerTier = diagOff;
         kernel<<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, quantized, scales, sums, maxAbs, means,
                                                                         sumAbs, lshCount, wordCount, signatures, workList, workCount,
                                                                         perBit ? workList + size_t(cellCount) * wordCount : nullptr, workCount + 32,
@@ -986,17 +983,10 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
     } else if (sliced) {
         e = hipMemsetAsync(signatures, 0, size_t(cellCount) * wordCount * sizeof(uint64_t), stream);    // halves nobody owns
         if (e != hipSuccess) return e;
-        const bool narrow = mode && mode[0] == 's' && mode[1] == 'l' && strstr(mode, "16") != nullptr;      // EM2_PROJECTION=sliced16
         const uint32_t cellBlocks = (cellCount + kCellsPerBlock - 1u) / kCellsPerBlock;
-        if (narrow) {
-            const dim3 grid(cellBlocks * 8u, (lshCount + 127u) / 128u);
-            projectionScreenSlicedKernel<16><<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, vectors32, sums, maxAbs, means, sumAbs,
-                                                                             lshCount, wordCount, signatures, workList, workCount);
-        } else {
-            const dim3 grid(cellBlocks * 8u, (lshCount + 255u) / 256u);
-            projectionScreenSlicedKernel<32><<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, vectors32, sums, maxAbs, means, sumAbs,
-                                                                             lshCount, wordCount, signatures, workList, workCount);
-        }
+        const dim3 grid(cellBlocks * 8u, (lshCount + 255u) / 256u);
+        projectionScreenSlicedKernel<32><<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, vectors32, sums, maxAbs, means, sumAbs,
+                                                                         lshCount, wordCount, signatures, workList, workCount);
     } else {
         const dim3 grid((cellCount + kCellsPerBlock - 1u) / kCellsPerBlock, (lshCount + 1023u) / 1024u);
         projectionScreenKernel<<<grid, dim3(256), 0, stream>>>(toc, data, cellCount, geneCount, vectors32, sums, maxAbs, means, sumAbs,
@@ -1013,7 +1003,8 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
                                                                           wordCount, signatures, workList, workCount, nextList, nextCount);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        projectionScreenBitsKernel<<<dim3(2048), dim3(256), 0, stream>>>(toc, data, geneCount, vectors32, sums, maxAbs, means, sumAbs, wordCount,
+        static_assert(kProjectionBitsBlocks % 8u == 0u && kProjectionBitsBlocks >= 8u, "projectionScreenBitsKernel: whole groups of 8 blocks");
+        projectionScreenBitsKernel<<<dim3(kProjectionBitsBlocks), dim3(256), 0, stream>>>(toc, data, geneCount, vectors32, sums, maxAbs, means, sumAbs, wordCount,
                                                                          signatures, workList + size_t(cellCount) * wordCount, workCount + 32,
                                                                          nextList, nextCount);
         e = hipGetLastError();

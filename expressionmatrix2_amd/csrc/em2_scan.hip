@@ -413,8 +413,6 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
     args.k = k;
     args.rowBegin = rowBegin;
     args.rowEnd = rowEnd;
-    args.departTicks = 0;
-    args.departWindow = 0;
     args.convoy = 0;
     args.rowFragmentBase = 0;
     args.rowState = nullptr;
@@ -448,10 +446,11 @@ hipError_t launchFsp4Scan(const uint32_t* sig32, uint32_t paddedDw, uint32_t cel
 #endif
 
     {
-        // EM2_SCAN_MODE=virtual + EM2_VIRTUAL_WORLD=P: the multi-GPU symmetric scan with all ranks played on this GPU
+        // EM2_SCAN_MODE=virtual:P -- the multi-GPU symmetric scan with all P ranks played on this GPU ("virtual" alone: 2)
         const char* mode = getenv("EM2_SCAN_MODE");
         if (mode && mode[0] == 'v' && rowBegin == 0 && rows == cellCount) {
-            uint64_t world = envNumber("EM2_VIRTUAL_WORLD", 2);
+            const char* colon = strchr(mode, ':');
+            uint64_t world = colon ? strtoull(colon + 1, nullptr, 10) : 2u;
             if (world < 1) world = 1;
             bool done = false;
             const hipError_t ev = runFsp4ShardedEmulation(sig32, paddedDw, cellCount, k, t, outPairs, outUsed, uint32_t(world), stream, &done);

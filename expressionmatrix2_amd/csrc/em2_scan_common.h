@@ -31,7 +31,7 @@ struct Fsp4Args {
     uint32_t k;
     uint32_t rowBegin;
     uint32_t rowEnd;
-    uint32_t departTicks;       // matrix form: an item's walk starts within departWindow of a multiple of this (100 MHz ticks); 0 = at once
+    uint32_t pad0;
     // persistent (segment-chained) variant only
     uint32_t* rowState;         // [rowBlocks*64][2] = {count, mMax} handed from one column segment to the next
     uint32_t* segmentsDone;     // [rowBlocks] number of finished column segments of the row block
@@ -61,7 +61,7 @@ struct Fsp4Args {
     // matrix-core form of the symmetric scan only (em2_scan_symmetric.hip)
     const void* fragments;      // the signatures as FP4 +-1 in MFMA fragment order, 512 B per cell
     uint32_t matrixLdsOffset;   // where the column tiles start in the block's dynamic LDS
-    uint32_t departWindow;      // (see departTicks)
+    uint32_t pad1;
     uint32_t convoy;            // matrix form: 0 = every walk starts at its segment's first column; 1 = a walk joins the walks of its XCD
                                 // where they are and wraps around (scanMatrixBody); n >= 2 (tests): every walk starts 64 (n - 1) columns in
     uint32_t rowFragmentBase;   // matrix form: the fragments of list / state slot 0's rows start this many 32-cell blocks into `fragments`
@@ -337,6 +337,13 @@ inline uint64_t envNumber(const char* name, uint64_t fallback)
     return end == v ? fallback : uint64_t(x);
 }
 
+
+// EM2_TIMING set (1: stages synchronised, 2: nothing synchronised): one line per launch of the scan on stderr as well.
+inline bool scanVerbose()
+{
+    const char* v = getenv("EM2_TIMING");
+    return v && (v[0] == '1' || v[0] == '2');
+}
 
 // The value of a measurement knob: 0 in the product, the environment variable in the diagnostic build.
 inline uint64_t diagNumber(const char* name)

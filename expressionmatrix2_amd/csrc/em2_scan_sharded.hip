@@ -201,10 +201,9 @@ fsp4TileKernel(Fsp4Args args)
 // fsp4TileKernel on the matrix cores (1024-bit signatures): tiles are (segment, quad of 4 row blocks), a block of 4
 // waves walks the columns of the segment below the quad in lock step (scanTilesMatrix, both sides deferred); the
 // quad's own 256 columns are done by the v_xor/v_bcnt code.  Prefix and segment lengths are multiples of 256 cells.
-template <bool PINNED, bool WIDE = false>
+template <bool WIDE = false>
 __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
 {
-    static_assert(!WIDE || PINNED, "the 2048-bit form has the hand-scheduled walk only");
     constexpr int W32 = WIDE ? 64 : 32;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -249,8 +248,7 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
         const uint32_t commonEnd = last ? quadRowBase : colEnd;
         const int32_t snapRow = rowValid ? aux->snap[row] : -1;
         if (colBegin < commonEnd) {
-            uint32_t unusedLogCount = 0;
-            if (PINNED) {
+            {
                 // the walk logs what passes either bound; both sides of every record go to the inbox afterwards
                 const uint32_t logCapacity = aux->logCapacity < kMatrixLogMargin ? kMatrixLogMargin : aux->logCapacity;
                 Entry* waveLog = aux->logs + size_t(blockIdx.x * 4u + wave) * 64u * logCapacity;
@@ -298,10 +296,6 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
                         }
                     }
                 }
-            } else {
-                scanTilesMatrix<true, true>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, colBegin, commonEnd,
-                                            2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), row, rowValid, lane, nullptr, 0u,
-                                            unusedLogCount, emitPos, emitEnd, tiles, shared);
             }
         }
         if (last && !idle) {
@@ -342,17 +336,10 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
 }
 
 __global__ void __launch_bounds__(256, 2)
-fsp4TileMatrixKernel(Fsp4Args args)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-    tileMatrixBody<false>(ldsRaw);
-}
-
-__global__ void __launch_bounds__(256, 2)
 fsp4TileMatrixPinnedKernel(Fsp4Args args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-    tileMatrixBody<true>(ldsRaw);
+    tileMatrixBody<false>(ldsRaw);
 }
 
 // 2048-bit signatures
@@ -360,7 +347,7 @@ __global__ void __launch_bounds__(256, 2)
 fsp4TileMatrixWideKernel(Fsp4Args args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-    tileMatrixBody<true, true>(ldsRaw);
+    tileMatrixBody<true>(ldsRaw);
 }
 
 // max over `count` arrays of `n` int32 laid out back to back (the emulation's stand-in for all_reduce(MAX))
@@ -718,8 +705,7 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             uint64_t blocksWanted = uint64_t(cuCount) * 2u;
             if (blocksWanted > own) blocksWanted = own;
             const void* tileMatrixKernel = wide ? reinterpret_cast<const void*>(&fsp4TileMatrixWideKernel)
-                                                : (matrixWalkPinned(2u) ? reinterpret_cast<const void*>(&fsp4TileMatrixPinnedKernel)
-                                                                        : reinterpret_cast<const void*>(&fsp4TileMatrixKernel));
+                                                : reinterpret_cast<const void*>(&fsp4TileMatrixPinnedKernel);
             e = hipFuncSetAttribute(tileMatrixKernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(matrixLds));
             if (e != hipSuccess) return e;
             void* matrixArgsArray[] = {&args};
@@ -815,7 +801,7 @@ __global__ void emulationOwnerBoundsKernel(const uint64_t* __restrict__ sorted, 
 }
 
 // All ranks of the sharded scan played one after the other on this GPU (tests; EM2_SCAN_MODE=virtual with
-// EM2_VIRTUAL_WORLD=P).  *done = false: not eligible or an entry pool overflowed; the caller runs the ordered scan.
+// EM2_SCAN_MODE=virtual:P).  *done = false: not eligible or an entry pool overflowed; the caller runs the ordered scan.
 hipError_t runFsp4ShardedEmulation(const uint32_t* sig32, uint32_t paddedDw, uint32_t cellCount, uint32_t k,
                                           const DeviceTables& t, PairOut* outPairs, uint32_t* outUsed, uint32_t world,
                                           hipStream_t stream, bool* done)
@@ -825,7 +811,7 @@ hipError_t runFsp4ShardedEmulation(const uint32_t* sig32, uint32_t paddedDw, uin
     for (uint32_t r = 0; r < world; ++r) plans.push_back(fsp4ShardPlan(cellCount, k, r, world));
     if (!plans[0].eligible) return hipSuccess;
     const Fsp4ShardPlan& p0 = plans[0];
-    const bool verbose = getenv("EM2_SCAN_VERBOSE") && getenv("EM2_SCAN_VERBOSE")[0] == '1';
+    const bool verbose = scanVerbose();
     // rank parts back to back, except that the snap arrays are laid out contiguously ([world][cellCount]) at the
     // end so that one kernel can play all_reduce(MAX)
     char* base = nullptr;
@@ -878,11 +864,9 @@ hipError_t runFsp4ShardedEmulation(const uint32_t* sig32, uint32_t paddedDw, uin
     uint64_t* gathered = reinterpret_cast<uint64_t*>(exchange + p0.offGathered - p0.rankBytes);
     // The exchange of the deferred candidates, as the product does it (csrc/em2_dist.hip, expressionmatrix2_amd/sharded.py): with a
     // power-of-two world every rank groups its pool by the owner of the target cell (phase 4) and the groups travel by
-    // all_to_all -- a rank receives, sorts and replays only the candidates of its own cells; otherwise (or with
-    // EM2_SHARDED_EXCHANGE=gather) every rank gathers every pool.  The routed form is played with device-to-device copies
+    // all_to_all -- a rank receives, sorts and replays only the candidates of its own cells; otherwise every rank gathers every pool.  The routed form is played with device-to-device copies
     // through one staging area per receiver; its grouping sort is timed as phase 4.
-    const bool routed = (world & (world - 1u)) == 0u && world > 1u &&
-                        !(getenv("EM2_SHARDED_EXCHANGE") && getenv("EM2_SHARDED_EXCHANGE")[0] == 'g');
+    const bool routed = (world & (world - 1u)) == 0u && world > 1u;
     std::vector<uint64_t> receivedEntries(world, 0);
     std::vector<size_t> phase4Events;
     char* staging = nullptr;

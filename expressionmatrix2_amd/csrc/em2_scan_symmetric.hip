@@ -301,7 +301,7 @@ widenSignaturesKernel(const uint32_t* __restrict__ sig32, uint32_t paddedDw, uin
 
 // TIMED (EM2_MATRIX_DIAG bit 2048, measurements only): every wave sums the shader-clock cycles it spends in the phases of
 // its items -- ticket, set-up, walk, hand-off wait, replay, the quad's own columns, publication -- and adds them to eight
-// 64-bit counters behind the inbox control words (printed by the launcher with EM2_SCAN_VERBOSE=1).
+// 64-bit counters behind the inbox control words (printed by the launcher with EM2_TIMING set).
 #define EM2_PHASE(index)                                                                                                       \
     do {                                                                                                                      \
         if (TIMED) {                                                                                                          \
@@ -310,12 +310,11 @@ widenSignaturesKernel(const uint32_t* __restrict__ sig32, uint32_t paddedDw, uin
             phaseStart = now_;                                                                                                \
         }                                                                                                                     \
     } while (0)
-template <bool IDENTITY, bool PINNED, bool WIDE = false, bool TIMED = false>
+template <bool IDENTITY, bool WIDE = false, bool TIMED = false>
 __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
 {
     uint64_t phaseCycles[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t phaseStart = TIMED ? __builtin_readcyclecounter() : 0ull;
-    static_assert(!WIDE || PINNED, "the 2048-bit form has the hand-scheduled walk only");
     constexpr int W32 = WIDE ? 64 : 32;                          // dwords per signature as the v_xor/v_bcnt parts read them
     constexpr float bits = WIDE ? 2.f * kMatrixBits : kMatrixBits;
     const uint32_t lane = threadIdx.x & 63u;
@@ -385,7 +384,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         const uint32_t row = rowBase + lane;
         const bool rowValid = !idle && row < aux->rowEnd;
         const uint32_t twoK = 2u * aux->k;
-        const uint32_t minLogCapacity = PINNED ? kMatrixLogMargin : 64u;
+        const uint32_t minLogCapacity = kMatrixLogMargin;
         uint32_t logCapacity = aux->logCapacity < minLogCapacity ? minLogCapacity : aux->logCapacity;
         Entry* myList = aux->buffers + (size_t(listBlock) * 64u + lane) * twoK;
         Entry* myLog = aux->logs + (size_t(blockIdx.x * 4u + wave) * 64u + lane) * logCapacity;
@@ -397,8 +396,8 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         // (a full row's last segment may end at a cell count that is no multiple of 32: the walk takes whole tiles)
         const uint32_t commonEnd = last ? quadRowBase : (fullRows ? colEnd & ~31u : colEnd);
         int32_t mMax = rowValid ? aux->mMaxInitial : -1;
-        uint32_t count = 0, logCount = 0;
-        uint32_t recordCount[2] = {0u, 0u};          // (hand-scheduled walk: the calling lane's records per accumulator)
+        uint32_t count = 0;
+        uint32_t recordCount[2] = {0u, 0u};          // (the calling lane's records per accumulator)
         bool haveState = seg == 0u;
         if (seg != 0u && !idle) {
             const uint32_t done = uint32_t(__builtin_amdgcn_readfirstlane(
@@ -415,25 +414,6 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
             }
         }
 
-        // ---- departures ----
-        // The blocks take their items whenever they finish the previous one, so the 64 blocks of an XCD walk the same
-        // segment's tiles at 64 different offsets, which its 4 MB L2 cannot hold together (47 % hits, 570 GB of fabric reads
-        // per launch at 1M cells).  With departTicks set, a walk starts only within departWindow ticks of a multiple of
-        // departTicks on the 100 MHz wall counter all blocks share: blocks that finish at about the same time leave together
-        // and follow each other through the tiles closely enough for the L2 to serve all but the first.  A block waits
-        // (asleep) for at most one period; order and content of everything it does are unchanged.
-        auto depart = [&]() {
-            if (threadIdx.x == 0u) {
-                const uint32_t period = aux->departTicks, window = aux->departWindow;
-                for (uint32_t spins = 0; spins < (1u << 16); ++spins) {
-                    if (uint32_t(__builtin_amdgcn_s_memrealtime() % period) < window) break;
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
-            __syncthreads();
-        };
-        if (PINNED && aux->departTicks != 0u && colBegin < commonEnd) depart();
-
         // ---- the convoy ----
         // The departures showed what the L2s can do when the walks of an XCD stay together, and what waiting for that costs.
         // Nobody waits here: a walk STARTS WHERE THE OTHERS ARE and goes around -- from its starting column to the segment's
@@ -448,7 +428,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         // and starts again at the segment's begin, as a walk without convoy (in the lower columns a stop is harmless: those
         // records are in order, they are replayed and removed).  Never at the bench's sizes (0 of 120 337 items stop at all).
         auto convoyStart = [&]() -> uint32_t {
-            return PINNED ? convoyStartColumn(aux, shared, seg, colBegin, commonEnd, ticket) : colBegin;
+            return convoyStartColumn(aux, shared, seg, colBegin, commonEnd, ticket);
         };
         bool failed = false;
         uint32_t start = convoyStart();         // (start == colBegin: a walk as ever)
@@ -464,7 +444,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                                                        bits - 2.f * float(mMax), rowHalf, myLog - size_t(lane) * logCapacity, logCapacity,
                                                        recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                        ldsAddress(walkBlock));
-                } else if (PINNED) {
+                } else {
                     if (EM2_DIAG_WORD(aux)) {
                         at = scanTilesMatrixPinned<IDENTITY, false, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, rangeEnd,
                                                          rowFragmentBlock, kMatrixBits - 2.f * float(mMax), myLog - size_t(lane) * logCapacity,
@@ -476,10 +456,6 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                                                          logCapacity, recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                          ldsAddress(walkBlock));
                     }
-                } else {
-                    at = scanTilesMatrix<IDENTITY>(static_cast<const FragmentWord4*>(aux->fragments), aux->snap, at, rangeEnd,
-                                                   rowFragmentBlock, kMatrixBits - 2.f * float(mMax), row, rowValid && !fullRows, lane, myLog,
-                                                   logCapacity, logCount, emitPos, emitEnd, tiles, shared);
                 }
             }
             EM2_PHASE(2);
@@ -495,7 +471,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
             }
             const bool stopped = at < rangeEnd;                           // (for its logs; the same in all waves of the block)
             if (TIMED && stopped) phaseCycles[7] += 1u;
-            if (stopped && PINNED && threadIdx.x == 0u && aux->convoy == 1u) {
+            if (stopped && threadIdx.x == 0u && aux->convoy == 1u) {
                 __hip_atomic_fetch_add(aux->inboxControl + kConvoyStopsWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (start != colBegin && !lower) {
@@ -530,7 +506,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
             }
             EM2_PHASE(3);
             // replay the log through the exact state machine (ascending column order per row)
-            if (PINNED) {
+            {
                 // (a walk that went around and stopped in its lower columns: those records only, the others stay)
                 const bool all = !(lower && stopped);
                 if (!idle && !failed) {
@@ -539,23 +515,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                 }
                 recordCount[0] = all ? 0u : firstRecord[0];
                 recordCount[1] = all ? 0u : firstRecord[1];
-            } else if (!idle && !failed) {
-                for (uint32_t i = 0;; ++i) {
-                    const bool active = i < logCount;
-                    if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
-                    uint32_t c = 0, m = 0;
-                    if (active) {
-                        const Entry e = myLog[i];
-                        c = e.cell;
-                        m = e.key;
-                    }
-                    const bool pass = active && int32_t(m) <= mMax;
-                    if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
-                        acceptColumn<IDENTITY>(pass, c, row, m, lane, listBlock, myList, twoK, count, mMax, ldsRaw);
-                    }
-                }
             }
-            logCount = 0;
             EM2_PHASE(4);
             if (at >= rangeEnd) {
                 if (!WIDE || rowHalf == 1u || colBegin >= commonEnd) break;
@@ -654,24 +614,15 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
 }
 #undef EM2_PHASE
 
-// The two entry points.  The kernel of the hand-scheduled walk lets the compiler allocate 64 vector registers only
-// (amdgpu_num_vgpr): v64..v255 hold the rows and the accumulators of the steps, which the compiler does not know
-// of -- this is what keeps its own code, the events of a tile included, out of them (the kernel descriptor still
-// asks for 256: the clobber lists of the steps count).
-template <bool IDENTITY>
-__global__ void __launch_bounds__(256, 2)
-fsp4ScanMatrixKernel(Fsp4Args args)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-    scanMatrixBody<IDENTITY, false>(ldsRaw);
-}
-
+// The entry points.  The compiler's own code in the walk (scanTilesMatrixPinned) lives in v0..v27: v28..v255 hold the rows,
+// the accumulators and the fragment ring of the steps, which the compiler does not know of (the kernel descriptor still asks for
+// 256 registers: the clobber lists of the steps count).
 template <bool IDENTITY>
 __global__ void __launch_bounds__(256, 2)
 fsp4ScanMatrixPinnedKernel(Fsp4Args args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-    scanMatrixBody<IDENTITY, true>(ldsRaw);
+    scanMatrixBody<IDENTITY>(ldsRaw);
 }
 
 // 2048-bit signatures (scanTilesMatrixWide)
@@ -680,7 +631,7 @@ __global__ void __launch_bounds__(256, 2)
 fsp4ScanMatrixWideKernel(Fsp4Args args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-    scanMatrixBody<IDENTITY, true, true>(ldsRaw);
+    scanMatrixBody<IDENTITY, true>(ldsRaw);
 }
 
 // (EM2_MATRIX_DIAG bit 2048: the same kernels with the phase timers, identity keys only)
@@ -689,7 +640,7 @@ __global__ void __launch_bounds__(256, 2)
 fsp4ScanMatrixTimedKernel(Fsp4Args args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-    scanMatrixBody<true, true, WIDE, true>(ldsRaw);
+    scanMatrixBody<true, WIDE, true>(ldsRaw);
 }
 
 // Second phase of the symmetric scan: one wave per triangle row block replays the sorted inbox entries of its 64
@@ -736,7 +687,7 @@ fsp4InboxReplayKernel(Fsp4Args args, const uint64_t* __restrict__ sorted, uint64
         bound[1] = lo1;
     }
     if (!rowValid) bound[1] = bound[0];
-    if (EM2_DIAG_WORD_OF(args) & 4096u) {        // (EM2_MATRIX_DIAG bit 4096: the longest inbox of a cell and of a wave's 64 cells, for EM2_SCAN_VERBOSE)
+    if (EM2_DIAG_WORD_OF(args) & 4096u) {        // (EM2_MATRIX_DIAG bit 4096: the longest inbox of a cell and of a wave's 64 cells, for the launcher's line)
         uint32_t longest = uint32_t(bound[1] - bound[0]);
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) longest = max(longest, uint32_t(__shfl_xor(int(longest), d, 64)));
@@ -777,7 +728,7 @@ fsp4InboxReplayKernel(Fsp4Args args, const uint64_t* __restrict__ sorted, uint64
 
 const void* scanMatrixKernelFor(bool identity, bool wide)
 {
-    if (identity && (diagNumber("EM2_MATRIX_DIAG") & 2048u) && (wide || matrixWalkPinned())) {
+    if (identity && (diagNumber("EM2_MATRIX_DIAG") & 2048u)) {
         return wide ? reinterpret_cast<const void*>(&fsp4ScanMatrixTimedKernel<true>)
                     : reinterpret_cast<const void*>(&fsp4ScanMatrixTimedKernel<false>);
     }
@@ -785,12 +736,8 @@ const void* scanMatrixKernelFor(bool identity, bool wide)
         return identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixWideKernel<true>)
                         : reinterpret_cast<const void*>(&fsp4ScanMatrixWideKernel<false>);
     }
-    if (matrixWalkPinned()) {
-        return identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixPinnedKernel<true>)
-                        : reinterpret_cast<const void*>(&fsp4ScanMatrixPinnedKernel<false>);
-    }
-    return identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<true>)
-                    : reinterpret_cast<const void*>(&fsp4ScanMatrixKernel<false>);
+    return identity ? reinterpret_cast<const void*>(&fsp4ScanMatrixPinnedKernel<true>)
+                    : reinterpret_cast<const void*>(&fsp4ScanMatrixPinnedKernel<false>);
 }
 
 
@@ -811,7 +758,7 @@ bool symmetricEligible(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
     // 1024-bit signatures take the matrix-core form, which wins much earlier (scan ms ordered / symmetric-matrix:
     // 30k cells 2.5 / 2.4, 60k 8.2 / 4.2, 100k 20.1 / 7.5)
     const bool matrix = matrixFormWanted(paddedDw) || matrixWideWanted(paddedDw);
-    return cellCount >= envNumber("EM2_SYMMETRIC_MIN_CELLS", matrix ? kSymmetricMatrixMinCells : kSymmetricMinCells);
+    return cellCount >= (matrix ? kSymmetricMatrixMinCells : kSymmetricMinCells);
 }
 
 static uint64_t inboxCapacity(uint32_t cellCount)
@@ -989,15 +936,13 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         }
     }
 
-    // Segments: as many as the column-count floor allows, up to kMaxSegments (EM2_SEGMENTS overrides): short
+    // Segments: as many as the column-count floor allows, up to kMaxSegments: short
     // segments keep the column snapshots fresh and even out the triangle.
     uint64_t minSegmentColumns = envNumber("EM2_MIN_SEGMENT_COLUMNS", 4096);
     if (minSegmentColumns < 1) minSegmentColumns = 1;
     const uint32_t maxSegments = matrix ? kMatrixMaxSegments : kMaxSegments;
     uint64_t segments = cellCount / minSegmentColumns;
     if (segments > maxSegments) segments = maxSegments;
-    const uint64_t forcedSegments = envNumber("EM2_SEGMENTS", 0);
-    if (forcedSegments >= 1 && forcedSegments <= maxSegments) segments = forcedSegments;
     if (segments < 1) segments = 1;
     uint32_t cps = uint32_t((uint64_t(cellCount) + segments - 1u) / segments);
     if (matrix) cps = (cps + 255u) & ~255u;
@@ -1033,7 +978,6 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         if (minColumns < 1) minColumns = 1;
         segmentsMatrix = cellCount / minColumns;
         if (segmentsMatrix > kMatrixMaxSegments) segmentsMatrix = kMatrixMaxSegments;
-        if (forcedSegments >= 1 && forcedSegments <= kMatrixMaxSegments) segmentsMatrix = forcedSegments;
         if (segmentsMatrix < 1) segmentsMatrix = 1;
         cpsMatrix = uint32_t((uint64_t(cellCount) + segmentsMatrix - 1u) / segmentsMatrix);
         cpsMatrix = (cpsMatrix + 255u) & ~255u;
@@ -1136,9 +1080,6 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         matrixArgs.totalTickets = uint32_t(ticketsMatrix);
         matrixArgs.fragments = ws + layout.fragments;
         matrixArgs.matrixLdsOffset = uint32_t((lds + 15u) & ~size_t(15));
-        // (EM2_MATRIX_DEPART_US / EM2_MATRIX_DEPART_WINDOW_US: period and window of the walks' departures, microseconds)
-        matrixArgs.departTicks = uint32_t(envNumber("EM2_MATRIX_DEPART_US", 0) * 100u);
-        matrixArgs.departWindow = uint32_t(envNumber("EM2_MATRIX_DEPART_WINDOW_US", envNumber("EM2_MATRIX_DEPART_US", 0) / 4u) * 100u);
         // (EM2_MATRIX_CONVOY: 0 = every walk from its segment's first column, 1 = the walks of an XCD go around together,
         // n >= 2: every walk starts 64 (n - 1) columns into its segment -- the tests' way to the same code)
         matrixArgs.convoy = uint32_t(envNumber("EM2_MATRIX_CONVOY", 1));
@@ -1161,9 +1102,9 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         uint64_t blocksWanted = uint64_t(cuCount) * uint64_t(blocksPerCu);
         if (blocksWanted * 4u > maxResidentWaves()) blocksWanted = maxResidentWaves() / 4u;      // the logs are sized for that
         if (blocksWanted > ticketsMatrix) blocksWanted = ticketsMatrix;
-        if (const char* v = getenv("EM2_SCAN_VERBOSE")) {
-            if (v[0] == '1') fprintf(stderr, "[em2] matrix kernel: %d blocks per CU, %llu blocks, %zu bytes of LDS, walk %s\n", blocksPerCu,
-                                     (unsigned long long)blocksWanted, matrixLds, matrixWalkPinned() ? "pinned" : "compiler");
+        if (scanVerbose()) {
+            fprintf(stderr, "[em2] matrix kernel: %d blocks per CU, %llu blocks, %zu bytes of LDS\n", blocksPerCu,
+                                     (unsigned long long)blocksWanted, matrixLds);
         }
         void* matrixArgsArray[] = {&matrixArgs};
         if (timing[0]) (void)hipEventRecord(timing[2], stream);
@@ -1231,8 +1172,8 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         lastLaunchInfo.segments = double(segments);
         lastLaunchInfo.fullRowCells = double(fullCellsClamped);
     }
-    if (const char* v = getenv("EM2_SCAN_VERBOSE")) {
-        if (v[0] == '1') fprintf(stderr, "[em2] symmetric scan%s: %u segments x %u columns, %u full-row blocks, %llu + %llu tickets, %llu inbox slots\n",
+    if (scanVerbose()) {
+        fprintf(stderr, "[em2] symmetric scan%s: %u segments x %u columns, %u full-row blocks, %llu + %llu tickets, %llu inbox slots\n",
                                  matrix ? " (matrix cores)" : "", uint32_t(matrix ? segmentsMatrix : segments), matrix ? cpsMatrix : cps, fullRowBlocks,
                                  (unsigned long long)tickets, (unsigned long long)(matrix ? ticketsMatrix : 0), (unsigned long long)used);
     }
@@ -1335,8 +1276,6 @@ hipError_t launchFsp4ScanRowsMatrix(Fsp4Args args, uint32_t paddedDw, bool ident
     if (minColumns < 1) minColumns = 1;
     uint64_t segments = cellCount / minColumns;
     if (segments > kMatrixMaxSegments) segments = kMatrixMaxSegments;
-    const uint64_t forcedSegments = envNumber("EM2_SEGMENTS", 0);
-    if (forcedSegments >= 1 && forcedSegments <= kMatrixMaxSegments) segments = forcedSegments;
     if (segments < 1) segments = 1;
     uint32_t cps = uint32_t((uint64_t(cellCount) + segments - 1u) / segments);
     cps = (cps + 255u) & ~255u;
@@ -1382,8 +1321,6 @@ hipError_t launchFsp4ScanRowsMatrix(Fsp4Args args, uint32_t paddedDw, bool ident
     args.shardFlags = 0;
     args.fragments = fragmentArea;
     args.matrixLdsOffset = uint32_t(matrixLdsOffset);
-    args.departTicks = 0;
-    args.departWindow = 0;
     args.convoy = uint32_t(envNumber("EM2_MATRIX_CONVOY", 1));
     if (cps / 64u > kConvoyMaxPairs && args.convoy == 1u) args.convoy = 0u;       // (positions have 12 bits)
 
@@ -1429,8 +1366,8 @@ hipError_t launchFsp4ScanRowsMatrix(Fsp4Args args, uint32_t paddedDw, bool ident
         if (e != hipSuccess) return e;
         args.rowFragmentBase = uint32_t(size_t(rowFragmentArea - fragmentArea) / (32u * bytesPerCell));
     }
-    if (const char* v = getenv("EM2_SCAN_VERBOSE")) {
-        if (v[0] == '1') fprintf(stderr, "[em2] rows form on the matrix cores: rows [%u, %u), %u segments x %u columns, %llu tickets, %llu blocks, "
+    if (scanVerbose()) {
+        fprintf(stderr, "[em2] rows form on the matrix cores: rows [%u, %u), %u segments x %u columns, %llu tickets, %llu blocks, "
                                          "row fragments %s\n", args.rowBegin, args.rowEnd, uint32_t(segments), cps, (unsigned long long)tickets,
                                  (unsigned long long)blocksWanted, args.rowBegin % 32u == 0u ? "in the columns' array" : "expanded once more");
     }

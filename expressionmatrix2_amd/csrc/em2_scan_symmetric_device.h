@@ -275,171 +275,9 @@ constexpr float kMatrixBits = 1024.f;
 // matrix form: 512 bits 486 / 274, 256 bits 349 / 302 (the zero-extended fragments cost the full 16 k-steps).
 constexpr uint32_t kMatrixMinPaddedDw = 8;
 
-// emitColumn for the walk below: the pool pointer and the key layout arrive in registers (emitColumn re-reads them
-// from the kernarg segment on purpose, which costs the matrix kernel a scalar-load round trip per event); only a chunk
-// that is used up goes through the out-of-line path.
-__device__ __forceinline__ void emitColumnFast(bool emit, uint32_t target, uint32_t candidate, uint32_t m, uint32_t lane,
-                                               uint32_t& emitPos, uint32_t& emitEnd, uint64_t* inbox, uint32_t rowBits)
-{
-    const uint64_t mask = __builtin_amdgcn_ballot_w64(emit);
-    if (mask == 0ull) return;
-    const uint32_t p = uint32_t(__builtin_amdgcn_readfirstlane(int(emitPos)));
-    const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(emitEnd)));
-    const uint32_t n = uint32_t(__builtin_popcountll(mask));
-    if (p > e || p + n > e) {
-        emitColumn(emit, target, candidate, m, lane, emitPos, emitEnd);      // disabled after an overflow, or a new chunk
-        return;
-    }
-    if (emit) inbox[p + lanesBelow(mask)] = (uint64_t(target) << (13u + rowBits)) | (uint64_t(candidate) << 13u) | uint64_t(m);
-    emitPos = p + n;
-}
-
-// The lock-step walk over the tiles [colBegin, colEnd) (multiples of 32).  Returns the first column not scanned, the
-// same in all waves of the block: the walk ends early, at a tile boundary, when some row's log could overflow in the
-// next tile.  stopWords: 3 LDS words, zero on entry and on return.
-// BOTH (the tile kernel of the sharded scan): the row side is deferred to the inbox as well, nothing is logged and the
-// walk never stops early.
-template <bool IDENTITY, bool BOTH = false>
-__device__ __forceinline__ uint32_t scanTilesMatrix(const FragmentWord4* __restrict__ fragments, const int32_t* snap,
-                                                    uint32_t colBegin, uint32_t colEnd, uint32_t rowFragmentBlock,
-                                                    float rowDot, uint32_t row, bool rowValid, uint32_t lane,
-                                                    Entry* myLog, uint32_t logCapacity, uint32_t& logCount,
-                                                    uint32_t& emitPos, uint32_t& emitEnd, FragmentWord4* tiles,
-                                                    volatile uint32_t* stopWords)
-{
-    const int scale = 0x7f7f7f7f;                // E8M0 127 = 2^0 in every byte
-    uint64_t* const inbox = kernelArgs()->inbox;
-    const uint32_t rowBits = kernelArgs()->rowBits;
-    FragmentWord4 rows[2][kMatrixSteps];
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-#pragma unroll
-        for (int s = 0; s < int(kMatrixSteps); s++) {
-            rows[t][s] = fragments[(size_t(rowFragmentBlock + uint32_t(t)) * kMatrixSteps + uint32_t(s)) * 64u + lane];
-        }
-    }
-    // A tile travels global -> LDS without touching registers (global_load_lds_dwordx4: the LDS address is the wave's
-    // base + lane * 16, which is exactly the fragment order).  Two tiles (64 columns) per barrier: the four waves may
-    // drift by a tile, which absorbs the difference between a tile with events and one without; the pair after the one
-    // being contracted is on its way meanwhile.
-    const uint32_t waveSlot = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))) * 64u;
-#define EM2_STAGE_TILE(tileIndex, buffer)                                                                                     \
-    do {                                                                                                                      \
-        const FragmentWord4* src_ = fragments + size_t(tileIndex) * kMatrixTileWords + threadIdx.x;                          \
-        FragmentWord4* dst_ = tiles + (buffer) * kMatrixTileWords + waveSlot;                                                \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) {                                                                   \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + j_ * 256),              \
-                                             (__attribute__((address_space(3))) void*)(dst_ + j_ * 256), 16, 0, 0);          \
-        }                                                                                                                     \
-    } while (0)
-    EM2_STAGE_TILE(colBegin / 32u, 0u);
-    if (colBegin + 32u < colEnd) EM2_STAGE_TILE(colBegin / 32u + 1u, 1u);
-    __syncthreads();
-    uint32_t iteration = 0;
-    // The bounds of columns (lane & 31) of the two tiles, fetched one pair ahead like the fragments (the compiler sinks
-    // a load placed in front of the MFMAs to its first use behind them, and the wave then sits out a global-load latency
-    // per tile).  Any value a cell published earlier is valid: bounds only tighten.
-    int32_t snapAhead[2];
-    snapAhead[0] = snap[colBegin + (lane & 31u)];
-    snapAhead[1] = colBegin + 32u < colEnd ? snap[colBegin + 32u + (lane & 31u)] : 0;
-    for (uint32_t colBase = colBegin; colBase < colEnd; colBase += 64u, ++iteration) {
-        const uint32_t pair = iteration & 1u;
-        const int32_t snapLane[2] = {snapAhead[0], snapAhead[1]};
-        if (colBase + 64u < colEnd) {
-            EM2_STAGE_TILE(colBase / 32u + 2u, 2u * (pair ^ 1u));
-            snapAhead[0] = snap[colBase + 64u + (lane & 31u)];
-        }
-        if (colBase + 96u < colEnd) {
-            EM2_STAGE_TILE(colBase / 32u + 3u, 2u * (pair ^ 1u) + 1u);
-            snapAhead[1] = snap[colBase + 96u + (lane & 31u)];
-        }
-#pragma unroll
-        for (int sub = 0; sub < 2; sub++) {
-            const uint32_t tileBase = colBase + 32u * uint32_t(sub);
-            if (tileBase >= colEnd) break;
-            const float columnDotLane = kMatrixBits - 2.f * float(snapLane[sub]);
-            Accumulator16 acc0 = {}, acc1 = {};
-            const FragmentWord4* tile = tiles + (2u * pair + uint32_t(sub)) * kMatrixTileWords;
-            // column fragments four k-steps ahead of their MFMAs (the LDS latency of a read is two MFMA pairs long)
-            FragmentWord4 ahead[4];
-#pragma unroll
-            for (int s = 0; s < 4; s++) ahead[s] = tile[s * 64 + int(lane)];
-            __builtin_amdgcn_s_setprio(2);          // the SIMD's other wave is in its column tests: MFMAs first
-#pragma unroll
-            for (int s = 0; s < int(kMatrixSteps); s++) {
-                const FragmentWord4 a = ahead[s & 3];
-                if (s + 4 < int(kMatrixSteps)) ahead[s & 3] = tile[(s + 4) * 64 + int(lane)];
-                const FragmentWord8 a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
-                const FragmentWord8 b0 = {rows[0][s].x, rows[0][s].y, rows[0][s].z, rows[0][s].w, 0, 0, 0, 0};
-                const FragmentWord8 b1 = {rows[1][s].x, rows[1][s].y, rows[1][s].z, rows[1][s].w, 0, 0, 0, 0};
-                acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, acc0, 4, 4, 0, scale, 0, scale);
-                acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, acc1, 4, 4, 0, scale, 0, scale);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            // lane = row: acc0[i] <- column (i&3) + 8*(i>>2), acc1[i] <- that + 4
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const auto swapped = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[i]), __float_as_uint(acc1[i]), false, false);
-                acc0[i] = __uint_as_float(swapped[0]);
-                acc1[i] = __uint_as_float(swapped[1]);
-            }
-            // Four columns per branch: the per-column compares are OR-ed as lane masks on the scalar unit, and only a group
-            // in which something passes looks at its columns one by one (a branch per column cost more than the compares:
-            // 1.6 -> 2.4 * 10^12 pairs/s in tools/ubench_mfma_pairs.hip, where nothing ever passes and groups are 8 wide; here
-            // about two events per tile make 4 the best width).
-#pragma unroll
-            for (int g = 0; g < 32 / kColumnsPerBranch; g++) {
-                float columnDots[kColumnsPerBranch];
-                bool any = false;
-#pragma unroll
-                for (int w = 0; w < kColumnsPerBranch; w++) {
-                    const int c = kColumnsPerBranch * g + w;       // column c sits in acc0 / acc1 as the swaps left it
-                    const float dot = (c & 7) < 4 ? acc0[4 * (c >> 3) + (c & 7)] : acc1[4 * (c >> 3) + (c & 7) - 4];
-                    columnDots[w] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(columnDotLane), c));
-                    // min(rowDot, columnDot) as one v_med3_f32 (fminf would canonicalise both inputs first)
-                    any |= dot >= __builtin_amdgcn_fmed3f(rowDot, columnDots[w], -INFINITY);
-                }
-                if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
-#pragma unroll
-                for (int w = 0; w < kColumnsPerBranch; w++) {
-                    const int c = kColumnsPerBranch * g + w;       // column c sits in acc0 / acc1 as the swaps left it
-                    const float dot = (c & 7) < 4 ? acc0[4 * (c >> 3) + (c & 7)] : acc1[4 * (c >> 3) + (c & 7) - 4];
-                    const float columnDot = columnDots[w];
-                    if (__builtin_amdgcn_ballot_w64(dot >= __builtin_amdgcn_fmed3f(rowDot, columnDot, -INFINITY)) != 0ull) {
-                        const uint32_t col = tileBase + uint32_t(c);
-                        const uint32_t m = uint32_t((kMatrixBits - dot) * 0.5f);
-                        emitColumnFast(rowValid && dot >= columnDot, col, row, m, lane, emitPos, emitEnd, inbox, rowBits);
-                        if (BOTH) {
-                            emitColumnFast(rowValid && dot >= rowDot, row, col, m, lane, emitPos, emitEnd, inbox, rowBits);
-                        } else if (dot >= rowDot) {
-                            storeEntry(myLog + logCount, col, m);
-                            ++logCount;
-                        }
-                    }
-                }
-            }
-        }
-        // a pair of tiles adds at most 64 entries to a row's log
-        const bool full = !BOTH && __builtin_amdgcn_ballot_w64(logCount + 64u > logCapacity) != 0ull;
-        const uint32_t slot = iteration % 3u;
-        if (full && lane == 0u) stopWords[slot] = 1u;
-        if (threadIdx.x == 0u) stopWords[(iteration + 1u) % 3u] = 0u;
-        __syncthreads();
-        if (stopWords[slot] != 0u) {
-            __syncthreads();
-            if (threadIdx.x == 0u) stopWords[slot] = 0u;
-            __syncthreads();
-            return colBase + 64u < colEnd ? colBase + 64u : colEnd;
-        }
-    }
-#undef EM2_STAGE_TILE
-    return colEnd;
-}
-
 // =========================================================================================================
-// The same walk with the tile step in hand-scheduled assembly (em2_matrix_step_asm.h, written by
-// tools/gen_matrix_step_asm.py) -- the form the kernels use; scanTilesMatrix above is kept for A/B runs
-// (EM2_MATRIX_WALK=0).  What changes against it:
+// The walk: the tile step is hand-scheduled assembly (em2_matrix_step_asm.h, written by tools/gen_matrix_step_asm.py).
+// Against round 1's compiler-scheduled walk (git history: scanTilesMatrix, 251 ms where this one takes 172):
 //  * the 32 MFMAs of a tile are fed through a four-deep ring of column fragments with counted lgkmcnt waits: one
 //    wave alone keeps the matrix pipe of its SIMD busy (the compiler's schedule of the loop above waits for
 //    lgkmcnt(0) in front of every second k-step);
@@ -560,7 +398,16 @@ __device__ __forceinline__ uint32_t convoyStartColumn(ArgsPtr aux, volatile uint
                                                       uint32_t commonEnd, uint32_t ticket)
 {
     const uint32_t mode = aux->convoy;
-    if (mode == 0u || colBegin + 128u >= commonEnd) return colBegin;
+    if (mode == 0u || colBegin + 128u >= commonEnd) {
+        // (no convoy for this item: the words of the block's previous item must not make its walk publish or go around)
+        if (threadIdx.x == 0u) {
+            shared[kConvoyCodeWord] = 0u;
+            shared[kWrapBeginWord] = 0u;
+            shared[kWrapEndWord] = 0u;
+        }
+        __syncthreads();
+        return colBegin;
+    }
     if (threadIdx.x == 0u) {
         uint32_t* word = aux->inboxControl + kConvoyWordsOffset + 2u * (blockIdx.x & 7u) + (seg & 1u);
         const uint32_t code = (seg + 1u) << 20;
@@ -1190,10 +1037,6 @@ static size_t scanMatrixLdsBytes(uint32_t k)
     return kMatrixLdsBytes - (matrixWalkAliasesSelection(k) ? 4u * kMatrixWalkLdsBytes : 0u);
 }
 
-// EM2_MATRIX_WALK=0 keeps the compiler-scheduled walk (scanTilesMatrix) for A/B runs.
-// (bit 0: fsp4ScanMatrixKernel, bit 1: fsp4TileMatrixKernel; default both)
-static bool matrixWalkPinned(uint32_t which = 1u) { return (envNumber("EM2_MATRIX_WALK", 3) & which) != 0; }
-
 constexpr uint32_t kSymmetricMinCells = 131072;
 constexpr uint32_t kSymmetricMatrixMinCells = 32768;
 constexpr uint32_t kMaxSegments = 64;
@@ -1204,20 +1047,21 @@ constexpr uint32_t kInboxChunk = 512;
 // Which signature widths take the matrix-core form of the triangle.  The fragments are always 1024 bits wide: a
 // narrower signature is zero-extended (a zero bit is +1 on both sides, so the dot product stays 1024 - 2 * mismatches),
 // which costs the full 16 k-steps per tile whatever the width.  EM2_SCAN_MATRIX: 0 never, 1 (default) the widths it
-// is faster for (129..1024 bits, kMatrixMinPaddedDw), 2 every width up to 1024 bits (tests).
+// is faster for (129..1024 bits, kMatrixMinPaddedDw), 2 every width up to 1024 bits (tests), 3 = 1 without the 2048-bit form.
 static bool matrixFormWanted(uint32_t paddedDw)
 {
     const uint64_t mode = envNumber("EM2_SCAN_MATRIX", 1);
     if (mode == 0 || paddedDw > 32u) return false;
-    return mode >= 2 || paddedDw >= kMatrixMinPaddedDw;
+    return mode == 2 || paddedDw >= kMatrixMinPaddedDw;
 }
 
 // 1025..2048-bit signatures (64 dwords as the scan sees them): the 2048-bit form of the matrix kernel
-// (fsp4ScanMatrixWideKernel: 32 rows per wave and pass, two passes).  EM2_SCAN_MATRIX=0 / EM2_SCAN_MATRIX_WIDE=0 keep
+// (fsp4ScanMatrixWideKernel: 32 rows per wave and pass, two passes).  EM2_SCAN_MATRIX=0 / 3 keep
 // the v_xor/v_bcnt form.
 static bool matrixWideWanted(uint32_t paddedDw)
 {
-    return paddedDw == 64u && envNumber("EM2_SCAN_MATRIX", 1) != 0 && envNumber("EM2_SCAN_MATRIX_WIDE", 1) != 0;
+    const uint64_t mode = envNumber("EM2_SCAN_MATRIX", 1);
+    return paddedDw == 64u && mode != 0 && mode != 3;
 }
 
 static size_t inboxSortTempBytes(uint64_t capacity)

@@ -102,9 +102,8 @@ class DevicePipeline:
                                              plan["sorted_offset"] + 8 * plan["gathered_capacity"]].view(torch.int64)
             self.count_buf = torch.zeros(2, dtype=torch.int64, device=device)
             # entries travel by all_to_all (each rank receives only the candidates of its own cells) when the owner
-            # of a target cell is a bit field of the entry key; EM2_SHARDED_EXCHANGE=gather keeps the all_gather
-            self.exchange_all_to_all = ((world_size & (world_size - 1)) == 0 and
-                                        os.environ.get("EM2_SHARDED_EXCHANGE", "alltoall") != "gather")
+            # of a target cell is a bit field of the entry key (a power-of-two world); otherwise the pools are all_gathered
+            self.exchange_all_to_all = (world_size & (world_size - 1)) == 0
         else:
             self._allocate_row_shard_scan()
         self.proj_ws_bytes = capi.dev_compute_signatures_workspace(max(1, self.rows), lsh_count)

@@ -51,6 +51,18 @@ def test_product_library_has_no_measurement_knobs(lib):
     assert "-DEM2_DIAG" in makefile and "libem2lsh_diag.so" in makefile
 
 
+def test_product_library_reads_few_environment_variables(lib):
+    """Test knobs that force rare paths at small sizes, and nothing else: at most 20 EM2_* names in the product library (round 4
+    had 38, a third of them A/B partners of measurements long settled), every one of them in DESIGN.md's table."""
+    blob = open(capi.LIBRARY_PATH, "rb").read()
+    names = sorted(set(m.decode() for m in re.findall(rb"EM2_[A-Z0-9_]+", blob)))
+    assert len(names) <= 20, names
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for name in names:
+        assert "`%s`" % name in design, name
+    assert os.path.getsize(capi.LIBRARY_PATH) < 10 * 1024 * 1024
+
+
 def test_generate_vectors_matches_oracle(lib, oracle):
     for genes, L, seed in [(7, 64, 231), (50, 128, 231), (33, 100, 5), (1, 1, 9)]:
         a = capi.lsh_generate_vectors(genes, L, seed)
@@ -103,21 +115,18 @@ def test_device_paths_fail_loudly_without_gpu(lib):
 
 def test_scan_form_query_knows_about_the_matrix_cores(lib, monkeypatch):
     # em2_dev_find_similar_pairs4_form_for: 129..2048-bit signatures take the symmetric form on the matrix cores (3) from
-    # 32768 cells on (EM2_SCAN_MATRIX=2: every width up to 2048; EM2_SCAN_MATRIX_WIDE=0: none above 1024), other widths the
+    # 32768 cells on (EM2_SCAN_MATRIX=2: every width up to 2048; 3: none above 1024), other widths the
     # v_xor/v_bcnt symmetric form (1) from 131072 cells on; a row shard is never symmetric.
     monkeypatch.delenv("EM2_SCAN_MODE", raising=False)
     monkeypatch.delenv("EM2_SCAN_MATRIX", raising=False)
-    monkeypatch.delenv("EM2_SCAN_MATRIX_WIDE", raising=False)
-    monkeypatch.delenv("EM2_SYMMETRIC_MIN_CELLS", raising=False)
     f = lib.em2_dev_find_similar_pairs4_form_for
     assert f(100000, 100000, 1024) == 3 and f(100000, 100000, 600) == 3
     assert f(20000, 20000, 1024) == 0
     assert f(100000, 100000, 512) == 3 and f(100000, 100000, 129) == 3
     assert f(100000, 100000, 128) == 0 and f(200000, 200000, 128) == 1 and f(200000, 200000, 4096) == 1
     assert f(100000, 100000, 2048) == 3 and f(100000, 100000, 1025) == 3 and f(20000, 20000, 2048) == 0
-    monkeypatch.setenv("EM2_SCAN_MATRIX_WIDE", "0")
+    monkeypatch.setenv("EM2_SCAN_MATRIX", "3")
     assert f(100000, 100000, 2048) == 0 and f(200000, 200000, 2048) == 1 and f(100000, 100000, 1024) == 3
-    monkeypatch.delenv("EM2_SCAN_MATRIX_WIDE")
     monkeypatch.setenv("EM2_SCAN_MATRIX", "2")
     assert f(100000, 100000, 64) == 3 and f(200000, 200000, 2048) == 3 and f(200000, 200000, 3000) == 1
     # a shard of the rows (never symmetric) takes the rows form on the matrix cores (4) from 2^31 (row, column) pairs on

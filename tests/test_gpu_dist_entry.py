@@ -1,6 +1,6 @@
 """The C-level multi-GPU entry (include/em2_lsh.h: em2_dist_find_similar_pairs4 / _with, csrc/em2_dist.hip).
  * world 2 and 4, all ranks on the one GPU of the test box, the transport table filled by tests/dist_entry_worker.py with
-   host-staged gloo collectives (RCCL refuses two ranks on one device): rows form, symmetric form with either exchange,
+   host-staged gloo collectives (RCCL refuses two ranks on one device): rows form, symmetric form with either exchange (two / four ranks: routed, three: gathered),
    overflow -> rows form together; every rank checks its contiguous rows against the oracle.
  * world 1 through REAL RCCL from a C++ program (tests/native/em2_dist_rccl.cpp, built here with hipcc): the RCCL binding
    (dlsym), ncclAllGather / ncclAllReduce / grouped ncclSend+ncclRecv on one rank, both forms, against
@@ -37,12 +37,13 @@ def test_rows_form_two_ranks():
     assert result["form"] == 0 and result["calls"] == {"all_gather": 2, "all_reduce": 0, "all_to_all": 0}
 
 
-@pytest.mark.parametrize("exchange,ranks,cells", [("alltoall", 2, 30000), ("gather", 2, 30000), ("alltoall", 4, 40003), ("alltoall", 3, 20001)])
-def test_symmetric_form(exchange, ranks, cells):
-    result = run_ranks(ranks, cells, 1024, 20, 0.2, 29642 + ranks + (10 if exchange == "gather" else 0),
-                       {"EM2_SHARDED_MIN_CELLS": "1000", "EM2_SHARDED_EXCHANGE": exchange})
+@pytest.mark.parametrize("ranks,cells", [(2, 30000), (4, 40003), (3, 20001)])
+def test_symmetric_form(ranks, cells):
+    """A power-of-two world routes every deferred candidate to the rank that owns its target cell (grouped send / recv); three
+    ranks gather the pools."""
+    result = run_ranks(ranks, cells, 1024, 20, 0.2, 29642 + ranks, {"EM2_SHARDED_MIN_CELLS": "1000"})
     assert result["form"] == 2
-    routed = exchange == "alltoall" and ranks & (ranks - 1) == 0
+    routed = ranks & (ranks - 1) == 0
     # per call: signatures + counts (+ the pool when gathered); two snapshot reductions + the outcome; candidates (routed) + rows +
     # used counts
     assert result["calls"]["all_reduce"] == 6

@@ -106,10 +106,8 @@ def scan_knobs():
     """Set / restore the scan kernel's test knobs (read with getenv at every launch)."""
     import os
     saved = {k: os.environ.get(k) for k in ("EM2_MIN_SEGMENT_COLUMNS", "EM2_LOG_CAPACITY", "EM2_SCAN_MODE",
-                                             "EM2_BLOCKS_PER_CU", "EM2_FULL_ROW_CELLS", "EM2_SEGMENTS",
-                                             "EM2_INBOX_CAPACITY", "EM2_SYMMETRIC_MIN_CELLS", "EM2_VIRTUAL_WORLD",
-                                             "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_SCAN_MATRIX", "EM2_MATRIX_WALK",
-                                             "EM2_SCAN_MATRIX_WIDE", "EM2_MATRIX_DEPART_US", "EM2_MATRIX_DEPART_WINDOW_US", "EM2_MATRIX_CONVOY")}
+                                             "EM2_BLOCKS_PER_CU", "EM2_FULL_ROW_CELLS", "EM2_INBOX_CAPACITY",
+                                             "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_SCAN_MATRIX", "EM2_MATRIX_CONVOY")}
 
     def set_knobs(**kw):
         for key, value in kw.items():
@@ -234,8 +232,8 @@ def test_fsp4_symmetric_sampled_rows_and_repeatability(oracle, scan_knobs):
         end = min(n, begin + 60)
         cell, sim, used = oracle.find_similar_pairs4_rows(sig, L, k, thr, begin, end)
         assert_same(first[0][begin:end], first[1][begin:end], cell, sim, used)
-    for blocks, segments in ((1, 7), (2, 64), (4, 33)):
-        scan_knobs(EM2_BLOCKS_PER_CU=blocks, EM2_SEGMENTS=segments, EM2_MIN_SEGMENT_COLUMNS=64)
+    for blocks, columns in ((1, 2900), (2, 313), (4, 607)):
+        scan_knobs(EM2_BLOCKS_PER_CU=blocks, EM2_MIN_SEGMENT_COLUMNS=columns)
         again = capi.find_similar_pairs4(sig, L, k, thr)
         assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])
 
@@ -250,7 +248,7 @@ def test_fsp4_symmetric_sampled_rows_and_repeatability(oracle, scan_knobs):
 def test_fsp4_sharded_virtual_world(oracle, scan_knobs, world, n, L, k, thr, kind):
     sig = make(n, L, kind)
     cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
-    scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=world, EM2_MIN_SEGMENT_COLUMNS=64, EM2_TILE_SEGMENTS=5)
+    scan_knobs(EM2_SCAN_MODE="virtual:%d" % world, EM2_MIN_SEGMENT_COLUMNS=64, EM2_TILE_SEGMENTS=5)
     pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
     assert_same(pairs, gused, cell, sim, used)
 
@@ -259,7 +257,7 @@ def test_fsp4_sharded_virtual_world(oracle, scan_knobs, world, n, L, k, thr, kin
 def test_fsp4_sharded_prefix_sizes_and_tilings(oracle, scan_knobs, permille, tile_segments, log_cap):
     sig = make(4000, 512, "clustered")
     cell, sim, used = oracle.find_similar_pairs4(sig, 512, 20, 0.2)
-    scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=4, EM2_MIN_SEGMENT_COLUMNS=100, EM2_PREFIX_PERMILLE=permille,
+    scan_knobs(EM2_SCAN_MODE="virtual:4", EM2_MIN_SEGMENT_COLUMNS=100, EM2_PREFIX_PERMILLE=permille,
                EM2_TILE_SEGMENTS=tile_segments, EM2_LOG_CAPACITY=log_cap)
     pairs, gused = capi.find_similar_pairs4(sig, 512, 20, 0.2)
     assert_same(pairs, gused, cell, sim, used)
@@ -268,7 +266,7 @@ def test_fsp4_sharded_prefix_sizes_and_tilings(oracle, scan_knobs, permille, til
 def test_fsp4_sharded_identical_cells_and_overflow_fallback(oracle, scan_knobs):
     sig = np.tile(synth.random_signatures(1, 256, seed=3), (1500, 1))
     cell, sim, used = oracle.find_similar_pairs4(sig, 256, 8, 0.2)
-    scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=2, EM2_MIN_SEGMENT_COLUMNS=64)
+    scan_knobs(EM2_SCAN_MODE="virtual:2", EM2_MIN_SEGMENT_COLUMNS=64)
     pairs, gused = capi.find_similar_pairs4(sig, 256, 8, 0.2)
     assert_same(pairs, gused, cell, sim, used)
     scan_knobs(EM2_INBOX_CAPACITY=1024)          # pools overflow -> the ordered scan runs instead
@@ -282,7 +280,7 @@ def test_fsp4_sharded_sampled_rows_of_larger_problem(oracle, scan_knobs):
     scan_knobs(EM2_SCAN_MODE="persistent")
     ordered = capi.find_similar_pairs4(sig, L, k, thr)
     for world in (2, 8):
-        scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=world)
+        scan_knobs(EM2_SCAN_MODE="virtual:%d" % world)
         got = capi.find_similar_pairs4(sig, L, k, thr)
         assert np.array_equal(got[0], ordered[0]) and np.array_equal(got[1], ordered[1])
 
@@ -296,7 +294,7 @@ def test_fsp4_golden_digests(scan_knobs, mode):
     from golden.make_golden import digest, make_signatures, regression_cases
     with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_regression.json")) as f:
         golden = json.load(f)
-    scan_knobs(EM2_SCAN_MODE=mode, EM2_MIN_SEGMENT_COLUMNS=64, EM2_FULL_ROW_CELLS=128, EM2_VIRTUAL_WORLD=2)
+    scan_knobs(EM2_SCAN_MODE=mode, EM2_MIN_SEGMENT_COLUMNS=64, EM2_FULL_ROW_CELLS=128)          # ("virtual" alone: two ranks)
     for case in regression_cases():
         sig = make_signatures(case)
         pairs, used = capi.find_similar_pairs4(sig, case["L"], case["k"], case["thr"])
@@ -341,10 +339,8 @@ def test_matrix_form_is_the_one_that_runs(oracle, scan_knobs):
     (2309, 600, 7, 0.0, "clustered", dict(EM2_FULL_ROW_CELLS=300, EM2_MIN_SEGMENT_COLUMNS=700)),         # cells % 256 != 0: a short last quad, an idle wave
     (1700, 1024, 5, -1.0, "random", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=512)),         # everything passes: logs fill, the walk stops and resumes
     (1700, 1024, 300, -0.5, "clustered", dict(EM2_FULL_ROW_CELLS=256, EM2_MIN_SEGMENT_COLUMNS=256, EM2_LOG_CAPACITY=1)),
-    (4000, 1024, 25, 0.5, "clustered", dict(EM2_FULL_ROW_CELLS=512, EM2_SEGMENTS=3, EM2_BLOCKS_PER_CU=1)),
+    (4000, 1024, 25, 0.5, "clustered", dict(EM2_FULL_ROW_CELLS=512, EM2_MIN_SEGMENT_COLUMNS=1300, EM2_BLOCKS_PER_CU=1)),
     (1300, 1024, 100, 0.2, "equal", dict(EM2_FULL_ROW_CELLS=256)),                                     # all cells identical: dot = 1024 everywhere
-    # walks leave on a common clock (the departure schedule, an A/B form): waiting changes nothing but the timing
-    (4000, 1024, 25, 0.2, "clustered", dict(EM2_FULL_ROW_CELLS=512, EM2_SEGMENTS=3, EM2_MATRIX_DEPART_US=50, EM2_MATRIX_DEPART_WINDOW_US=5)),
 ])
 def test_matrix_form_matches_oracle(oracle, scan_knobs, n, L, k, thr, kind, knobs):
     sig = np.tile(make(1, L, "random"), (n, 1)) if kind == "equal" else make(n, L, kind)
@@ -358,13 +354,13 @@ def test_matrix_form_matches_oracle(oracle, scan_knobs, n, L, k, thr, kind, knob
 @pytest.mark.parametrize("convoy", [0, 2, 3, 6])
 @pytest.mark.parametrize("n,L,k,thr,kind,knobs", [
     (2500, 1024, 10, 0.2, "clustered", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=512)),
-    (4000, 1024, 25, 0.2, "clustered", dict(EM2_FULL_ROW_CELLS=512, EM2_SEGMENTS=3)),                  # full rows go around as well
+    (4000, 1024, 25, 0.2, "clustered", dict(EM2_FULL_ROW_CELLS=512, EM2_MIN_SEGMENT_COLUMNS=1300)),      # full rows go around as well
     (2309, 600, 7, 0.0, "clustered", dict(EM2_FULL_ROW_CELLS=300, EM2_MIN_SEGMENT_COLUMNS=700)),       # an idle wave
     (1700, 1024, 5, -1.0, "random", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=512)),          # logs fill on either side of the wrap
     (1700, 1024, 300, -0.5, "clustered", dict(EM2_FULL_ROW_CELLS=256, EM2_MIN_SEGMENT_COLUMNS=512, EM2_LOG_CAPACITY=1)),
     (2500, 2048, 10, 0.2, "clustered", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=512)),       # the 2048-bit walk: each pass goes around
     (1700, 2048, 5, -1.0, "random", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=512)),
-    (3100, 1500, 40, 0.1, "clustered", dict(EM2_FULL_ROW_CELLS=256, EM2_SEGMENTS=2, EM2_LOG_CAPACITY=1)),
+    (3100, 1500, 40, 0.1, "clustered", dict(EM2_FULL_ROW_CELLS=256, EM2_MIN_SEGMENT_COLUMNS=1500, EM2_LOG_CAPACITY=1)),
 ])
 def test_matrix_form_walks_that_go_around(oracle, scan_knobs, n, L, k, thr, kind, knobs, convoy):
     """The convoy: a walk starts where the other walks of its XCD are and goes around its segment; the replay
@@ -421,12 +417,12 @@ def test_matrix_form_of_narrow_signatures(oracle, scan_knobs, n, L, k, thr, kind
     (2309, 1025, 7, 0.0, "clustered", dict(EM2_FULL_ROW_CELLS=300, EM2_MIN_SEGMENT_COLUMNS=700)),     # a short last quad, an idle wave
     (1700, 2048, 5, -1.0, "random", dict(EM2_FULL_ROW_CELLS=0, EM2_MIN_SEGMENT_COLUMNS=512)),         # everything passes: the walk stops and resumes
     (1700, 2048, 300, -0.5, "clustered", dict(EM2_FULL_ROW_CELLS=256, EM2_MIN_SEGMENT_COLUMNS=256, EM2_LOG_CAPACITY=1)),
-    (4000, 2000, 25, 0.5, "clustered", dict(EM2_FULL_ROW_CELLS=512, EM2_SEGMENTS=3, EM2_BLOCKS_PER_CU=1)),
+    (4000, 2000, 25, 0.5, "clustered", dict(EM2_FULL_ROW_CELLS=512, EM2_MIN_SEGMENT_COLUMNS=1300, EM2_BLOCKS_PER_CU=1)),
     (1300, 2048, 100, 0.2, "equal", dict(EM2_FULL_ROW_CELLS=256)),                                     # all cells identical: dot = 2048 everywhere
 ])
 def test_matrix_form_of_2048_bit_signatures(oracle, scan_knobs, n, L, k, thr, kind, knobs):
     """1025..2048 bits: the 2048-bit form of the matrix kernel (fsp4ScanMatrixWideKernel: 32 rows per wave and pass, two
-    passes over the columns).  Same bytes as the oracle and as the v_xor/v_bcnt form (EM2_SCAN_MATRIX_WIDE=0)."""
+    passes over the columns).  Same bytes as the oracle and as the v_xor/v_bcnt form (EM2_SCAN_MATRIX=3: no matrix form above 1024 bits)."""
     sig = np.tile(make(1, L, "random"), (n, 1)) if kind == "equal" else make(n, L, kind)
     cell, sim, used = oracle.find_similar_pairs4(sig, L, k, thr)
     scan_knobs(EM2_SCAN_MODE="triangle", **knobs)
@@ -434,7 +430,7 @@ def test_matrix_form_of_2048_bit_signatures(oracle, scan_knobs, n, L, k, thr, ki
     info = capi.dev_find_similar_pairs4_last_launch()
     assert info["form"] == 3 and info["matrix_pairs"] > 0
     assert_same(pairs, gused, cell, sim, used)
-    scan_knobs(EM2_SCAN_MODE="triangle", EM2_SCAN_MATRIX_WIDE=0, **knobs)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_SCAN_MATRIX=3, **knobs)
     pairs, gused = capi.find_similar_pairs4(sig, L, k, thr)
     assert capi.dev_find_similar_pairs4_last_launch()["form"] == 1
     assert_same(pairs, gused, cell, sim, used)
@@ -447,7 +443,7 @@ def test_matrix_form_inbox_overflow_falls_back(oracle, scan_knobs):
     pairs, gused = capi.find_similar_pairs4(sig, 1024, 10, -0.5)
     assert capi.dev_find_similar_pairs4_last_launch()["form"] == 4          # every row walked all columns instead, on the matrix cores
     assert_same(pairs, gused, cell, sim, used)
-    scan_knobs(EM2_SCAN_MODE="triangle", EM2_FULL_ROW_CELLS=0, EM2_INBOX_CAPACITY=1024, EM2_SCAN_MATRIX_WIDE=0)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_FULL_ROW_CELLS=0, EM2_INBOX_CAPACITY=1024, EM2_SCAN_MATRIX=3)
     sig = make(2000, 2048, "clustered")
     cell, sim, used = oracle.find_similar_pairs4(sig, 2048, 10, -0.5)
     pairs, gused = capi.find_similar_pairs4(sig, 2048, 10, -0.5)
@@ -481,7 +477,7 @@ def run_row_shard(sig, L, k, thr, begin, end):
     (2309, 600, 7, 0.0, "clustered", dict(EM2_MIN_SEGMENT_COLUMNS=700)),                       # zero-extended fragments
     (1700, 1024, 5, -1.0, "random", dict(EM2_MIN_SEGMENT_COLUMNS=512)),                        # everything passes: the walks stop and resume
     (1700, 1024, 300, -0.5, "clustered", dict(EM2_MIN_SEGMENT_COLUMNS=256, EM2_LOG_CAPACITY=1)),
-    (4000, 1024, 25, 0.5, "clustered", dict(EM2_SEGMENTS=3, EM2_BLOCKS_PER_CU=1)),
+    (4000, 1024, 25, 0.5, "clustered", dict(EM2_MIN_SEGMENT_COLUMNS=1300, EM2_BLOCKS_PER_CU=1)),
     (2500, 2048, 10, 0.2, "clustered", dict(EM2_MIN_SEGMENT_COLUMNS=512)),                     # the 2048-bit walk
     (2307, 1500, 12, -0.5, "clustered", dict(EM2_MIN_SEGMENT_COLUMNS=256, EM2_LOG_CAPACITY=1)),
     (2500, 1024, 10, 0.2, "clustered", dict(EM2_MIN_SEGMENT_COLUMNS=512, EM2_MATRIX_CONVOY=3)),   # every walk goes around its segment
@@ -538,7 +534,7 @@ def test_sharded_virtual_world_tiles_on_the_matrix_cores(oracle, scan_knobs, wor
     sig = make(n, 1024, "clustered")
     cell, sim, used = oracle.find_similar_pairs4(sig, 1024, 20, 0.2)
     for matrix in (1, 0):
-        scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=world, EM2_PREFIX_PERMILLE=permille, EM2_TILE_SEGMENTS=3,
+        scan_knobs(EM2_SCAN_MODE="virtual:%d" % world, EM2_PREFIX_PERMILLE=permille, EM2_TILE_SEGMENTS=3,
                    EM2_SCAN_MATRIX=matrix)
         pairs, gused = capi.find_similar_pairs4(sig, 1024, 20, 0.2)
         info = capi.dev_find_similar_pairs4_last_launch()
@@ -549,12 +545,12 @@ def test_sharded_virtual_world_tiles_on_the_matrix_cores(oracle, scan_knobs, wor
 @pytest.mark.parametrize("world,n,L,permille", [(2, 6000, 2048, 200), (4, 9000, 1500, 300), (3, 5000, 2048, 250), (8, 9000, 1025, 100)])
 def test_sharded_virtual_world_2048_bit_tiles_on_the_matrix_cores(oracle, scan_knobs, world, n, L, permille):
     """The same with 1025..2048-bit signatures: phases 0 / 1 on fsp4ScanMatrixWideKernel, the tiles on
-    fsp4TileMatrixWideKernel; EM2_SCAN_MATRIX_WIDE=0 (v_xor/v_bcnt everywhere) gives the same bytes."""
+    fsp4TileMatrixWideKernel; EM2_SCAN_MATRIX=3 (v_xor/v_bcnt everywhere at this width) gives the same bytes."""
     sig = make(n, L, "clustered")
     cell, sim, used = oracle.find_similar_pairs4(sig, L, 20, 0.2)
     for wide in (1, 0):
-        scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=world, EM2_PREFIX_PERMILLE=permille, EM2_TILE_SEGMENTS=3,
-                   EM2_SCAN_MATRIX_WIDE=wide)
+        scan_knobs(EM2_SCAN_MODE="virtual:%d" % world, EM2_PREFIX_PERMILLE=permille, EM2_TILE_SEGMENTS=3,
+                   EM2_SCAN_MATRIX=1 if wide else 3)
         pairs, gused = capi.find_similar_pairs4(sig, L, 20, 0.2)
         info = capi.dev_find_similar_pairs4_last_launch()
         assert info["form"] == 2 and (info["matrix_pairs"] > 0) == bool(wide)
@@ -563,14 +559,14 @@ def test_sharded_virtual_world_2048_bit_tiles_on_the_matrix_cores(oracle, scan_k
 
 def test_sharded_tile_walk_repeats_bit_identically(scan_knobs):
     """The deferred square of the sharded scan on the matrix cores (hand-scheduled walk, both sides deferred) against
-    the compiler-scheduled walk on a problem of a few thousand tiles, many times over: a tile piece that reaches LDS
+    the v_xor/v_bcnt form on a problem of a few thousand tiles, many times over: a tile piece that reaches LDS
     late or in the wrong place shows as a handful of mismatch counts that are off by one or two (found this way:
     global_load_lds with a scalar base and a 32-bit lane offset left a 1 KB piece of a tile stale in about every
     second run; the 64-bit lane address form does not)."""
     sig = synth.clustered_signatures(24000, 1024, cluster_count=12, flip=0.2, seed=77)
-    scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=4, EM2_MATRIX_WALK=0)
+    scan_knobs(EM2_SCAN_MODE="virtual:4", EM2_SCAN_MATRIX=0)
     reference = capi.find_similar_pairs4(sig, 1024, 40, 0.2)
-    scan_knobs(EM2_SCAN_MODE="virtual", EM2_VIRTUAL_WORLD=4, EM2_MATRIX_WALK=3)
+    scan_knobs(EM2_SCAN_MODE="virtual:4", EM2_SCAN_MATRIX=1)
     for attempt in range(25):
         again = capi.find_similar_pairs4(sig, 1024, 40, 0.2)
         assert np.array_equal(reference[1], again[1]), attempt

@@ -139,48 +139,44 @@ def test_fsp5_last_launch_reports_what_the_filter_read(oracle):
     assert info["distinct_candidates"] == int(member.sum())
 
 
-@pytest.mark.parametrize("mode", ["union", "sort"])
-def test_fsp5_union_forms_agree(oracle, monkeypatch, mode):
+def test_fsp5_union_forms_agree(oracle):
     """The duplicate-free ascending union of a cell's buckets (src/multipleSetUnion.hpp:44-76) through the LDS bitmap
-    (unionKernel, default) and through gather + segmented sort (EM2_FSP5_UNION=sort): both against the oracle, on shapes
-    that need several passes of the bitmap's id range would be too large for a unit test -- the pass logic is exercised by
-    ids on both sides of a word and of a thread's 17-word share, overflowing buckets, and cells whose union is everything."""
-    monkeypatch.setenv("EM2_FSP5_UNION", mode)
-    for n, L, k, thr, q, ovf in ((5000, 192, 12, 0.1, 6, 0), (3333, 256, 7, 0.2, 11, 25), (70, 64, 3, -1.0, 1, 0)):
+    (unionKernel: up to 256 slices) and through gather + segmented sort (more slices than that: 512 here): both against the
+    oracle, on shapes that need several passes of the bitmap's id range would be too large for a unit test -- the pass logic is
+    exercised by ids on both sides of a word and of a thread's 17-word share, overflowing buckets, and cells whose union is
+    everything."""
+    for n, L, k, thr, q, ovf in ((5000, 192, 12, 0.1, 6, 0), (3333, 256, 7, 0.2, 11, 25), (70, 64, 3, -1.0, 1, 0),
+                                 (1500, 1024, 9, 0.1, 2, 0), (900, 1024, 5, 0.2, 3, 700)):
         sig = synth.clustered_signatures(n, L, cluster_count=5, flip=0.2, seed=n)
         check(oracle, sig, L, k, thr, q, ovf)
 
 
-@pytest.mark.parametrize("order,batch_log2", [("id", "29"), ("group", "29"), ("group", "20"), ("id", "20")])
-def test_fsp5_filter_visiting_orders_agree(oracle, monkeypatch, order, batch_log2):
+@pytest.mark.parametrize("batch_log2", ["29", "20"])
+def test_fsp5_many_batches_agree(oracle, monkeypatch, batch_log2):
     """The filter visits the cells of a batch grouped by a neighbourhood label (smallest id in any of the cell's buckets, two
-    rounds of pointer jumping), every XCD working through its own eighth of that order, instead of in id order
-    (EM2_FSP5_ORDER=id): a schedule, the SimilarPairs are the same.  EM2_FSP5_BATCH_LOG2=20 cuts the cells into many
-    batches (a million candidate ids each), whose orders are computed one by one."""
-    monkeypatch.setenv("EM2_FSP5_ORDER", order)
+    rounds of pointer jumping), every XCD working through its own eighth of that order: a schedule, the SimilarPairs are the
+    oracle's.  EM2_FSP5_BATCH_LOG2=20 cuts the cells into many batches (a million candidate ids each), whose orders are computed
+    one by one."""
     monkeypatch.setenv("EM2_FSP5_BATCH_LOG2", batch_log2)
     for n, L, k, thr, q, ovf in ((6000, 256, 12, 0.1, 8, 0), (9000, 2048, 9, 0.2, 12, 300), (70, 64, 3, -1.0, 1, 0), (3001, 128, 5, 0.0, 7, 0)):
         sig = synth.clustered_signatures(n, L, cluster_count=7, flip=0.2, seed=n + 3)
         check(oracle, sig, L, k, thr, q, ovf)
 
 
-@pytest.mark.parametrize("mode", ["wide", "cooperative", "lane"])
-def test_fsp5_filter_forms_agree(oracle, monkeypatch, mode):
-    """The candidate filter (src/ExpressionMatrixLsh.cpp:436-457) as 16-byte loads with several candidates in flight
-    (filterWideKernel, default), as round 2's cooperative 8-byte form and as one lane per candidate (EM2_FSP5_FILTER): all
-    against the oracle, on even and odd word counts (odd ones keep the 8-byte form in every mode)."""
-    monkeypatch.setenv("EM2_FSP5_FILTER", mode)
-    for n, L, k, thr, q, ovf in ((4000, 256, 12, 0.1, 8, 0), (3000, 2048, 9, 0.2, 11, 25), (2500, 192, 5, 0.0, 6, 0), (900, 4096, 4, 0.2, 12, 0)):
+def test_fsp5_filter_forms_agree(oracle):
+    """The candidate filter (src/ExpressionMatrixLsh.cpp:436-457) by shape: 16-byte loads with several candidates in flight for
+    an even number of 64-bit words up to 4096 bits (filterWideKernel: 256, 2048, 4096 bits here, and 128 bits = one unit), the
+    cooperative 8-byte form for odd word counts (192 bits) and up to 8192 bits (6400), one lane per candidate beyond (8320)."""
+    for n, L, k, thr, q, ovf in ((4000, 256, 12, 0.1, 8, 0), (3000, 2048, 9, 0.2, 11, 25), (2500, 192, 5, 0.0, 6, 0), (900, 4096, 4, 0.2, 12, 0),
+                                 (1200, 128, 6, 0.1, 7, 0), (500, 6400, 4, 0.2, 12, 0), (400, 8320, 4, 0.2, 12, 0)):
         sig = synth.clustered_signatures(n, L, cluster_count=5, flip=0.2, seed=n + 1)
         check(oracle, sig, L, k, thr, q, ovf)
 
 
-@pytest.mark.parametrize("mode", ["tiers", "unpacked", "global", "lds"])
-def test_fsp5_long_lists_all_selection_tiers(oracle, mode, monkeypatch):
-    """Lists of 4097.., 12289.. candidates with few distinct keys (ties decide who survives keepBest) and with many: the
-    wave-parallel selection in global memory (default), the 144 KB LDS tier + global memory, and round 1's LDS tier + one
-    lane in HBM must all reproduce libstdc++'s nth_element."""
-    monkeypatch.setenv("EM2_FSP5_SELECT", mode)
+def test_fsp5_long_lists_all_selection_tiers(oracle):
+    """Lists of 4097.., 12289.. candidates with few distinct keys (ties decide who survives keepBest) and with many: the packed
+    LDS tiers (up to 16384 entries), the wave-parallel selection in global memory beyond, and -- k = 2500, above the packed
+    tiers' 2048 -- the tiers of whole entries must all reproduce libstdc++'s nth_element."""
     rng = np.random.default_rng(17)
     for cells, L, k, flips in ((5000, 64, 7, 3), (5600, 128, 50, 12), (13000, 128, 25, 10), (7000, 256, 100, 40), (17000, 64, 3, 6), (5000, 128, 2500, 30)):
         base = synth.random_signatures(1, L, seed=cells)

@@ -118,37 +118,14 @@ def test_ticket_schedule_matches_too(lib, oracle, monkeypatch, batch):
     assert iterations == expected_iterations and np.array_equal(got, expected)
 
 
-@pytest.mark.parametrize("hub_degree,parallel_edges", [(300, 0), (2500, 100)])
-def test_global_memory_form_matches_too(lib, oracle, monkeypatch, hub_degree, parallel_edges):
-    # EM2_LABEL_FORM=global: round 2's kernel (tables searched in global memory; candidates of hubs staged there), kept for A/B
-    # runs and as the form the LDS kernel falls back on for tables and candidate lists beyond its areas.
-    monkeypatch.setenv("EM2_LABEL_FORM", "global")
-    rng = np.random.default_rng(12)
-    cells, v0, v1, sim = fast_graph(rng, 20000, 10, 16, 3, hub_degree, parallel_edges)
-    got, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim)
-    expected, expected_iterations = oracle.label_propagation(cells, v0, v1, sim)
-    assert iterations == expected_iterations and np.array_equal(got, expected)
-
-
-@pytest.mark.parametrize("hub_degree,parallel_edges", [(300, 0), (700, 100)])
-def test_strided_schedule_matches_too(lib, oracle, monkeypatch, hub_degree, parallel_edges):
-    # EM2_LABEL_SCHEDULE=strided: wave w of W takes positions w, w + W, ... and loads three turns ahead (the fastest form of an
-    # iteration without changes, the slower one overall: DESIGN.md 3.6); the default draws positions from a ticket per unit.
-    monkeypatch.setenv("EM2_LABEL_SCHEDULE", "strided")
-    rng = np.random.default_rng(13)
-    cells, v0, v1, sim = fast_graph(rng, 30000, 10, 16, 3, hub_degree, parallel_edges)
-    got, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim)
-    expected, expected_iterations = oracle.label_propagation(cells, v0, v1, sim)
-    assert iterations == expected_iterations and np.array_equal(got, expected)
-
-
-@pytest.mark.parametrize("areas,schedule", [("0", ""), ("1", ""), ("1", "strided")])
-def test_turns_that_find_no_lds_area_take_the_global_memory_forms(lib, oracle, monkeypatch, areas, schedule):
+@pytest.mark.parametrize("areas,ticket", [("0", ""), ("1", ""), ("1", "4")])
+def test_turns_that_find_no_lds_area_take_the_global_memory_forms(lib, oracle, monkeypatch, areas, ticket):
     # The 16 waves of a unit share a pool of LDS areas (tables beyond the registers, keys of large neighbourhoods); a turn that
-    # finds none sorts its keys and keeps its table in global memory.  EM2_LABEL_POOL_AREAS shrinks the pool so that it happens.
+    # finds none sorts its keys and keeps its table in global memory.  EM2_LABEL_POOL_AREAS shrinks the pool so that it happens
+    # (also under the global ticket, whose 256-thread blocks have an area per wave).
     monkeypatch.setenv("EM2_LABEL_POOL_AREAS", areas)
-    if schedule:
-        monkeypatch.setenv("EM2_LABEL_SCHEDULE", schedule)
+    if ticket:
+        monkeypatch.setenv("EM2_LABEL_TICKET_BATCH", ticket)
     rng = np.random.default_rng(15)
     cells, v0, v1, sim = fast_graph(rng, 30000, 10, 16, 40, 400, 50)
     got, iterations = capi.cell_graph_label_propagation(cells, v0, v1, sim)

@@ -31,17 +31,17 @@ def run_two_ranks(extra_env, cells, port, ranks=2):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("exchange", ["alltoall", "gather"])
-def test_sharded_symmetric_scan_two_ranks(exchange):
-    result = run_two_ranks({"EM2_SHARDED_MIN_CELLS": "1000", "EM2_SHARDED_EXCHANGE": exchange}, cells=30000,
-                           port=29631 if exchange == "alltoall" else 29634)
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_sharded_symmetric_scan_two_ranks(ranks):
+    """Two ranks exchange their deferred candidates by all_to_all (a power-of-two world), three gather the pools."""
+    result = run_two_ranks({"EM2_SHARDED_MIN_CELLS": "1000"}, cells=30000, port=29631 if ranks == 2 else 29634, ranks=ranks)
     assert result["config"]["scan"] == "sharded-symmetric"
-    assert result["n_gpus"] == 2 and result["parity_check"]["fsp4_rows"] > 0
+    assert result["n_gpus"] == ranks and result["parity_check"]["fsp4_rows"] > 0
     assert result["roofline"]["inbox_entries"] > 0
     # north_star's own partitioning was measured first, by the same contract, and rides along
     leg = result["row_shard_leg"]
     assert leg["scan"] == "row-shards" and leg["value"] > 0 and leg["steps"] == 1 and leg["parity_check"]["fsp4_rows"] > 0
-    assert result["collective_check"]["ranks_counted_by_all_reduce"] == 2 and result["collective_check"]["rank_ids_gathered"] == [0, 1]
+    assert result["collective_check"]["ranks_counted_by_all_reduce"] == ranks and result["collective_check"]["rank_ids_gathered"] == list(range(ranks))
 
 
 def test_sharded_symmetric_scan_four_ranks_ragged_size():

@@ -84,21 +84,36 @@ def test_screening_pass_defers_to_exact_arithmetic_when_it_cannot_decide(oracle)
     assert 0.3 * cells * L < ones < 0.7 * cells * L            # the signs are genuinely mixed
 
 
-@pytest.mark.parametrize("mode", ["exact", "default", "words", "sliced", "sliced16", "screen"])
-def test_exact_only_and_screened_paths_agree_with_oracle(oracle, mode, monkeypatch):
-    """default = 16-bit fixed-point first tier -> float tier on the undecided single bits and words -> exact arithmetic; words =
-    the same with everything undecided listed by words (EM2_PROJECTION_BITS=0, round 2's form); sliced / sliced16 / screen = the
-    float forms as first tier; exact = no screening at all."""
-    cells, genes, L = 800, 3000, 1024
+def exact_signatures(toc, data, genes, vectors, L):
+    """The exact arithmetic alone (sequential FP64, no screening tier): em2_dev_compute_signatures without the auxiliary
+    block of the hyperplanes."""
+    import torch
+    cells = len(toc) - 1
+    d_toc = torch.from_numpy(np.ascontiguousarray(toc).view(np.int64)).cuda()
+    d_data = torch.from_numpy(np.ascontiguousarray(data).view(np.int64)).cuda()
+    d_vectors = torch.from_numpy(np.ascontiguousarray(vectors)).cuda()
+    d_sig = torch.zeros((cells, capi.word_count(L)), dtype=torch.int64, device="cuda")
+    ws_bytes = capi.dev_compute_signatures_workspace(cells, L)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    capi.dev_compute_signatures(d_toc.data_ptr(), d_data.data_ptr(), cells, genes, d_vectors.data_ptr(), 0, L, d_sig.data_ptr(),
+                                ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return d_sig.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("L", [1024, 1000, 96, 100, 63])
+def test_exact_only_and_screened_paths_agree_with_oracle(oracle, L):
+    """The first tier by shape: a whole number of 64-bit words (1024) takes the 16-bit fixed-point tier -> float tier on the
+    undecided single bits and words -> exact arithmetic; whole 32-bit slices (96) the XCD-sliced float form first; a multiple
+    of 4 bits (1000, 100) one block per 1024 bits on the float copy; anything else (63) the exact arithmetic alone -- which
+    every width is also held to through the device entry without the hyperplanes' auxiliary block."""
+    cells, genes = 800, 3000
     toc, g, c = synth.expression_matrix(cells, genes, density=0.02, cluster_count=6, seed=9)
     vectors = oracle.generate_lsh_vectors(genes, L, 231)
     expect = oracle.compute_signatures(toc, g, c, genes, vectors, L)
-    if mode == "words":
-        monkeypatch.setenv("EM2_PROJECTION_BITS", "0")
-    elif mode != "default":
-        monkeypatch.setenv("EM2_PROJECTION", mode)
-    got = capi.compute_signatures(toc, capi.make_counts(g, c), genes, vectors, L)
-    assert np.array_equal(got, expect)
+    data = capi.make_counts(g, c)
+    assert np.array_equal(capi.compute_signatures(toc, data, genes, vectors, L), expect)
+    assert np.array_equal(exact_signatures(toc, data, genes, vectors, L), expect)
 
 
 @pytest.mark.parametrize("cells,genes,L,density,count_scale", [
@@ -111,20 +126,16 @@ def test_exact_only_and_screened_paths_agree_with_oracle(oracle, mode, monkeypat
 def test_tiers_equal_exact_arithmetic_on_many_cells(cells, genes, L, density, count_scale, monkeypatch):
     """The screening tiers only ever decide a bit when their bound says the exact sequential FP64 sum has that sign: on
     tens of millions of bits the default path (16-bit tier, float tier, exact) must reproduce the exact-arithmetic kernel
-    (EM2_PROJECTION=exact, itself bit-exact against the oracle in the tests above) everywhere."""
+    (exact_signatures, itself bit-exact against the oracle in the test above) everywhere."""
     toc, g, c = synth.expression_matrix(cells, genes, density=density, cluster_count=7, seed=cells + L)
     c = (c.astype(np.float64) * count_scale).astype(np.float32)
     idx = np.arange(genes * L, dtype=np.uint64).reshape(genes, L)
     vectors = synth.uniform01(11, idx) - 0.5
     vectors /= np.sqrt((vectors * vectors).sum(axis=0))
     data = capi.make_counts(g, c)
-    monkeypatch.setenv("EM2_PROJECTION", "exact")
-    exact = capi.compute_signatures(toc, data, genes, vectors, L)
-    monkeypatch.delenv("EM2_PROJECTION")
+    exact = exact_signatures(toc, data, genes, vectors, L)
     got = capi.compute_signatures(toc, data, genes, vectors, L)
     assert np.array_equal(got, exact)
-    monkeypatch.setenv("EM2_PROJECTION", "sliced")
-    assert np.array_equal(capi.compute_signatures(toc, data, genes, vectors, L), exact)
 
 
 def test_screening_with_huge_and_tiny_magnitudes(oracle):
@@ -155,18 +166,18 @@ def test_fractional_counts_and_the_cell_mean(oracle, spread):
     assert np.array_equal(got, expect)
 
 
-@pytest.mark.parametrize("case", ["integers", "float-tier-forced", "one-fraction", "count-32768", "sum-above-65535", "negative", "at-the-limits"])
+@pytest.mark.parametrize("case", ["integers", "all-fractions", "one-fraction", "count-32768", "sum-above-65535", "negative", "at-the-limits"])
 def test_integer_first_tier_and_when_it_steps_aside(oracle, monkeypatch, case):
     """The first tier has an exact integer form (v_mad_i32_i16, 32-bit sums) for matrices whose counts are all integers of at
     most 15 bits with sum|count| <= 65535 per cell; the statistics kernel sets a device flag otherwise and the float form runs.
-    Same signatures either way, against the oracle: integer counts (integer form), the float form forced by
-    EM2_PROJECTION_INTEGER=0, and matrices that must step aside -- one fractional count in one cell, a count of 32768, a cell
+    Same signatures either way, against the oracle: integer counts (integer form), counts that are all fractions (float form),
+    and matrices that must step aside -- one fractional count in one cell, a count of 32768, a cell
     whose counts sum above 65535 -- plus negative integers and a cell exactly at both limits (integer form)."""
     cells, genes, L = 700, 1500, 1024
     toc, g, c = synth.expression_matrix(cells, genes, density=0.06, cluster_count=5, seed=21)
     c = c.copy()
-    if case == "float-tier-forced":
-        monkeypatch.setenv("EM2_PROJECTION_INTEGER", "0")
+    if case == "all-fractions":
+        c = (c * np.float32(0.37)).astype(np.float32)
     elif case == "one-fraction":
         c[len(c) // 2] = np.float32(2.5)
     elif case == "count-32768":

@@ -17,8 +17,8 @@ import synth  # noqa: E402
 from label_graphs import fast_graph  # noqa: E402
 from expressionmatrix2_amd import capi  # noqa: E402
 
-KNOBS = ("EM2_SCAN_MODE", "EM2_MIN_SEGMENT_COLUMNS", "EM2_LOG_CAPACITY", "EM2_FULL_ROW_CELLS", "EM2_VIRTUAL_WORLD",
-         "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_BLOCKS_PER_CU", "EM2_SEGMENTS", "EM2_SCAN_MATRIX", "EM2_MATRIX_CONVOY")
+KNOBS = ("EM2_SCAN_MODE", "EM2_MIN_SEGMENT_COLUMNS", "EM2_LOG_CAPACITY", "EM2_FULL_ROW_CELLS",
+         "EM2_PREFIX_PERMILLE", "EM2_TILE_SEGMENTS", "EM2_BLOCKS_PER_CU", "EM2_SCAN_MATRIX", "EM2_MATRIX_CONVOY")
 
 
 def main():
@@ -40,16 +40,14 @@ def main():
                         ties=int(rng.choice([0, 0, 2, 16])), graph_seed=int(rng.integers(1 << 30)),
                         seed=int(rng.choice([231, 1, 2 ** 33 + 7])), stable=int(rng.choice([0, 1, 3])),
                         max_iterations=int(rng.choice([0, 1, 3, 100])), ticket=str(rng.choice(["", "", "1", "3", "8"])),
-                        form=str(rng.choice(["", "", "", "global"])), schedule=str(rng.choice(["", "", "strided"])),
                         pool=str(rng.choice(["", "", "0", "1", "3"])))
             cells, v0, v1, s = fast_graph(np.random.default_rng(case["graph_seed"]), vertices, degree, case["clusters"],
                                           case["hubs"], case["hub_degree"], case["parallel"] if vertices > 3 else 0, case["ties"])
-            for name, key in (("EM2_LABEL_TICKET_BATCH", "ticket"), ("EM2_LABEL_FORM", "form"), ("EM2_LABEL_SCHEDULE", "schedule"),
-                              ("EM2_LABEL_POOL_AREAS", "pool")):
+            for name, key in (("EM2_LABEL_TICKET_BATCH", "ticket"), ("EM2_LABEL_POOL_AREAS", "pool")):
                 if case[key]:
                     os.environ[name] = case[key]
             got = capi.cell_graph_label_propagation(cells, v0, v1, s, case["seed"], case["stable"], case["max_iterations"])
-            for name in ("EM2_LABEL_TICKET_BATCH", "EM2_LABEL_FORM", "EM2_LABEL_SCHEDULE", "EM2_LABEL_POOL_AREAS"):
+            for name in ("EM2_LABEL_TICKET_BATCH", "EM2_LABEL_POOL_AREAS"):
                 os.environ.pop(name, None)
             expect = oracle.label_propagation(cells, v0, v1, s, case["seed"], case["stable"], case["max_iterations"])
             if got[1] != expect[1] or not np.array_equal(got[0], expect[0]):
@@ -70,19 +68,18 @@ def main():
         what = os.environ.get("FUZZ_ONLY", what)
         label = dict(n=n, L=L, k=k, thr=thr, clusters=clusters, flip=flip, sig_seed=sig_seed)
         if what == "fsp4":
-            knobs = {"EM2_SCAN_MODE": str(rng.choice(["persistent", "triangle", "virtual", "simple"])),
+            knobs = {"EM2_SCAN_MODE": str(rng.choice(["persistent", "triangle", "virtual:%d" % int(rng.choice([1, 2, 3, 4, 8])), "simple", "rows"])),
                      "EM2_MIN_SEGMENT_COLUMNS": str(int(rng.choice([64, 100, 257, 1000, 4096]))),
                      "EM2_LOG_CAPACITY": str(int(rng.choice([1, 3, 16, 256]))),
                      "EM2_FULL_ROW_CELLS": str(int(rng.choice([0, 64, 200, 1000, 100000]))),
-                     "EM2_VIRTUAL_WORLD": str(int(rng.choice([1, 2, 3, 4, 8]))),
                      "EM2_PREFIX_PERMILLE": str(int(rng.choice([50, 200, 500, 900]))),
                      "EM2_TILE_SEGMENTS": str(int(rng.choice([1, 3, 17, 256]))),
                      "EM2_BLOCKS_PER_CU": str(int(rng.choice([1, 2, 4]))),
-                     "EM2_SCAN_MATRIX": str(int(rng.choice([0, 1, 1]))),
+                     "EM2_SCAN_MATRIX": str(int(rng.choice([0, 1, 1, 2, 3]))),
                      # (the convoy of the matrix walks: off, following the other blocks, or every walk n - 1 pairs of tiles in)
                      "EM2_MATRIX_CONVOY": str(int(rng.choice([0, 1, 1, 2, 3, 5, 9, 30])))}
             if os.environ.get("FUZZ_MODE"):
-                knobs["EM2_SCAN_MODE"] = os.environ["FUZZ_MODE"]
+                knobs["EM2_SCAN_MODE"] = os.environ["FUZZ_MODE"] if os.environ["FUZZ_MODE"] != "virtual" else knobs["EM2_SCAN_MODE"] if knobs["EM2_SCAN_MODE"].startswith("virtual") else "virtual:2"
                 knobs["EM2_SCAN_MATRIX"] = "1"
             os.environ.update(knobs)
             label.update(knobs)
@@ -91,9 +88,7 @@ def main():
         elif what == "fsp5":
             q = int(rng.choice([1, 3, 8, 13, 20]))
             overflow = int(rng.choice([0, 5, 1000]))
-            knobs = {"EM2_FSP5_ORDER": str(rng.choice(["group", "group", "id"])), "EM2_FSP5_BATCH_LOG2": str(int(rng.choice([20, 22, 29]))),
-                     "EM2_SCRATCH_CACHE_MB": str(int(rng.choice([0, 1, 32768]))), "EM2_FSP5_FILTER": str(rng.choice(["wide", "wide", "cooperative", "lane"])),
-                     "EM2_FSP5_UNION": str(rng.choice(["bitmap", "bitmap", "sort"]))}
+            knobs = {"EM2_FSP5_BATCH_LOG2": str(int(rng.choice([20, 22, 29]))), "EM2_SCRATCH_CACHE_MB": str(int(rng.choice([0, 1, 4096])))}
             os.environ.update(knobs)
             label.update(q=q, overflow=overflow, **knobs)
             cell, sim, used = oracle.find_similar_pairs5(sig, L, k, thr, q, overflow)
@@ -129,11 +124,9 @@ def main():
             cells, genes = int(rng.choice([1, 50, 300, 1000])), int(rng.choice([1, 10, 200, 1500]))
             toc, g, c = synth.expression_matrix(cells, genes, density=float(rng.choice([0.0, 0.01, 0.2])), cluster_count=3,
                                                 seed=int(rng.integers(1 << 30)))
-            os.environ["EM2_PROJECTION"] = str(rng.choice(["sliced", "screen", "exact", "sliced16"]))
             vectors = oracle.generate_lsh_vectors(genes, L, int(rng.integers(1 << 20)))
             expect = oracle.compute_signatures(toc, g, c, genes, vectors, L)
             got = capi.compute_signatures(toc, capi.make_counts(g, c), genes, vectors, L)
-            os.environ.pop("EM2_PROJECTION", None)
             if not np.array_equal(expect, got):
                 raise SystemExit("PARITY FAILURE signatures %r" % dict(cells=cells, genes=genes, L=L))
             runs[what] += 1

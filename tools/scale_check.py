@@ -3,7 +3,7 @@
 
     python3 tools/scale_check.py fsp5   # BASELINE configs[3] shape: 1M cells, 2048 bit, lshSliceLength 20
     python3 tools/scale_check.py fsp4w  # findSimilarPairs4 at 2048 bit, 200k cells
-    CELLS=1000000 LSH=1024 SWEEP="EM2_SCAN_MODE=persistent;EM2_SEGMENTS=32,EM2_FULL_ROW_CELLS=8192" \
+    CELLS=1000000 LSH=1024 SWEEP="EM2_SCAN_MODE=persistent;EM2_MIN_SEGMENT_COLUMNS=32768,EM2_FULL_ROW_CELLS=8192" \
         python3 tools/scale_check.py sweep   # scan-only timings under different EM2_* knobs, each parity-checked
 
 Signatures are synthetic (64 cluster centres, each bit flipped with probability 0.15), generated in HBM with
