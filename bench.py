@@ -348,6 +348,66 @@ def rows_form_block(args, capi, pipe, oracle, sig_host, torch, threads, shards=(
             "shards": out}
 
 
+def facade_block(args, capi, synthetic, torch, toc, data, reference_pairs, reference_used):
+    """The user-visible call: ExpressionMatrix.findSimilarPairs4(similarPairsName=...) on a data directory in the reference's
+    formats (src/PythonModule.cpp:802-824) -- mmap'd CellExpressionCounts in, SimilarPairs-<name>-{Info,Pairs,CellInfo} out.
+    Wall time of the call (second of two), and its stages from the library's own timers (a third call with EM2_TIMING=1, whose
+    stages are synchronised: they do not overlap as they do in the timed call).  The reference's accounting separates the store
+    as well ("excluding time to store similarities", src/ExpressionMatrixLsh.cpp:270-285).  The files' pairs must equal the
+    device pipeline's result.  Never `value`: the inputs are not resident in HBM here."""
+    import re
+    import shutil
+    import tempfile
+    from expressionmatrix2_amd import ExpressionMatrix, files
+    C, G, L, k, thr = args.cells, args.genes, args.lsh_count, args.k, args.threshold
+    t_h, g_h, c_h = synthetic.csr_to_host(toc, data)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 8 * (1 << 30) else tempfile.gettempdir()
+    directory = tempfile.mkdtemp(prefix="em2bench", dir=base)
+    try:
+        t0 = time.perf_counter()
+        files.create_directory(directory, G, t_h, capi.make_counts(g_h, c_h))
+        create_s = time.perf_counter() - t0
+        del t_h, g_h, c_h
+        e = ExpressionMatrix(directory)
+        wall = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            e.findSimilarPairs4(similarPairsName="Bench", k=k, similarityThreshold=thr, lshCount=L, seed=args.seed)
+            wall.append(time.perf_counter() - t0)
+        _, pairs, used = files.read_similar_pairs(directory, "Bench")
+        same = bool(np.array_equal(used, reference_used) and np.array_equal(pairs["cell"], reference_pairs["cell"]) and
+                    np.array_equal(pairs["similarity"].view(np.uint32), reference_pairs["similarity"].view(np.uint32)))
+        if not same:
+            raise SystemExit("PARITY FAILURE: SimilarPairs written by ExpressionMatrix.findSimilarPairs4 differ from the device pipeline's")
+        # the split: the library's timers write to file descriptor 2
+        sys.stderr.flush()
+        saved = os.dup(2)
+        stages = {}
+        with tempfile.TemporaryFile(mode="w+b") as capture:
+            os.dup2(capture.fileno(), 2)
+            os.environ["EM2_TIMING"] = "1"
+            try:
+                t0 = time.perf_counter()
+                e.findSimilarPairs4(similarPairsName="Bench", k=k, similarityThreshold=thr, lshCount=L, seed=args.seed)
+                staged_wall = time.perf_counter() - t0
+            finally:
+                os.environ.pop("EM2_TIMING", None)
+                os.dup2(saved, 2)
+                os.close(saved)
+            capture.seek(0)
+            for line in capture.read().decode(errors="replace").splitlines():
+                m = re.match(r"\[em2 timing\]\s+(.*?):\s+(.*) ([0-9.]+) ms$", line)
+                if m and "symmetric scan" not in line and "matrix kernel" not in line:
+                    stages["%s: %s" % (m.group(1).strip(), m.group(2).strip())] = float(m.group(3))
+        return {"what": "ExpressionMatrix.findSimilarPairs4 on a data directory (mmap'd CSR in, SimilarPairs files out), %d cells x %d genes; "
+                        "PCIe and file I/O included -- beside the headline, never `value`" % (C, G),
+                "directory_on": base, "create_directory_s": create_s, "call_s": wall[1], "first_call_s": wall[0],
+                "call_with_synchronised_stage_timers_s": staged_wall, "stages_ms": stages,
+                "rows_equal_to_the_device_pipeline": int(C)}
+    finally:
+        shutil.rmtree(directory, ignore_errors=True)
+
+
 def small_config(args, capi, sharded, synthetic, oracle, device, torch, cells=100000, genes=20000, steps=10, warmup=2):
     """BASELINE configs[1] on one GPU: ms per step and pairs/s, gated like the headline."""
     L, k, thr = args.lsh_count, args.k, args.threshold
@@ -466,17 +526,79 @@ def bench_fsp5(args, capi, oracle, device, torch):
                    "slices": info["slice_count"], "batches": info["batches"]},
         "phases_ms": {"candidate_filter": filter_ms, "selection": select_ms,
                       "tables_and_candidate_unions": elapsed / args.steps * 1e3 - filter_ms - select_ms},
-        "roofline": {"kernel": ("filterWideKernel<%s> (all batches)" % ("1, 16" if W == 32 else "2, 16" if W == 64 else "T, LPC")) if W % 2 == 0 and W <= 64 and
-                               True else "filterCooperativeKernel (all batches)", "kernel_ms": filter_ms, "bound": "hbm", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "algorithmic_bytes": algorithmic, "distinct_candidates": distinct, "gathered_candidates": info["gathered_candidates"],
-                     "note": "SURVEY.md 8(d): candidates x 8*W bytes of signature gathers + 4*N*sliceCount bytes of tables; candidates "
-                             "= the distinct ids of every cell's union of buckets, which is what the filter gathers (counted by the "
-                             "library); kernel_ms = HIP events around the filter kernels on the launch stream.  Since round 4 the filter "
-                             "visits cells grouped by neighbourhood, so most of these bytes come from the L2s and not over the fabric "
-                             "(`traffic`, from the PMC digest, is what crosses the fabric): frac may exceed 1 -- the byte model against "
-                             "the HBM peak no longer bounds the kernel, its vector ALUs do (VALU busy 66-85 % in the digest)"},
+        # The bound that binds the filter since the grouped visiting order (round 4): its vector ALUs.  Essential work = one v_xor_b32
+        # and one v_bcnt_u32_b32 per 32 bits of every distinct candidate's signature (SURVEY 8(d)'s own VALU ceiling for
+        # xor/popcount: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz lane-operations per second, the issue rate measured in
+        # profiles/r01_ubench_valu_xor_bcnt.txt); `bound_unit` "lane-op/s".  The HBM byte model of 8(d) rides along (hbm_view).
+        "roofline": {"kernel": ("filterWideKernel<%s> (all batches)" % ("1, 16" if W == 32 else "2, 16" if W == 64 else "T, LPC")) if W % 2 == 0 and W <= 64
+                               else "filterCooperativeKernel (all batches)", "kernel_ms": filter_ms, "bound": "valu",
+                     "achieved": distinct * 2.0 * W * 2.0 / (filter_ms * 1e-3) / 1e12 if filter_ms > 0 else 0.0,
+                     "peak": VALU_LANE_OPS_PER_S / 1e12, "unit": "T lane-op/s",
+                     "frac": distinct * 2.0 * W * 2.0 / (filter_ms * 1e-3) / VALU_LANE_OPS_PER_S if filter_ms > 0 else 0.0,
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "essential_lane_ops": distinct * 2.0 * W * 2.0, "distinct_candidates": distinct, "gathered_candidates": info["gathered_candidates"],
+                     "hbm_view": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes": algorithmic},
+                     "note": "essential lane-ops = distinct candidates x (2 x W 32-bit words) x 2 instructions (v_xor_b32 + v_bcnt_u32_b32); "
+                             "candidates = the distinct ids of every cell's union of buckets (counted by the library); kernel_ms = HIP events "
+                             "around the filter kernels on the launch stream.  hbm_view = SURVEY.md 8(d)'s byte model (candidates x 8*W bytes of "
+                             "gathers + 4*N*sliceCount of tables) against the HBM peak: since the filter visits cells grouped by neighbourhood "
+                             "those bytes come from the L2s (`traffic` is what crosses the fabric), its frac exceeds 1 and bounds nothing.  "
+                             "The filter executes about 3.4 x the essential instructions (lane sums, rank bookkeeping, address arithmetic)"},
+        # the other stages against what they must at least move (bytes over the HBM peak): none of them is near it -- the union
+        # is bound by its own instructions (VALU busy 84 %), the selection by LDS latency at 4-5 waves per CU
+        "stage_bounds": {
+            "candidate_unions": {"least_bytes": info["gathered_candidates"] * 4.0 + distinct * 4.0,
+                                 "least_ms_at_hbm_peak": (info["gathered_candidates"] * 4.0 + distinct * 4.0) / (HBM_PEAK_GBS * 1e9) * 1e3,
+                                 "note": "every gathered bucket member read once (4 B), every distinct candidate written once (4 B)"},
+            "selection": {"least_bytes": distinct * 8.0 + C * k * 8.0, "least_ms_at_hbm_peak": (distinct * 8.0 + C * k * 8.0) / (HBM_PEAK_GBS * 1e9) * 1e3,
+                          "note": "every list entry read once (8 B), k pairs per cell written (8 B)"},
+            "tables": {"least_bytes": C * info["slice_count"] * (12.0 + 12.0) * 3.0, "least_ms_at_hbm_peak": C * info["slice_count"] * 72.0 / (HBM_PEAK_GBS * 1e9) * 1e3,
+                       "note": "one key (8 B) + cell id (4 B) per (slice, cell), read and written by each of ~3 radix passes"}},
         "parity_check": check,
+    }
+
+
+def chain_roofline(capi, args, times, edges, iterations, cells, per_vertex):
+    """The chain's dominant kernel (the scan of its findSimilarPairs4, against the FP4 MFMA peak as on the headline) and the
+    least the two consumers must move, against the HBM peak -- with what binds them instead."""
+    launch = capi.dev_find_similar_pairs4_last_launch()
+    contraction = 2048.0 if args.lsh_count > 1024 else 1024.0
+    flops = launch["matrix_pairs"] * 2.0 * contraction
+    tflops = flops / (launch["matrix_kernel_ms"] * 1e-3) / 1e12 if launch["matrix_kernel_ms"] > 0 else 0.0
+    label_ms = times["labelPropagationClustering"] / args.steps * 1e3
+    graph_ms = times["createCellGraph"] / args.steps * 1e3
+    # label propagation: an iteration reads one 32-byte record per (vertex, neighbour) -- 2 x edges of them -- and a record's 128-byte
+    # line is what a random gather moves; the turns of an iteration are ordered (a vertex waits for its neighbours at smaller
+    # positions of the shuffle): the longest such chain, not bandwidth, sets the pace
+    record_bytes = 2.0 * edges * 32.0 * max(1, iterations)
+    line_bytes = 2.0 * edges * 128.0 * max(1, iterations)
+    # createCellGraph: the first <= graph_k pairs of every cell (8 B each), the selections written and read twice (count, write),
+    # and for every selected neighbour with a smaller id a gather of its list (graph_k x 4 B in one or two 128-byte lines)
+    graph_bytes = cells * per_vertex * 8.0 + 3.0 * cells * per_vertex * 8.0 + 3.0 * edges * 12.0
+    graph_gathers = 2.0 * cells * per_vertex * 0.5
+    return {
+        "kernel": "fsp4ScanMatrixPinnedKernel<true> (the chain's findSimilarPairs4)", "kernel_ms": launch["matrix_kernel_ms"], "bound": "mfma",
+        "achieved": tflops, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_FP4_PEAK_TFLOPS, "traffic": None,
+        "flop_per_launch": flops,
+        "label_propagation": {
+            "ms": label_ms, "iterations": iterations, "bound": "hbm", "least_bytes": record_bytes, "least_bytes_in_128_byte_lines": line_bytes,
+            "frac_of_hbm_peak_by_records": record_bytes / (label_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if label_ms > 0 else None,
+            "frac_of_hbm_peak_by_lines": line_bytes / (label_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if label_ms > 0 else None,
+            "turns_per_s": cells * max(1, iterations) / (label_ms * 1e-3) if label_ms > 0 else None,
+            "note": "bytes = 2 x edges x 32 B (one record per vertex and neighbour) per iteration, or x 128 B as the lines the gathers move "
+                    "(profiles/r04_pmc_bench_chain_1Mcells.json: 5.2 GB fetched per launch against 0.97 GB of records).  What binds is the "
+                    "ORDER: the reference's asynchronous updates (src/CellGraph.cpp:445-616) make a vertex wait for every neighbour at a "
+                    "smaller position of the iteration's shuffle, and the kernel keeps that order bit for bit (DESIGN.md 3.6); ms includes "
+                    "the host's renumbering of the clusters"},
+        "create_cell_graph": {
+            "ms": graph_ms, "bound": "hbm", "least_bytes": graph_bytes,
+            "frac_of_hbm_peak": graph_bytes / (graph_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if graph_ms > 0 else None,
+            "dependent_gathers": graph_gathers,
+            "note": "bytes = the first graph_k pairs of every cell, the selections (written once, read by the count and the write pass) "
+                    "and the edges; the mutual-selection test gathers the list of every selected neighbour with a smaller id (80 B in "
+                    "one or two 128-byte lines, from an 80 MB array that no L2 holds): 11-12.6 GB of fabric reads per filterEdgesKernel "
+                    "launch in profiles/r04_pmc_bench_chain_1Mcells.json -- the kernel is bound by those gathers' latency (VALU 2-3 %), "
+                    "3 % of the chain"},
     }
 
 
@@ -547,10 +669,9 @@ def bench_chain(args, capi, sharded, synthetic, oracle, device, torch):
                                % (C, G, L, k, thr, thr, args.graph_k),
                    "cells": C, "edges": int(edge_count), "iterations": int(iterations), "clusters": int(clusters.max()) + 1 if len(clusters) else 0},
         "phases_ms": {key: value / args.steps * 1e3 for key, value in times.items()},
-        "roofline": None,
+        "roofline": chain_roofline(capi, args, times, int(edge_count), int(iterations), C, per_vertex),
         "note": "SimilarPairs and the graph's edges stay device-resident from findSimilarPairs4 through createCellGraph "
-                "(em2_dev_cell_graph_edges) to the clusters (em2_dev_cell_graph_label_propagation); label propagation is "
-                "latency-bound pointer chasing, no roofline is attached to it (DESIGN.md 3.6)",
+                "(em2_dev_cell_graph_edges) to the clusters (em2_dev_cell_graph_label_propagation)",
         "parity_check": check,
     }
 
@@ -1017,6 +1138,9 @@ def main():
         result["extra"] = {}
         if not args.no_check:
             result["extra"]["rows_form_one_gpu_as_rank_r_of_P"] = rows_form_block(args, capi, pipe, oracle, sig_host, torch, gate_threads)
+            reference_pairs, reference_used = pipe.results_for(0, C)
+            result["extra"]["facade_e2e"] = facade_block(args, capi, synthetic, torch, inputs["toc"], inputs["data"], reference_pairs, reference_used)
+            del reference_pairs, reference_used
         leg.clear()
         inputs.clear()
         del pipe, vectors
@@ -1030,11 +1154,11 @@ def main():
         small.steps, small.warmup = 2, 1
         line = bench_fsp5(small, capi, oracle, device, torch)
         result["extra"]["configs[3]"] = {key: line[key] for key in ("metric", "value", "unit", "ms_per_step", "steps", "config",
-                                                                     "phases_ms", "roofline", "parity_check")}
+                                                                     "phases_ms", "roofline", "stage_bounds", "parity_check")}
         torch.cuda.empty_cache()
         line = bench_chain(small, capi, sharded, synthetic, oracle, device, torch)
         result["extra"]["configs[4]"] = {key: line[key] for key in ("metric", "value", "unit", "ms_per_step", "steps", "config",
-                                                                     "phases_ms", "parity_check", "note")}
+                                                                     "phases_ms", "roofline", "parity_check", "note")}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -666,15 +666,49 @@ int em2_dev_subset_fill(const uint64_t* d_globalToc, const em2_count* d_globalDa
 }
 
 
+static int subsetFindSimilarPairs4(const uint64_t* globalToc, const em2_count* globalData, uint32_t globalCellCount,
+                                   const uint32_t* cellIds, uint32_t cellCount, const uint32_t* geneLocalIds,
+                                   uint32_t globalGeneCount, uint32_t geneCount, const double* vectors,
+                                   const double* (*vectorsWhenNeeded)(void*), void* vectorsContext, uint32_t lshCount,
+                                   uint64_t* signatures, uint32_t k, double similarityThreshold, em2_pair* pairs,
+                                   uint32_t* usedCount);
+
 int em2_subset_find_similar_pairs4(const uint64_t* globalToc, const em2_count* globalData, uint32_t globalCellCount,
                                    const uint32_t* cellIds, uint32_t cellCount, const uint32_t* geneLocalIds,
                                    uint32_t globalGeneCount, uint32_t geneCount, const double* vectors, uint32_t lshCount,
                                    uint64_t* signatures, uint32_t k, double similarityThreshold, em2_pair* pairs,
                                    uint32_t* usedCount)
 {
+    if (!vectors && cellCount && lshCount && geneCount) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_subset_find_similar_pairs4: null pointer");
+    return subsetFindSimilarPairs4(globalToc, globalData, globalCellCount, cellIds, cellCount, geneLocalIds, globalGeneCount, geneCount,
+                                   vectors, nullptr, nullptr, lshCount, signatures, k, similarityThreshold, pairs, usedCount);
+}
+
+// The same call with the hyperplanes delivered WHEN THEY ARE NEEDED (behind the upload of the expression matrix and its subset):
+// the facade (em2_host.cpp) draws them on a thread of its own meanwhile -- Lsh::generateLshVectors is 0.15 s of one host core at
+// 30 000 genes x 1024 bits, the uploads in front of the projection about as long.  Internal to the library.
+int em2_internal_subset_find_similar_pairs4(const uint64_t* globalToc, const em2_count* globalData, uint32_t globalCellCount,
+                                            const uint32_t* cellIds, uint32_t cellCount, const uint32_t* geneLocalIds,
+                                            uint32_t globalGeneCount, uint32_t geneCount,
+                                            const double* (*vectorsWhenNeeded)(void*), void* vectorsContext, uint32_t lshCount,
+                                            uint64_t* signatures, uint32_t k, double similarityThreshold, em2_pair* pairs,
+                                            uint32_t* usedCount)
+{
+    if (!vectorsWhenNeeded) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_internal_subset_find_similar_pairs4: null pointer");
+    return subsetFindSimilarPairs4(globalToc, globalData, globalCellCount, cellIds, cellCount, geneLocalIds, globalGeneCount, geneCount,
+                                   nullptr, vectorsWhenNeeded, vectorsContext, lshCount, signatures, k, similarityThreshold, pairs, usedCount);
+}
+
+static int subsetFindSimilarPairs4(const uint64_t* globalToc, const em2_count* globalData, uint32_t globalCellCount,
+                                   const uint32_t* cellIds, uint32_t cellCount, const uint32_t* geneLocalIds,
+                                   uint32_t globalGeneCount, uint32_t geneCount, const double* vectors,
+                                   const double* (*vectorsWhenNeeded)(void*), void* vectorsContext, uint32_t lshCount,
+                                   uint64_t* signatures, uint32_t k, double similarityThreshold, em2_pair* pairs,
+                                   uint32_t* usedCount)
+{
     if (lshCount == 0 || geneCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_subset_find_similar_pairs4: lshCount and geneCount must be positive");
     if (cellCount == 0) return EM2_OK;
-    if (!globalToc || !geneLocalIds || !vectors) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_subset_find_similar_pairs4: null pointer");
+    if (!globalToc || !geneLocalIds) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_subset_find_similar_pairs4: null pointer");
     const bool wantPairs = usedCount != nullptr;
     if (wantPairs && !pairs && k) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_subset_find_similar_pairs4: null pairs");
     if (!wantPairs && !signatures) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_subset_find_similar_pairs4: nothing to compute");
@@ -746,6 +780,11 @@ int em2_subset_find_similar_pairs4(const uint64_t* globalToc, const em2_count* g
     EM2_HIP(dVectors.allocate(size_t(geneCount) * lshCount * sizeof(double)));
     EM2_HIP(dSig.allocate(size_t(cellCount) * words * sizeof(uint64_t)));
     EM2_HIP(dWs.allocate(wsBytes));
+    if (!vectors) {
+        vectors = vectorsWhenNeeded(vectorsContext);            // (waits for the thread that draws them)
+        if (!vectors) return fail(EM2_ERROR_RUNTIME, em2_last_error());
+        timer.stage("wait for the hyperplanes");
+    }
     EM2_HIP(hipMemcpy(dVectors.p, vectors, size_t(geneCount) * lshCount * sizeof(double), hipMemcpyHostToDevice));
     void* aux = nullptr;
     if (lshCount % 4u == 0u) {          // (other widths: the exact arithmetic only)

@@ -1,7 +1,17 @@
 #include "em2_host.h"
 
+// internal to the library (em2_capi.hip)
+extern "C" void em2_internal_set_last_error(const char* message);
+extern "C" int em2_internal_subset_find_similar_pairs4(const uint64_t* globalToc, const em2_count* globalData, uint32_t globalCellCount,
+                                                       const uint32_t* cellIds, uint32_t cellCount, const uint32_t* geneLocalIds,
+                                                       uint32_t globalGeneCount, uint32_t geneCount,
+                                                       const double* (*vectorsWhenNeeded)(void*), void* vectorsContext, uint32_t lshCount,
+                                                       uint64_t* signatures, uint32_t k, double similarityThreshold, em2_pair* pairs,
+                                                       uint32_t* usedCount);
+
 #include <chrono>
 #include <functional>
+#include <future>
 #include <memory>
 #include <cstdio>
 #include <cstdlib>
@@ -334,9 +344,19 @@ void Matrix::runLshPath(const char* what, const std::string& geneSetName, const 
     if (lshCount == 0 || lshCount > 0xffffffffULL || k > 0xffffffffULL) fail(EM2_ERROR_INVALID_ARGUMENT, std::string(what) + ": lshCount or k out of range");
     const uint32_t geneCount = genes->size();
     timer.stage("lookup");
-    std::vector<double> vectors(size_t(geneCount) * lshCount);
-    if (em2_lsh_generate_vectors(geneCount, uint32_t(lshCount), seed, vectors.data()) != EM2_OK) fail(EM2_ERROR_RUNTIME, em2_last_error());
-    timer.stage("hyperplanes");
+    // Lsh::generateLshVectors (src/Lsh.cpp:68-113) on a thread of its own: the device call asks for the hyperplanes when it has
+    // uploaded the expression matrix and taken its subset (em2_internal_subset_find_similar_pairs4)
+    struct Hyperplanes {
+        std::vector<double> values;
+        std::future<int> drawn;
+        std::string error;
+    } hyperplanes;
+    hyperplanes.values.resize(size_t(geneCount) * lshCount);
+    hyperplanes.drawn = std::async(std::launch::async, [&hyperplanes, geneCount, lshCount, seed]() {
+        const int rc = em2_lsh_generate_vectors(geneCount, uint32_t(lshCount), seed, hyperplanes.values.data());
+        if (rc != EM2_OK) hyperplanes.error = em2_last_error();          // (the error text is thread-local: carried over)
+        return rc;
+    });
     const size_t words = (lshCount - 1) / 64 + 1;
     if (signatures) signatures->assign(size_t(cellCount) * words, 0);
     em2_pair* pairs = nullptr;
@@ -344,13 +364,23 @@ void Matrix::runLshPath(const char* what, const std::string& geneSetName, const 
         pairs = pairsFor(cellCount);           // where the pairs go (the mapped SimilarPairs file)
         used->assign(cellCount, 0);
     }
-    const int rc = em2_subset_find_similar_pairs4(
+    const int rc = em2_internal_subset_find_similar_pairs4(
         static_cast<const uint64_t*>(toc_.data()), static_cast<const em2_count*>(data_.data()), uint32_t(toc_.objectCount() - 1),
         cellIds, cellCount, static_cast<const uint32_t*>(genes->localIds.data()), uint32_t(genes->localIds.objectCount()),
-        geneCount, vectors.data(), uint32_t(lshCount), signatures ? signatures->data() : nullptr, uint32_t(k),
-        similarityThreshold, pairs, used ? used->data() : nullptr);
+        geneCount,
+        [](void* context) -> const double* {
+            Hyperplanes* h = static_cast<Hyperplanes*>(context);
+            if (h->drawn.get() != EM2_OK) {
+                em2_internal_set_last_error(h->error.c_str());
+                return nullptr;
+            }
+            return h->values.data();
+        },
+        &hyperplanes, uint32_t(lshCount), signatures ? signatures->data() : nullptr, uint32_t(k), similarityThreshold, pairs,
+        used ? used->data() : nullptr);
+    if (hyperplanes.drawn.valid()) hyperplanes.drawn.wait();          // (a call that failed before it asked for them)
     if (rc != EM2_OK) fail(rc, em2_last_error());
-    timer.stage("device: subset, signatures, pairs (incl. transfers)");
+    timer.stage("hyperplanes (a thread) under the uploads; device: subset, signatures, pairs (incl. transfers)");
 }
 
 void Matrix::findSimilarPairs4(const std::string& geneSetName, const std::string& cellSetName,
