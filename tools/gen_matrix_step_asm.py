@@ -267,6 +267,9 @@ def place(s, o, k, what, prev0, prev1, slot, carry=False):
         elif letter == "C":
             s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass0_%d" % (k & 1)], vreg(THR0), vreg(prev0 + k)))
             s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass1_%d" % (k & 1)], vreg(THR1), vreg(prev1 + k)))
+            if BIAS:
+                s.emit("v_sub_f32 %s, %s, %s" % (vreg(prev0 + k), vreg(bound), vreg(bound)))
+                s.emit("v_sub_f32 %s, %s, %s" % (vreg(prev1 + k), vreg(bound), vreg(bound)))
 
 
 # The ring of fragments runs through a PAIR of tiles: the step of a pair's first tile (X) ends by reading the first four
@@ -281,6 +284,12 @@ TILE_BOUND = os.environ.get("EM2_GEN_TILE_BOUND", "0") == "1"
 # nothing passed), EXEC is restored; five more instructions per result, all of them masked off almost always (DESIGN 3.1.6:
 # 4.9 PFLOP/s at every record rate against 6.6 at the scan's -- instructions under an empty EXEC are not free, the stores least).
 CMPX = os.environ.get("EM2_GEN_CMPX", "0") == "1"
+# EM2_GEN_BIAS=1 (experiment): what the 0/1 operand encoding would add to a step.  With bits as 0 / 1 the dot
+# product is popcount(a & b) and mismatches = pa + pb - 2 dot: the accumulators of the NEXT tile must start at -(pa_r + pb_c) / 2
+# instead of 0 so that the test and the records stay as they are.  Each register of the set under test is re-initialised right
+# behind its test (v_add_f32 of a row term and a column term that travels like the bounds), and a tile's first MFMAs take the
+# accumulator as their C operand.  Timing only: the terms are the bounds' registers here.
+BIAS = os.environ.get("EM2_GEN_BIAS", "0") == "1"
 # EM2_GEN_STUB: the form of the stubs.  "branches" = round 2's (two s_mov around the record); "saveexec" = s_and_saveexec_b64
 # instead of the first two; "mfma" = that, and the checks of a k-step sit directly in front of its second matrix instruction, of
 # which every stub carries a copy (shift_in); "empty" = no record at all (measurement: the branches alone).
@@ -320,7 +329,7 @@ def step(cur, prev, tests, operands):
             # (the form without block scales: scale 2^0 is what the operands want, and v_mfma_scale_* is two instructions --
             # a v_mfma_ld_scale_b32 in front of this one -- 16 bytes instead of 8 and an issue slot more per MFMA)
             mfma = ("v_mfma_f32_32x32x64_f8f6f4 %s, %s, %s, %s cbsz:4 blgp:4"
-                    % (vreg(acc, 16), vreg(slot, 4), vreg(rows + 4 * k, 4), "0" if k == 0 else vreg(acc, 16)))
+                    % (vreg(acc, 16), vreg(slot, 4), vreg(rows + 4 * k, 4), "0" if (k == 0 and not BIAS) else vreg(acc, 16)))
             if a == 1 and tests and STUB == "mfma" and k:
                 shift_in(s, o, k - 1, carried=mfma)        # (emits the instruction itself behind the two checks)
             else:
