@@ -59,9 +59,9 @@ VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9     # 256 CUs x 4 SIMD x 16 lanes/clk
 # The PMC digests `traffic` may come from (tools/profile_bench.sh -> tools/profile_digest.py), one per workload; each names
 # the configuration it was taken on and is used for that configuration only (tests/test_bench_plumbing_cpu.py).
 PROFILE_DIGESTS = {
-    "fsp4": "r04_pmc_bench_1Mcells_1gpu.json",
-    "fsp5": "r04_pmc_bench_fsp5_1Mcells_2048bit.json",
-    "chain": "r04_pmc_bench_chain_1Mcells.json",
+    "fsp4": "r05_pmc_bench_1Mcells_1gpu.json",
+    "fsp5": "r05_pmc_bench_fsp5_1Mcells_2048bit.json",
+    "chain": "r05_pmc_bench_chain_1Mcells.json",
 }
 TRAFFIC_NOTE = "FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE, bytes per launch of the profiled run"
 
@@ -586,7 +586,7 @@ def chain_roofline(capi, args, times, edges, iterations, cells, per_vertex):
             "frac_of_hbm_peak_by_lines": line_bytes / (label_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if label_ms > 0 else None,
             "turns_per_s": cells * max(1, iterations) / (label_ms * 1e-3) if label_ms > 0 else None,
             "note": "bytes = 2 x edges x 32 B (one record per vertex and neighbour) per iteration, or x 128 B as the lines the gathers move "
-                    "(profiles/r04_pmc_bench_chain_1Mcells.json: 5.2 GB fetched per launch against 0.97 GB of records).  What binds is the "
+                    "(profiles/r05_pmc_bench_chain_1Mcells.json: 5.2 GB fetched per launch against 0.97 GB of records).  What binds is the "
                     "ORDER: the reference's asynchronous updates (src/CellGraph.cpp:445-616) make a vertex wait for every neighbour at a "
                     "smaller position of the iteration's shuffle, and the kernel keeps that order bit for bit (DESIGN.md 3.6); ms includes "
                     "the host's renumbering of the clusters"},
@@ -597,7 +597,7 @@ def chain_roofline(capi, args, times, edges, iterations, cells, per_vertex):
             "note": "bytes = the first graph_k pairs of every cell, the selections (written once, read by the count and the write pass) "
                     "and the edges; the mutual-selection test gathers the list of every selected neighbour with a smaller id (80 B in "
                     "one or two 128-byte lines, from an 80 MB array that no L2 holds): 11-12.6 GB of fabric reads per filterEdgesKernel "
-                    "launch in profiles/r04_pmc_bench_chain_1Mcells.json -- the kernel is bound by those gathers' latency (VALU 2-3 %), "
+                    "launch in profiles/r05_pmc_bench_chain_1Mcells.json -- the kernel is bound by those gathers' latency (VALU 2-3 %), "
                     "3 % of the chain"},
     }
 

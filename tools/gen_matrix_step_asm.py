@@ -198,6 +198,21 @@ def stubs(s, o, prev0, prev1):
             s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET + a), vreg(OFFSET + a)))
             s.emit("s_mov_b64 exec, %s" % o["save"])
             return
+        if STUB == "pend":
+            # (experiment, DESIGN.md 8: ONE pending record per lane, stored by a flush at the end of the step; an event in a
+            # lane whose record is still pending stores that one first.  One log per lane: v28 alone counts.)
+            s.emit("s_and_saveexec_b64 %s, %s" % (o["save"], mask))
+            s.emit("v_cmp_ne_u32_e32 vcc, 0, %s" % vreg(RECORD))
+            s.emit("s_cbranch_vccz L_free_%d_%d_%%=" % (k, a))
+            s.emit("s_mov_b64 exec, vcc")
+            s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET), vreg(RECORD, 2), o["logBase"]))
+            s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET), vreg(OFFSET)))
+            s.emit("s_mov_b64 exec, %s" % mask)
+            s.emit("L_free_%d_%d_%%=:" % (k, a))
+            s.emit("v_or_b32_e64 %s, %s, %d" % (vreg(RECORD), o["tileCode"], 2 * k + a))     # (the caller's tile code has bit 31 set: "pending")
+            s.emit("v_mov_b32 %s, %s" % (vreg(RECORD + 1), vreg(acc)))
+            s.emit("s_mov_b64 exec, %s" % o["save"])
+            return
         if STUB in ("saveexec", "mfma"):
             s.emit("s_and_saveexec_b64 %s, %s" % (o["save"], mask))
         else:
@@ -221,6 +236,15 @@ def stubs(s, o, prev0, prev1):
             record(k, 1)
         s.emit("s_branch L_back_%d_%d_%%=" % (k, 0 if carried else a))
     s.emit("L_end_%=:")
+    if STUB == "pend":
+        s.emit("v_cmp_ne_u32_e32 vcc, 0, %s" % vreg(RECORD))
+        s.emit("s_cbranch_vccz L_flushed_%=")
+        s.emit("s_and_saveexec_b64 %s, vcc" % o["save"])
+        s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET), vreg(RECORD, 2), o["logBase"]))
+        s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET), vreg(OFFSET)))
+        s.emit("v_mov_b32 %s, 0" % vreg(RECORD))
+        s.emit("s_mov_b64 exec, %s" % o["save"])
+        s.emit("L_flushed_%=:")
     s.emit("v_mov_b32 %s, %s" % (o["count"], vreg(OFFSET)))
     s.emit("v_mov_b32 %s, %s" % (o["count1"], vreg(OFFSET + 1)))
 
@@ -519,7 +543,8 @@ def main():
     out.write("#define EM2_MATRIX_OWNED_REGISTERS %s\n\n" % owned)
     out.write("#define EM2_MATRIX_STEP_CLOBBERS \"memory\", \"vcc\", \"scc\", EM2_MATRIX_OWNED_REGISTERS\n\n")
     # the lane's record offset lives in a register of the walk from step to step
-    out.write("#define EM2_MATRIX_SET_RECORD_OFFSETS \"v_mov_b32 v%d, %%0\\nv_mov_b32 v%d, %%1\\n\"\n\n" % (OFFSET, OFFSET + 1))
+    out.write("#define EM2_MATRIX_SET_RECORD_OFFSETS \"v_mov_b32 v%d, %%0\\nv_mov_b32 v%d, %%1\\n%s\"\n\n"
+              % (OFFSET, OFFSET + 1, "v_mov_b32 v%d, 0\\n" % RECORD if STUB == "pend" else ""))
     # the B operand in one go: 32 loads straight into the registers, one wait.  %0 = address of the wave's first row
     # fragment (scalar pair); the fragments of a 32-row block are 1 KB apart (64 lanes x 16 bytes), the second block
     # follows the first

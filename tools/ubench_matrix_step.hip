@@ -11,6 +11,9 @@
 #include <cstdlib>
 #include <vector>
 #include "em2_matrix_step_asm.h"
+#ifndef UBENCH_TILE_BIT
+#define UBENCH_TILE_BIT 0u          // (-DUBENCH_TILE_BIT=0x80000000u for EM2_GEN_STUB=pend: a record word that is never 0)
+#endif
 
 // LDS: 4 tiles (64 KB), then per wave: rowDot float[64] (256 B) + bounds float[4][32] (512 B)
 __global__ void __launch_bounds__(256) stepLoop(int rounds, int mode, float bound, const unsigned* tiles, const unsigned* rows,
@@ -59,11 +62,11 @@ __global__ void __launch_bounds__(256) stepLoop(int rounds, int mode, float boun
         } else {
             asm volatile(EM2_MATRIX_STEP_X_TESTING_Y
                          : "=v"(recordOffset), "=v"(recordOffset1), "=&s"(scratch[0]), "=&s"(scratch[1]), "=&s"(scratch[2]), "=&s"(scratch[3]), "=&s"(scratch[4])
-                         : "s"(t0), "s"(walkLds + 256), "s"(walkLds), "s"(logBase), "s"(unsigned(r) * 64u)
+                         : "s"(t0), "s"(walkLds + 256), "s"(walkLds), "s"(logBase), "s"(unsigned(r) * 64u | UBENCH_TILE_BIT)
                          : EM2_MATRIX_STEP_CLOBBERS);
             asm volatile(EM2_MATRIX_STEP_Y_TESTING_X
                          : "=v"(recordOffset), "=v"(recordOffset1), "=&s"(scratch[0]), "=&s"(scratch[1]), "=&s"(scratch[2]), "=&s"(scratch[3]), "=&s"(scratch[4])
-                         : "s"(t1), "s"(walkLds + 256 + 128), "s"(walkLds), "s"(logBase), "s"(unsigned(r) * 64u + 32u)
+                         : "s"(t1), "s"(walkLds + 256 + 128), "s"(walkLds), "s"(logBase), "s"(unsigned(r) * 64u + 32u | UBENCH_TILE_BIT)
                          : EM2_MATRIX_STEP_CLOBBERS);
             if ((r & 15) == 15) {       // (the log of a lane holds 4096 records: start over)
                 counts[(blockIdx.x * 4 + wave) * 64 + lane] += (recordOffset - offset) / 8 + (recordOffset1 - offset1) / 8;
