@@ -227,7 +227,9 @@ vectorsToQuantizedKernel(const double* __restrict__ vectors, uint32_t geneCount,
         if (gene == 0u) scales[bit] = scale;
         double q = scale > 0. ? rint(vectors[i] / scale) : 0.;
         q = q > 32767. ? 32767. : (q < -32767. ? -32767. : q);
-        out[(uint64_t(bit >> 6) * geneCount + gene) * 64u + (bit & 63u)] = int16_t(int(q));
+        // (inside a gene's 128-byte line the word's bits are TRANSPOSED as an 8 x 8 matrix: position 8 s + t holds bit 8 t + s, so
+        // that the lane that ends up with position 8 s + t of the first tier's sums -- lane 8 t + s -- holds the bit of its own number)
+        out[(uint64_t(bit >> 6) * geneCount + gene) * 64u + (((bit & 7u) << 3) | ((bit >> 3) & 7u))] = int16_t(int(q));
     }
 }
 
@@ -267,10 +269,13 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
     // the word's slice of the 16-bit copy (wave-uniform: a scalar base) and the lane's 16 bytes of a gene's 128-byte line
     const char* slice = reinterpret_cast<const char*>(quantized + size_t(word) * geneCount * 64u);
     const uint32_t laneBytes = sub * 16u;
-    // The 24 per-bit constants of a lane (sum, largest magnitude and scale of its 8 hyperplane columns) are only needed
-    // once per cell, after the gathers: they wait in LDS and are read there through an index the compiler cannot see
-    // through, so that they do not become 48 registers held across the gather loop (146 registers, three waves per SIMD:
-    // the loop lives on latency).
+    // After the gathers a lane finishes ONE bit of the word, the bit of its own number (see the reduction below), with the
+    // three constants of that hyperplane column (sum, largest magnitude, scale).  (Until round 5 every lane
+    // finished the eight bits of its 16 bytes, all eight entry groups the same eight: 24 constants per lane, which waited in
+    // LDS -- 64 bytes apart, lanes sub and sub + 4 on the same banks: 4.6e9 bank-conflict cycles per launch at 1M cells,
+    // profiles/r04_pmc_bench_1Mcells_1gpu.json -- and eight times the double-precision work.)
+    // They wait in LDS (lane l reads element l: no two lanes on a bank) behind an index the compiler cannot see through: held
+    // in registers across the gather loop they cost the float form its fifth wave per SIMD (98 registers).
     __shared__ double bitConstants[3][64];
     if (threadIdx.x < 64u) {
         bitConstants[0][threadIdx.x] = vectorSums[word * 64u + threadIdx.x];
@@ -341,6 +346,11 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
                     else u[q] = *reinterpret_cast<const uint4*>(slice + ((gene[q] << 7) | laneBytes));
                 }
                 const bool lastPart = first + (half + 1u) * kPart >= entryCount;
+                if (DIAG == 1 && INTEGER) {
+#pragma unroll
+                    for (uint32_t q = 0; q < kInFlight; ++q) exact[q & 7u] += int((u[q].x ^ u[q].y ^ u[q].z ^ u[q].w) & 0xffu) + int(x[q]);
+                    continue;
+                }
                 if (DIAG == 1) {
 #pragma unroll
                     for (uint32_t q = 0; q < kInFlight; ++q) {
@@ -389,64 +399,69 @@ projectionScreenQuantizedKernel(const uint64_t* __restrict__ toc, const CountIn*
             }
         }
 #undef EM2_LOAD_ENTRIES
+        // The eight entry groups' sums, TRANSPOSED on the way: a lane holds eight sums (positions 8 sub .. 8 sub + 7 of the line)
+        // over its group's entries; in three exchanges (group bit 0, 1, 2) it gives away half of what it still holds and adds
+        // what its partner gives -- 4 + 2 + 1 values cross instead of 3 x 8 -- and ends with the one sum of position
+        // 8 sub + group over ALL entries, which by the copy's order inside a line is bit 8 group + sub = the lane's own number.
+        // (The additions of a bit happen in the order of the butterfly this replaces; the integer form is exact anyway.)
+        double mine;
         if (INTEGER) {
-            // (the eight entry groups' sums: still exact in 32 bits, sum|count| <= 65535 bounds the cell's whole sum)
+            int four[4], two[2];
 #pragma unroll
-            for (int d = 8; d < 64; d <<= 1) {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) exact[t] += __shfl_xor(exact[t], d, 64);
+            for (int i = 0; i < 4; ++i) {
+                const int give = (group & 1u) ? exact[2 * i] : exact[2 * i + 1];
+                four[i] = ((group & 1u) ? exact[2 * i + 1] : exact[2 * i]) + __shfl_xor(give, 8, 64);          // t = 2 i + (group & 1)
             }
 #pragma unroll
-            for (int t = 0; t < 8; ++t) a[t] = double(exact[t]);
+            for (int i = 0; i < 2; ++i) {
+                const int give = (group & 2u) ? four[2 * i] : four[2 * i + 1];
+                two[i] = ((group & 2u) ? four[2 * i + 1] : four[2 * i]) + __shfl_xor(give, 16, 64);            // t = 4 i + (group & 3)
+            }
+            const int give = (group & 4u) ? two[0] : two[1];
+            mine = double(((group & 4u) ? two[1] : two[0]) + __shfl_xor(give, 32, 64));                        // t = group
         } else {
+            double four[4], two[2];
 #pragma unroll
-            for (int d = 8; d < 64; d <<= 1) {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) a[t] += __shfl_xor(a[t], d, 64);
+            for (int i = 0; i < 4; ++i) {
+                const double give = (group & 1u) ? a[2 * i] : a[2 * i + 1];
+                four[i] = ((group & 1u) ? a[2 * i + 1] : a[2 * i]) + __shfl_xor(give, 8, 64);
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const double give = (group & 2u) ? four[2 * i] : four[2 * i + 1];
+                two[i] = ((group & 2u) ? four[2 * i + 1] : four[2 * i]) + __shfl_xor(give, 16, 64);
+            }
+            const double give = (group & 4u) ? two[0] : two[1];
+            mine = ((group & 4u) ? two[1] : two[0]) + __shfl_xor(give, 32, 64);
         }
         const double mean = means[c];
         const double n = double(jEnd - jBegin);
         const double factor = (n + 12.) * 2.220446049250313e-16 * 1.000001;
         const double absMean = fabs(mean);
         const double absX = sumAbs[c];
-        uint32_t byte = 0;
-        uint32_t ambiguousBits = 0;             // bit t: the lane's t-th bit is undecided
-        uint32_t firstConstant = sub * 8u;
-        asm volatile("" : "+v"(firstConstant));          // (not loop-invariant as far as the compiler knows)
-        const double* constantsOfLane = allConstants + firstConstant;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const double sT = constantsOfLane[t], mxT = constantsOfLane[64 + t], scaleT = constantsOfLane[128 + t];
-            const double total = __fma_rn(a[t], scaleT, __dmul_rn(-mean, sT));
-            // (+ the single-precision chunks: 16 * 2^-24 * sum|count * q| * scale <= 9.6e-7 * sum|x| * max|U_i|, and a
-            // subnormal slack for them)
-            // (INTEGER: the sum of count * q is exact, that term and the subnormal slack are not needed)
-            const double bound = factor * (absMean * fabs(sT) + absX * mxT) + 0.501 * scaleT * absX +
-                                 (INTEGER ? 0. : 9.6e-7 * absX * mxT + n * 1.5e-45 * scaleT) + 1e-300;
-            // (a single-precision chunk that overflowed makes the total infinite: undecided as well)
-            ambiguousBits |= (!(fabs(total) > bound) || !(fabs(total) <= 1.7976931348623157e308)) ? (1u << t) : 0u;
-            byte |= (total > 0.) ? (0x80u >> t) : 0u;                  // first bit most significant
-        }
-        // 8 lanes x 8 bits -> one MSB-first 64-bit word
-        uint64_t w = uint64_t(byte) << (56u - 8u * sub);
-#pragma unroll
-        for (int d = 1; d < 8; d <<= 1) {
-            const uint32_t lo = uint32_t(__shfl_xor(int(uint32_t(w)), d, 8));
-            const uint32_t hi = uint32_t(__shfl_xor(int(uint32_t(w >> 32)), d, 8));
-            w |= uint64_t(lo) | (uint64_t(hi) << 32);
-        }
+        uint32_t constantOfLane = lane;
+        asm volatile("" : "+v"(constantOfLane));          // (not loop-invariant as far as the compiler knows)
+        const double sumOfBit = allConstants[constantOfLane], maxOfBit = allConstants[64u + constantOfLane],
+                     scaleOfBit = allConstants[128u + constantOfLane];
+        const double total = __fma_rn(mine, scaleOfBit, __dmul_rn(-mean, sumOfBit));
+        // (+ the single-precision chunks: 16 * 2^-24 * sum|count * q| * scale <= 9.6e-7 * sum|x| * max|U_i|, and a
+        // subnormal slack for them)
+        // (INTEGER: the sum of count * q is exact, that term and the subnormal slack are not needed)
+        const double bound = factor * (absMean * fabs(sumOfBit) + absX * maxOfBit) + 0.501 * scaleOfBit * absX +
+                             (INTEGER ? 0. : 9.6e-7 * absX * maxOfBit + n * 1.5e-45 * scaleOfBit) + 1e-300;
+        // (a single-precision chunk that overflowed makes the total infinite: undecided as well)
+        const bool ambiguous = !(fabs(total) > bound) || !(fabs(total) <= 1.7976931348623157e308);
+        // lane l = bit l of the word, first bit most significant
+        const uint64_t w = __brevll(__builtin_amdgcn_ballot_w64(total > 0.));
         // A word with undecided bits goes to a later tier.  Almost always it is ONE bit (a cell has 1.1 undecided bits in 1.07
         // words on the benchmark data): such a word is listed by that bit, for the per-bit form of the float tier (one float
         // per count instead of the 64 of the whole word); anything else is listed as a word.
-        const uint32_t ambLanes = uint32_t(__builtin_amdgcn_ballot_w64(ambiguousBits != 0u)) & 0xffu;
-        const uint32_t firstAmbLane = ambLanes ? uint32_t(__builtin_ctz(ambLanes)) : 0u;
-        const uint32_t bitsOfThatLane = uint32_t(__builtin_amdgcn_readlane(int(ambiguousBits), int(firstAmbLane)));
+        const uint64_t ambiguousMask = __builtin_amdgcn_ballot_w64(ambiguous);
         if (lane == 0u) {
             signatures[size_t(c) * wordCount + word] = w;
-            if (ambLanes != 0u && DIAG == 0) {
-                if ((ambLanes & (ambLanes - 1u)) == 0u && (bitsOfThatLane & (bitsOfThatLane - 1u)) == 0u && bitList) {
-                    const uint32_t bit = word * 64u + firstAmbLane * 8u + uint32_t(__builtin_ctz(bitsOfThatLane));
+            if (ambiguousMask != 0ull && DIAG == 0) {
+                if ((ambiguousMask & (ambiguousMask - 1ull)) == 0ull && bitList) {
+                    const uint32_t bit = word * 64u + uint32_t(__builtin_ctzll(ambiguousMask));
                     bitList[atomicAdd(bitCount, 1u)] = (uint64_t(c) << 32) | bit;
                 } else {
                     workList[atomicAdd(workCount, 1u)] = (uint64_t(c) << 32) | word;
@@ -959,7 +974,9 @@ hipError_t launchProjectionScreened(const uint64_t* toc, const CountIn* data, ui
 #ifdef EM2_DIAG
         const char* diagText = getenv("EM2_PROJECTION_DIAG");
         const int diag = diagText ? atoi(diagText) : 0;
-        auto kernel = diag == 1 ? &projectionScreenQuantizedKernel<1> : (diag == 2 ? &projectionScreenQuantizedKernel<2> : &projectionScreenQuantizedKernel<0>);
+        // (1 / 2: the float form's gathers alone / arithmetic alone; 3 / 4: the same of the integer form)
+        auto kernel = diag == 1 ? &projectionScreenQuantizedKernel<1> : (diag == 2 ? &projectionScreenQuantizedKernel<2> :
+                      (diag == 3 ? &projectionScreenQuantizedKernel<1, true> : (diag == 4 ? &projectionScreenQuantizedKernel<2, true> : &projectionScreenQuantizedKernel<0>)));
         const bool diagOff = diag == 0;
 #else
         auto kernel = &projectionScreenQuantizedKernel<0>;
