@@ -530,7 +530,7 @@ def bench_fsp5(args, capi, oracle, device, torch):
         # and one v_bcnt_u32_b32 per 32 bits of every distinct candidate's signature (SURVEY 8(d)'s own VALU ceiling for
         # xor/popcount: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz lane-operations per second, the issue rate measured in
         # profiles/r01_ubench_valu_xor_bcnt.txt); `bound_unit` "lane-op/s".  The HBM byte model of 8(d) rides along (hbm_view).
-        "roofline": {"kernel": ("filterWideKernel<%s> (all batches)" % ("1, 16" if W == 32 else "2, 16" if W == 64 else "T, LPC")) if W % 2 == 0 and W <= 64
+        "roofline": {"kernel": ("filterWideKernel<%s> (all batches)" % ("4, 4" if W == 32 else "2, 16" if W == 64 else "T, LPC")) if W % 2 == 0 and W <= 64
                                else "filterCooperativeKernel (all batches)", "kernel_ms": filter_ms, "bound": "valu",
                      "achieved": distinct * 2.0 * W * 2.0 / (filter_ms * 1e-3) / 1e12 if filter_ms > 0 else 0.0,
                      "peak": VALU_LANE_OPS_PER_S / 1e12, "unit": "T lane-op/s",

@@ -524,8 +524,8 @@ filterCooperativeKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32
 // 16-byte units -- at 2048 bits one 256-byte request per candidate, where filterCooperativeKernel issues two 128-byte requests
 // of 8-byte lane loads (8-byte accesses reach 0.54-0.70 of the 16-byte rate: MI355X_MICROARCH.md, visibility table) -- and a
 // lane has UNROLL such loads outstanding before the first popcount.  Everything else is filterCooperativeKernel.
-// T: 16-byte units per lane -- 1 (up to 2048 bits with 16 lanes per candidate), 2 (up to 4096 bits).  LPC: lanes per candidate
-// as a compile-time constant (16, 8), or 0 = decided at run time (narrow signatures); FULL: every lane holds a unit of the row
+// T: 16-byte units per lane -- 1 (narrow signatures, 16 lanes per candidate), 4 (2048 bits: four lanes per candidate), 2 (up to
+// 4096 bits).  LPC: lanes per candidate as a compile-time constant (16, 8, 4), or 0 = decided at run time (narrow signatures); FULL: every lane holds a unit of the row
 // (units == T * LPC: 2048 and 4096 bits).  Since the grouped visiting order the kernel
 // is bound by its vector ALUs (VALU busy 85 %), so the inner loop is straight-line code: the loads are unconditional (a slot
 // without a candidate reads the cell's own row and counts 0), one 16-byte load per unit, the 16-lane sums are four
@@ -1264,7 +1264,10 @@ hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin,
             filterWideKernel<TT, LL, FF><<<filterBlocks, 256, 0, stream>>>(d_sig, words, batchBegin, batchCells, segBegin.as<uint32_t>(), sorted,  \
                                                                      lists.as<Entry>(), tables.mGlobal, tables.keyOfMismatch,         \
                                                                      listCounts.as<uint32_t>(), distinct, order, orderChunk)
-            if (unitsPerLane == 1u && units == 16u) EM2_FILTER_WIDE(1, 16, true);
+            // (2048 bits: FOUR units per lane and four lanes per candidate -- two reduction steps instead of four and a quarter of
+            // the per-candidate bookkeeping per unit: 66.3 -> 62.5 ms at 1M cells, same box; {1, 16} 66.3, {2, 8} 68.1, {8, 2} 77.2,
+            // {16, 1} 196.5; eight loads in flight instead of four change nothing, two cost 10 ms: profiles/r05_fsp5_experiments.md)
+            if (unitsPerLane == 1u && units == 16u) EM2_FILTER_WIDE(4, 4, true);
             else if (unitsPerLane == 1u && lanesPerCandidate == 16u) EM2_FILTER_WIDE(1, 16, false);
             else if (unitsPerLane == 1u && lanesPerCandidate == 8u) EM2_FILTER_WIDE(1, 8, false);
             else if (unitsPerLane == 1u) EM2_FILTER_WIDE(1, 0, false);
