@@ -580,16 +580,24 @@ filterWideKernel(const uint64_t* __restrict__ sig, uint32_t words, uint32_t batc
         mine[t] = sig16[size_t(c) * units + unit[t]];
     }
     uint32_t n = 0;
+    // (the candidate ids and the list entries are streams: non-temporal, so that they do not push the signatures the XCD's cells
+    // share out of its L2.  The ids of the NEXT 64 candidates are loaded before this turn's rows are: a turn was two dependent
+    // memory round trips, ids then rows.  A candidate's predecessor comes from the lane below, lane 0's from the turn before.)
+    uint32_t nextCand = begin + lane < end ? __builtin_nontemporal_load(sortedCandidates + begin + lane) : 0u;
+    uint32_t lastOfPreviousTurn = 0;
     for (uint32_t base = begin; base < end; base += 64u) {
         const uint32_t i = base + lane;
         bool need = false;
-        uint32_t cand = 0;
-        if (i < end) {
-            // (the candidate ids and the list entries are streams: non-temporal, so that they do not push the signatures the
-            // XCD's cells share out of its L2)
-            cand = __builtin_nontemporal_load(sortedCandidates + i);
-            const bool duplicate = i > listBegin && __builtin_nontemporal_load(sortedCandidates + i - 1u) == cand;
-            need = !duplicate && cand != c;                                  // ExpressionMatrixLsh.cpp:437-439
+        const uint32_t cand = nextCand;
+        nextCand = i + 64u < end ? __builtin_nontemporal_load(sortedCandidates + i + 64u) : 0u;
+        {
+            const uint32_t below = uint32_t(__shfl_up(int(cand), 1, 64));
+            const uint32_t previous = lane ? below : lastOfPreviousTurn;
+            lastOfPreviousTurn = uint32_t(__builtin_amdgcn_readlane(int(cand), 63));
+            if (i < end) {
+                const bool duplicate = i > listBegin && previous == cand;
+                need = !duplicate && cand != c;                                  // ExpressionMatrixLsh.cpp:437-439
+            }
         }
         const uint64_t needMask = __builtin_amdgcn_ballot_w64(need);
         const uint32_t needCount = uint32_t(__builtin_popcountll(needMask));
