@@ -182,10 +182,6 @@ int em2_lsh_generate_vectors(uint32_t geneCount, uint32_t lshCount, uint32_t see
     const size_t total = size_t(geneCount) * lshCount;
     const size_t pairCount = (total + 1) / 2;
     std::vector<uint32_t> raw(2 * pairCount);
-    {
-        std::mt19937 engine(seed);
-        for (size_t i = 0; i < 2 * pairCount; i++) raw[i] = uint32_t(engine());
-    }
     unsigned threads = std::thread::hardware_concurrency();
     if (threads > 32) threads = 32;
     if (threads < 1 || total < (1u << 16)) threads = 1;
@@ -204,7 +200,7 @@ int em2_lsh_generate_vectors(uint32_t geneCount, uint32_t lshCount, uint32_t see
     };
     const double scale = 1.0 / 4294967296.0;
     const double twoPi = 2.0 * 3.14159265358979323846;
-    parallel(pairCount, [&](size_t begin, size_t end) {
+    auto variates = [&](size_t begin, size_t end) {
         for (size_t p = begin; p < end; p++) {
             const double r1 = double(raw[2 * p]) * scale;
             const double r2 = double(raw[2 * p + 1]) * scale;
@@ -212,7 +208,66 @@ int em2_lsh_generate_vectors(uint32_t geneCount, uint32_t lshCount, uint32_t see
             vectors[2 * p] = rho * std::cos(twoPi * r1);
             if (2 * p + 1 < total) vectors[2 * p + 1] = rho * std::sin(twoPi * r1);
         }
-    });
+    };
+    // The engine, 624 values at a time: the three loops of a state update have no dependence closer than 227 elements and
+    // the compiler vectorises them (25 ms for the 3.1e7 draws of 30 000 genes x 1 024 bits where std::mt19937, one value
+    // per call, takes 72; tests/test_capi_cpu.py holds it to std::mt19937).  The variates are formed behind it, part by part.
+    struct Mt19937Blocks {
+        uint32_t s[624];
+        explicit Mt19937Blocks(uint32_t seed)
+        {
+            s[0] = seed;
+            for (uint32_t i = 1; i < 624; ++i) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + i;
+        }
+        static inline uint32_t mix(uint32_t a, uint32_t b)
+        {
+            const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+            return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        void next(uint32_t* out, size_t count)          // the next count <= 624 values
+        {
+            for (int i = 0; i < 227; ++i) s[i] = s[i + 397] ^ mix(s[i], s[i + 1]);
+            for (int i = 227; i < 623; ++i) s[i] = s[i - 227] ^ mix(s[i], s[i + 1]);
+            s[623] = s[396] ^ mix(s[623], s[0]);
+            for (size_t i = 0; i < count; ++i) {
+                uint32_t y = s[i];
+                y ^= y >> 11;
+                y ^= (y << 7) & 0x9d2c5680u;
+                y ^= (y << 15) & 0xefc60000u;
+                y ^= y >> 18;
+                out[i] = y;
+            }
+        }
+    };
+    {
+        // (no thread ever waits for the engine by spinning: under a CPU quota 63 spinning workers got the whole process throttled
+        // for hundreds of milliseconds at a time.  The engine's output goes to the workers in eight parts; the workers of a part
+        // run while the engine produces the next.)
+        constexpr size_t kParts = 8;
+        const size_t rawCount = 2 * pairCount;
+        std::vector<std::thread> pool;
+        Mt19937Blocks engine(seed);
+        size_t produced = 0;          // raw values written
+        for (size_t part = 0; part < kParts; ++part) {
+            const size_t partEndPair = part + 1 == kParts ? pairCount : std::min(pairCount, (pairCount / kParts + 1) * (part + 1));
+            while (produced < 2 * partEndPair) {
+                engine.next(raw.data() + produced, std::min(size_t(624), rawCount - produced));
+                produced += std::min(size_t(624), rawCount - produced);
+            }
+            const size_t beginPair = part == 0 ? 0 : std::min(pairCount, (pairCount / kParts + 1) * part);
+            if (threads == 1) {
+                variates(beginPair, partEndPair);
+                continue;
+            }
+            const unsigned workers = std::max(1u, threads / 2u);
+            const size_t per = (partEndPair - beginPair + workers - 1) / workers;
+            for (unsigned t = 0; t < workers; t++) {
+                const size_t begin = std::min(partEndPair, beginPair + size_t(t) * per), end = std::min(partEndPair, begin + per);
+                if (begin < end) pool.emplace_back(variates, begin, end);
+            }
+        }
+        for (std::thread& th : pool) th.join();
+    }
     std::vector<double> sumOfSquares(lshCount, 0.);
     parallel(lshCount, [&](size_t begin, size_t end) {          // per bit: genes in ascending order
         for (size_t g = 0; g < geneCount; g++) {
@@ -814,12 +869,33 @@ static int subsetFindSimilarPairs4(const uint64_t* globalToc, const em2_count* g
     EM2_HIP(dPairs.allocate(size_t(cellCount) * k * sizeof(em2_pair)));
     EM2_HIP(dUsed.allocate(size_t(cellCount) * sizeof(uint32_t)));
     EM2_HIP(dScanWs.allocate(scanWsBytes));
+    // The pages of the result, touched while the device scans.  ExpressionMatrix.findSimilarPairs4 hands over the mapping of a
+    // `-Pairs` file it has just created (800 MB at 1M cells, k = 100): the copy at the end of this call took 137-161 ms into those
+    // untouched pages and 14 ms into touched ones (same box, hipMemcpy both times; host threads copying in parallel out of pinned
+    // buffers made it 230: the page faults of one file do not run side by side).  One host thread writes a zero into every page
+    // -- about 125 ms, under the 190 ms of the scan, and only there: started at the top of the call its page faults ran against
+    // the device allocations' and releases' changes to the address space, and one call in three took a second longer.  The
+    // caller's buffer is the caller's to read only after the call; a failed scan leaves zeros in the pages that were reached.
+    struct PageToucher {
+        std::thread thread;
+        ~PageToucher() { if (thread.joinable()) thread.join(); }
+    } toucher;
+    if (size_t(cellCount) * k * sizeof(em2_pair) >= (size_t(64) << 20)) {
+        volatile char* bytes = reinterpret_cast<volatile char*>(pairs);
+        const size_t size = size_t(cellCount) * k * sizeof(em2_pair);
+        toucher.thread = std::thread([bytes, size]() {
+            for (size_t at = 0; at < size; at += 4096) bytes[at] = 0;
+            bytes[size - 1] = 0;
+        });
+    }
     rc = em2_dev_find_similar_pairs4(dSig.as<uint64_t>(), cellCount, 0, cellCount, lshCount, k, similarityThreshold,
                                      dPairs.as<em2_pair>(), dUsed.as<uint32_t>(), dScanWs.p, scanWsBytes, nullptr);
     if (rc != EM2_OK) return rc;
     rc = em2_dev_find_similar_pairs4_status(dScanWs.p, cellCount, k, nullptr);
     if (rc != EM2_OK) return rc;
     timer.stage("allocate + scan");
+    if (toucher.thread.joinable()) toucher.thread.join();
+    timer.stage("wait for the result's pages");
     EM2_HIP(hipMemcpy(pairs, dPairs.p, size_t(cellCount) * k * sizeof(em2_pair), hipMemcpyDeviceToHost));
     EM2_HIP(hipMemcpy(usedCount, dUsed.p, size_t(cellCount) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     timer.stage("pairs to host");

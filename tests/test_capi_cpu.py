@@ -64,7 +64,10 @@ def test_product_library_reads_few_environment_variables(lib):
 
 
 def test_generate_vectors_matches_oracle(lib, oracle):
-    for genes, L, seed in [(7, 64, 231), (50, 128, 231), (33, 100, 5), (1, 1, 9)]:
+    # (from 65 536 values on the engine runs 624 values at a time on the calling thread and the variates are formed behind it by
+    # the other host threads, chunk by chunk of 65 536 pairs: sizes of one, three and sixteen chunks, an odd total among them)
+    for genes, L, seed in [(7, 64, 231), (50, 128, 231), (33, 100, 5), (1, 1, 9), (64, 1024, 231), (300, 1024, 231), (257, 1001, 7),
+                           (2000, 1024, 1), (1, 65537, 4294967295)]:
         a = capi.lsh_generate_vectors(genes, L, seed)
         b = oracle.generate_lsh_vectors(genes, L, seed)
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
