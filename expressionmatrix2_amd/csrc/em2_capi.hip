@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <functional>
 #include <thread>
 #include <cstdio>
@@ -149,6 +150,36 @@ struct CallTimer {
     }
 };
 
+// The host threads this process may keep busy: the hardware's, or the CPU quota of its control group when that is smaller
+// (the GPU boxes of the pool show 256 hardware threads under a quota of 16 CPUs; threads beyond the quota get the whole
+// process throttled for the rest of the scheduler's period, the thread that talks to the device included).
+unsigned usableCpus()
+{
+    unsigned n = std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {               // cgroup v2: "<quota|max> <period>"
+        char quota[32] = {0};
+        long period = 0;
+        if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && quota[0] != 'm') {
+            const long cpus = std::atol(quota) / period;
+            if (cpus >= 1 && unsigned(cpus) < n) n = unsigned(cpus);
+        }
+        std::fclose(f);
+    } else {
+        long quota = -1, period = 0;                                           // cgroup v1
+        if (FILE* q = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (std::fscanf(q, "%ld", &quota) != 1) quota = -1;
+            std::fclose(q);
+        }
+        if (FILE* q = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (std::fscanf(q, "%ld", &period) != 1) period = 0;
+            std::fclose(q);
+        }
+        if (quota > 0 && period > 0 && quota / period >= 1 && unsigned(quota / period) < n) n = unsigned(quota / period);
+    }
+    return n;
+}
+
 // RAII device allocation for the host-buffer entry points.
 struct DeviceBuffer {
     void* p = nullptr;
@@ -182,7 +213,7 @@ int em2_lsh_generate_vectors(uint32_t geneCount, uint32_t lshCount, uint32_t see
     const size_t total = size_t(geneCount) * lshCount;
     const size_t pairCount = (total + 1) / 2;
     std::vector<uint32_t> raw(2 * pairCount);
-    unsigned threads = std::thread::hardware_concurrency();
+    unsigned threads = usableCpus();
     if (threads > 32) threads = 32;
     if (threads < 1 || total < (1u << 16)) threads = 1;
     auto parallel = [&](size_t n, const std::function<void(size_t, size_t)>& body) {
@@ -240,33 +271,70 @@ int em2_lsh_generate_vectors(uint32_t geneCount, uint32_t lshCount, uint32_t see
         }
     };
     {
-        // (no thread ever waits for the engine by spinning: under a CPU quota 63 spinning workers got the whole process throttled
-        // for hundreds of milliseconds at a time.  The engine's output goes to the workers in eight parts; the workers of a part
-        // run while the engine produces the next.)
-        constexpr size_t kParts = 8;
+        // The engine runs on the calling thread; the variates of what it has produced are formed by threads - 1 workers that take
+        // ranges of 16 384 pairs from a queue and sleep when it is empty -- never more busy threads than usableCpus(), and none
+        // that spins.
         const size_t rawCount = 2 * pairCount;
+        constexpr size_t kTaskPairs = size_t(1) << 14;
+        std::mutex mutex;
+        std::condition_variable wake;
+        size_t ready = 0, next = 0;          // pairs whose raw values exist / pairs handed out (both multiples of kTaskPairs or pairCount)
+        bool done = false;
         std::vector<std::thread> pool;
+        for (unsigned t = 1; t < threads; t++) {
+            pool.emplace_back([&]() {
+                for (;;) {
+                    size_t begin, end;
+                    {
+                        std::unique_lock<std::mutex> lock(mutex);
+                        wake.wait(lock, [&]() { return next < ready || done; });
+                        if (next >= ready) return;
+                        begin = next;
+                        end = std::min(ready, begin + kTaskPairs);
+                        next = end;
+                    }
+                    variates(begin, end);
+                }
+            });
+        }
         Mt19937Blocks engine(seed);
-        size_t produced = 0;          // raw values written
-        for (size_t part = 0; part < kParts; ++part) {
-            const size_t partEndPair = part + 1 == kParts ? pairCount : std::min(pairCount, (pairCount / kParts + 1) * (part + 1));
-            while (produced < 2 * partEndPair) {
-                engine.next(raw.data() + produced, std::min(size_t(624), rawCount - produced));
-                produced += std::min(size_t(624), rawCount - produced);
-            }
-            const size_t beginPair = part == 0 ? 0 : std::min(pairCount, (pairCount / kParts + 1) * part);
-            if (threads == 1) {
-                variates(beginPair, partEndPair);
-                continue;
-            }
-            const unsigned workers = std::max(1u, threads / 2u);
-            const size_t per = (partEndPair - beginPair + workers - 1) / workers;
-            for (unsigned t = 0; t < workers; t++) {
-                const size_t begin = std::min(partEndPair, beginPair + size_t(t) * per), end = std::min(partEndPair, begin + per);
-                if (begin < end) pool.emplace_back(variates, begin, end);
+        size_t produced = 0, announced = 0;          // raw values written / pairs announced to the workers
+        while (produced < rawCount) {
+            const size_t count = std::min(size_t(624), rawCount - produced);
+            engine.next(raw.data() + produced, count);
+            produced += count;
+            const size_t whole = produced == rawCount ? pairCount : (produced / 2) / kTaskPairs * kTaskPairs;
+            if (threads > 1 && whole > announced) {
+                {
+                    std::lock_guard<std::mutex> lock(mutex);
+                    ready = whole;
+                }
+                wake.notify_all();
+                announced = whole;
             }
         }
-        for (std::thread& th : pool) th.join();
+        if (threads == 1) {
+            variates(0, pairCount);
+        } else {
+            // the calling thread helps with what is left, then lets the workers go
+            for (;;) {
+                size_t begin, end;
+                {
+                    std::lock_guard<std::mutex> lock(mutex);
+                    if (next >= ready) break;
+                    begin = next;
+                    end = std::min(ready, begin + kTaskPairs);
+                    next = end;
+                }
+                variates(begin, end);
+            }
+            {
+                std::lock_guard<std::mutex> lock(mutex);
+                done = true;
+            }
+            wake.notify_all();
+            for (std::thread& th : pool) th.join();
+        }
     }
     std::vector<double> sumOfSquares(lshCount, 0.);
     parallel(lshCount, [&](size_t begin, size_t end) {          // per bit: genes in ascending order
