@@ -63,6 +63,19 @@ PROFILE_DIGESTS = {
     "fsp5": "r05_pmc_bench_fsp5_1Mcells_2048bit.json",
     "chain": "r05_pmc_bench_chain_1Mcells.json",
 }
+def usable_cpus():
+    """The host threads worth starting: os.cpu_count(), or the CPU quota of the control group when that is smaller (the GPU boxes
+    of the pool show 256 hardware threads under a quota of 16 CPUs: threads beyond it only get the process throttled)."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            n = max(1, min(n, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 TRAFFIC_NOTE = "FETCH_SIZE x 2 for 16-byte loads + WRITE_SIZE, bytes per launch of the profiled run"
 
 
@@ -257,7 +270,7 @@ def oracle_rows_parallel(oracle, sig_host, L, k, thr, ranges, threads=0):
     """The oracle's per-cell findSimilarPairs4 contract (rows against all columns) for the row ranges, spread over host threads
     (the ctypes call releases the GIL; rows are independent).  Returns [(begin, end, cell, sim, used)] in pieces."""
     from concurrent.futures import ThreadPoolExecutor
-    threads = threads or max(1, min(64, os.cpu_count() or 1))
+    threads = threads or max(1, min(64, usable_cpus()))
     total = sum(e - b for b, e in ranges)
     per = max(1, -(-total // (4 * threads)))
     pieces = [(s0, min(e, s0 + per)) for b, e in ranges for s0 in range(b, e, per)]
@@ -763,7 +776,7 @@ def main():
     # With several ranks on one host the gates share its cores: every rank checks its share of the rows with its share of the
     # threads (the job as a whole still compares >= --check-rows rows per gate).
     rows_per_gate = args.check_rows if world == 1 or args.check_rows <= 0 else max(min(1024, args.check_rows), -(-args.check_rows // world))
-    gate_threads = args.check_threads or max(1, min(64, (os.cpu_count() or 1) // world))
+    gate_threads = args.check_threads or max(1, min(64, usable_cpus() // world))
 
     def run_leg(pipe, label, golden_cases):
         """One measurement by the contract: correctness gate (an untimed pass against the CPU oracle), W warmup steps, exactly K
@@ -1110,14 +1123,14 @@ def main():
             "cores": 1,
             "kind": "port",
             "sample": "oracle literal findSimilarPairs4 pair loop + selection on the first %d cells of the same "
-                      "signatures (%.3g unordered pairs, %.1f s, host has %d cores, 1 used)"
-                      % (m, m * (m - 1) / 2.0, dt, os.cpu_count() or 0),
+                      "signatures (%.3g unordered pairs, %.1f s, host has %d hardware threads and a quota of %d CPUs, 1 used)"
+                      % (m, m * (m - 1) / 2.0, dt, os.cpu_count() or 0, usable_cpus()),
         }
         # Not the reference's way of running (it is single-threaded): the same sample with the per-cell contract's rows
         # spread over host threads (every row against all m columns, i.e. each pair from both sides), to show what the
         # whole host could do.  Reported beside the baseline, never used for any ratio.
         from concurrent.futures import ThreadPoolExecutor
-        threads = max(1, min(64, os.cpu_count() or 1))
+        threads = max(1, min(64, usable_cpus()))
         bounds = [m * i // threads for i in range(threads + 1)]
         t2 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=threads) as pool:
