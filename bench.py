@@ -361,6 +361,38 @@ def rows_form_block(args, capi, pipe, oracle, sig_host, torch, threads, shards=(
             "shards": out}
 
 
+def non_integer_projection_block(pipe, oracle, synthetic, torch, toc, data, vectors_host, repeats=3):
+    """The projection of the same matrix with every count x 1.5 (normalised expression matrices are not integers): the 16-bit
+    tier then sums its products in floating point instead of exactly in integers.  Signatures of 64 cells against the oracle."""
+    G, L = pipe.gene_count, pipe.lsh_count
+    scaled = data.clone()
+    scaled.view(torch.float32)[1::2] *= 1.5          # em2_count = {gene: uint32, count: float32}
+    original = pipe.data
+    pipe.data = scaled
+    try:
+        times = []
+        for _ in range(repeats + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            pipe.project()
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1))
+        tier = pipe.projection_tier()
+        sample = min(64, pipe.rows)
+        t_h, g_h, c_h = synthetic.csr_to_host(toc[:sample + 1], scaled[:int(toc[sample].item())])
+        expect = oracle.compute_signatures(t_h, g_h, c_h, G, vectors_host, L)
+        got = pipe.local_sig[:sample].cpu().numpy().view(np.uint64).reshape(sample, -1)
+        if not np.array_equal(expect, got):
+            raise SystemExit("PARITY FAILURE: signatures of the non-integer matrix differ from the oracle")
+    finally:
+        pipe.data = original
+        pipe.project()                                # (the pipeline's signatures are the integer matrix's again)
+        torch.cuda.synchronize()
+    return {"what": "em2_dev_compute_signatures on the headline's matrix with every count x 1.5", "tier": tier,
+            "ms": sum(times[1:]) / repeats, "signature_cells_against_the_oracle": sample}
+
+
 def facade_block(args, capi, synthetic, torch, toc, data, reference_pairs, reference_used):
     """The user-visible call: ExpressionMatrix.findSimilarPairs4(similarPairsName=...) on a data directory in the reference's
     formats (src/PythonModule.cpp:802-824) -- mmap'd CellExpressionCounts in, SimilarPairs-<name>-{Info,Pairs,CellInfo} out.
@@ -1031,7 +1063,11 @@ def main():
                 "kernel_ms": proj_ms, "bound": "hbm", "achieved": proj_bytes / (proj_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": proj_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": proj_bytes,
                 "flop_per_launch": 2.0 * nnz_local * L, "tflops": 2.0 * nnz_local * L / (proj_ms * 1e-3) / 1e12,
-                "note": "kernel_ms = HIP events around em2_dev_compute_signatures on the launch stream (16-bit fixed-point screening "
+                "tier": pipe.projection_tier(),
+                "note": "tier = the first tier the library ran on THIS data (include/em2_lsh.h, EM2_TIER_*: the synthetic counts are "
+                        "integers, so the 16-bit copy's products are summed exactly in integers; extra.projection_non_integer_counts "
+                        "times the same matrix with every count x 1.5).  "
+                        "kernel_ms = HIP events around em2_dev_compute_signatures on the launch stream (16-bit fixed-point screening "
                         "tier, float tier on the words and single bits it left, exact recomputation of the rest); traffic = fabric bytes "
                         "of all its kernels per launch from the committed PMC digest of this configuration: the tiers gather one "
                         "hyperplane line per (count, 64-bit word) from a copy that fills the L2s, so they move far more than the "
@@ -1152,6 +1188,7 @@ def main():
         if not args.no_check:
             result["extra"]["rows_form_one_gpu_as_rank_r_of_P"] = rows_form_block(args, capi, pipe, oracle, sig_host, torch, gate_threads)
             reference_pairs, reference_used = pipe.results_for(0, C)
+            result["extra"]["projection_non_integer_counts"] = non_integer_projection_block(pipe, oracle, synthetic, torch, inputs["toc"], inputs["data"], vectors_host)
             result["extra"]["facade_e2e"] = facade_block(args, capi, synthetic, torch, inputs["toc"], inputs["data"], reference_pairs, reference_used)
             del reference_pairs, reference_used
         leg.clear()

@@ -44,6 +44,7 @@ SYMBOLS = {
     "em2_dev_compute_signatures": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p,
                                               _c.c_void_p, _c.c_uint32, _c.c_void_p, _c.c_void_p, _c.c_size_t,
                                               _c.c_void_p]),
+    "em2_dev_compute_signatures_tier": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_int, _c.c_void_p]),
     "em2_dev_vector_aux_bytes": (_c.c_size_t, [_c.c_uint32, _c.c_uint32]),
     "em2_dev_prepare_vectors": (_c.c_int, [_c.c_void_p, _c.c_uint32, _c.c_uint32, _c.c_void_p, _c.c_void_p]),
     "em2_dev_find_similar_pairs4_workspace": (_c.c_size_t, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32]),
@@ -518,6 +519,16 @@ def dev_compute_signatures(toc_ptr, data_ptr, cell_count, gene_count, vectors_pt
     check(load().em2_dev_compute_signatures(toc_ptr, data_ptr, cell_count, gene_count, vectors_ptr,
                                             vector_aux_ptr, lsh_count, sig_ptr, workspace_ptr, workspace_bytes,
                                             stream))
+
+
+TIER_NAMES = ("exact", "float", "fixed16-float", "fixed16-integer")
+
+
+def dev_compute_signatures_tier(workspace_ptr, cell_count, lsh_count, have_vector_aux=True):
+    """Which first tier the last dev_compute_signatures call on this workspace ran (include/em2_lsh.h: EM2_TIER_*), by name."""
+    tier = ctypes.c_int(-1)
+    check(load().em2_dev_compute_signatures_tier(workspace_ptr, cell_count, lsh_count, 1 if have_vector_aux else 0, ctypes.byref(tier)))
+    return TIER_NAMES[tier.value]
 
 
 def dev_vector_aux_bytes(gene_count, lsh_count):

@@ -183,8 +183,42 @@ unsigned usableCpus()
 // RAII device allocation for the host-buffer entry points.
 struct DeviceBuffer {
     void* p = nullptr;
-    ~DeviceBuffer() { if (p) (void)hipFree(p); }
+    size_t cachedBytes = 0;          // allocateCached: the block's size in the library's scratch cache
+    bool idle = false;               // the owner sets it when the device has finished with the block (a synchronous copy came back)
+    ~DeviceBuffer()
+    {
+        if (!p) return;
+        if (cachedBytes && idle) em2::scratchGive(p, cachedBytes);
+        else (void)hipFree(p);
+    }
     hipError_t allocate(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    // from the scratch cache of the process when it holds a block of that size (em2_fsp5.hip: capped, em2_dev_release_scratch()
+    // frees it), and back into it when the call completed
+    hipError_t allocateCached(size_t bytes)
+    {
+        bytes = bytes ? bytes : 1;
+        p = em2::scratchTake(bytes, &cachedBytes);
+        if (p) return hipSuccess;
+        cachedBytes = bytes;
+        const auto t0 = std::chrono::steady_clock::now();
+        const hipError_t e = hipMalloc(&p, bytes);
+        if (getenv("EM2_TIMING")) fprintf(stderr, "[em2 timing] hipMalloc of %zu bytes (not in the scratch cache): %.1f ms, %s\n", bytes,
+                                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), e == hipSuccess ? "ok" : "FAILED");
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            em2::fsp5ReleaseScratch();          // (memory held by the cache may be what is missing)
+            return hipMalloc(&p, bytes);
+        }
+        return e;
+    }
+    // (the caller knows the device has finished with the block)
+    void release()
+    {
+        if (!p) return;
+        if (cachedBytes) em2::scratchGive(p, cachedBytes);
+        else (void)hipFree(p);
+        p = nullptr;
+    }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -461,6 +495,27 @@ int em2_dev_compute_signatures(const uint64_t* d_toc, const em2_count* d_data, u
     }
     EM2_HIP(em2::launchCellMeans(d_toc, data, cellCount, geneCount, means, s));
     EM2_HIP(em2::launchProjection(d_toc, data, cellCount, d_vectors, vectorSums, means, lshCount, d_signatures, s));
+    return EM2_OK;
+}
+
+
+int em2_dev_compute_signatures_tier(const void* d_workspace, uint32_t cellCount, uint32_t lshCount, int haveVectorAux, int* tier)
+{
+    if (!tier || lshCount == 0) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_compute_signatures_tier: bad argument");
+    *tier = EM2_TIER_EXACT;
+    if (!haveVectorAux || lshCount % 4u != 0u || cellCount == 0) return EM2_OK;
+    if (lshCount % 64u != 0u) {
+        *tier = EM2_TIER_FLOAT;
+        return EM2_OK;
+    }
+    // (the flag the statistics kernel raises when some count is no small integer: word 48 of the counters behind the two
+    // per-cell arrays of the workspace, csrc/em2_project.hip: launchProjectionScreened)
+    if (!d_workspace) return fail(EM2_ERROR_INVALID_ARGUMENT, "em2_dev_compute_signatures_tier: null workspace");
+    const char* ws = reinterpret_cast<const char*>(alignUp(reinterpret_cast<size_t>(d_workspace)));
+    const size_t a = (size_t(cellCount) * sizeof(double) + 255u) & ~size_t(255u);
+    uint32_t notAllInteger = 0;
+    EM2_HIP(hipMemcpy(&notAllInteger, ws + 2u * a + 48u * sizeof(uint32_t), sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *tier = notAllInteger ? EM2_TIER_FIXED16_FLOAT : EM2_TIER_FIXED16_INTEGER;
     return EM2_OK;
 }
 
@@ -874,12 +929,12 @@ static int subsetFindSimilarPairs4(const uint64_t* globalToc, const em2_count* g
     const uint32_t words = wordCountOf(lshCount);
     CallTimer timer;
     DeviceBuffer dSrcToc, dSrcData, dLocal, dToc, dData, dSubsetWs, dVectors, dSig, dWs, dAux;
-    EM2_HIP(dSrcToc.allocate((size_t(cellCount) + 1) * sizeof(uint64_t)));
-    EM2_HIP(dSrcData.allocate(srcNnz * sizeof(em2_count)));
-    EM2_HIP(dLocal.allocate(size_t(globalGeneCount) * sizeof(uint32_t)));
-    EM2_HIP(dToc.allocate((size_t(cellCount) + 1) * sizeof(uint64_t)));
+    EM2_HIP(dSrcToc.allocateCached((size_t(cellCount) + 1) * sizeof(uint64_t)));
+    EM2_HIP(dSrcData.allocateCached(srcNnz * sizeof(em2_count)));
+    EM2_HIP(dLocal.allocateCached(size_t(globalGeneCount) * sizeof(uint32_t)));
+    EM2_HIP(dToc.allocateCached((size_t(cellCount) + 1) * sizeof(uint64_t)));
     const size_t subsetWs = em2::subsetWorkspaceBytes(cellCount);
-    EM2_HIP(dSubsetWs.allocate(subsetWs));
+    EM2_HIP(dSubsetWs.allocateCached(subsetWs));
     EM2_HIP(hipMemcpy(dSrcToc.p, srcToc, (size_t(cellCount) + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     if (srcNnz) EM2_HIP(hipMemcpy(dSrcData.p, srcData, srcNnz * sizeof(em2_count), hipMemcpyHostToDevice));
     if (globalGeneCount) EM2_HIP(hipMemcpy(dLocal.p, geneLocalIds, size_t(globalGeneCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -890,19 +945,18 @@ static int subsetFindSimilarPairs4(const uint64_t* globalToc, const em2_count* g
                                    globalGeneCount, dToc.as<uint64_t>(), dSubsetWs.p, subsetWs, nullptr));
     uint64_t nnz = 0;
     EM2_HIP(hipMemcpy(&nnz, dToc.as<uint64_t>() + cellCount, sizeof(uint64_t), hipMemcpyDeviceToHost));
-    EM2_HIP(dData.allocate(nnz * sizeof(em2_count)));
+    EM2_HIP(dData.allocateCached(nnz * sizeof(em2_count)));
     EM2_HIP(em2::launchSubsetFill(dSrcToc.as<uint64_t>(), dSrcData.as<em2::CountIn>(), nullptr, cellCount, dLocal.as<uint32_t>(),
                                   globalGeneCount, dToc.as<uint64_t>(), dData.as<em2::CountIn>(), nullptr));
     EM2_HIP(hipStreamSynchronize(nullptr));
-    (void)hipFree(dSrcData.p);
-    dSrcData.p = nullptr;
+    dSrcData.release();
     timer.stage("subset");
 
     // signatures (same steps as em2_compute_signatures, on the device-resident subset)
     const size_t wsBytes = em2_dev_compute_signatures_workspace(cellCount, lshCount);
-    EM2_HIP(dVectors.allocate(size_t(geneCount) * lshCount * sizeof(double)));
-    EM2_HIP(dSig.allocate(size_t(cellCount) * words * sizeof(uint64_t)));
-    EM2_HIP(dWs.allocate(wsBytes));
+    EM2_HIP(dVectors.allocateCached(size_t(geneCount) * lshCount * sizeof(double)));
+    EM2_HIP(dSig.allocateCached(size_t(cellCount) * words * sizeof(uint64_t)));
+    EM2_HIP(dWs.allocateCached(wsBytes));
     if (!vectors) {
         vectors = vectorsWhenNeeded(vectorsContext);            // (waits for the thread that draws them)
         if (!vectors) return fail(EM2_ERROR_RUNTIME, em2_last_error());
@@ -911,7 +965,7 @@ static int subsetFindSimilarPairs4(const uint64_t* globalToc, const em2_count* g
     EM2_HIP(hipMemcpy(dVectors.p, vectors, size_t(geneCount) * lshCount * sizeof(double), hipMemcpyHostToDevice));
     void* aux = nullptr;
     if (lshCount % 4u == 0u) {          // (other widths: the exact arithmetic only)
-        EM2_HIP(dAux.allocate(em2_dev_vector_aux_bytes(geneCount, lshCount)));
+        EM2_HIP(dAux.allocateCached(em2_dev_vector_aux_bytes(geneCount, lshCount)));
         const int prc = em2_dev_prepare_vectors(dVectors.as<double>(), geneCount, lshCount, dAux.p, nullptr);
         if (prc != EM2_OK) return prc;
         aux = dAux.p;
@@ -924,19 +978,20 @@ static int subsetFindSimilarPairs4(const uint64_t* globalToc, const em2_count* g
     if (signatures) EM2_HIP(hipMemcpy(signatures, dSig.p, size_t(cellCount) * words * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (!wantPairs) return EM2_OK;
     // free what the scan does not need before its (large) workspace is allocated
-    for (DeviceBuffer* b : {&dVectors, &dAux, &dWs, &dData, &dToc, &dSrcToc, &dLocal, &dSubsetWs}) {
-        if (b->p) (void)hipFree(b->p);
-        b->p = nullptr;
-    }
+    // (the stream was synchronised behind the projection: idle blocks, back to the process's scratch cache -- every large
+    // allocation of this call comes from there: a hipMalloc of gigabytes took 1.6-2.8 s in one call of fourteen on one box,
+    // whichever allocation it hit, and 2 ms otherwise)
+    for (DeviceBuffer* b : {&dVectors, &dAux, &dWs, &dData, &dToc, &dSrcToc, &dLocal, &dSubsetWs}) b->release();
     if (k == 0) {
         std::memset(usedCount, 0, size_t(cellCount) * sizeof(uint32_t));
         return EM2_OK;
     }
     const size_t scanWsBytes = em2_dev_find_similar_pairs4_workspace(cellCount, cellCount, lshCount, k);
     DeviceBuffer dPairs, dUsed, dScanWs;
-    EM2_HIP(dPairs.allocate(size_t(cellCount) * k * sizeof(em2_pair)));
-    EM2_HIP(dUsed.allocate(size_t(cellCount) * sizeof(uint32_t)));
-    EM2_HIP(dScanWs.allocate(scanWsBytes));
+    EM2_HIP(dPairs.allocateCached(size_t(cellCount) * k * sizeof(em2_pair)));
+    EM2_HIP(dUsed.allocateCached(size_t(cellCount) * sizeof(uint32_t)));
+    EM2_HIP(dScanWs.allocateCached(scanWsBytes));
+    timer.stage("allocate result + workspace");
     // The pages of the result, touched while the device scans.  ExpressionMatrix.findSimilarPairs4 hands over the mapping of a
     // `-Pairs` file it has just created (800 MB at 1M cells, k = 100): the copy at the end of this call took 137-161 ms into those
     // untouched pages and 14 ms into touched ones (same box, hipMemcpy both times; host threads copying in parallel out of pinned
@@ -961,12 +1016,13 @@ static int subsetFindSimilarPairs4(const uint64_t* globalToc, const em2_count* g
     if (rc != EM2_OK) return rc;
     rc = em2_dev_find_similar_pairs4_status(dScanWs.p, cellCount, k, nullptr);
     if (rc != EM2_OK) return rc;
-    timer.stage("allocate + scan");
+    timer.stage("scan");
     if (toucher.thread.joinable()) toucher.thread.join();
     timer.stage("wait for the result's pages");
     EM2_HIP(hipMemcpy(pairs, dPairs.p, size_t(cellCount) * k * sizeof(em2_pair), hipMemcpyDeviceToHost));
     EM2_HIP(hipMemcpy(usedCount, dUsed.p, size_t(cellCount) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     timer.stage("pairs to host");
+    dPairs.idle = dUsed.idle = dScanWs.idle = dSig.idle = true;          // (the copies above were synchronous: the device is done with them)
     return EM2_OK;
 }
 

@@ -128,6 +128,9 @@ struct Fsp5LaunchInfo {
 Fsp5LaunchInfo fsp5LastLaunchInfo();
 // Frees the device scratch runFsp5 keeps between calls (em2_fsp5.hip: ScratchCache).
 void fsp5ReleaseScratch();
+// (em2_fsp5.hip) blocks of that cache for the library's other host-buffer entry points
+void* scratchTake(size_t bytes, size_t* got);
+void scratchGive(void* p, size_t bytes);
 
 hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin, uint32_t rowEnd, uint32_t lshCount,
                    uint32_t k, uint32_t q, uint64_t bucketOverflow, const DeviceTables& tables, PairOut* d_pairs,

@@ -895,7 +895,7 @@ selectGlobalKernel(uint32_t batchCells, const uint32_t* __restrict__ segmentBegi
 // the process keeps between calls: hipMalloc of gigabytes costs anything between 4 and 200 ms per call depending on the state of
 // the box (measured: the same command, two leases), more than the tables' kernels.  A block goes back to the cache only when
 // the call completed (its stream synchronised); a call that returns early with an error frees its blocks (hipFree waits for the
-// device).  EM2_SCRATCH_CACHE_MB caps what is kept (default: a sixteenth of the device's memory; 0 = nothing is kept); em2_dev_release_scratch() frees it.
+// device).  EM2_SCRATCH_CACHE_MB caps what is kept (default: an eighth of the device's memory; 0 = nothing is kept); em2_dev_release_scratch() frees it.
 class ScratchCache {
 public:
     void* take(size_t bytes, int device, size_t* got)
@@ -946,15 +946,18 @@ private:
     struct Block { void* p; size_t bytes; int device; };
     static size_t capBytes()
     {
-        // what a host process can live with: a sixteenth of the device's memory (18 GB of an MI355X's 288: one call's scratch at
-        // a million cells x 2048 bits is 10 GB) unless EM2_SCRATCH_CACHE_MB says otherwise (0: nothing is kept)
+        // what a host process can live with: an eighth of the device's memory (36 GB of an MI355X's 288) unless
+        // EM2_SCRATCH_CACHE_MB says otherwise (0: nothing is kept).  One findSimilarPairs5 call's scratch at a million cells x
+        // 2048 bits is 10 GB; the scan workspace of em2_subset_find_similar_pairs4 at a million cells is 27 GB, and it is the block
+        // that matters: its hipMalloc took 0.4 ms in 22 calls of 24 on one box and 2.7 and 4.0 s in the other two (a sixteenth,
+        // round 5's first choice, could not hold it).
         if (const char* v = getenv("EM2_SCRATCH_CACHE_MB")) return size_t(strtoull(v, nullptr, 10)) << 20;
-        static size_t sixteenth = 0;
-        if (!sixteenth) {
+        static size_t eighth = 0;
+        if (!eighth) {
             size_t freeBytes = 0, totalBytes = 0;
-            sixteenth = hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && totalBytes ? totalBytes / 16u : size_t(4) << 30;
+            eighth = hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && totalBytes ? totalBytes / 8u : size_t(4) << 30;
         }
-        return sixteenth;
+        return eighth;
     }
     std::mutex mutex_;
     std::vector<Block> blocks_;
@@ -1036,6 +1039,28 @@ thread_local Fsp5LaunchInfo lastFsp5Info = {0., 0., 0., 0., -1., -1., -1.};
 Fsp5LaunchInfo fsp5LastLaunchInfo() { return lastFsp5Info; }
 
 void fsp5ReleaseScratch() { ScratchCache::instance().clear(); }
+
+// The cache for other host-buffer entry points of the library (csrc/em2_capi.hip: the result and the scan workspace of
+// em2_subset_find_similar_pairs4 -- 6 GB at 1M cells, whose hipMalloc took 1.6-2.7 s in two calls of fourteen on one box and
+// 1.7 ms otherwise).  scratchTake: a cached block of at least `bytes` on the current device, or nullptr; scratchGive: an IDLE block
+// back (freed when the cache is full).
+void* scratchTake(size_t bytes, size_t* got)
+{
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    return ScratchCache::instance().take(bytes ? bytes : 1, device, got);
+}
+
+void scratchGive(void* p, size_t bytes)
+{
+    int device = 0;
+    if (!p) return;
+    if (hipGetDevice(&device) != hipSuccess) {
+        (void)hipFree(p);
+        return;
+    }
+    ScratchCache::instance().give(p, bytes, device);
+}
 
 hipError_t runFsp5(const uint64_t* d_sig, uint32_t cellCount, uint32_t rowBegin, uint32_t rowEnd, uint32_t lshCount,
                    uint32_t k, uint32_t q, uint64_t bucketOverflow, const DeviceTables& tables, PairOut* d_pairs,

@@ -161,6 +161,12 @@ class DevicePipeline:
                                         stream)
         self._mark("projection")
 
+    def projection_tier(self):
+        """Which first tier the last project() ran (waits for the device): capi.TIER_NAMES."""
+        if not self.rows:
+            return None
+        return capi.dev_compute_signatures_tier(self.proj_ws.data_ptr(), self.rows, self.lsh_count, True)
+
     def exchange(self):
         if self.world_size > 1:
             self.dist.all_gather_into_tensor(self.full_sig, self.local_sig)

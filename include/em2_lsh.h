@@ -146,6 +146,16 @@ int em2_dev_compute_signatures(const uint64_t* d_toc, const em2_count* d_data, u
                                uint32_t lshCount, uint64_t* d_signatures, void* d_workspace,
                                size_t workspaceBytes, void* stream);
 
+/* Which FIRST tier the last em2_dev_compute_signatures call on this workspace ran (the result does not depend on it; the time
+ * does -- DESIGN.md 3.2).  The call waits for the device.  haveVectorAux: whether that call was given d_vectorAux.
+ *   EM2_TIER_EXACT           the reference's arithmetic on every bit (no auxiliary block, or lshCount no multiple of 4)
+ *   EM2_TIER_FLOAT           the float copy of the hyperplanes under its error bound (lshCount no multiple of 64)
+ *   EM2_TIER_FIXED16_FLOAT   the 16-bit fixed-point copy, products summed in floating point (some count is no small integer)
+ *   EM2_TIER_FIXED16_INTEGER the 16-bit fixed-point copy, products summed exactly in 32-bit integers (every count an integer of
+ *                            at most 15 bits, every cell's sum of |count| at most 65 535: expression COUNTS)                    */
+enum { EM2_TIER_EXACT = 0, EM2_TIER_FLOAT = 1, EM2_TIER_FIXED16_FLOAT = 2, EM2_TIER_FIXED16_INTEGER = 3 };
+int em2_dev_compute_signatures_tier(const void* d_workspace, uint32_t cellCount, uint32_t lshCount, int haveVectorAux, int* tier);
+
 /* Bytes of device scratch em2_dev_find_similar_pairs4 needs for rowCount rows. */
 size_t em2_dev_find_similar_pairs4_workspace(uint32_t cellCount, uint32_t rowCount, uint32_t lshCount,
                                              uint32_t k);
@@ -308,9 +318,11 @@ int em2_dev_find_similar_pairs5(const uint64_t* d_signatures, uint32_t cellCount
 int em2_dev_find_similar_pairs5_last_launch(double* values, uint32_t valueCount);
 
 /* findSimilarPairs5 keeps its device scratch (bucket tables, candidate ids, candidate lists: about 10 GB at a million cells x
- * 2048 bits) between calls of the process, because allocating gigabytes costs up to 200 ms per call on some hosts; at most
- * EM2_SCRATCH_CACHE_MB megabytes are kept (default 32768, 0 = none).  This call frees what is kept.  The reference has no
- * counterpart (its tables are std::vectors of the call, src/ExpressionMatrixLsh.cpp:377-389). */
+ * 2048 bits) between calls of the process, and em2_subset_find_similar_pairs4 the device copy of its result and its scan
+ * workspace (6 GB at a million cells), because allocating gigabytes costs anything between 2 ms and 2.7 s per call depending on
+ * the state of the host; at most EM2_SCRATCH_CACHE_MB megabytes are kept (default: an eighth of the device's memory, 0 = none).
+ * This call frees what is kept.  The reference has no counterpart (its tables are std::vectors of the call,
+ * src/ExpressionMatrixLsh.cpp:377-389). */
 void em2_dev_release_scratch(void);
 
 /* ------------------------------------------------------------------------------------------------------
