@@ -196,3 +196,48 @@ def test_integer_first_tier_and_when_it_steps_aside(oracle, monkeypatch, case):
     expect = oracle.compute_signatures(toc, g, c, genes, vectors, L)
     got = capi.compute_signatures(toc, capi.make_counts(g, c), genes, vectors, L)
     assert np.array_equal(got, expect)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case, L, aux, tier", [("integers", 1024, True, "fixed16-integer"), ("negative", 128, True, "fixed16-integer"),
+                                                ("all-fractions", 1024, True, "fixed16-float"), ("one-fraction", 1024, True, "fixed16-float"),
+                                                ("count-32768", 1024, True, "fixed16-float"), ("sum-above-65535", 1024, True, "fixed16-float"),
+                                                ("integers", 100, True, "float"), ("integers", 96, True, "float"), ("integers", 63, True, "exact"),
+                                                ("integers", 1024, False, "exact")])
+def test_the_library_says_which_first_tier_ran(oracle, case, L, aux, tier):
+    """em2_dev_compute_signatures_tier (include/em2_lsh.h): the first tier the last device call on a workspace ran -- the exact-integer
+    form of the 16-bit tier for expression counts, its floating form when the statistics kernel found a count that is no small
+    integer, the float copy for widths that are no multiple of 64, the reference's arithmetic alone otherwise.  bench.py prints it
+    (roofline_projection.tier).  Signatures against the oracle as everywhere."""
+    import torch
+    cells, genes = 300, 900
+    toc, g, c = synth.expression_matrix(cells, genes, density=0.06, cluster_count=5, seed=23)
+    c = c.copy()
+    if case == "all-fractions":
+        c = (c * np.float32(0.37)).astype(np.float32)
+    elif case == "one-fraction":
+        c[len(c) // 2] = np.float32(2.5)
+    elif case == "count-32768":
+        c[7] = np.float32(32768.0)
+    elif case == "sum-above-65535":
+        lo, hi = int(toc[3]), int(toc[4])
+        c[lo:hi] = np.float32(np.ceil(65536.0 / max(1, hi - lo)) + 1)
+    elif case == "negative":
+        c[::3] = -c[::3]
+    vectors = oracle.generate_lsh_vectors(genes, L, 231)
+    expect = oracle.compute_signatures(toc, g, c, genes, vectors, L)
+    data = capi.make_counts(g, c)
+    d_toc = torch.from_numpy(np.ascontiguousarray(toc).view(np.int64)).cuda()
+    d_data = torch.from_numpy(np.ascontiguousarray(data).view(np.int64)).cuda()
+    d_vectors = torch.from_numpy(np.ascontiguousarray(vectors)).cuda()
+    d_sig = torch.zeros((cells, capi.word_count(L)), dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    d_aux = torch.empty(capi.dev_vector_aux_bytes(genes, L), dtype=torch.uint8, device="cuda")
+    if aux:
+        capi.dev_prepare_vectors(d_vectors.data_ptr(), genes, L, d_aux.data_ptr(), stream)
+    ws_bytes = capi.dev_compute_signatures_workspace(cells, L)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    capi.dev_compute_signatures(d_toc.data_ptr(), d_data.data_ptr(), cells, genes, d_vectors.data_ptr(), d_aux.data_ptr() if aux else 0, L,
+                                d_sig.data_ptr(), ws.data_ptr(), ws_bytes, stream)
+    assert capi.dev_compute_signatures_tier(ws.data_ptr(), cells, L, aux) == tier
+    assert np.array_equal(d_sig.cpu().numpy().view(np.uint64), expect)
