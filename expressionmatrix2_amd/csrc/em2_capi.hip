@@ -514,6 +514,9 @@ int em2_dev_compute_signatures_tier(const void* d_workspace, uint32_t cellCount,
     const char* ws = reinterpret_cast<const char*>(alignUp(reinterpret_cast<size_t>(d_workspace)));
     const size_t a = (size_t(cellCount) * sizeof(double) + 255u) & ~size_t(255u);
     uint32_t notAllInteger = 0;
+    // (every stream of the device, non-blocking ones included: the call has no stream of its own, and a copy on the null
+    // stream does not order behind a projection launched on a stream created with hipStreamNonBlocking)
+    EM2_HIP(hipDeviceSynchronize());
     EM2_HIP(hipMemcpy(&notAllInteger, ws + 2u * a + 48u * sizeof(uint32_t), sizeof(uint32_t), hipMemcpyDeviceToHost));
     *tier = notAllInteger ? EM2_TIER_FIXED16_FLOAT : EM2_TIER_FIXED16_INTEGER;
     return EM2_OK;

@@ -87,6 +87,9 @@ __global__ void ownerBoundsKernel(const uint64_t* __restrict__ sorted, uint64_t 
 
 // out[i] = in[rows[i]] (rows of k pairs and their used counts): packs the finished rows of the blocks this rank owns in
 // ascending cell order (which is grouped by destination rank), or scatters received rows into the shard.
+// The outcome flag of a rank, written from the launch's own argument (no host buffer has to outlive the call).
+__global__ void setOutcomeFlagKernel(int32_t* flag, int32_t value) { *flag = value; }
+
 __global__ void __launch_bounds__(256)
 moveRowsKernel(const em2_pair* __restrict__ inPairs, const uint32_t* __restrict__ inUsed, const uint32_t* __restrict__ inRow,
                const uint32_t* __restrict__ outRow, uint32_t rowCount, uint32_t k, em2_pair* __restrict__ outPairs,
@@ -386,6 +389,11 @@ int em2_dist_find_similar_pairs4_with(const em2_collectives* c, const uint64_t* 
         receivedEntries = uint64_t(world) * maxUsed;
     }
     timer.stage(EM2_DIST_MS_EXCHANGE);
+    // The outcome word (the first word of the count matrix, which has served) says "failed" from here until this rank
+    // clears it at the end: a rank whose device falls into a sticky error behind this point cannot write its flag any more,
+    // and must not enter the reduction with a stale zero.
+    int32_t* dFailed = reinterpret_cast<int32_t*>(counts);
+    recordHip(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dFailed), 1, 1, stream), "hipMemsetD32Async(outcome flag)");
     phase(3, receivedEntries);          // (a failure from here on is returned after the last collective)
     timer.stage(EM2_DIST_MS_SCAN);
 
@@ -452,16 +460,17 @@ int em2_dist_find_similar_pairs4_with(const em2_collectives* c, const uint64_t* 
     }
     recordHip(hipStreamSynchronize(stream), "hipStreamSynchronize");          // the host lists above must outlive the copies
     // ---- the outcome is collective: a rank that failed behind the agreement has sent rows that mean nothing ----
-    int32_t* dFailed = reinterpret_cast<int32_t*>(counts);                    // (the count matrix has served)
+    // (nothing returns between the last all_to_all and this reduction.  The flag is written by a kernel from its own argument:
+    // no copy out of this frame is left queued behind a return; if the launch fails -- a device in a sticky error -- the word
+    // keeps the 1 it was preset to.  Whatever happens, the stream is drained before the call returns: the reduction runs on the
+    // caller's workspace.)
     int32_t failed = localError != EM2_OK ? 1 : 0;
-    // (nothing returns between the last all_to_all and this reduction: a rank whose device is in a sticky error -- the copy of its
-    // flag fails too -- still enters it, with whatever the word holds; its own error is what it returns)
-    recordHip(hipMemcpyAsync(dFailed, &failed, 4u, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(outcome flag)");
-    if (c->all_reduce_max_i32(c->context, dFailed, 1, stream) != 0) return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: all_reduce of the outcome failed");
-    if (localError == EM2_OK) {
-        EM2_DIST_HIP(hipMemcpyAsync(&failed, dFailed, 4u, hipMemcpyDeviceToHost, stream));
-        EM2_DIST_HIP(hipStreamSynchronize(stream));
-    }
+    setOutcomeFlagKernel<<<dim3(1), dim3(1), 0, stream>>>(dFailed, failed);
+    recordHip(hipGetLastError(), "setOutcomeFlagKernel");
+    const bool reduced = c->all_reduce_max_i32(c->context, dFailed, 1, stream) == 0;
+    if (reduced && localError == EM2_OK) recordHip(hipMemcpyAsync(&failed, dFailed, 4u, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(outcome)");
+    recordHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if (!reduced) return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: all_reduce of the outcome failed");
     timer.stage(EM2_DIST_MS_REDISTRIBUTE);
     if (localError != EM2_OK) return fail(localError, localMessage);
     if (failed) return fail(EM2_ERROR_RUNTIME, "em2_dist_find_similar_pairs4: another rank failed behind the ranks' agreement (phase 3 or the "

@@ -346,10 +346,12 @@ void Matrix::runLshPath(const char* what, const std::string& geneSetName, const 
     timer.stage("lookup");
     // Lsh::generateLshVectors (src/Lsh.cpp:68-113) on a thread of its own: the device call asks for the hyperplanes when it has
     // uploaded the expression matrix and taken its subset (em2_internal_subset_find_similar_pairs4)
+    // (members are destroyed in reverse order: the future -- whose destructor joins the generator thread -- goes first, so the
+    // thread can never write `error` or `values` after their destruction when this frame unwinds)
     struct Hyperplanes {
         std::vector<double> values;
-        std::future<int> drawn;
         std::string error;
+        std::future<int> drawn;
     } hyperplanes;
     hyperplanes.values.resize(size_t(geneCount) * lshCount);
     hyperplanes.drawn = std::async(std::launch::async, [&hyperplanes, geneCount, lshCount, seed]() {

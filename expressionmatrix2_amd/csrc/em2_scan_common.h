@@ -100,9 +100,15 @@ __device__ __forceinline__ void waveLdsFence()
 
 // Entries of a row list are written by one lane and read back by other lanes of the same wave: read them
 // at agent scope (L2-served, bypassing the CU's L1) after the writer's vmcnt(0).
+// (The lists, the logs and the inbox are global memory, but their addresses come out of the kernel-argument block, which the
+// kernels read through a laundered pointer: the compiler cannot know the address space and would access them with flat_
+// instructions, which count against lgkmcnt as well as vmcnt and make every LDS wait a wait for the memory traffic too.  The
+// helpers below say "global".)
+typedef __attribute__((address_space(1))) uint64_t* GlobalWordPtr;
+typedef const __attribute__((address_space(1))) uint64_t* GlobalConstWordPtr;
 __device__ __forceinline__ Entry loadEntryCoherent(const Entry* p)
 {
-    const uint64_t v = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED,
+    const uint64_t v = __hip_atomic_load((GlobalConstWordPtr)reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
     Entry e;
     e.cell = uint32_t(v);
@@ -112,7 +118,13 @@ __device__ __forceinline__ Entry loadEntryCoherent(const Entry* p)
 
 __device__ __forceinline__ void storeEntry(Entry* p, uint32_t cell, uint32_t key)
 {
-    *reinterpret_cast<uint64_t*>(p) = uint64_t(cell) | (uint64_t(key) << 32);
+    *(GlobalWordPtr)reinterpret_cast<uint64_t*>(p) = uint64_t(cell) | (uint64_t(key) << 32);
+}
+
+// an inbox entry (or any 64-bit word of global memory)
+__device__ __forceinline__ void storeGlobalWord(uint64_t* p, uint64_t v)
+{
+    *(GlobalWordPtr)p = v;
 }
 
 // m += popcount(x) as ONE instruction.  The compiler usually forms v_bcnt_u32_b32 with its free accumulate from
@@ -144,16 +156,36 @@ __device__ __forceinline__ ArgsPtr kernelArgs()
 // area.  Out of line on purpose: inlining the selection's nested loops into the scan kernel raised SGPR
 // pressure enough to spill the column chunk registers inside the steady-state loop.
 // Returns the key of the entry that ends at position k-1 (tmp.back(), ExpressionMatrixLsh.cpp:249,256).
-__device__ __attribute__((noinline)) uint32_t cutListToBest(Entry* lds, Entry* g, uint32_t n, uint32_t k,
+// The LDS area arrives as an LDS pointer (address space 3): through a generic pointer -- all an out-of-line function can know
+// of its argument -- every access to it was a flat_ instruction that waited for ALL of the wave's outstanding memory traffic
+// (vmcnt(0) and lgkmcnt(0): the lists' and the inbox's stores, the replay's loads in flight), some 140 times per selection.
+typedef __attribute__((address_space(3))) Entry* LdsEntryPtr;
+__device__ __attribute__((noinline)) uint32_t cutListToBest(LdsEntryPtr ldsArea, Entry* g, uint32_t n, uint32_t k,
                                                             uint32_t lane, bool writeBack)
 {
+    Entry* lds = (Entry*)ldsArea;           // (a cast the compiler sees through: the accesses below are ds_ instructions)
+    // The arguments of an out-of-line function arrive in vector registers, and everything derived from them counts as divergent:
+    // the selection's loops became loops under EXEC masks.  The counts and the pointers are wave-uniform: say so.  (Both together:
+    // the scan kernel on clustered data 235 -> 225 ms, profiles/r06_scan_experiments.md.)
+    n = uint32_t(__builtin_amdgcn_readfirstlane(int(n)));
+    k = uint32_t(__builtin_amdgcn_readfirstlane(int(k)));
+    {
+        const uint64_t address = reinterpret_cast<uint64_t>(g);
+        g = reinterpret_cast<Entry*>(uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(address))))) |
+                                     (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(address >> 32))))) << 32));
+        const uint32_t ldsAddress = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uintptr_t(ldsArea)))));
+        lds = (Entry*)(LdsEntryPtr)(uintptr_t)ldsAddress;
+    }
     for (uint32_t i = lane; i < n; i += 64u) lds[i] = loadEntryCoherent(g + i);
     waveLdsFence();
     // This wave's LDS area is [2k entries][2k uint16][2k uint16] (kLdsBytesPerEntrySlot each); n <= 2k.
     uint16_t* Lpos = reinterpret_cast<uint16_t*>(lds + 2u * k);
     nthElementWave(lds, Lpos, Lpos + 2u * k, int(k), int(n), lane);
     if (writeBack) {
-        for (uint32_t i = lane; i < k; i += 64u) g[i] = lds[i];
+        for (uint32_t i = lane; i < k; i += 64u) {
+            const Entry e = lds[i];
+            storeEntry(g + i, e.cell, e.key);
+        }
     }
     const uint32_t backKey = lds[k - 1u].key;
     return backKey;
@@ -187,7 +219,7 @@ __device__ __forceinline__ void acceptColumn(bool pass, uint32_t col, uint32_t r
             const uint32_t src = uint32_t(__builtin_ctzll(full));
             full &= full - 1ull;
             Entry* g = waveBuffers + size_t(src) * twoK;
-            const uint32_t backKey = cutListToBest(lds, g, twoK, k, lane, true);
+            const uint32_t backKey = cutListToBest((LdsEntryPtr)lds, g, twoK, k, lane, true);
             // readfirstlane: the table load completes HERE, so the scan loop never has to wait on vector memory
             const int32_t newMax = __builtin_amdgcn_readfirstlane(aux->acceptMaxByKey[backKey]);
             if (lane == src) {
@@ -219,7 +251,7 @@ __device__ __forceinline__ void finishRows(uint32_t lane, uint32_t waveIndex, ui
         uint32_t n = uint32_t(__builtin_amdgcn_readlane(int(count), int(src)));
         Entry* g = waveBuffers + size_t(src) * twoK;
         if (n > k) {
-            cutListToBest(lds, g, n, k, lane, false);
+            cutListToBest((LdsEntryPtr)lds, g, n, k, lane, false);
             n = k;
         } else {
             for (uint32_t i = lane; i < n; i += 64u) lds[i] = loadEntryCoherent(g + i);

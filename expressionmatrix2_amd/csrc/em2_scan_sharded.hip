@@ -251,7 +251,7 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
             {
                 // the walk logs what passes either bound; both sides of every record go to the inbox afterwards
                 const uint32_t logCapacity = aux->logCapacity < kMatrixLogMargin ? kMatrixLogMargin : aux->logCapacity;
-                Entry* waveLog = aux->logs + size_t(blockIdx.x * 4u + wave) * 64u * logCapacity;
+                WalkRecord* waveLog = reinterpret_cast<WalkRecord*>(aux->logs) + size_t(blockIdx.x * 4u + wave) * 64u * logCapacity;
                 // The walk may start where the other walks of the XCD are and go around (the convoy, scanMatrixBody); here the
                 // order of the columns means nothing -- both sides of every record go to the inbox, which is sorted -- so the
                 // logs are emptied after every call, wherever it stopped.  range = [at, end), then [colBegin, start).
@@ -589,7 +589,7 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             if (const char* v = getenv("EM2_BLOCKS_PER_CU")) {
                 if (atoi(v) == 1) blocksWanted = uint64_t(cuCount);
             }
-            if (blocksWanted * 4u > maxResidentWaves()) blocksWanted = maxResidentWaves() / 4u;
+            if (blocksWanted * 8u > maxResidentWaves()) blocksWanted = maxResidentWaves() / 8u;
             if (blocksWanted > tickets) blocksWanted = tickets;
             e = hipFuncSetAttribute(matrixKernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(matrixLds));
             if (e != hipSuccess) return e;

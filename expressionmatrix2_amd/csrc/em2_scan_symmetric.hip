@@ -315,6 +315,8 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
 {
     uint64_t phaseCycles[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t phaseStart = TIMED ? __builtin_readcyclecounter() : 0ull;
+    uint64_t walkRecords = 0, replayCalls = 0;      // (TIMED: this lane's records over the launch; replays of the wave)
+    uint64_t replayTimed[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // (TIMED: the replay's split, see the launcher's line)
     constexpr int W32 = WIDE ? 64 : 32;                          // dwords per signature as the v_xor/v_bcnt parts read them
     constexpr float bits = WIDE ? 2.f * kMatrixBits : kMatrixBits;
     const uint32_t lane = threadIdx.x & 63u;
@@ -387,7 +389,10 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         const uint32_t minLogCapacity = kMatrixLogMargin;
         uint32_t logCapacity = aux->logCapacity < minLogCapacity ? minLogCapacity : aux->logCapacity;
         Entry* myList = aux->buffers + (size_t(listBlock) * 64u + lane) * twoK;
-        Entry* myLog = aux->logs + (size_t(blockIdx.x * 4u + wave) * 64u + lane) * logCapacity;
+        // (the walk's records are 16 bytes apart: its waves -- at most eight per CU -- share the area the v_xor/v_bcnt kernels'
+        // sixteen waves per CU have for their 8-byte log entries)
+        WalkRecord* waveLog = reinterpret_cast<WalkRecord*>(aux->logs) + size_t(blockIdx.x * 4u + wave) * 64u * logCapacity;
+        Entry* myLog = reinterpret_cast<Entry*>(waveLog + size_t(lane) * logCapacity);       // (an argument the exact v_xor/v_bcnt loops below never use)
         const uint32_t cps = aux->columnsPerSegment;
         const uint32_t colBegin = seg * cps;
         uint32_t colEnd = colBegin + cps;
@@ -441,24 +446,28 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
             if (at < rangeEnd) {
                 if (WIDE) {
                     at = scanTilesMatrixWide<IDENTITY>(aux->fragments, aux->snap, at, rangeEnd, rowFragmentBlock + rowHalf,
-                                                       bits - 2.f * float(mMax), rowHalf, myLog - size_t(lane) * logCapacity, logCapacity,
+                                                       bits - 2.f * float(mMax), rowHalf, waveLog, logCapacity,
                                                        recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                        ldsAddress(walkBlock));
                 } else {
                     if (EM2_DIAG_WORD(aux)) {
                         at = scanTilesMatrixPinned<IDENTITY, false, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, rangeEnd,
-                                                         rowFragmentBlock, kMatrixBits - 2.f * float(mMax), myLog - size_t(lane) * logCapacity,
+                                                         rowFragmentBlock, kMatrixBits - 2.f * float(mMax), waveLog,
                                                          logCapacity, recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                          ldsAddress(walkBlock));
                     } else {
                         at = scanTilesMatrixPinned<IDENTITY, false, false>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, rangeEnd,
-                                                         rowFragmentBlock, kMatrixBits - 2.f * float(mMax), myLog - size_t(lane) * logCapacity,
+                                                         rowFragmentBlock, kMatrixBits - 2.f * float(mMax), waveLog,
                                                          logCapacity, recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                          ldsAddress(walkBlock));
                     }
                 }
             }
             EM2_PHASE(2);
+            if (TIMED) {
+                walkRecords += recordCount[0] + recordCount[1];
+                replayCalls += 1u;
+            }
             if (TIMED && start != colBegin && !lower) phaseCycles[7] += 1u << 20;           // (walks that joined a convoy)
             if (start != colBegin && !lower && (at & kWalkInLowerColumns) != 0u) {
                 // the walk went around within the call: it is in its lower columns (or through with them)
@@ -510,8 +519,8 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                 // (a walk that went around and stopped in its lower columns: those records only, the others stay)
                 const bool all = !(lower && stopped);
                 if (!idle && !failed) {
-                    replayWalkLogs<IDENTITY, WIDE>(myLog - size_t(lane) * logCapacity, logCapacity, recordCount, firstRecord, all, lane, row,
-                                                   rowValid, !fullRows, listBlock, myList, twoK, count, mMax, emitPos, emitEnd, ldsRaw);
+                    replayWalkLogs<IDENTITY, WIDE>(waveLog, logCapacity, recordCount, firstRecord, all, lane, row, rowValid, !fullRows,
+                                                   listBlock, myList, twoK, count, mMax, emitPos, emitEnd, ldsRaw, ldsAddress(tiles), TIMED ? replayTimed : nullptr);
                 }
                 recordCount[0] = all ? 0u : firstRecord[0];
                 recordCount[1] = all ? 0u : firstRecord[1];
@@ -605,6 +614,17 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
     if (TIMED && lane == 0u) {
         unsigned long long* counters = reinterpret_cast<unsigned long long*>(kernelArgs()->inboxControl + 16);
         for (int i = 0; i < 8; i++) atomicAdd(counters + i, (unsigned long long)phaseCycles[i]);
+    }
+    if (TIMED) {
+        // (bytes 144..159 of the control block: the launch's records and its calls of the replay)
+        unsigned long long* more = reinterpret_cast<unsigned long long*>(kernelArgs()->inboxControl + 36);
+        atomicAdd(more, (unsigned long long)walkRecords);
+        if (lane == 0u) atomicAdd(more + 1, (unsigned long long)replayCalls);
+        // (the replay's split: the convoy's words, bytes 160..223 -- a timed launch that wants it runs with EM2_MATRIX_CONVOY=0)
+        if (lane == 0u && kernelArgs()->convoy == 0u) {
+            unsigned long long* split = reinterpret_cast<unsigned long long*>(kernelArgs()->inboxControl + 40);
+            for (int i = 0; i < 8; i++) atomicAdd(split + i, (unsigned long long)replayTimed[i]);
+        }
     }
     if (threadIdx.x == 0u) {
         unsigned long long* clockWords = reinterpret_cast<unsigned long long*>(kernelArgs()->inboxControl + kClockWordsOffset);
@@ -1100,7 +1120,7 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
             if (atoi(v) >= 1 && atoi(v) < blocksPerCu) blocksPerCu = atoi(v);
         }
         uint64_t blocksWanted = uint64_t(cuCount) * uint64_t(blocksPerCu);
-        if (blocksWanted * 4u > maxResidentWaves()) blocksWanted = maxResidentWaves() / 4u;      // the logs are sized for that
+        if (blocksWanted * 8u > maxResidentWaves()) blocksWanted = maxResidentWaves() / 8u;      // the logs are sized for that
         if (blocksWanted > ticketsMatrix) blocksWanted = ticketsMatrix;
         if (scanVerbose()) {
             fprintf(stderr, "[em2] matrix kernel: %d blocks per CU, %llu blocks, %zu bytes of LDS\n", blocksPerCu,
@@ -1147,6 +1167,19 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
             fprintf(stderr, "; %.0f cycles per item and wave outside the walk; %.0f walks stopped for their logs\n",
                     (total - double(cycles[2])) / (4.0 * double(ticketsMatrixCount ? ticketsMatrixCount : 1)), double(cycles[7] & 0xfffffu) / 4.0);
             fprintf(stderr, "[em2] matrix kernel: %.0f walks started inside their segment\n", double(cycles[7] >> 20) / 4.0);
+            unsigned long long more[2] = {0, 0};
+            if (hipMemcpy(more, ws + layout.control + 144u, sizeof(more), hipMemcpyDeviceToHost) == hipSuccess) {
+                fprintf(stderr, "[em2] matrix kernel: %llu records logged (%.2f per wave and tile), %llu replays of a wave's logs\n", more[0],
+                        double(more[0]) / (double(cellCount) * double(cellCount) / 4096.0), more[1]);
+            }
+            unsigned long long split[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (envNumber("EM2_MATRIX_CONVOY", 1) == 0 && hipMemcpy(split, ws + layout.control + 160u, sizeof(split), hipMemcpyDeviceToHost) == hipSuccess) {
+                const double t = total > 0 ? total : 1;
+                fprintf(stderr, "[em2] matrix kernel, replay (%% of the waves' cycles): selections %llu: drain %.2f, cut %.2f, table + fence %.2f; "
+                                "%llu short rows %.2f (with their selections), %llu long rows %.2f\n", split[3], 100.0 * double(split[0]) / t,
+                        100.0 * double(split[1]) / t, 100.0 * double(split[2]) / t, split[4], 100.0 * double(split[5]) / t, split[6],
+                        100.0 * double(split[7]) / t);
+            }
         }
     }
     {
@@ -1258,7 +1291,7 @@ hipError_t launchFsp4ScanRowsMatrix(Fsp4Args args, uint32_t paddedDw, bool ident
         if (atoi(v) >= 1 && atoi(v) < blocksPerCu) blocksPerCu = atoi(v);
     }
     uint64_t blocksWanted = uint64_t(cuCount) * uint64_t(blocksPerCu);
-    if (blocksWanted * 4u > maxResidentWaves()) blocksWanted = maxResidentWaves() / 4u;      // the logs are sized for that
+    if (blocksWanted * 8u > maxResidentWaves()) blocksWanted = maxResidentWaves() / 8u;      // the logs are sized for that
 
     // Segments as in the symmetric launch (24 576 / 16 384 columns at large sizes); a launch of few rows takes shorter
     // ones, down to 2048 columns, until there are some four items per resident block.
@@ -1355,7 +1388,13 @@ hipError_t launchFsp4ScanRowsMatrix(Fsp4Args args, uint32_t paddedDw, bool ident
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    if (args.rowBegin % 32u == 0u) {
+    // The rows' fragments are addressed in place -- inside the columns' array -- only when every 64-row block of the launch
+    // lies within that array: a shard that begins at 32 (mod 64) and ends with the cells would otherwise read 32 cells past
+    // it, into workspace nobody wrote (expandFragmentsKernel pads with copies of the last cell, so that a padded lane only
+    // ever holds +-1 operands and cannot pass a bound; stale FP4 magnitudes could).
+    const bool rowsInPlace = args.rowBegin % 32u == 0u &&
+                             uint64_t(args.rowBegin) + 64ull * rowBlocks <= uint64_t((cellCount + 63u) / 64u) * 64u;
+    if (rowsInPlace) {
         args.rowFragmentBase = args.rowBegin / 32u;             // the rows are whole blocks of the columns' array
     } else {
         if (!rowFragmentArea) return hipErrorInvalidValue;
@@ -1369,7 +1408,7 @@ hipError_t launchFsp4ScanRowsMatrix(Fsp4Args args, uint32_t paddedDw, bool ident
     if (scanVerbose()) {
         fprintf(stderr, "[em2] rows form on the matrix cores: rows [%u, %u), %u segments x %u columns, %llu tickets, %llu blocks, "
                                          "row fragments %s\n", args.rowBegin, args.rowEnd, uint32_t(segments), cps, (unsigned long long)tickets,
-                                 (unsigned long long)blocksWanted, args.rowBegin % 32u == 0u ? "in the columns' array" : "expanded once more");
+                                 (unsigned long long)blocksWanted, rowsInPlace ? "in the columns' array" : "expanded once more");
     }
     void* argsArray[] = {&args};
     if (timing[0]) (void)hipEventRecord(timing[0], stream);

@@ -23,7 +23,7 @@ typedef const __attribute__((address_space(4))) int32_t* ScalarIntPtr;
 __device__ __attribute__((noinline)) uint64_t refillInboxChunk(uint64_t* inbox, uint32_t* control, uint64_t capacity,
                                                                uint32_t chunk, uint32_t lane, uint32_t pos, uint32_t end)
 {
-    for (uint32_t i = pos + lane; i < end; i += 64u) inbox[i] = ~0ull;      // sentinels sort to the end
+    for (uint32_t i = pos + lane; i < end; i += 64u) storeGlobalWord(inbox + i, ~0ull);      // sentinels sort to the end
     unsigned long long base = 0;
     if (lane == 0u) {
         base = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(control), (unsigned long long)chunk,
@@ -61,7 +61,7 @@ __device__ __forceinline__ void emitColumn(bool emit, uint32_t col, uint32_t row
     }
     if (emit) {
         const uint32_t nb = aux->rowBits;
-        aux->inbox[p + lanesBelow(mask)] = (uint64_t(col) << (13u + nb)) | (uint64_t(row) << 13u) | uint64_t(m);
+        storeGlobalWord(aux->inbox + p + lanesBelow(mask), (uint64_t(col) << (13u + nb)) | (uint64_t(row) << 13u) | uint64_t(m));
     }
     emitPos = p + n;
     emitEnd = e;
@@ -159,8 +159,8 @@ __device__ __forceinline__ uint32_t scanColumnsEmit(const uint32_t* __restrict__
                             if (at <= uint32_t(__builtin_amdgcn_readfirstlane(int(emitEnd)))) {
                                 if (emit) {
                                     ArgsPtr aux = kernelArgs();
-                                    aux->inbox[at + lanesBelow(emitMask)] =
-                                        (uint64_t(col) << (13u + aux->rowBits)) | (uint64_t(row) << 13u) | uint64_t(m);
+                                    storeGlobalWord(aux->inbox + at + lanesBelow(emitMask),
+                                                    (uint64_t(col) << (13u + aux->rowBits)) | (uint64_t(row) << 13u) | uint64_t(m));
                                 }
                                 emitPos = at + uint32_t(__builtin_popcountll(emitMask));
                                 stop = inboxRoom(emitPos, emitEnd) < 64u;
@@ -344,25 +344,34 @@ __device__ __forceinline__ uint32_t laneId()
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
-// A record of the walk: the step's stub wrote {first column of the tile | 2i + a, dot} into the log of the LANE in which
-// register i of accumulator a passed its test (em2_matrix_step_asm.h).  Lane s = 32 h + t holds rows t and 32 + t of the
-// wave and the columns 8q + 4h + j of a tile (i = 4q + j): its records ascend in the column.
-struct WalkRecord {
+// A record of the walk: the step's stub wrote {first column of the tile | 2i + a, dot, column bound} into the log of the LANE
+// in which register i of accumulator a passed its test (em2_matrix_step_asm.h: 12 bytes, 16 apart).  Lane s = 32 h + t holds
+// rows t and 32 + t of the wave and the columns 8q + 4h + j of a tile (i = 4q + j): its records ascend in the column.  The
+// third word is the bound the walk tested the COLUMN side against (1024 - 2 x the column's published cut-off as the walk staged
+// it, at most two pairs of tiles old; any value a cell published is valid, bounds only tighten): dot >= bound is the column
+// side's test, which the replay therefore decides without a load of its own per record.
+struct __attribute__((aligned(16))) WalkRecord {
     uint32_t code;                  // tile's first column (a multiple of 32) | 2i + a
     float dot;                      // 1024 - 2 * mismatches
+    float bound;                    // 1024 - 2 * the column's cut-off (1026: a column that takes no candidates)
 };
+static_assert(sizeof(WalkRecord) == EM2_MATRIX_RECORD_BYTES, "the steps store their records 16 bytes apart");
 __device__ __forceinline__ uint32_t walkRecordColumn(uint32_t code, uint32_t half)
 {
     const uint32_t i = (code & 31u) >> 1;
     return (code & ~31u) + 8u * (i >> 2) + 4u * half + (i & 3u);
 }
-// (the records of a lane are written by that lane and read by others: past the L1, like the row lists)
-__device__ __forceinline__ WalkRecord loadWalkRecord(const Entry* log, uint32_t index)
+// (The records of a lane are written by that lane and read by others, from addresses that earlier replays of the same wave
+// have read: the replay starts with an acquire at agent scope -- the L1's lines go -- and reads them with plain loads.)
+typedef uint32_t WalkRecordWords __attribute__((ext_vector_type(3)));         // (16 bytes apart, like the records)
+__device__ __forceinline__ WalkRecord loadWalkRecord(const WalkRecord* log, uint32_t index)
 {
-    const Entry e = loadEntryCoherent(log + index);
+    // (global memory, said so: the log's address comes out of the kernel-argument block, see em2_scan_common.h)
+    const WalkRecordWords w = ((const __attribute__((address_space(1))) WalkRecordWords*)reinterpret_cast<const WalkRecordWords*>(log))[index];
     WalkRecord r;
-    r.code = e.cell;
-    r.dot = __uint_as_float(e.key);
+    r.code = w.x;
+    r.dot = __uint_as_float(w.y);
+    r.bound = __uint_as_float(w.z);
     return r;
 }
 
@@ -464,7 +473,7 @@ template <bool IDENTITY, bool BOTH = false, bool DIAG = false>
 __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* auxArg, const void* fragmentsArg, const void* snapArg,
                                                                     uint32_t colBeginArg, uint32_t colEndArg,
                                                                     uint32_t rowFragmentBlockArg, float rowDotArg,
-                                                                    Entry* waveLogArg, uint32_t logCapacityArg, uint32_t* recordCount,
+                                                                    WalkRecord* waveLogArg, uint32_t logCapacityArg, uint32_t* recordCount,
                                                                     uint32_t tilesLdsArg, uint32_t stopWordsLdsArg, uint32_t walkLdsArg)
 {
     const GlobalFragmentPtr fragments = (GlobalFragmentPtr)uniform64(reinterpret_cast<uint64_t>(fragmentsArg));
@@ -487,13 +496,13 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     const uint32_t halfCapacity = logCapacity / 2u;
     // byte offsets into the wave's log area: where the lane's two logs begin, where its next records go (kept in two
     // registers of the walk; the steps return them), and beyond which the walk has to stop
-    const uint32_t firstOffset0 = laneId() * logCapacity * uint32_t(sizeof(Entry));
-    const uint32_t firstOffset1 = firstOffset0 + halfCapacity * uint32_t(sizeof(Entry));
+    const uint32_t firstOffset0 = laneId() * logCapacity * EM2_MATRIX_RECORD_BYTES;
+    const uint32_t firstOffset1 = firstOffset0 + halfCapacity * EM2_MATRIX_RECORD_BYTES;
     const uint32_t stopRecords = halfCapacity > kMatrixLogMargin / 2u ? halfCapacity - kMatrixLogMargin / 2u : 0u;
-    const uint32_t stopOffset0 = firstOffset0 + stopRecords * uint32_t(sizeof(Entry));
-    const uint32_t stopOffset1 = firstOffset1 + stopRecords * uint32_t(sizeof(Entry));
-    uint32_t recordOffset = firstOffset0 + recordCount[0] * uint32_t(sizeof(Entry));
-    uint32_t recordOffset1 = firstOffset1 + recordCount[1] * uint32_t(sizeof(Entry));
+    const uint32_t stopOffset0 = firstOffset0 + stopRecords * EM2_MATRIX_RECORD_BYTES;
+    const uint32_t stopOffset1 = firstOffset1 + stopRecords * EM2_MATRIX_RECORD_BYTES;
+    uint32_t recordOffset = firstOffset0 + recordCount[0] * EM2_MATRIX_RECORD_BYTES;
+    uint32_t recordOffset1 = firstOffset1 + recordCount[1] * EM2_MATRIX_RECORD_BYTES;
     {
         const uint32_t lane = laneId();
         ldsPointer<LdsFloatPtr>(walkLds + kWalkRowDot)[lane] = rowDotArg;         // for the steps: float[64], lane = row
@@ -541,8 +550,8 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
 #define EM2_WAIT_STAGED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define EM2_KEEP_WRAP_COUNTS()                                                                                                \
     do {                                                                                                                      \
-        ldsPointer<LdsWordPtr>(walkLds + kWalkWrapCounts)[laneId()] = (recordOffset - firstOffset0) / uint32_t(sizeof(Entry)); \
-        ldsPointer<LdsWordPtr>(walkLds + kWalkWrapCounts)[64u + laneId()] = (recordOffset1 - firstOffset1) / uint32_t(sizeof(Entry)); \
+        ldsPointer<LdsWordPtr>(walkLds + kWalkWrapCounts)[laneId()] = (recordOffset - firstOffset0) / EM2_MATRIX_RECORD_BYTES; \
+        ldsPointer<LdsWordPtr>(walkLds + kWalkWrapCounts)[64u + laneId()] = (recordOffset1 - firstOffset1) / EM2_MATRIX_RECORD_BYTES; \
     } while (0)
     EM2_STAGE_TILE(colBegin / 32u, 0u);
     if (colBegin + 32u < colEnd) EM2_STAGE_TILE(colBegin / 32u + 1u, 1u);
@@ -697,8 +706,8 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     // caller replays the logs (it reads past the L1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tested && !(diag & 1u)) {
-        recordCount[0] = (recordOffset - firstOffset0) / uint32_t(sizeof(Entry));
-        recordCount[1] = (recordOffset1 - firstOffset1) / uint32_t(sizeof(Entry));
+        recordCount[0] = (recordOffset - firstOffset0) / EM2_MATRIX_RECORD_BYTES;
+        recordCount[1] = (recordOffset1 - firstOffset1) / EM2_MATRIX_RECORD_BYTES;
     }
     return lowerColumns ? result | kWalkInLowerColumns : result;
 }
@@ -711,7 +720,7 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
 template <bool IDENTITY, bool BOTH = false>
 __device__ __attribute__((noinline)) uint32_t scanTilesMatrixWide(const void* fragmentsArg, const void* snapArg, uint32_t colBeginArg,
                                                                   uint32_t colEndArg, uint32_t rowFragmentBlockArg, float rowDotArg,
-                                                                  uint32_t rowHalfArg, Entry* waveLogArg, uint32_t logCapacityArg,
+                                                                  uint32_t rowHalfArg, WalkRecord* waveLogArg, uint32_t logCapacityArg,
                                                                   uint32_t* recordCount, uint32_t tilesLdsArg, uint32_t stopWordsLdsArg,
                                                                   uint32_t walkLdsArg)
 {
@@ -731,10 +740,10 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixWide(const void* fr
     const uint64_t convoyAddress = uint64_t(uniform(stopWords[kConvoyAddressWord])) | (uint64_t(uniform(stopWords[kConvoyAddressWord + 1u])) << 32);
     const uint32_t wrapBegin = uniform(stopWords[kWrapBeginWord]), wrapEnd = uniform(stopWords[kWrapEndWord]);
     const uint32_t halfCapacity = logCapacity / 2u;
-    const uint32_t firstOffset = (laneId() * logCapacity + rowHalf * halfCapacity) * uint32_t(sizeof(Entry));
+    const uint32_t firstOffset = (laneId() * logCapacity + rowHalf * halfCapacity) * EM2_MATRIX_RECORD_BYTES;
     const uint32_t stopRecords = halfCapacity > kMatrixLogMargin / 2u ? halfCapacity - kMatrixLogMargin / 2u : 0u;
-    const uint32_t stopOffset = firstOffset + stopRecords * uint32_t(sizeof(Entry));
-    uint32_t recordOffset = firstOffset + recordCount[rowHalf] * uint32_t(sizeof(Entry));
+    const uint32_t stopOffset = firstOffset + stopRecords * EM2_MATRIX_RECORD_BYTES;
+    uint32_t recordOffset = firstOffset + recordCount[rowHalf] * EM2_MATRIX_RECORD_BYTES;
     uint32_t unusedOffset = 0;
     const uint32_t stateBase = walkLds + kWalkRowDot + 128u * rowHalf;       // the half's 32 row bounds
     {
@@ -776,7 +785,7 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixWide(const void* fr
     __syncthreads();
     if (wrapBegin < wrapEnd && waveSlot == 0u && laneId() == 0u) stopWords[kWrapBeginWord] = stopWords[kWrapEndWord] = 0u;
 #define EM2_KEEP_WRAP_COUNTS()                                                                                                \
-    ldsPointer<LdsWordPtr>(walkLds + kWalkWrapCounts)[rowHalf * 64u + laneId()] = (recordOffset - firstOffset) / uint32_t(sizeof(Entry))
+    ldsPointer<LdsWordPtr>(walkLds + kWalkWrapCounts)[rowHalf * 64u + laneId()] = (recordOffset - firstOffset) / EM2_MATRIX_RECORD_BYTES
     bool tested = false;
     uint64_t passScratch[5];
     bool pending = false;
@@ -881,139 +890,450 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixWide(const void* fr
     if (keepCounts) EM2_KEEP_WRAP_COUNTS();         // (a walk that stopped at the very end of its higher columns)
 #undef EM2_KEEP_WRAP_COUNTS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tested) recordCount[rowHalf] = (recordOffset - firstOffset) / uint32_t(sizeof(Entry));
+    if (tested) recordCount[rowHalf] = (recordOffset - firstOffset) / EM2_MATRIX_RECORD_BYTES;
     return lowerColumns ? result | kWalkInLowerColumns : result;
 }
 
 // The log of `lane` for accumulator a in the wave's log area.
-__device__ __forceinline__ const Entry* walkLogOf(const Entry* waveLog, uint32_t logCapacity, uint32_t lane, uint32_t a)
+__device__ __forceinline__ const WalkRecord* walkLogOf(const WalkRecord* waveLog, uint32_t logCapacity, uint32_t lane, uint32_t a)
 {
     return waveLog + size_t(lane) * logCapacity + a * (logCapacity / 2u);
 }
 
-// A log read a few records ahead of its use (the records were written by another lane: every load goes past the L1, and
-// a replay that waited for each one -- the next record is needed to decide which stream to take from -- spent most of its
-// time in that latency).
-// The records are taken in the order first, first + 1, ..., stored - 1 and then -- a walk that went around its segment
-// (scanMatrixBody, "convoy") -- 0 .. first - 1: the log of such a walk holds the columns from its starting point to the
-// segment's end in front of the columns from the segment's begin to its starting point.
-struct WalkLogReader {
-    const Entry* log;
-    uint32_t count, fetched, taken, first, stored;
-    WalkRecord ahead[4];
-    __device__ __forceinline__ uint32_t physical(uint32_t i) const { return first + i < stored ? first + i : first + i - stored; }
-    // n records of a log that holds `stored`, from record `from` on
-    __device__ __forceinline__ void start(const Entry* l, uint32_t n, uint32_t from = 0u, uint32_t storedRecords = 0u)
-    {
-        log = l;
-        count = n;
-        first = from;
-        stored = from ? storedRecords : n;
-        fetched = taken = 0u;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            ahead[i].code = 0u;
-            ahead[i].dot = 0.f;
-            if (uint32_t(i) < count) ahead[i] = loadWalkRecord(log, physical(uint32_t(i)));
-        }
-        fetched = count < 4u ? count : 4u;
-    }
-    __device__ __forceinline__ bool have() const { return taken < count; }
-    __device__ __forceinline__ WalkRecord front() const { return ahead[0]; }
-    __device__ __forceinline__ void pop()
-    {
-        ahead[0] = ahead[1];
-        ahead[1] = ahead[2];
-        ahead[2] = ahead[3];
-        if (fetched < count) ahead[3] = loadWalkRecord(log, physical(fetched));
-        fetched += fetched < count ? 1u : 0u;
-        ++taken;
-    }
+// An element of the replay's merge: a record as (column, mismatches | the column side's test in bit 31).
+struct MergeElement {
+    uint32_t col, payload;
 };
+__device__ __forceinline__ MergeElement mergeElementOf(bool have, const WalkRecord& r, uint32_t half, float bits)
+{
+    MergeElement e;
+    e.col = have ? walkRecordColumn(r.code, half) : 0xffffffffu;           // (sentinels sort behind every record)
+    e.payload = have ? (uint32_t((bits - r.dot) * 0.5f) | (r.dot >= r.bound ? 0x80000000u : 0u)) : 0u;
+    return e;
+}
+// lo = the element with the smaller column (columns of records are all different)
+__device__ __forceinline__ void orderElements(MergeElement& lo, MergeElement& hi)
+{
+    const bool swap = hi.col < lo.col;
+    const MergeElement a = lo, b = hi;
+    lo.col = swap ? b.col : a.col;
+    lo.payload = swap ? b.payload : a.payload;
+    hi.col = swap ? a.col : b.col;
+    hi.payload = swap ? a.payload : b.payload;
+}
+// The lanes whose bit STRIDE is clear (they keep the smaller element of a compare-exchange), as a mask
+template <uint32_t STRIDE> __device__ __forceinline__ constexpr uint64_t lowerLanesOf()
+{
+    return STRIDE == 32u ? 0x00000000ffffffffull : STRIDE == 16u ? 0x0000ffff0000ffffull : STRIDE == 8u ? 0x00ff00ff00ff00ffull
+         : STRIDE == 4u ? 0x0f0f0f0f0f0f0f0full : STRIDE == 2u ? 0x3333333333333333ull : 0x5555555555555555ull;
+}
+// The element of lane (lane ^ STRIDE), without the LDS: quad permutes for 1 and 2, a mirror of eight lanes followed by a
+// reversal of four for 4 (7 - i, then ^ 3: i ^ 4), a rotation of sixteen lanes by eight for 8, and the gfx950 row / half swaps
+// for 16 and 32: with the same value as both operands v_permlane16_swap / v_permlane32_swap return the even rows' (the lower
+// half's) value in every lane of their first result and the odd rows' (the upper half's) in the second
+// (tools/probe/permlane_swap.hip).  ds_bpermute in their place made a merge a chain of twelve LDS round trips behind the matrix
+// walk's fragment reads.
+template <uint32_t STRIDE>
+__device__ __forceinline__ MergeElement partnerElement(const MergeElement& e)
+{
+    MergeElement p;
+    if (STRIDE == 1u) {
+        p.col = uint32_t(__builtin_amdgcn_update_dpp(0, int(e.col), 0xB1, 0xf, 0xf, false));          // quad_perm:[1,0,3,2]
+        p.payload = uint32_t(__builtin_amdgcn_update_dpp(0, int(e.payload), 0xB1, 0xf, 0xf, false));
+    } else if (STRIDE == 2u) {
+        p.col = uint32_t(__builtin_amdgcn_update_dpp(0, int(e.col), 0x4E, 0xf, 0xf, false));          // quad_perm:[2,3,0,1]
+        p.payload = uint32_t(__builtin_amdgcn_update_dpp(0, int(e.payload), 0x4E, 0xf, 0xf, false));
+    } else if (STRIDE == 4u) {
+        const int c = __builtin_amdgcn_update_dpp(0, int(e.col), 0x141, 0xf, 0xf, false);             // row_half_mirror
+        const int y = __builtin_amdgcn_update_dpp(0, int(e.payload), 0x141, 0xf, 0xf, false);
+        p.col = uint32_t(__builtin_amdgcn_update_dpp(0, c, 0x1B, 0xf, 0xf, false));                   // quad_perm:[3,2,1,0]
+        p.payload = uint32_t(__builtin_amdgcn_update_dpp(0, y, 0x1B, 0xf, 0xf, false));
+    } else if (STRIDE == 8u) {
+        p.col = uint32_t(__builtin_amdgcn_update_dpp(0, int(e.col), 0x128, 0xf, 0xf, false));         // row_ror:8
+        p.payload = uint32_t(__builtin_amdgcn_update_dpp(0, int(e.payload), 0x128, 0xf, 0xf, false));
+    } else {
+        const bool lower = __builtin_amdgcn_inverse_ballot_w64(lowerLanesOf<STRIDE>());
+        if (STRIDE == 16u) {
+            const auto c = __builtin_amdgcn_permlane16_swap(e.col, e.col, false, false);
+            const auto y = __builtin_amdgcn_permlane16_swap(e.payload, e.payload, false, false);
+            p.col = lower ? uint32_t(c[1]) : uint32_t(c[0]);
+            p.payload = lower ? uint32_t(y[1]) : uint32_t(y[0]);
+        } else {
+            const auto c = __builtin_amdgcn_permlane32_swap(e.col, e.col, false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap(e.payload, e.payload, false, false);
+            p.col = lower ? uint32_t(c[1]) : uint32_t(c[0]);
+            p.payload = lower ? uint32_t(y[1]) : uint32_t(y[0]);
+        }
+    }
+    return p;
+}
+// One stage: the lanes whose bit STRIDE is clear keep the smaller column, the others the larger (columns of records are all
+// different; two sentinels may change places).  One compare, one scalar xor with the stage's lane mask, two selects.
+template <uint32_t STRIDE, int R>
+__device__ __forceinline__ void bitonicStage(MergeElement (&e)[R])
+{
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const MergeElement other = partnerElement<STRIDE>(e[i]);
+        const bool take = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64(other.col < e[i].col) ^ ~lowerLanesOf<STRIDE>());
+        e[i].col = take ? other.col : e[i].col;
+        e[i].payload = take ? other.payload : e[i].payload;
+    }
+}
+// The bitonic merge of 64 R elements -- element i of the sequence sits in e[i >> 6] of lane i & 63; the first half ascends, the
+// second descends -- into ascending order: log2(64 R) compare-exchange stages, those of 64 elements and more apart between the
+// registers of a lane, the others between lanes.
+template <int R>
+__device__ __forceinline__ void bitonicMergeWave(MergeElement (&e)[R])
+{
+    if (R == 4) {
+        orderElements(e[0], e[2]);
+        orderElements(e[1], e[3]);
+        orderElements(e[0], e[1]);
+        orderElements(e[2], e[3]);
+    } else {
+        orderElements(e[0], e[1]);
+    }
+    bitonicStage<32u, R>(e);
+    bitonicStage<16u, R>(e);
+    bitonicStage<8u, R>(e);
+    bitonicStage<4u, R>(e);
+    bitonicStage<2u, R>(e);
+    bitonicStage<1u, R>(e);
+}
 
-// The replay of the walk's logs for the rows of the wave (lane = row, as everywhere outside the walk).  Row r = 32a + t
-// finds its records in the accumulator-a logs of lanes t (columns 8q .. 8q+3 of every group) and 32 + t (columns 8q+4 ..
-// 8q+7); both ascend in the column, and the row's candidates must be offered in ascending order: a two-way merge, every
-// lane its own, all lanes in step.  Per record: the row side through the exact state machine (acceptColumn), the column
-// side -- unless the rows scan all columns themselves (full rows) -- to the inbox if it passes the column's published
-// cut-off, read now (fresher than the one the walk tested against: fewer entries).
+// One row of the replay (replayWalkLogs): its 64 R merged elements, lane j of register b holding element 64 b + j of `n`, are
+// offered to the row's exact state machine in that order -- the lanes test together against the row's cut-off, what passes is
+// appended to the row's list behind a prefix count, and a list that reaches 2k entries inside a batch is cut right behind the
+// record that filled it (src/ExpressionMatrixLsh.cpp:243-251: push, then keepBest at 2k), the lanes behind that record testing
+// again against the new cut-off.  Then the column side: the records whose third word said so go to the inbox, one compaction
+// per batch.  rowId / listRow: the row's cell id and its list; count / mMax: the row's state (uniform), updated.
+// (what the replay reads from the kernel-argument block, once per call instead of once per row: a scalar load there is two
+// hundred cycles in front of whatever needs it)
+struct ReplayArgs {
+    Entry* lists;                       // the lists of the wave's 64 rows
+    uint64_t* inbox;
+    const int32_t* acceptMaxByKey;
+    const uint32_t* keyOfMismatch;
+    uint32_t k, twoK, columnShift;      // columnShift = 13 + rowBits: where an inbox entry's target cell begins
+};
+template <bool IDENTITY, int R>
+__device__ __forceinline__ void replayRowElements(const MergeElement (&e)[R], uint32_t n, uint32_t lane, uint32_t rowId, bool emitRow,
+                                                  Entry* listRow, const ReplayArgs& args, uint32_t& count, int32_t& mMax, uint32_t& emitPos,
+                                                  uint32_t& emitEnd, unsigned char* ldsRaw, uint64_t* timed = nullptr)
+{
+    const uint32_t twoK = args.twoK;
+#pragma unroll
+    for (int b = 0; b < R; b++) {
+        if (64u * uint32_t(b) >= n) break;
+        const uint32_t col = e[b].col, m = e[b].payload & 0x7fffffffu;
+        bool active = 64u * uint32_t(b) + lane < n;
+        for (;;) {
+            const bool pass = active && int32_t(m) <= mMax && col != rowId;
+            const uint64_t passMask = __builtin_amdgcn_ballot_w64(pass);
+            if (passMask == 0ull) break;
+            const uint32_t passes = uint32_t(__builtin_popcountll(passMask)), room = twoK - count;
+            const uint32_t index = lanesBelow(passMask);
+            if (pass && index < room) {
+                uint32_t key = m;
+                if (!IDENTITY) key = args.keyOfMismatch[m];
+                storeEntry(listRow + count + index, col, key);
+            }
+            if (passes < room) {
+                count += passes;
+                break;
+            }
+            // the list is full behind the record of index room - 1: keepBest, the new cut-off, and the lanes behind that record again
+            Entry* lds = reinterpret_cast<Entry*>(ldsRaw + size_t(threadIdx.x >> 6) * twoK * kLdsBytesPerEntrySlot);
+            const uint64_t ts0 = timed ? __builtin_readcyclecounter() : 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const uint64_t ts1 = timed ? __builtin_readcyclecounter() : 0ull;
+            const uint32_t backKey = cutListToBest((LdsEntryPtr)lds, listRow, twoK, args.k, lane, true);
+            const uint64_t ts2 = timed ? __builtin_readcyclecounter() : 0ull;
+            mMax = __builtin_amdgcn_readfirstlane(args.acceptMaxByKey[backKey]);
+            count = args.k;
+            waveLdsFence();
+            if (timed) {
+                const uint64_t ts3 = __builtin_readcyclecounter();
+                timed[0] += ts1 - ts0;
+                timed[1] += ts2 - ts1;
+                timed[2] += ts3 - ts2;
+                timed[3] += 1u;
+            }
+            const uint32_t filler = uint32_t(__builtin_ctzll(__builtin_amdgcn_ballot_w64(pass && index == room - 1u)));
+            active = active && lane > filler;
+        }
+        if (emitRow) {
+            // the column side: one compaction per batch into the wave's chunk of the inbox (emitColumn, with the arguments at hand)
+            const bool emit = 64u * uint32_t(b) + lane < n && (e[b].payload >> 31) != 0u;
+            const uint64_t emitMask = __builtin_amdgcn_ballot_w64(emit);
+            if (emitMask != 0ull) {
+                uint32_t p = uniform(emitPos), end = uniform(emitEnd);
+                if (p <= end) {             // (p > end: emission disabled after an overflow)
+                    const uint32_t entries = uint32_t(__builtin_popcountll(emitMask));
+                    if (p + entries > end) {
+                        ArgsPtr aux = kernelArgs();
+                        const uint64_t fresh = refillInboxChunk(aux->inbox, aux->inboxControl, aux->inboxCapacity, aux->inboxChunk, lane, p, end);
+                        p = uint32_t(fresh);
+                        end = uint32_t(fresh >> 32);
+                    }
+                    if (p <= end) {
+                        if (emit) {
+                            storeGlobalWord(args.inbox + p + lanesBelow(emitMask),
+                                            (uint64_t(col) << args.columnShift) | (uint64_t(rowId) << 13u) | uint64_t(m));
+                        }
+                        p += entries;
+                    }
+                    emitPos = p;
+                    emitEnd = end;
+                }
+            }
+        }
+    }
+}
+
+// The replay of the walk's logs for the rows of the wave, ROW BY ROW, the lanes side by side on one row's records.
+// Row r = 32a + t finds its records in the accumulator-a logs of lanes t (columns 8q .. 8q+3 of every group) and 32 + t (columns
+// 8q+4 .. 8q+7); both ascend in the column, and the row's candidates must be offered in ascending order.  The wave loads the two
+// logs side by side -- the first ascending over the lanes, the second descending -- and merges them with a bitonic network (one
+// record per lane and log for logs of up to 64 records, two beyond: a log holds 128 at most, kLogCapacity / 2); replayRowElements
+// does the rest.  The loads of four rows are in flight while one is replayed (the records come from the L2: a form in which
+// every lane merged its own row's two logs record by record waited a round trip per record, as long as the fullest lane had
+// records, and spent a third of the waves' time there on clustered data).  Rows with a long log follow, one at a time.
+// Per record: the row side through the exact state machine, the column side -- unless the rows scan all columns themselves
+// (full rows) -- to the inbox if the record's third word says that it passed the column's published cut-off.
 // recordCount[a] = the calling lane's number of records in its log of accumulator a.  A walk that went around its segment:
 // firstRecord[a] = the lane's number of records when the walk reached the segment's end (their columns are the higher ones and
 // come last); all = false replays only the records from firstRecord on (the walk stopped for its logs in the lower columns:
 // those are in order and go first, the others stay).
+// lane = row for row / rowValid / myList / count / mMax, as everywhere outside the walk.
+struct ReplayRowLoads {
+    uint32_t row;                       // 0..63, 64 = none
+    uint32_t nA, nB;                    // records to replay of the row's two logs
+};
+// The records of a row travel global -> LDS without touching registers (global_load_lds_dwordx4: LDS address = M0 + 16 * lane),
+// into a ring of four slots of two 1 KB pieces per wave -- lane j's record of the first log at 16 j, of the second at 4096 + 16 j -- and are
+// waited for by COUNT, so that the loads of the next three rows stay in flight while a row is replayed.  Left to the compiler
+// (loads into registers) the wait in front of a row's first use was vmcnt(0): the loop's stores -- the lists, the inbox -- come
+// in numbers it cannot bound, and it then drains the queue, a round trip to the L2 per row; and registers that an asm statement
+// loads into are copied by the compiler while the load is in flight.  The LDS has no such copies.  Every call issues exactly
+// two transfers (replayWalkLogs: a slot without a row loads for nobody), memory operations complete in order, and whatever
+// else the loop issues in between only makes the count more conservative.
+// The ring lives in the block's tile buffers, which nobody reads between two calls of the walk (its last barrier is behind
+// the last read of a tile, and its staging has been waited for): slot i of wave w in the 4 KB piece of tile buffer i >> 1 that
+// only wave w's staging writes (scanTilesMatrixPinned: EM2_STAGE_TILE) -- a wave that is back in the walk while its block's
+// other waves still replay writes nothing of theirs.  (A wave stages the 1 KB pieces 4 KB apart of every 16 KB buffer that begin
+// 1 KB x its number into it: two of the four pieces of a buffer are a slot.)
+constexpr uint32_t kReplayRingSecondLog = 4096u;
+__device__ __forceinline__ uint32_t replayRingSlot(uint32_t tilesLds, uint32_t wave, uint32_t slot)
+{
+    return tilesLds + (slot >> 1) * (kMatrixTileWords * 16u) + (slot & 1u) * 8192u + wave * 1024u;
+}
+__device__ __forceinline__ void issueRecordLoads(uint32_t ringSlotLds, const WalkRecord* logA, uint32_t indexA, const WalkRecord* logB,
+                                                 uint32_t indexB)
+{
+    const uint64_t addressA = reinterpret_cast<uint64_t>(logA + indexA), addressB = reinterpret_cast<uint64_t>(logB + indexB);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+                 "s_add_u32 m0, %2, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                 :
+                 : "v"(addressA), "v"(addressB), "s"(ringSlotLds)
+                 : "memory", "m0", "scc");
+}
+template <int YOUNGER>
+__device__ __forceinline__ void awaitRecordLoads()
+{
+    static_assert(YOUNGER == 0 || YOUNGER == 6, "transfers come in pairs, four rows are in flight");
+    if (YOUNGER == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+typedef const volatile __attribute__((address_space(3))) WalkRecordWords* LdsRecordPtr;
+__device__ __forceinline__ WalkRecord walkRecordOf(const WalkRecordWords& w)
+{
+    WalkRecord r;
+    r.code = w.x;
+    r.dot = __uint_as_float(w.y);
+    r.bound = __uint_as_float(w.z);
+    return r;
+}
 template <bool IDENTITY, bool WIDE = false>
-__device__ __forceinline__ void replayWalkLogs(const Entry* waveLog, uint32_t logCapacity, const uint32_t (&recordCount)[2],
+__device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32_t logCapacity, const uint32_t (&recordCount)[2],
                                                const uint32_t (&firstRecord)[2], bool all, uint32_t lane,
                                                uint32_t row, bool rowValid, bool emitColumns, uint32_t listBlock, Entry* myList,
                                                uint32_t twoK, uint32_t& count, int32_t& mMax, uint32_t& emitPos, uint32_t& emitEnd,
-                                               unsigned char* ldsRaw)
+                                               unsigned char* ldsRaw, uint32_t tilesLds, uint64_t* timed = nullptr)
 {
-    const uint32_t t = lane & 31u, a = lane >> 5;
-    // the counts of the two source logs: accumulator a of lanes t and 32 + t
-    const uint32_t mine0 = uint32_t(__shfl(int(recordCount[0]), int(t), 64)), mine1 = uint32_t(__shfl(int(recordCount[1]), int(t), 64));
-    const uint32_t theirs0 = uint32_t(__shfl(int(recordCount[0]), int(t + 32u), 64)), theirs1 = uint32_t(__shfl(int(recordCount[1]), int(t + 32u), 64));
-    const uint32_t mineFirst0 = uint32_t(__shfl(int(firstRecord[0]), int(t), 64)), mineFirst1 = uint32_t(__shfl(int(firstRecord[1]), int(t), 64));
-    const uint32_t theirsFirst0 = uint32_t(__shfl(int(firstRecord[0]), int(t + 32u), 64)), theirsFirst1 = uint32_t(__shfl(int(firstRecord[1]), int(t + 32u), 64));
-    WalkLogReader lower, upper;
+    const uint64_t tr0 = timed ? __builtin_readcyclecounter() : 0ull;
+    constexpr float bits = (WIDE ? 2.f : 1.f) * kMatrixBits;
+    // (the caller's arrays live in scratch memory -- the walk takes them by address: one read each)
+    const uint32_t stored0Mine = recordCount[0], stored1Mine = recordCount[1], first0Mine = firstRecord[0], first1Mine = firstRecord[1];
+    // what this lane's two logs hold for the replay, and which rows have records at all (bit 32 a + t: row 32 a + t)
+    const uint32_t mine[2] = {all ? stored0Mine : stored0Mine - first0Mine, all ? stored1Mine : stored1Mine - first1Mine};
+    uint64_t rowsWithRecords = 0, rowsWithLongLogs = 0;
+#pragma unroll
+    for (uint32_t a = 0; a < 2u; a++) {
+        const uint64_t some = __builtin_amdgcn_ballot_w64(mine[a] != 0u), longLog = __builtin_amdgcn_ballot_w64(mine[a] > 64u);
+        const uint64_t rowsLong = (longLog | (longLog >> 32)) & 0xffffffffull;
+        rowsWithLongLogs |= rowsLong << (32u * a);
+        rowsWithRecords |= (((some | (some >> 32)) & 0xffffffffull) & ~rowsLong) << (32u * a);
+    }
+    if ((rowsWithRecords | rowsWithLongLogs) == 0ull) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (the logs: written by other lanes, read here with plain loads)
+    const uint64_t validRows = __builtin_amdgcn_ballot_w64(rowValid);
+    const uint32_t rowOfWave = uniform(row - lane);
+    ReplayArgs args;
     {
-        const uint32_t stored = a ? mine1 : mine0, first = a ? mineFirst1 : mineFirst0;
-        lower.start(walkLogOf(waveLog, logCapacity, t, a), all ? stored : stored - first, first, stored);
+        ArgsPtr aux = kernelArgs();
+        args.lists = aux->buffers + size_t(listBlock) * 64u * twoK;
+        args.inbox = aux->inbox;
+        args.acceptMaxByKey = aux->acceptMaxByKey;
+        args.keyOfMismatch = aux->keyOfMismatch;
+        args.k = aux->k;
+        args.twoK = twoK;
+        args.columnShift = 13u + aux->rowBits;
     }
+    Entry* const listOfWave = args.lists;
+    // logical record i of a log that holds `stored` records and is read from record `first` on
+    auto physical = [](uint32_t i, uint32_t first, uint32_t stored) { return first + i < stored ? first + i : first + i - stored; };
+    auto countsOf = [&](uint32_t r, uint32_t h, uint32_t& n, uint32_t& first, uint32_t& stored) {
+        const uint32_t owner = (r & 31u) + 32u * h;
+        const uint32_t stored0 = uint32_t(__builtin_amdgcn_readlane(int(stored0Mine), int(owner)));
+        const uint32_t stored1 = uint32_t(__builtin_amdgcn_readlane(int(stored1Mine), int(owner)));
+        const uint32_t first0 = uint32_t(__builtin_amdgcn_readlane(int(first0Mine), int(owner)));
+        const uint32_t first1 = uint32_t(__builtin_amdgcn_readlane(int(first1Mine), int(owner)));
+        stored = r < 32u ? stored0 : stored1;
+        first = r < 32u ? first0 : first1;
+        n = all ? stored : stored - first;
+    };
+    auto issue = [&](ReplayRowLoads& slot, uint32_t ringSlotLds) {
+        // (no branch around the loads, not even when no row is left -- the slot then loads row 0's first places for nobody: a
+        // slot that kept its old registers on one path would be copied behind the loads of the other, and waited for there)
+        const bool any = rowsWithRecords != 0ull;
+        const uint32_t r = any ? uint32_t(__builtin_ctzll(rowsWithRecords)) : 0u;
+        rowsWithRecords &= rowsWithRecords - 1ull;           // (0 stays 0)
+        slot.row = any ? r : 64u;
+        uint32_t firstA, storedA, firstB, storedB;
+        countsOf(r, 0u, slot.nA, firstA, storedA);
+        countsOf(r, 1u, slot.nB, firstB, storedB);
+        slot.nA = any ? slot.nA : 0u;
+        slot.nB = any ? slot.nB : 0u;
+        const WalkRecord* logA = walkLogOf(waveLog, logCapacity, r & 31u, r >> 5);
+        const WalkRecord* logB = walkLogOf(waveLog, logCapacity, (r & 31u) + 32u, r >> 5);
+        // (every lane loads, lanes without a record the log's first place: a load under a condition is a value that must be
+        // merged with its alternative right behind it, i.e. waited for at once -- and the point is to wait four rows later)
+        issueRecordLoads(ringSlotLds, logA, lane < slot.nA ? physical(lane, firstA, storedA) : 0u, logB,
+                         63u - lane < slot.nB ? physical(63u - lane, firstB, storedB) : 0u);
+    };
+    auto rowState = [&](uint32_t r, uint32_t& countOfRow, int32_t& mMaxOfRow) {
+        countOfRow = uint32_t(__builtin_amdgcn_readlane(int(count), int(r)));
+        mMaxOfRow = __builtin_amdgcn_readlane(mMax, int(r));
+    };
+    auto keepRowState = [&](uint32_t r, uint32_t countOfRow, int32_t mMaxOfRow) {
+        if (lane == r) {
+            count = countOfRow;
+            mMax = mMaxOfRow;
+        }
+    };
+    auto process = [&](const ReplayRowLoads& slot, uint32_t ringSlotLds) {
+        const uint32_t r = slot.row;
+        const WalkRecordWords a0 = ldsPointer<LdsRecordPtr>(ringSlotLds)[lane], b0 = ldsPointer<LdsRecordPtr>(ringSlotLds + kReplayRingSecondLog)[lane];
+        MergeElement e[2];
+        e[0] = mergeElementOf(lane < slot.nA, walkRecordOf(a0), 0u, bits);
+        e[1] = mergeElementOf(63u - lane < slot.nB, walkRecordOf(b0), 1u, bits);
+        bitonicMergeWave<2>(e);
+        uint32_t countOfRow;
+        int32_t mMaxOfRow;
+        rowState(r, countOfRow, mMaxOfRow);
+        replayRowElements<IDENTITY, 2>(e, slot.nA + slot.nB, lane, rowOfWave + r, emitColumns && ((validRows >> r) & 1ull) != 0ull,
+                                       listOfWave + size_t(r) * twoK, args, countOfRow, mMaxOfRow, emitPos, emitEnd, ldsRaw, timed);
+        keepRowState(r, countOfRow, mMaxOfRow);
+        if (timed) timed[4] += 1u;
+    };
     {
-        const uint32_t stored = a ? theirs1 : theirs0, first = a ? theirsFirst1 : theirsFirst0;
-        upper.start(walkLogOf(waveLog, logCapacity, t + 32u, a), all ? stored : stored - first, first, stored);
+        // four rows in flight: a row's two transfers have the six of the three rows behind it younger than themselves at its turn
+        const uint32_t wave = uniform(threadIdx.x >> 6);
+        const uint32_t ring0 = replayRingSlot(tilesLds, wave, 0u), ring1 = replayRingSlot(tilesLds, wave, 1u);
+        const uint32_t ring2 = replayRingSlot(tilesLds, wave, 2u), ring3 = replayRingSlot(tilesLds, wave, 3u);
+        ReplayRowLoads s0, s1, s2, s3;
+        issue(s0, ring0);
+        issue(s1, ring1);
+        issue(s2, ring2);
+        issue(s3, ring3);
+        for (;;) {
+            awaitRecordLoads<6>();
+            if (s0.row >= 64u) break;
+            process(s0, ring0);
+            issue(s0, ring0);
+            awaitRecordLoads<6>();
+            if (s1.row >= 64u) break;
+            process(s1, ring1);
+            issue(s1, ring1);
+            awaitRecordLoads<6>();
+            if (s2.row >= 64u) break;
+            process(s2, ring2);
+            issue(s2, ring2);
+            awaitRecordLoads<6>();
+            if (s3.row >= 64u) break;
+            process(s3, ring3);
+            issue(s3, ring3);
+        }
+        awaitRecordLoads<0>();          // (the transfers that were issued for nobody: the tile buffers go back to the walk)
     }
-    const int32_t* snap = kernelArgs()->snap;
-    for (;;) {
-        const bool have0 = lower.have(), have1 = upper.have();
-        const bool active = have0 || have1;
-        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
-        const WalkRecord r0 = lower.front(), r1 = upper.front();
-        const uint32_t col0 = have0 ? walkRecordColumn(r0.code, 0u) : 0xffffffffu;
-        const uint32_t col1 = have1 ? walkRecordColumn(r1.code, 1u) : 0xffffffffu;
-        const bool take0 = col0 < col1;                   // (the halves never hold the same column)
-        const uint32_t col = take0 ? col0 : col1;
-        const float dot = take0 ? r0.dot : r1.dot;
-        const uint32_t m = uint32_t(((WIDE ? 2.f : 1.f) * kMatrixBits - dot) * 0.5f);
-        if (active) {
-            if (take0) lower.pop();
-            else upper.pop();
-        }
-        const bool passRow = active && int32_t(m) <= mMax;
-        if (__builtin_amdgcn_ballot_w64(passRow) != 0ull) {
-            acceptColumn<IDENTITY>(passRow, col, row, m, lane, listBlock, myList, twoK, count, mMax, ldsRaw);
-        }
-        if (emitColumns) {
-            const bool passColumn = active && rowValid && int32_t(m) <= __hip_atomic_load(snap + (active ? col : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            emitColumn(passColumn, col, row, m, lane, emitPos, emitEnd);
-        }
+    const uint64_t tr1 = timed ? __builtin_readcyclecounter() : 0ull;
+    if (timed) timed[5] += tr1 - tr0;
+    // ---- rows with a log of more than 64 records: two records per lane and log ----
+    while (rowsWithLongLogs != 0ull) {
+        if (timed) timed[6] += 1u;
+        const uint32_t r = uint32_t(__builtin_ctzll(rowsWithLongLogs));
+        rowsWithLongLogs &= rowsWithLongLogs - 1ull;
+        uint32_t nA, firstA, storedA, nB, firstB, storedB;
+        countsOf(r, 0u, nA, firstA, storedA);
+        countsOf(r, 1u, nB, firstB, storedB);
+        const WalkRecord* logA = walkLogOf(waveLog, logCapacity, r & 31u, r >> 5);
+        const WalkRecord* logB = walkLogOf(waveLog, logCapacity, (r & 31u) + 32u, r >> 5);
+        const WalkRecord a0 = loadWalkRecord(logA, lane < nA ? physical(lane, firstA, storedA) : 0u);
+        const WalkRecord a1 = loadWalkRecord(logA, 64u + lane < nA ? physical(64u + lane, firstA, storedA) : 0u);
+        const WalkRecord b0 = loadWalkRecord(logB, 63u - lane < nB ? physical(63u - lane, firstB, storedB) : 0u);
+        const WalkRecord b1 = loadWalkRecord(logB, 127u - lane < nB ? physical(127u - lane, firstB, storedB) : 0u);
+        // the sequence: the first log's 128 places ascending, then the second log's 128 places descending
+        MergeElement e[4];
+        e[0] = mergeElementOf(lane < nA, a0, 0u, bits);
+        e[1] = mergeElementOf(64u + lane < nA, a1, 0u, bits);
+        e[2] = mergeElementOf(127u - lane < nB, b1, 1u, bits);
+        e[3] = mergeElementOf(63u - lane < nB, b0, 1u, bits);
+        bitonicMergeWave<4>(e);
+        uint32_t countOfRow;
+        int32_t mMaxOfRow;
+        rowState(r, countOfRow, mMaxOfRow);
+        replayRowElements<IDENTITY, 4>(e, nA + nB, lane, rowOfWave + r, emitColumns && ((validRows >> r) & 1ull) != 0ull,
+                                       listOfWave + size_t(r) * twoK, args, countOfRow, mMaxOfRow, emitPos, emitEnd, ldsRaw, timed);
+        keepRowState(r, countOfRow, mMaxOfRow);
     }
+    if (timed) timed[7] += __builtin_readcyclecounter() - tr1;
 }
 
 // The tile kernel of the sharded scan defers both sides: every lane empties its own two logs, order is irrelevant (the
 // inbox is sorted).  rowBase = cell id of the wave's row 0.
 template <bool WIDE = false>
-__device__ __forceinline__ void drainWalkLogs(const Entry* waveLog, uint32_t logCapacity, const uint32_t (&recordCount)[2], uint32_t lane,
+__device__ __forceinline__ void drainWalkLogs(const WalkRecord* waveLog, uint32_t logCapacity, const uint32_t (&recordCount)[2], uint32_t lane,
                                               uint32_t rowBase, uint32_t cellCount, uint32_t& emitPos, uint32_t& emitEnd)
 {
     const int32_t* snap = kernelArgs()->snap;
+    if (__builtin_amdgcn_ballot_w64((recordCount[0] | recordCount[1]) != 0u) == 0ull) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (plain loads of what this lane stored through the L2)
 #pragma unroll
     for (uint32_t a = 0; a < 2u; a++) {
-        const Entry* log = walkLogOf(waveLog, logCapacity, lane, a);
+        const WalkRecord* log = walkLogOf(waveLog, logCapacity, lane, a);
         const uint32_t rowId = rowBase + 32u * a + (lane & 31u);
         const int32_t snapOfRow = rowId < cellCount ? snap[rowId] : -1;
         for (uint32_t i = 0;; ++i) {
             const bool active = i < recordCount[a];
             if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
-            WalkRecord r;
-            r.code = 0u;
-            r.dot = 0.f;
+            WalkRecord r = WalkRecord();
             if (active) r = loadWalkRecord(log, i);
             const uint32_t col = walkRecordColumn(r.code, lane >> 5);
             const uint32_t m = uint32_t(((WIDE ? 2.f : 1.f) * kMatrixBits - r.dot) * 0.5f);
             const bool valid = active && rowId < cellCount;
-            const int32_t snapCol = valid ? snap[col] : -1;
-            emitColumn(valid && int32_t(m) <= snapCol, col, rowId, m, lane, emitPos, emitEnd);        // target col
+            emitColumn(valid && r.dot >= r.bound, col, rowId, m, lane, emitPos, emitEnd);             // target col
             emitColumn(valid && int32_t(m) <= snapOfRow, rowId, col, m, lane, emitPos, emitEnd);      // target row
         }
     }

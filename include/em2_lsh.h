@@ -147,7 +147,9 @@ int em2_dev_compute_signatures(const uint64_t* d_toc, const em2_count* d_data, u
                                size_t workspaceBytes, void* stream);
 
 /* Which FIRST tier the last em2_dev_compute_signatures call on this workspace ran (the result does not depend on it; the time
- * does -- DESIGN.md 3.2).  The call waits for the device.  haveVectorAux: whether that call was given d_vectorAux.
+ * does -- DESIGN.md 3.2).  The call waits for the whole device (hipDeviceSynchronize: it has no stream argument), and the
+ * workspace must be untouched since that call -- the tier is read from a word the projection leaves in it.  haveVectorAux:
+ * whether that call was given d_vectorAux.
  *   EM2_TIER_EXACT           the reference's arithmetic on every bit (no auxiliary block, or lshCount no multiple of 4)
  *   EM2_TIER_FLOAT           the float copy of the hyperplanes under its error bound (lshCount no multiple of 64)
  *   EM2_TIER_FIXED16_FLOAT   the 16-bit fixed-point copy, products summed in floating point (some count is no small integer)
@@ -193,6 +195,7 @@ int em2_dev_find_similar_pairs4_form_for(uint32_t cellCount, uint32_t rowCount, 
  * symmetric scan: FP4 +-1 contraction, signatures zero-extended to 1024 or 2048 bits), [8] the shader clock in GHz that
  * kernel ran at (sums over its blocks of s_memtime and s_memrealtime ticks; 0 when unknown). */
 int em2_dev_find_similar_pairs4_last_launch(double* values, uint32_t valueCount);
+
 
 /* findSimilarPairs4 for the rows [rowBegin,rowEnd) of the cell set against all cellCount cells: the shard
  * one rank owns.  d_signatures holds ALL cellCount signatures (after the all-gather).  d_pairs has

@@ -453,14 +453,16 @@ def test_matrix_form_inbox_overflow_falls_back(oracle, scan_knobs):
 
 # ---- the rows form on the matrix cores: rows [rowBegin, rowEnd) x all columns (a rank's shard; the overflow fallback) ----
 
-def run_row_shard(sig, L, k, thr, begin, end):
-    """em2_dev_find_similar_pairs4 for rows [begin, end): (cell, similarity bits, used) as numpy arrays."""
+def run_row_shard(sig, L, k, thr, begin, end, poison=None):
+    """em2_dev_find_similar_pairs4 for rows [begin, end): (cell, similarity bits, used) as numpy arrays.  poison: the byte the
+    workspace is filled with before the call (what a caller's recycled memory may hold)."""
     import torch
     n = sig.shape[0]
     rows = end - begin
     d_sig = torch.from_numpy(sig.view(np.int64)).cuda()
     ws_bytes = capi.dev_find_similar_pairs4_workspace(n, rows, L, k)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda") if poison is None else \
+        torch.full((ws_bytes,), poison, dtype=torch.uint8, device="cuda")
     d_pairs = torch.empty((rows, k, 2), dtype=torch.int32, device="cuda")
     d_used = torch.empty(rows, dtype=torch.int32, device="cuda")
     capi.dev_find_similar_pairs4(d_sig.data_ptr(), n, begin, end, L, k, thr, d_pairs.data_ptr(), d_used.data_ptr(), ws.data_ptr(),
@@ -497,6 +499,25 @@ def test_rows_form_on_the_matrix_cores(oracle, scan_knobs, n, L, k, thr, kind, k
         assert np.array_equal(gused, used), (begin, end)
         assert np.array_equal(gcell, cell), (begin, end)
         assert np.array_equal(gsim, sim.view(np.uint32)), (begin, end)
+
+
+@pytest.mark.parametrize("n,L", [(3000, 1024), (2977, 1024), (2500, 2048), (3040, 600)])
+def test_rows_form_shard_at_32_mod_64_that_ends_with_the_cells(oracle, scan_knobs, n, L):
+    """a shard that begins at 32 (mod 64) and ends with the cells has a last 64-row block that reaches past the
+    columns' fragment array; its fragments must not be addressed in place there.  The workspace is poisoned (0x77: FP4
+    magnitudes above 1 in every nibble), so that a read past the array shows."""
+    k, thr = 20, 0.2
+    sig = make(n, L, "clustered")
+    scan_knobs(EM2_SCAN_MODE="rows", EM2_MIN_SEGMENT_COLUMNS=512)
+    for begin in (32, 1056, (n // 64) * 64 - 32, (n // 64) * 64 - 96):
+        for end in (n, n - 1):
+            cell, sim, used = oracle.find_similar_pairs4_rows(sig, L, k, thr, begin, end)
+            for poison in (0x77, 0xff, 0x00):
+                gcell, gsim, gused = run_row_shard(sig, L, k, thr, begin, end, poison=poison)
+                assert capi.dev_find_similar_pairs4_last_launch()["form"] == 4
+                assert np.array_equal(gused, used), (begin, end, poison)
+                assert np.array_equal(gcell, cell), (begin, end, poison)
+                assert np.array_equal(gsim, sim.view(np.uint32)), (begin, end, poison)
 
 
 @pytest.mark.parametrize("n,L,k,thr,kind", CASES)

@@ -124,27 +124,20 @@ def tests_of(s, o, q, j, k, prev0, prev1):
     s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass1_%d" % (k & 1)], vreg(THR1), vreg(prev1 + k)))
 
 
-def shift_in(s, o, k, carried=None):
-    """Scalar half: a register whose test passed in some lane goes through its stub (out of line, behind the body).
-    carried (EM2_GEN_STUB=mfma): the matrix instruction that follows the two checks in the body.  A stub then begins with a
-    copy of it and comes back BEHIND it: the instruction enters the pipe as soon as the stub's first instruction has been
-    fetched, and the record, the stores and the branch back run in its shadow instead of in front of it."""
+def shift_in(s, o, k):
+    """Scalar half: a register whose test passed in some lane goes through its stub (out of line, behind the body)."""
     if CMPX:
         return
     for a in range(2):
         s.emit("s_cmp_lg_u64 %s, 0" % o["pass%d_%d" % (a, k & 1)])
         s.emit("s_cbranch_scc1 L_stub_%d_%d_%%=" % (k, a))
-        if not carried:
-            s.emit("L_back_%d_%d_%%=:" % (k, a))
-        s.stubs.append((k, a, carried))
-    if carried:
-        s.emit(carried)
-        s.emit("L_back_%d_0_%%=:" % k)
+        s.emit("L_back_%d_%d_%%=:" % (k, a))
+        s.stubs.append((k, a))
 
 
 def stubs(s, o, prev0, prev1):
-    """The lanes in which register k of accumulator a passed append one record to their log in global memory:
-    {tile's first column | 2k + a, dot as it stands in the accumulator}."""
+    """The lanes in which register k of accumulator a passed append one record to their log in global memory
+    (record_and_store)."""
     if CMPX:
         s.emit("v_mov_b32 %s, %s" % (o["count"], vreg(OFFSET)))
         s.emit("v_mov_b32 %s, %s" % (o["count1"], vreg(OFFSET + 1)))
@@ -156,95 +149,19 @@ def stubs(s, o, prev0, prev1):
         if STUB == "empty":          # (measurement only: what the two branches of an event cost by themselves)
             return
         mask = o["pass%d_%d" % (a, k & 1)]
-        if STUB in ("addfirst", "store4", "dsw", "storeonly"):
-            s.emit("v_or_b32_e64 %s, %s, %d" % (vreg(RECORD), o["tileCode"], 2 * k + a))
-            s.emit("v_mov_b32 %s, %s" % (vreg(RECORD + 1), vreg(acc)))
-            s.emit("s_and_saveexec_b64 %s, %s" % (o["save"], mask))
-            if STUB == "storeonly":        # (measurement: the store without the count)
-                s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET + a), vreg(RECORD, 2), o["logBase"]))
-            else:
-                s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET + a), vreg(OFFSET + a)))
-                if STUB == "addfirst":
-                    s.emit("global_store_dwordx2 %s, %s, %s offset:-8" % (vreg(OFFSET + a), vreg(RECORD, 2), o["logBase"]))
-                elif STUB == "store4":
-                    s.emit("global_store_dword %s, %s, %s offset:-8" % (vreg(OFFSET + a), vreg(RECORD + 1), o["logBase"]))
-                else:                      # (measurement: an LDS write of the same size instead; the address is the tile pointer)
-                    # (the ubench's LDS: 64 KB of tiles, 3 KB of walk blocks, then -- with -DUBENCH_EXTRA_LDS -- a spare 4 KB)
-                    s.emit("v_mbcnt_lo_u32_b32 %s, -1, 0" % vreg(THR0))
-                    s.emit("v_mbcnt_hi_u32_b32 %s, -1, %s" % (vreg(THR0), vreg(THR0)))
-                    s.emit("v_lshlrev_b32 %s, 3, %s" % (vreg(THR0), vreg(THR0)))
-                    s.emit("v_add_u32 %s, 0x%x, %s" % (vreg(THR0), 65536 + 4 * 768, vreg(THR0)))
-                    s.emit("ds_write_b64 %s, %s" % (vreg(THR0), vreg(RECORD, 2)))
-            s.emit("s_mov_b64 exec, %s" % o["save"])
-            return
-        if STUB in ("early", "nostore", "valuonly", "addc"):
-            # the record is formed under the full EXEC (its registers are scratch), only the store and the count are masked
-            s.emit("v_or_b32_e64 %s, %s, %d" % (vreg(RECORD), o["tileCode"], 2 * k + a))
-            s.emit("v_mov_b32 %s, %s" % (vreg(RECORD + 1), vreg(acc)))
-            if STUB == "valuonly":       # (measurement: three vector instructions, no EXEC change, no store)
-                s.emit("v_add_u32 %s, 0, %s" % (vreg(OFFSET + a), vreg(OFFSET + a)))
-                return
-            if STUB == "addc":
-                # the count without EXEC: + 8 where the mask is set (two instructions, no hazard); only the store is masked
-                s.emit("v_cndmask_b32_e64 %s, 0, 8, %s" % (vreg(THR0), mask))
-                s.emit("s_and_saveexec_b64 %s, %s" % (o["save"], mask))
-                s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET + a), vreg(RECORD, 2), o["logBase"]))
-                s.emit("s_mov_b64 exec, %s" % o["save"])
-                s.emit("v_add_u32 %s, %s, %s" % (vreg(OFFSET + a), vreg(THR0), vreg(OFFSET + a)))
-                return
-            s.emit("s_and_saveexec_b64 %s, %s" % (o["save"], mask))
-            if STUB != "nostore":
-                s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET + a), vreg(RECORD, 2), o["logBase"]))
-            s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET + a), vreg(OFFSET + a)))
-            s.emit("s_mov_b64 exec, %s" % o["save"])
-            return
-        if STUB == "pend":
-            # (experiment, DESIGN.md 8: ONE pending record per lane, stored by a flush at the end of the step; an event in a
-            # lane whose record is still pending stores that one first.  One log per lane: v28 alone counts.)
-            s.emit("s_and_saveexec_b64 %s, %s" % (o["save"], mask))
-            s.emit("v_cmp_ne_u32_e32 vcc, 0, %s" % vreg(RECORD))
-            s.emit("s_cbranch_vccz L_free_%d_%d_%%=" % (k, a))
-            s.emit("s_mov_b64 exec, vcc")
-            s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET), vreg(RECORD, 2), o["logBase"]))
-            s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET), vreg(OFFSET)))
-            s.emit("s_mov_b64 exec, %s" % mask)
-            s.emit("L_free_%d_%d_%%=:" % (k, a))
-            s.emit("v_or_b32_e64 %s, %s, %d" % (vreg(RECORD), o["tileCode"], 2 * k + a))     # (the caller's tile code has bit 31 set: "pending")
-            s.emit("v_mov_b32 %s, %s" % (vreg(RECORD + 1), vreg(acc)))
-            s.emit("s_mov_b64 exec, %s" % o["save"])
-            return
-        if STUB in ("saveexec", "mfma"):
+        if STUB == "saveexec":
             s.emit("s_and_saveexec_b64 %s, %s" % (o["save"], mask))
         else:
             s.emit("s_mov_b64 %s, exec" % o["save"])
             s.emit("s_mov_b64 exec, %s" % mask)
-        s.emit("v_or_b32_e64 %s, %s, %d" % (vreg(RECORD), o["tileCode"], 2 * k + a))
-        s.emit("v_mov_b32 %s, %s" % (vreg(RECORD + 1), vreg(acc)))
-        s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET + a), vreg(RECORD, 2), o["logBase"]))
-        s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET + a), vreg(OFFSET + a)))
+        record_and_store(s, o, k, a, acc)
         s.emit("s_mov_b64 exec, %s" % o["save"])
 
-    for k, a, carried in s.stubs:
+    for k, a in s.stubs:
         s.emit("L_stub_%d_%d_%%=:" % (k, a))
-        if carried:
-            s.emit(carried)
         record(k, a)
-        if carried and a == 0:
-            # the other accumulator's check, which the body would have made next
-            s.emit("s_cmp_lg_u64 %s, 0" % o["pass1_%d" % (k & 1)])
-            s.emit("s_cbranch_scc0 L_back_%d_0_%%=" % k)
-            record(k, 1)
-        s.emit("s_branch L_back_%d_%d_%%=" % (k, 0 if carried else a))
+        s.emit("s_branch L_back_%d_%d_%%=" % (k, a))
     s.emit("L_end_%=:")
-    if STUB == "pend":
-        s.emit("v_cmp_ne_u32_e32 vcc, 0, %s" % vreg(RECORD))
-        s.emit("s_cbranch_vccz L_flushed_%=")
-        s.emit("s_and_saveexec_b64 %s, vcc" % o["save"])
-        s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET), vreg(RECORD, 2), o["logBase"]))
-        s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET), vreg(OFFSET)))
-        s.emit("v_mov_b32 %s, 0" % vreg(RECORD))
-        s.emit("s_mov_b64 exec, %s" % o["save"])
-        s.emit("L_flushed_%=:")
     s.emit("v_mov_b32 %s, %s" % (o["count"], vreg(OFFSET)))
     s.emit("v_mov_b32 %s, %s" % (o["count1"], vreg(OFFSET + 1)))
 
@@ -315,18 +232,43 @@ CMPX = os.environ.get("EM2_GEN_CMPX", "0") == "1"
 # accumulator as their C operand.  Timing only: the terms are the bounds' registers here.
 BIAS = os.environ.get("EM2_GEN_BIAS", "0") == "1"
 # EM2_GEN_STUB: the form of the stubs.  "branches" = round 2's (two s_mov around the record); "saveexec" = s_and_saveexec_b64
-# instead of the first two; "mfma" = that, and the checks of a k-step sit directly in front of its second matrix instruction, of
-# which every stub carries a copy (shift_in); "empty" = no record at all (measurement: the branches alone).
+# instead of the first two; "empty" = no record at all (measurement: the branches alone).  The other forms round 5 measured
+# (profiles/r05_scan_experiments.md: the store first / last / narrower / to LDS, one pending record per lane, the k-step's second
+# matrix instruction issued from inside the stub) are in the git history: none of them moved the product.
 STUB = os.environ.get("EM2_GEN_STUB", "branches")
 
 
-def masked_record(s, o, k, a, thr, acc, first):
-    """The branch-free test of register k of accumulator a: EXEC = the lanes that pass, their record stored, EXEC restored."""
-    s.emit("v_cmpx_le_f32_e32 vcc, %s, %s" % (vreg(thr), vreg(acc + k)))
+def column_bound_register(k):
+    """The register that holds the column bound register k of an accumulator was tested against: the buffers of four bounds
+    alternate with the groups of four registers, and the buffer of group q is refilled (for group q + 2) only behind the stubs of
+    its last register."""
+    q, j = k >> 2, k & 3
+    return BOUNDS if TILE_BOUND else BOUNDS + 4 * (q & 1) + j
+
+
+RECORD_BYTES = 16
+
+
+def record_and_store(s, o, k, a, acc):
+    """The record of register k of accumulator a, in the lanes of EXEC: {tile's first column | 2k + a, dot as it stands in the
+    accumulator, the column bound it was tested against} -- 12 bytes, 16 apart -- appended to the lane's log.  The third word
+    is what lets the replay decide the column side of the pair without a load of its own per record (the column's published
+    cut-off as the walk staged it, two pairs of tiles old at most).  v32 (the other threshold of the tests, THR1) is scratch
+    inside a stub: the v_min that writes it for the next register comes behind the stubs of this one."""
     s.emit("v_or_b32_e64 %s, %s, %d" % (vreg(RECORD), o["tileCode"], 2 * k + a))
-    s.emit("v_mov_b32 %s, %s" % (vreg(RECORD + 1), vreg(acc + k)))
-    s.emit("global_store_dwordx2 %s, %s, %s" % (vreg(OFFSET + a), vreg(RECORD, 2), o["logBase"]))
-    s.emit("v_add_u32 %s, 8, %s" % (vreg(OFFSET + a), vreg(OFFSET + a)))
+    s.emit("v_mov_b32 %s, %s" % (vreg(RECORD + 1), vreg(acc)))
+    s.emit("v_mov_b32 %s, %s" % (vreg(RECORD + 2), vreg(column_bound_register(k))))
+    s.emit("global_store_dwordx3 %s, %s, %s" % (vreg(OFFSET + a), vreg(RECORD, 3), o["logBase"]))
+    s.emit("v_add_u32 %s, %d, %s" % (vreg(OFFSET + a), RECORD_BYTES, vreg(OFFSET + a)))
+
+
+def masked_record(s, o, k, a, thr, acc, first):
+    """The branch-free test of register k of accumulator a: EXEC = the lanes that pass, their record stored, EXEC restored.
+    (The record's third word takes v32, which is THR1: accumulator 1's threshold is re-formed behind accumulator 0's record.)"""
+    if a == 1:
+        s.emit("v_min_f32 %s, %s, %s" % (vreg(thr), vreg(ROW_BOUND1), vreg(column_bound_register(k))))
+    s.emit("v_cmpx_le_f32_e32 vcc, %s, %s" % (vreg(thr), vreg(acc + k)))
+    record_and_store(s, o, k, a, acc + k)
     s.emit("s_mov_b64 exec, %s" % o["save"])
 
 
@@ -354,12 +296,9 @@ def step(cur, prev, tests, operands):
             # a v_mfma_ld_scale_b32 in front of this one -- 16 bytes instead of 8 and an issue slot more per MFMA)
             mfma = ("v_mfma_f32_32x32x64_f8f6f4 %s, %s, %s, %s cbsz:4 blgp:4"
                     % (vreg(acc, 16), vreg(slot, 4), vreg(rows + 4 * k, 4), "0" if (k == 0 and not BIAS) else vreg(acc, 16)))
-            if a == 1 and tests and STUB == "mfma" and k:
-                shift_in(s, o, k - 1, carried=mfma)        # (emits the instruction itself behind the two checks)
-            else:
-                s.emit(mfma)
+            s.emit(mfma)
             if a == 0 and tests:
-                place(s, o, k, PLACE[0].replace("S", "") if STUB == "mfma" else PLACE[0], prev0, prev1, slot, carry_out)
+                place(s, o, k, PLACE[0], prev0, prev1, slot, carry_out)
         if tests:
             place(s, o, k, PLACE[1], prev0, prev1, slot, carry_out)
         else:
@@ -429,7 +368,7 @@ def wide_shift_in(s, o, i):
     s.emit("s_cmp_lg_u64 %s, 0" % o["pass0_%d" % (i & 1)])
     s.emit("s_cbranch_scc1 L_stub_%d_0_%%=" % i)
     s.emit("L_back_%d_0_%%=:" % i)
-    s.stubs.append((i, 0, None))
+    s.stubs.append((i, 0))
 
 
 def wide_min(s, i):
@@ -543,8 +482,8 @@ def main():
     out.write("#define EM2_MATRIX_OWNED_REGISTERS %s\n\n" % owned)
     out.write("#define EM2_MATRIX_STEP_CLOBBERS \"memory\", \"vcc\", \"scc\", EM2_MATRIX_OWNED_REGISTERS\n\n")
     # the lane's record offset lives in a register of the walk from step to step
-    out.write("#define EM2_MATRIX_SET_RECORD_OFFSETS \"v_mov_b32 v%d, %%0\\nv_mov_b32 v%d, %%1\\n%s\"\n\n"
-              % (OFFSET, OFFSET + 1, "v_mov_b32 v%d, 0\\n" % RECORD if STUB == "pend" else ""))
+    out.write("#define EM2_MATRIX_SET_RECORD_OFFSETS \"v_mov_b32 v%d, %%0\\nv_mov_b32 v%d, %%1\\n\"\n\n" % (OFFSET, OFFSET + 1))
+    out.write("#define EM2_MATRIX_RECORD_BYTES %du\n\n" % RECORD_BYTES)
     # the B operand in one go: 32 loads straight into the registers, one wait.  %0 = address of the wave's first row
     # fragment (scalar pair); the fragments of a 32-row block are 1 KB apart (64 lanes x 16 bytes), the second block
     # follows the first
