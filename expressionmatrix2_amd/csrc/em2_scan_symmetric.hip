@@ -520,7 +520,7 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                 const bool all = !(lower && stopped);
                 if (!idle && !failed) {
                     replayWalkLogs<IDENTITY, WIDE>(waveLog, logCapacity, recordCount, firstRecord, all, lane, row, rowValid, !fullRows,
-                                                   listBlock, myList, twoK, count, mMax, emitPos, emitEnd, ldsRaw, ldsAddress(tiles), TIMED ? replayTimed : nullptr);
+                                                   listBlock, myList, twoK, count, mMax, emitPos, emitEnd, ldsRaw, ldsAddress(tiles), colBegin, TIMED ? replayTimed : nullptr);
                 }
                 recordCount[0] = all ? 0u : firstRecord[0];
                 recordCount[1] = all ? 0u : firstRecord[1];
@@ -1001,6 +1001,10 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
         if (segmentsMatrix < 1) segmentsMatrix = 1;
         cpsMatrix = uint32_t((uint64_t(cellCount) + segmentsMatrix - 1u) / segmentsMatrix);
         cpsMatrix = (cpsMatrix + 255u) & ~255u;
+        if (cpsMatrix > kMaxColumnsPerItem) {           // (the replay's merge keys hold a column relative to its item's first in 19 bits)
+            segmentsMatrix = (uint64_t(cellCount) + kMaxColumnsPerItem - 1u) / kMaxColumnsPerItem;
+            cpsMatrix = (uint32_t((uint64_t(cellCount) + segmentsMatrix - 1u) / segmentsMatrix) + 255u) & ~255u;
+        }
         segmentsMatrix = (uint64_t(cellCount) + cpsMatrix - 1u) / cpsMatrix;
         for (uint32_t sIdx = 0; sIdx < segmentsMatrix; ++sIdx) {
             uint32_t firstQuad = uint32_t((uint64_t(sIdx) * cpsMatrix) / 64u);      // a multiple of 4
@@ -1175,10 +1179,10 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
             unsigned long long split[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (envNumber("EM2_MATRIX_CONVOY", 1) == 0 && hipMemcpy(split, ws + layout.control + 160u, sizeof(split), hipMemcpyDeviceToHost) == hipSuccess) {
                 const double t = total > 0 ? total : 1;
-                fprintf(stderr, "[em2] matrix kernel, replay (%% of the waves' cycles): selections %llu: drain %.2f, cut %.2f, table + fence %.2f; "
-                                "%llu short rows %.2f (with their selections), %llu long rows %.2f\n", split[3], 100.0 * double(split[0]) / t,
-                        100.0 * double(split[1]) / t, 100.0 * double(split[2]) / t, split[4], 100.0 * double(split[5]) / t, split[6],
-                        100.0 * double(split[7]) / t);
+                fprintf(stderr, "[em2] matrix kernel, replay (%% of the waves' cycles): %llu pair turns: await %.2f, read + merge %.2f, rows %.2f, emit %.2f, "
+                                "issue %.2f; all short rows %.2f; %llu rows of their own, %llu long rows\n", split[3], 100.0 * double(split[0]) / t,
+                        100.0 * double(split[1]) / t, 100.0 * double(split[2]) / t, 100.0 * double(split[6]) / t, 100.0 * double(split[7]) / t,
+                        100.0 * double(split[5]) / t, split[4], 0ull);
             }
         }
     }
@@ -1312,6 +1316,10 @@ hipError_t launchFsp4ScanRowsMatrix(Fsp4Args args, uint32_t paddedDw, bool ident
     if (segments < 1) segments = 1;
     uint32_t cps = uint32_t((uint64_t(cellCount) + segments - 1u) / segments);
     cps = (cps + 255u) & ~255u;
+    if (cps > kMaxColumnsPerItem) {             // (the replay's merge keys hold a column relative to its item's first in 19 bits)
+        segments = (uint64_t(cellCount) + kMaxColumnsPerItem - 1u) / kMaxColumnsPerItem;
+        cps = (uint32_t((uint64_t(cellCount) + segments - 1u) / segments) + 255u) & ~255u;
+    }
     segments = (uint64_t(cellCount) + cps - 1u) / cps;
     const uint64_t tickets = segments * quads;
     if (tickets >= 0xffffffffull) return hipErrorInvalidValue;

@@ -900,26 +900,26 @@ __device__ __forceinline__ const WalkRecord* walkLogOf(const WalkRecord* waveLog
     return waveLog + size_t(lane) * logCapacity + a * (logCapacity / 2u);
 }
 
-// An element of the replay's merge: a record as (column, mismatches | the column side's test in bit 31).
-struct MergeElement {
-    uint32_t col, payload;
-};
-__device__ __forceinline__ MergeElement mergeElementOf(bool have, const WalkRecord& r, uint32_t half, float bits)
+// An element of the replay's merge: a record as ONE word that sorts by the column -- (column - the item's first column) << 13
+// | the column side's test << 12 | mismatches (at most 2048).  The columns of an item lie within 2^19 of its first one (the
+// launchers keep a segment that short), the columns of a row's records are all different, so comparing the words compares the
+// columns; 0xffffffff stands behind every record.  One word instead of (column, payload): a vector instruction of the replay
+// waits for a gap between the matrix instructions of the wave it shares its SIMD with -- some 30 cycles each, measured -- so
+// the replay's time is its count of vector instructions, and the merge network is most of them.
+constexpr uint32_t kMergeColumnShift = 13u, kMergePassBit = 0x1000u, kMergeMismatchMask = 0xfffu;
+constexpr uint32_t kMaxColumnsPerItem = 1u << 19;
+__device__ __forceinline__ uint32_t mergeKeyOf(bool have, const WalkRecord& r, uint32_t half, float bits, uint32_t firstColumn)
 {
-    MergeElement e;
-    e.col = have ? walkRecordColumn(r.code, half) : 0xffffffffu;           // (sentinels sort behind every record)
-    e.payload = have ? (uint32_t((bits - r.dot) * 0.5f) | (r.dot >= r.bound ? 0x80000000u : 0u)) : 0u;
-    return e;
+    const uint32_t relative = walkRecordColumn(r.code, half) - firstColumn;
+    const uint32_t m = uint32_t(__builtin_fmaf(r.dot, -0.5f, 0.5f * bits));
+    const uint32_t key = (relative << kMergeColumnShift) | m | (r.dot >= r.bound ? kMergePassBit : 0u);
+    return have ? key : 0xffffffffu;
 }
-// lo = the element with the smaller column (columns of records are all different)
-__device__ __forceinline__ void orderElements(MergeElement& lo, MergeElement& hi)
+__device__ __forceinline__ void orderKeys(uint32_t& lo, uint32_t& hi)
 {
-    const bool swap = hi.col < lo.col;
-    const MergeElement a = lo, b = hi;
-    lo.col = swap ? b.col : a.col;
-    lo.payload = swap ? b.payload : a.payload;
-    hi.col = swap ? a.col : b.col;
-    hi.payload = swap ? a.payload : b.payload;
+    const uint32_t a = lo, b = hi;
+    lo = a < b ? a : b;
+    hi = a < b ? b : a;
 }
 // The lanes whose bit STRIDE is clear (they keep the smaller element of a compare-exchange), as a mask
 template <uint32_t STRIDE> __device__ __forceinline__ constexpr uint64_t lowerLanesOf()
@@ -927,87 +927,75 @@ template <uint32_t STRIDE> __device__ __forceinline__ constexpr uint64_t lowerLa
     return STRIDE == 32u ? 0x00000000ffffffffull : STRIDE == 16u ? 0x0000ffff0000ffffull : STRIDE == 8u ? 0x00ff00ff00ff00ffull
          : STRIDE == 4u ? 0x0f0f0f0f0f0f0f0full : STRIDE == 2u ? 0x3333333333333333ull : 0x5555555555555555ull;
 }
-// The element of lane (lane ^ STRIDE), without the LDS: quad permutes for 1 and 2, a mirror of eight lanes followed by a
+// The key of lane (lane ^ STRIDE), without the LDS: quad permutes for 1 and 2, a mirror of eight lanes followed by a
 // reversal of four for 4 (7 - i, then ^ 3: i ^ 4), a rotation of sixteen lanes by eight for 8, and the gfx950 row / half swaps
 // for 16 and 32: with the same value as both operands v_permlane16_swap / v_permlane32_swap return the even rows' (the lower
 // half's) value in every lane of their first result and the odd rows' (the upper half's) in the second
-// (tools/probe/permlane_swap.hip).  ds_bpermute in their place made a merge a chain of twelve LDS round trips behind the matrix
+// (tools/probe/permlane_swap.hip).  ds_bpermute in their place made a merge a chain of LDS round trips behind the matrix
 // walk's fragment reads.
 template <uint32_t STRIDE>
-__device__ __forceinline__ MergeElement partnerElement(const MergeElement& e)
+__device__ __forceinline__ uint32_t partnerKey(uint32_t key)
 {
-    MergeElement p;
-    if (STRIDE == 1u) {
-        p.col = uint32_t(__builtin_amdgcn_update_dpp(0, int(e.col), 0xB1, 0xf, 0xf, false));          // quad_perm:[1,0,3,2]
-        p.payload = uint32_t(__builtin_amdgcn_update_dpp(0, int(e.payload), 0xB1, 0xf, 0xf, false));
-    } else if (STRIDE == 2u) {
-        p.col = uint32_t(__builtin_amdgcn_update_dpp(0, int(e.col), 0x4E, 0xf, 0xf, false));          // quad_perm:[2,3,0,1]
-        p.payload = uint32_t(__builtin_amdgcn_update_dpp(0, int(e.payload), 0x4E, 0xf, 0xf, false));
-    } else if (STRIDE == 4u) {
-        const int c = __builtin_amdgcn_update_dpp(0, int(e.col), 0x141, 0xf, 0xf, false);             // row_half_mirror
-        const int y = __builtin_amdgcn_update_dpp(0, int(e.payload), 0x141, 0xf, 0xf, false);
-        p.col = uint32_t(__builtin_amdgcn_update_dpp(0, c, 0x1B, 0xf, 0xf, false));                   // quad_perm:[3,2,1,0]
-        p.payload = uint32_t(__builtin_amdgcn_update_dpp(0, y, 0x1B, 0xf, 0xf, false));
-    } else if (STRIDE == 8u) {
-        p.col = uint32_t(__builtin_amdgcn_update_dpp(0, int(e.col), 0x128, 0xf, 0xf, false));         // row_ror:8
-        p.payload = uint32_t(__builtin_amdgcn_update_dpp(0, int(e.payload), 0x128, 0xf, 0xf, false));
-    } else {
-        const bool lower = __builtin_amdgcn_inverse_ballot_w64(lowerLanesOf<STRIDE>());
-        if (STRIDE == 16u) {
-            const auto c = __builtin_amdgcn_permlane16_swap(e.col, e.col, false, false);
-            const auto y = __builtin_amdgcn_permlane16_swap(e.payload, e.payload, false, false);
-            p.col = lower ? uint32_t(c[1]) : uint32_t(c[0]);
-            p.payload = lower ? uint32_t(y[1]) : uint32_t(y[0]);
-        } else {
-            const auto c = __builtin_amdgcn_permlane32_swap(e.col, e.col, false, false);
-            const auto y = __builtin_amdgcn_permlane32_swap(e.payload, e.payload, false, false);
-            p.col = lower ? uint32_t(c[1]) : uint32_t(c[0]);
-            p.payload = lower ? uint32_t(y[1]) : uint32_t(y[0]);
-        }
+    if (STRIDE == 1u) return uint32_t(__builtin_amdgcn_update_dpp(0, int(key), 0xB1, 0xf, 0xf, false));          // quad_perm:[1,0,3,2]
+    if (STRIDE == 2u) return uint32_t(__builtin_amdgcn_update_dpp(0, int(key), 0x4E, 0xf, 0xf, false));          // quad_perm:[2,3,0,1]
+    if (STRIDE == 4u) {
+        const int mirrored = __builtin_amdgcn_update_dpp(0, int(key), 0x141, 0xf, 0xf, false);                    // row_half_mirror
+        return uint32_t(__builtin_amdgcn_update_dpp(0, mirrored, 0x1B, 0xf, 0xf, false));                         // quad_perm:[3,2,1,0]
     }
-    return p;
+    if (STRIDE == 8u) return uint32_t(__builtin_amdgcn_update_dpp(0, int(key), 0x128, 0xf, 0xf, false));          // row_ror:8
+    const bool lower = __builtin_amdgcn_inverse_ballot_w64(lowerLanesOf<STRIDE>());
+    if (STRIDE == 16u) {
+        const auto both = __builtin_amdgcn_permlane16_swap(key, key, false, false);
+        return lower ? uint32_t(both[1]) : uint32_t(both[0]);
+    }
+    const auto both = __builtin_amdgcn_permlane32_swap(key, key, false, false);
+    return lower ? uint32_t(both[1]) : uint32_t(both[0]);
 }
-// One stage: the lanes whose bit STRIDE is clear keep the smaller column, the others the larger (columns of records are all
-// different; two sentinels may change places).  One compare, one scalar xor with the stage's lane mask, two selects.
+// One stage: the lanes whose bit STRIDE is clear keep the smaller key, the others the larger
 template <uint32_t STRIDE, int R>
-__device__ __forceinline__ void bitonicStage(MergeElement (&e)[R])
+__device__ __forceinline__ void bitonicStage(uint32_t (&key)[R])
 {
+    const bool lower = __builtin_amdgcn_inverse_ballot_w64(lowerLanesOf<STRIDE>());
 #pragma unroll
     for (int i = 0; i < R; i++) {
-        const MergeElement other = partnerElement<STRIDE>(e[i]);
-        const bool take = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64(other.col < e[i].col) ^ ~lowerLanesOf<STRIDE>());
-        e[i].col = take ? other.col : e[i].col;
-        e[i].payload = take ? other.payload : e[i].payload;
+        const uint32_t other = partnerKey<STRIDE>(key[i]);
+        const uint32_t smaller = other < key[i] ? other : key[i], larger = other < key[i] ? key[i] : other;
+        key[i] = lower ? smaller : larger;
     }
 }
-// The bitonic merge of 64 R elements -- element i of the sequence sits in e[i >> 6] of lane i & 63; the first half ascends, the
-// second descends -- into ascending order: log2(64 R) compare-exchange stages, those of 64 elements and more apart between the
+// Two bitonic merges at once, one per half of the wave: 32 keys each, one per lane
+__device__ __forceinline__ void bitonicMergeHalves(uint32_t& key)
+{
+    uint32_t one[1] = {key};
+    bitonicStage<16u, 1>(one);
+    bitonicStage<8u, 1>(one);
+    bitonicStage<4u, 1>(one);
+    bitonicStage<2u, 1>(one);
+    bitonicStage<1u, 1>(one);
+    key = one[0];
+}
+// The bitonic merge of 64 R keys -- key i of the sequence sits in key[i >> 6] of lane i & 63; the first half ascends, the
+// second descends -- into ascending order: log2(64 R) compare-exchange stages, those of 64 keys and more apart between the
 // registers of a lane, the others between lanes.
 template <int R>
-__device__ __forceinline__ void bitonicMergeWave(MergeElement (&e)[R])
+__device__ __forceinline__ void bitonicMergeWave(uint32_t (&key)[R])
 {
     if (R == 4) {
-        orderElements(e[0], e[2]);
-        orderElements(e[1], e[3]);
-        orderElements(e[0], e[1]);
-        orderElements(e[2], e[3]);
+        orderKeys(key[0], key[2]);
+        orderKeys(key[1], key[3]);
+        orderKeys(key[0], key[1]);
+        orderKeys(key[2], key[3]);
     } else {
-        orderElements(e[0], e[1]);
+        orderKeys(key[0], key[1]);
     }
-    bitonicStage<32u, R>(e);
-    bitonicStage<16u, R>(e);
-    bitonicStage<8u, R>(e);
-    bitonicStage<4u, R>(e);
-    bitonicStage<2u, R>(e);
-    bitonicStage<1u, R>(e);
+    bitonicStage<32u, R>(key);
+    bitonicStage<16u, R>(key);
+    bitonicStage<8u, R>(key);
+    bitonicStage<4u, R>(key);
+    bitonicStage<2u, R>(key);
+    bitonicStage<1u, R>(key);
 }
 
-// One row of the replay (replayWalkLogs): its 64 R merged elements, lane j of register b holding element 64 b + j of `n`, are
-// offered to the row's exact state machine in that order -- the lanes test together against the row's cut-off, what passes is
-// appended to the row's list behind a prefix count, and a list that reaches 2k entries inside a batch is cut right behind the
-// record that filled it (src/ExpressionMatrixLsh.cpp:243-251: push, then keepBest at 2k), the lanes behind that record testing
-// again against the new cut-off.  Then the column side: the records whose third word said so go to the inbox, one compaction
-// per batch.  rowId / listRow: the row's cell id and its list; count / mMax: the row's state (uniform), updated.
 // (what the replay reads from the kernel-argument block, once per call instead of once per row: a scalar load there is two
 // hundred cycles in front of whatever needs it)
 struct ReplayArgs {
@@ -1016,79 +1004,143 @@ struct ReplayArgs {
     const int32_t* acceptMaxByKey;
     const uint32_t* keyOfMismatch;
     uint32_t k, twoK, columnShift;      // columnShift = 13 + rowBits: where an inbox entry's target cell begins
+    uint32_t vectorMemoryIssued;        // vector-memory instructions the replay is certain to have issued so far (awaitVectorMemory)
+    uint32_t firstColumn;               // of the item's columns: the merge keys hold columns relative to it
+    bool selfPairs;                     // the rows' own cells may be among their columns (full rows): dropped here
 };
+// The column side of a batch of records: one compaction into the wave's chunk of the inbox (emitColumn, with the arguments at hand)
+__device__ __forceinline__ void emitBatchToInbox(bool emit, uint32_t col, uint32_t rowId, uint32_t m, uint32_t lane, ReplayArgs& args,
+                                                 uint32_t& emitPos, uint32_t& emitEnd)
+{
+    const uint64_t emitMask = __builtin_amdgcn_ballot_w64(emit);
+    if (emitMask == 0ull) return;
+    uint32_t p = uniform(emitPos), end = uniform(emitEnd);
+    if (p > end) return;                // (emission disabled after an overflow)
+    const uint32_t entries = uint32_t(__builtin_popcountll(emitMask));
+    if (p + entries > end) {
+        ArgsPtr aux = kernelArgs();
+        const uint64_t fresh = refillInboxChunk(aux->inbox, aux->inboxControl, aux->inboxCapacity, aux->inboxChunk, lane, p, end);
+        p = uint32_t(fresh);
+        end = uint32_t(fresh >> 32);
+    }
+    if (p <= end) {
+        if (emit) storeGlobalWord(args.inbox + p + lanesBelow(emitMask), (uint64_t(col) << args.columnShift) | (uint64_t(rowId) << 13u) | uint64_t(m));
+        args.vectorMemoryIssued += 1u;
+        p += entries;
+    }
+    emitPos = p;
+    emitEnd = end;
+}
+
 template <bool IDENTITY, int R>
-__device__ __forceinline__ void replayRowElements(const MergeElement (&e)[R], uint32_t n, uint32_t lane, uint32_t rowId, bool emitRow,
-                                                  Entry* listRow, const ReplayArgs& args, uint32_t& count, int32_t& mMax, uint32_t& emitPos,
+__device__ __forceinline__ void replayRowElements(const uint32_t (&key)[R], uint32_t n, uint32_t lane, uint32_t rowId, bool emitRow,
+                                                  Entry* listRow, ReplayArgs& args, uint32_t& count, int32_t& mMax, uint32_t& emitPos,
                                                   uint32_t& emitEnd, unsigned char* ldsRaw, uint64_t* timed = nullptr)
 {
     const uint32_t twoK = args.twoK;
 #pragma unroll
     for (int b = 0; b < R; b++) {
         if (64u * uint32_t(b) >= n) break;
-        const uint32_t col = e[b].col, m = e[b].payload & 0x7fffffffu;
-        bool active = 64u * uint32_t(b) + lane < n;
+        const uint32_t col = (key[b] >> kMergeColumnShift) + args.firstColumn, m = key[b] & kMergeMismatchMask;
+        bool active = 64u * uint32_t(b) + lane < n && !(args.selfPairs && col == rowId);
         for (;;) {
-            const bool pass = active && int32_t(m) <= mMax && col != rowId;
+            const bool pass = active && int32_t(m) <= mMax;
             const uint64_t passMask = __builtin_amdgcn_ballot_w64(pass);
             if (passMask == 0ull) break;
             const uint32_t passes = uint32_t(__builtin_popcountll(passMask)), room = twoK - count;
             const uint32_t index = lanesBelow(passMask);
             if (pass && index < room) {
-                uint32_t key = m;
-                if (!IDENTITY) key = args.keyOfMismatch[m];
-                storeEntry(listRow + count + index, col, key);
+                uint32_t entryKey = m;
+                if (!IDENTITY) entryKey = args.keyOfMismatch[m];
+                storeEntry(listRow + count + index, col, entryKey);
             }
+            args.vectorMemoryIssued += 1u;          // (some lane passed, and the list has room for one at least)
             if (passes < room) {
                 count += passes;
                 break;
             }
             // the list is full behind the record of index room - 1: keepBest, the new cut-off, and the lanes behind that record again
             Entry* lds = reinterpret_cast<Entry*>(ldsRaw + size_t(threadIdx.x >> 6) * twoK * kLdsBytesPerEntrySlot);
-            const uint64_t ts0 = timed ? __builtin_readcyclecounter() : 0ull;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            const uint64_t ts1 = timed ? __builtin_readcyclecounter() : 0ull;
             const uint32_t backKey = cutListToBest((LdsEntryPtr)lds, listRow, twoK, args.k, lane, true);
-            const uint64_t ts2 = timed ? __builtin_readcyclecounter() : 0ull;
             mMax = __builtin_amdgcn_readfirstlane(args.acceptMaxByKey[backKey]);
             count = args.k;
             waveLdsFence();
-            if (timed) {
-                const uint64_t ts3 = __builtin_readcyclecounter();
-                timed[0] += ts1 - ts0;
-                timed[1] += ts2 - ts1;
-                timed[2] += ts3 - ts2;
-                timed[3] += 1u;
-            }
             const uint32_t filler = uint32_t(__builtin_ctzll(__builtin_amdgcn_ballot_w64(pass && index == room - 1u)));
             active = active && lane > filler;
         }
         if (emitRow) {
-            // the column side: one compaction per batch into the wave's chunk of the inbox (emitColumn, with the arguments at hand)
-            const bool emit = 64u * uint32_t(b) + lane < n && (e[b].payload >> 31) != 0u;
-            const uint64_t emitMask = __builtin_amdgcn_ballot_w64(emit);
-            if (emitMask != 0ull) {
-                uint32_t p = uniform(emitPos), end = uniform(emitEnd);
-                if (p <= end) {             // (p > end: emission disabled after an overflow)
-                    const uint32_t entries = uint32_t(__builtin_popcountll(emitMask));
-                    if (p + entries > end) {
-                        ArgsPtr aux = kernelArgs();
-                        const uint64_t fresh = refillInboxChunk(aux->inbox, aux->inboxControl, aux->inboxCapacity, aux->inboxChunk, lane, p, end);
-                        p = uint32_t(fresh);
-                        end = uint32_t(fresh >> 32);
-                    }
-                    if (p <= end) {
-                        if (emit) {
-                            storeGlobalWord(args.inbox + p + lanesBelow(emitMask),
-                                            (uint64_t(col) << args.columnShift) | (uint64_t(rowId) << 13u) | uint64_t(m));
-                        }
-                        p += entries;
-                    }
-                    emitPos = p;
-                    emitEnd = end;
-                }
-            }
+            emitBatchToInbox(64u * uint32_t(b) + lane < n && (key[b] & kMergePassBit) != 0u, col, rowId, m, lane, args, emitPos, emitEnd);
         }
+    }
+}
+
+// Two rows at once, one per half of the wave: what replayRowElements does for one, for rows whose merged records fit 32 lanes
+// (two logs of 16 records at most: most rows of most replays).  Lane 32 h + j holds merged record j of row h; the halves'
+// states are uniform within a half (X: lanes 0..31, Y: 32..63), the ballots are shared, and a half whose list fills up is cut --
+// the whole wave works on that one list -- before its lanes behind the filling record test again.
+template <bool IDENTITY>
+__device__ __forceinline__ void replayPairElements(uint32_t key, uint32_t lane, uint32_t rowX, uint32_t rowY,
+                                                   uint32_t rowOfWave, bool emitX, bool emitY, ReplayArgs& args, uint32_t& countX,
+                                                   int32_t& mMaxX, uint32_t& countY, int32_t& mMaxY, uint32_t& emitPos, uint32_t& emitEnd,
+                                                   unsigned char* ldsRaw, uint64_t* timed = nullptr)
+{
+    const uint64_t tq0 = timed ? __builtin_readcyclecounter() : 0ull;
+    const uint32_t twoK = args.twoK;
+    const bool upper = __builtin_amdgcn_inverse_ballot_w64(0xffffffff00000000ull);
+    const uint32_t col = (key >> kMergeColumnShift) + args.firstColumn, m = key & kMergeMismatchMask;
+    const uint32_t rowId = rowOfWave + (upper ? rowY : rowX);
+    // (a sentinel's column is beyond every count: `have` needs no look at the counts)
+    const bool have = key != 0xffffffffu;
+    bool active = have && !(args.selfPairs && col == rowId);
+    for (;;) {
+        const bool pass = active && int32_t(m) <= (upper ? mMaxY : mMaxX);
+        const uint64_t passMask = __builtin_amdgcn_ballot_w64(pass);
+        if (passMask == 0ull) break;
+        const uint32_t passesX = uint32_t(__builtin_popcount(uint32_t(passMask))), passesY = uint32_t(__builtin_popcount(uint32_t(passMask >> 32)));
+        const uint32_t roomX = twoK - countX, roomY = twoK - countY;
+        // the entry's place among the lists of the wave's rows (32 bits; one address computation at the store)
+        const uint32_t placeX = rowX * twoK + countX, placeY = rowY * twoK + countY - passesX;
+        const uint32_t index = lanesBelow(passMask);
+        const uint32_t limit = upper ? passesX + roomY : roomX;
+        if (pass && index < limit) {
+            uint32_t entryKey = m;
+            if (!IDENTITY) entryKey = args.keyOfMismatch[m];
+            storeEntry(args.lists + ((upper ? placeY : placeX) + index), col, entryKey);
+        }
+        args.vectorMemoryIssued += 1u;          // (some lane passed, and its list has room for one at least)
+        const bool fullX = passesX >= roomX, fullY = passesY >= roomY;
+        if (!fullX) countX += passesX;
+        if (!fullY) countY += passesY;
+        if (!fullX && !fullY) break;
+        // (a half that did not fill its list is through with this batch; a half that did goes on behind the record that filled it)
+        uint32_t fillerX = 64u, fillerY = 64u;
+        Entry* lds = reinterpret_cast<Entry*>(ldsRaw + size_t(threadIdx.x >> 6) * twoK * kLdsBytesPerEntrySlot);
+        if (fullX) {
+            fillerX = uint32_t(__builtin_ctzll(__builtin_amdgcn_ballot_w64(pass && !upper && index == roomX - 1u)));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const uint32_t backKey = cutListToBest((LdsEntryPtr)lds, args.lists + size_t(rowX) * twoK, twoK, args.k, lane, true);
+            mMaxX = __builtin_amdgcn_readfirstlane(args.acceptMaxByKey[backKey]);
+            countX = args.k;
+            waveLdsFence();
+        }
+        if (fullY) {
+            fillerY = uint32_t(__builtin_ctzll(__builtin_amdgcn_ballot_w64(pass && upper && index == passesX + roomY - 1u)));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const uint32_t backKey = cutListToBest((LdsEntryPtr)lds, args.lists + size_t(rowY) * twoK, twoK, args.k, lane, true);
+            mMaxY = __builtin_amdgcn_readfirstlane(args.acceptMaxByKey[backKey]);
+            countY = args.k;
+            waveLdsFence();
+        }
+        active = active && (upper ? lane > fillerY && fullY : lane > fillerX && fullX);
+    }
+    const uint64_t tq1 = timed ? __builtin_readcyclecounter() : 0ull;
+    if (emitX || emitY) {
+        emitBatchToInbox(have && (key & kMergePassBit) != 0u && (upper ? emitY : emitX), col, rowId, m, lane, args, emitPos, emitEnd);
+    }
+    if (timed) {
+        timed[2] += tq1 - tq0;
+        timed[6] += __builtin_readcyclecounter() - tq1;
     }
 }
 
@@ -1110,6 +1162,7 @@ __device__ __forceinline__ void replayRowElements(const MergeElement (&e)[R], ui
 struct ReplayRowLoads {
     uint32_t row;                       // 0..63, 64 = none
     uint32_t nA, nB;                    // records to replay of the row's two logs
+    uint32_t issuedAt;                  // ReplayArgs::vectorMemoryIssued behind the row's two transfers
 };
 // The records of a row travel global -> LDS without touching registers (global_load_lds_dwordx4: LDS address = M0 + 16 * lane),
 // into a ring of four slots of two 1 KB pieces per wave -- lane j's record of the first log at 16 j, of the second at 4096 + 16 j -- and are
@@ -1139,12 +1192,35 @@ __device__ __forceinline__ void issueRecordLoads(uint32_t ringSlotLds, const Wal
                  : "v"(addressA), "v"(addressB), "s"(ringSlotLds)
                  : "memory", "m0", "scc");
 }
-template <int YOUNGER>
-__device__ __forceinline__ void awaitRecordLoads()
+__device__ __forceinline__ void issueRecordLoad(uint32_t ringSlotLds, uint64_t address)
 {
-    static_assert(YOUNGER == 0 || YOUNGER == 6, "transfers come in pairs, four rows are in flight");
-    if (YOUNGER == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(address), "s"(ringSlotLds) : "memory", "m0");
+}
+// Waits until at most `younger` of the wave's vector-memory operations are outstanding.  The operations complete in order, so
+// a transfer is complete once no more operations are outstanding than were issued behind it.  The replay counts what it
+// issues behind a transfer -- the later turns' transfers AND the stores of the turns in between (the lists, the inbox): with the
+// transfers alone as the count, a turn waited for the stores of the turn before it, a round trip to the L2 again.  Counting too
+// few is safe (a longer wait), so only stores that are certain to be issued are counted, and 15 stands for "15 or more".
+__device__ __forceinline__ void awaitVectorMemory(uint32_t younger)
+{
+    switch (younger < 15u ? younger : 15u) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    }
 }
 typedef const volatile __attribute__((address_space(3))) WalkRecordWords* LdsRecordPtr;
 __device__ __forceinline__ WalkRecord walkRecordOf(const WalkRecordWords& w)
@@ -1160,7 +1236,7 @@ __device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32
                                                const uint32_t (&firstRecord)[2], bool all, uint32_t lane,
                                                uint32_t row, bool rowValid, bool emitColumns, uint32_t listBlock, Entry* myList,
                                                uint32_t twoK, uint32_t& count, int32_t& mMax, uint32_t& emitPos, uint32_t& emitEnd,
-                                               unsigned char* ldsRaw, uint32_t tilesLds, uint64_t* timed = nullptr)
+                                               unsigned char* ldsRaw, uint32_t tilesLds, uint32_t firstColumn, uint64_t* timed = nullptr)
 {
     const uint64_t tr0 = timed ? __builtin_readcyclecounter() : 0ull;
     constexpr float bits = (WIDE ? 2.f : 1.f) * kMatrixBits;
@@ -1168,15 +1244,20 @@ __device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32
     const uint32_t stored0Mine = recordCount[0], stored1Mine = recordCount[1], first0Mine = firstRecord[0], first1Mine = firstRecord[1];
     // what this lane's two logs hold for the replay, and which rows have records at all (bit 32 a + t: row 32 a + t)
     const uint32_t mine[2] = {all ? stored0Mine : stored0Mine - first0Mine, all ? stored1Mine : stored1Mine - first1Mine};
-    uint64_t rowsWithRecords = 0, rowsWithLongLogs = 0;
+    // rows by the length of their longer log: up to 16 records (two rows per turn), up to 64 (a row per turn), beyond (two
+    // records per lane and log)
+    uint64_t rowsWithShortLogs = 0, rowsWithRecords = 0, rowsWithLongLogs = 0;
 #pragma unroll
     for (uint32_t a = 0; a < 2u; a++) {
-        const uint64_t some = __builtin_amdgcn_ballot_w64(mine[a] != 0u), longLog = __builtin_amdgcn_ballot_w64(mine[a] > 64u);
+        const uint64_t some = __builtin_amdgcn_ballot_w64(mine[a] != 0u), over16 = __builtin_amdgcn_ballot_w64(mine[a] > 16u);
+        const uint64_t longLog = __builtin_amdgcn_ballot_w64(mine[a] > 64u);
+        const uint64_t rowsSome = (some | (some >> 32)) & 0xffffffffull, rowsOver16 = (over16 | (over16 >> 32)) & 0xffffffffull;
         const uint64_t rowsLong = (longLog | (longLog >> 32)) & 0xffffffffull;
         rowsWithLongLogs |= rowsLong << (32u * a);
-        rowsWithRecords |= (((some | (some >> 32)) & 0xffffffffull) & ~rowsLong) << (32u * a);
+        rowsWithRecords |= (rowsOver16 & ~rowsLong) << (32u * a);
+        rowsWithShortLogs |= (rowsSome & ~rowsOver16) << (32u * a);
     }
-    if ((rowsWithRecords | rowsWithLongLogs) == 0ull) return;
+    if ((rowsWithShortLogs | rowsWithRecords | rowsWithLongLogs) == 0ull) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (the logs: written by other lanes, read here with plain loads)
     const uint64_t validRows = __builtin_amdgcn_ballot_w64(rowValid);
     const uint32_t rowOfWave = uniform(row - lane);
@@ -1190,6 +1271,9 @@ __device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32
         args.k = aux->k;
         args.twoK = twoK;
         args.columnShift = 13u + aux->rowBits;
+        args.vectorMemoryIssued = 0u;
+        args.firstColumn = firstColumn;
+        args.selfPairs = !emitColumns;          // (rows that scan all columns themselves meet their own cells; a triangle's rows lie behind their columns)
     }
     Entry* const listOfWave = args.lists;
     // logical record i of a log that holds `stored` records and is read from record `first` on
@@ -1222,6 +1306,8 @@ __device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32
         // merged with its alternative right behind it, i.e. waited for at once -- and the point is to wait four rows later)
         issueRecordLoads(ringSlotLds, logA, lane < slot.nA ? physical(lane, firstA, storedA) : 0u, logB,
                          63u - lane < slot.nB ? physical(63u - lane, firstB, storedB) : 0u);
+        args.vectorMemoryIssued += 2u;
+        slot.issuedAt = args.vectorMemoryIssued;
     };
     auto rowState = [&](uint32_t r, uint32_t& countOfRow, int32_t& mMaxOfRow) {
         countOfRow = uint32_t(__builtin_amdgcn_readlane(int(count), int(r)));
@@ -1236,9 +1322,9 @@ __device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32
     auto process = [&](const ReplayRowLoads& slot, uint32_t ringSlotLds) {
         const uint32_t r = slot.row;
         const WalkRecordWords a0 = ldsPointer<LdsRecordPtr>(ringSlotLds)[lane], b0 = ldsPointer<LdsRecordPtr>(ringSlotLds + kReplayRingSecondLog)[lane];
-        MergeElement e[2];
-        e[0] = mergeElementOf(lane < slot.nA, walkRecordOf(a0), 0u, bits);
-        e[1] = mergeElementOf(63u - lane < slot.nB, walkRecordOf(b0), 1u, bits);
+        uint32_t e[2];
+        e[0] = mergeKeyOf(lane < slot.nA, walkRecordOf(a0), 0u, bits, args.firstColumn);
+        e[1] = mergeKeyOf(63u - lane < slot.nB, walkRecordOf(b0), 1u, bits, args.firstColumn);
         bitonicMergeWave<2>(e);
         uint32_t countOfRow;
         int32_t mMaxOfRow;
@@ -1248,9 +1334,129 @@ __device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32
         keepRowState(r, countOfRow, mMaxOfRow);
         if (timed) timed[4] += 1u;
     };
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    // ---- rows with short logs, two per turn: row X's 32 places in lanes 0..31, row Y's in lanes 32..63; of a row's places the
+    // first 16 are its first log's, ascending, the other 16 its second log's, descending ----
+    {
+        struct PairLoads {
+            uint32_t rowX, rowY;            // 64 = none
+            uint32_t valid;                 // per lane: its place holds a record (kept in a register: four counts selected by the
+                                            // lane's half and log were turned into a table in scratch memory, read -- and waited
+                                            // for with everything else in flight -- at every turn)
+            uint32_t issuedAt;              // args.vectorMemoryIssued behind the turn's transfer
+        };
+        const bool upper = lane >= 32u, second = (lane & 16u) != 0u;
+        const uint32_t place = second ? 31u - (lane & 31u) : lane & 31u;          // logical index in the lane's log
+        auto issuePair = [&](PairLoads& slot, uint32_t ringSlotLds) {
+            const bool anyX = rowsWithShortLogs != 0ull;
+            const uint32_t rX = anyX ? uint32_t(__builtin_ctzll(rowsWithShortLogs)) : 0u;
+            rowsWithShortLogs &= rowsWithShortLogs - 1ull;
+            const bool anyY = rowsWithShortLogs != 0ull;
+            const uint32_t rY = anyY ? uint32_t(__builtin_ctzll(rowsWithShortLogs)) : 0u;
+            rowsWithShortLogs &= rowsWithShortLogs - 1ull;
+            slot.rowX = anyX ? rX : 64u;
+            slot.rowY = anyY ? rY : 64u;
+            uint32_t nAX, nBX, nAY, nBY, firstAX, storedAX, firstBX, storedBX, firstAY, storedAY, firstBY, storedBY;
+            countsOf(rX, 0u, nAX, firstAX, storedAX);
+            countsOf(rX, 1u, nBX, firstBX, storedBX);
+            countsOf(rY, 0u, nAY, firstAY, storedAY);
+            countsOf(rY, 1u, nBY, firstBY, storedBY);
+            // the lane's log: row X or Y by the lane's half, first or second log by its quarter
+            const uint32_t nX = second ? nBX : nAX, nY = second ? nBY : nAY;
+            const uint32_t firstX = second ? firstBX : firstAX, firstY = second ? firstBY : firstAY;
+            const uint32_t storedX = second ? storedBX : storedAX, storedY = second ? storedBY : storedAY;
+            const uint32_t n = upper ? (anyY ? nY : 0u) : (anyX ? nX : 0u);
+            const uint32_t first = upper ? firstY : firstX, stored = upper ? storedY : storedX;
+            const uint32_t r = upper ? rY : rX;
+            const bool valid = place < n;
+            slot.valid = valid ? 1u : 0u;
+            const WalkRecord* log = walkLogOf(waveLog, logCapacity, (r & 31u) + (second ? 32u : 0u), r >> 5);
+            issueRecordLoad(ringSlotLds, reinterpret_cast<uint64_t>(log + (valid ? physical(place, first, stored) : 0u)));
+            args.vectorMemoryIssued += 1u;
+            slot.issuedAt = args.vectorMemoryIssued;
+        };
+        auto processPair = [&](const PairLoads& slot, uint32_t ringSlotLds) {
+            const uint64_t tp0 = timed ? __builtin_readcyclecounter() : 0ull;
+            const WalkRecordWords w = ldsPointer<LdsRecordPtr>(ringSlotLds)[lane];
+            uint32_t e = mergeKeyOf(slot.valid != 0u, walkRecordOf(w), second ? 1u : 0u, bits, args.firstColumn);
+            bitonicMergeHalves(e);
+            if (timed) {
+                asm volatile("" : "+v"(e));
+                timed[1] += __builtin_readcyclecounter() - tp0;
+                timed[3] += 1u;
+            }
+            const uint32_t rX = slot.rowX, rY = slot.rowY < 64u ? slot.rowY : slot.rowX;          // (no second row: nothing of it is active)
+            uint32_t countX, countY;
+            int32_t mMaxX, mMaxY;
+            rowState(rX, countX, mMaxX);
+            rowState(rY, countY, mMaxY);
+            replayPairElements<IDENTITY>(e, lane, rX, rY, rowOfWave, emitColumns && ((validRows >> rX) & 1ull) != 0ull,
+                                         emitColumns && slot.rowY < 64u && ((validRows >> rY) & 1ull) != 0ull, args, countX, mMaxX, countY,
+                                         mMaxY, emitPos, emitEnd, ldsRaw, timed);
+            keepRowState(rX, countX, mMaxX);
+            if (slot.rowY < 64u) keepRowState(rY, countY, mMaxY);
+        };
+        const uint32_t ring0 = replayRingSlot(tilesLds, wave, 0u), ring1 = replayRingSlot(tilesLds, wave, 1u);
+        const uint32_t ring2 = replayRingSlot(tilesLds, wave, 2u), ring3 = replayRingSlot(tilesLds, wave, 3u);
+        PairLoads s0, s1, s2, s3;
+        issuePair(s0, ring0);
+        issuePair(s1, ring1);
+        issuePair(s2, ring2);
+        issuePair(s3, ring3);
+        for (;;) {
+            {
+                const uint64_t tw0 = timed ? __builtin_readcyclecounter() : 0ull;
+                awaitVectorMemory(uniform(args.vectorMemoryIssued - s0.issuedAt));
+                if (timed) timed[0] += __builtin_readcyclecounter() - tw0;
+            }
+            if (s0.rowX >= 64u) break;
+            processPair(s0, ring0);
+            {
+                const uint64_t ti0 = timed ? __builtin_readcyclecounter() : 0ull;
+                issuePair(s0, ring0);
+                if (timed) timed[7] += __builtin_readcyclecounter() - ti0;
+            }
+            {
+                const uint64_t tw0 = timed ? __builtin_readcyclecounter() : 0ull;
+                awaitVectorMemory(uniform(args.vectorMemoryIssued - s1.issuedAt));
+                if (timed) timed[0] += __builtin_readcyclecounter() - tw0;
+            }
+            if (s1.rowX >= 64u) break;
+            processPair(s1, ring1);
+            {
+                const uint64_t ti0 = timed ? __builtin_readcyclecounter() : 0ull;
+                issuePair(s1, ring1);
+                if (timed) timed[7] += __builtin_readcyclecounter() - ti0;
+            }
+            {
+                const uint64_t tw0 = timed ? __builtin_readcyclecounter() : 0ull;
+                awaitVectorMemory(uniform(args.vectorMemoryIssued - s2.issuedAt));
+                if (timed) timed[0] += __builtin_readcyclecounter() - tw0;
+            }
+            if (s2.rowX >= 64u) break;
+            processPair(s2, ring2);
+            {
+                const uint64_t ti0 = timed ? __builtin_readcyclecounter() : 0ull;
+                issuePair(s2, ring2);
+                if (timed) timed[7] += __builtin_readcyclecounter() - ti0;
+            }
+            {
+                const uint64_t tw0 = timed ? __builtin_readcyclecounter() : 0ull;
+                awaitVectorMemory(uniform(args.vectorMemoryIssued - s3.issuedAt));
+                if (timed) timed[0] += __builtin_readcyclecounter() - tw0;
+            }
+            if (s3.rowX >= 64u) break;
+            processPair(s3, ring3);
+            {
+                const uint64_t ti0 = timed ? __builtin_readcyclecounter() : 0ull;
+                issuePair(s3, ring3);
+                if (timed) timed[7] += __builtin_readcyclecounter() - ti0;
+            }
+        }
+        awaitVectorMemory(0u);
+    }
     {
         // four rows in flight: a row's two transfers have the six of the three rows behind it younger than themselves at its turn
-        const uint32_t wave = uniform(threadIdx.x >> 6);
         const uint32_t ring0 = replayRingSlot(tilesLds, wave, 0u), ring1 = replayRingSlot(tilesLds, wave, 1u);
         const uint32_t ring2 = replayRingSlot(tilesLds, wave, 2u), ring3 = replayRingSlot(tilesLds, wave, 3u);
         ReplayRowLoads s0, s1, s2, s3;
@@ -1259,24 +1465,24 @@ __device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32
         issue(s2, ring2);
         issue(s3, ring3);
         for (;;) {
-            awaitRecordLoads<6>();
+            awaitVectorMemory(uniform(args.vectorMemoryIssued - s0.issuedAt));
             if (s0.row >= 64u) break;
             process(s0, ring0);
             issue(s0, ring0);
-            awaitRecordLoads<6>();
+            awaitVectorMemory(uniform(args.vectorMemoryIssued - s1.issuedAt));
             if (s1.row >= 64u) break;
             process(s1, ring1);
             issue(s1, ring1);
-            awaitRecordLoads<6>();
+            awaitVectorMemory(uniform(args.vectorMemoryIssued - s2.issuedAt));
             if (s2.row >= 64u) break;
             process(s2, ring2);
             issue(s2, ring2);
-            awaitRecordLoads<6>();
+            awaitVectorMemory(uniform(args.vectorMemoryIssued - s3.issuedAt));
             if (s3.row >= 64u) break;
             process(s3, ring3);
             issue(s3, ring3);
         }
-        awaitRecordLoads<0>();          // (the transfers that were issued for nobody: the tile buffers go back to the walk)
+        awaitVectorMemory(0u);          // (the transfers that were issued for nobody: the tile buffers go back to the walk)
     }
     const uint64_t tr1 = timed ? __builtin_readcyclecounter() : 0ull;
     if (timed) timed[5] += tr1 - tr0;
@@ -1295,11 +1501,11 @@ __device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32
         const WalkRecord b0 = loadWalkRecord(logB, 63u - lane < nB ? physical(63u - lane, firstB, storedB) : 0u);
         const WalkRecord b1 = loadWalkRecord(logB, 127u - lane < nB ? physical(127u - lane, firstB, storedB) : 0u);
         // the sequence: the first log's 128 places ascending, then the second log's 128 places descending
-        MergeElement e[4];
-        e[0] = mergeElementOf(lane < nA, a0, 0u, bits);
-        e[1] = mergeElementOf(64u + lane < nA, a1, 0u, bits);
-        e[2] = mergeElementOf(127u - lane < nB, b1, 1u, bits);
-        e[3] = mergeElementOf(63u - lane < nB, b0, 1u, bits);
+        uint32_t e[4];
+        e[0] = mergeKeyOf(lane < nA, a0, 0u, bits, args.firstColumn);
+        e[1] = mergeKeyOf(64u + lane < nA, a1, 0u, bits, args.firstColumn);
+        e[2] = mergeKeyOf(127u - lane < nB, b1, 1u, bits, args.firstColumn);
+        e[3] = mergeKeyOf(63u - lane < nB, b0, 1u, bits, args.firstColumn);
         bitonicMergeWave<4>(e);
         uint32_t countOfRow;
         int32_t mMaxOfRow;
@@ -1308,7 +1514,6 @@ __device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32
                                        listOfWave + size_t(r) * twoK, args, countOfRow, mMaxOfRow, emitPos, emitEnd, ldsRaw, timed);
         keepRowState(r, countOfRow, mMaxOfRow);
     }
-    if (timed) timed[7] += __builtin_readcyclecounter() - tr1;
 }
 
 // The tile kernel of the sharded scan defers both sides: every lane empties its own two logs, order is irrelevant (the

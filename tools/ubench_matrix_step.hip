@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) stepLoop(int rounds, int mode, float boun
                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(int(unsigned(v >> 32))) << 32);
     };
     const unsigned long long rowAddress = uniform64(reinterpret_cast<unsigned long long>(rows) + size_t(blockIdx.x * 4 + wave) * 32768);
-    const unsigned long long logBase = uniform64(reinterpret_cast<unsigned long long>(logs) + size_t(blockIdx.x * 4 + wave) * 64 * 4096 * 8);
+    const unsigned long long logBase = uniform64(reinterpret_cast<unsigned long long>(logs) + size_t(blockIdx.x * 4 + wave) * 64 * 4096 * EM2_MATRIX_RECORD_BYTES);
     asm volatile(EM2_MATRIX_LOAD_ROWS : : "s"(rowAddress) : EM2_MATRIX_STEP_CLOBBERS);
     unsigned offset = lane * 4096 * 8, offset1 = lane * 4096 * 8 + 2048 * 8;
     asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(offset), "v"(offset1) : EM2_MATRIX_OWNED_REGISTERS);
@@ -137,7 +137,7 @@ int main(int argc, char** argv)
     unsigned long long* dLogs;
     hipMalloc(&dTiles, 65536);
     hipMalloc(&dRows, rows.size() * 4);
-    hipMalloc(&dLogs, waves * 64 * 4096 * 8);
+    hipMalloc(&dLogs, size_t(waves) * 64 * 4096 * EM2_MATRIX_RECORD_BYTES);
     hipMalloc(&dCounts, waves * 64 * 4);
     hipMemcpy(dTiles, tiles.data(), 65536, hipMemcpyHostToDevice);
     hipMemcpy(dRows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice);
