@@ -453,6 +453,61 @@ def facade_block(args, capi, synthetic, torch, toc, data, reference_pairs, refer
         shutil.rmtree(directory, ignore_errors=True)
 
 
+def clustered_regime_block(args, capi, oracle, device, torch, threads, regimes=((64, 0.15), (8, 0.05)), repeats=3, oracle_rows=1024):
+    """The scan alone on SURVEY.md 8(d)'s scan-only input -- cluster centres, every bit flipped with probability `flip`, cells
+    dealt to the clusters at random -- at the headline's size: signatures whose same-cluster similarity (0.70 at flip 0.15) lies
+    ABOVE the reference's default graph threshold, where the headline's projected signatures (similarity ~ 0.10 inside a cluster)
+    lie below it.  Per regime: em2_dev_find_similar_pairs4 over all cells (best of `repeats` after one untimed call), the matrix
+    kernel's own time by HIP events inside the library and its fraction of the dense FP4 peak, the deferred candidates against
+    the pool that holds them, and `oracle_rows` rows in 16 places of the last call's result against the oracle.  (VERDICT r5:
+    the scan's rate is a property of the data; this is the data on which it is lowest.)"""
+    C, L, k, thr = args.cells, args.lsh_count, args.k, args.threshold
+    stream = torch.cuda.current_stream().cuda_stream
+    pairs = torch.zeros((C, k, 2), dtype=torch.int32, device=device)
+    used = torch.zeros(C, dtype=torch.int32, device=device)
+    ws_bytes = capi.dev_find_similar_pairs4_workspace(C, C, L, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    out = {"note": "scan only (no projection): synthetic_signatures(clusters, flip), threshold %g, k = %d; kernel_ms / clock from the "
+                   "library's own events and counters (em2_dev_find_similar_pairs4_last_launch); frac = 2 x %d flop per pair on the "
+                   "matrix cores / kernel_ms / the dense FP4 peak" % (thr, k, 2048 if L > 1024 else 1024), "regimes": []}
+    for clusters, flip in regimes:
+        sig = synthetic_signatures(torch, C, L, device, clusters, flip, 4321)
+        times, kernel = [], []
+        for i in range(repeats + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            capi.dev_find_similar_pairs4(sig.data_ptr(), C, 0, C, L, k, thr, pairs.data_ptr(), used.data_ptr(), ws.data_ptr(), ws_bytes, stream)
+            torch.cuda.synchronize()
+            if i:
+                times.append(time.perf_counter() - t0)
+                kernel.append(capi.dev_find_similar_pairs4_last_launch()["matrix_kernel_ms"])
+        capi.dev_find_similar_pairs4_status(ws.data_ptr(), C, k, stream)
+        launch = capi.dev_find_similar_pairs4_last_launch()
+        entry = {"clusters": clusters, "flip": flip, "scan_ms": min(times) * 1e3, "unordered_pairs_per_s": C * (C - 1) / 2.0 / min(times),
+                 "scan_form": launch["form"], "kernel_ms": min(kernel), "clock_ghz": launch["matrix_clock_ghz"] or None,
+                 "deferred_candidates": launch["inbox_entries"], "deferred_candidates_per_cell": launch["inbox_entries"] / C,
+                 "deferred_pool_entries_per_cell": 1024}
+        if launch["matrix_pairs"] > 0 and min(kernel) > 0:
+            flops = launch["matrix_pairs"] * 2.0 * (2048.0 if L > 1024 else 1024.0)
+            entry["roofline"] = {"bound": "mfma", "achieved": flops / (min(kernel) * 1e-3) / 1e12, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": flops / (min(kernel) * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS}
+        if not args.no_check:
+            sig_host = sig.cpu().numpy().view(np.uint64)
+            host_pairs = pairs.cpu().numpy().view(np.uint32)
+            host_used = used.cpu().numpy().view(np.uint32)
+            checked = 0
+            for b, e, cell, sim, oused in oracle_rows_parallel(oracle, sig_host, L, k, thr, sample_ranges([(0, C)], oracle_rows), threads):
+                if not (np.array_equal(host_used[b:e], oused) and np.array_equal(host_pairs[b:e, :, 0], cell) and
+                        np.array_equal(host_pairs[b:e, :, 1], sim.view(np.uint32))):
+                    raise SystemExit("PARITY FAILURE: clustered regime %d / %g, rows [%d, %d)" % (clusters, flip, b, e))
+                checked += e - b
+            entry["rows_equal_to_the_oracle"] = checked
+            del sig_host, host_pairs, host_used
+        out["regimes"].append(entry)
+        del sig
+    return out
+
+
 def small_config(args, capi, sharded, synthetic, oracle, device, torch, cells=100000, genes=20000, steps=10, warmup=2):
     """BASELINE configs[1] on one GPU: ms per step and pairs/s, gated like the headline."""
     L, k, thr = args.lsh_count, args.k, args.threshold
@@ -721,6 +776,208 @@ def bench_chain(args, capi, sharded, synthetic, oracle, device, torch):
     }
 
 
+def timed_steps_across_ranks(args, torch, dist, device, step):
+    """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; the MAX over the ranks."""
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def bench_fsp5_ranks(args, capi, sharded, oracle, device, torch, dist, world, rank, watchdog, collective_check):
+    """BASELINE configs[3] on N GPUs, partitioned as SURVEY.md 8(e) and src/ExpressionMatrixLsh.cpp:405-483 allow: the loop over
+    the cells is a loop over independent rows, so every rank builds the (replicated) slice tables from the full signature array
+    and queries only the cells of its contiguous id range -- em2_dev_find_similar_pairs5(rowBegin, rowEnd) -- with NO data-path
+    collective.  The signatures are the scan-only synthetic ones, generated on every rank from the same seed (what an all-gather of
+    the projection's shards would leave there, as on the headline's line).  Gate: cells of every rank's own range, in places spread
+    over it, against the oracle.  value = cells of the whole job / the slowest rank's time."""
+    C, L, k, thr, q = args.cells, 2048 if args.lsh_count == 1024 else args.lsh_count, args.k, args.threshold, args.slice_length
+    begin, end = sharded.shard_range(C, world, rank)
+    rows = end - begin
+    watchdog.arm("fsp5: signatures, first pass and parity gate", 900)
+    sig = synthetic_signatures(torch, C, L, device)
+    pairs = torch.zeros((max(1, rows), k, 2), dtype=torch.int32, device=device)
+    used = torch.zeros(max(1, rows), dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    stage_ms = {"candidate_filter": 0.0, "selection": 0.0}
+
+    def step():
+        if rows:
+            capi.dev_find_similar_pairs5(sig.data_ptr(), C, begin, end, L, k, thr, q, args.bucket_overflow, pairs.data_ptr(), used.data_ptr(), stream)
+
+    step()
+    torch.cuda.synchronize()
+    check = {"skipped": "--no-check"}
+    if not args.no_check and rows:
+        sig_host = sig.cpu().numpy().view(np.uint64)
+        places = 8
+        span = max(1, min(rows, max(64, args.fsp5_check_cells // world)) // places)
+        listed = np.unique(np.concatenate([np.arange(b, b + span) for b in
+                                           [begin + (rows - span) * i // (places - 1) for i in range(places)]]).clip(begin, end - 1)).astype(np.uint32)
+        cell, sim, oused = oracle.find_similar_pairs5_cells(sig_host, L, k, thr, q, args.bucket_overflow, listed)
+        index = torch.from_numpy(listed.astype(np.int64) - begin).to(device)
+        got = pairs[index].cpu().numpy().view(np.uint32)
+        if not (np.array_equal(used[index].cpu().numpy().view(np.uint32), oused) and np.array_equal(got[:, :, 0], cell) and
+                np.array_equal(got[:, :, 1], sim.view(np.uint32))):
+            raise SystemExit("PARITY FAILURE: findSimilarPairs5 of rank %d differs from the oracle on the sampled cells" % rank)
+        check = {"fsp5_cells_rank0": int(len(listed)), "places": places}
+        del sig_host
+    # every rank's gate has passed when the collective below returns (a rank that failed has exited: the others' watchdogs end the run)
+    counted = torch.tensor([0 if args.no_check else 1], dtype=torch.int64, device=device)
+    dist.all_reduce(counted)
+    check["ranks_that_passed_their_gate"] = int(counted.item())
+    watchdog.arm("fsp5: warmup and timed steps", 180 + 20 * (args.warmup + args.steps))
+    elapsed = timed_steps_across_ranks(args, torch, dist, device, step)
+    info = capi.dev_find_similar_pairs5_last_launch() if rows else {"filter_ms": 0.0, "select_ms": 0.0, "slice_count": 0, "batches": 0,
+                                                                    "distinct_candidates": 0, "gathered_candidates": 0}
+    stages = torch.tensor([info["filter_ms"], info["select_ms"]], dtype=torch.float64, device=device)
+    dist.all_reduce(stages, op=dist.ReduceOp.MAX)
+    stage_ms["candidate_filter"], stage_ms["selection"] = (float(x) for x in stages.tolist())
+    watchdog.disarm()
+    distinct = info["distinct_candidates"] if info["distinct_candidates"] >= 0 else info["gathered_candidates"]
+    W = capi.word_count(L)
+    return {
+        "metric": "cells/sec through findSimilarPairs5 (bucketed LSH, tables + candidate filter + selection)",
+        "value": C * args.steps / elapsed, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u64 popcount", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3]: %d synthetic cells, %d-bit signatures, findSimilarPairs5 lshSliceLength=%d "
+                               "bucketOverflow=%d k=%d threshold=%g, cells sharded by id range over %d GPU(s), slice tables replicated"
+                               % (C, L, q, args.bucket_overflow, k, thr, world),
+                   "cells": C, "lsh_count": L, "k": k, "slice_length": q, "bucket_overflow": args.bucket_overflow,
+                   "rows_per_gpu": sharded.shard_size(C, world), "slices": info["slice_count"], "batches_rank0": info["batches"]},
+        "phases_ms_max_over_ranks": dict(stage_ms, tables_and_candidate_unions=elapsed / args.steps * 1e3 - stage_ms["candidate_filter"] - stage_ms["selection"]),
+        "collectives_in_a_step": "none: every rank builds the slice tables of ALL cells itself (they are what is replicated) and queries its own "
+                                 "cells; the tables' share of a step (a radix sort over cells x slices keys) does not shrink with the ranks",
+        "roofline": {"kernel": "filterWideKernel (all batches, rank 0)", "kernel_ms": info["filter_ms"], "bound": "valu",
+                     "achieved": distinct * 2.0 * W * 2.0 / (info["filter_ms"] * 1e-3) / 1e12 if info["filter_ms"] > 0 else 0.0,
+                     "peak": VALU_LANE_OPS_PER_S / 1e12, "unit": "T lane-op/s",
+                     "frac": distinct * 2.0 * W * 2.0 / (info["filter_ms"] * 1e-3) / VALU_LANE_OPS_PER_S if info["filter_ms"] > 0 else 0.0,
+                     "traffic": None, "essential_lane_ops": distinct * 2.0 * W * 2.0, "distinct_candidates_rank0": distinct,
+                     "note": "rank 0's filter: essential v_xor_b32 + v_bcnt_u32_b32 lane-operations of its cells' distinct candidates against "
+                             "the vector ALUs' issue rate (as on the 1-GPU line)"},
+        "parity_check": check, "collective_check": collective_check,
+    }
+
+
+def bench_chain_ranks(args, capi, sharded, synthetic, oracle, device, torch, dist, world, rank, watchdog, collective_check):
+    """BASELINE configs[4] on N GPUs: findSimilarPairs4 with north_star's partitioning (projection shards, all-gather of the
+    signatures, every rank its contiguous rows against all columns on the matrix cores), an all-gather of the finished rows
+    (k pairs per cell: 800 MB at 1M cells), then createCellGraph and label propagation on rank 0 -- both are serial by contract
+    (insertion order of the edges; the turns of an iteration) and take 20 % of the 1-GPU chain.  Gate: the
+    whole edge list and every label against the oracle, from the gathered pairs."""
+    C, G, L, k, thr = args.cells, args.genes, args.lsh_count, args.k, args.threshold
+    watchdog.arm("chain: inputs, first pass and parity gate", 1200)
+    saved = os.environ.get("EM2_SHARDED_SCAN")
+    os.environ["EM2_SHARDED_SCAN"] = "0"            # (contiguous rows per rank: the gathered buffer is the SimilarPairs table)
+    try:
+        pipe = sharded.DevicePipeline(C, G, L, k, thr, world_size=world, rank=rank, dist=dist, device=device)
+    finally:
+        if saved is None:
+            os.environ.pop("EM2_SHARDED_SCAN", None)
+        else:
+            os.environ["EM2_SHARDED_SCAN"] = saved
+    toc, data = synthetic.expression_shard(pipe.row_begin, pipe.row_end, G, density=args.density, device=device)
+    vectors_host = capi.lsh_generate_vectors(G, L, args.seed)
+    pipe.set_inputs(toc, data, torch.from_numpy(vectors_host).to(device))
+    size = pipe.shard
+    local_pairs = torch.zeros((size, k, 2), dtype=torch.int32, device=device)
+    local_used = torch.zeros(size, dtype=torch.int32, device=device)
+    all_pairs = torch.zeros((size * world, k, 2), dtype=torch.int32, device=device)
+    all_used = torch.zeros(size * world, dtype=torch.int32, device=device)
+    cells = np.arange(C, dtype=np.uint32)
+    per_vertex = min(args.graph_k, k) if args.graph_k else k
+    if rank == 0:
+        d_v0 = torch.empty(C * per_vertex, dtype=torch.int32, device=device)
+        d_v1 = torch.empty(C * per_vertex, dtype=torch.int32, device=device)
+        d_sim = torch.empty(C * per_vertex, dtype=torch.float32, device=device)
+    times = {"findSimilarPairs4": 0.0, "gather_pairs": 0.0, "createCellGraph": 0.0, "labelPropagationClustering": 0.0}
+    outcome = {}
+
+    def step(record=True, fetch=False):
+        t0 = time.perf_counter()
+        pipe.step()
+        pipe.check()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if pipe.rows:
+            local_pairs[:pipe.rows].copy_(pipe.pairs[:pipe.rows])
+            local_used[:pipe.rows].copy_(pipe.used[:pipe.rows])
+        dist.all_gather_into_tensor(all_pairs, local_pairs)
+        dist.all_gather_into_tensor(all_used, local_used)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if rank == 0:
+            edges = capi.dev_cell_graph_edges_to_device(all_pairs.data_ptr(), all_used.data_ptr(), C, k, cells, cells, thr, args.graph_k,
+                                                        d_v0.data_ptr(), d_v1.data_ptr(), d_sim.data_ptr())
+            t3 = time.perf_counter()
+            clusters, iterations = capi.dev_cell_graph_label_propagation(cells, d_v0.data_ptr(), d_v1.data_ptr(), d_sim.data_ptr(), edges)
+            t4 = time.perf_counter()
+            outcome.update(edges=int(edges), iterations=int(iterations), clusters=clusters)
+            if fetch:
+                outcome.update(v0=d_v0[:edges].cpu().numpy().view(np.uint32), v1=d_v1[:edges].cpu().numpy().view(np.uint32),
+                               sim=d_sim[:edges].cpu().numpy())
+            if record:
+                times["createCellGraph"] += t3 - t2
+                times["labelPropagationClustering"] += t4 - t3
+        if record:
+            times["findSimilarPairs4"] += t1 - t0
+            times["gather_pairs"] += t2 - t1
+
+    step(record=False, fetch=True)
+    check = {"skipped": "--no-check"}
+    if rank == 0 and not args.no_check:
+        p = all_pairs[:C].cpu().numpy().view(np.uint32)
+        u = all_used[:C].cpu().numpy().view(np.uint32)
+        ev0, ev1, es = oracle.cell_graph_edges(p[:, :, 0], p[:, :, 1].view(np.float32), u, cells, cells, thr, args.graph_k, hashed=C > 250000)
+        if not (np.array_equal(ev0, outcome["v0"]) and np.array_equal(ev1, outcome["v1"]) and
+                np.array_equal(es.view(np.uint32), outcome["sim"].view(np.uint32))):
+            raise SystemExit("PARITY FAILURE: cell graph edges differ from the oracle")
+        oc, oit = oracle.label_propagation(cells, outcome["v0"], outcome["v1"], outcome["sim"])
+        if not (np.array_equal(oc, outcome["clusters"]) and oit == outcome["iterations"]):
+            raise SystemExit("PARITY FAILURE: clusters differ from the oracle")
+        # the gathered rows themselves: sampled rows of every rank's range against the oracle's findSimilarPairs4
+        sig_host = pipe.full_sig[:C].cpu().numpy().view(np.uint64)
+        rows_checked = 0
+        for b, e, cell, sim, oused in oracle_rows_parallel(oracle, sig_host, L, k, thr, sample_ranges([(0, C)], min(args.check_rows, 1024)), 0):
+            if not (np.array_equal(u[b:e], oused) and np.array_equal(p[b:e, :, 0], cell) and np.array_equal(p[b:e, :, 1], sim.view(np.uint32))):
+                raise SystemExit("PARITY FAILURE: gathered SimilarPairs rows [%d, %d) differ from the oracle" % (b, e))
+            rows_checked += e - b
+        check = {"edges": outcome["edges"], "labels": int(C), "iterations": outcome["iterations"], "gathered_rows_against_oracle": rows_checked}
+        del p, u, ev0, ev1, es, oc, sig_host
+    dist.barrier()
+    watchdog.arm("chain: warmup and timed steps", 240 + 30 * (args.warmup + args.steps))
+    elapsed = timed_steps_across_ranks(args, torch, dist, device, step)
+    watchdog.disarm()
+    steps_recorded = args.warmup + args.steps            # (step() records the warm-up steps too: the phases are means over all of them)
+    gathered_bytes = float(size) * world * (k * 8 + 4)
+    return {
+        "metric": "cells/sec through findSimilarPairs4 -> createCellGraph -> labelPropagationClustering",
+        "value": C * args.steps / elapsed, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "fp4 e2m1 +-1 products, f32 accumulate, exact (scan) / f32 similarities", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: %d synthetic cells x %d genes, %d-bit signatures, findSimilarPairs4 k=%d threshold=%g "
+                               "(rows sharded over %d GPUs) -> all-gather of the pairs -> createCellGraph(threshold %g, k=%d) -> label "
+                               "propagation on rank 0" % (C, G, L, k, thr, world, thr, args.graph_k),
+                   "cells": C, "edges": outcome.get("edges"), "iterations": outcome.get("iterations"),
+                   "clusters": int(outcome["clusters"].max()) + 1 if rank == 0 and len(outcome.get("clusters", [])) else None},
+        "phases_ms_rank0": {key: value / steps_recorded * 1e3 for key, value in times.items()},
+        "collectives_in_a_step": {"all_gather_signatures_bytes": float(pipe.shard) * world * capi.word_count(L) * 8,
+                                  "all_gather_pairs_bytes": gathered_bytes, "backend": dist.get_backend()},
+        "parity_check": check, "collective_check": collective_check,
+        "note": "graph and labels run on rank 0 while the other ranks wait: their order is the contract (DESIGN.md 3.4, 3.6)",
+    }
+
+
 def main():
     args = parse_args()
     # (the pool's driver only supports dmabuf IPC: without this RCCL fails with hipIpcGetMemHandle: invalid argument)
@@ -771,14 +1028,25 @@ def main():
     W = capi.word_count(L)
     device = torch.device("cuda", local_rank)
     if args.workload != "fsp4":
-        if world != 1:
-            raise SystemExit("bench.py --workload %s is a 1-GPU secondary line" % args.workload)
         import oracle_binding
         oracle = oracle_binding.load_oracle()
+        if world == 1:
+            if args.workload == "fsp5":
+                print(json.dumps(bench_fsp5(args, capi, oracle, device, torch)))
+            else:
+                print(json.dumps(bench_chain(args, capi, sharded, synthetic, oracle, device, torch)))
+            return
+        # BASELINE names 8 x MI355X for configs[3] and configs[4]: their legs on N ranks (rows by cell-id range)
         if args.workload == "fsp5":
-            print(json.dumps(bench_fsp5(args, capi, oracle, device, torch)))
+            line = bench_fsp5_ranks(args, capi, sharded, oracle, device, torch, dist, world, rank, watchdog, collective_check)
         else:
-            print(json.dumps(bench_chain(args, capi, sharded, synthetic, oracle, device, torch)))
+            line = bench_chain_ranks(args, capi, sharded, synthetic, oracle, device, torch, dist, world, rank, watchdog, collective_check)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        watchdog.arm("destroy_process_group", 60)
+        watchdog.exit_code = 0
+        dist.destroy_process_group()
+        watchdog.disarm()
         return
 
     # ---- synthetic inputs, resident in HBM ----
@@ -787,6 +1055,8 @@ def main():
     import oracle_binding
     oracle = oracle_binding.load_oracle()
     inputs = {}
+
+    prepare_ms = []
 
     def make_pipe(sharded_scan):
         saved = os.environ.get("EM2_SHARDED_SCAN")
@@ -801,8 +1071,13 @@ def main():
                 os.environ["EM2_SHARDED_SCAN"] = saved
         if not inputs:
             inputs["toc"], inputs["data"] = synthetic.expression_shard(pipe.row_begin, pipe.row_end, G, density=args.density, device=device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         pipe.set_inputs(inputs["toc"], inputs["data"], vectors)
         torch.cuda.synchronize()
+        # (em2_dev_prepare_vectors: the hyperplanes' column sums of src/Lsh.cpp:137-144 and their quantised copies -- once per
+        # hyperplane matrix, outside the timed step, itemised on the line as phases_ms_rank0.prepare_vectors_once)
+        prepare_ms.append((time.perf_counter() - t0) * 1e3)
         return pipe
 
     # With several ranks on one host the gates share its cores: every rank checks its share of the rows with its share of the
@@ -941,7 +1216,8 @@ def main():
                 "scan": ("sharded-symmetric" if sharded_symmetric else "row-shards-matrix" if rows_matrix else "symmetric-matrix" if matrix
                          else "symmetric" if symmetric else "row-shards"),
             },
-            "phases_ms_rank0": {"projection": proj_ms, "scan": scan_ms},
+            "phases_ms_rank0": {"projection": proj_ms, "scan": scan_ms,
+                                "prepare_vectors_once": prepare_ms[-1] if prepare_ms else None},
             "roofline": None,
         }
         hbm_roofline = {
@@ -1195,6 +1471,9 @@ def main():
         inputs.clear()
         del pipe, vectors
         torch.cuda.empty_cache()
+        if L <= 2048:
+            result["extra"]["clustered_regime"] = clustered_regime_block(args, capi, oracle, device, torch, gate_threads)
+            torch.cuda.empty_cache()
         result["extra"]["configs[1]"] = small_config(args, capi, sharded, synthetic, oracle, device, torch)
         # BASELINE configs[3] (bucketed findSimilarPairs5, 2048 bit) and configs[4] (findSimilarPairs4 -> createCellGraph ->
         # label propagation) at their 1-GPU sizes, a few steps each: the secondary lines of --workload fsp5 / chain,

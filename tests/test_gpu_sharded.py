@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_two_ranks(extra_env, cells, port, ranks=2):
+def run_two_ranks(extra_env, cells, port, ranks=2, extra_args=(), timeout=600):
     env = dict(os.environ)
     env.update({"EM2_BENCH_SHARE_DEVICE": "1", "EM2_BENCH_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1",
                 # two persistent kernels share one GPU here: keep them from oversubscribing it (hand-off waits of one
@@ -23,8 +23,8 @@ def run_two_ranks(extra_env, cells, port, ranks=2):
     env.update(extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1",
-           "--warmup", "0", "--cells", str(cells), "--genes", "3000", "--no-cpu-baseline", "--check-rows", "96"]
-    done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+           "--warmup", "0", "--cells", str(cells), "--genes", "3000", "--no-cpu-baseline", "--check-rows", "96"] + list(extra_args)
+    done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
     lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
     assert len(lines) == 1
@@ -88,3 +88,44 @@ def test_plain_command_starts_its_own_ranks():
     result = json.loads(lines[0])
     assert result["n_gpus"] == 2 and result["collective_check"]["ranks_counted_by_all_reduce"] == 2
     assert result["row_shard_leg"]["value"] > 0 and result["row_shard_leg"]["parity_check"]["fsp4_rows"] > 0
+
+
+# ---- BASELINE configs[3] and configs[4] on several ranks (bench.py --workload fsp5 / chain --gpus N) ----
+
+@pytest.mark.parametrize("ranks,cells", [(2, 20000), (3, 20011)])
+def test_fsp5_leg_on_several_ranks(ranks, cells):
+    """findSimilarPairs5 with the cells sharded by id range and the slice tables replicated: every rank's sampled cells equal
+    the oracle's (the rank exits non-zero otherwise), no data-path collective."""
+    result = run_two_ranks({}, cells=cells, port=29641 + ranks, ranks=ranks,
+                           extra_args=["--workload", "fsp5", "--slice-length", "14", "--fsp5-check-cells", "512"])
+    assert result["n_gpus"] == ranks and result["value"] > 0 and result["scaling"] == "strong"
+    assert result["parity_check"]["ranks_that_passed_their_gate"] == ranks and result["parity_check"]["fsp5_cells_rank0"] > 0
+    assert result["collective_check"]["ranks_counted_by_all_reduce"] == ranks
+    assert result["collectives_in_a_step"].startswith("none")
+
+
+@pytest.mark.parametrize("ranks,cells", [(2, 20000), (3, 20011)])
+def test_chain_leg_on_several_ranks(ranks, cells):
+    """findSimilarPairs4 by row shards -> all-gather of the pairs -> createCellGraph + label propagation on rank 0: the whole
+    edge list, every label and sampled gathered rows equal the oracle's."""
+    result = run_two_ranks({}, cells=cells, port=29651 + ranks, ranks=ranks, extra_args=["--workload", "chain", "--k", "30"])
+    assert result["n_gpus"] == ranks and result["value"] > 0
+    check = result["parity_check"]
+    assert check["edges"] > 0 and check["labels"] == cells and check["gathered_rows_against_oracle"] > 0
+    assert result["collectives_in_a_step"]["all_gather_pairs_bytes"] > 0
+    assert result["phases_ms_rank0"]["gather_pairs"] > 0
+
+
+def test_eight_ranks_dry_run_of_every_leg():
+    """First-contact readiness: EIGHT ranks on the one GPU at 131 072 cells, gloo for the collectives -- the
+    row-shard leg, the sharded symmetric leg (all_to_all among eight), and the fsp5 and chain legs -- every rank's gate against
+    the oracle.  Not a measurement: eight processes share a device."""
+    result = run_two_ranks({"EM2_SHARDED_MIN_CELLS": "1000"}, cells=131072, port=29661, ranks=8, timeout=1500)
+    assert result["config"]["scan"] == "sharded-symmetric" and result["n_gpus"] == 8
+    assert result["parity_check"]["fsp4_rows"] > 0 and result["row_shard_leg"]["parity_check"]["fsp4_rows"] > 0
+    assert result["collective_check"]["rank_ids_gathered"] == list(range(8))
+    result = run_two_ranks({}, cells=131072, port=29662, ranks=8, timeout=1500,
+                           extra_args=["--workload", "fsp5", "--slice-length", "16", "--fsp5-check-cells", "512"])
+    assert result["parity_check"]["ranks_that_passed_their_gate"] == 8
+    result = run_two_ranks({}, cells=131072, port=29663, ranks=8, timeout=1500, extra_args=["--workload", "chain", "--k", "30"])
+    assert result["parity_check"]["labels"] == 131072 and result["parity_check"]["gathered_rows_against_oracle"] > 0
