@@ -8,6 +8,7 @@
 #include "em2_tables.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -219,6 +220,12 @@ struct DeviceBuffer {
         else (void)hipFree(p);
         p = nullptr;
     }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// a piece of a larger device block
+struct Piece {
+    void* p = nullptr;
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -931,13 +938,45 @@ static int subsetFindSimilarPairs4(const uint64_t* globalToc, const em2_count* g
 
     const uint32_t words = wordCountOf(lshCount);
     CallTimer timer;
-    DeviceBuffer dSrcToc, dSrcData, dLocal, dToc, dData, dSubsetWs, dVectors, dSig, dWs, dAux;
-    EM2_HIP(dSrcToc.allocateCached((size_t(cellCount) + 1) * sizeof(uint64_t)));
-    EM2_HIP(dSrcData.allocateCached(srcNnz * sizeof(em2_count)));
-    EM2_HIP(dLocal.allocateCached(size_t(globalGeneCount) * sizeof(uint32_t)));
-    EM2_HIP(dToc.allocateCached((size_t(cellCount) + 1) * sizeof(uint64_t)));
+    // ONE device block for the whole call, from the process's scratch cache (em2_fsp5.hip: capped, em2_dev_release_scratch()
+    // frees it): the signatures first, then whatever the current phase needs -- the CSR, its subset, the hyperplanes and the
+    // projection's workspace; then, in the same place, the result and the scan's workspace.  A hipMalloc of gigabytes took
+    // 1.6-4 s in one call of twelve on the boxes of the pool, whichever allocation it hit, so every large buffer of the call has
+    // come out of the cache since round 5 -- as a dozen blocks then, 36 GB kept between calls; as one block of the call's peak
+    // now (13 GB at a million cells).
+    // The pool of deferred candidates is most of the scan's workspace (16 bytes per entry and cell: the pool and its sorted copy).
+    // This call starts with room for 512 entries per cell -- the bench's data use 240, 12 GB of workspace at a million cells --
+    // and the process comes back for the 1024 of the device-level call (19 GB) once a launch has overflowed the smaller pool
+    // (strongly clustered data: the launch then fell back on every row against all columns, correct but twice the work).
+    static std::atomic<bool> wantsTheFullPool{false};
+    struct PoolSize {
+        PoolSize(uint32_t entries) { em2::fsp4SetInboxEntriesPerCell(entries); }
+        ~PoolSize() { em2::fsp4SetInboxEntriesPerCell(0u); }
+    } poolSize(wantsTheFullPool.load() ? 0u : 512u);
     const size_t subsetWs = em2::subsetWorkspaceBytes(cellCount);
-    EM2_HIP(dSubsetWs.allocateCached(subsetWs));
+    const size_t wsBytes = em2_dev_compute_signatures_workspace(cellCount, lshCount);
+    const size_t auxBytes = lshCount % 4u == 0u ? em2_dev_vector_aux_bytes(geneCount, lshCount) : 0;
+    const size_t scanWsBytes = wantPairs && k ? em2_dev_find_similar_pairs4_workspace(cellCount, cellCount, lshCount, k) : 0;
+    const size_t sigBytes = alignUp(size_t(cellCount) * words * sizeof(uint64_t));
+    const size_t firstPhase = 2u * alignUp((size_t(cellCount) + 1) * sizeof(uint64_t)) + 2u * alignUp(srcNnz * sizeof(em2_count)) +
+                              alignUp(size_t(globalGeneCount) * sizeof(uint32_t)) + alignUp(subsetWs) +
+                              alignUp(size_t(geneCount) * lshCount * sizeof(double)) + alignUp(wsBytes) + alignUp(auxBytes) + 4096u;
+    const size_t secondPhase = wantPairs && k ? alignUp(size_t(cellCount) * k * sizeof(em2_pair)) + alignUp(size_t(cellCount) * sizeof(uint32_t)) +
+                                                    alignUp(scanWsBytes) + 4096u : 0;
+    DeviceBuffer arena;
+    EM2_HIP(arena.allocateCached(sigBytes + (firstPhase > secondPhase ? firstPhase : secondPhase) + 256u));
+    size_t arenaAt = alignUp(reinterpret_cast<size_t>(arena.p)) - reinterpret_cast<size_t>(arena.p);
+    auto carve = [&](size_t bytes) {
+        Piece piece;
+        piece.p = static_cast<char*>(arena.p) + arenaAt;
+        arenaAt += alignUp(bytes ? bytes : 1);
+        return piece;
+    };
+    const Piece dSig = carve(size_t(cellCount) * words * sizeof(uint64_t));
+    const size_t phaseBegin = arenaAt;
+    const Piece dSrcToc = carve((size_t(cellCount) + 1) * sizeof(uint64_t)), dSrcData = carve(srcNnz * sizeof(em2_count));
+    const Piece dLocal = carve(size_t(globalGeneCount) * sizeof(uint32_t)), dToc = carve((size_t(cellCount) + 1) * sizeof(uint64_t));
+    const Piece dSubsetWs = carve(subsetWs);
     EM2_HIP(hipMemcpy(dSrcToc.p, srcToc, (size_t(cellCount) + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     if (srcNnz) EM2_HIP(hipMemcpy(dSrcData.p, srcData, srcNnz * sizeof(em2_count), hipMemcpyHostToDevice));
     if (globalGeneCount) EM2_HIP(hipMemcpy(dLocal.p, geneLocalIds, size_t(globalGeneCount) * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -948,18 +987,15 @@ static int subsetFindSimilarPairs4(const uint64_t* globalToc, const em2_count* g
                                    globalGeneCount, dToc.as<uint64_t>(), dSubsetWs.p, subsetWs, nullptr));
     uint64_t nnz = 0;
     EM2_HIP(hipMemcpy(&nnz, dToc.as<uint64_t>() + cellCount, sizeof(uint64_t), hipMemcpyDeviceToHost));
-    EM2_HIP(dData.allocateCached(nnz * sizeof(em2_count)));
+    if (nnz > srcNnz) return fail(EM2_ERROR_RUNTIME, "em2_subset_find_similar_pairs4: the subset holds more counts than its source");
+    const Piece dData = carve(nnz * sizeof(em2_count));
     EM2_HIP(em2::launchSubsetFill(dSrcToc.as<uint64_t>(), dSrcData.as<em2::CountIn>(), nullptr, cellCount, dLocal.as<uint32_t>(),
                                   globalGeneCount, dToc.as<uint64_t>(), dData.as<em2::CountIn>(), nullptr));
     EM2_HIP(hipStreamSynchronize(nullptr));
-    dSrcData.release();
     timer.stage("subset");
 
     // signatures (same steps as em2_compute_signatures, on the device-resident subset)
-    const size_t wsBytes = em2_dev_compute_signatures_workspace(cellCount, lshCount);
-    EM2_HIP(dVectors.allocateCached(size_t(geneCount) * lshCount * sizeof(double)));
-    EM2_HIP(dSig.allocateCached(size_t(cellCount) * words * sizeof(uint64_t)));
-    EM2_HIP(dWs.allocateCached(wsBytes));
+    const Piece dVectors = carve(size_t(geneCount) * lshCount * sizeof(double)), dWs = carve(wsBytes);
     if (!vectors) {
         vectors = vectorsWhenNeeded(vectorsContext);            // (waits for the thread that draws them)
         if (!vectors) return fail(EM2_ERROR_RUNTIME, em2_last_error());
@@ -968,7 +1004,7 @@ static int subsetFindSimilarPairs4(const uint64_t* globalToc, const em2_count* g
     EM2_HIP(hipMemcpy(dVectors.p, vectors, size_t(geneCount) * lshCount * sizeof(double), hipMemcpyHostToDevice));
     void* aux = nullptr;
     if (lshCount % 4u == 0u) {          // (other widths: the exact arithmetic only)
-        EM2_HIP(dAux.allocateCached(em2_dev_vector_aux_bytes(geneCount, lshCount)));
+        const Piece dAux = carve(auxBytes);
         const int prc = em2_dev_prepare_vectors(dVectors.as<double>(), geneCount, lshCount, dAux.p, nullptr);
         if (prc != EM2_OK) return prc;
         aux = dAux.p;
@@ -979,21 +1015,17 @@ static int subsetFindSimilarPairs4(const uint64_t* globalToc, const em2_count* g
     EM2_HIP(hipStreamSynchronize(nullptr));
     timer.stage("hyperplanes to device + projection");
     if (signatures) EM2_HIP(hipMemcpy(signatures, dSig.p, size_t(cellCount) * words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    arena.idle = true;          // (every use of the block so far has been waited for; a failure below leaves it to the cache all the same)
     if (!wantPairs) return EM2_OK;
-    // free what the scan does not need before its (large) workspace is allocated
-    // (the stream was synchronised behind the projection: idle blocks, back to the process's scratch cache -- every large
-    // allocation of this call comes from there: a hipMalloc of gigabytes took 1.6-2.8 s in one call of fourteen on one box,
-    // whichever allocation it hit, and 2 ms otherwise)
-    for (DeviceBuffer* b : {&dVectors, &dAux, &dWs, &dData, &dToc, &dSrcToc, &dLocal, &dSubsetWs}) b->release();
     if (k == 0) {
         std::memset(usedCount, 0, size_t(cellCount) * sizeof(uint32_t));
         return EM2_OK;
     }
-    const size_t scanWsBytes = em2_dev_find_similar_pairs4_workspace(cellCount, cellCount, lshCount, k);
-    DeviceBuffer dPairs, dUsed, dScanWs;
-    EM2_HIP(dPairs.allocateCached(size_t(cellCount) * k * sizeof(em2_pair)));
-    EM2_HIP(dUsed.allocateCached(size_t(cellCount) * sizeof(uint32_t)));
-    EM2_HIP(dScanWs.allocateCached(scanWsBytes));
+    // the scan's buffers take the place of everything but the signatures (the stream was synchronised behind the projection)
+    arena.idle = false;
+    arenaAt = phaseBegin;
+    const Piece dPairs = carve(size_t(cellCount) * k * sizeof(em2_pair)), dUsed = carve(size_t(cellCount) * sizeof(uint32_t));
+    const Piece dScanWs = carve(scanWsBytes);
     timer.stage("allocate result + workspace");
     // The pages of the result, touched while the device scans.  ExpressionMatrix.findSimilarPairs4 hands over the mapping of a
     // `-Pairs` file it has just created (800 MB at 1M cells, k = 100): the copy at the end of this call took 137-161 ms into those
@@ -1019,13 +1051,15 @@ static int subsetFindSimilarPairs4(const uint64_t* globalToc, const em2_count* g
     if (rc != EM2_OK) return rc;
     rc = em2_dev_find_similar_pairs4_status(dScanWs.p, cellCount, k, nullptr);
     if (rc != EM2_OK) return rc;
+    // (all rows in one launch that ended as "rows x all columns on the matrix cores": the symmetric scan's pool overflowed)
+    if (em2::fsp4LastLaunchInfo().form == 4 && em2::fsp4UsesSymmetricScan(cellCount, cellCount, em2::paddedDwords(lshCount))) wantsTheFullPool.store(true);
     timer.stage("scan");
     if (toucher.thread.joinable()) toucher.thread.join();
     timer.stage("wait for the result's pages");
     EM2_HIP(hipMemcpy(pairs, dPairs.p, size_t(cellCount) * k * sizeof(em2_pair), hipMemcpyDeviceToHost));
     EM2_HIP(hipMemcpy(usedCount, dUsed.p, size_t(cellCount) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     timer.stage("pairs to host");
-    dPairs.idle = dUsed.idle = dScanWs.idle = dSig.idle = true;          // (the copies above were synchronous: the device is done with them)
+    arena.idle = true;          // (the copies above were synchronous: the device is done with the block)
     return EM2_OK;
 }
 

@@ -128,6 +128,7 @@ struct Fsp5LaunchInfo {
 Fsp5LaunchInfo fsp5LastLaunchInfo();
 // Frees the device scratch runFsp5 keeps between calls (em2_fsp5.hip: ScratchCache).
 void fsp5ReleaseScratch();
+void fsp4SetInboxEntriesPerCell(uint32_t entries);       // (this thread's symmetric scans: 0 = the default of 1024; em2_scan_symmetric.hip)
 // (em2_fsp5.hip) blocks of that cache for the library's other host-buffer entry points
 void* scratchTake(size_t bytes, size_t* got);
 void scratchGive(void* p, size_t bytes);

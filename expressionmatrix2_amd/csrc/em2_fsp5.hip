@@ -916,15 +916,26 @@ public:
     }
     void give(void* p, size_t bytes, int device)
     {
+        std::vector<Block> evicted;
+        bool kept = false;
         {
             std::lock_guard<std::mutex> guard(mutex_);
-            if (total_ + bytes <= capBytes() && blocks_.size() < 256u) {
+            const size_t cap = capBytes();
+            if (bytes <= cap) {
+                // a block that fits the cap by itself makes room for itself: the OLDEST blocks go first (what the cache is for
+                // is the few large blocks of the last call -- the scan's workspace, the result -- not whatever arrived first)
+                while (!blocks_.empty() && (total_ + bytes > cap || blocks_.size() >= 256u)) {
+                    evicted.push_back(blocks_.front());
+                    total_ -= blocks_.front().bytes;
+                    blocks_.erase(blocks_.begin());
+                }
                 blocks_.push_back(Block{p, bytes, device});
                 total_ += bytes;
-                return;
+                kept = true;
             }
         }
-        (void)hipFree(p);
+        for (const Block& b : evicted) (void)hipFree(b.p);
+        if (!kept) (void)hipFree(p);
     }
     void clear()
     {
@@ -946,18 +957,18 @@ private:
     struct Block { void* p; size_t bytes; int device; };
     static size_t capBytes()
     {
-        // what a host process can live with: an eighth of the device's memory (36 GB of an MI355X's 288) unless
+        // what a host process can live with: a sixteenth of the device's memory (18 GB of an MI355X's 288) unless
         // EM2_SCRATCH_CACHE_MB says otherwise (0: nothing is kept).  One findSimilarPairs5 call's scratch at a million cells x
-        // 2048 bits is 10 GB; the scan workspace of em2_subset_find_similar_pairs4 at a million cells is 27 GB, and it is the block
-        // that matters: its hipMalloc took 0.4 ms in 22 calls of 24 on one box and 2.7 and 4.0 s in the other two (a sixteenth,
-        // round 5's first choice, could not hold it).
+        // 2048 bits is 10 GB; the scan workspace of em2_subset_find_similar_pairs4 at a million cells is 12 GB (round 5: 27, and an
+        // eighth of the memory to hold it), and it is the block that matters: its hipMalloc took 0.4 ms in 22 calls of 24 on one
+        // box and 2.7 and 4.0 s in the other two.
         if (const char* v = getenv("EM2_SCRATCH_CACHE_MB")) return size_t(strtoull(v, nullptr, 10)) << 20;
-        static size_t eighth = 0;
-        if (!eighth) {
+        static size_t share = 0;
+        if (!share) {
             size_t freeBytes = 0, totalBytes = 0;
-            eighth = hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && totalBytes ? totalBytes / 8u : size_t(4) << 30;
+            share = hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && totalBytes ? totalBytes / 16u : size_t(4) << 30;
         }
-        return eighth;
+        return share;
     }
     std::mutex mutex_;
     std::vector<Block> blocks_;

@@ -781,12 +781,18 @@ bool symmetricEligible(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw)
     return cellCount >= (matrix ? kSymmetricMatrixMinCells : kSymmetricMinCells);
 }
 
+// Deferred candidates per cell the pool has room for: 1024 unless the calling thread says otherwise (the facade of
+// em2_subset_find_similar_pairs4, which allocates the workspace itself, starts with less and comes back for the full pool if the
+// launch overflowed: fsp4SetInboxEntriesPerCell).
+thread_local uint32_t inboxEntriesPerCell = 0;
+void fsp4SetInboxEntriesPerCell(uint32_t entries) { inboxEntriesPerCell = entries; }
+
 static uint64_t inboxCapacity(uint32_t cellCount)
 {
     // EM2_INBOX_CAPACITY (entries) is a test knob: tiny pools force the overflow -> ordered-scan fallback.
     const uint64_t forced = envNumber("EM2_INBOX_CAPACITY", 0);
     if (forced >= kInboxChunk) return forced < 0xfff00000ull ? forced : 0xfff00000ull;
-    uint64_t cap = uint64_t(cellCount) * 1024u;
+    uint64_t cap = uint64_t(cellCount) * (inboxEntriesPerCell ? inboxEntriesPerCell : 1024u);
     const uint64_t floor = uint64_t(maxResidentWaves()) * kInboxChunk * 2u;      // every wave can hold a chunk
     if (cap < floor) cap = floor;
     if (cap > 0xfff00000ull) cap = 0xfff00000ull;
@@ -803,7 +809,7 @@ static SymmetricLayout symmetricLayout(uint32_t cellCount, uint32_t paddedDw)
 {
     SymmetricLayout l;
     l.capacity = inboxCapacity(cellCount);
-    l.tempBytes = inboxSortTempBytes(l.capacity);
+    l.tempBytes = inboxSortTempBytesDoubleBuffer(l.capacity);
     size_t at = 0;
     l.snap = at;    at += align256(size_t(cellCount) * 4u);
     l.table = at;   at += align256(kTableWords * 4u);
@@ -1219,9 +1225,10 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
     if (used) {
         size_t tempBytes = layout.tempBytes;
         uint64_t* out = reinterpret_cast<uint64_t*>(ws + layout.poolB);
-        e = rocprim::radix_sort_keys(ws + layout.temp, tempBytes, args.inbox, out, size_t(used), 13u, 13u + 2u * rowBits, stream);
+        rocprim::double_buffer<uint64_t> keys(args.inbox, out);
+        e = rocprim::radix_sort_keys(ws + layout.temp, tempBytes, keys, size_t(used), 13u, 13u + 2u * rowBits, stream);
         if (e != hipSuccess) return e;
-        sorted = out;
+        sorted = keys.current();
     }
     if (rowBlocks > fullRowBlocks) {
         const uint32_t waves = rowBlocks - fullRowBlocks;

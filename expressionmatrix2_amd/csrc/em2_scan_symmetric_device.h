@@ -1589,6 +1589,17 @@ static bool matrixWideWanted(uint32_t paddedDw)
     return paddedDw == 64u && mode != 0 && mode != 3;
 }
 
+// (the double-buffer form of the sort: the two pools are its two buffers, and its temporary storage is the digit counts alone --
+// the keys-in / keys-out form asks for a third buffer of the pool's size on top)
+static size_t inboxSortTempBytesDoubleBuffer(uint64_t capacity)
+{
+    size_t bytes = 0;
+    uint64_t* none = nullptr;
+    rocprim::double_buffer<uint64_t> keys(none, none);
+    if (rocprim::radix_sort_keys(nullptr, bytes, keys, size_t(capacity), 0u, 64u, hipStream_t(nullptr)) != hipSuccess) return 0;
+    return bytes;
+}
+
 static size_t inboxSortTempBytes(uint64_t capacity)
 {
     size_t bytes = 0;

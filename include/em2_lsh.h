@@ -322,8 +322,10 @@ int em2_dev_find_similar_pairs5_last_launch(double* values, uint32_t valueCount)
 
 /* findSimilarPairs5 keeps its device scratch (bucket tables, candidate ids, candidate lists: about 10 GB at a million cells x
  * 2048 bits) between calls of the process, and em2_subset_find_similar_pairs4 the device copy of its result and its scan
- * workspace (6 GB at a million cells), because allocating gigabytes costs anything between 2 ms and 2.7 s per call depending on
- * the state of the host; at most EM2_SCRATCH_CACHE_MB megabytes are kept (default: an eighth of the device's memory, 0 = none).
+ * workspace (12 GB at a million cells: it starts with room for 512 deferred candidates per cell and takes the 19 GB of the
+ * device-level call once a launch of the process has overflowed that), because allocating gigabytes costs anything between
+ * 2 ms and 2.7 s per call depending on the state of the host; at most EM2_SCRATCH_CACHE_MB megabytes are kept (default: a
+ * sixteenth of the device's memory -- 18 GB of an MI355X's 288 --, the oldest blocks making room for newer ones; 0 = none).
  * This call frees what is kept.  The reference has no counterpart (its tables are std::vectors of the call,
  * src/ExpressionMatrixLsh.cpp:377-389). */
 void em2_dev_release_scratch(void);
