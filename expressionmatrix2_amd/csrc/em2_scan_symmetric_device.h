@@ -1244,20 +1244,21 @@ __device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32
     const uint32_t stored0Mine = recordCount[0], stored1Mine = recordCount[1], first0Mine = firstRecord[0], first1Mine = firstRecord[1];
     // what this lane's two logs hold for the replay, and which rows have records at all (bit 32 a + t: row 32 a + t)
     const uint32_t mine[2] = {all ? stored0Mine : stored0Mine - first0Mine, all ? stored1Mine : stored1Mine - first1Mine};
-    // rows by the length of their longer log: up to 16 records (two rows per turn), up to 64 (a row per turn), beyond (two
-    // records per lane and log)
-    uint64_t rowsWithShortLogs = 0, rowsWithRecords = 0, rowsWithLongLogs = 0;
+    // rows by the length of their longer log: up to 16 records (two rows per turn), up to 32 (a row per turn, a record per lane),
+    // up to 64 (a row per turn, a record per lane and log), beyond (two records per lane and log)
+    uint64_t rowsWithShortLogs = 0, rowsWithMediumLogs = 0, rowsWithRecords = 0, rowsWithLongLogs = 0;
 #pragma unroll
     for (uint32_t a = 0; a < 2u; a++) {
         const uint64_t some = __builtin_amdgcn_ballot_w64(mine[a] != 0u), over16 = __builtin_amdgcn_ballot_w64(mine[a] > 16u);
-        const uint64_t longLog = __builtin_amdgcn_ballot_w64(mine[a] > 64u);
+        const uint64_t over32 = __builtin_amdgcn_ballot_w64(mine[a] > 32u), longLog = __builtin_amdgcn_ballot_w64(mine[a] > 64u);
         const uint64_t rowsSome = (some | (some >> 32)) & 0xffffffffull, rowsOver16 = (over16 | (over16 >> 32)) & 0xffffffffull;
-        const uint64_t rowsLong = (longLog | (longLog >> 32)) & 0xffffffffull;
+        const uint64_t rowsOver32 = (over32 | (over32 >> 32)) & 0xffffffffull, rowsLong = (longLog | (longLog >> 32)) & 0xffffffffull;
         rowsWithLongLogs |= rowsLong << (32u * a);
-        rowsWithRecords |= (rowsOver16 & ~rowsLong) << (32u * a);
+        rowsWithRecords |= (rowsOver32 & ~rowsLong) << (32u * a);
+        rowsWithMediumLogs |= (rowsOver16 & ~rowsOver32) << (32u * a);
         rowsWithShortLogs |= (rowsSome & ~rowsOver16) << (32u * a);
     }
-    if ((rowsWithShortLogs | rowsWithRecords | rowsWithLongLogs) == 0ull) return;
+    if ((rowsWithShortLogs | rowsWithMediumLogs | rowsWithRecords | rowsWithLongLogs) == 0ull) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (the logs: written by other lanes, read here with plain loads)
     const uint64_t validRows = __builtin_amdgcn_ballot_w64(rowValid);
     const uint32_t rowOfWave = uniform(row - lane);
@@ -1452,6 +1453,79 @@ __device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32
                 issuePair(s3, ring3);
                 if (timed) timed[7] += __builtin_readcyclecounter() - ti0;
             }
+        }
+        awaitVectorMemory(0u);
+    }
+    // ---- rows whose logs hold 32 records at most each, one per turn: the first log's 32 places in lanes 0..31, ascending, the
+    // second log's in lanes 32..63, descending; one transfer, one key per lane, six stages ----
+    {
+        struct MediumLoads {
+            uint32_t row;                   // 64 = none
+            uint32_t valid;                 // per lane: its place holds a record
+            uint32_t n;                     // the row's records
+            uint32_t issuedAt;
+        };
+        const bool second = lane >= 32u;
+        const uint32_t place = second ? 63u - lane : lane;
+        auto issueMedium = [&](MediumLoads& slot, uint32_t ringSlotLds) {
+            const bool any = rowsWithMediumLogs != 0ull;
+            const uint32_t r = any ? uint32_t(__builtin_ctzll(rowsWithMediumLogs)) : 0u;
+            rowsWithMediumLogs &= rowsWithMediumLogs - 1ull;
+            slot.row = any ? r : 64u;
+            uint32_t nA, nB, firstA, storedA, firstB, storedB;
+            countsOf(r, 0u, nA, firstA, storedA);
+            countsOf(r, 1u, nB, firstB, storedB);
+            slot.n = any ? nA + nB : 0u;
+            const uint32_t n = any ? (second ? nB : nA) : 0u;
+            const uint32_t first = second ? firstB : firstA, stored = second ? storedB : storedA;
+            const bool valid = place < n;
+            slot.valid = valid ? 1u : 0u;
+            const WalkRecord* log = walkLogOf(waveLog, logCapacity, (r & 31u) + (second ? 32u : 0u), r >> 5);
+            issueRecordLoad(ringSlotLds, reinterpret_cast<uint64_t>(log + (valid ? physical(place, first, stored) : 0u)));
+            args.vectorMemoryIssued += 1u;
+            slot.issuedAt = args.vectorMemoryIssued;
+        };
+        auto processMedium = [&](const MediumLoads& slot, uint32_t ringSlotLds) {
+            const WalkRecordWords w = ldsPointer<LdsRecordPtr>(ringSlotLds)[lane];
+            uint32_t e[1] = {mergeKeyOf(slot.valid != 0u, walkRecordOf(w), second ? 1u : 0u, bits, args.firstColumn)};
+            bitonicStage<32u, 1>(e);
+            bitonicStage<16u, 1>(e);
+            bitonicStage<8u, 1>(e);
+            bitonicStage<4u, 1>(e);
+            bitonicStage<2u, 1>(e);
+            bitonicStage<1u, 1>(e);
+            const uint32_t r = slot.row;
+            uint32_t countOfRow;
+            int32_t mMaxOfRow;
+            rowState(r, countOfRow, mMaxOfRow);
+            replayRowElements<IDENTITY, 1>(e, slot.n, lane, rowOfWave + r, emitColumns && ((validRows >> r) & 1ull) != 0ull,
+                                           listOfWave + size_t(r) * twoK, args, countOfRow, mMaxOfRow, emitPos, emitEnd, ldsRaw, timed);
+            keepRowState(r, countOfRow, mMaxOfRow);
+        };
+        const uint32_t ring0 = replayRingSlot(tilesLds, wave, 0u), ring1 = replayRingSlot(tilesLds, wave, 1u);
+        const uint32_t ring2 = replayRingSlot(tilesLds, wave, 2u), ring3 = replayRingSlot(tilesLds, wave, 3u);
+        MediumLoads s0, s1, s2, s3;
+        issueMedium(s0, ring0);
+        issueMedium(s1, ring1);
+        issueMedium(s2, ring2);
+        issueMedium(s3, ring3);
+        for (;;) {
+            awaitVectorMemory(uniform(args.vectorMemoryIssued - s0.issuedAt));
+            if (s0.row >= 64u) break;
+            processMedium(s0, ring0);
+            issueMedium(s0, ring0);
+            awaitVectorMemory(uniform(args.vectorMemoryIssued - s1.issuedAt));
+            if (s1.row >= 64u) break;
+            processMedium(s1, ring1);
+            issueMedium(s1, ring1);
+            awaitVectorMemory(uniform(args.vectorMemoryIssued - s2.issuedAt));
+            if (s2.row >= 64u) break;
+            processMedium(s2, ring2);
+            issueMedium(s2, ring2);
+            awaitVectorMemory(uniform(args.vectorMemoryIssued - s3.issuedAt));
+            if (s3.row >= 64u) break;
+            processMedium(s3, ring3);
+            issueMedium(s3, ring3);
         }
         awaitVectorMemory(0u);
     }
