@@ -715,22 +715,61 @@ fsp4InboxReplayKernel(Fsp4Args args, const uint64_t* __restrict__ sorted, uint64
         clock1 = __builtin_readcyclecounter();
     }
     const uint32_t idMask = (1u << nb) - 1u;
-    // Entries are fetched four at a time (independent loads in flight: the loop is latency-bound otherwise) and then
-    // offered one by one, in order.
-    constexpr int kAhead = 4;
-    for (uint64_t i = bound[0];; i += kAhead) {
-        if (__builtin_amdgcn_ballot_w64(i < bound[1]) == 0ull) break;
-        uint64_t e[kAhead];
+    // Row by row, the lanes side by side on ONE cell's entries, 64 at a time (they ascend in the candidate): the cells' inboxes are
+    // of very different lengths -- 240 entries on average at the bench's data and 4 000 for the longest, 930 and 52 000 on 8 tight
+    // clusters -- and with a lane per cell, an entry per turn, the wave took as many turns (each a round trip to the L2) as
+    // its longest inbox had entries: the longest cell of the launch alone was 12 to 38 ms on clustered data.
+    {
+        ReplayArgs rargs;
+        rargs.lists = args.buffers + size_t(block) * 64u * twoK;
+        rargs.inbox = nullptr;
+        rargs.acceptMaxByKey = args.acceptMaxByKey;
+        rargs.keyOfMismatch = args.keyOfMismatch;
+        rargs.k = args.k;
+        rargs.twoK = twoK;
+        rargs.columnShift = 0u;
+        rargs.vectorMemoryIssued = 0u;
+        rargs.firstColumn = 0u;
+        rargs.selfPairs = false;
+        const uint64_t begin = bound[0];
+        const uint32_t mine = uint32_t(bound[1] - bound[0]);
+        uint64_t rowsWithEntries = __builtin_amdgcn_ballot_w64(mine != 0u);
+        while (rowsWithEntries != 0ull) {
+            const uint32_t r = uint32_t(__builtin_ctzll(rowsWithEntries));
+            rowsWithEntries &= rowsWithEntries - 1ull;
+            const uint32_t n = uint32_t(__builtin_amdgcn_readlane(int(mine), int(r)));
+            const uint64_t first = uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(begin)), int(r)))) |
+                                   (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(begin >> 32)), int(r)))) << 32);
+            uint32_t countOfRow = uint32_t(__builtin_amdgcn_readlane(int(count), int(r)));
+            int32_t mMaxOfRow = __builtin_amdgcn_readlane(mMax, int(r));
+            Entry* listRow = rargs.lists + size_t(r) * twoK;
+            const uint64_t* entries = sorted + first;
+            // (four batches at a time, the next four loaded under them -- every lane loads, past the end the last entry again:
+            // one batch ahead, a batch waited for most of a round trip to the L2)
+            uint64_t current[4], ahead[4];
 #pragma unroll
-        for (int q = 0; q < kAhead; ++q) e[q] = (i + q < bound[1]) ? sorted[i + q] : 0ull;
+            for (uint32_t j = 0; j < 4u; j++) {
+                const uint32_t index = 64u * j + lane;
+                current[j] = entries[index < n ? index : n - 1u];
+            }
+            for (uint32_t at = 0; at < n; at += 256u) {
 #pragma unroll
-        for (int q = 0; q < kAhead; ++q) {
-            const bool active = i + q < bound[1];
-            const uint32_t c = uint32_t(e[q] >> 13u) & idMask;
-            const uint32_t m = uint32_t(e[q]) & 0x1fffu;
-            const bool pass = active && int32_t(m) <= mMax;
-            if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
-                acceptColumn<IDENTITY>(pass, c, row, m, lane, block, myList, twoK, count, mMax, ldsRaw);
+                for (uint32_t j = 0; j < 4u; j++) {
+                    const uint32_t index = at + 256u + 64u * j + lane;
+                    ahead[j] = entries[index < n ? index : n - 1u];
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    if (at + 64u * j >= n) break;
+                    offerBatchToRow<IDENTITY>(at + 64u * j + lane < n, uint32_t(current[j] >> 13u) & idMask, uint32_t(current[j]) & 0x1fffu, lane,
+                                              listRow, rargs, countOfRow, mMaxOfRow, ldsRaw);
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) current[j] = ahead[j];
+            }
+            if (lane == r) {
+                count = countOfRow;
+                mMax = mMaxOfRow;
             }
         }
     }

@@ -1032,43 +1032,53 @@ __device__ __forceinline__ void emitBatchToInbox(bool emit, uint32_t col, uint32
     emitEnd = end;
 }
 
+// A batch of one row's candidates, lane by lane in ascending order of the candidate, through the row's exact state machine: the
+// lanes test together against the row's cut-off, what passes is appended to the row's list behind a prefix count, and a list
+// that reaches 2k entries inside the batch is cut right behind the candidate that filled it (src/ExpressionMatrixLsh.cpp:243-251:
+// push, then keepBest at 2k), the lanes behind that candidate testing again against the new cut-off.
+template <bool IDENTITY>
+__device__ __forceinline__ void offerBatchToRow(bool active, uint32_t col, uint32_t m, uint32_t lane, Entry* listRow, ReplayArgs& args,
+                                                uint32_t& count, int32_t& mMax, unsigned char* ldsRaw)
+{
+    const uint32_t twoK = args.twoK;
+    for (;;) {
+        const bool pass = active && int32_t(m) <= mMax;
+        const uint64_t passMask = __builtin_amdgcn_ballot_w64(pass);
+        if (passMask == 0ull) break;
+        const uint32_t passes = uint32_t(__builtin_popcountll(passMask)), room = twoK - count;
+        const uint32_t index = lanesBelow(passMask);
+        if (pass && index < room) {
+            uint32_t entryKey = m;
+            if (!IDENTITY) entryKey = args.keyOfMismatch[m];
+            storeEntry(listRow + count + index, col, entryKey);
+        }
+        args.vectorMemoryIssued += 1u;          // (some lane passed, and the list has room for one at least)
+        if (passes < room) {
+            count += passes;
+            break;
+        }
+        // the list is full behind the candidate of index room - 1: keepBest, the new cut-off, and the lanes behind that candidate again
+        Entry* lds = reinterpret_cast<Entry*>(ldsRaw + size_t(threadIdx.x >> 6) * twoK * kLdsBytesPerEntrySlot);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const uint32_t backKey = cutListToBest((LdsEntryPtr)lds, listRow, twoK, args.k, lane, true);
+        mMax = __builtin_amdgcn_readfirstlane(args.acceptMaxByKey[backKey]);
+        count = args.k;
+        waveLdsFence();
+        const uint32_t filler = uint32_t(__builtin_ctzll(__builtin_amdgcn_ballot_w64(pass && index == room - 1u)));
+        active = active && lane > filler;
+    }
+}
+
 template <bool IDENTITY, int R>
 __device__ __forceinline__ void replayRowElements(const uint32_t (&key)[R], uint32_t n, uint32_t lane, uint32_t rowId, bool emitRow,
                                                   Entry* listRow, ReplayArgs& args, uint32_t& count, int32_t& mMax, uint32_t& emitPos,
                                                   uint32_t& emitEnd, unsigned char* ldsRaw, uint64_t* timed = nullptr)
 {
-    const uint32_t twoK = args.twoK;
 #pragma unroll
     for (int b = 0; b < R; b++) {
         if (64u * uint32_t(b) >= n) break;
         const uint32_t col = (key[b] >> kMergeColumnShift) + args.firstColumn, m = key[b] & kMergeMismatchMask;
-        bool active = 64u * uint32_t(b) + lane < n && !(args.selfPairs && col == rowId);
-        for (;;) {
-            const bool pass = active && int32_t(m) <= mMax;
-            const uint64_t passMask = __builtin_amdgcn_ballot_w64(pass);
-            if (passMask == 0ull) break;
-            const uint32_t passes = uint32_t(__builtin_popcountll(passMask)), room = twoK - count;
-            const uint32_t index = lanesBelow(passMask);
-            if (pass && index < room) {
-                uint32_t entryKey = m;
-                if (!IDENTITY) entryKey = args.keyOfMismatch[m];
-                storeEntry(listRow + count + index, col, entryKey);
-            }
-            args.vectorMemoryIssued += 1u;          // (some lane passed, and the list has room for one at least)
-            if (passes < room) {
-                count += passes;
-                break;
-            }
-            // the list is full behind the record of index room - 1: keepBest, the new cut-off, and the lanes behind that record again
-            Entry* lds = reinterpret_cast<Entry*>(ldsRaw + size_t(threadIdx.x >> 6) * twoK * kLdsBytesPerEntrySlot);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            const uint32_t backKey = cutListToBest((LdsEntryPtr)lds, listRow, twoK, args.k, lane, true);
-            mMax = __builtin_amdgcn_readfirstlane(args.acceptMaxByKey[backKey]);
-            count = args.k;
-            waveLdsFence();
-            const uint32_t filler = uint32_t(__builtin_ctzll(__builtin_amdgcn_ballot_w64(pass && index == room - 1u)));
-            active = active && lane > filler;
-        }
+        offerBatchToRow<IDENTITY>(64u * uint32_t(b) + lane < n && !(args.selfPairs && col == rowId), col, m, lane, listRow, args, count, mMax, ldsRaw);
         if (emitRow) {
             emitBatchToInbox(64u * uint32_t(b) + lane < n && (key[b] & kMergePassBit) != 0u, col, rowId, m, lane, args, emitPos, emitEnd);
         }
