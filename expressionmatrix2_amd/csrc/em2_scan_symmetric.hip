@@ -524,6 +524,13 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                 }
                 recordCount[0] = all ? 0u : firstRecord[0];
                 recordCount[1] = all ? 0u : firstRecord[1];
+                // The rows' cut-offs as they stand, for whoever walks these cells as columns meanwhile: any value a cell held at
+                // some point of its sequence is a valid snapshot, and one published at every replay instead of at the item's end
+                // is a segment fresher when thresholds fall fast (threshold 0: half of all pairs pass a cell's first bound, and
+                // with the cut-offs of an item's start the launch's first items alone filled the pool of deferred candidates).
+                if (haveState && !fullRows && rowValid && !failed) {
+                    __hip_atomic_store(aux->snap + row, mMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             EM2_PHASE(4);
             if (at >= rangeEnd) {
