@@ -59,9 +59,9 @@ VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9     # 256 CUs x 4 SIMD x 16 lanes/clk
 # The PMC digests `traffic` may come from (tools/profile_bench.sh -> tools/profile_digest.py), one per workload; each names
 # the configuration it was taken on and is used for that configuration only (tests/test_bench_plumbing_cpu.py).
 PROFILE_DIGESTS = {
-    "fsp4": "r05_pmc_bench_1Mcells_1gpu.json",
+    "fsp4": "r06_pmc_bench_1Mcells_1gpu.json",
     "fsp5": "r05_pmc_bench_fsp5_1Mcells_2048bit.json",
-    "chain": "r05_pmc_bench_chain_1Mcells.json",
+    "chain": "r06_pmc_bench_chain_1Mcells.json",
 }
 def usable_cpus():
     """The host threads worth starting: os.cpu_count(), or the CPU quota of the control group when that is smaller (the GPU boxes
