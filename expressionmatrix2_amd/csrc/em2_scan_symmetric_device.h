@@ -1269,9 +1269,6 @@ __device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32
         rowsWithShortLogs |= (rowsSome & ~rowsOver16) << (32u * a);
     }
     if ((rowsWithShortLogs | rowsWithMediumLogs | rowsWithRecords | rowsWithLongLogs) == 0ull) return;
-#ifdef EM2_REPLAY_PRIORITY
-    __builtin_amdgcn_s_setprio(EM2_REPLAY_PRIORITY);
-#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (the logs: written by other lanes, read here with plain loads)
     const uint64_t validRows = __builtin_amdgcn_ballot_w64(rowValid);
     const uint32_t rowOfWave = uniform(row - lane);
@@ -1601,9 +1598,6 @@ __device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32
                                        listOfWave + size_t(r) * twoK, args, countOfRow, mMaxOfRow, emitPos, emitEnd, ldsRaw, timed);
         keepRowState(r, countOfRow, mMaxOfRow);
     }
-#ifdef EM2_REPLAY_PRIORITY
-    __builtin_amdgcn_s_setprio(0);
-#endif
 }
 
 // The tile kernel of the sharded scan defers both sides: every lane empties its own two logs, order is irrelevant (the
