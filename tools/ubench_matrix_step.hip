@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) stepLoop(int rounds, int mode, float boun
     const unsigned long long rowAddress = uniform64(reinterpret_cast<unsigned long long>(rows) + size_t(blockIdx.x * 4 + wave) * 32768);
     const unsigned long long logBase = uniform64(reinterpret_cast<unsigned long long>(logs) + size_t(blockIdx.x * 4 + wave) * 64 * 4096 * EM2_MATRIX_RECORD_BYTES);
     asm volatile(EM2_MATRIX_LOAD_ROWS : : "s"(rowAddress) : EM2_MATRIX_STEP_CLOBBERS);
-    unsigned offset = lane * 4096 * 8, offset1 = lane * 4096 * 8 + 2048 * 8;
+    unsigned offset = lane * 4096 * EM2_MATRIX_RECORD_BYTES, offset1 = lane * 4096 * EM2_MATRIX_RECORD_BYTES + 2048 * EM2_MATRIX_RECORD_BYTES;
     asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(offset), "v"(offset1) : EM2_MATRIX_OWNED_REGISTERS);
     unsigned long long scratch[5];
     unsigned recordOffset = offset, recordOffset1 = offset1;
@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) stepLoop(int rounds, int mode, float boun
                            "s"(unsigned(r) * 64u + 32u)
                          : EM2_MATRIX_STEP_CLOBBERS);
             if ((r & 15) == 15) {
-                counts[(blockIdx.x * 4 + wave) * 64 + lane] += (recordOffset - offset) / 8 + (recordOffset1 - offset1) / 8;
+                counts[(blockIdx.x * 4 + wave) * 64 + lane] += (recordOffset - offset) / EM2_MATRIX_RECORD_BYTES + (recordOffset1 - offset1) / EM2_MATRIX_RECORD_BYTES;
                 asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(offset), "v"(offset1) : EM2_MATRIX_OWNED_REGISTERS);
             }
 #endif
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) stepLoop(int rounds, int mode, float boun
                          : "s"(t1), "s"(walkLds + 256 + 128), "s"(walkLds), "s"(logBase), "s"(unsigned(r) * 64u + 32u | UBENCH_TILE_BIT)
                          : EM2_MATRIX_STEP_CLOBBERS);
             if ((r & 15) == 15) {       // (the log of a lane holds 4096 records: start over)
-                counts[(blockIdx.x * 4 + wave) * 64 + lane] += (recordOffset - offset) / 8 + (recordOffset1 - offset1) / 8;
+                counts[(blockIdx.x * 4 + wave) * 64 + lane] += (recordOffset - offset) / EM2_MATRIX_RECORD_BYTES + (recordOffset1 - offset1) / EM2_MATRIX_RECORD_BYTES;
                 asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(offset), "v"(offset1) : EM2_MATRIX_OWNED_REGISTERS);
             }
         }
@@ -149,7 +149,8 @@ int main(int argc, char** argv)
     const float mean = argc > 6 ? float(atof(argv[5])) : 0.f, sigma = argc > 6 ? float(atof(argv[6])) : 32.f;
     run("tests, nothing passes", 2, rounds, 1, 1e9f, dTiles, dRows, dLogs, dCounts);
     run("pair: tests, nothing passes", 2, rounds, 2, 1e9f, dTiles, dRows, dLogs, dCounts);
-    const float sigmas[] = {3.5f, 3.0f, 2.5f};
+    // (3.28 sigma: about one record per wave and tile, the rate of the bench's data in round 6's diagnostic build)
+    const float sigmas[] = {3.5f, 3.28f, 3.0f, 2.5f};
     for (float s : sigmas) {
         char name[64];
         snprintf(name, sizeof(name), "events, bound %.1f sigma", s);
