@@ -21,7 +21,7 @@ imported torch or touched a GPU -- relays its output (rank 0's one JSON line) an
 
 Also on the JSON line:
     roofline      the dominant kernel.  1 GPU, 129..2048-bit signatures: fsp4ScanMatrixPinnedKernel / fsp4ScanMatrixWideKernel,
-                  the triangle part of the scan as FP4 +-1 dot products on the matrix cores -- bound "mfma": 2 x 1024 (2048)
+                  the triangle part of the scan as FP4 dot products (0 / 1 operands up to 1024 bits, +-1 above) on the matrix cores -- bound "mfma": 2 x 1024 (2048)
                   flop per (row, column) pair the launcher counted / the kernel's duration (HIP events on the launch stream,
                   recorded inside the library) against the dense FP4 MFMA peak (10 PFLOP/s), with the in-kernel clock and the
                   fraction at that clock beside it; `hbm_view` keeps SURVEY.md 8(d)'s byte model (2*8*W bytes per unordered
@@ -964,7 +964,7 @@ def bench_chain_ranks(args, capi, sharded, synthetic, oracle, device, torch, dis
         "metric": "cells/sec through findSimilarPairs4 -> createCellGraph -> labelPropagationClustering",
         "value": C * args.steps / elapsed, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "fp4 e2m1 +-1 products, f32 accumulate, exact (scan) / f32 similarities", "data": "synthetic",
+        "dtype": "fp4 e2m1 0/1 products, f32 accumulate, exact (scan) / f32 similarities", "data": "synthetic",
         "config": {"workload": "BASELINE configs[4]: %d synthetic cells x %d genes, %d-bit signatures, findSimilarPairs4 k=%d threshold=%g "
                                "(rows sharded over %d GPUs) -> all-gather of the pairs -> createCellGraph(threshold %g, k=%d) -> label "
                                "propagation on rank 0" % (C, G, L, k, thr, world, thr, args.graph_k),
@@ -1250,7 +1250,8 @@ def main():
                         "(recorded inside the library for the symmetric form, around the call otherwise)",
         }
         if matrix:
-            result["dtype"] = "fp4 e2m1 +-1 products, f32 accumulate, exact (scan on the matrix cores) / u32 popcount (band, full rows) / f64 (projection)"
+            result["dtype"] = ("fp4 e2m1 %s products, f32 accumulate, exact (scan on the matrix cores) / u32 popcount (band, full rows) / f64 (projection)"
+                               % ("+-1" if L > 1024 else "0/1"))
         matrix_traffic = None
         matrix_traffic_source = None
         pinned_walk = True
@@ -1262,10 +1263,12 @@ def main():
                 matrix_traffic_source = "profiles/%s (tools/profile_bench.sh: %s)" % (PROFILE_DIGESTS["fsp4"], TRAFFIC_NOTE)
         if matrix and launch["matrix_kernel_ms"] > 0:
             # Dominant kernel: fsp4ScanMatrixKernel, bound by the matrix cores.  One (row, column) pair = a 1024-long dot
-            # product of FP4 +-1 values = 2 * 1024 flop on v_mfma_scale_f32_32x32x64_f8f6f4; peak = the dense FP4 MFMA
+            # product of FP4 0 / 1 values = 2 * 1024 flop on v_mfma_f32_32x32x64_f8f6f4; peak = the dense FP4 MFMA
             # figure of MI355X_MICROARCH.md (10 PFLOP/s).  The HBM / instruction view of the same launch rides along.
             # (signatures of 1025..2048 bits: fsp4ScanMatrixWideKernel, a 2048-long contraction per pair)
             contraction = 2048.0 if L > 1024 else 1024.0
+            operand_note = ("+-1 operands: 2048 - 2 * mismatches" if L > 1024 else
+                            "0 / 1 operands, the accumulator starts at -(popcount(row) + popcount(column)) / 2 and ends at -mismatches / 2")
             flops = launch["matrix_pairs"] * 2.0 * contraction
             tflops = flops / (launch["matrix_kernel_ms"] * 1e-3) / 1e12
             result["roofline"] = {
@@ -1273,12 +1276,12 @@ def main():
                           ("fsp4ScanMatrixPinnedKernel<true>" if pinned_walk else "fsp4ScanMatrixKernel<true>"),
                 "kernel_ms": launch["matrix_kernel_ms"],
                 "form": ("row shards on the matrix cores (north_star's partitioning): every row of the rank's contiguous shard walks ALL "
-                         "columns in ascending order as FP4 +-1 dot products (%d - 2 * mismatches, exact in f32), i.e. each unordered "
-                         "pair is evaluated once per side across the node; no inbox, no sort, no second kernel" % int(contraction))
+                         "columns in ascending order as FP4 dot products over %d bits (%s; exact in f32), i.e. each unordered "
+                         "pair is evaluated once per side across the node; no inbox, no sort, no second kernel" % (int(contraction), operand_note))
                         if rows_matrix else
-                        "symmetric, triangle part on the matrix cores: every unordered pair evaluated once as an FP4 +-1 dot "
-                        "product (%d - 2 * mismatches, exact in f32); the first cells' full rows and each quad's own 256 columns "
-                        "stay on v_xor/v_bcnt; inbox sort + replay follow" % int(contraction),
+                        "symmetric, triangle part on the matrix cores: every unordered pair evaluated once as an FP4 dot "
+                        "product over %d bits (%s; exact in f32); the first cells' full rows and each quad's own 256 columns "
+                        "stay on v_xor/v_bcnt; inbox sort + replay follow" % (int(contraction), operand_note),
                 "bound": "mfma",
                 "achieved": tflops,
                 "peak": MFMA_FP4_PEAK_TFLOPS,
@@ -1307,7 +1310,7 @@ def main():
             # scan time of the rank (phases 0..3 and the collectives between them; no per-kernel events here).
             flops = launch["matrix_pairs"] * 2.0 * 1024.0
             tflops = flops / (scan_ms * 1e-3) / 1e12
-            result["dtype"] = "fp4 e2m1 +-1 products, f32 accumulate, exact (phases 1-2 on the matrix cores) / u32 popcount (phase 0, bands) / f64 (projection)"
+            result["dtype"] = "fp4 e2m1 0/1 products, f32 accumulate, exact (phases 1-2 on the matrix cores) / u32 popcount (phase 0, bands) / f64 (projection)"
             result["roofline"] = {
                 "kernel": "fsp4ScanMatrixKernel<true> + fsp4TileMatrixKernel (rank 0)",
                 "kernel_ms": scan_ms,

@@ -57,7 +57,7 @@ size_t fsp4ControlBytes(uint32_t rowCount);
 size_t fsp4SymmetricBytes(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw);
 bool fsp4UsesSymmetricScan(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw);
 // Whether a launch of rowCount rows against cellCount columns that is not symmetric takes the rows form on the matrix
-// cores (form 4: every row walks all columns as FP4 +-1 dot products); fsp4SymmetricBytes then sizes its workspace.
+// cores (form 4: every row walks all columns as FP4 dot products); fsp4SymmetricBytes then sizes its workspace.
 bool fsp4UsesRowsMatrixScan(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw);
 // Whether signatures of this padded width take the matrix-core form of the symmetric scan (EM2_SCAN_MATRIX included).
 bool fsp4MatrixFormWanted(uint32_t paddedDw);
@@ -83,7 +83,7 @@ struct Fsp4ShardPlan {
     uint32_t blocks, prefixBlocks, prefixCells, ownBlocks, maxOwnBlocks, ownPrefixBlocks;
     uint64_t capLocal, capGathered;
     size_t sortTempBytes;
-    size_t offLists, offControl, offSnap, offTable, offInboxControl, offPool, offFragments, rankBytes, offGathered, offSorted, offTemp, totalBytes;
+    size_t offLists, offControl, offSnap, offTable, offInboxControl, offPool, offFragments, offTerms, rankBytes, offGathered, offSorted, offTemp, totalBytes;
 };
 Fsp4ShardPlan fsp4ShardPlan(uint32_t cellCount, uint32_t k, uint32_t rank, uint32_t world);
 hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint32_t* sig32, uint32_t paddedDw,

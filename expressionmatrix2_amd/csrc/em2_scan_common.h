@@ -59,7 +59,8 @@ struct Fsp4Args {
     uint32_t columnLimit;       // columns [0, columnLimit) only (symmetric kernels)
     uint32_t shardFlags;        // kShardNoFinish | kShardPublishAll | kShardGlobalOutput
     // matrix-core form of the symmetric scan only (em2_scan_symmetric.hip)
-    const void* fragments;      // the signatures as FP4 +-1 in MFMA fragment order, 512 B per cell
+    const void* fragments;      // the signatures as FP4 in MFMA fragment order: 0 / 1, 512 B per cell (1024-bit steps); +-1, 1 KB per cell (2048-bit steps)
+    const float* terms;         // 1024-bit steps: -popcount / 2 of every cell's signature, padded with the last cell's to a multiple of 64 cells + 64
     uint32_t matrixLdsOffset;   // where the column tiles start in the block's dynamic LDS
     uint32_t pad1;
     uint32_t convoy;            // matrix form: 0 = every walk starts at its segment's first column; 1 = a walk joins the walks of its XCD

@@ -247,6 +247,8 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
         const bool last = quadRowBase < colEnd;
         const uint32_t commonEnd = last ? quadRowBase : colEnd;
         const int32_t snapRow = rowValid ? aux->snap[row] : -1;
+        // (1024 bits: -popcount / 2 of the lane's row; a row that is none starts so low that its results pass no bound)
+        const float rowTerm = WIDE ? 0.f : rowValid ? aux->terms[row] : -4096.f;
         if (colBegin < commonEnd) {
             {
                 // the walk logs what passes either bound; both sides of every record go to the inbox afterwards
@@ -274,13 +276,13 @@ __device__ __forceinline__ void tileMatrixBody(unsigned char* ldsRaw)
                                                                    2.f * kMatrixBits - 2.f * float(snapRow), rowHalf, waveLog, logCapacity, records,
                                                                    ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)), ldsAddress(walkBlock));
                         } else if (EM2_DIAG_WORD(aux)) {
-                            next = scanTilesMatrixPinned<true, true, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, end,
-                                                               2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), waveLog, logCapacity,
+                            next = scanTilesMatrixPinned<true, true, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, aux->terms, at, end,
+                                                               2u * fragmentBlock, matrixBoundOf<false>(snapRow), rowTerm, waveLog, logCapacity,
                                                                records, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                                ldsAddress(walkBlock));
                         } else {
-                            next = scanTilesMatrixPinned<true, true, false>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, end,
-                                                               2u * fragmentBlock, kMatrixBits - 2.f * float(snapRow), waveLog, logCapacity,
+                            next = scanTilesMatrixPinned<true, true, false>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, aux->terms, at, end,
+                                                               2u * fragmentBlock, matrixBoundOf<false>(snapRow), rowTerm, waveLog, logCapacity,
                                                                records, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                                ldsAddress(walkBlock));
                         }
@@ -432,6 +434,7 @@ Fsp4ShardPlan fsp4ShardPlan(uint32_t cellCount, uint32_t k, uint32_t rank, uint3
     p.offInboxControl = at; at += 256u;
     p.offPool = at;         at += align256(size_t(p.capLocal) * 8u);
     p.offFragments = at;    at += align256(size_t(p.blocks) * 64u * 1024u);     // FP4 fragments of up to 2048 bits (matrix-core kernels)
+    p.offTerms = at;        at += align256(matrixTermCount(p.blocks * 64u) * 4u);       // ... and the 1024-bit steps' terms
     p.rankBytes = at;
     p.offGathered = at;     at += align256(size_t(p.capGathered) * 8u);
     p.offSorted = at;       at += align256(size_t(p.capGathered) * 8u);
@@ -570,9 +573,11 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
             if (e != hipSuccess) return e;
             const uint32_t matrixSteps = wide ? 2u * kMatrixSteps : kMatrixSteps;
             const uint32_t fragmentCount = plan.blocks * 2u * matrixSteps * 64u;
-            e = launchExpandFragments(sig32, cellCount, fragmentCount, ws + plan.offFragments, matrixSteps, stream);
+            e = launchExpandFragments(sig32, cellCount, fragmentCount, ws + plan.offFragments, matrixSteps,
+                                      reinterpret_cast<float*>(ws + plan.offTerms), stream);
             if (e != hipSuccess) return e;
             args.fragments = ws + plan.offFragments;
+            args.terms = reinterpret_cast<const float*>(ws + plan.offTerms);
             args.matrixLdsOffset = uint32_t(matrixLdsOffset);
             // No convoy here unless a test forces one (EM2_MATRIX_CONVOY >= 2): these launches are a few items per block, which
             // start together and stay together (measured at 1M cells, four ranks: 16.2 ms per launch without, 16.8 with it).
@@ -691,9 +696,11 @@ hipError_t launchFsp4ShardPhase(const Fsp4ShardPlan& plan, int phase, const uint
         if (matrix) {
             const uint32_t matrixSteps = wide ? 2u * kMatrixSteps : kMatrixSteps;
             const uint32_t fragmentCount = plan.blocks * 2u * matrixSteps * 64u;
-            e = launchExpandFragments(sig32, cellCount, fragmentCount, ws + plan.offFragments, matrixSteps, stream);
+            e = launchExpandFragments(sig32, cellCount, fragmentCount, ws + plan.offFragments, matrixSteps,
+                                      reinterpret_cast<float*>(ws + plan.offTerms), stream);
             if (e != hipSuccess) return e;
             args.fragments = ws + plan.offFragments;
+            args.terms = reinterpret_cast<const float*>(ws + plan.offTerms);
             args.matrixLdsOffset = 0u;
             // the tiles' walks go around their segments in convoys (scanMatrixBody; 30.5 -> 29.8 ms per launch at 1M cells, four
             // ranks); the position words start at zero

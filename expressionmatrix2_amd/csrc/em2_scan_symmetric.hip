@@ -265,8 +265,9 @@ fsp4ScanSymmetricKernel(Fsp4Args args)
 }
 
 // sig32 [cell][2 * steps] -> fragments [cell / 32][k-step][lane]: lane l of k-step s holds cell (l & 31) of the block, bits
-// s*64 + (l >> 5)*32 .. +31, one nibble per bit (0x2 = +1, 0xA = -1).  Cells past the end repeat the last one.
-// steps = 16 (1024 bits) or 32 (2048 bits).
+// s*64 + (l >> 5)*32 .. +31, one FP4 nibble per bit.  Cells past the end repeat the last one.
+// steps = 16 (1024 bits): a bit is 0x0 = 0 / 0x2 = 1 (the steps count popcount(row & column): em2_matrix_step_asm.h,
+// EM2_MATRIX_ZERO_ONE); steps = 32 (2048 bits): 0x2 = +1 / 0xA = -1.
 __global__ void __launch_bounds__(256)
 expandFragmentsKernel(const uint32_t* __restrict__ sig32, uint32_t cellCount, uint32_t fragmentCount,
                       FragmentWord4* __restrict__ out, uint32_t steps = kMatrixSteps)
@@ -277,15 +278,30 @@ expandFragmentsKernel(const uint32_t* __restrict__ sig32, uint32_t cellCount, ui
     uint32_t cell = block * 32u + (lane & 31u);
     if (cell >= cellCount) cell = cellCount - 1u;
     const uint32_t word = sig32[size_t(cell) * (2u * steps) + step * 2u + (lane >> 5)];
+    const bool zeroOne = EM2_MATRIX_ZERO_ONE && steps == kMatrixSteps;
+    const uint32_t zero = zeroOne ? 0x0u : 0x2u, one = zeroOne ? 0x2u : 0xAu;
     FragmentWord4 v;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
         uint32_t packed = 0;
 #pragma unroll
-        for (int n = 0; n < 8; n++) packed |= (((word >> (d * 8 + n)) & 1u) ? 0xAu : 0x2u) << (4 * n);
+        for (int n = 0; n < 8; n++) packed |= (((word >> (d * 8 + n)) & 1u) ? one : zero) << (4 * n);
         v[d] = int(packed);
     }
     out[i] = v;
+}
+
+// The column (and row) terms of the 0 / 1 steps: -popcount / 2 of every cell's signature (sig32 [cell][dwords]); entries past
+// the last cell repeat it, as the fragments do.
+__global__ void __launch_bounds__(256)
+signatureTermsKernel(const uint32_t* __restrict__ sig32, uint32_t dwords, uint32_t cellCount, uint32_t termCount, float* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= termCount) return;
+    const uint32_t cell = i < cellCount ? i : cellCount - 1u;
+    uint32_t bits = 0;
+    for (uint32_t w = 0; w < dwords; ++w) bits += uint32_t(__builtin_popcount(sig32[size_t(cell) * dwords + w]));
+    out[i] = -0.5f * float(bits);
 }
 
 // sig32 [cell][paddedDw] -> [cell][32], zero-extended: what the matrix kernel's v_xor/v_bcnt parts and the fragment
@@ -441,6 +457,8 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
         bool lower = false;                     // the walk has gone around: [colBegin, start) now
         uint32_t firstRecord[2] = {0u, 0u};     // the lane's records when it did
         uint32_t rowHalf = 0;           // (2048 bits: the columns are walked once per half of the wave's rows)
+        // (1024 bits: -popcount / 2 of the lane's row; a row that is none starts so low that its results pass no bound)
+        const float rowTerm = WIDE ? 0.f : rowValid ? aux->terms[row] : -4096.f;
         EM2_PHASE(1);
         for (;;) {
             if (at < rangeEnd) {
@@ -451,13 +469,13 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                                                        ldsAddress(walkBlock));
                 } else {
                     if (EM2_DIAG_WORD(aux)) {
-                        at = scanTilesMatrixPinned<IDENTITY, false, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, rangeEnd,
-                                                         rowFragmentBlock, kMatrixBits - 2.f * float(mMax), waveLog,
+                        at = scanTilesMatrixPinned<IDENTITY, false, true>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, aux->terms, at, rangeEnd,
+                                                         rowFragmentBlock, matrixBoundOf<false>(mMax), rowTerm, waveLog,
                                                          logCapacity, recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                          ldsAddress(walkBlock));
                     } else {
-                        at = scanTilesMatrixPinned<IDENTITY, false, false>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, at, rangeEnd,
-                                                         rowFragmentBlock, kMatrixBits - 2.f * float(mMax), waveLog,
+                        at = scanTilesMatrixPinned<IDENTITY, false, false>((const void*)(uintptr_t)aux, aux->fragments, aux->snap, aux->terms, at, rangeEnd,
+                                                         rowFragmentBlock, matrixBoundOf<false>(mMax), rowTerm, waveLog,
                                                          logCapacity, recordCount, ldsAddress(tiles), ldsAddress(const_cast<uint32_t*>(shared)),
                                                          ldsAddress(walkBlock));
                     }
@@ -474,9 +492,15 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
                 at &= ~kWalkInLowerColumns;
                 lower = true;
                 rangeEnd = start;
-                const volatile uint32_t* counts = reinterpret_cast<const volatile uint32_t*>(walkBlock + kWalkWrapCounts);
-                firstRecord[0] = WIDE && rowHalf != 0u ? 0u : counts[lane];
-                firstRecord[1] = WIDE && rowHalf == 0u ? 0u : counts[64u + lane];
+                if (WIDE) {
+                    const volatile uint32_t* counts = reinterpret_cast<const volatile uint32_t*>(walkBlock + kWalkWrapCounts);
+                    firstRecord[0] = rowHalf != 0u ? 0u : counts[lane];
+                    firstRecord[1] = rowHalf == 0u ? 0u : counts[64u + lane];
+                } else {
+                    const volatile uint8_t* counts = walkBlock + kWalkWrapCounts8;
+                    firstRecord[0] = counts[lane];
+                    firstRecord[1] = counts[64u + lane];
+                }
             }
             const bool stopped = at < rangeEnd;                           // (for its logs; the same in all waves of the block)
             if (TIMED && stopped) phaseCycles[7] += 1u;
@@ -847,7 +871,7 @@ static uint64_t inboxCapacity(uint32_t cellCount)
 
 
 struct SymmetricLayout {
-    size_t snap, table, tableMatrix, control, poolA, poolB, temp, fragments, widened, total, tempBytes;
+    size_t snap, table, tableMatrix, control, poolA, poolB, temp, fragments, terms, widened, total, tempBytes;
     uint64_t capacity;
 };
 
@@ -866,6 +890,7 @@ static SymmetricLayout symmetricLayout(uint32_t cellCount, uint32_t paddedDw)
     l.temp = at;    at += align256(l.tempBytes);
     // FP4 fragments, matrix form: 4 bits per signature bit
     l.fragments = at; at += align256(size_t((cellCount + 63u) / 64u) * 64u * (matrixWideWanted(paddedDw) ? 1024u : 512u));
+    l.terms = at;     at += align256(matrixTermCount(cellCount) * 4u);
     // signatures zero-extended to 1024 bits for the v_xor/v_bcnt parts of the matrix kernel (a quad's own 256 columns)
     l.widened = at;
     if (paddedDw < 32u && matrixFormWanted(paddedDw)) at += align256(size_t(cellCount) * 128u);
@@ -901,7 +926,7 @@ bool rowsMatrixEligible(uint32_t cellCount, uint32_t rowCount, uint32_t paddedDw
 }
 
 struct RowsMatrixLayout {
-    size_t snap, table, control, fragments, rowFragments, widened, total;
+    size_t snap, table, control, fragments, terms, rowFragments, widened, total;
 };
 
 // (rows that are not all cells get room for a copy of their fragments: a rowBegin that is no multiple of 32 cannot
@@ -915,10 +940,11 @@ static RowsMatrixLayout rowsMatrixLayout(uint32_t cellCount, uint32_t rowCount, 
     l.table = at;     at += align256(kTableWords * 4u);
     l.control = at;   at += 256u;
     l.fragments = at; at += size_t((cellCount + 63u) / 64u) * 64u * bytesPerCell;
-    l.rowFragments = at;
+    l.rowFragments = at;          // (whole 32-cell blocks behind the columns' fragments: Fsp4Args::rowFragmentBase counts them)
     if (rowCount < cellCount) at += size_t((rowCount + 63u) / 64u) * 64u * bytesPerCell;
     l.widened = at;
     if (paddedDw < 32u && matrixFormWanted(paddedDw)) at += align256(size_t(cellCount) * 128u);
+    l.terms = at;     at += align256(matrixTermCount(cellCount) * 4u);
     l.total = at;
     return l;
 }
@@ -1146,10 +1172,10 @@ hipError_t launchFsp4ScanSymmetric(Fsp4Args args, uint32_t paddedDw, bool identi
             if (e != hipSuccess) return e;
             matrixArgs.sig32 = widened;
         }
-        expandFragmentsKernel<<<dim3((fragmentCount + 255u) / 256u), dim3(256), 0, stream>>>(
-            matrixArgs.sig32, cellCount, fragmentCount, reinterpret_cast<FragmentWord4*>(ws + layout.fragments), matrixSteps);
-        e = hipGetLastError();
+        e = launchExpandFragments(matrixArgs.sig32, cellCount, fragmentCount, ws + layout.fragments, matrixSteps,
+                                  reinterpret_cast<float*>(ws + layout.terms), stream);
         if (e != hipSuccess) return e;
+        matrixArgs.terms = reinterpret_cast<const float*>(ws + layout.terms);
         matrixArgs.segTable = reinterpret_cast<const uint32_t*>(ws + layout.tableMatrix);
         matrixArgs.segments = uint32_t(segmentsMatrix);
         matrixArgs.columnsPerSegment = cpsMatrix;
@@ -1320,16 +1346,18 @@ hipError_t launchFsp4ScanRowsMatrix(Fsp4Args args, uint32_t paddedDw, bool ident
     if (!(matrixFormWanted(paddedDw) || wide) || wavesPerBlock != 4u ||
         ((lds + 15u) & ~size_t(15)) + scanMatrixLdsBytes(args.k) > 150u * 1024u) return hipSuccess;
     char* ws = static_cast<char*>(ws_);
-    char *snapArea, *tableArea, *controlArea, *fragmentArea, *rowFragmentArea, *widenedArea;
+    char *snapArea, *tableArea, *controlArea, *fragmentArea, *rowFragmentArea, *widenedArea, *termArea;
     if (symmetricWorkspace) {
         const SymmetricLayout l = symmetricLayout(cellCount, paddedDw);
         snapArea = ws + l.snap; tableArea = ws + l.tableMatrix; controlArea = ws + l.control;
         fragmentArea = ws + l.fragments; rowFragmentArea = nullptr; widenedArea = ws + l.widened;
+        termArea = ws + l.terms;
         if (args.rowBegin != 0u) return hipErrorInvalidValue;
     } else {
         const RowsMatrixLayout l = rowsMatrixLayout(cellCount, rows, paddedDw);
         snapArea = ws + l.snap; tableArea = ws + l.table; controlArea = ws + l.control;
         fragmentArea = ws + l.fragments; rowFragmentArea = rows < cellCount ? ws + l.rowFragments : nullptr; widenedArea = ws + l.widened;
+        termArea = ws + l.terms;
     }
     const void* matrixKernel = scanMatrixKernelFor(identity, wide);
     const size_t matrixLdsOffset = (lds + 15u) & ~size_t(15);
@@ -1444,15 +1472,14 @@ hipError_t launchFsp4ScanRowsMatrix(Fsp4Args args, uint32_t paddedDw, bool ident
     {
         const uint32_t columnBlocks = (cellCount + 63u) / 64u;
         const uint32_t fragmentCount = columnBlocks * 2u * matrixSteps * 64u;
-        expandFragmentsKernel<<<dim3((fragmentCount + 255u) / 256u), dim3(256), 0, stream>>>(
-            args.sig32, cellCount, fragmentCount, reinterpret_cast<FragmentWord4*>(fragmentArea), matrixSteps);
-        e = hipGetLastError();
+        e = launchExpandFragments(args.sig32, cellCount, fragmentCount, fragmentArea, matrixSteps, reinterpret_cast<float*>(termArea), stream);
         if (e != hipSuccess) return e;
+        args.terms = reinterpret_cast<const float*>(termArea);
     }
     // The rows' fragments are addressed in place -- inside the columns' array -- only when every 64-row block of the launch
     // lies within that array: a shard that begins at 32 (mod 64) and ends with the cells would otherwise read 32 cells past
     // it, into workspace nobody wrote (expandFragmentsKernel pads with copies of the last cell, so that a padded lane only
-    // ever holds +-1 operands and cannot pass a bound; stale FP4 magnitudes could).
+    // ever holds the operands of a signature and cannot pass a bound; stale FP4 magnitudes could).
     const bool rowsInPlace = args.rowBegin % 32u == 0u &&
                              uint64_t(args.rowBegin) + 64ull * rowBlocks <= uint64_t((cellCount + 63u) / 64u) * 64u;
     if (rowsInPlace) {
@@ -1526,10 +1553,15 @@ const void* fsp4SymmetricKernelFor(uint32_t paddedDw, bool identity)
 }
 
 hipError_t launchExpandFragments(const uint32_t* sig32, uint32_t cellCount, uint32_t fragmentCount, void* out, uint32_t steps,
-                                 hipStream_t stream)
+                                 float* terms, hipStream_t stream)
 {
     expandFragmentsKernel<<<dim3((fragmentCount + 255u) / 256u), dim3(256), 0, stream>>>(sig32, cellCount, fragmentCount,
                                                                                          static_cast<FragmentWord4*>(out), steps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !terms) return e;
+    // (matrixTermCount(cellCount) entries; the 2048-bit steps never read them)
+    const uint32_t termCount = uint32_t(matrixTermCount(cellCount));
+    signatureTermsKernel<<<dim3((termCount + 255u) / 256u), dim3(256), 0, stream>>>(sig32, 2u * steps, cellCount, termCount, terms);
     return hipGetLastError();
 }
 

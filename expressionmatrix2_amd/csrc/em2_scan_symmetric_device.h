@@ -243,10 +243,13 @@ __device__ __forceinline__ uint32_t unpark(uint32_t v)
 
 
 // =========================================================================================================
-// Matrix-core form of the triangle part (1024-bit signatures).  A signature bit becomes the FP4 (E2M1) value +1 or -1;
-// the dot product of two cells over the 1024 (padded) bits is 1024 - 2m, exact in the f32 accumulator, and
-// v_mfma_scale_f32_32x32x64_f8f6f4 (scales 2^0) contracts 64 bits of 32 x 32 cells per instruction: 8 times the
-// pairs per SIMD clock of the v_xor/v_bcnt loop at its instruction floor (tools/ubench_mfma_pairs.hip).
+// Matrix-core form of the triangle part (1024-bit signatures).  A signature bit becomes the FP4 (E2M1) value 0 or 1
+// (round 6; +1 / -1 before, and still in the 2048-bit form): the dot product of two cells over the 1024 (padded) bits is
+// popcount(a & b) and m = popcount(a) + popcount(b) - 2 dot, so an accumulator that STARTS at -(popcount(a) + popcount(b)) / 2
+// ends at -m / 2, exact in f32 (matrixBoundOf, mismatchesOfMatrixResult); v_mfma_f32_32x32x64_f8f6f4 contracts 64 bits of
+// 32 x 32 cells per instruction: 8 times the pairs per SIMD clock of the v_xor/v_bcnt loop at its instruction floor
+// (tools/ubench_mfma_pairs.hip).  On 0 / 1 operands the matrix pipe holds 2.37 GHz where +-1 held 2.25 (fewer products that
+// change sign); the terms cost 32 vector instructions and four LDS reads per tile (profiles/r06_scan_experiments.md, 4).
 //
 // The contract of the scan does not change, only who counts.  A block of 4 waves owns 4 consecutive triangle row
 // blocks (a "quad", 256 cells); its waves walk the columns below the quad in lock step, 32 at a time: the tile's
@@ -314,6 +317,7 @@ constexpr uint32_t kMatrixLogMargin = 96u;
 constexpr uint32_t kClockWordsOffset = 32u;     // in 32-bit words
 
 typedef const __attribute__((address_space(3))) int32_t* LdsIntPtr;
+typedef volatile __attribute__((address_space(3))) uint8_t* LdsBytePtr;
 
 // LDS byte address -> pointer (32 bits on the device; the detour keeps the host pass of the compiler quiet)
 template <typename P>
@@ -323,11 +327,33 @@ __device__ __forceinline__ P ldsPointer(uint32_t address)
 }
 
 // Per-wave LDS block of the walk (byte offsets).
-constexpr uint32_t kWalkRowDot = 0u;            // float[64]: bound of row r as a dot product (1024 - 2 mMax), read by the steps
-constexpr uint32_t kWalkBounds = 256u;          // float[4][32]: column bounds of the four tile buffers (as dot products)
-constexpr uint32_t kWalkSnapStage = 768u;       // int32[2][64]: the published cut-offs of a pair of tiles, as loaded
+constexpr uint32_t kWalkRowDot = 0u;            // float[64]: bound of row r in the accumulators' unit (matrixBoundOf), read by the steps
+constexpr uint32_t kWalkBounds = 256u;          // float[4][32]: column bounds of the four tile buffers (same unit)
+constexpr uint32_t kWalkSnapStage = 768u;       // int32[64] (1024-bit walk) / int32[2][64] (2048-bit walk): published cut-offs as loaded
+// the 2048-bit walk (+-1 operands):
 constexpr uint32_t kWalkWrapCounts = 1280u;     // uint32[2][64]: a walk that went around -- the lanes' records per accumulator when it did
-constexpr uint32_t kMatrixWalkLdsBytes = 1792u;
+// the 1024-bit walk (0 / 1 operands):
+constexpr uint32_t kWalkTermRing = 1024u;       // float[3][64]: the column terms (-popcount / 2) of three pairs of tiles, as loaded
+constexpr uint32_t kWalkWrapCounts8 = 1792u;    // uint8[2][64]: the same counts as kWalkWrapCounts (a log holds 128 records)
+constexpr uint32_t kMatrixWalkLdsBytes = 1920u;
+static_assert(kLogCapacity / 2u <= 255u, "kWalkWrapCounts8 holds a log's record count in a byte");
+
+// A mismatch count as a bound / a result of the matrix steps.  1024-bit steps (EM2_MATRIX_ZERO_ONE: FP4 0 / 1 operands, an
+// accumulator starts at -(popcount of the row + popcount of the column) / 2 and adds popcount(row & column)): -mismatches / 2.
+// 2048-bit steps (+-1 operands, accumulators start at 0): bits - 2 mismatches.  -1 ("nothing passes") lies above every result
+// in both.
+template <bool WIDE>
+__device__ __forceinline__ float matrixBoundOf(int32_t mismatches)
+{
+    if (WIDE || !EM2_MATRIX_ZERO_ONE) return (WIDE ? 2048.f : 1024.f) - 2.f * float(mismatches);
+    return -0.5f * float(mismatches);
+}
+template <bool WIDE>
+__device__ __forceinline__ uint32_t mismatchesOfMatrixResult(float result)
+{
+    if (WIDE || !EM2_MATRIX_ZERO_ONE) return uint32_t(((WIDE ? 2048.f : 1024.f) - result) * 0.5f);
+    return uint32_t(result * -2.f);
+}
 
 __device__ __forceinline__ uint32_t uniform(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
 
@@ -347,13 +373,13 @@ __device__ __forceinline__ uint32_t laneId()
 // A record of the walk: the step's stub wrote {first column of the tile | 2i + a, dot, column bound} into the log of the LANE
 // in which register i of accumulator a passed its test (em2_matrix_step_asm.h: 12 bytes, 16 apart).  Lane s = 32 h + t holds
 // rows t and 32 + t of the wave and the columns 8q + 4h + j of a tile (i = 4q + j): its records ascend in the column.  The
-// third word is the bound the walk tested the COLUMN side against (1024 - 2 x the column's published cut-off as the walk staged
-// it, at most two pairs of tiles old; any value a cell published is valid, bounds only tighten): dot >= bound is the column
-// side's test, which the replay therefore decides without a load of its own per record.
+// third word is the bound the walk tested the COLUMN side against (matrixBoundOf of the column's published cut-off as the walk
+// staged it, at most two pairs of tiles old; any value a cell published is valid, bounds only tighten): dot >= bound is the
+// column side's test, which the replay therefore decides without a load of its own per record.
 struct __attribute__((aligned(16))) WalkRecord {
     uint32_t code;                  // tile's first column (a multiple of 32) | 2i + a
-    float dot;                      // 1024 - 2 * mismatches
-    float bound;                    // 1024 - 2 * the column's cut-off (1026: a column that takes no candidates)
+    float dot;                      // the accumulator: -mismatches / 2 (1024-bit steps), 2048 - 2 * mismatches (2048-bit steps)
+    float bound;                    // matrixBoundOf(the column's cut-off) (of -1: a column that takes no candidates)
 };
 static_assert(sizeof(WalkRecord) == EM2_MATRIX_RECORD_BYTES, "the steps store their records 16 bytes apart");
 __device__ __forceinline__ uint32_t walkRecordColumn(uint32_t code, uint32_t half)
@@ -471,13 +497,14 @@ __device__ __forceinline__ uint32_t convoyStartColumn(ArgsPtr aux, volatile uint
 // with kWalkInLowerColumns.
 template <bool IDENTITY, bool BOTH = false, bool DIAG = false>
 __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* auxArg, const void* fragmentsArg, const void* snapArg,
-                                                                    uint32_t colBeginArg, uint32_t colEndArg,
-                                                                    uint32_t rowFragmentBlockArg, float rowDotArg,
+                                                                    const void* termsArg, uint32_t colBeginArg, uint32_t colEndArg,
+                                                                    uint32_t rowFragmentBlockArg, float rowDotArg, float rowTermArg,
                                                                     WalkRecord* waveLogArg, uint32_t logCapacityArg, uint32_t* recordCount,
                                                                     uint32_t tilesLdsArg, uint32_t stopWordsLdsArg, uint32_t walkLdsArg)
 {
     const GlobalFragmentPtr fragments = (GlobalFragmentPtr)uniform64(reinterpret_cast<uint64_t>(fragmentsArg));
     const GlobalIntPtr snap = (GlobalIntPtr)uniform64(reinterpret_cast<uint64_t>(snapArg));
+    const uint64_t terms = uniform64(reinterpret_cast<uint64_t>(termsArg));
     const uint32_t colBegin = uniform(colBeginArg), colEnd = uniform(colEndArg);
     const uint32_t rowFragmentBlock = uniform(rowFragmentBlockArg), logCapacity = uniform(logCapacityArg);
     const uint32_t tilesLds = uniform(tilesLdsArg);
@@ -507,11 +534,14 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         const uint32_t lane = laneId();
         ldsPointer<LdsFloatPtr>(walkLds + kWalkRowDot)[lane] = rowDotArg;         // for the steps: float[64], lane = row
         asm volatile(EM2_MATRIX_SET_RECORD_OFFSETS : : "v"(recordOffset), "v"(recordOffset1) : EM2_MATRIX_OWNED_REGISTERS);
+
         // the B operand: the 2 x 16 fragments of the wave's rows straight into their registers (v128..v255)
         const uint64_t rowFragments = reinterpret_cast<uint64_t>(fragments) + size_t(rowFragmentBlock) * kMatrixTileWords * 16u;
         asm volatile(EM2_MATRIX_LOAD_ROWS : : "s"(rowFragments) : EM2_MATRIX_STEP_CLOBBERS);
     }
     const uint32_t waveSlot = uniform(threadIdx.x >> 6) * 64u;
+    // the terms of the lane's two rows (lane l computes rows l & 31 and 32 + (l & 31)): operands of every step
+    const float rowTerm0 = __shfl(rowTermArg, int(laneId() & 31u), 64), rowTerm1 = __shfl(rowTermArg, int(32u + (laneId() & 31u)), 64);
     // A tile travels global -> LDS without touching registers (global_load_lds_dwordx4: LDS address = M0 + 16 * lane,
     // which is exactly the fragment order; this wave moves its quarter, 4 x 1 KB).  Issued from inline asm: the compiler
     // must not know of these transfers -- it orders every LDS access of its own behind an LDS-DMA it has seen with
@@ -541,24 +571,52 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         uint32_t column_ = (firstColumn) + laneId();                                                                          \
         column_ = column_ < (lastColumn) ? column_ : (lastColumn) - 1u;                                                       \
         const uint64_t address_ = reinterpret_cast<uint64_t>(snap) + uint64_t(column_) * 4u;                                 \
-        const uint32_t dst_ = walkLds + kWalkSnapStage + (buffer) * 256u;                                                     \
+        const uint32_t dst_ = walkLds + kWalkSnapStage;                                                                       \
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"                                           \
                      :                                                                                                        \
                      : "v"(address_), "s"(dst_)                                                                               \
                      : "memory", "m0");                                                                                       \
     } while (0)
+    // The column terms of a pair of tiles (lane = column; the array is padded past the last cell) into slot `ringSlot` of the
+    // ring of three pairs: the set a step restarts computes the tile AFTER the step's own, so the terms run a pair ahead of the
+    // cut-offs.
+#define EM2_STAGE_TERMS(firstColumn, ringSlot)                                                                                \
+    do {                                                                                                                      \
+        const uint64_t address_ = terms + uint64_t((firstColumn) + laneId()) * 4u;                                            \
+        const uint32_t dst_ = walkLds + kWalkTermRing + (ringSlot) * 256u;                                                    \
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"                                           \
+                     :                                                                                                        \
+                     : "v"(address_), "s"(dst_)                                                                               \
+                     : "memory", "m0");                                                                                       \
+    } while (0)
+    // the pair of tiles behind the pair at `base` of the columns [.., end): the next of these columns, or -- at their end -- the
+    // first of the lower ones (a walk that goes around); false: there is none
+#define EM2_FOLLOWING_PAIR(base, end, lower, nextBase_, nextEnd_, nextLower_)                                                 \
+    ((nextBase_) = (base) + 64u, (nextEnd_) = (end), (nextLower_) = (lower),                                                  \
+     ((nextBase_) >= (end) && !(lower) && wrapBegin < wrapEnd) ? ((nextBase_) = wrapBegin, (nextEnd_) = wrapEnd, (nextLower_) = true) : false, \
+     (nextBase_) < (nextEnd_))
 #define EM2_WAIT_STAGED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define EM2_KEEP_WRAP_COUNTS()                                                                                                \
     do {                                                                                                                      \
-        ldsPointer<LdsWordPtr>(walkLds + kWalkWrapCounts)[laneId()] = (recordOffset - firstOffset0) / EM2_MATRIX_RECORD_BYTES; \
-        ldsPointer<LdsWordPtr>(walkLds + kWalkWrapCounts)[64u + laneId()] = (recordOffset1 - firstOffset1) / EM2_MATRIX_RECORD_BYTES; \
+        ldsPointer<LdsBytePtr>(walkLds + kWalkWrapCounts8)[laneId()] = uint8_t((recordOffset - firstOffset0) / EM2_MATRIX_RECORD_BYTES); \
+        ldsPointer<LdsBytePtr>(walkLds + kWalkWrapCounts8)[64u + laneId()] = uint8_t((recordOffset1 - firstOffset1) / EM2_MATRIX_RECORD_BYTES); \
     } while (0)
     EM2_STAGE_TILE(colBegin / 32u, 0u);
     if (colBegin + 32u < colEnd) EM2_STAGE_TILE(colBegin / 32u + 1u, 1u);
     EM2_STAGE_SNAP(colBegin, colEnd, 0u);
+    EM2_STAGE_TERMS(colBegin, 0u);
+    {
+        uint32_t secondBase, secondEnd;
+        bool secondLower;
+        if (EM2_FOLLOWING_PAIR(colBegin, colEnd, false, secondBase, secondEnd, secondLower)) EM2_STAGE_TERMS(secondBase, 1u);
+    }
     EM2_WAIT_STAGED();
     __syncthreads();
     if (wrapBegin < wrapEnd && waveSlot == 0u && laneId() == 0u) stopWords[kWrapBeginWord] = stopWords[kWrapEndWord] = 0u;
+    // the two sets start as the first two tiles' row + column terms; from here on every testing step restarts the set it tests
+    asm volatile(EM2_MATRIX_INIT_X : : "s"(walkLds + kWalkTermRing), "v"(rowTerm0), "v"(rowTerm1) : EM2_MATRIX_STEP_CLOBBERS);
+    asm volatile(EM2_MATRIX_INIT_Y : : "s"(walkLds + kWalkTermRing + 128u), "v"(rowTerm0), "v"(rowTerm1) : EM2_MATRIX_STEP_CLOBBERS);
+    uint32_t ring = 0;              // iteration % 3: the slot of this pair's terms
     bool tested = false;
     uint64_t passScratch[5];        // scalar pairs for the steps: pass masks in flight, saved exec
     bool pending = false, pendingInY = false;
@@ -573,7 +631,8 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     int32_t stagedSnap = snapStage[laneId()];
     for (uint32_t colBase = colBegin;; ++iteration) {
         const uint32_t pair = iteration & 1u;
-        boundScratch[pair * 64u + laneId()] = kMatrixBits - 2.f * float(stagedSnap);
+        boundScratch[pair * 64u + laneId()] = matrixBoundOf<false>(stagedSnap);
+        const uint32_t ringNext = ring == 2u ? 0u : ring + 1u, ringSecond = ringNext == 2u ? 0u : ringNext + 1u;
         // the pair behind this one: the next of these columns, or -- at their end -- the first of the lower ones
         uint32_t nextBase = colBase + 64u, nextEnd = rangeEnd;
         const bool around = nextBase >= rangeEnd && !lowerColumns && wrapBegin < wrapEnd;
@@ -586,15 +645,22 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
             EM2_STAGE_TILE(nextBase / 32u, 2u * (pair ^ 1u));
             EM2_STAGE_SNAP(nextBase, nextEnd, pair ^ 1u);
             if (nextBase + 32u < nextEnd) EM2_STAGE_TILE(nextBase / 32u + 1u, 2u * (pair ^ 1u) + 1u);
+            uint32_t secondBase, secondEnd;
+            bool secondLower;
+            if (EM2_FOLLOWING_PAIR(nextBase, nextEnd, lowerColumns || around, secondBase, secondEnd, secondLower)) {
+                EM2_STAGE_TERMS(secondBase, ringSecond);
+            }
         }
         // ---- first tile of the pair -> X, under it the test of the pending tile (always in Y here) ----
         {
             const uint32_t tileBase = tilesLds + 2u * pair * (kMatrixTileWords * 16u);
             if (pending && !(diag & 32u)) {
                 const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
+                // (Y, tested here, computes this pair's second tile next)
                 asm volatile(EM2_MATRIX_STEP_X_TESTING_Y
                              : "=v"(recordOffset), "=v"(recordOffset1), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
-                             : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(logBase), "s"(pendingBase)
+                             : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(logBase), "s"(pendingBase),
+                               "s"(walkLds + kWalkTermRing + ring * 256u + 128u), "v"(rowTerm0), "v"(rowTerm1)
                              : EM2_MATRIX_STEP_CLOBBERS);
                 tested = true;
             } else {
@@ -617,9 +683,11 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         } else if (colBase + 32u < rangeEnd) {
             const uint32_t tileBase = tilesLds + (2u * pair + 1u) * (kMatrixTileWords * 16u);
             const uint32_t boundBase = walkLds + kWalkBounds + pendingSlot * 128u;
+            // (X, tested here, computes the next pair's first tile next)
             asm volatile(EM2_MATRIX_STEP_Y_TESTING_X
                          : "=v"(recordOffset), "=v"(recordOffset1), "=&s"(passScratch[0]), "=&s"(passScratch[1]), "=&s"(passScratch[2]), "=&s"(passScratch[3]), "=&s"(passScratch[4])
-                         : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(logBase), "s"(pendingBase)
+                         : "s"(tileBase), "s"(boundBase), "s"(walkLds + kWalkRowDot), "s"(logBase), "s"(pendingBase),
+                           "s"(walkLds + kWalkTermRing + ringNext * 256u), "v"(rowTerm0), "v"(rowTerm1)
                          : EM2_MATRIX_STEP_CLOBBERS);
             tested = true;
             pendingInY = true;
@@ -642,6 +710,10 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
                 tested = true;
                 pending = false;
                 EM2_KEEP_WRAP_COUNTS();
+                // (no step has restarted the sets for the lower columns' first pair: X was tested without one, Y was left
+                // with the terms of a tile that does not exist)
+                asm volatile(EM2_MATRIX_INIT_X : : "s"(walkLds + kWalkTermRing + ringNext * 256u), "v"(rowTerm0), "v"(rowTerm1) : EM2_MATRIX_STEP_CLOBBERS);
+                asm volatile(EM2_MATRIX_INIT_Y : : "s"(walkLds + kWalkTermRing + ringNext * 256u + 128u), "v"(rowTerm0), "v"(rowTerm1) : EM2_MATRIX_STEP_CLOBBERS);
             } else {
                 keepCounts = true;
             }
@@ -657,7 +729,7 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         if (!(diag & 128u)) EM2_WAIT_STAGED();          // (128: measurements only -- the tiles are used before they have arrived)
         if (!(diag & 64u)) __syncthreads();
         const uint32_t stop = stopWords[slot];
-        stagedSnap = snapStage[(pair ^ 1u) * 64u + laneId()];
+        stagedSnap = snapStage[laneId()];
         if (convoyCode != 0u && (iteration & 3u) == 0u && waveSlot == 0u && laneId() == 0u) {
             publishWalkPosition(convoyAddress, convoyCode + ((colBase >> 6) - convoyPairBase));
         }
@@ -682,9 +754,12 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         }
         if (around && convoyCode != 0u && ((convoyCode >> 12) & 0xffu) < 255u) convoyCode += 1u << 12;       // the convoy's next lap
         colBase = nextBase;
+        ring = ringNext;
     }
 #undef EM2_STAGE_TILE
 #undef EM2_STAGE_SNAP
+#undef EM2_STAGE_TERMS
+#undef EM2_FOLLOWING_PAIR
 #undef EM2_WAIT_STAGED
     // ---- the tile still untested ----
     if (pending && !(diag & 32u)) {
@@ -911,7 +986,8 @@ constexpr uint32_t kMaxColumnsPerItem = 1u << 19;
 __device__ __forceinline__ uint32_t mergeKeyOf(bool have, const WalkRecord& r, uint32_t half, float bits, uint32_t firstColumn)
 {
     const uint32_t relative = walkRecordColumn(r.code, half) - firstColumn;
-    const uint32_t m = uint32_t(__builtin_fmaf(r.dot, -0.5f, 0.5f * bits));
+    // (bits == 0: a result of the 0 / 1 steps, -mismatches / 2)
+    const uint32_t m = uint32_t(__builtin_fmaf(r.dot, bits == 0.f ? -2.f : -0.5f, 0.5f * bits));
     const uint32_t key = (relative << kMergeColumnShift) | m | (r.dot >= r.bound ? kMergePassBit : 0u);
     return have ? key : 0xffffffffu;
 }
@@ -1249,7 +1325,7 @@ __device__ __forceinline__ void replayWalkLogs(const WalkRecord* waveLog, uint32
                                                unsigned char* ldsRaw, uint32_t tilesLds, uint32_t firstColumn, uint64_t* timed = nullptr)
 {
     const uint64_t tr0 = timed ? __builtin_readcyclecounter() : 0ull;
-    constexpr float bits = (WIDE ? 2.f : 1.f) * kMatrixBits;
+    constexpr float bits = WIDE ? 2.f * kMatrixBits : EM2_MATRIX_ZERO_ONE ? 0.f : kMatrixBits;          // (mergeKeyOf)
     // (the caller's arrays live in scratch memory -- the walk takes them by address: one read each)
     const uint32_t stored0Mine = recordCount[0], stored1Mine = recordCount[1], first0Mine = firstRecord[0], first1Mine = firstRecord[1];
     // what this lane's two logs hold for the replay, and which rows have records at all (bit 32 a + t: row 32 a + t)
@@ -1620,7 +1696,7 @@ __device__ __forceinline__ void drainWalkLogs(const WalkRecord* waveLog, uint32_
             WalkRecord r = WalkRecord();
             if (active) r = loadWalkRecord(log, i);
             const uint32_t col = walkRecordColumn(r.code, lane >> 5);
-            const uint32_t m = uint32_t(((WIDE ? 2.f : 1.f) * kMatrixBits - r.dot) * 0.5f);
+            const uint32_t m = mismatchesOfMatrixResult<WIDE>(r.dot);
             const bool valid = active && rowId < cellCount;
             emitColumn(valid && r.dot >= r.bound, col, rowId, m, lane, emitPos, emitEnd);             // target col
             emitColumn(valid && int32_t(m) <= snapOfRow, rowId, col, m, lane, emitPos, emitEnd);      // target row
@@ -1630,6 +1706,10 @@ __device__ __forceinline__ void drainWalkLogs(const WalkRecord* waveLog, uint32_
 
 
 // ---- host-side constants and small helpers of both units ----
+
+// entries of Fsp4Args::terms: one per cell, padded with the last cell's to whole pairs of tiles and one pair more (the walk
+// stages the terms of a pair of tiles 64 lanes wide without looking at the end)
+static size_t matrixTermCount(uint32_t cellCount) { return size_t((cellCount + 63u) / 64u) * 64u + 64u; }
 
 // dynamic LDS of the matrix kernels behind matrixLdsOffset: four tiles, the stop words + ticket, the waves' walk blocks
 constexpr size_t kMatrixLdsBytes = 4u * kMatrixTileWords * 16u + 64u + 4u * kMatrixWalkLdsBytes;
@@ -1654,7 +1734,7 @@ constexpr uint32_t kTableWords = 2u * kMatrixMaxSegments + 2u;
 constexpr uint32_t kInboxChunk = 512;
 
 // Which signature widths take the matrix-core form of the triangle.  The fragments are always 1024 bits wide: a
-// narrower signature is zero-extended (a zero bit is +1 on both sides, so the dot product stays 1024 - 2 * mismatches),
+// narrower signature is zero-extended (a zero bit adds nothing to either popcount or to the dot product),
 // which costs the full 16 k-steps per tile whatever the width.  EM2_SCAN_MATRIX: 0 never, 1 (default) the widths it
 // is faster for (129..1024 bits, kMatrixMinPaddedDw), 2 every width up to 1024 bits (tests), 3 = 1 without the 2048-bit form.
 static bool matrixFormWanted(uint32_t paddedDw)
@@ -1698,8 +1778,9 @@ static size_t inboxSortTempBytes(uint64_t capacity)
 const void* fsp4SymmetricKernelFor(uint32_t paddedDw, bool identity);          // fsp4ScanSymmetricKernel<paddedDw, identity>
 const void* scanMatrixKernelFor(bool identity, bool wide = false);             // the matrix-core scan kernel the settings select
 hipError_t residentWaveSlots(const void* kernel, uint32_t wavesPerBlock, size_t lds, uint32_t* slots);
+// (terms: matrixTermCount(cellCount) floats for the 1024-bit steps' row and column terms, or null)
 hipError_t launchExpandFragments(const uint32_t* sig32, uint32_t cellCount, uint32_t fragmentCount, void* out, uint32_t steps,
-                                 hipStream_t stream);
+                                 float* terms, hipStream_t stream);
 hipError_t launchInboxReplay(bool identity, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const Fsp4Args& args,
                              const uint64_t* sorted, uint64_t count);
 

@@ -179,8 +179,9 @@ int em2_dev_subset_fill(const uint64_t* d_globalToc, const em2_count* d_globalDa
  * evaluated once, as in the reference's own loop (src/ExpressionMatrixLsh.cpp:218-263), and offered to both cells. */
 int em2_dev_find_similar_pairs4_form(uint32_t cellCount, uint32_t rowCount);
 
-/* The same question with the signature width: for 129..2048 bits the symmetric form contracts its pairs as FP4 +-1
- * dot products on the matrix cores (3; 1024 - 2 * mismatches up to 1024 bits, 2048 - 2 * mismatches above; exact in f32)
+/* The same question with the signature width: for 129..2048 bits the symmetric form contracts its pairs as FP4 dot
+ * products on the matrix cores (3; up to 1024 bits 0 / 1 operands, popcount(a & b) - (popcount(a) + popcount(b)) / 2 =
+ * -mismatches / 2; above, +-1 operands, 2048 - 2 * mismatches; both exact in f32)
  * and starts at 32768 cells instead of 131072.  A launch that is not symmetric -- a shard of the rows, SURVEY 8(e)'s
  * partitioning across GPUs -- takes the rows form on the matrix cores (4) from 2^31 (row, column) pairs on: every row walks
  * all columns in ascending order, which is the per-cell contract of src/ExpressionMatrixLsh.cpp:200-285 as it stands.
@@ -192,7 +193,7 @@ int em2_dev_find_similar_pairs4_form_for(uint32_t cellCount, uint32_t rowCount, 
  * (symmetric form, which synchronises anyway), else -1, [2] (64-row wave, column) steps executed, [3] symmetric
  * form: inbox entries sorted and replayed, [4] column segments, [5] cells whose rows scanned all columns, [6] pairs
  * contracted on the matrix cores and [7] the duration in ms of that kernel alone (form 3, the matrix-core form of the
- * symmetric scan: FP4 +-1 contraction, signatures zero-extended to 1024 or 2048 bits), [8] the shader clock in GHz that
+ * symmetric scan: FP4 contraction, signatures zero-extended to 1024 or 2048 bits), [8] the shader clock in GHz that
  * kernel ran at (sums over its blocks of s_memtime and s_memrealtime ticks; 0 when unknown). */
 int em2_dev_find_similar_pairs4_last_launch(double* values, uint32_t valueCount);
 

@@ -5,7 +5,7 @@ matrix-core walk (fsp4ScanMatrixKernel in csrc/em2_scan_symmetric.hip, fsp4TileM
     python3 tools/gen_matrix_step_asm.py > expressionmatrix2_amd/csrc/em2_matrix_step_asm.h
 
 One step = the 32 x 64 dot products of one 32-column tile with the wave's 64 rows: 16 k-steps x 2
-v_mfma_scale_f32_32x32x64_f8f6f4 (FP4 +-1 operands, f32 accumulate), the column fragments read from LDS through a
+v_mfma_f32_32x32x64_f8f6f4 (FP4 0 / 1 operands -- see ZERO_ONE below --, f32 accumulate), the column fragments read from LDS through a
 four-deep register ring with COUNTED lgkmcnt waits (the compiler's own schedule reuses two registers and waits for
 lgkmcnt(0) in front of every second k-step, which exposes the LDS latency 8 times per tile), and -- interleaved with
 the MFMAs, two results per k-step -- the test of the PREVIOUS tile's results against min(row bound, column bound): the
@@ -14,7 +14,7 @@ step of tile t hides the column tests of tile t-1 under its own matrix instructi
 Everything the step touches sits in fixed physical registers that the compiler never sees as values: inline-asm
 operands cannot be indexed by sub-register, a step has more operands than the 30 an asm statement may carry, and with
 the tuples pinned by "{v[a:b]}" constraints the register allocator moved other values into them and reloaded 32 row
-registers from scratch in front of every step.  So v32..v255 belong to the walk: every asm statement of the walk
+registers from scratch in front of every step.  So v20..v255 belong to the walk: every asm statement of the walk
 lists them as clobbered (no value of the compiler's lives there across a step), the rows are written by
 EM2_MATRIX_SET_ROW_FRAGMENT, the results are read by EM2_MATRIX_READ_X / _Y, and the steps take scalar operands only
 (LDS base addresses): the per-lane state of the walk -- row bounds, log counts -- lives in LDS, so that the walk's
@@ -27,15 +27,17 @@ loop holds no vector value of the compiler's across a step or across the call of
     v[96:111] / v[112:127]  accumulator set Y
     v[48:63]    ring of four column fragments (A operand)
     v[40:47]    two buffers of four column bounds (the previous tile's, this lane's half)
+    v[20:27]    two buffers of four column terms (of the tile the set under test computes next), v36 their LDS address
     v28 / v29 byte offsets of the lane's next record for accumulator 0 / 1 in the wave's log area; v30 / v31 the record
     (stubs);
-    v32 lane, then a threshold; v33 / v34 / v35 LDS addresses (tile, bounds, row state), v36 scale, v37 / v38 row bounds,
+    v32 lane, then a threshold; v33 / v34 / v35 LDS addresses (tile, bounds, row state), v37 / v38 row bounds,
     v39 the other threshold
 
 Accumulator layout (32x32 result, columns = A = M, rows = B = N): lane l, register i of a set's first / second
 accumulator holds row (l & 31) / 32 + (l & 31) and column 8 * (i >> 2) + 4 * (l >> 5) + (i & 3) of the tile.
 
-Test of register i = 4q + j of accumulator a of the previous tile:
+Test of register i = 4q + j of accumulator a of the previous tile (bounds and results in the accumulators' unit: -mismatches / 2
+with the 0 / 1 operands):
     pass = min(rowBound[a], columnBound[8q + 4 * (l >> 5) + j]) <= dot            (q = the "group" of 8 columns)
 A register that passes in some lane branches to its stub behind the body: the passing lanes append a record
 {first column of the tile | 2i + a, dot} (8 bytes) to their OWN log in global memory -- one log per lane and accumulator,
@@ -56,7 +58,9 @@ BOUNDS = 40
 LANE, TILE_ADDR, BOUND_ADDR, STATE_ADDR, SCALE, ROW_BOUND0, ROW_BOUND1, THR0 = 32, 33, 34, 35, 36, 37, 38, 39
 THR1 = LANE          # the lane id is dead once the addresses are formed
 OFFSET, RECORD = 28, 30          # v28 (accumulator 0) and v29 (accumulator 1), v[30:31]
-FIRST_OWNED = 28
+TERMS = 20                       # the 0/1 encoding: two buffers of four column terms (v[20:27]), which travel like the column bounds
+TERM_ADDR = SCALE                # ... read from LDS at this address (v36 carried the block scale of the v_mfma_scale form once)
+FIRST_OWNED = 20                 # (the terms of the lane's two rows are operands of the steps: two registers of the compiler's)
 STEPS = 16
 
 
@@ -105,6 +109,10 @@ def prologue(s, o, tile, tests):
             s.lds("bounds0", "ds_read_b32 %s, %s" % (vreg(BOUNDS), vreg(BOUND_ADDR)))
         else:
             s.lds("bounds0", "ds_read_b128 %s, %s" % (vreg(BOUNDS, 4), vreg(BOUND_ADDR)))
+        if ZERO_ONE and "termBase" in o:
+            s.emit("v_lshrrev_b32 %s, 5, %s" % (vreg(TERM_ADDR), vreg(LANE)))
+            s.emit("v_lshl_add_u32 %s, %s, 4, %s" % (vreg(TERM_ADDR), vreg(TERM_ADDR), o["termBase"]))       # + 16 * (lane >> 5)
+            s.lds("terms0", "ds_read_b128 %s, %s" % (vreg(TERMS, 4), vreg(TERM_ADDR)))
 
 
 def tests_of(s, o, q, j, k, prev0, prev1):
@@ -128,11 +136,33 @@ def shift_in(s, o, k):
     """Scalar half: a register whose test passed in some lane goes through its stub (out of line, behind the body)."""
     if CMPX:
         return
-    for a in range(2):
-        s.emit("s_cmp_lg_u64 %s, 0" % o["pass%d_%d" % (a, k & 1)])
-        s.emit("s_cbranch_scc1 L_stub_%d_%d_%%=" % (k, a))
-        s.emit("L_back_%d_%d_%%=:" % (k, a))
-        s.stubs.append((k, a))
+    if STUB == "merged":
+        # one check for both accumulators: the stub looks at the two masks itself
+        s.emit("s_or_b64 vcc, %s, %s" % (o["pass0_%d" % (k & 1)], o["pass1_%d" % (k & 1)]))
+        s.emit("s_cbranch_vccnz L_stub_%d_%%=" % k)
+        s.emit("L_back_%d_%%=:" % k)
+        s.stubs.append((k, None))
+    else:
+        for a in range(2):
+            s.emit("s_cmp_lg_u64 %s, 0" % o["pass%d_%d" % (a, k & 1)])
+            s.emit("s_cbranch_scc1 L_stub_%d_%d_%%=" % (k, a))
+            s.emit("L_back_%d_%d_%%=:" % (k, a))
+            s.stubs.append((k, a))
+    if ZERO_ONE and "termBase" in o and (RESTART == "S" or k == STEPS - 1):
+        restart(s, o, k)
+
+
+def restart(s, o, k):
+    """The 0/1 encoding: register k of the set under test, tested and recorded, becomes the start of ITS next tile: row term +
+    column term of that tile (the next step's first MFMAs take the set as their C operand).  The terms of a group of four
+    registers arrive like the bounds, one group ahead."""
+    q, j = k >> 2, k & 3
+    if j == 0:
+        s.wait_for("terms%d" % q)
+    term = TERMS + 4 * (q & 1) + j
+    prev0, prev1 = o["prev"]
+    s.emit("v_add_f32 %s, %s, %s" % (vreg(prev0 + k), vreg(term), o["rowTerm0"]))
+    s.emit("v_add_f32 %s, %s, %s" % (vreg(prev1 + k), vreg(term), o["rowTerm1"]))
 
 
 def stubs(s, o, prev0, prev1):
@@ -158,6 +188,17 @@ def stubs(s, o, prev0, prev1):
         s.emit("s_mov_b64 exec, %s" % o["save"])
 
     for k, a in s.stubs:
+        if a is None:
+            s.emit("L_stub_%d_%%=:" % k)
+            s.emit("s_mov_b64 %s, exec" % o["save"])
+            for b in range(2):
+                s.emit("s_mov_b64 exec, %s" % o["pass%d_%d" % (b, k & 1)])
+                s.emit("s_cbranch_execz L_skip_%d_%d_%%=" % (k, b))
+                record_and_store(s, o, k, b, (prev0, prev1)[b] + k)
+                s.emit("L_skip_%d_%d_%%=:" % (k, b))
+            s.emit("s_mov_b64 exec, %s" % o["save"])
+            s.emit("s_branch L_back_%d_%%=" % k)
+            continue
         s.emit("L_stub_%d_%d_%%=:" % (k, a))
         record(k, a)
         s.emit("s_branch L_back_%d_%d_%%=" % (k, a))
@@ -202,15 +243,18 @@ def place(s, o, k, what, prev0, prev1, slot, carry=False):
             if j == 1 and q < 3 and not TILE_BOUND:
                 s.lds("bounds%d" % (q + 1), "ds_read_b128 %s, %s offset:%d"
                       % (vreg(BOUNDS + 4 * ((q + 1) & 1), 4), vreg(BOUND_ADDR), 32 * (q + 1)))
+                if ZERO_ONE and "termBase" in o:
+                    # (the buffer held group q - 1, whose last register restarted in front of this k-step's first test)
+                    s.lds("terms%d" % (q + 1), "ds_read_b128 %s, %s offset:%d"
+                          % (vreg(TERMS + 4 * ((q + 1) & 1), 4), vreg(TERM_ADDR), 32 * (q + 1)))
         if letter == "C" and CMPX:
             masked_record(s, o, k, 0, THR0, prev0, True)
             masked_record(s, o, k, 1, THR1, prev1, False)
         elif letter == "C":
             s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass0_%d" % (k & 1)], vreg(THR0), vreg(prev0 + k)))
             s.emit("v_cmp_le_f32_e64 %s, %s, %s" % (o["pass1_%d" % (k & 1)], vreg(THR1), vreg(prev1 + k)))
-            if BIAS:
-                s.emit("v_sub_f32 %s, %s, %s" % (vreg(prev0 + k), vreg(bound), vreg(bound)))
-                s.emit("v_sub_f32 %s, %s, %s" % (vreg(prev1 + k), vreg(bound), vreg(bound)))
+            if ZERO_ONE and "termBase" in o and RESTART == "C" and k and "S" in PLACE[0]:
+                restart(s, o, k - 1)          # (its stubs ran in front of this k-step's second MFMA)
 
 
 # The ring of fragments runs through a PAIR of tiles: the step of a pair's first tile (X) ends by reading the first four
@@ -225,12 +269,19 @@ TILE_BOUND = os.environ.get("EM2_GEN_TILE_BOUND", "0") == "1"
 # nothing passed), EXEC is restored; five more instructions per result, all of them masked off almost always (DESIGN 3.1.6:
 # 4.9 PFLOP/s at every record rate against 6.6 at the scan's -- instructions under an empty EXEC are not free, the stores least).
 CMPX = os.environ.get("EM2_GEN_CMPX", "0") == "1"
-# EM2_GEN_BIAS=1 (experiment): what the 0/1 operand encoding would add to a step.  With bits as 0 / 1 the dot
-# product is popcount(a & b) and mismatches = pa + pb - 2 dot: the accumulators of the NEXT tile must start at -(pa_r + pb_c) / 2
-# instead of 0 so that the test and the records stay as they are.  Each register of the set under test is re-initialised right
-# behind its test (v_add_f32 of a row term and a column term that travels like the bounds), and a tile's first MFMAs take the
-# accumulator as their C operand.  Timing only: the terms are the bounds' registers here.
-BIAS = os.environ.get("EM2_GEN_BIAS", "0") == "1"
+# The operand encoding.  "01" (the product since round 6): a signature bit is FP4 0 / 1 on both sides, the dot product is
+# popcount(a & b) and mismatches = pa + pb - 2 dot -- so an accumulator STARTS at -(pa_row + pb_column) / 2 and ends at
+# -mismatches / 2: bounds, tests and records are in that unit.  Every register of the set under test restarts right behind its
+# test and its stubs (restart(): row term + column term of the set's next tile), and a tile's first MFMAs take the set as their
+# C operand.  The matrix pipe draws less power on these operands than on +-1 (fewer products that change sign): the step
+# holds a higher clock (profiles/r06_scan_experiments.md, 4).  "pm1": the +-1 form of rounds 2-5 (accumulators start at 0, the
+# dot product is 1024 - 2 mismatches); tools/ubench_matrix_step.hip can still be built with it.  The 2048-bit (WIDE) steps are
+# +-1 in either case.
+ZERO_ONE = os.environ.get("EM2_GEN_ENCODING", "01") == "01"
+# where a register restarts: "C" (the product) behind the compares of the k-step that follows its own -- its stubs ran in front of
+# that k-step's second MFMA --, "S" right behind its stubs, between that k-step's two MFMAs (the microbenchmark: 50.0 against
+# 48.7 ms at the bench's record rate; profiles/r06_scan_experiments.md)
+RESTART = os.environ.get("EM2_GEN_RESTART", "C")
 # EM2_GEN_STUB: the form of the stubs.  "branches" = round 2's (two s_mov around the record); "saveexec" = s_and_saveexec_b64
 # instead of the first two; "empty" = no record at all (measurement: the branches alone).  The other forms round 5 measured
 # (profiles/r05_scan_experiments.md: the store first / last / narrower / to LDS, one pending record per lane, the k-step's second
@@ -276,7 +327,7 @@ def step(cur, prev, tests, operands):
     """cur / prev: 'X' or 'Y'.  operands: placeholder names -> asm operand text."""
     cur0, cur1 = SETS[cur]
     prev0, prev1 = SETS[prev]
-    o = operands
+    o = dict(operands, prev=(prev0, prev1))
     s = Stream()
     carry_out = CARRY and cur == "X"
     carry_in = CARRY and cur == "Y"
@@ -295,7 +346,7 @@ def step(cur, prev, tests, operands):
             # (the form without block scales: scale 2^0 is what the operands want, and v_mfma_scale_* is two instructions --
             # a v_mfma_ld_scale_b32 in front of this one -- 16 bytes instead of 8 and an issue slot more per MFMA)
             mfma = ("v_mfma_f32_32x32x64_f8f6f4 %s, %s, %s, %s cbsz:4 blgp:4"
-                    % (vreg(acc, 16), vreg(slot, 4), vreg(rows + 4 * k, 4), "0" if (k == 0 and not BIAS) else vreg(acc, 16)))
+                    % (vreg(acc, 16), vreg(slot, 4), vreg(rows + 4 * k, 4), "0" if (k == 0 and not ZERO_ONE) else vreg(acc, 16)))
             s.emit(mfma)
             if a == 0 and tests:
                 place(s, o, k, PLACE[0], prev0, prev1, slot, carry_out)
@@ -309,6 +360,32 @@ def step(cur, prev, tests, operands):
     if tests:
         shift_in(s, o, STEPS - 1)
         stubs(s, o, prev0, prev1)
+    return s.lines
+
+
+def init_set(name, operands):
+    """The 0/1 encoding: accumulator set `name` becomes the start of a tile -- row term + column term in all 32 registers -- from
+    the tile's 32 column terms at termBase (the layout of the bounds).  For the first two tiles of a walk, whose sets no step
+    has restarted (and for the pair behind a test without a step).  MFMAs into the set may still be in flight: wait them out."""
+    acc0, acc1 = SETS[name]
+    o = operands
+    s = Stream()
+    s.emit("s_nop 15")
+    s.emit("s_nop 15")
+    s.emit("s_nop 15")
+    s.emit("v_mbcnt_lo_u32_b32 %s, -1, 0" % vreg(LANE))
+    s.emit("v_mbcnt_hi_u32_b32 %s, -1, %s" % (vreg(LANE), vreg(LANE)))
+    s.emit("v_lshrrev_b32 %s, 5, %s" % (vreg(TERM_ADDR), vreg(LANE)))
+    s.emit("v_lshl_add_u32 %s, %s, 4, %s" % (vreg(TERM_ADDR), vreg(TERM_ADDR), o["termBase"]))
+    homes = (TERMS, TERMS + 4, BOUNDS, BOUNDS + 4)          # (the bounds' buffers are idle outside a step)
+    for q in range(4):
+        s.lds("terms%d" % q, "ds_read_b128 %s, %s offset:%d" % (vreg(homes[q], 4), vreg(TERM_ADDR), 32 * q))
+    for q in range(4):
+        s.wait_for("terms%d" % q)
+        for j in range(4):
+            s.emit("v_add_f32 %s, %s, %s" % (vreg(acc0 + 4 * q + j), vreg(homes[q] + j), o["rowTerm0"]))
+            s.emit("v_add_f32 %s, %s, %s" % (vreg(acc1 + 4 * q + j), vreg(homes[q] + j), o["rowTerm1"]))
+    assert not s.queue, s.queue
     return s.lines
 
 
@@ -464,17 +541,25 @@ def main():
     #                       column of the tile under test)
     #   step without tests: %0 tileBase
     #   test only:          %0 / %1 record offsets, %2..%6 scratch pairs, %7 boundBase, %8 stateBase, %9 logBase, %10 tileCode
+    #   (the 0/1 encoding) step with tests: %12 termBase -- LDS byte address of the 32 column terms of the tile the set under
+    #                       test computes next --, %13 / %14 ("v") the terms of the lane's rows l & 31 / 32 + (l & 31);
+    #                       EM2_MATRIX_INIT_X / _Y: %0 termBase of the tile the set computes first, %1 / %2 the row terms
     passes = {"pass0_0": "%2", "pass1_0": "%3", "pass0_1": "%4", "pass1_1": "%5", "save": "%6"}
     with_tests = dict(passes, count="%0", count1="%1", tileBase="%7", boundBase="%8", stateBase="%9", logBase="%10", tileCode="%11")
+    wide_with_tests = dict(with_tests)
+    if ZERO_ONE:
+        with_tests.update(termBase="%12", rowTerm0="%13", rowTerm1="%14")
     without = {"tileBase": "%0"}
     only = dict(passes, count="%0", count1="%1", boundBase="%7", stateBase="%8", logBase="%9", tileCode="%10")
     for cur, prev in (("X", "Y"), ("Y", "X")):
         out.write(macro("EM2_MATRIX_STEP_%s_TESTING_%s" % (cur, prev), step(cur, prev, True, with_tests)))
         out.write(macro("EM2_MATRIX_STEP_%s" % cur, step(cur, prev, False, without)))
         out.write(macro("EM2_MATRIX_TEST_%s" % cur, test_only(cur, only)))
+        if ZERO_ONE:
+            out.write(macro("EM2_MATRIX_INIT_%s" % cur, init_set(cur, {"termBase": "%0", "rowTerm0": "%1", "rowTerm1": "%2"})))
     # the same three for 2048-bit signatures (operand lists as above; %1, %3 and %5 are unused)
     for cur, prev in (("X", "Y"), ("Y", "X")):
-        out.write(macro("EM2_MATRIX_WIDE_STEP_%s_TESTING_%s" % (cur, prev), wide_step(cur, prev, True, with_tests)))
+        out.write(macro("EM2_MATRIX_WIDE_STEP_%s_TESTING_%s" % (cur, prev), wide_step(cur, prev, True, wide_with_tests)))
         out.write(macro("EM2_MATRIX_WIDE_STEP_%s" % cur, wide_step(cur, prev, False, without)))
         out.write(macro("EM2_MATRIX_WIDE_TEST_%s" % cur, wide_test_only(cur, only)))
     # every vector register the walk owns: no value of the compiler's may live there across any of its asm statements
@@ -484,6 +569,8 @@ def main():
     # the lane's record offset lives in a register of the walk from step to step
     out.write("#define EM2_MATRIX_SET_RECORD_OFFSETS \"v_mov_b32 v%d, %%0\\nv_mov_b32 v%d, %%1\\n\"\n\n" % (OFFSET, OFFSET + 1))
     out.write("#define EM2_MATRIX_RECORD_BYTES %du\n\n" % RECORD_BYTES)
+    # the 0/1 encoding of the 1024-bit steps: 1 (accumulators in units of -mismatches / 2) or 0 (+-1: 1024 - 2 mismatches)
+    out.write("#define EM2_MATRIX_ZERO_ONE %d\n\n" % (1 if ZERO_ONE else 0))
     # the B operand in one go: 32 loads straight into the registers, one wait.  %0 = address of the wave's first row
     # fragment (scalar pair); the fragments of a 32-row block are 1 KB apart (64 lanes x 16 bytes), the second block
     # follows the first

@@ -7,27 +7,36 @@
 //            3.0 gives the scan's rate of about four records per wave and tile; the stubs store their records.
 //   hipcc --offload-arch=gfx950 -O2 -I expressionmatrix2_amd/csrc -o ubench_matrix_step tools/ubench_matrix_step.hip
 #include <hip/hip_runtime.h>
+#pragma clang diagnostic ignored "-Wunused-value"          // (hip calls whose status nobody reads: a microbenchmark)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include "em2_matrix_step_asm.h"
+// The 0 / 1 steps (EM2_MATRIX_ZERO_ONE) restart the accumulators from row + column terms: zeros here (a block of 256 bytes
+// behind the waves' bounds), so the record rates follow the bounds as they do with the +-1 steps.
+#if EM2_MATRIX_ZERO_ONE
+#define UBENCH_TERM_OPERANDS(base) , "s"(base), "v"(0.f), "v"(0.f)
+#else
+#define UBENCH_TERM_OPERANDS(base)
+#endif
 #ifndef UBENCH_TILE_BIT
 #define UBENCH_TILE_BIT 0u          // (-DUBENCH_TILE_BIT=0x80000000u for EM2_GEN_STUB=pend: a record word that is never 0)
 #endif
 
-// LDS: 4 tiles (64 KB), then per wave: rowDot float[64] (256 B) + bounds float[4][32] (512 B)
+// LDS: 4 tiles (64 KB), then per wave: rowDot float[64] (256 B) + bounds float[4][32] (512 B) + terms float[2][32] (256 B)
 __global__ void __launch_bounds__(256) stepLoop(int rounds, int mode, float bound, const unsigned* tiles, const unsigned* rows,
                                                 unsigned long long* logs, unsigned* counts, float* out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     for (unsigned i = threadIdx.x; i < 65536 / 4; i += 256) reinterpret_cast<unsigned*>(lds)[i] = tiles[i];
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* walk = reinterpret_cast<float*>(lds + 65536 + wave * 768);
+    float* walk = reinterpret_cast<float*>(lds + 65536 + wave * 1024);
     walk[lane] = bound;
     for (int i = lane; i < 128; i += 64) walk[64 + i] = bound;
+    walk[192 + lane] = 0.f;
     __syncthreads();
     const unsigned base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
-    const unsigned walkLds = unsigned(__builtin_amdgcn_readfirstlane(int(base + 65536 + wave * 768)));
+    const unsigned walkLds = unsigned(__builtin_amdgcn_readfirstlane(int(base + 65536 + wave * 1024)));
     auto uniform64 = [](unsigned long long v) {
         return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(int(unsigned(v))) |
                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(int(unsigned(v >> 32))) << 32);
@@ -63,10 +72,12 @@ __global__ void __launch_bounds__(256) stepLoop(int rounds, int mode, float boun
             asm volatile(EM2_MATRIX_STEP_X_TESTING_Y
                          : "=v"(recordOffset), "=v"(recordOffset1), "=&s"(scratch[0]), "=&s"(scratch[1]), "=&s"(scratch[2]), "=&s"(scratch[3]), "=&s"(scratch[4])
                          : "s"(t0), "s"(walkLds + 256), "s"(walkLds), "s"(logBase), "s"(unsigned(r) * 64u | UBENCH_TILE_BIT)
+                           UBENCH_TERM_OPERANDS(walkLds + 768)
                          : EM2_MATRIX_STEP_CLOBBERS);
             asm volatile(EM2_MATRIX_STEP_Y_TESTING_X
                          : "=v"(recordOffset), "=v"(recordOffset1), "=&s"(scratch[0]), "=&s"(scratch[1]), "=&s"(scratch[2]), "=&s"(scratch[3]), "=&s"(scratch[4])
                          : "s"(t1), "s"(walkLds + 256 + 128), "s"(walkLds), "s"(logBase), "s"(unsigned(r) * 64u + 32u | UBENCH_TILE_BIT)
+                           UBENCH_TERM_OPERANDS(walkLds + 768 + 128)
                          : EM2_MATRIX_STEP_CLOBBERS);
             if ((r & 15) == 15) {       // (the log of a lane holds 4096 records: start over)
                 counts[(blockIdx.x * 4 + wave) * 64 + lane] += (recordOffset - offset) / EM2_MATRIX_RECORD_BYTES + (recordOffset1 - offset1) / EM2_MATRIX_RECORD_BYTES;
@@ -90,9 +101,9 @@ static void run(const char* name, int blocksPerCu, int rounds, int mode, float b
     hipEventCreate(&a);
     hipEventCreate(&b);
 #ifdef UBENCH_EXTRA_LDS
-    const size_t ldsBytes = 65536 + 4 * 768 + 4096;          // (a spare 4 KB behind the walk blocks: EM2_GEN_STUB=dsw writes there)
+    const size_t ldsBytes = 65536 + 4 * 1024 + 4096;          // (a spare 4 KB behind the walk blocks: EM2_GEN_STUB=dsw writes there)
 #else
-    const size_t ldsBytes = 65536 + 4 * 768;
+    const size_t ldsBytes = 65536 + 4 * 1024;
 #endif
     hipFuncSetAttribute(reinterpret_cast<const void*>(&stepLoop), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
     stepLoop<<<cus * blocksPerCu, 256, ldsBytes>>>(16, mode, bound, tiles, rows, logs, counts, out);
