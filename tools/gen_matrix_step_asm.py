@@ -187,7 +187,20 @@ def stubs(s, o, prev0, prev1):
         record_and_store(s, o, k, a, acc)
         s.emit("s_mov_b64 exec, %s" % o["save"])
 
-    for k, a in s.stubs:
+    for entry in s.stubs:
+        if len(entry) == 3:
+            k, a, mfma = entry
+            s.emit("L_stub_%d_%d_%%=:" % (k, a))
+            s.emit(mfma)
+            record(k, a)
+            if a == 0:
+                # (the other accumulator's check was skipped with the body's)
+                s.emit("s_cmp_lg_u64 %s, 0" % o["pass1_%d" % (k & 1)])
+                s.emit("s_cbranch_scc0 L_after_%d_%%=" % k)
+                record(k, 1)
+            s.emit("s_branch L_after_%d_%%=" % k)
+            continue
+        k, a = entry
         if a is None:
             s.emit("L_stub_%d_%%=:" % k)
             s.emit("s_mov_b64 %s, exec" % o["save"])
@@ -283,10 +296,14 @@ ZERO_ONE = os.environ.get("EM2_GEN_ENCODING", "01") == "01"
 # 48.7 ms at the bench's record rate; profiles/r06_scan_experiments.md)
 RESTART = os.environ.get("EM2_GEN_RESTART", "C")
 # EM2_GEN_STUB: the form of the stubs.  "branches" = round 2's (two s_mov around the record); "saveexec" = s_and_saveexec_b64
-# instead of the first two; "empty" = no record at all (measurement: the branches alone).  The other forms round 5 measured
+# instead of the first two; "empty" = no record at all (measurement: the branches alone); "merged" = one scalar test per pair of
+# results, the stub looks at both masks; "mfma" = the checks directly in front of the k-step's second MFMA, a stub starts with a
+# copy of it (both measured on the 0/1 step in round 6: profiles/r06_scan_experiments.md, 4 -- neither moves the product).  The other forms round 5 measured
 # (profiles/r05_scan_experiments.md: the store first / last / narrower / to LDS, one pending record per lane, the k-step's second
 # matrix instruction issued from inside the stub) are in the git history: none of them moved the product.
 STUB = os.environ.get("EM2_GEN_STUB", "branches")
+if STUB == "mfma":
+    THR1 = STATE_ADDR          # (a stub runs between a register's v_min and its v_cmp there, and v32 is the record's third word)
 
 
 def column_bound_register(k):
@@ -347,9 +364,18 @@ def step(cur, prev, tests, operands):
             # a v_mfma_ld_scale_b32 in front of this one -- 16 bytes instead of 8 and an issue slot more per MFMA)
             mfma = ("v_mfma_f32_32x32x64_f8f6f4 %s, %s, %s, %s cbsz:4 blgp:4"
                     % (vreg(acc, 16), vreg(slot, 4), vreg(rows + 4 * k, 4), "0" if (k == 0 and not ZERO_ONE) else vreg(acc, 16)))
+            if a == 1 and tests and STUB == "mfma" and k:
+                # the checks of register k - 1 directly in front of the k-step's second MFMA: a stub starts with a copy of it (the
+                # matrix pipe has work while the wave is out of line) and comes back BEHIND the one in the body
+                for b in range(2):
+                    s.emit("s_cmp_lg_u64 %s, 0" % o["pass%d_%d" % (b, (k - 1) & 1)])
+                    s.emit("s_cbranch_scc1 L_stub_%d_%d_%%=" % (k - 1, b))
+                    s.stubs.append((k - 1, b, mfma))
             s.emit(mfma)
+            if a == 1 and tests and STUB == "mfma" and k:
+                s.emit("L_after_%d_%%=:" % (k - 1))
             if a == 0 and tests:
-                place(s, o, k, PLACE[0], prev0, prev1, slot, carry_out)
+                place(s, o, k, PLACE[0].replace("S", "") if STUB == "mfma" else PLACE[0], prev0, prev1, slot, carry_out)
         if tests:
             place(s, o, k, PLACE[1], prev0, prev1, slot, carry_out)
         else:
