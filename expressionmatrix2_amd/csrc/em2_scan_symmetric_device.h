@@ -565,8 +565,8 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     } while (0)
     // The published cut-offs of the 64 columns of a pair of tiles (lane = column) travel the same way one pair ahead
     // (columns past the end repeat the last one: never tested).  Any value a cell published earlier is valid: bounds
-    // only tighten.
-#define EM2_STAGE_SNAP(firstColumn, lastColumn, buffer)                                                                       \
+    // only tighten.  One buffer: the wave has the pair's values in a register (stagedSnap) before it issues the next load.
+#define EM2_STAGE_SNAP(firstColumn, lastColumn)                                                                               \
     do {                                                                                                                      \
         uint32_t column_ = (firstColumn) + laneId();                                                                          \
         column_ = column_ < (lastColumn) ? column_ : (lastColumn) - 1u;                                                       \
@@ -603,7 +603,7 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
     } while (0)
     EM2_STAGE_TILE(colBegin / 32u, 0u);
     if (colBegin + 32u < colEnd) EM2_STAGE_TILE(colBegin / 32u + 1u, 1u);
-    EM2_STAGE_SNAP(colBegin, colEnd, 0u);
+    EM2_STAGE_SNAP(colBegin, colEnd);
     EM2_STAGE_TERMS(colBegin, 0u);
     {
         uint32_t secondBase, secondEnd;
@@ -643,7 +643,7 @@ __device__ __attribute__((noinline)) uint32_t scanTilesMatrixPinned(const void* 
         const bool more = nextBase < nextEnd;
         if (more) {
             EM2_STAGE_TILE(nextBase / 32u, 2u * (pair ^ 1u));
-            EM2_STAGE_SNAP(nextBase, nextEnd, pair ^ 1u);
+            EM2_STAGE_SNAP(nextBase, nextEnd);
             if (nextBase + 32u < nextEnd) EM2_STAGE_TILE(nextBase / 32u + 1u, 2u * (pair ^ 1u) + 1u);
             uint32_t secondBase, secondEnd;
             bool secondLower;
