@@ -133,7 +133,7 @@ __device__ __forceinline__ void waveSyncFor()
     else waveSync();
 }
 
-// __move_median_to_first for the wave forms (one lane calls it): the four elements are loaded at once -- one LDS round trip
+// __move_median_to_first for the wave forms in LDS (one lane calls it): the four elements are loaded at once -- one LDS round trip
 // instead of a chain of dependent ones (a 200-entry selection of the scan spends most of its time between partitions) --, the
 // decision tree is medianToFirst's, and swapping a[result] with the median is two stores.  result, ia, ib, ic are distinct
 // (introselect calls it on ranges of more than three elements).
@@ -293,7 +293,7 @@ __device__ inline void nthElementWaveT(E* a, Index* Lpos, Index* Rpos, int nth, 
         }
         --depthLimit;
         if (lane == 0u) {
-            if (CHUNKS > 1) medianToFirstLoaded(a, first, first + 1, first + (last - first) / 2, last - 1);
+            if (!GLOBAL) medianToFirstLoaded(a, first, first + 1, first + (last - first) / 2, last - 1);
             else medianToFirst(a, first, first + 1, first + (last - first) / 2, last - 1);
         }
         waveSyncFor<GLOBAL>();
