@@ -137,7 +137,7 @@ __device__ __forceinline__ void waveSyncFor()
 // instead of a chain of dependent ones (a 200-entry selection of the scan spends most of its time between partitions) --, the
 // decision tree is medianToFirst's, and swapping a[result] with the median is two stores.  result, ia, ib, ic are distinct
 // (introselect calls it on ranges of more than three elements).
-template <class E> __device__ __forceinline__ void medianToFirstLoaded(E* a, int result, int ia, int ib, int ic)
+template <class E> __device__ __forceinline__ uint32_t medianToFirstLoaded(E* a, int result, int ia, int ib, int ic)
 {
     const E er = a[result], ea = a[ia], eb = a[ib], ec = a[ic];
     int m;
@@ -152,6 +152,7 @@ template <class E> __device__ __forceinline__ void medianToFirstLoaded(E* a, int
     const E em = m == ia ? ea : (m == ib ? eb : ec);
     a[result] = em;
     a[m] = er;
+    return uint32_t(em.key);            // (the partition's pivot: its caller hands it on instead of reading a[result] back)
 }
 
 __device__ __forceinline__ uint32_t lanesBelow(uint64_t mask)
@@ -165,13 +166,17 @@ __device__ __forceinline__ uint32_t lanesBelow(uint64_t mask)
 // The scan's 2k-entry selections keep CHUNKS = 1: their ranges fit one or two chunks, and the unrolled bodies cost the
 // scan kernels more than they saved (same box, alternating: +0.3 ms kernel, +0.7 ms scan at 1M cells).
 template <class Index, bool GLOBAL, class E = Entry, int CHUNKS = 1>
-__device__ inline int partitionWaveT(E* a, int lo, int hi, Index* Lpos, Index* Rpos, uint32_t lane)
+__device__ inline int partitionWaveT(E* a, int lo, int hi, Index* Lpos, Index* Rpos, uint32_t lane, bool havePivot = false, uint32_t pivotKey = 0u)
 {
-    const uint32_t pk = a[lo - 1].key;
+    // (a 2k-entry selection of the scan is a chain of LDS round trips under the neighbour wave's matrix instructions: every one
+    // that can be had from a register is taken from there -- the pivot from the lane that placed it, the next chunk's keys a turn
+    // ahead, the cut from the lanes that hold the crossing pair)
+    const uint32_t pk = havePivot ? pivotKey : uint32_t(a[lo - 1].key);
     int nL = 0, nR = 0;
     // (LDS form: the keys of four chunks are loaded before the first of them is used -- the scan writes only the position
     // arrays, and a wave that waited for every chunk's load spent its time in LDS latency, one wave per SIMD being the rule)
     constexpr int kChunks = GLOBAL ? 1 : CHUNKS;
+    uint32_t ahead = (!GLOBAL && CHUNKS == 1 && lo + int(lane) < hi) ? uint32_t(a[lo + int(lane)].key) : 0u;
     for (int base = lo; base < hi; base += 64 * kChunks) {
         uint32_t key[kChunks];
         bool valid[kChunks];
@@ -179,7 +184,12 @@ __device__ inline int partitionWaveT(E* a, int lo, int hi, Index* Lpos, Index* R
         for (int j = 0; j < kChunks; ++j) {
             const int x = base + 64 * j + int(lane);
             valid[j] = x < hi;
-            key[j] = valid[j] ? a[x].key : 0u;
+            if (!GLOBAL && CHUNKS == 1) {
+                key[j] = ahead;
+                ahead = x + 64 < hi ? uint32_t(a[x + 64].key) : 0u;
+            } else {
+                key[j] = valid[j] ? a[x].key : 0u;
+            }
         }
 #pragma unroll
         for (int j = 0; j < kChunks; ++j) {
@@ -258,8 +268,21 @@ __device__ inline int partitionWaveT(E* a, int lo, int hi, Index* Lpos, Index* R
                 a[y] = ex;
             }
             const uint64_t mc = __builtin_amdgcn_ballot_w64(c);
+            const uint64_t mv = __builtin_amdgcn_ballot_w64(valid);
             T += __builtin_popcountll(mc);
-            if (mc != __builtin_amdgcn_ballot_w64(valid)) break;
+            if (mc != mv) {
+                // The pairs stop crossing inside this chunk, at the lane f = T - base (c is a prefix of the valid lanes: L
+                // ascends, R descends).  Lane f holds L[T]; R[nR - T] is what lane f - 1 holds as its y -- or, for f == 0, the
+                // entry behind R[nR - 1 - T] = lane 0's y, which only the position array has.  Both from registers when f > 0.
+                const int f = T - base;
+                if (!GLOBAL && f > 0 && T < nR) {
+                    const int lT = __builtin_amdgcn_readlane(x, f);
+                    const int rT = __builtin_amdgcn_readlane(y, f - 1);
+                    waveSyncFor<GLOBAL>();
+                    return lT < rT ? lT : rT;           // (T > 0 and T < nL here: the rule below with both operands at hand)
+                }
+                break;
+            }
         }
     }
     waveSyncFor<GLOBAL>();
@@ -292,12 +315,14 @@ __device__ inline void nthElementWaveT(E* a, Index* Lpos, Index* Rpos, int nth, 
             return;
         }
         --depthLimit;
+        uint32_t pivotKey = 0u;
         if (lane == 0u) {
-            if (!GLOBAL) medianToFirstLoaded(a, first, first + 1, first + (last - first) / 2, last - 1);
+            if (!GLOBAL) pivotKey = medianToFirstLoaded(a, first, first + 1, first + (last - first) / 2, last - 1);
             else medianToFirst(a, first, first + 1, first + (last - first) / 2, last - 1);
         }
+        if (!GLOBAL) pivotKey = uint32_t(__builtin_amdgcn_readfirstlane(int(pivotKey)));
         waveSyncFor<GLOBAL>();
-        const int cut = partitionWaveT<Index, GLOBAL, E, CHUNKS>(a, first + 1, last, Lpos, Rpos, lane);
+        const int cut = partitionWaveT<Index, GLOBAL, E, CHUNKS>(a, first + 1, last, Lpos, Rpos, lane, !GLOBAL, pivotKey);
         if (cut <= nth) first = cut;
         else last = cut;
     }
