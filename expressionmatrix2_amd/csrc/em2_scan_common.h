@@ -177,7 +177,22 @@ __device__ __attribute__((noinline)) uint32_t cutListToBest(LdsEntryPtr ldsArea,
         const uint32_t ldsAddress = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uintptr_t(ldsArea)))));
         lds = (Entry*)(LdsEntryPtr)(uintptr_t)ldsAddress;
     }
-    for (uint32_t i = lane; i < n; i += 64u) lds[i] = loadEntryCoherent(g + i);
+    // (four loads in flight: one load and one LDS store per turn paid a memory round trip per 64 entries -- four of them for
+    // the scan's 200-entry lists, a good part of a selection's time)
+    for (uint32_t base = 0; base < n; base += 256u) {
+        Entry e[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t i = base + 64u * j + lane;
+            e[j] = Entry();
+            if (i < n) e[j] = loadEntryCoherent(g + i);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t i = base + 64u * j + lane;
+            if (i < n) lds[i] = e[j];
+        }
+    }
     waveLdsFence();
     // This wave's LDS area is [2k entries][2k uint16][2k uint16] (kLdsBytesPerEntrySlot each); n <= 2k.
     uint16_t* Lpos = reinterpret_cast<uint16_t*>(lds + 2u * k);
