@@ -1031,7 +1031,52 @@ __device__ __forceinline__ uint32_t partnerKey(uint32_t key)
 template <uint32_t STRIDE, int R>
 __device__ __forceinline__ void bitonicStage(uint32_t (&key)[R])
 {
+    if (STRIDE == 8u || STRIDE == 4u) {
+        // Eight (four) lanes apart, the lanes that keep the smaller key are whole banks of four: the DPP instructions' own bank
+        // masks say who takes the minimum and who the maximum -- two instructions and no lane mask in scalar registers, where
+        // min, max and a select under such a mask were three (and the masks of five strides were spilled to a register's lanes
+        // and read back at every turn of the replay).  (s_nop: a DPP operand written by the instruction in front needs two
+        // wait states, which the assembler does not add inside an asm statement.)
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            uint32_t out;
+            if (STRIDE == 8u) {
+                asm("s_nop 1\n\t"
+                    "v_min_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                    "v_max_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc"
+                    : "=&v"(out) : "v"(key[i]));
+            } else {
+                const uint32_t mirrored = uint32_t(__builtin_amdgcn_update_dpp(0, int(key[i]), 0x141, 0xf, 0xf, false));        // row_half_mirror: 7 - i
+                asm("s_nop 1\n\t"
+                    "v_min_u32_dpp %0, %1, %2 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0x5\n\t"
+                    "v_max_u32_dpp %0, %1, %2 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xa"
+                    : "=&v"(out) : "v"(mirrored), "v"(key[i]));
+            }
+            key[i] = out;
+        }
+        return;
+    }
     const bool lower = __builtin_amdgcn_inverse_ballot_w64(lowerLanesOf<STRIDE>());
+    if (STRIDE >= 16u) {
+        // (the swap hands every lane both keys of its pair -- the even rows' / lower half's in the first result: their minimum
+        // and maximum need no partner to be picked first)
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            uint32_t first, second;
+            if (STRIDE == 16u) {
+                const auto both = __builtin_amdgcn_permlane16_swap(key[i], key[i], false, false);
+                first = uint32_t(both[0]);
+                second = uint32_t(both[1]);
+            } else {
+                const auto both = __builtin_amdgcn_permlane32_swap(key[i], key[i], false, false);
+                first = uint32_t(both[0]);
+                second = uint32_t(both[1]);
+            }
+            const uint32_t smaller = first < second ? first : second, larger = first < second ? second : first;
+            key[i] = lower ? smaller : larger;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const uint32_t other = partnerKey<STRIDE>(key[i]);
