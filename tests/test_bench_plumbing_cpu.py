@@ -77,8 +77,9 @@ def test_oracle_rows_parallel_equals_one_call(oracle):
 
 
 def test_plain_command_with_gpus_2_starts_its_own_ranks():
-    """No launcher, no GPU here: the parent must start two ranks as children (each of which reports that it needs a GPU) and
-    hand back their non-zero exit code -- not stop with 'must be launched with torch.distributed.run'."""
+    """No launcher, no GPU here: the parent must start two ranks as children (which report that they need a GPU -- the
+    launcher ends the other rank as soon as the first has failed, so one report is all that is certain) and hand back their
+    non-zero exit code -- not stop with 'must be launched with torch.distributed.run'."""
     env = {key: value for key, value in os.environ.items() if key not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cells", "2048"],
                          capture_output=True, text=True, timeout=300, env=env)
@@ -86,7 +87,7 @@ def test_plain_command_with_gpus_2_starts_its_own_ranks():
     if bench_has_gpu():
         return
     assert run.returncode != 0
-    assert run.stderr.count("bench.py needs a GPU") >= 2
+    assert run.stderr.count("bench.py needs a GPU") >= 1 and "torch.distributed" in run.stderr
 
 
 def bench_has_gpu():
