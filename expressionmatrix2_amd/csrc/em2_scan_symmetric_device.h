@@ -1035,19 +1035,19 @@ __device__ __forceinline__ void bitonicStage(uint32_t (&key)[R])
         // Eight (four) lanes apart, the lanes that keep the smaller key are whole banks of four: the DPP instructions' own bank
         // masks say who takes the minimum and who the maximum -- two instructions and no lane mask in scalar registers, where
         // min, max and a select under such a mask were three (and the masks of five strides were spilled to a register's lanes
-        // and read back at every turn of the replay).  (s_nop: a DPP operand written by the instruction in front needs two
-        // wait states, which the assembler does not add inside an asm statement.)
+        // and read back at every turn of the replay).  (s_nop 4: a DPP operand written by the vector instruction in front needs two
+        // wait states, an EXEC written by one five; nothing adds them inside an asm statement.)
 #pragma unroll
         for (int i = 0; i < R; i++) {
             uint32_t out;
             if (STRIDE == 8u) {
-                asm("s_nop 1\n\t"
+                asm("s_nop 4\n\t"
                     "v_min_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
                     "v_max_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc"
                     : "=&v"(out) : "v"(key[i]));
             } else {
                 const uint32_t mirrored = uint32_t(__builtin_amdgcn_update_dpp(0, int(key[i]), 0x141, 0xf, 0xf, false));        // row_half_mirror: 7 - i
-                asm("s_nop 1\n\t"
+                asm("s_nop 4\n\t"
                     "v_min_u32_dpp %0, %1, %2 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0x5\n\t"
                     "v_max_u32_dpp %0, %1, %2 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xa"
                     : "=&v"(out) : "v"(mirrored), "v"(key[i]));
