@@ -342,8 +342,8 @@ __device__ __forceinline__ void scanMatrixBody(unsigned char* ldsRaw)
     // The wave's LDS block of the walk is its selection area (never needed at the same time) when that is large enough
     // and 16-byte aligned, and sits behind the tiles otherwise (matrixWalkAliasesSelection on the host side).
     const uint32_t selectionStride = 2u * kernelArgs()->k * kLdsBytesPerEntrySlot;
-    unsigned char* walkBlock = (selectionStride >= kMatrixWalkLdsBytes && selectionStride % 16u == 0u)
-                                   ? ldsRaw + wave * selectionStride
+    unsigned char* walkBlock = matrixWalkBlockInSelectionArea(selectionStride)
+                                   ? ldsRaw + matrixWalkBlockOffsetInSelectionAreas(selectionStride, wave)
                                    : ldsRaw + kernelArgs()->matrixLdsOffset + 4u * kMatrixTileWords * 16u + 64u + wave * kMatrixWalkLdsBytes;
     // shared[0..2] stop words of the walk, shared[3] the block's ticket, shared[4..8] the convoy (kConvoyStartWord ...)
     if (threadIdx.x < 12u) shared[threadIdx.x] = 0u;

@@ -1759,11 +1759,23 @@ static size_t matrixTermCount(uint32_t cellCount) { return size_t((cellCount + 6
 // dynamic LDS of the matrix kernels behind matrixLdsOffset: four tiles, the stop words + ticket, the waves' walk blocks
 constexpr size_t kMatrixLdsBytes = 4u * kMatrixTileWords * 16u + 64u + 4u * kMatrixWalkLdsBytes;
 
+// The wave's walk block (16-byte aligned: the steps read it 16 bytes at a time) inside its selection area of `stride` bytes: at
+// the area's begin, or 8 bytes in where an odd k puts that at 8 (mod 16) -- until round 6 an odd k kept the blocks apart, and
+// from k = 93 on that cost the kernel its second block per CU.
+__host__ __device__ static inline bool matrixWalkBlockInSelectionArea(uint32_t stride)
+{
+    return stride >= kMatrixWalkLdsBytes + (stride % 16u);
+}
+__host__ __device__ static inline uint32_t matrixWalkBlockOffsetInSelectionAreas(uint32_t stride, uint32_t wave)
+{
+    const uint32_t begin = wave * stride;
+    return begin + (16u - begin % 16u) % 16u;
+}
+
 // fsp4ScanMatrixKernel: the waves' walk blocks alias their selection areas when those are large enough (see there)
 static bool matrixWalkAliasesSelection(uint32_t k)
 {
-    const uint32_t selectionStride = 2u * k * kLdsBytesPerEntrySlot;
-    return selectionStride >= kMatrixWalkLdsBytes && selectionStride % 16u == 0u;
+    return matrixWalkBlockInSelectionArea(2u * k * kLdsBytesPerEntrySlot);
 }
 
 static size_t scanMatrixLdsBytes(uint32_t k)

@@ -501,6 +501,18 @@ def test_rows_form_on_the_matrix_cores(oracle, scan_knobs, n, L, k, thr, kind, k
         assert np.array_equal(gsim, sim.view(np.uint32)), (begin, end)
 
 
+@pytest.mark.parametrize("k", [79, 80, 81, 85, 99, 101, 171])
+def test_matrix_form_with_k_around_the_walk_blocks_place(oracle, scan_knobs, k):
+    """The walk's per-wave LDS block lives inside the wave's selection area (2k entries) when that is large enough -- from k = 80
+    on, 8 bytes in where an odd k puts the area at 8 (mod 16) -- and behind the tiles otherwise: every side of those borders."""
+    sig = synth.clustered_signatures(3000, 1024, cluster_count=4, flip=0.2, seed=k)
+    cell, sim, used = oracle.find_similar_pairs4(sig, 1024, k, 0.0)
+    scan_knobs(EM2_SCAN_MODE="triangle", EM2_MIN_SEGMENT_COLUMNS=512, EM2_FULL_ROW_CELLS=256)
+    pairs, gused = capi.find_similar_pairs4(sig, 1024, k, 0.0)
+    assert capi.dev_find_similar_pairs4_last_launch()["form"] == 3
+    assert_same(pairs, gused, cell, sim, used)
+
+
 @pytest.mark.parametrize("n,L", [(3000, 1024), (2977, 1024), (2500, 2048), (3040, 600)])
 def test_rows_form_shard_at_32_mod_64_that_ends_with_the_cells(oracle, scan_knobs, n, L):
     """a shard that begins at 32 (mod 64) and ends with the cells has a last 64-row block that reaches past the
